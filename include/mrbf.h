@@ -1,0 +1,184 @@
+/* mrbf.h -- C ABI of the MI355X-native RBF surrogate engine (libmrbf.so).
+ *
+ * Drop-in boundary for Morbit.jl's RbfConfig hot path.  Morbit reaches this
+ * arithmetic through Julia multiple dispatch into RadialBasisFunctionModels.jl;
+ * each entry point below names the reference interface it replaces.  A Julia
+ * maintainer binds these with `ccall` (see INTEGRATION.md and
+ * morbit.jl_amd/julia/HipRbf.jl); tests and bench bind them with ctypes.
+ *
+ * Conventions
+ *   - every call returns int32: 0 ok; <0 = -(1-based index of the invalid
+ *     argument); >0 numerical / runtime error (MRBF_E*).  Nothing throws or
+ *     aborts across the ABI.  mrbf_last_error(ctx) gives a static string.
+ *   - all numbers are fp64.  Buffers may be HOST or DEVICE pointers (detected
+ *     with hipPointerGetAttributes); host buffers are copied over PCIe inside
+ *     the call, device buffers are used in place on the context's stream.
+ *   - the caller owns in/out buffers for the duration of the call (Julia:
+ *     GC.@preserve); the library owns ctx and model handles.
+ *   - one ctx per host thread; a ctx is not thread-safe; ctxs are independent.
+ *   - layouts (chosen so that Julia's native arrays are passed zero-copy):
+ *       centres  n x d row-major  == Julia d x n column-major
+ *                                 == reinterpret(reshape, Float64, Vector{SVector{d}})
+ *       values   n x k row-major  == Julia k x n column-major (Vector{MVector{k}})
+ *       weights  n x k row-major, poly q x k row-major, basis [1, x_1..x_d]
+ *       X        m x d row-major;  vals m x k row-major
+ *       jac      per point a k x d COLUMN-major block (unsafe_wrap as Matrix k x d)
+ *       Phi n x n, Pi n x q column-major.
+ */
+#ifndef MRBF_H
+#define MRBF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mrbf_ctx mrbf_ctx;
+typedef struct mrbf_model mrbf_model;
+
+/* kernel ids in the order of Morbit.RbfKernels (src/models/RbfModel.jl:48-54).
+ * (a, b) are what _get_kernel_params (RbfModel.jl:665-690) hands to the package:
+ *   cubic: a = beta (odd, default 3)              inv_multiquadric / multiquadric: a = alpha, b = beta (default 1, 1/2)
+ *   thin_plate_spline: a = k (default 2)          gaussian: a = alpha (default 1) */
+enum {
+    MRBF_CUBIC = 0,
+    MRBF_INV_MULTIQUADRIC = 1,
+    MRBF_MULTIQUADRIC = 2,
+    MRBF_THIN_PLATE_SPLINE = 3,
+    MRBF_GAUSSIAN = 4
+};
+
+enum {
+    MRBF_OK = 0,
+    MRBF_ENOTPD = 1,    /* Cholesky met a non-positive pivot and the LU retry was disabled */
+    MRBF_ESINGULAR = 2, /* LU met an exactly zero pivot (info.factor_info = its 1-based index) */
+    MRBF_EHIP = 3,      /* a HIP runtime call failed */
+    MRBF_EBLAS = 4,     /* a rocBLAS / rocSOLVER call failed */
+    MRBF_ENOMEM = 5,
+    MRBF_ENODEVICE = 6, /* no usable GPU: the library never computes on the CPU */
+    MRBF_ENCCL = 7
+};
+
+/* solve paths reported in mrbf_fit_info.path */
+enum {
+    MRBF_PATH_CHOL = 1,      /* Phi SPD, no tail: potrf(Phi) */
+    MRBF_PATH_PROJ_CHOL = 2, /* tail + conditionally p.d. kernel: potrf(P Phi P + mu Q1 Q1') on null(Pi') */
+    MRBF_PATH_LU = 3         /* indefinite saddle system [Phi Pi; Pi' 0]: getrf */
+};
+
+/* mrbf_set_option keys */
+enum {
+    MRBF_OPT_GRAM_MODE = 1,    /* 0 = MFMA GEMM-form (default), 1 = VALU difference-form (reference arithmetic) */
+    MRBF_OPT_RESIDUAL = 2,     /* 1 = compute rel_residual / max|Pi'w| after a fit (default 1) */
+    MRBF_OPT_FORCE_PATH = 3,   /* 0 = automatic, else one of MRBF_PATH_* */
+    MRBF_OPT_CHOL_IMPL = 4,    /* 0 = library default, 1 = rocSOLVER potrf, 2 = built-in blocked MFMA Cholesky */
+    MRBF_OPT_EVAL_IMPL = 5,    /* 0 = default, 1 = GEMM pipeline, 2 = fused MFMA kernel */
+    MRBF_OPT_TIMING = 6        /* 1 = record per-phase hipEvents (default 1) */
+};
+
+typedef struct {
+    int32_t path;         /* MRBF_PATH_* actually taken */
+    int32_t factor_info;  /* potrf / getrf info (0 = clean) */
+    int32_t n, q;         /* system sizes */
+    double rel_residual;  /* ||Phi w + Pi lam - Y||_F / ||Y||_F recomputed through the eval kernels; NaN if disabled */
+    double max_pitw;      /* max |Pi' w|; NaN if disabled */
+    double mu;            /* shift used by the projected Cholesky (0 otherwise) */
+    float ms_gram, ms_project, ms_factor, ms_solve, ms_check, ms_total; /* hipEvent times on the ctx stream */
+} mrbf_fit_info;
+
+typedef struct {
+    float ms_total;
+    float ms_dist, ms_kernel, ms_contract; /* phases of the evaluation (0 when fused) */
+} mrbf_eval_info;
+
+/* per-GPU context: stream, rocBLAS handle, grow-only workspace arena.
+ * device_id < 0 selects the current device. */
+int32_t mrbf_init(int32_t device_id, mrbf_ctx **ctx);
+int32_t mrbf_shutdown(mrbf_ctx *ctx);
+const char *mrbf_last_error(const mrbf_ctx *ctx); /* ctx may be NULL: last init error */
+const char *mrbf_version(void);
+int32_t mrbf_set_option(mrbf_ctx *ctx, int32_t key, double value);
+int32_t mrbf_get_option(const mrbf_ctx *ctx, int32_t key, double *value);
+/* run on the caller's hipStream_t (e.g. torch's current stream); NULL restores the ctx's own stream */
+int32_t mrbf_set_stream(mrbf_ctx *ctx, void *hip_stream);
+int32_t mrbf_sync(mrbf_ctx *ctx);
+
+/* Phi (n x n) and Pi (n x q) -- replaces RBF.get_matrices(phi, centers; poly_deg)
+ * (src/models/RbfModel.jl:374-375).  Pi_out may be NULL.  *ms (may be NULL)
+ * receives the hipEvent time of the assembly kernels alone. */
+int32_t mrbf_gram(mrbf_ctx *ctx, int64_t n, int32_t d, const double *centres, int32_t kernel_id, double a, double b,
+                  int32_t poly_deg, double *Phi_out, double *Pi_out, float *ms);
+
+/* Gram assembly + factorisation + solve for all k outputs -- replaces
+ * RBF.RBFInterpolationModel(sites, values, kernel, params, poly_deg) in update_model
+ * (src/models/RbfModel.jl:759-763).  Keeps centres / weights resident on the device in
+ * *model.  weights_out (n x k), poly_out (q x k) and info may be NULL. */
+int32_t mrbf_fit(mrbf_ctx *ctx, int64_t n, int32_t d, int32_t k, const double *centres, const double *values,
+                 int32_t kernel_id, double a, double b, int32_t poly_deg, mrbf_model **model, double *weights_out,
+                 double *poly_out, mrbf_fit_info *info);
+
+/* build a model from known coefficients (no solve): lets a caller that kept the
+ * round-4 factors (RbfModel.jl:657-660 note) or a checkpoint skip the fit */
+int32_t mrbf_model_from_coeffs(mrbf_ctx *ctx, int64_t n, int32_t d, int32_t k, const double *centres,
+                               const double *weights, const double *poly, int32_t kernel_id, double a, double b,
+                               int32_t poly_deg, mrbf_model **model);
+
+/* values and Jacobians at m points, all k outputs in one sweep -- replaces
+ * model(x), model(x, l), RBF.grad(model, x, l), RBF.jac(model, x, rows)
+ * (src/models/RbfModel.jl:783-800) and the per-output closures of
+ * _get_optim_handle (src/AbstractSurrogateInterface.jl:98-106).
+ * vals_out (m x k) or jac_out (m x [k x d col-major]) may be NULL. */
+int32_t mrbf_eval(mrbf_ctx *ctx, const mrbf_model *model, int64_t m, const double *X, double *vals_out,
+                  double *jac_out, mrbf_eval_info *info);
+
+/* all step sizes of the Armijo backtracking loop in one batch -- replaces the
+ * sequential loop of _backtrack (src/descent.jl:150-185) with condition
+ * _armijo_condition (src/descent.jl:137-143).  Evaluates x + step0*shrink^i*dir,
+ * i = 0..max_loops, and returns the first i that satisfies the condition (or the
+ * index at which the reference loop would have stopped).  x_plus (d), mx_plus (k),
+ * step (d) and n_loops are outputs (host or device). */
+int32_t mrbf_backtrack(mrbf_ctx *ctx, const mrbf_model *model, const double *x, const double *dir, double step0,
+                       double omega, int32_t strict, double const_rhs, double shrink, double min_stepsize,
+                       int32_t max_loops, double *x_plus, double *mx_plus, double *step, int32_t *n_loops);
+
+int32_t mrbf_model_dims(const mrbf_model *model, int64_t *n, int32_t *d, int32_t *k, int32_t *q);
+int32_t mrbf_free_model(mrbf_ctx *ctx, mrbf_model *model);
+
+/* many-problem mode (the reference's Threads.@threads loop over independent
+ * problems, examples/large_scale_benchmarks.jl:253): shards problems round-robin
+ * over n_dev GPUs inside this process, one host thread + ctx + stream per GPU,
+ * fit + eval per problem, fixed-size result record per problem. */
+typedef struct {
+    int64_t n, m;
+    int32_t d, k, kernel_id, poly_deg;
+    double a, b;
+    const double *centres; /* host, n x d */
+    const double *values;  /* host, n x k */
+    const double *X;       /* host, m x d (may be NULL when m == 0) */
+    double *weights_out;   /* host n x k or NULL */
+    double *poly_out;      /* host q x k or NULL */
+    double *vals_out;      /* host m x k or NULL */
+    double *jac_out;       /* host m x k x d or NULL */
+} mrbf_problem;
+
+typedef struct {
+    int32_t status;   /* return code of the failing call, 0 if ok */
+    int32_t device;   /* GPU that ran it */
+    mrbf_fit_info fit;
+    float ms_eval;
+    double checksum_w;    /* sum of weights (order-fixed reduction on the device) */
+    double checksum_vals; /* sum of values */
+} mrbf_result;
+
+int32_t mrbf_batch_run(int32_t n_dev, const int32_t *device_ids, int64_t n_problems, const mrbf_problem *problems,
+                       mrbf_result *results);
+
+/* debug / test hooks (exported so the parity tests can pin kernel-level behaviour) */
+int32_t mrbf_debug_mfma_layout(mrbf_ctx *ctx, double *out16x16_a_times_b, const double *A16x4, const double *B4x16);
+int32_t mrbf_debug_potrf(mrbf_ctx *ctx, int64_t n, double *A_colmajor_inout, int32_t impl, int32_t *info, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MRBF_H */

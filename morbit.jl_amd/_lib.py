@@ -1,0 +1,171 @@
+"""ctypes binding of libmrbf.so (include/mrbf.h).  No CPU fallback: a missing library or GPU is an error."""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmrbf.so")
+
+c_dp = ctypes.POINTER(ctypes.c_double)
+c_fp = ctypes.POINTER(ctypes.c_float)
+c_ip = ctypes.POINTER(ctypes.c_int32)
+c_vp = ctypes.c_void_p
+
+# error codes (mrbf.h)
+MRBF_OK, MRBF_ENOTPD, MRBF_ESINGULAR, MRBF_EHIP, MRBF_EBLAS, MRBF_ENOMEM, MRBF_ENODEVICE, MRBF_ENCCL = range(8)
+PATH_CHOL, PATH_PROJ_CHOL, PATH_LU = 1, 2, 3
+OPT_GRAM_MODE, OPT_RESIDUAL, OPT_FORCE_PATH, OPT_CHOL_IMPL, OPT_EVAL_IMPL, OPT_TIMING = 1, 2, 3, 4, 5, 6
+
+
+class FitInfo(ctypes.Structure):
+    _fields_ = [("path", ctypes.c_int32), ("factor_info", ctypes.c_int32), ("n", ctypes.c_int32), ("q", ctypes.c_int32),
+                ("rel_residual", ctypes.c_double), ("max_pitw", ctypes.c_double), ("mu", ctypes.c_double),
+                ("ms_gram", ctypes.c_float), ("ms_project", ctypes.c_float), ("ms_factor", ctypes.c_float),
+                ("ms_solve", ctypes.c_float), ("ms_check", ctypes.c_float), ("ms_total", ctypes.c_float)]
+
+    def asdict(self):
+        return {f: getattr(self, f) for f, _ in self._fields_}
+
+
+class EvalInfo(ctypes.Structure):
+    _fields_ = [("ms_total", ctypes.c_float), ("ms_dist", ctypes.c_float), ("ms_kernel", ctypes.c_float),
+                ("ms_contract", ctypes.c_float)]
+
+    def asdict(self):
+        return {f: getattr(self, f) for f, _ in self._fields_}
+
+
+class Problem(ctypes.Structure):
+    _fields_ = [("n", ctypes.c_int64), ("m", ctypes.c_int64), ("d", ctypes.c_int32), ("k", ctypes.c_int32),
+                ("kernel_id", ctypes.c_int32), ("poly_deg", ctypes.c_int32), ("a", ctypes.c_double), ("b", ctypes.c_double),
+                ("centres", c_dp), ("values", c_dp), ("X", c_dp), ("weights_out", c_dp), ("poly_out", c_dp),
+                ("vals_out", c_dp), ("jac_out", c_dp)]
+
+
+class Result(ctypes.Structure):
+    _fields_ = [("status", ctypes.c_int32), ("device", ctypes.c_int32), ("fit", FitInfo), ("ms_eval", ctypes.c_float),
+                ("checksum_w", ctypes.c_double), ("checksum_vals", ctypes.c_double)]
+
+
+# every symbol include/mrbf.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "mrbf_init": (ctypes.c_int32, [ctypes.c_int32, ctypes.POINTER(c_vp)]),
+    "mrbf_shutdown": (ctypes.c_int32, [c_vp]),
+    "mrbf_last_error": (ctypes.c_char_p, [c_vp]),
+    "mrbf_version": (ctypes.c_char_p, []),
+    "mrbf_set_option": (ctypes.c_int32, [c_vp, ctypes.c_int32, ctypes.c_double]),
+    "mrbf_get_option": (ctypes.c_int32, [c_vp, ctypes.c_int32, c_dp]),
+    "mrbf_set_stream": (ctypes.c_int32, [c_vp, c_vp]),
+    "mrbf_sync": (ctypes.c_int32, [c_vp]),
+    "mrbf_gram": (ctypes.c_int32, [c_vp, ctypes.c_int64, ctypes.c_int32, c_vp, ctypes.c_int32, ctypes.c_double,
+                                   ctypes.c_double, ctypes.c_int32, c_vp, c_vp, c_fp]),
+    "mrbf_fit": (ctypes.c_int32, [c_vp, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, c_vp, c_vp, ctypes.c_int32,
+                                  ctypes.c_double, ctypes.c_double, ctypes.c_int32, ctypes.POINTER(c_vp), c_vp, c_vp,
+                                  ctypes.POINTER(FitInfo)]),
+    "mrbf_model_from_coeffs": (ctypes.c_int32, [c_vp, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, c_vp, c_vp, c_vp,
+                                                ctypes.c_int32, ctypes.c_double, ctypes.c_double, ctypes.c_int32,
+                                                ctypes.POINTER(c_vp)]),
+    "mrbf_eval": (ctypes.c_int32, [c_vp, c_vp, ctypes.c_int64, c_vp, c_vp, c_vp, ctypes.POINTER(EvalInfo)]),
+    "mrbf_backtrack": (ctypes.c_int32, [c_vp, c_vp, c_vp, c_vp, ctypes.c_double, ctypes.c_double, ctypes.c_int32,
+                                        ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int32, c_vp, c_vp,
+                                        c_vp, c_ip]),
+    "mrbf_model_dims": (ctypes.c_int32, [c_vp, ctypes.POINTER(ctypes.c_int64), c_ip, c_ip, c_ip]),
+    "mrbf_free_model": (ctypes.c_int32, [c_vp, c_vp]),
+    "mrbf_batch_run": (ctypes.c_int32, [ctypes.c_int32, c_ip, ctypes.c_int64, ctypes.POINTER(Problem),
+                                        ctypes.POINTER(Result)]),
+    "mrbf_debug_mfma_layout": (ctypes.c_int32, [c_vp, c_vp, c_vp, c_vp]),
+    "mrbf_debug_potrf": (ctypes.c_int32, [c_vp, ctypes.c_int64, c_vp, ctypes.c_int32, c_ip, c_fp]),
+}
+
+_LIB = None
+
+
+class MrbfError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libmrbf error %d: %s" % (code, msg))
+        self.code = code
+
+
+def load():
+    """Load libmrbf.so and bind every exported symbol; raises if the extension has not been built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libmrbf.so is not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "or `make -C morbit.jl_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = lib
+    return _LIB
+
+
+def as_ptr(a):
+    """void* of a NumPy array (host) or of anything exposing data_ptr() (a torch tensor, host or device)."""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return ctypes.c_void_p(a.ctypes.data)
+    if hasattr(a, "data_ptr"):
+        return ctypes.c_void_p(a.data_ptr())
+    raise TypeError("expected numpy array or tensor, got %r" % type(a))
+
+
+def host_f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+class Context:
+    """One per host thread and GPU (mrbf_init / mrbf_shutdown)."""
+
+    def __init__(self, device_id=-1):
+        self.lib = load()
+        h = c_vp()
+        rc = self.lib.mrbf_init(device_id, ctypes.byref(h))
+        if rc != 0:
+            raise MrbfError(rc, (self.lib.mrbf_last_error(None) or b"").decode())
+        self.h = h
+
+    def check(self, rc):
+        if rc != 0:
+            raise MrbfError(rc, (self.lib.mrbf_last_error(self.h) or b"").decode())
+
+    def set_option(self, key, value):
+        self.check(self.lib.mrbf_set_option(self.h, key, float(value)))
+
+    def get_option(self, key):
+        v = ctypes.c_double()
+        self.check(self.lib.mrbf_get_option(self.h, key, ctypes.byref(v)))
+        return v.value
+
+    def sync(self):
+        self.check(self.lib.mrbf_sync(self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mrbf_shutdown(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_DEFAULT_CTX = {}
+
+
+def default_context(device_id=-1):
+    import threading
+
+    key = (threading.get_ident(), device_id)
+    if key not in _DEFAULT_CTX:
+        _DEFAULT_CTX[key] = Context(device_id)
+    return _DEFAULT_CTX[key]

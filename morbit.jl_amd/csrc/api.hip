@@ -1,0 +1,309 @@
+// extern "C" entry points of include/mrbf.h (argument checking, staging of host buffers, dispatch).
+#include <algorithm>
+#include <thread>
+
+#include "common.hpp"
+
+using namespace mrbf;
+
+static int check_kernel(mrbf_ctx *ctx, int kid, double a, double b, int deg, int argpos) {
+    if (kid < 0 || kid > 4) return fail(ctx, -argpos, "kernel_id %d not in 0..4 (Morbit.RbfKernels)", kid);
+    // same sanity checks as RbfConfig's @assert block (RbfModel.jl:102-111)
+    if (kid == MRBF_CUBIC && !(a >= 1.0 && std::fmod(a, 2.0) == 1.0))
+        return fail(ctx, -(argpos + 1), "cubic exponent must be an odd integer >= 1 (got %g)", a);
+    if (kid == MRBF_THIN_PLATE_SPLINE && !(a >= 1.0 && std::fmod(a, 1.0) == 0.0 && a <= 16.0))
+        return fail(ctx, -(argpos + 1), "thin plate spline k must be an integer >= 1 (got %g)", a);
+    if ((kid == MRBF_GAUSSIAN || kid == MRBF_MULTIQUADRIC || kid == MRBF_INV_MULTIQUADRIC) && !(a > 0.0))
+        return fail(ctx, -(argpos + 1), "shape parameter must be strictly positive (got %g)", a);
+    if (kid == MRBF_MULTIQUADRIC && !(b > 0.0 && std::fmod(b, 1.0) != 0.0))
+        return fail(ctx, -(argpos + 2), "multiquadric exponent must be positive and non-integer (got %g)", b);
+    if (kid == MRBF_INV_MULTIQUADRIC && !(b > 0.0))
+        return fail(ctx, -(argpos + 2), "inverse multiquadric exponent must be positive (got %g)", b);
+    if (deg < -1 || deg > 1) return fail(ctx, -(argpos + 3), "polynomial_degree must be -1, 0 or 1 (RbfModel.jl:21), got %d", deg);
+    return 0;
+}
+
+extern "C" {
+
+int32_t mrbf_gram(mrbf_ctx *ctx, int64_t n, int32_t d, const double *centres, int32_t kernel_id, double a, double b,
+                  int32_t poly_deg, double *Phi_out, double *Pi_out, float *ms) {
+    if (!ctx) return -1;
+    if (n < 0 || n > 46000) return fail(ctx, -2, "n = %lld out of range", (long long)n);
+    if (d < 1 || d > 4096) return fail(ctx, -3, "d = %d out of range", d);
+    if (!centres && n > 0) return fail(ctx, -4, "centres is NULL");
+    MRBF_TRY(check_kernel(ctx, kernel_id, a, b, poly_deg, 5));
+    if (!Phi_out) return fail(ctx, -9, "Phi_out is NULL");
+    if (n == 0) return MRBF_OK;
+    (void)hipSetDevice(ctx->device);
+    const int q = poly_dim(d, poly_deg);
+    const int64_t npad = round_up(n, 128);
+    const int dpad = (int)round_up(d, 16);
+    const KP kp = make_kp(kernel_id, a, b);
+    const double *C;
+    double *Xc, *sq, *mean, *Phi, *Pi = nullptr;
+    MRBF_TRY(stage_in(ctx, S_STAGE_A, centres, (size_t)n * d, &C));
+    MRBF_TRY(get_buf(ctx, S_XC, (size_t)npad * dpad, &Xc));
+    MRBF_TRY(get_buf(ctx, S_SQ, (size_t)npad, &sq));
+    MRBF_TRY(get_buf(ctx, S_MEAN, (size_t)dpad, &mean));
+    MRBF_TRY(stage_out(ctx, S_PHI, Phi_out, (size_t)n * n, &Phi));
+    MRBF_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    if (ctx->gram_mode != 1) MRBF_TRY(launch_center_pad(ctx, C, n, d, nullptr, mean, Xc, npad, dpad, sq));
+    MRBF_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    MRBF_TRY(launch_gram(ctx, ctx->gram_mode, C, Xc, sq, n, npad, d, dpad, kp, Phi, n));
+    MRBF_HIP(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+    if (Pi_out && q > 0) {
+        MRBF_TRY(stage_out(ctx, S_PI, Pi_out, (size_t)n * q, &Pi));
+        MRBF_TRY(launch_poly_matrix(ctx, C, n, d, q, Pi, n));
+    }
+    MRBF_TRY(finish_out(ctx, Phi_out, Phi, (size_t)n * n));
+    if (Pi) MRBF_TRY(finish_out(ctx, Pi_out, Pi, (size_t)n * q));
+    MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ms) MRBF_HIP(ctx, hipEventElapsedTime(ms, ctx->ev[1], ctx->ev[2]));
+    return MRBF_OK;
+}
+
+int32_t mrbf_fit(mrbf_ctx *ctx, int64_t n, int32_t d, int32_t k, const double *centres, const double *values,
+                 int32_t kernel_id, double a, double b, int32_t poly_deg, mrbf_model **model, double *weights_out,
+                 double *poly_out, mrbf_fit_info *info) {
+    if (!ctx) return -1;
+    if (n < 1 || n > 46000) return fail(ctx, -2, "n = %lld out of range", (long long)n);
+    if (d < 1 || d > 4096) return fail(ctx, -3, "d = %d out of range", d);
+    if (k < 1 || k > 1024) return fail(ctx, -4, "k = %d out of range", k);
+    if (!centres) return fail(ctx, -5, "centres is NULL");
+    if (!values) return fail(ctx, -6, "values is NULL");
+    MRBF_TRY(check_kernel(ctx, kernel_id, a, b, poly_deg, 7));
+    if (!model) return fail(ctx, -11, "model is NULL");
+    *model = nullptr;
+    (void)hipSetDevice(ctx->device);
+    const double *C, *Y;
+    MRBF_TRY(stage_in(ctx, S_STAGE_A, centres, (size_t)n * d, &C));
+    MRBF_TRY(stage_in(ctx, S_STAGE_B, values, (size_t)n * k, &Y));
+    mrbf_model *M = nullptr;
+    MRBF_TRY(build_model_shell(ctx, n, d, k, C, kernel_id, a, b, poly_deg, &M));
+    int rc = fit_model(ctx, M, Y, info);
+    if (rc != 0) {
+        (void)hipStreamSynchronize(ctx->stream);
+        destroy_model(M);
+        return rc;
+    }
+    if (weights_out) {
+        if (is_device_ptr(weights_out))
+            MRBF_HIP(ctx, hipMemcpyAsync(weights_out, M->W, (size_t)n * k * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        else
+            MRBF_HIP(ctx, hipMemcpyAsync(weights_out, M->W, (size_t)n * k * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (poly_out && M->q > 0) {
+        if (is_device_ptr(poly_out))
+            MRBF_HIP(ctx, hipMemcpyAsync(poly_out, M->lam, (size_t)M->q * k * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        else
+            MRBF_HIP(ctx, hipMemcpyAsync(poly_out, M->lam, (size_t)M->q * k * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *model = M;
+    return MRBF_OK;
+}
+
+int32_t mrbf_model_from_coeffs(mrbf_ctx *ctx, int64_t n, int32_t d, int32_t k, const double *centres,
+                               const double *weights, const double *poly, int32_t kernel_id, double a, double b,
+                               int32_t poly_deg, mrbf_model **model) {
+    if (!ctx) return -1;
+    if (n < 1 || n > 46000) return fail(ctx, -2, "n out of range");
+    if (d < 1 || d > 4096) return fail(ctx, -3, "d out of range");
+    if (k < 1 || k > 1024) return fail(ctx, -4, "k out of range");
+    if (!centres) return fail(ctx, -5, "centres is NULL");
+    if (!weights) return fail(ctx, -6, "weights is NULL");
+    MRBF_TRY(check_kernel(ctx, kernel_id, a, b, poly_deg, 8));
+    const int q = poly_dim(d, poly_deg);
+    if (q > 0 && !poly) return fail(ctx, -7, "poly is NULL but polynomial_degree >= 0");
+    if (!model) return fail(ctx, -12, "model is NULL");
+    (void)hipSetDevice(ctx->device);
+    const double *C, *W, *L = nullptr;
+    MRBF_TRY(stage_in(ctx, S_STAGE_A, centres, (size_t)n * d, &C));
+    MRBF_TRY(stage_in(ctx, S_STAGE_B, weights, (size_t)n * k, &W));
+    if (q > 0) MRBF_TRY(stage_in(ctx, S_STAGE_C, poly, (size_t)q * k, &L));
+    mrbf_model *M = nullptr;
+    MRBF_TRY(build_model_shell(ctx, n, d, k, C, kernel_id, a, b, poly_deg, &M));
+    MRBF_HIP(ctx, hipMemcpyAsync(M->W, W, (size_t)n * k * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    MRBF_HIP(ctx, hipMemsetAsync(M->Wc, 0, (size_t)M->npad * k * sizeof(double), ctx->stream));
+    for (int l = 0; l < k; ++l)  // strided copy W[:, l] -> Wc[:, l]
+        MRBF_HIP(ctx, hipMemcpy2DAsync(M->Wc + (size_t)l * M->npad, sizeof(double), W + l, (size_t)k * sizeof(double),
+                                       sizeof(double), (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
+    if (q > 0) MRBF_HIP(ctx, hipMemcpyAsync(M->lam, L, (size_t)q * k * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *model = M;
+    return MRBF_OK;
+}
+
+int32_t mrbf_eval(mrbf_ctx *ctx, const mrbf_model *model, int64_t m, const double *X, double *vals_out, double *jac_out,
+                  mrbf_eval_info *info) {
+    if (!ctx) return -1;
+    if (!model) return fail(ctx, -2, "model is NULL");
+    if (m < 0) return fail(ctx, -3, "m < 0");
+    if (info) std::memset(info, 0, sizeof(*info));
+    if (m == 0) return MRBF_OK;
+    if (!X) return fail(ctx, -4, "X is NULL");
+    (void)hipSetDevice(ctx->device);
+    const int d = model->d, k = model->k;
+    const double *Xd;
+    double *V = nullptr, *J = nullptr;
+    MRBF_TRY(stage_in(ctx, S_STAGE_C, X, (size_t)m * d, &Xd));
+    if (vals_out) MRBF_TRY(stage_out(ctx, S_OUT_A, vals_out, (size_t)m * k, &V));
+    if (jac_out) MRBF_TRY(stage_out(ctx, S_OUT_B, jac_out, (size_t)m * k * d, &J));
+    MRBF_TRY(eval_model(ctx, model, m, Xd, V, J, info));
+    if (V) MRBF_TRY(finish_out(ctx, vals_out, V, (size_t)m * k));
+    if (J) MRBF_TRY(finish_out(ctx, jac_out, J, (size_t)m * k * d));
+    MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MRBF_OK;
+}
+
+int32_t mrbf_backtrack(mrbf_ctx *ctx, const mrbf_model *model, const double *x, const double *dir, double step0,
+                       double omega, int32_t strict, double const_rhs, double shrink, double min_stepsize,
+                       int32_t max_loops, double *x_plus, double *mx_plus, double *step, int32_t *n_loops) {
+    if (!ctx) return -1;
+    if (!model) return fail(ctx, -2, "model is NULL");
+    if (!x) return fail(ctx, -3, "x is NULL");
+    if (!dir) return fail(ctx, -4, "dir is NULL");
+    if (!(shrink > 0.0 && shrink < 1.0)) return fail(ctx, -9, "shrink must be in (0,1)");
+    if (max_loops < 0 || max_loops > 100000) return fail(ctx, -11, "max_loops out of range");
+    (void)hipSetDevice(ctx->device);
+    const int d = model->d, k = model->k;
+    std::vector<double> hx(d), hd(d);
+    auto fetch = [&](const double *src, double *dst) -> int {
+        if (is_device_ptr(src)) {
+            MRBF_HIP(ctx, hipMemcpy(dst, src, d * sizeof(double), hipMemcpyDeviceToHost));
+        } else {
+            std::memcpy(dst, src, d * sizeof(double));
+        }
+        return 0;
+    };
+    MRBF_TRY(fetch(x, hx.data()));
+    MRBF_TRY(fetch(dir, hd.data()));
+    // step sizes exactly as the sequential loop produces them: step_size *= alpha (descent.jl:176)
+    const int L = max_loops + 1;
+    std::vector<double> steps(L);
+    steps[0] = step0;
+    for (int i = 1; i < L; ++i) steps[i] = steps[i - 1] * shrink;
+    // batch: row 0 = x, row 1+i = x .+ steps[i] .* dir   (descent.jl:162, :177)
+    std::vector<double> Xb((size_t)(L + 1) * d), Vb((size_t)(L + 1) * k);
+    for (int t = 0; t < d; ++t) Xb[t] = hx[t];
+    for (int i = 0; i < L; ++i)
+        for (int t = 0; t < d; ++t) Xb[(size_t)(i + 1) * d + t] = hx[t] + steps[i] * hd[t];
+    int rc = mrbf_eval(ctx, model, L + 1, Xb.data(), Vb.data(), nullptr, nullptr);
+    if (rc != 0) return rc;
+    // scan with the reference's loop logic (descent.jl:166-180)
+    const double *mx = Vb.data();
+    int i = 0;
+    while (i < max_loops) {
+        const double *mp = Vb.data() + (size_t)(i + 1) * k;
+        bool ok;
+        if (strict) {
+            ok = true;
+            for (int l = 0; l < k; ++l) ok = ok && ((mx[l] - mp[l]) >= steps[i] * const_rhs * omega);
+        } else {
+            ok = (*std::max_element(mx, mx + k) - *std::max_element(mp, mp + k)) >= steps[i] * const_rhs * omega;
+        }
+        if (ok) break;
+        if (steps[i] <= min_stepsize) break;
+        ++i;
+    }
+    std::vector<double> hs(d);
+    for (int t = 0; t < d; ++t) hs[t] = steps[i] * hd[t];
+    auto put = [&](double *dst, const double *src, size_t cnt) -> int {
+        if (!dst) return 0;
+        if (is_device_ptr(dst)) {
+            MRBF_HIP(ctx, hipMemcpy(dst, src, cnt * sizeof(double), hipMemcpyHostToDevice));
+        } else {
+            std::memcpy(dst, src, cnt * sizeof(double));
+        }
+        return 0;
+    };
+    MRBF_TRY(put(x_plus, Xb.data() + (size_t)(i + 1) * d, d));
+    MRBF_TRY(put(mx_plus, Vb.data() + (size_t)(i + 1) * k, k));
+    MRBF_TRY(put(step, hs.data(), d));
+    if (n_loops) *n_loops = i;
+    return MRBF_OK;
+}
+
+int32_t mrbf_model_dims(const mrbf_model *model, int64_t *n, int32_t *d, int32_t *k, int32_t *q) {
+    if (!model) return -1;
+    if (n) *n = model->n;
+    if (d) *d = model->d;
+    if (k) *k = model->k;
+    if (q) *q = model->q;
+    return MRBF_OK;
+}
+
+int32_t mrbf_free_model(mrbf_ctx *ctx, mrbf_model *model) {
+    if (!ctx) return -1;
+    if (!model) return MRBF_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    destroy_model(model);
+    return MRBF_OK;
+}
+
+int32_t mrbf_batch_run(int32_t n_dev, const int32_t *device_ids, int64_t n_problems, const mrbf_problem *problems,
+                       mrbf_result *results) {
+    if (n_dev < 1) return -1;
+    if (n_problems < 0) return -3;
+    if (n_problems > 0 && (!problems || !results)) return -4;
+    int visible = 0;
+    if (hipGetDeviceCount(&visible) != hipSuccess || visible <= 0) return MRBF_ENODEVICE;
+    std::vector<int> devs(n_dev);
+    for (int g = 0; g < n_dev; ++g) {
+        devs[g] = device_ids ? device_ids[g] : g;
+        if (devs[g] < 0 || devs[g] >= visible) return -2;
+    }
+    std::vector<int> rcs(n_dev, 0);
+    auto worker = [&](int g) {
+        mrbf_ctx *ctx = nullptr;
+        int rc = mrbf_init(devs[g], &ctx);
+        if (rc != 0) {
+            rcs[g] = rc;
+            for (int64_t p = g; p < n_problems; p += n_dev) {
+                std::memset(&results[p], 0, sizeof(mrbf_result));
+                results[p].status = rc;
+                results[p].device = devs[g];
+            }
+            return;
+        }
+        for (int64_t p = g; p < n_problems; p += n_dev) {  // round-robin shard, no exchange between problems
+            const mrbf_problem &pr = problems[p];
+            mrbf_result &res = results[p];
+            std::memset(&res, 0, sizeof(res));
+            res.device = devs[g];
+            mrbf_model *M = nullptr;
+            std::vector<double> wtmp, vtmp;
+            double *wout = pr.weights_out, *vout = pr.vals_out;
+            if (!wout) {
+                wtmp.resize((size_t)pr.n * pr.k);
+                wout = wtmp.data();
+            }
+            res.status = mrbf_fit(ctx, pr.n, pr.d, pr.k, pr.centres, pr.values, pr.kernel_id, pr.a, pr.b, pr.poly_deg, &M,
+                                  wout, pr.poly_out, &res.fit);
+            if (res.status == 0 && pr.m > 0) {
+                if (!vout) {
+                    vtmp.resize((size_t)pr.m * pr.k);
+                    vout = vtmp.data();
+                }
+                mrbf_eval_info ei;
+                res.status = mrbf_eval(ctx, M, pr.m, pr.X, vout, pr.jac_out, &ei);
+                res.ms_eval = ei.ms_total;
+                if (res.status == 0)
+                    for (size_t i = 0; i < (size_t)pr.m * pr.k; ++i) res.checksum_vals += vout[i];
+            }
+            if (res.status == 0 || M)
+                for (size_t i = 0; M && i < (size_t)pr.n * pr.k; ++i) res.checksum_w += wout[i];
+            if (M) mrbf_free_model(ctx, M);
+        }
+        mrbf_shutdown(ctx);
+    };
+    std::vector<std::thread> th;
+    for (int g = 0; g < n_dev; ++g) th.emplace_back(worker, g);
+    for (auto &t : th) t.join();
+    for (int g = 0; g < n_dev; ++g)
+        if (rcs[g] != 0) return rcs[g];
+    return MRBF_OK;
+}
+
+}  // extern "C"

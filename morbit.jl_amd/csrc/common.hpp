@@ -1,0 +1,127 @@
+// Internal declarations of libmrbf (not part of the ABI; the ABI is include/mrbf.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rocblas/rocblas.h>
+#include <rocsolver/rocsolver.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mrbf.h"
+
+namespace mrbf {
+
+// ---- kernel parameters handed to device code -------------------------------------------
+struct KP {
+    int kid;
+    double a, b;
+    double a2;    // alpha^2 (gaussian / multiquadrics)
+    double sgn;   // sign convention of the conditionally p.d. kernels
+    int fast;     // 1: beta == 1/2 (multiquadrics) or beta == 3 (cubic): sqrt path instead of pow
+    int ik;       // thin plate spline k
+    double phi0;  // phi(0) = diagonal of Phi
+};
+KP make_kp(int kid, double a, double b);
+int cpd_order(int kid, double a, double b);
+inline int poly_dim(int d, int deg) { return deg < 0 ? 0 : (deg == 0 ? 1 : d + 1); }
+
+// ---- workspace arena: named grow-only device buffers -----------------------------------
+enum Slot {
+    S_XC = 0, S_SQ, S_MEAN, S_PHI, S_PI, S_Q1, S_W1, S_G, S_R, S_TAU, S_RHS, S_T1, S_T2, S_IPIV, S_INFO,
+    S_STAGE_A, S_STAGE_B, S_STAGE_C, S_STAGE_D, S_EVAL_E, S_EVAL_A, S_EVAL_J, S_EVAL_SA, S_EVAL_XC, S_EVAL_XSQ,
+    S_OUT_A, S_OUT_B, S_CHOL_WS, S_MISC, S_NSLOTS
+};
+struct Buf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace mrbf
+
+struct mrbf_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    rocblas_handle blas = nullptr;
+    mrbf::Buf slots[mrbf::S_NSLOTS];
+    hipEvent_t ev[8] = {};
+    std::string err;
+    // options
+    int gram_mode = 0, residual = 1, force_path = 0, chol_impl = 0, eval_impl = 0, timing = 1;
+};
+
+struct mrbf_model {
+    int64_t n = 0, npad = 0;
+    int d = 0, dpad = 0, k = 0, q = 0, deg = -1;
+    mrbf::KP kp{};
+    double *C = nullptr;     // n x d original centres (row-major)
+    double *Xc = nullptr;    // npad x dpad centred, zero padded
+    double *sq = nullptr;    // npad squared norms of the centred rows
+    double *mean = nullptr;  // dpad centroid
+    double *W = nullptr;     // n x k row-major weights
+    double *Wc = nullptr;    // npad x k column-major weights (zero padded) for the GEMM-shaped contractions
+    double *lam = nullptr;   // q x k row-major
+};
+
+namespace mrbf {
+
+// ---- error plumbing ---------------------------------------------------------------------
+int fail(mrbf_ctx *ctx, int code, const char *fmt, ...);
+#define MRBF_HIP(ctx, call)                                                                                  \
+    do {                                                                                                      \
+        hipError_t e__ = (call);                                                                              \
+        if (e__ != hipSuccess)                                                                                \
+            return mrbf::fail(ctx, e__ == hipErrorOutOfMemory ? MRBF_ENOMEM : MRBF_EHIP, "%s: %s (%s:%d)", #call, \
+                              hipGetErrorString(e__), __FILE__, __LINE__);                                    \
+    } while (0)
+#define MRBF_BLAS(ctx, call)                                                                                 \
+    do {                                                                                                      \
+        rocblas_status s__ = (call);                                                                          \
+        if (s__ != rocblas_status_success)                                                                    \
+            return mrbf::fail(ctx, MRBF_EBLAS, "%s: rocblas status %d (%s:%d)", #call, (int)s__, __FILE__, __LINE__); \
+    } while (0)
+#define MRBF_TRY(call)             \
+    do {                           \
+        int rc__ = (call);         \
+        if (rc__ != 0) return rc__; \
+    } while (0)
+
+int get_buf(mrbf_ctx *ctx, Slot s, size_t bytes, void **out);
+template <class T>
+inline int get_buf(mrbf_ctx *ctx, Slot s, size_t count, T **out) {
+    return get_buf(ctx, s, count * sizeof(T), (void **)out);
+}
+bool is_device_ptr(const void *p);
+// device view of a caller buffer: the pointer itself when it is device memory, else a staged copy
+int stage_in(mrbf_ctx *ctx, Slot s, const double *user, size_t count, const double **dev);
+// device buffer to produce an output into (user's own when device memory, else staging)
+int stage_out(mrbf_ctx *ctx, Slot s, double *user, size_t count, double **dev);
+int finish_out(mrbf_ctx *ctx, double *user, const double *dev, size_t count);
+
+inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// ---- launchers implemented in the .hip files (all asynchronous on ctx->stream) ----------
+// prep.hip
+int launch_center_pad(mrbf_ctx *ctx, const double *X, int64_t n, int d, const double *mean_or_null, double *mean_out,
+                      double *Xc, int64_t npad, int dpad, double *sq);
+int launch_poly_matrix(mrbf_ctx *ctx, const double *C, int64_t n, int d, int q, double *Pi, int64_t ldpi);
+int launch_transpose(mrbf_ctx *ctx, const double *in, int64_t rows, int64_t cols, double *out);  // in rows x cols row-major -> out col-major ld=rows... see impl
+// gram.hip
+int launch_gram(mrbf_ctx *ctx, int mode, const double *C, const double *Xc, const double *sq, int64_t n, int64_t npad,
+                int d, int dpad, const KP &kp, double *Phi, int64_t ld);
+// eval.hip
+int eval_model(mrbf_ctx *ctx, const mrbf_model *M, int64_t m, const double *Xdev, double *vals_dev, double *jac_dev,
+               mrbf_eval_info *info);
+// chol.hip
+int potrf_lower(mrbf_ctx *ctx, int impl, int64_t n, double *A, int64_t lda, int *info_host);
+// solve.hip
+int fit_model(mrbf_ctx *ctx, mrbf_model *M, const double *Ydev, mrbf_fit_info *info);
+int build_model_shell(mrbf_ctx *ctx, int64_t n, int d, int k, const double *Cdev, int kid, double a, double b, int deg,
+                      mrbf_model **out);
+void destroy_model(mrbf_model *M);
+
+}  // namespace mrbf

@@ -1,0 +1,229 @@
+// Context, workspace arena, host<->device staging, options.
+#include <cstdarg>
+
+#include "common.hpp"
+
+namespace mrbf {
+
+static thread_local std::string g_init_err;
+
+int fail(mrbf_ctx *ctx, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx)
+        ctx->err = buf;
+    else
+        g_init_err = buf;
+    return code;
+}
+
+int cpd_order(int kid, double a, double b) {
+    switch (kid) {
+        case MRBF_CUBIC: return (int)std::ceil(a / 2.0);
+        case MRBF_MULTIQUADRIC: return (int)std::ceil(b);
+        case MRBF_THIN_PLATE_SPLINE: return (int)a + 1;
+        default: return 0;
+    }
+}
+
+KP make_kp(int kid, double a, double b) {
+    KP p{};
+    p.kid = kid;
+    p.a = a;
+    p.b = b;
+    p.a2 = a * a;
+    p.sgn = 1.0;
+    p.fast = 0;
+    p.ik = 0;
+    switch (kid) {
+        case MRBF_GAUSSIAN: p.phi0 = 1.0; break;
+        case MRBF_MULTIQUADRIC:
+            p.sgn = ((int)std::ceil(b) & 1) ? -1.0 : 1.0;
+            p.fast = (b == 0.5);
+            p.phi0 = p.sgn;
+            break;
+        case MRBF_INV_MULTIQUADRIC:
+            p.fast = (b == 0.5);
+            p.phi0 = 1.0;
+            break;
+        case MRBF_CUBIC:
+            p.sgn = ((int)std::ceil(a / 2.0) & 1) ? -1.0 : 1.0;
+            p.fast = (a == 3.0);
+            p.a2 = 0.0;
+            p.phi0 = 0.0;
+            break;
+        case MRBF_THIN_PLATE_SPLINE:
+            p.ik = (int)a;
+            p.sgn = ((p.ik + 1) & 1) ? -1.0 : 1.0;
+            p.a2 = 0.0;
+            p.phi0 = 0.0;
+            break;
+    }
+    return p;
+}
+
+int get_buf(mrbf_ctx *ctx, Slot s, size_t bytes, void **out) {
+    Buf &b = ctx->slots[s];
+    if (bytes == 0) bytes = 16;
+    if (b.bytes < bytes) {
+        if (b.p) {
+            // a previous launch on the stream may still be using the old buffer
+            MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            MRBF_HIP(ctx, hipFree(b.p));
+            b.p = nullptr;
+            b.bytes = 0;
+        }
+        size_t want = bytes + bytes / 8;  // slack so slowly growing problems do not realloc every call
+        want = (want + 255) & ~size_t(255);
+        MRBF_HIP(ctx, hipMalloc(&b.p, want));
+        b.bytes = want;
+    }
+    *out = b.p;
+    return 0;
+}
+
+bool is_device_ptr(const void *p) {
+    if (!p) return false;
+    hipPointerAttribute_t attr;
+    std::memset(&attr, 0, sizeof(attr));
+    hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // plain malloc'ed memory on older runtimes: clear the sticky error
+        return false;
+    }
+    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+int stage_in(mrbf_ctx *ctx, Slot s, const double *user, size_t count, const double **dev) {
+    if (is_device_ptr(user)) {
+        *dev = user;
+        return 0;
+    }
+    double *b = nullptr;
+    MRBF_TRY(get_buf(ctx, s, count, &b));
+    MRBF_HIP(ctx, hipMemcpyAsync(b, user, count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    *dev = b;
+    return 0;
+}
+
+int stage_out(mrbf_ctx *ctx, Slot s, double *user, size_t count, double **dev) {
+    if (is_device_ptr(user)) {
+        *dev = user;
+        return 0;
+    }
+    return get_buf(ctx, s, count, dev);
+}
+
+int finish_out(mrbf_ctx *ctx, double *user, const double *dev, size_t count) {
+    if (user == dev || user == nullptr) return 0;
+    MRBF_HIP(ctx, hipMemcpyAsync(user, dev, count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    return 0;
+}
+
+}  // namespace mrbf
+
+using namespace mrbf;
+
+extern "C" {
+
+const char *mrbf_version(void) { return "mrbf 0.1.0 (gfx950)"; }
+
+const char *mrbf_last_error(const mrbf_ctx *ctx) { return ctx ? ctx->err.c_str() : g_init_err.c_str(); }
+
+int32_t mrbf_init(int32_t device_id, mrbf_ctx **out) {
+    if (!out) return -2;
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
+        return fail(nullptr, MRBF_ENODEVICE, "no HIP device visible (%s); libmrbf has no CPU path",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    }
+    if (device_id < 0) {
+        if (hipGetDevice(&device_id) != hipSuccess) device_id = 0;
+    }
+    if (device_id >= ndev) return fail(nullptr, -1, "device_id %d out of range (%d devices)", device_id, ndev);
+    mrbf_ctx *ctx = new mrbf_ctx();
+    ctx->device = device_id;
+    auto bail = [&](int code, const char *what) {
+        std::string msg = std::string(what) + " failed";
+        delete ctx;
+        return fail(nullptr, code, "%s", msg.c_str());
+    };
+    if (hipSetDevice(device_id) != hipSuccess) return bail(MRBF_EHIP, "hipSetDevice");
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess)
+        return bail(MRBF_EHIP, "hipStreamCreate");
+    ctx->stream = ctx->own_stream;
+    if (rocblas_create_handle(&ctx->blas) != rocblas_status_success) return bail(MRBF_EBLAS, "rocblas_create_handle");
+    rocblas_set_stream(ctx->blas, ctx->stream);
+    rocblas_set_pointer_mode(ctx->blas, rocblas_pointer_mode_host);
+    for (auto &ev : ctx->ev)
+        if (hipEventCreate(&ev) != hipSuccess) return bail(MRBF_EHIP, "hipEventCreate");
+    *out = ctx;
+    return MRBF_OK;
+}
+
+int32_t mrbf_shutdown(mrbf_ctx *ctx) {
+    if (!ctx) return -1;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &b : ctx->slots)
+        if (b.p) (void)hipFree(b.p);
+    for (auto &ev : ctx->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    if (ctx->blas) rocblas_destroy_handle(ctx->blas);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return MRBF_OK;
+}
+
+int32_t mrbf_set_option(mrbf_ctx *ctx, int32_t key, double value) {
+    if (!ctx) return -1;
+    int v = (int)value;
+    switch (key) {
+        case MRBF_OPT_GRAM_MODE: ctx->gram_mode = v; break;
+        case MRBF_OPT_RESIDUAL: ctx->residual = v; break;
+        case MRBF_OPT_FORCE_PATH: ctx->force_path = v; break;
+        case MRBF_OPT_CHOL_IMPL: ctx->chol_impl = v; break;
+        case MRBF_OPT_EVAL_IMPL: ctx->eval_impl = v; break;
+        case MRBF_OPT_TIMING: ctx->timing = v; break;
+        default: return fail(ctx, -2, "unknown option key %d", key);
+    }
+    return MRBF_OK;
+}
+
+int32_t mrbf_get_option(const mrbf_ctx *ctx, int32_t key, double *value) {
+    if (!ctx) return -1;
+    if (!value) return -3;
+    switch (key) {
+        case MRBF_OPT_GRAM_MODE: *value = ctx->gram_mode; break;
+        case MRBF_OPT_RESIDUAL: *value = ctx->residual; break;
+        case MRBF_OPT_FORCE_PATH: *value = ctx->force_path; break;
+        case MRBF_OPT_CHOL_IMPL: *value = ctx->chol_impl; break;
+        case MRBF_OPT_EVAL_IMPL: *value = ctx->eval_impl; break;
+        case MRBF_OPT_TIMING: *value = ctx->timing; break;
+        default: return -2;
+    }
+    return MRBF_OK;
+}
+
+int32_t mrbf_set_stream(mrbf_ctx *ctx, void *hip_stream) {
+    if (!ctx) return -1;
+    (void)hipSetDevice(ctx->device);
+    MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    MRBF_BLAS(ctx, rocblas_set_stream(ctx->blas, ctx->stream));
+    return MRBF_OK;
+}
+
+int32_t mrbf_sync(mrbf_ctx *ctx) {
+    if (!ctx) return -1;
+    MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MRBF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,365 @@
+// Interpolation-weight solve -- replaces the dense `\` inside RBF.RBFInterpolationModel
+// (/root/reference/src/models/RbfModel.jl:759-763):   [Phi Pi; Pi' 0] [w; lam] = [Y; 0].
+//
+// Paths (mrbf_fit_info.path):
+//   CHOL       q = 0, kernel strictly p.d. (gaussian, inverse multiquadric):  potrf(Phi), potrs.
+//   PROJ_CHOL  q > 0 and the kernel is conditionally p.d. of order <= deg + 1 (the situation Morbit
+//              itself relies on for cholesky(Z' Phi Z), RbfModel.jl:391-395).  With Pi = Q1 R (thin QR)
+//              and P = I - Q1 Q1',  K = P Phi P + mu Q1 Q1' is s.p.d.;  K w = P Y gives w in null(Pi'),
+//              lam = R^-1 Q1' (Y - Phi w).  K is formed IN PLACE on the lower triangle of Phi by one
+//              symm + one syr2k + one syrk (4 n^2 q flops, all level 3), so the factorisation stays an
+//              n x n blocked Cholesky on the matrix cores instead of an (n+q) LU.
+//   LU         anything else (tail of too low a degree for the kernel's order, failed Cholesky):
+//              getrf/getrs on the full saddle matrix.
+#include "common.hpp"
+
+namespace mrbf {
+
+__global__ void fill_saddle_kernel(const double *__restrict__ Pi, int64_t n, int q, double *__restrict__ S, int64_t N) {
+    // S[0:n, n+t] = Pi[:, t];  S[n+t, 0:n] = Pi[:, t]';  S[n:, n:] = 0
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t tot = n * q;
+    if (idx < tot) {
+        const int64_t i = idx % n;
+        const int t = (int)(idx / n);
+        const double v = Pi[idx];
+        S[i + (n + t) * N] = v;
+        S[(n + t) + i * N] = v;
+    } else if (idx < tot + (int64_t)q * q) {
+        const int64_t r = idx - tot;
+        S[(n + r % q) + (n + r / q) * N] = 0.0;
+    }
+}
+
+// B (N x k col-major, ld N): rows [0,n) from Y (n x k row-major), rows [n,N) zero
+__global__ void rhs_from_values_kernel(const double *__restrict__ Y, int64_t n, int k, double *__restrict__ B, int64_t N) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * k) return;
+    const int64_t i = idx % N;
+    const int l = (int)(idx / N);
+    B[idx] = (i < n) ? Y[i * k + l] : 0.0;
+}
+
+// W (n x k row-major), Wc (npad x k col-major zero padded), lam (q x k row-major) from solution B (ldB x k col-major)
+__global__ void scatter_solution_kernel(const double *__restrict__ B, int64_t ldB, int64_t n, int64_t npad, int k, int q,
+                                        int64_t lam_row0, double *__restrict__ W, double *__restrict__ Wc,
+                                        double *__restrict__ lam, const double *__restrict__ lamsrc, int64_t ldlam) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < npad * k) {
+        const int64_t i = idx % npad;
+        const int l = (int)(idx / npad);
+        const double v = (i < n) ? B[i + l * ldB] : 0.0;
+        Wc[idx] = v;
+        if (i < n) W[i * k + l] = v;
+    } else if (idx < npad * k + (int64_t)q * k) {
+        const int64_t r = idx - npad * k;
+        const int t = (int)(r % q), l = (int)(r / q);
+        lam[(int64_t)t * k + l] = lamsrc[lam_row0 + t + l * ldlam];
+    }
+}
+
+__global__ void copy_upper_kernel(const double *__restrict__ A, int64_t lda, int q, double *__restrict__ R) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= q * q) return;
+    const int i = idx % q, j = idx / q;
+    R[idx] = (i <= j) ? A[i + (int64_t)j * lda] : 0.0;
+}
+
+__global__ void trace_kernel(const double *__restrict__ G, int q, double *__restrict__ out) {
+    // single block, deterministic
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < q; i += 256) s += G[i + (int64_t)i * q];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0];
+}
+
+__global__ void max_abs_kernel(const double *__restrict__ v, int64_t cnt, double *__restrict__ out) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < cnt; i += 256) s = fmax(s, fabs(v[i]));
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + w]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0];
+}
+
+// out[0] = sum (a-b)^2, out[1] = sum b^2 over cnt entries (single block, deterministic)
+__global__ void residual_kernel(const double *__restrict__ a, const double *__restrict__ b, int64_t cnt,
+                                double *__restrict__ out) {
+    __shared__ double r0[256], r1[256];
+    double s0 = 0.0, s1 = 0.0;
+    for (int64_t i = threadIdx.x; i < cnt; i += 256) {
+        const double df = a[i] - b[i];
+        s0 = fma(df, df, s0);
+        s1 = fma(b[i], b[i], s1);
+    }
+    r0[threadIdx.x] = s0;
+    r1[threadIdx.x] = s1;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            r0[threadIdx.x] += r0[threadIdx.x + w];
+            r1[threadIdx.x] += r1[threadIdx.x + w];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out[0] = r0[0];
+        out[1] = r1[0];
+    }
+}
+
+static inline unsigned nblk(int64_t cnt) { return (unsigned)((cnt + 255) / 256); }
+
+void destroy_model(mrbf_model *M) {
+    if (!M) return;
+    for (double *p : {M->C, M->Xc, M->sq, M->mean, M->W, M->Wc, M->lam})
+        if (p) (void)hipFree(p);
+    delete M;
+}
+
+int build_model_shell(mrbf_ctx *ctx, int64_t n, int d, int k, const double *Cdev, int kid, double a, double b, int deg,
+                      mrbf_model **out) {
+    mrbf_model *M = new mrbf_model();
+    M->n = n;
+    M->d = d;
+    M->k = k;
+    M->deg = deg;
+    M->q = poly_dim(d, deg);
+    M->npad = round_up(n, 128);
+    M->dpad = (int)round_up(d, 16);
+    M->kp = make_kp(kid, a, b);
+    auto alloc = [&](double **p, size_t cnt) { return hipMalloc((void **)p, std::max<size_t>(cnt, 2) * sizeof(double)); };
+    hipError_t e = hipSuccess;
+    if (e == hipSuccess) e = alloc(&M->C, (size_t)n * d);
+    if (e == hipSuccess) e = alloc(&M->Xc, (size_t)M->npad * M->dpad);
+    if (e == hipSuccess) e = alloc(&M->sq, (size_t)M->npad);
+    if (e == hipSuccess) e = alloc(&M->mean, (size_t)M->dpad);
+    if (e == hipSuccess) e = alloc(&M->W, (size_t)n * k);
+    if (e == hipSuccess) e = alloc(&M->Wc, (size_t)M->npad * k);
+    if (e == hipSuccess) e = alloc(&M->lam, (size_t)std::max(M->q, 1) * k);
+    if (e != hipSuccess) {
+        destroy_model(M);
+        return fail(ctx, MRBF_ENOMEM, "model allocation failed: %s", hipGetErrorString(e));
+    }
+    if (Cdev != M->C)
+        MRBF_HIP(ctx, hipMemcpyAsync(M->C, Cdev, (size_t)n * d * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    MRBF_TRY(launch_center_pad(ctx, M->C, n, d, nullptr, M->mean, M->Xc, M->npad, M->dpad, M->sq));
+    *out = M;
+    return 0;
+}
+
+static int read_info(mrbf_ctx *ctx, const int *dinfo, int *hinfo) {
+    MRBF_HIP(ctx, hipMemcpyAsync(hinfo, dinfo, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// ---- LU on the saddle system ---------------------------------------------------------------------
+static int fit_lu(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info *info) {
+    const int64_t n = M->n, N = n + M->q;
+    const int k = M->k, q = M->q;
+    double *S, *B, *Pi = nullptr;
+    int *ipiv, *dinfo;
+    MRBF_TRY(get_buf(ctx, S_PHI, (size_t)N * N, &S));
+    MRBF_TRY(get_buf(ctx, S_RHS, (size_t)N * k, &B));
+    MRBF_TRY(get_buf(ctx, S_IPIV, (size_t)N, &ipiv));
+    MRBF_TRY(get_buf(ctx, S_INFO, (size_t)4, &dinfo));
+    hipLaunchKernelGGL(rhs_from_values_kernel, dim3(nblk(N * k)), dim3(256), 0, ctx->stream, Y, n, k, B, N);
+    MRBF_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    MRBF_TRY(launch_gram(ctx, ctx->gram_mode, M->C, M->Xc, M->sq, n, M->npad, M->d, M->dpad, M->kp, S, N));
+    MRBF_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    if (q > 0) {
+        MRBF_TRY(get_buf(ctx, S_PI, (size_t)n * q, &Pi));
+        MRBF_TRY(launch_poly_matrix(ctx, M->C, n, M->d, q, Pi, n));
+        hipLaunchKernelGGL(fill_saddle_kernel, dim3(nblk(n * q + (int64_t)q * q)), dim3(256), 0, ctx->stream, Pi, n, q, S, N);
+    }
+    MRBF_HIP(ctx, hipGetLastError());
+    MRBF_HIP(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
+    MRBF_BLAS(ctx, rocsolver_dgetrf(ctx->blas, (int)N, (int)N, S, (int)N, ipiv, dinfo));
+    MRBF_HIP(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+    int hinfo = 0;
+    MRBF_TRY(read_info(ctx, dinfo, &hinfo));
+    info->factor_info = hinfo;
+    info->path = MRBF_PATH_LU;
+    if (hinfo != 0) return fail(ctx, MRBF_ESINGULAR, "saddle matrix is singular (getrf info = %d, N = %lld)", hinfo, (long long)N);
+    MRBF_BLAS(ctx, rocsolver_dgetrs(ctx->blas, rocblas_operation_none, (int)N, k, S, (int)N, ipiv, B, (int)N));
+    hipLaunchKernelGGL(scatter_solution_kernel, dim3(nblk(M->npad * k + (int64_t)q * k)), dim3(256), 0, ctx->stream, B, N, n,
+                       M->npad, k, q, n, M->W, M->Wc, M->lam, B, N);
+    MRBF_HIP(ctx, hipGetLastError());
+    MRBF_HIP(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+    MRBF_HIP(ctx, hipEventSynchronize(ctx->ev[3]));
+    MRBF_HIP(ctx, hipEventElapsedTime(&info->ms_gram, ctx->ev[0], ctx->ev[1]));
+    MRBF_HIP(ctx, hipEventElapsedTime(&info->ms_project, ctx->ev[1], ctx->ev[5]));
+    MRBF_HIP(ctx, hipEventElapsedTime(&info->ms_factor, ctx->ev[5], ctx->ev[2]));
+    MRBF_HIP(ctx, hipEventElapsedTime(&info->ms_solve, ctx->ev[2], ctx->ev[3]));
+    return 0;
+}
+
+// ---- Cholesky paths ------------------------------------------------------------------------------
+// returns 0 with *not_pd = 1 when the factorisation met a non-positive pivot (caller may retry with LU)
+static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info *info, int *not_pd) {
+    const int64_t n = M->n;
+    const int k = M->k, q = M->q;
+    const double one = 1.0, zero = 0.0, mone = -1.0, mhalf = -0.5;
+    *not_pd = 0;
+    double *Phi, *B;
+    MRBF_TRY(get_buf(ctx, S_PHI, (size_t)n * n, &Phi));
+    MRBF_TRY(get_buf(ctx, S_RHS, (size_t)n * k, &B));
+    hipLaunchKernelGGL(rhs_from_values_kernel, dim3(nblk(n * k)), dim3(256), 0, ctx->stream, Y, n, k, B, n);
+    MRBF_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));  // ev0..ev1 bracket the Gram kernel alone
+    MRBF_TRY(launch_gram(ctx, ctx->gram_mode, M->C, M->Xc, M->sq, n, M->npad, M->d, M->dpad, M->kp, Phi, n));
+    MRBF_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+
+    double *Q1 = nullptr, *Wm = nullptr, *G = nullptr, *R = nullptr, *tau = nullptr, *T1 = nullptr, *scal = nullptr;
+    info->mu = 0.0;
+    if (q > 0) {
+        MRBF_TRY(get_buf(ctx, S_Q1, (size_t)n * q, &Q1));
+        MRBF_TRY(get_buf(ctx, S_W1, (size_t)n * q, &Wm));
+        MRBF_TRY(get_buf(ctx, S_G, (size_t)q * q, &G));
+        MRBF_TRY(get_buf(ctx, S_R, (size_t)q * q, &R));
+        MRBF_TRY(get_buf(ctx, S_TAU, (size_t)q, &tau));
+        MRBF_TRY(get_buf(ctx, S_T1, (size_t)q * k, &T1));
+        MRBF_TRY(get_buf(ctx, S_MISC, (size_t)8, &scal));
+        // thin QR of Pi
+        MRBF_TRY(launch_poly_matrix(ctx, M->C, n, M->d, q, Q1, n));
+        MRBF_BLAS(ctx, rocsolver_dgeqrf(ctx->blas, (int)n, q, Q1, (int)n, tau));
+        hipLaunchKernelGGL(copy_upper_kernel, dim3(nblk((int64_t)q * q)), dim3(256), 0, ctx->stream, Q1, n, q, R);
+        MRBF_BLAS(ctx, rocsolver_dorgqr(ctx->blas, (int)n, q, q, Q1, (int)n, tau));
+        // W1 = Phi Q1 ; G = Q1' W1 ; W = W1 - 1/2 Q1 G
+        MRBF_BLAS(ctx, rocblas_dsymm(ctx->blas, rocblas_side_left, rocblas_fill_lower, (int)n, q, &one, Phi, (int)n, Q1, (int)n,
+                                     &zero, Wm, (int)n));
+        MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, q, q, (int)n, &one, Q1,
+                                     (int)n, Wm, (int)n, &zero, G, q));
+        hipLaunchKernelGGL(trace_kernel, dim3(1), dim3(256), 0, ctx->stream, G, q, scal);
+        MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, (int)n, q, q, &mhalf, Q1, (int)n,
+                                     G, q, &one, Wm, (int)n));
+        // K = Phi - Q1 W' - W Q1'   (lower triangle, in place)
+        MRBF_BLAS(ctx, rocblas_dsyr2k(ctx->blas, rocblas_fill_lower, rocblas_operation_none, (int)n, q, &mone, Q1, (int)n, Wm,
+                                      (int)n, &one, Phi, (int)n));
+        // mu = trace(P Phi P) / (n - q): the mean eigenvalue of Z' Phi Z, so the shift sits inside the spectrum
+        double trG = 0.0;
+        MRBF_HIP(ctx, hipMemcpyAsync(&trG, scal, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        double mu = ((double)n * M->kp.phi0 - trG) / (double)std::max<int64_t>(n - q, 1);
+        if (!(mu > 0.0) || !std::isfinite(mu)) {
+            *not_pd = 1;  // trace <= 0: Z' Phi Z cannot be positive definite
+            info->factor_info = -1;
+            return 0;
+        }
+        info->mu = mu;
+        MRBF_BLAS(ctx, rocblas_dsyrk(ctx->blas, rocblas_fill_lower, rocblas_operation_none, (int)n, q, &mu, Q1, (int)n, &one, Phi,
+                                     (int)n));
+        // B = P Y = Y - Q1 (Q1' Y);  T1 keeps Q1' Y for lam
+        MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, q, k, (int)n, &one, Q1,
+                                     (int)n, B, (int)n, &zero, T1, q));
+        MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, (int)n, k, q, &mone, Q1, (int)n,
+                                     T1, q, &one, B, (int)n));
+    }
+    MRBF_HIP(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+    int hinfo = 0;
+    MRBF_TRY(potrf_lower(ctx, ctx->chol_impl, n, Phi, n, &hinfo));
+    MRBF_HIP(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+    info->factor_info = hinfo;
+    if (hinfo != 0) {
+        *not_pd = 1;
+        return 0;
+    }
+    MRBF_BLAS(ctx, rocsolver_dpotrs(ctx->blas, rocblas_fill_lower, (int)n, k, Phi, (int)n, B, (int)n));
+    if (q > 0) {
+        double *T2;
+        MRBF_TRY(get_buf(ctx, S_T2, (size_t)q * k, &T2));
+        // re-project w (rounding hygiene): w -= Q1 (Q1' w)
+        MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, q, k, (int)n, &one, Q1,
+                                     (int)n, B, (int)n, &zero, T2, q));
+        MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, (int)n, k, q, &mone, Q1, (int)n,
+                                     T2, q, &one, B, (int)n));
+        // lam = R^-1 (Q1' Y - (Phi Q1)' w);  (Phi Q1)' w = W' w because Q1' w = 0
+        MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, q, k, (int)n, &mone, Wm,
+                                     (int)n, B, (int)n, &one, T1, q));
+        MRBF_BLAS(ctx, rocblas_dtrsm(ctx->blas, rocblas_side_left, rocblas_fill_upper, rocblas_operation_none,
+                                     rocblas_diagonal_non_unit, q, k, &one, R, q, T1, q));
+    }
+    hipLaunchKernelGGL(scatter_solution_kernel, dim3(nblk(M->npad * k + (int64_t)q * k)), dim3(256), 0, ctx->stream, B, n, n,
+                       M->npad, k, q, (int64_t)0, M->W, M->Wc, M->lam, T1 ? T1 : B, (int64_t)q);
+    MRBF_HIP(ctx, hipGetLastError());
+    MRBF_HIP(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+    MRBF_HIP(ctx, hipEventSynchronize(ctx->ev[4]));
+    MRBF_HIP(ctx, hipEventElapsedTime(&info->ms_gram, ctx->ev[0], ctx->ev[1]));
+    MRBF_HIP(ctx, hipEventElapsedTime(&info->ms_project, ctx->ev[1], ctx->ev[2]));
+    MRBF_HIP(ctx, hipEventElapsedTime(&info->ms_factor, ctx->ev[2], ctx->ev[3]));
+    MRBF_HIP(ctx, hipEventElapsedTime(&info->ms_solve, ctx->ev[3], ctx->ev[4]));
+    info->path = q > 0 ? MRBF_PATH_PROJ_CHOL : MRBF_PATH_CHOL;
+    return 0;
+}
+
+// residual ||s(C) - Y|| / ||Y|| through the evaluation kernels (an independent code path), and max |Pi' w|
+static int fit_check(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info *info) {
+    const int64_t n = M->n;
+    const int k = M->k, q = M->q;
+    double *V, *scal;
+    MRBF_TRY(get_buf(ctx, S_STAGE_D, (size_t)n * k, &V));
+    MRBF_TRY(get_buf(ctx, S_MISC, (size_t)8, &scal));
+    MRBF_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    MRBF_TRY(eval_model(ctx, M, n, M->C, V, nullptr, nullptr));
+    hipLaunchKernelGGL(residual_kernel, dim3(1), dim3(256), 0, ctx->stream, V, Y, n * k, scal);
+    double h[3] = {0, 0, 0};
+    if (q > 0) {
+        double *Pi, *T;
+        const double one = 1.0, zero = 0.0;
+        MRBF_TRY(get_buf(ctx, S_PI, (size_t)n * q, &Pi));
+        MRBF_TRY(get_buf(ctx, S_T2, (size_t)q * k, &T));
+        MRBF_TRY(launch_poly_matrix(ctx, M->C, n, M->d, q, Pi, n));
+        MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, q, k, (int)n, &one, Pi,
+                                     (int)n, M->Wc, (int)M->npad, &zero, T, q));
+        hipLaunchKernelGGL(max_abs_kernel, dim3(1), dim3(256), 0, ctx->stream, T, (int64_t)q * k, scal + 2);
+    }
+    MRBF_HIP(ctx, hipGetLastError());
+    MRBF_HIP(ctx, hipMemcpyAsync(h, scal, 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    MRBF_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    info->rel_residual = std::sqrt(h[0]) / std::max(std::sqrt(h[1]), 1e-300);
+    info->max_pitw = q > 0 ? h[2] : 0.0;
+    MRBF_HIP(ctx, hipEventElapsedTime(&info->ms_check, ctx->ev[0], ctx->ev[1]));
+    return 0;
+}
+
+int fit_model(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info *info) {
+    mrbf_fit_info local;
+    if (!info) info = &local;
+    std::memset(info, 0, sizeof(*info));
+    info->n = (int32_t)M->n;
+    info->q = M->q;
+    info->rel_residual = NAN;
+    info->max_pitw = NAN;
+    const int order = cpd_order(M->kp.kid, M->kp.a, M->kp.b);
+    int path = ctx->force_path;
+    if (path == 0) path = (order <= M->deg + 1 && M->n > M->q) ? (M->q > 0 ? MRBF_PATH_PROJ_CHOL : MRBF_PATH_CHOL) : MRBF_PATH_LU;
+    if (path == MRBF_PATH_CHOL && M->q > 0) path = MRBF_PATH_PROJ_CHOL;
+    if (path == MRBF_PATH_PROJ_CHOL && M->q == 0) path = MRBF_PATH_CHOL;
+    if (path != MRBF_PATH_LU) {
+        int not_pd = 0;
+        MRBF_TRY(fit_chol(ctx, M, Y, info, &not_pd));
+        if (not_pd) {
+            if (ctx->force_path != 0)
+                return fail(ctx, MRBF_ENOTPD, "Cholesky path forced but the matrix is not positive definite (info = %d)",
+                            info->factor_info);
+            path = MRBF_PATH_LU;  // retry on the saddle system (re-assembles Phi)
+        }
+    }
+    if (path == MRBF_PATH_LU) MRBF_TRY(fit_lu(ctx, M, Y, info));
+    if (ctx->residual) MRBF_TRY(fit_check(ctx, M, Y, info));
+    info->ms_total = info->ms_gram + info->ms_project + info->ms_factor + info->ms_solve;
+    return 0;
+}
+
+}  // namespace mrbf

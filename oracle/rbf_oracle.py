@@ -146,16 +146,30 @@ def poly_matrix(X, deg):
     return P
 
 
-def pairwise_dist(X, C):
-    """||x - c||_2 in DIFFERENCE form (what norm(x - c) does in the reference)."""
+def pairwise_dist(X, C, threads=None):
+    """||x - c||_2 in DIFFERENCE form (what norm(x - c) does in the reference).
+    Row chunks sized for the cache, spread over a thread pool (NumPy releases the GIL):
+    this is the "best-effort CPU mode" of BASELINE.md section 2."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+
     X = np.atleast_2d(X)
     C = np.atleast_2d(C)
     out = np.empty((X.shape[0], C.shape[0]))
-    # chunk rows to bound memory
-    step = max(1, int(2 ** 24 // max(1, C.shape[0] * C.shape[1])))
-    for i in range(0, X.shape[0], step):
+    step = max(1, int(2 ** 18 // max(1, C.shape[0] * C.shape[1])))
+
+    def work(i):
         diff = X[i : i + step, None, :] - C[None, :, :]
         out[i : i + step] = np.sqrt(np.einsum("ijk,ijk->ij", diff, diff))
+
+    starts = range(0, X.shape[0], step)
+    nthreads = threads or min(len(starts), os.cpu_count() or 1)
+    if nthreads <= 1 or X.shape[0] * C.shape[0] < 1 << 16:
+        for i in starts:
+            work(i)
+    else:
+        with ThreadPoolExecutor(nthreads) as ex:
+            list(ex.map(work, starts))
     return out
 
 

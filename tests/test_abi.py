@@ -1,0 +1,78 @@
+"""CPU tests of the drop-in boundary: libmrbf.so loads, exports exactly what include/mrbf.h declares,
+the ctypes table binds the same set, and without a GPU every compute path fails loudly (no CPU fallback)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests.conftest import ROOT, has_gpu
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "mrbf.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mrbf_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import morbit.jl_amd as pkg
+
+    if not os.path.exists(pkg._lib.LIB_PATH):
+        import __graft_entry__
+
+        __graft_entry__.build()
+    return pkg._lib.load()
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    import morbit.jl_amd as pkg
+
+    declared = header_symbols()
+    assert len(declared) >= 18
+    for name in declared:
+        assert hasattr(lib, name), "libmrbf.so does not export %s" % name
+    assert sorted(pkg._lib.SIGNATURES) == declared
+    exported = subprocess.check_output(["nm", "-D", "--defined-only", pkg._lib.LIB_PATH]).decode()
+    for name in declared:
+        assert re.search(r"\bT %s\b" % name, exported), name
+
+
+def test_struct_layouts_match_header():
+    from morbit.jl_amd import _lib
+
+    assert ctypes.sizeof(_lib.FitInfo) == 4 * 4 + 3 * 8 + 6 * 4 == 64
+    assert ctypes.sizeof(_lib.EvalInfo) == 16
+    assert ctypes.sizeof(_lib.Problem) == 2 * 8 + 4 * 4 + 2 * 8 + 7 * 8 == 104
+    assert _lib.Result.fit.offset == 8
+
+
+def test_version_and_no_cpu_fallback(lib):
+    assert b"gfx950" in lib.mrbf_version()
+    if has_gpu():
+        pytest.skip("GPU present: the no-device error path is not reachable")
+    import morbit.jl_amd as pkg
+
+    with pytest.raises(pkg.MrbfError) as ei:
+        pkg.Context()
+    assert ei.value.code == pkg._lib.MRBF_ENODEVICE
+    assert "no CPU path" in str(ei.value)
+    with pytest.raises(pkg.MrbfError):
+        pkg.update_model(pkg.RbfConfig(), np.zeros((4, 2)), np.zeros((4, 1)))
+    res = (pkg._lib.Result * 1)()
+    prob = (pkg._lib.Problem * 1)()
+    assert lib.mrbf_batch_run(1, None, 1, prob, res) == pkg._lib.MRBF_ENODEVICE
+    assert lib.mrbf_fit(None, 1, 1, 1, None, None, 0, 3.0, 0.0, 1, None, None, None, None) == -1
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg_dir = os.path.join(ROOT, "morbit.jl_amd")
+    for base, _, files in os.walk(pkg_dir):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".jl", ".cpp", ".h")):
+                src = open(os.path.join(base, f), errors="ignore").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f
+                assert "librbf_oracle" not in src, f
