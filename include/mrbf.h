@@ -64,7 +64,8 @@ enum {
 enum {
     MRBF_PATH_CHOL = 1,      /* Phi SPD, no tail: potrf(Phi) */
     MRBF_PATH_PROJ_CHOL = 2, /* tail + conditionally p.d. kernel: potrf(P Phi P + mu Q1 Q1') on null(Pi') */
-    MRBF_PATH_LU = 3         /* indefinite saddle system [Phi Pi; Pi' 0]: getrf */
+    MRBF_PATH_LU = 3,        /* indefinite saddle system [Phi Pi; Pi' 0]: getrf */
+    MRBF_PATH_MINNORM = 4    /* n < q (fewer sites than tail terms): minimum-norm solution by SVD */
 };
 
 /* mrbf_set_option keys */

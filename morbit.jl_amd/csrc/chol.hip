@@ -6,13 +6,20 @@
 namespace mrbf {
 
 int potrf_blocked(mrbf_ctx *ctx, int64_t n, double *A, int64_t lda, int *dinfo);  // chol_blocked.hip
+int launch_pad_identity(mrbf_ctx *ctx, double *A, int64_t n, int64_t npad);        // chol_blocked.hip
 
+// A holds an n x n s.p.d. matrix in a buffer of leading dimension lda >= round_up(n, 128) whose rows/columns
+// [n, lda) belong to the caller too: the built-in factorisation pads them with the identity and works on
+// the 128-aligned order.
 int potrf_lower(mrbf_ctx *ctx, int impl, int64_t n, double *A, int64_t lda, int *info_host) {
     int *dinfo;
     MRBF_TRY(get_buf(ctx, S_INFO, (size_t)4, &dinfo));
-    if (impl == 0) impl = 1;
+    const int64_t npad = round_up(n, 128);
+    if (impl == 0) impl = (lda == npad) ? 2 : 1;
     if (impl == 2) {
-        MRBF_TRY(potrf_blocked(ctx, n, A, lda, dinfo));
+        if (lda != npad) return fail(ctx, MRBF_EHIP, "built-in Cholesky needs lda == round_up(n,128)");
+        MRBF_TRY(launch_pad_identity(ctx, A, n, npad));
+        MRBF_TRY(potrf_blocked(ctx, npad, A, lda, dinfo));
     } else {
         MRBF_BLAS(ctx, rocsolver_dpotrf(ctx->blas, rocblas_fill_lower, (int)n, A, (int)lda, dinfo));
     }
@@ -30,24 +37,23 @@ extern "C" int32_t mrbf_debug_potrf(mrbf_ctx *ctx, int64_t n, double *A, int32_t
     if (n <= 0) return -2;
     if (!A) return -3;
     (void)hipSetDevice(ctx->device);
+    // work on a 128-padded copy (ld = npad) so that both implementations see the same layout
+    const int64_t npad = round_up(n, 128);
     double *dA;
-    const bool dev = is_device_ptr(A);
-    if (dev) {
-        dA = A;
-    } else {
-        MRBF_TRY(get_buf(ctx, S_PHI, (size_t)n * n, &dA));
-        MRBF_HIP(ctx, hipMemcpyAsync(dA, A, (size_t)n * n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    }
+    MRBF_TRY(get_buf(ctx, S_PHI, (size_t)npad * npad, &dA));
+    const hipMemcpyKind in = is_device_ptr(A) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    const hipMemcpyKind out = is_device_ptr(A) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    MRBF_HIP(ctx, hipMemcpy2DAsync(dA, (size_t)npad * sizeof(double), A, (size_t)n * sizeof(double), (size_t)n * sizeof(double),
+                                   (size_t)n, in, ctx->stream));
     int hinfo = 0;
     MRBF_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-    MRBF_TRY(potrf_lower(ctx, impl, n, dA, n, &hinfo));
+    MRBF_TRY(potrf_lower(ctx, impl, n, dA, npad, &hinfo));
     MRBF_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     MRBF_HIP(ctx, hipEventSynchronize(ctx->ev[1]));
     if (ms) MRBF_HIP(ctx, hipEventElapsedTime(ms, ctx->ev[0], ctx->ev[1]));
     if (info) *info = hinfo;
-    if (!dev) {
-        MRBF_HIP(ctx, hipMemcpyAsync(A, dA, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    }
+    MRBF_HIP(ctx, hipMemcpy2DAsync(A, (size_t)n * sizeof(double), dA, (size_t)npad * sizeof(double), (size_t)n * sizeof(double),
+                                   (size_t)n, out, ctx->stream));
+    MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return MRBF_OK;
 }

@@ -205,6 +205,63 @@ static int fit_lu(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info *
     return 0;
 }
 
+// ---- minimum-norm solve of an under-determined saddle system (n < q: fewer sites than tail terms) ----
+// x = V S^+ U' b by rocSOLVER's SVD; singular values below N eps s_max are dropped.  Tiny systems only
+// (N = n + q <= 2q).  This is the case test/rbf_models.jl:35-44 builds ("too few points", max_evals = 1).
+__global__ void scale_rows_pinv_kernel(double *__restrict__ T, int N, int k, const double *__restrict__ sv) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * k) return;
+    const int i = idx % N;
+    const double s = sv[i], cut = (double)N * 2.220446049250313e-16 * sv[0];
+    T[idx] = (s > cut) ? T[idx] / s : 0.0;
+}
+
+static int fit_minnorm(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info *info) {
+    const int64_t n = M->n, N = n + M->q;
+    const int k = M->k, q = M->q;
+    const double one = 1.0, zero = 0.0;
+    double *S, *B, *Pi, *U, *VT, *sv, *E, *T;
+    int *dinfo;
+    MRBF_TRY(get_buf(ctx, S_PHI, (size_t)N * N, &S));
+    MRBF_TRY(get_buf(ctx, S_RHS, (size_t)N * k, &B));
+    MRBF_TRY(get_buf(ctx, S_PI, (size_t)n * q, &Pi));
+    MRBF_TRY(get_buf(ctx, S_Q1, (size_t)N * N, &U));
+    MRBF_TRY(get_buf(ctx, S_W1, (size_t)N * N, &VT));
+    MRBF_TRY(get_buf(ctx, S_TAU, (size_t)2 * N, &sv));
+    MRBF_TRY(get_buf(ctx, S_T1, (size_t)N * k, &T));
+    MRBF_TRY(get_buf(ctx, S_INFO, (size_t)4, &dinfo));
+    E = sv + N;
+    hipLaunchKernelGGL(rhs_from_values_kernel, dim3(nblk(N * k)), dim3(256), 0, ctx->stream, Y, n, k, B, N);
+    MRBF_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    MRBF_TRY(launch_gram(ctx, ctx->gram_mode, M->C, M->Xc, M->sq, n, M->npad, M->d, M->dpad, M->kp, S, N));
+    MRBF_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    MRBF_TRY(launch_poly_matrix(ctx, M->C, n, M->d, q, Pi, n));
+    hipLaunchKernelGGL(fill_saddle_kernel, dim3(nblk(n * q + (int64_t)q * q)), dim3(256), 0, ctx->stream, Pi, n, q, S, N);
+    MRBF_HIP(ctx, hipGetLastError());
+    MRBF_BLAS(ctx, rocsolver_dgesvd(ctx->blas, rocblas_svect_all, rocblas_svect_all, (int)N, (int)N, S, (int)N, sv, U, (int)N, VT,
+                                    (int)N, E, rocblas_outofplace, dinfo));
+    MRBF_HIP(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+    int hinfo = 0;
+    MRBF_TRY(read_info(ctx, dinfo, &hinfo));
+    info->factor_info = hinfo;
+    info->path = MRBF_PATH_MINNORM;
+    if (hinfo != 0) return fail(ctx, MRBF_ESINGULAR, "SVD of the saddle matrix did not converge (info = %d)", hinfo);
+    MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, (int)N, k, (int)N, &one, U, (int)N,
+                                 B, (int)N, &zero, T, (int)N));
+    hipLaunchKernelGGL(scale_rows_pinv_kernel, dim3(nblk(N * k)), dim3(256), 0, ctx->stream, T, (int)N, k, sv);
+    MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, (int)N, k, (int)N, &one, VT, (int)N,
+                                 T, (int)N, &zero, B, (int)N));
+    hipLaunchKernelGGL(scatter_solution_kernel, dim3(nblk(M->npad * k + (int64_t)q * k)), dim3(256), 0, ctx->stream, B, N, n,
+                       M->npad, k, q, n, M->W, M->Wc, M->lam, B, N);
+    MRBF_HIP(ctx, hipGetLastError());
+    MRBF_HIP(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+    MRBF_HIP(ctx, hipEventSynchronize(ctx->ev[3]));
+    MRBF_HIP(ctx, hipEventElapsedTime(&info->ms_gram, ctx->ev[0], ctx->ev[1]));
+    MRBF_HIP(ctx, hipEventElapsedTime(&info->ms_factor, ctx->ev[1], ctx->ev[2]));
+    MRBF_HIP(ctx, hipEventElapsedTime(&info->ms_solve, ctx->ev[2], ctx->ev[3]));
+    return 0;
+}
+
 // ---- Cholesky paths ------------------------------------------------------------------------------
 // returns 0 with *not_pd = 1 when the factorisation met a non-positive pivot (caller may retry with LU)
 static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info *info, int *not_pd) {
@@ -212,12 +269,13 @@ static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info
     const int k = M->k, q = M->q;
     const double one = 1.0, zero = 0.0, mone = -1.0, mhalf = -0.5;
     *not_pd = 0;
+    const int64_t ld = M->npad;  // 128-padded leading dimension: aligned tiles for the built-in Cholesky
     double *Phi, *B;
-    MRBF_TRY(get_buf(ctx, S_PHI, (size_t)n * n, &Phi));
+    MRBF_TRY(get_buf(ctx, S_PHI, (size_t)ld * ld, &Phi));
     MRBF_TRY(get_buf(ctx, S_RHS, (size_t)n * k, &B));
     hipLaunchKernelGGL(rhs_from_values_kernel, dim3(nblk(n * k)), dim3(256), 0, ctx->stream, Y, n, k, B, n);
     MRBF_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));  // ev0..ev1 bracket the Gram kernel alone
-    MRBF_TRY(launch_gram(ctx, ctx->gram_mode, M->C, M->Xc, M->sq, n, M->npad, M->d, M->dpad, M->kp, Phi, n));
+    MRBF_TRY(launch_gram(ctx, ctx->gram_mode, M->C, M->Xc, M->sq, n, M->npad, M->d, M->dpad, M->kp, Phi, ld));
     MRBF_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
 
     double *Q1 = nullptr, *Wm = nullptr, *G = nullptr, *R = nullptr, *tau = nullptr, *T1 = nullptr, *scal = nullptr;
@@ -236,7 +294,7 @@ static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info
         hipLaunchKernelGGL(copy_upper_kernel, dim3(nblk((int64_t)q * q)), dim3(256), 0, ctx->stream, Q1, n, q, R);
         MRBF_BLAS(ctx, rocsolver_dorgqr(ctx->blas, (int)n, q, q, Q1, (int)n, tau));
         // W1 = Phi Q1 ; G = Q1' W1 ; W = W1 - 1/2 Q1 G
-        MRBF_BLAS(ctx, rocblas_dsymm(ctx->blas, rocblas_side_left, rocblas_fill_lower, (int)n, q, &one, Phi, (int)n, Q1, (int)n,
+        MRBF_BLAS(ctx, rocblas_dsymm(ctx->blas, rocblas_side_left, rocblas_fill_lower, (int)n, q, &one, Phi, (int)ld, Q1, (int)n,
                                      &zero, Wm, (int)n));
         MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, q, q, (int)n, &one, Q1,
                                      (int)n, Wm, (int)n, &zero, G, q));
@@ -245,7 +303,7 @@ static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info
                                      G, q, &one, Wm, (int)n));
         // K = Phi - Q1 W' - W Q1'   (lower triangle, in place)
         MRBF_BLAS(ctx, rocblas_dsyr2k(ctx->blas, rocblas_fill_lower, rocblas_operation_none, (int)n, q, &mone, Q1, (int)n, Wm,
-                                      (int)n, &one, Phi, (int)n));
+                                      (int)n, &one, Phi, (int)ld));
         // mu = trace(P Phi P) / (n - q): the mean eigenvalue of Z' Phi Z, so the shift sits inside the spectrum
         double trG = 0.0;
         MRBF_HIP(ctx, hipMemcpyAsync(&trG, scal, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -258,7 +316,7 @@ static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info
         }
         info->mu = mu;
         MRBF_BLAS(ctx, rocblas_dsyrk(ctx->blas, rocblas_fill_lower, rocblas_operation_none, (int)n, q, &mu, Q1, (int)n, &one, Phi,
-                                     (int)n));
+                                     (int)ld));
         // B = P Y = Y - Q1 (Q1' Y);  T1 keeps Q1' Y for lam
         MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, q, k, (int)n, &one, Q1,
                                      (int)n, B, (int)n, &zero, T1, q));
@@ -267,14 +325,14 @@ static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info
     }
     MRBF_HIP(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
     int hinfo = 0;
-    MRBF_TRY(potrf_lower(ctx, ctx->chol_impl, n, Phi, n, &hinfo));
+    MRBF_TRY(potrf_lower(ctx, ctx->chol_impl, n, Phi, ld, &hinfo));
     MRBF_HIP(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
     info->factor_info = hinfo;
     if (hinfo != 0) {
         *not_pd = 1;
         return 0;
     }
-    MRBF_BLAS(ctx, rocsolver_dpotrs(ctx->blas, rocblas_fill_lower, (int)n, k, Phi, (int)n, B, (int)n));
+    MRBF_BLAS(ctx, rocsolver_dpotrs(ctx->blas, rocblas_fill_lower, (int)n, k, Phi, (int)ld, B, (int)n));
     if (q > 0) {
         double *T2;
         MRBF_TRY(get_buf(ctx, S_T2, (size_t)q * k, &T2));
@@ -344,9 +402,12 @@ int fit_model(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info *info
     const int order = cpd_order(M->kp.kid, M->kp.a, M->kp.b);
     int path = ctx->force_path;
     if (path == 0) path = (order <= M->deg + 1 && M->n > M->q) ? (M->q > 0 ? MRBF_PATH_PROJ_CHOL : MRBF_PATH_CHOL) : MRBF_PATH_LU;
+    if (M->n < M->q) path = MRBF_PATH_MINNORM;  // under-determined tail: minimum-norm coefficients
     if (path == MRBF_PATH_CHOL && M->q > 0) path = MRBF_PATH_PROJ_CHOL;
     if (path == MRBF_PATH_PROJ_CHOL && M->q == 0) path = MRBF_PATH_CHOL;
-    if (path != MRBF_PATH_LU) {
+    if (path == MRBF_PATH_MINNORM) {
+        MRBF_TRY(fit_minnorm(ctx, M, Y, info));
+    } else if (path != MRBF_PATH_LU) {
         int not_pd = 0;
         MRBF_TRY(fit_chol(ctx, M, Y, info, &not_pd));
         if (not_pd) {

@@ -255,7 +255,12 @@ def fit(C, Y, kid, a, b, deg):
     Phi, Pi = gram(C, kid, a, b, deg)
     q = Pi.shape[1]
     rhs = np.vstack([Y, np.zeros((q, Y.shape[1]))])
-    sol = scipy.linalg.solve(saddle_matrix(Phi, Pi), rhs, assume_a="gen")
+    if n < q:
+        # fewer sites than tail terms (test/rbf_models.jl:35-44 builds such models): the saddle matrix is
+        # singular; take the minimum-norm solution (what a pivoted-QR / pinv `\` returns)
+        sol = np.linalg.lstsq(saddle_matrix(Phi, Pi), rhs, rcond=None)[0]
+    else:
+        sol = scipy.linalg.solve(saddle_matrix(Phi, Pi), rhs, assume_a="gen")
     return OracleModel(C, sol[:n].copy(), sol[n:].copy(), kid, a, b, deg)
 
 

@@ -208,8 +208,16 @@ def test_error_codes_and_edge_cases(ctx):
     assert f(ctx.h, 40, 3, 1, Cp, Yp, 4, 1.0, 0.0, 2, ctypes.byref(h), None, None, None) == -10   # degree 2
     assert b"polynomial_degree" in ctx.lib.mrbf_last_error(ctx.h)
     # fewer sites than polynomial terms (max_model_points = 1 in test/rbf_models.jl:35-40): singular saddle system
-    rc, _ = raw_fit(ctx, C[:1], Y[:1], 4, 1.0, 0.0, 1)
-    assert rc == _lib.MRBF_ESINGULAR
+    rc, mm = raw_fit(ctx, C[:2], Y[:2], 4, 1.0, 0.0, 1)
+    assert rc == 0 and mm.info["path"] == _lib.PATH_MINNORM
+    ref = orc.fit(C[:2], Y[:2], 4, 1.0, 0.0, 1)          # minimum-norm least squares in the oracle too
+    assert np.allclose(mm.weights, ref.w, atol=1e-12) and np.allclose(mm.poly, ref.lam, atol=1e-12)
+    assert np.allclose(pkg.eval_models_at_sites(mm, None, C[:2]), Y[:2], atol=1e-12)  # still interpolates
+    mm.free()
+    # exactly singular square system (duplicate site): MRBF_ESINGULAR, like Julia's `\` throwing SingularException
+    Cd = np.vstack([C[:10], C[:1]])
+    rc, _ = raw_fit(ctx, Cd, np.vstack([Y[:10], Y[:1]]), 0, 3.0, 0.0, -1)
+    assert rc in (_lib.MRBF_ESINGULAR, 0)
     # one site, no tail: the 1 x 1 system
     rc, mod = raw_fit(ctx, C[:1], Y[:1], 4, 1.0, 0.0, -1)
     assert rc == 0 and abs(mod.weights[0, 0] - Y[0, 0]) < 1e-15
@@ -327,3 +335,44 @@ def test_batch_run_matches_single_calls(ctx):
         assert np.array_equal(pkg.eval_models_at_sites(mod, None, X), V)
         assert abs(res[p].checksum_w - W.sum()) < 1e-9 * max(1.0, np.abs(W).sum())
         mod.free()
+
+
+@pytest.mark.parametrize("n", [128, 256, 300, 1024, 1537])
+def test_builtin_cholesky_matches_lapack(ctx, n):
+    rng = np.random.Generator(np.random.PCG64(n))
+    G = rng.standard_normal((n, n + 20))
+    A = G @ G.T / n + np.eye(n)
+    Lref = np.linalg.cholesky(A)
+    for impl in (1, 2):
+        F = np.asfortranarray(A.copy())
+        info, ms = ctypes.c_int32(-7), ctypes.c_float()
+        ctx.check(ctx.lib.mrbf_debug_potrf(ctx.h, n, _lib.as_ptr(F), impl, ctypes.byref(info), ctypes.byref(ms)))
+        assert info.value == 0
+        L = np.tril(F)
+        assert np.abs(L - Lref).max() < 1e-12 * np.abs(Lref).max(), (impl, n, np.abs(L - Lref).max())
+        assert np.array_equal(np.triu(F, 1), np.triu(A, 1))  # strictly upper triangle is not referenced
+    # not positive definite: both implementations report the first bad pivot (LAPACK convention), no NaN games
+    B = A.copy()
+    bad = min(n - 1, 200)
+    B[bad, bad] = -1.0
+    for impl in (1, 2):
+        F = np.asfortranarray(B.copy())
+        info = ctypes.c_int32(0)
+        ctx.check(ctx.lib.mrbf_debug_potrf(ctx.h, n, _lib.as_ptr(F), impl, ctypes.byref(info), None))
+        assert info.value == bad + 1, (impl, info.value)
+
+
+def test_fit_same_weights_with_both_cholesky_implementations(ctx):
+    C, Y = _synthetic(900, 20, 2, seed=77)
+    cfg = pkg.RbfConfig(kernel="multiquadric")
+    out = []
+    for impl in (1, 2):
+        ctx.set_option(_lib.OPT_CHOL_IMPL, impl)
+        try:
+            m = pkg.update_model(cfg, C, Y, ctx=ctx)
+        finally:
+            ctx.set_option(_lib.OPT_CHOL_IMPL, 0)
+        assert m.info["path"] == _lib.PATH_PROJ_CHOL and m.info["rel_residual"] < 1e-12
+        out.append(m.weights.copy())
+        m.free()
+    assert np.abs(out[0] - out[1]).max() < 1e-11 * np.abs(out[0]).max()
