@@ -178,6 +178,13 @@ int32_t mrbf_batch_run(int32_t n_dev, const int32_t *device_ids, int64_t n_probl
 /* debug / test hooks (exported so the parity tests can pin kernel-level behaviour) */
 int32_t mrbf_debug_mfma_layout(mrbf_ctx *ctx, double *out16x16_a_times_b, const double *A16x4, const double *B4x16);
 int32_t mrbf_debug_potrf(mrbf_ctx *ctx, int64_t n, double *A_colmajor_inout, int32_t impl, int32_t *info, float *ms);
+int32_t mrbf_debug_diag(mrbf_ctx *ctx, const double *A128, int32_t reps, float *ms_per_call, double *shader_cycles,
+                        double *realtime_us);
+/* micro-benchmarks (tools/microbench.py): sustained f64 MFMA issue rate and the rocBLAS dgemm reference */
+int32_t mrbf_debug_mfma_peak(mrbf_ctx *ctx, int32_t blocks_per_cu, int32_t threads, int32_t iters, float *ms, double *tflops);
+int32_t mrbf_debug_mfma_asm(mrbf_ctx *ctx, int32_t variant, int32_t blocks_per_cu, int32_t iters, float *ms, double *tflops,
+                            double *cycles_per_mfma);
+int32_t mrbf_debug_dgemm(mrbf_ctx *ctx, int32_t m, int32_t n, int32_t k, float *ms, double *tflops);
 
 #ifdef __cplusplus
 }

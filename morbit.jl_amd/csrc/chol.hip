@@ -6,6 +6,7 @@
 namespace mrbf {
 
 int potrf_blocked(mrbf_ctx *ctx, int64_t n, double *A, int64_t lda, int *dinfo);  // chol_blocked.hip
+int debug_diag(mrbf_ctx *ctx, const double *A128_dev, int reps, float *ms_per_call, unsigned long long *stamps_host);
 int launch_pad_identity(mrbf_ctx *ctx, double *A, int64_t n, int64_t npad);        // chol_blocked.hip
 
 // A holds an n x n s.p.d. matrix in a buffer of leading dimension lda >= round_up(n, 128) whose rows/columns
@@ -55,5 +56,24 @@ extern "C" int32_t mrbf_debug_potrf(mrbf_ctx *ctx, int64_t n, double *A, int32_t
     MRBF_HIP(ctx, hipMemcpy2DAsync(A, (size_t)n * sizeof(double), dA, (size_t)npad * sizeof(double), (size_t)n * sizeof(double),
                                    (size_t)n, out, ctx->stream));
     MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MRBF_OK;
+}
+
+extern "C" int32_t mrbf_debug_diag(mrbf_ctx *ctx, const double *A128, int32_t reps, float *ms_per_call, double *shader_cycles,
+                                   double *realtime_us) {
+    if (!ctx) return -1;
+    if (!A128) return -2;
+    (void)hipSetDevice(ctx->device);
+    const double *dA;
+    MRBF_TRY(stage_in(ctx, S_STAGE_A, A128, 128 * 128, &dA));
+    unsigned long long st[6] = {0, 0, 0, 0, 0, 0};
+    float ms = 0;
+    MRBF_TRY(debug_diag(ctx, dA, reps, &ms, st));
+    if (ms_per_call) *ms_per_call = ms;
+    if (shader_cycles) *shader_cycles = (double)st[0];
+    if (realtime_us) *realtime_us = (double)st[1] / 100.0;
+    if (getenv("MRBF_DIAG_VERBOSE"))
+        fprintf(stderr, "diag segments (cycles over 128 columns, wave 0): barrier %llu read %llu critical %llu rest %llu\n", st[2], st[3],
+                st[4], st[5]);
     return MRBF_OK;
 }

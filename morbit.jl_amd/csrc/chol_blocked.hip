@@ -106,9 +106,20 @@ __global__ __launch_bounds__(256, 2) void chol_update_kernel(const double *__res
                 for (int i = 0; i < 4; ++i) acc[j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[j], a[i], acc[j][i], 0, 0, 0);
         }
     }
-    // epilogue (f64 C/D map: col = lane & 15 -> i, row = (lane >> 4) + 4 r -> j)
+    // epilogue (f64 C/D map: col = lane & 15 -> i, row = (lane >> 4) + 4 r -> j).  The read-modify-write is done in
+    // batches of 16 values (all loads of a batch issued before its first store): element-wise `*dst -= acc` makes the
+    // compiler serialise 64 dependent load -> store round trips, because it cannot prove the addresses distinct.
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
+    for (int j = 0; j < NJ; ++j) {
+        double cv[4][4];
+        if (MODE != UPD_OVERWRITE) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t gj = J0 + joff + j * 16 + l4 + 4 * r;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) cv[r][i] = C[(I0 + ioff + i * 16 + l15) + gj * ldc];
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int64_t gj = J0 + joff + j * 16 + l4 + 4 * r;
@@ -119,125 +130,235 @@ __global__ __launch_bounds__(256, 2) void chol_update_kernel(const double *__res
                 if (MODE == UPD_OVERWRITE) {
                     *dst = acc[j][i][r];
                 } else if (MODE == UPD_FULL_SUB) {
-                    *dst -= acc[j][i][r];
+                    *dst = cv[r][i] - acc[j][i][r];
                 } else {
-                    if (ti != tj || gi >= gj) *dst -= acc[j][i][r];
+                    if (ti != tj || gi >= gj) *dst = cv[r][i] - acc[j][i][r];
                 }
             }
         }
+    }
 }
 
-// ---- D: Cholesky of one 128 x 128 diagonal block + inverse of its factor ---------------------------------
-// 256 threads as a 16 x 16 grid; thread (ti, tj) keeps A[ti + 16u][tj + 16v], u, v = 0..7, in registers.
-// Right-looking: at column k its 16 owner threads scale the column (1/sqrt of the pivot, broadcast inside
-// their 16-lane group) and publish it through a double-buffered LDS vector; one barrier per column; every
-// thread then applies the rank-1 update to the part of its 8 x 8 register block that lies in the trailing
-// lower triangle.  The 8 phases (k / 16) are separate template instantiations so register indices stay
-// static and finished column blocks drop out of the update.
-struct DiagShared {
-    double Ls[CNB * (CNB + 1)];  // factor, column-major, ld 129 (read by the inverse sweep)
-    double colb[2][CNB];
-    double rdiag[CNB];
+// ---- D: Cholesky of one 128 x 128 diagonal block + inverse of its factor, ONE sweep -------------------------
+// The block is augmented with an identity below it, [A; I] (256 x 128): the right-looking elimination that
+// turns A into L turns the identity rows into I * L^-T, i.e. the inverse comes out of the same 128 column
+// steps (no second sweep).  512 threads: threads 0..255 (half 0) hold A as a 16 x 16 thread grid with an
+// 8 x 8 register block each (thread (ti, tj): rows ti + 16u, columns tj + 16v); threads 256..511 (half 1)
+// hold the identity rows the same way.  Per column k: its owner threads publish the scaled column (half 0)
+// / the unscaled column (half 1) and 1/l_kk through a double-buffered LDS vector, ONE barrier, then every
+// thread applies the rank-1 update to the live part of its register block.  1/sqrt(pivot) is v_rsq_f64 +
+// Newton steps (a correctly rounded sqrt and divide would put ~500 cycles on the critical path per column).
+// The 8 phases (k / 16) are separate template instantiations so register indices stay static.
+struct __attribute__((aligned(16))) DiagShared {
+    double col[2][2 * CNB];  // [buf][0..127] scaled column of L, [128..255] unscaled column of the identity rows
+    double rinv[2];
     int sbad;
+    unsigned long long seg[4];  // diagnostic launches only: cycles of wave 0 in barrier / read / critical / rest
+    int stamp;
 };
 
-template <int KV>
-__device__ __forceinline__ void chol_phase(double (&a)[8][8], DiagShared &sh, int ti, int tj, int &buf, int &bad) {
+__device__ __forceinline__ double fast_rsqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    const double h = 0.5 * x;
+#pragma unroll
+    for (int it = 0; it < 3; ++it) y = y * fma(-h, y * y, 1.5);
+    return y;
+}
+
+// One phase = 16 columns.  On entry column k = 16 KV of L (scaled), the matching unscaled column of the
+// identity rows and 1/l_kk are already published in sh.col[buf] / sh.rinv[buf].  Each iteration: barrier,
+// read the published column, FIRST bring the next column (k+1) up to date, scale and publish it (the
+// critical path: pivot copy -> rsqrt -> scale -> LDS), THEN apply the rest of the rank-1 update of column k,
+// so that work overlaps the other waves' path to the next barrier.  Every thread keeps a private copy `piv`
+// of its group's pivot a[j][j], j = tj + 16 KV, updated with the same fma as the real entry, so no
+// cross-lane traffic sits on the critical path inside a phase.
+template <int KV, bool STAMP>
+__device__ __forceinline__ void diag_phase(double (&a)[8][8], DiagShared &sh, int ti, int tj, int half, int &buf, int &bad) {
+    constexpr int KN = (KV < 7) ? KV + 1 : 7;  // register column block of the first column of the next phase
+    double piv = 0.0;
+    if (half == 0) piv = __shfl(a[KV][KV], tj, 16);  // true value lives in lane (ti == tj) of this 16-lane group
 #pragma unroll 1
     for (int kk = 0; kk < 16; ++kk) {
         const int k = KV * 16 + kk;
-        // the pivot lives in lane (ti == kk) of the owner group (tj == kk), register a[KV][KV]
-        const double piv = __shfl(a[KV][KV], kk, 16);
-        if (tj == kk) {
-            double rinv = 0.0;
-            if (piv > 0.0) {
-                rinv = 1.0 / sqrt(piv);
-            } else if (bad == 0) {
-                bad = k + 1;
-            }
-            if (ti == 0) sh.rdiag[k] = rinv;
+        const bool st = STAMP && threadIdx.x < 64;
+        unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        if (st) s0 = __builtin_amdgcn_s_memtime();
+        __syncthreads();  // column k, the identity rows' column k and rinv_k are visible
+        if (st) s1 = __builtin_amdgcn_s_memtime();
+        double lj[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = ti + 16 * u;
-                double val = 0.0;
-                if (i >= k) {
-                    val = a[u][KV] * rinv;
-                    a[u][KV] = val;
+        for (int v = KV; v < 8; ++v) lj[v] = sh.col[buf][tj + 16 * v];
+        if (half == 0) {
+            double li[8];
+#pragma unroll
+            for (int u = KV; u < 8; ++u) li[u] = sh.col[buf][ti + 16 * u];
+            if (st) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                s2 = __builtin_amdgcn_s_memtime();
+            }
+            // ---- critical path: next column kn = k + 1
+            if (kk < 15) {
+                if (tj > kk) piv = fma(-lj[KV], lj[KV], piv);  // groups whose column of this phase is still ahead
+                if (tj == kk + 1) {
+                    const int kn = k + 1;
+                    double rinv = 0.0;
+                    if (piv > 0.0) {
+                        rinv = fast_rsqrt(piv);
+                    } else if (bad == 0) {
+                        bad = kn + 1;
+                    }
+                    if (ti == 0) sh.rinv[buf ^ 1] = rinv;
+                    double w[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int i = ti + 16 * u;
+                        double val = 0.0;
+                        if (u >= KV && i >= kn) {
+                            val = fma(-li[u], lj[KV], a[u][KV]) * rinv;
+                            a[u][KV] = val;
+                        }
+                        w[u] = val;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) sh.col[buf ^ 1][ti + 16 * u] = w[u];
                 }
-                sh.colb[buf][i] = val;
+            } else if (KV < 7) {
+                // last column of the phase: the next column opens phase KV + 1, owner group tj == 0,
+                // pivot a[kn][kn] in lane ti == 0 of that group, register a[KN][KN]
+                if (tj == 0) {
+                    const int kn = k + 1;
+                    const double pv = __shfl(fma(-li[KN], lj[KN], a[KN][KN]), 0, 16);
+                    double rinv = 0.0;
+                    if (pv > 0.0) {
+                        rinv = fast_rsqrt(pv);
+                    } else if (bad == 0) {
+                        bad = kn + 1;
+                    }
+                    if (ti == 0) sh.rinv[buf ^ 1] = rinv;
+                    double w[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        double val = 0.0;
+                        if (u >= KN) {  // i >= kn = 16 KN always holds here
+                            val = fma(-li[u], lj[KN], a[u][KN]) * rinv;
+                            a[u][KN] = val;
+                        }
+                        w[u] = val;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) sh.col[buf ^ 1][ti + 16 * u] = w[u];
+                }
             }
-        }
-        __syncthreads();
-        double li[8], lj[8];
+            if (st) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                s3 = __builtin_amdgcn_s_memtime();
+            }
+            // ---- rest of the rank-1 update of column k (the next column's entries were done above by its owners).
+            // Unconditional FMAs with masked operands: only the diagonal register blocks (u == v) need i >= j,
+            // which is the per-thread constant ti >= tj, and only the v == KV block needs j > k (tj > kk).
+            const bool own_next = (kk < 15) ? (tj == kk + 1) : (KV < 7 && tj == 0);
+            const bool lowtri = ti >= tj;
 #pragma unroll
-        for (int u = KV; u < 8; ++u) li[u] = sh.colb[buf][ti + 16 * u];
+            for (int v = KV; v < 8; ++v) {
+                double ljv = lj[v];
+                if (v == KV) ljv = (tj > kk && !(own_next && kk < 15)) ? ljv : 0.0;
+                if (v == KN && KV < 7) ljv = (own_next && kk == 15) ? 0.0 : ljv;
+                a[v][v] = fma(lowtri ? -li[v] : 0.0, ljv, a[v][v]);
 #pragma unroll
-        for (int v = KV; v < 8; ++v) lj[v] = sh.colb[buf][tj + 16 * v];
+                for (int u = v + 1; u < 8; ++u) a[u][v] = fma(-li[u], ljv, a[u][v]);
+            }
+            if (st && threadIdx.x == 0) {
+                asm volatile("" ::"v"(a[7][7]));
+                const unsigned long long s4 = __builtin_amdgcn_s_memtime();
+                sh.seg[0] += s1 - s0;
+                sh.seg[1] += s2 - s1;
+                sh.seg[2] += s3 - s2;
+                sh.seg[3] += s4 - s3;
+            }
+        } else {
+            // identity rows r = ti + 16u: e[r][k] *= rinv_k; e[r][j] -= e[r][k] l_jk (j > k); rows r > k are still zero
+            const double rinv = sh.rinv[buf];
+            const double ljk = (tj > kk) ? lj[KV] : 0.0;  // j > k matters for the v == KV block only
 #pragma unroll
-        for (int v = KV; v < 8; ++v) {
-            const int j = tj + 16 * v;
+            for (int u = 0; u <= KV; ++u) {
+                const double erk = sh.col[buf][CNB + ti + 16 * u] * rinv;
+                if (tj == kk) a[u][KV] = erk;
+                a[u][KV] = fma(-erk, ljk, a[u][KV]);
 #pragma unroll
-            for (int u = v; u < 8; ++u) {  // i >= j needs u >= v
-                const int i = ti + 16 * u;
-                if (j > k && i >= j) a[u][v] = fma(-li[u], lj[v], a[u][v]);
+                for (int v = KV + 1; v < 8; ++v) a[u][v] = fma(-erk, lj[v], a[u][v]);
+            }
+            // publish the (unscaled) next column of these rows for the next iteration
+            if (kk < 15) {
+                if (tj == kk + 1) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) sh.col[buf ^ 1][CNB + ti + 16 * u] = (u <= KV) ? a[u][KV] : 0.0;
+                }
+            } else if (KV < 7) {
+                if (tj == 0) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) sh.col[buf ^ 1][CNB + ti + 16 * u] = (u <= KN) ? a[u][KN] : 0.0;
+                }
             }
         }
         buf ^= 1;
     }
 }
 
-// X = L^-1 by a right-looking sweep over rows: x[k][:] /= L[k][k]; x[i][:] -= L[i][k] x[k][:] for i > k
-template <int KU>
-__device__ __forceinline__ void inv_phase(double (&x)[8][8], DiagShared &sh, int ti, int tj, int &buf) {
-#pragma unroll 1
-    for (int kk = 0; kk < 16; ++kk) {
-        const int k = KU * 16 + kk;
-        if (ti == kk) {  // owners of row k: one lane per 16-lane group, every tj
-            const double rinv = sh.rdiag[k];
-#pragma unroll
-            for (int v = 0; v <= KU; ++v) {
-                const double val = x[KU][v] * rinv;
-                x[KU][v] = val;
-                sh.colb[buf][tj + 16 * v] = val;
-            }
-        }
-        __syncthreads();
-        double xr[8];
-#pragma unroll
-        for (int v = 0; v <= KU; ++v) xr[v] = sh.colb[buf][tj + 16 * v];
-#pragma unroll
-        for (int u = KU; u < 8; ++u) {
-            const int i = ti + 16 * u;
-            const double lik = (i > k) ? sh.Ls[i + k * (CNB + 1)] : 0.0;
-#pragma unroll
-            for (int v = 0; v <= KU; ++v) x[u][v] = fma(-lik, xr[v], x[u][v]);  // xr is 0 for columns j > k
-        }
-        buf ^= 1;
-    }
-}
-
-__global__ __launch_bounds__(256, 1) void chol_diag_kernel(double *__restrict__ A, int64_t lda, double *__restrict__ Linv,
-                                                        int *__restrict__ info, int col0) {
+template <bool STAMP>
+__global__ __launch_bounds__(512) void chol_diag_kernel(double *__restrict__ A, int64_t lda, double *__restrict__ Linv,
+                                                        int *__restrict__ info, int col0,
+                                                        unsigned long long *__restrict__ stamps) {
     __shared__ DiagShared sh;
     if (*info != 0) return;
-    const int tid = threadIdx.x, ti = tid & 15, tj = tid >> 4;
+    unsigned long long t0 = 0, r0 = 0;
+    if (STAMP) {
+        if (threadIdx.x == 0) sh.seg[0] = sh.seg[1] = sh.seg[2] = sh.seg[3] = 0;
+        __syncthreads();  // diagnostic launches only (mrbf_debug_diag): shader-clock and 100 MHz real-time stamps
+        t0 = __builtin_amdgcn_s_memtime();
+        r0 = __builtin_amdgcn_s_memrealtime();
+    }
+    const int tid = threadIdx.x, ti = tid & 15, tj = (tid >> 4) & 15, half = tid >> 8;
     double a[8][8];
 #pragma unroll
     for (int v = 0; v < 8; ++v)
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int i = ti + 16 * u, j = tj + 16 * v;
-            a[u][v] = (i >= j) ? A[i + (int64_t)j * lda] : 0.0;
+            if (half == 0)
+                a[u][v] = (i >= j) ? A[i + (int64_t)j * lda] : 0.0;
+            else
+                a[u][v] = (i == j) ? 1.0 : 0.0;
         }
     int buf = 0, bad = 0;
-    chol_phase<0>(a, sh, ti, tj, buf, bad);
-    chol_phase<1>(a, sh, ti, tj, buf, bad);
-    chol_phase<2>(a, sh, ti, tj, buf, bad);
-    chol_phase<3>(a, sh, ti, tj, buf, bad);
-    chol_phase<4>(a, sh, ti, tj, buf, bad);
-    chol_phase<5>(a, sh, ti, tj, buf, bad);
-    chol_phase<6>(a, sh, ti, tj, buf, bad);
-    chol_phase<7>(a, sh, ti, tj, buf, bad);
+    // prologue: publish column 0 (owner group tj == 0, pivot in its lane ti == 0)
+    if (tj == 0) {
+        if (half == 0) {
+            const double pv = __shfl(a[0][0], 0, 16);
+            double rinv = 0.0;
+            if (pv > 0.0) {
+                rinv = fast_rsqrt(pv);
+            } else {
+                bad = 1;
+            }
+            if (ti == 0) sh.rinv[0] = rinv;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                a[u][0] *= rinv;
+                sh.col[0][ti + 16 * u] = a[u][0];
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sh.col[0][CNB + ti + 16 * u] = (u == 0) ? a[0][0] : 0.0;
+        }
+    }
+    diag_phase<0, STAMP>(a, sh, ti, tj, half, buf, bad);
+    diag_phase<1, STAMP>(a, sh, ti, tj, half, buf, bad);
+    diag_phase<2, STAMP>(a, sh, ti, tj, half, buf, bad);
+    diag_phase<3, STAMP>(a, sh, ti, tj, half, buf, bad);
+    diag_phase<4, STAMP>(a, sh, ti, tj, half, buf, bad);
+    diag_phase<5, STAMP>(a, sh, ti, tj, half, buf, bad);
+    diag_phase<6, STAMP>(a, sh, ti, tj, half, buf, bad);
+    diag_phase<7, STAMP>(a, sh, ti, tj, half, buf, bad);
     // non-positive pivot: report the 1-based global index of the first one (LAPACK potrf convention)
     if (tid == 0) sh.sbad = 0x7fffffff;
     __syncthreads();
@@ -247,36 +368,23 @@ __global__ __launch_bounds__(256, 1) void chol_diag_kernel(double *__restrict__ 
         if (tid == 0) *info = col0 + sh.sbad;
         return;
     }
-    // write the factor: global (lower part of the block) + LDS copy for the inverse sweep
 #pragma unroll
     for (int v = 0; v < 8; ++v)
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int i = ti + 16 * u, j = tj + 16 * v;
-            if (i >= j) A[i + (int64_t)j * lda] = a[u][v];
-            sh.Ls[i + j * (CNB + 1)] = (i >= j) ? a[u][v] : 0.0;
+            if (half == 0) {
+                if (i >= j) A[i + (int64_t)j * lda] = a[u][v];  // the factor, lower part of the block in place
+            } else {
+                // half 1 holds (L^-T)[r = i][j] = Linv[j][r]: lower-triangular inverse, column-major, zeros above
+                Linv[j + i * CNB] = (j >= i) ? a[u][v] : 0.0;
+            }
         }
-#pragma unroll
-    for (int v = 0; v < 8; ++v)
-#pragma unroll
-        for (int u = 0; u < 8; ++u) a[u][v] = (ti + 16 * u == tj + 16 * v) ? 1.0 : 0.0;
-    __syncthreads();
-    buf = 0;
-    inv_phase<0>(a, sh, ti, tj, buf);
-    inv_phase<1>(a, sh, ti, tj, buf);
-    inv_phase<2>(a, sh, ti, tj, buf);
-    inv_phase<3>(a, sh, ti, tj, buf);
-    inv_phase<4>(a, sh, ti, tj, buf);
-    inv_phase<5>(a, sh, ti, tj, buf);
-    inv_phase<6>(a, sh, ti, tj, buf);
-    inv_phase<7>(a, sh, ti, tj, buf);
-#pragma unroll
-    for (int v = 0; v < 8; ++v)
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = ti + 16 * u, j = tj + 16 * v;
-            Linv[i + j * CNB] = (i >= j) ? a[u][v] : 0.0;
-        }
+    if (STAMP && threadIdx.x == 0) {
+        stamps[0] = __builtin_amdgcn_s_memtime() - t0;
+        stamps[1] = __builtin_amdgcn_s_memrealtime() - r0;
+        for (int q = 0; q < 4; ++q) stamps[2 + q] = sh.seg[q];
+    }
 }
 
 // identity padding of rows/columns [n, npad) of an npad x npad column-major matrix (lower part is what matters)
@@ -297,6 +405,37 @@ int launch_pad_identity(mrbf_ctx *ctx, double *A, int64_t n, int64_t npad) {
     return 0;
 }
 
+// diagnostic: run the diagonal-block kernel `reps` times back to back on copies of one 128 x 128 s.p.d. block
+int debug_diag(mrbf_ctx *ctx, const double *A128_dev, int reps, float *ms_per_call, unsigned long long *stamps_host) {
+    const bool with_stamps = reps > 0;
+    if (reps < 0) reps = -reps;
+    double *W, *Linv;
+    int *dinfo;
+    unsigned long long *st;
+    MRBF_TRY(get_buf(ctx, S_PHI, (size_t)CNB * CNB * reps, &W));
+    MRBF_TRY(get_buf(ctx, S_CHOL_WS, (size_t)CNB * CNB, &Linv));
+    MRBF_TRY(get_buf(ctx, S_INFO, (size_t)4, &dinfo));
+    MRBF_TRY(get_buf(ctx, S_MISC, (size_t)8, (double **)&st));
+    for (int r = 0; r < reps; ++r)
+        MRBF_HIP(ctx, hipMemcpyAsync(W + (size_t)r * CNB * CNB, A128_dev, sizeof(double) * CNB * CNB, hipMemcpyDeviceToDevice, ctx->stream));
+    MRBF_HIP(ctx, hipMemsetAsync(dinfo, 0, sizeof(int), ctx->stream));
+    MRBF_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    for (int r = 0; r < reps; ++r)
+        if (with_stamps)
+            hipLaunchKernelGGL(chol_diag_kernel<true>, dim3(1), dim3(512), 0, ctx->stream, W + (size_t)r * CNB * CNB, (int64_t)CNB, Linv,
+                               dinfo, 0, st);
+        else
+            hipLaunchKernelGGL(chol_diag_kernel<false>, dim3(1), dim3(512), 0, ctx->stream, W + (size_t)r * CNB * CNB, (int64_t)CNB, Linv,
+                               dinfo, 0, (unsigned long long *)nullptr);
+    MRBF_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    MRBF_HIP(ctx, hipEventSynchronize(ctx->ev[1]));
+    float t;
+    MRBF_HIP(ctx, hipEventElapsedTime(&t, ctx->ev[0], ctx->ev[1]));
+    *ms_per_call = t / reps;
+    MRBF_HIP(ctx, hipMemcpy(stamps_host, st, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return 0;
+}
+
 // A: n x n with n % 128 == 0, lda % 2 == 0, 16-byte aligned.  dinfo: device int, set to 0 here.
 int potrf_blocked(mrbf_ctx *ctx, int64_t n, double *A, int64_t lda, int *dinfo) {
     if (n % CNB != 0 || (lda & 1) || (reinterpret_cast<uintptr_t>(A) & 15))
@@ -309,7 +448,8 @@ int potrf_blocked(mrbf_ctx *ctx, int64_t n, double *A, int64_t lda, int *dinfo) 
     for (int j = 0; j < nb; ++j) {
         const int64_t c = (int64_t)j * CNB;
         double *Ajj = A + c + c * lda;
-        hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, ctx->stream, Ajj, lda, Linv, dinfo, (int)c);
+        hipLaunchKernelGGL(chol_diag_kernel<false>, dim3(1), dim3(512), 0, ctx->stream, Ajj, lda, Linv, dinfo, (int)c,
+                           (unsigned long long *)nullptr);
         const int64_t m = n - c - CNB;
         if (m <= 0) break;
         double *A21 = A + (c + CNB) + c * lda;
