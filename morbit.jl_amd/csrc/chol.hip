@@ -7,7 +7,7 @@ namespace mrbf {
 
 int potrf_blocked(mrbf_ctx *ctx, int64_t n, double *A, int64_t lda, int *dinfo);  // chol_blocked.hip
 int debug_diag(mrbf_ctx *ctx, const double *A128_dev, int reps, float *ms_per_call, unsigned long long *stamps_host);
-int launch_pad_identity(mrbf_ctx *ctx, double *A, int64_t n, int64_t npad);        // chol_blocked.hip
+int launch_pad_identity(mrbf_ctx *ctx, double *A, int64_t n, int64_t npad, int64_t ld);  // chol_blocked.hip
 
 // A holds an n x n s.p.d. matrix in a buffer of leading dimension lda >= round_up(n, 128) whose rows/columns
 // [n, lda) belong to the caller too: the built-in factorisation pads them with the identity and works on
@@ -16,10 +16,10 @@ int potrf_lower(mrbf_ctx *ctx, int impl, int64_t n, double *A, int64_t lda, int 
     int *dinfo;
     MRBF_TRY(get_buf(ctx, S_INFO, (size_t)4, &dinfo));
     const int64_t npad = round_up(n, 128);
-    if (impl == 0) impl = (lda == npad) ? 2 : 1;
+    if (impl == 0) impl = (lda >= npad) ? 2 : 1;
     if (impl == 2) {
-        if (lda != npad) return fail(ctx, MRBF_EHIP, "built-in Cholesky needs lda == round_up(n,128)");
-        MRBF_TRY(launch_pad_identity(ctx, A, n, npad));
+        if (lda < npad) return fail(ctx, MRBF_EHIP, "built-in Cholesky needs lda >= round_up(n,128)");
+        MRBF_TRY(launch_pad_identity(ctx, A, n, npad, lda));
         MRBF_TRY(potrf_blocked(ctx, npad, A, lda, dinfo));
     } else {
         MRBF_BLAS(ctx, rocsolver_dpotrf(ctx->blas, rocblas_fill_lower, (int)n, A, (int)lda, dinfo));

@@ -387,20 +387,20 @@ __global__ __launch_bounds__(512) void chol_diag_kernel(double *__restrict__ A, 
     }
 }
 
-// identity padding of rows/columns [n, npad) of an npad x npad column-major matrix (lower part is what matters)
-__global__ void pad_identity_kernel(double *__restrict__ A, int64_t n, int64_t npad) {
+// identity padding of rows/columns [n, npad) of the leading npad x npad block of a column-major matrix (leading dim ld)
+__global__ void pad_identity_kernel(double *__restrict__ A, int64_t n, int64_t npad, int64_t ld) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t pw = npad - n;
     if (idx >= npad * pw) return;
-    const int64_t j = n + idx / npad, i = idx % npad;  // columns n..npad-1 (all rows)
-    A[i + j * npad] = (i == j) ? 1.0 : 0.0;
-    if (i < n) A[j + i * npad] = 0.0;  // mirrored rows n..npad-1 in columns < n
+    const int64_t j = n + idx / npad, i = idx % npad;  // columns n..npad-1 (rows 0..npad-1)
+    A[i + j * ld] = (i == j) ? 1.0 : 0.0;
+    if (i < n) A[j + i * ld] = 0.0;  // mirrored rows n..npad-1 in columns < n
 }
 
-int launch_pad_identity(mrbf_ctx *ctx, double *A, int64_t n, int64_t npad) {
+int launch_pad_identity(mrbf_ctx *ctx, double *A, int64_t n, int64_t npad, int64_t ld) {
     if (npad == n) return 0;
     const int64_t cnt = npad * (npad - n);
-    hipLaunchKernelGGL(pad_identity_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, A, n, npad);
+    hipLaunchKernelGGL(pad_identity_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, A, n, npad, ld);
     MRBF_HIP(ctx, hipGetLastError());
     return 0;
 }
@@ -436,31 +436,152 @@ int debug_diag(mrbf_ctx *ctx, const double *A128_dev, int reps, float *ms_per_ca
     return 0;
 }
 
-// A: n x n with n % 128 == 0, lda % 2 == 0, 16-byte aligned.  dinfo: device int, set to 0 here.
-int potrf_blocked(mrbf_ctx *ctx, int64_t n, double *A, int64_t lda, int *dinfo) {
-    if (n % CNB != 0 || (lda & 1) || (reinterpret_cast<uintptr_t>(A) & 15))
-        return fail(ctx, MRBF_EHIP, "potrf_blocked needs a 128-padded, 16-byte aligned matrix (n=%lld lda=%lld)", (long long)n,
-                    (long long)lda);
-    double *Linv;
-    MRBF_TRY(get_buf(ctx, S_CHOL_WS, (size_t)CNB * CNB, &Linv));
+// C(lower tile pairs of an nt x nt tile grid) -= A B'  with K a multiple of 16 (the projection's rank-2q update
+// of Phi reuses the trailing-update kernel)
+int launch_update_lower(mrbf_ctx *ctx, const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc, int64_t nt,
+                        int K) {
+    if (nt <= 0 || K <= 0) return 0;
+    hipLaunchKernelGGL((chol_update_kernel<128, UPD_LOWER_SUB>), dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256), 0, ctx->stream, A,
+                       lda, B, ldb, C, ldc, K, (const int *)nullptr);
+    MRBF_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+// Blocked right-looking Cholesky of the leading ncols x ncols block of a TALL matrix (mrows >= ncols, both
+// multiples of 128, lda even, 16-byte aligned): on return the top square holds L and the rows below hold
+// A_below * L^-T.  Appending right-hand sides as extra ROWS therefore yields the forward substitution
+// L^-1 b for free, and appending a tall matrix X below its Gram matrix X'X yields the Q factor of X
+// (Cholesky-QR).  linv_all (optional) receives the 128 x 128 inverses of all diagonal blocks of L.
+int potrf_blocked_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int64_t lda, int *dinfo, double *linv_all) {
+    if (ncols % CNB != 0 || mrows % CNB != 0 || mrows < ncols || (lda & 1) || (reinterpret_cast<uintptr_t>(A) & 15))
+        return fail(ctx, MRBF_EHIP, "potrf_blocked needs 128-padded, 16-byte aligned storage (ncols=%lld mrows=%lld lda=%lld)",
+                    (long long)ncols, (long long)mrows, (long long)lda);
+    double *Lone = nullptr;
+    if (!linv_all) MRBF_TRY(get_buf(ctx, S_CHOL_WS, (size_t)CNB * CNB, &Lone));
     MRBF_HIP(ctx, hipMemsetAsync(dinfo, 0, sizeof(int), ctx->stream));
-    const int nb = (int)(n / CNB);
+    const int nb = (int)(ncols / CNB);
     for (int j = 0; j < nb; ++j) {
         const int64_t c = (int64_t)j * CNB;
         double *Ajj = A + c + c * lda;
+        double *Linv = linv_all ? linv_all + (size_t)j * CNB * CNB : Lone;
         hipLaunchKernelGGL(chol_diag_kernel<false>, dim3(1), dim3(512), 0, ctx->stream, Ajj, lda, Linv, dinfo, (int)c,
                            (unsigned long long *)nullptr);
-        const int64_t m = n - c - CNB;
+        const int64_t m = mrows - c - CNB;  // rows below the diagonal block
         if (m <= 0) break;
         double *A21 = A + (c + CNB) + c * lda;
         // T: A21 <- A21 * Linv'   (each workgroup owns full rows of the 128-wide panel: in place is safe)
         hipLaunchKernelGGL((chol_update_kernel<64, UPD_OVERWRITE>), dim3((unsigned)(m / 64), 1), dim3(256), 0, ctx->stream,
                            A21, lda, Linv, (int64_t)CNB, A21, lda, CNB, dinfo);
-        // U: A22 -= A21 A21'  on lower-triangular tile pairs
-        const int64_t mt = m / CNB;
-        double *A22 = A + (c + CNB) + (c + CNB) * lda;
-        hipLaunchKernelGGL((chol_update_kernel<128, UPD_LOWER_SUB>), dim3((unsigned)(mt * (mt + 1) / 2)), dim3(256), 0,
-                           ctx->stream, A21, lda, A21, lda, A22, lda, CNB, dinfo);
+        // U: trailing update.  Square part (rows and columns < ncols): lower-triangular tile pairs.
+        const int64_t mt = (ncols - c - CNB) / CNB;
+        if (mt > 0) {
+            double *A22 = A + (c + CNB) + (c + CNB) * lda;
+            hipLaunchKernelGGL((chol_update_kernel<128, UPD_LOWER_SUB>), dim3((unsigned)(mt * (mt + 1) / 2)), dim3(256), 0,
+                               ctx->stream, A21, lda, A21, lda, A22, lda, CNB, dinfo);
+            // rows below the square: full rectangle  A[ncols:, c+128:ncols] -= A[ncols:, c] A[c+128:ncols, c]'
+            const int64_t mx = (mrows - ncols) / CNB;
+            if (mx > 0) {
+                const double *Ax = A + ncols + c * lda;
+                double *Cx = A + ncols + (c + CNB) * lda;
+                hipLaunchKernelGGL((chol_update_kernel<128, UPD_FULL_SUB>), dim3((unsigned)mx, (unsigned)mt), dim3(256), 0,
+                                   ctx->stream, Ax, lda, A21, lda, Cx, lda, CNB, dinfo);
+            }
+        }
+    }
+    MRBF_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+int potrf_blocked(mrbf_ctx *ctx, int64_t n, double *A, int64_t lda, int *dinfo) {
+    return potrf_blocked_tall(ctx, n, n, A, lda, dinfo, nullptr);
+}
+
+// ---- backward substitution  L' x = y  for k right-hand sides, using the stored diagonal-block inverses ----------
+// Y: npad x k column-major (ld npad), overwritten by x.  Launch i (i = nb-1 .. 0) has i + 1 workgroups: workgroup
+// j < i applies  y_j -= L(i,j)' x_i ; workgroup j == i - 1 then finishes  x_{i-1} = Linv_{i-1}' y_{i-1}  (all later
+// updates of y_{i-1} were applied by earlier launches).  A prologue launch computes x_{nb-1}.
+// res[l][c] = sum_r T(r, c) x_l[r] for one 128 x 128 column-major tile: wave w takes columns 32w .. 32w+31, its lanes
+// span the rows (two coalesced 512-byte reads per column), wave-shuffle reduction per column.
+template <int KB>
+__device__ __forceinline__ void tile_tdot(const double *__restrict__ Tl, int64_t ldt, const double *xs /* LDS KB x 128 */,
+                                          double *res /* LDS KB x 128 */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double x0[KB], x1[KB];
+#pragma unroll
+    for (int l = 0; l < KB; ++l) {
+        x0[l] = xs[l * CNB + lane];
+        x1[l] = xs[l * CNB + 64 + lane];
+    }
+    for (int cc = 0; cc < 32; cc += 4) {
+        double t0[4], t1[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double *col = Tl + (int64_t)(wave * 32 + cc + q) * ldt;
+            t0[q] = col[lane];
+            t1[q] = col[64 + lane];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int l = 0; l < KB; ++l) {
+                double v = fma(t0[q], x0[l], t1[q] * x1[l]);
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+                if (lane == 0) res[l * CNB + wave * 32 + cc + q] = v;
+            }
+        }
+    }
+}
+
+template <int KB>
+__global__ __launch_bounds__(256) void chol_backsolve_kernel(const double *__restrict__ L, int64_t lda, const double *__restrict__ linv_all,
+                                                             double *__restrict__ Y, int64_t ldy, int k0, int i /* block row */,
+                                                             int prologue) {
+    __shared__ double xs[KB * CNB];
+    __shared__ double res[KB * CNB];
+    const int tid = threadIdx.x;
+    const int j = blockIdx.x;
+    if (!prologue) {
+        // x_i (already final) -> LDS
+        for (int t = tid; t < KB * CNB; t += 256) xs[t] = Y[(int64_t)(k0 + t / CNB) * ldy + (int64_t)i * CNB + (t % CNB)];
+        __syncthreads();
+        tile_tdot<KB>(L + (int64_t)i * CNB + (int64_t)j * CNB * lda, lda, xs, res);  // tile L(i, j)
+        __syncthreads();
+        for (int t = tid; t < KB * CNB; t += 256) {
+            double *yp = Y + (int64_t)(k0 + t / CNB) * ldy + (int64_t)j * CNB + (t % CNB);
+            const double v = *yp - res[t];
+            *yp = v;
+            xs[t] = v;  // y_j after this update, kept for the finishing step below
+        }
+        if (j != i - 1) return;
+        __syncthreads();
+    } else {
+        for (int t = tid; t < KB * CNB; t += 256) xs[t] = Y[(int64_t)(k0 + t / CNB) * ldy + (int64_t)i * CNB + (t % CNB)];
+        __syncthreads();
+    }
+    // finish block jb: x = Linv' y  (Linv lower triangular, zeros above the diagonal are stored)
+    const int jb = prologue ? i : i - 1;
+    tile_tdot<KB>(linv_all + (size_t)jb * CNB * CNB, CNB, xs, res);
+    __syncthreads();
+    for (int t = tid; t < KB * CNB; t += 256) Y[(int64_t)(k0 + t / CNB) * ldy + (int64_t)jb * CNB + (t % CNB)] = res[t];
+}
+
+int backsolve_blocked(mrbf_ctx *ctx, int64_t npad, const double *L, int64_t lda, const double *linv_all, double *Y, int64_t ldy, int k) {
+    const int nb = (int)(npad / CNB);
+    for (int k0 = 0; k0 < k; k0 += 4) {
+        const int kb = std::min(4, k - k0);
+#define MRBF_BS(KBV, grid, ii, pro)                                                                                         \
+    hipLaunchKernelGGL((chol_backsolve_kernel<KBV>), dim3((unsigned)(grid)), dim3(256), 0, ctx->stream, L, lda, linv_all, Y, ldy, \
+                       k0, ii, pro)
+        for (int i = nb - 1; i >= 0; --i) {
+            const bool pro = (i == nb - 1);
+            if (pro) {
+                if (kb == 1) MRBF_BS(1, 1, i, 1); else if (kb == 2) MRBF_BS(2, 1, i, 1); else if (kb == 3) MRBF_BS(3, 1, i, 1); else MRBF_BS(4, 1, i, 1);
+            }
+            if (i > 0) {
+                if (kb == 1) MRBF_BS(1, i, i, 0); else if (kb == 2) MRBF_BS(2, i, i, 0); else if (kb == 3) MRBF_BS(3, i, i, 0); else MRBF_BS(4, i, i, 0);
+            }
+        }
+#undef MRBF_BS
     }
     MRBF_HIP(ctx, hipGetLastError());
     return 0;

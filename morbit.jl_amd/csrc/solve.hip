@@ -263,91 +263,197 @@ static int fit_minnorm(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_i
 }
 
 // ---- Cholesky paths ------------------------------------------------------------------------------
-// returns 0 with *not_pd = 1 when the factorisation met a non-positive pivot (caller may retry with LU)
+int potrf_blocked_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int64_t lda, int *dinfo, double *linv_all);
+int backsolve_blocked(mrbf_ctx *ctx, int64_t npad, const double *L, int64_t lda, const double *linv_all, double *Y, int64_t ldy, int k);
+int launch_update_lower(mrbf_ctx *ctx, const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc, int64_t nt, int K);
+int launch_pad_identity(mrbf_ctx *ctx, double *A, int64_t n, int64_t npad, int64_t ld);
+
+// extra row tile(s) of the extended matrix: row npad + l = right-hand side l (a row), zero beyond k
+__global__ void set_rhs_rows_kernel(double *__restrict__ A, int64_t ld, int64_t npad, int xt, const double *__restrict__ B, int k) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= npad * xt) return;
+    const int l = (int)(idx % xt);
+    const int64_t i = idx / xt;
+    A[(npad + l) + i * ld] = (l < k) ? B[i + (int64_t)l * npad] : 0.0;
+}
+__global__ void get_rhs_rows_kernel(const double *__restrict__ A, int64_t ld, int64_t npad, double *__restrict__ B, int k) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= npad * k) return;
+    const int l = (int)(idx % k);
+    const int64_t i = idx / k;
+    B[i + (int64_t)l * npad] = A[(npad + l) + i * ld];
+}
+// Tall[(dq + i) + t*lt] = Xc[i*dpad + t]  (row-major centred coordinates -> column-major block below the Gram matrix)
+__global__ void xc_to_tall_kernel(const double *__restrict__ Xc, int64_t n, int d, int dpad, double *__restrict__ Tall, int64_t lt,
+                                  int64_t dq) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * d) return;
+    const int64_t i = idx / d;
+    const int t = (int)(idx % d);
+    Tall[(dq + i) + (int64_t)t * lt] = Xc[i * dpad + t];
+}
+// Q1 = [1/sqrt(n) | Qx]  (npad x q, ld npad, rows >= n zero)
+__global__ void build_q1_kernel(const double *__restrict__ Tall, int64_t lt, int64_t dq, int64_t n, int64_t npad, int q,
+                                double *__restrict__ Q1) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= npad * q) return;
+    const int64_t i = idx % npad;
+    const int t = (int)(idx / npad);
+    double v = 0.0;
+    if (i < n) v = (t == 0) ? 1.0 / sqrt((double)n) : Tall[(dq + i) + (int64_t)(t - 1) * lt];
+    Q1[idx] = v;
+}
+// PA = [Q1 | V | 0], PB = [V | Q1 | 0] with V = W - (mu/2) Q1   (npad x K2, ld npad)
+__global__ void build_panels_kernel(const double *__restrict__ Q1, const double *__restrict__ W, double mu, int64_t n, int64_t npad,
+                                    int q, int K2, double *__restrict__ PA, double *__restrict__ PB) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= npad * K2) return;
+    const int64_t i = idx % npad;
+    const int t = (int)(idx / npad);
+    double a = 0.0, b = 0.0;
+    if (i < n && t < 2 * q) {
+        const int tt = t % q;
+        const double qv = Q1[i + (int64_t)tt * npad];
+        const double vv = fma(-0.5 * mu, qv, W[i + (int64_t)tt * npad]);
+        a = (t < q) ? qv : vv;
+        b = (t < q) ? vv : qv;
+    }
+    PA[idx] = a;
+    PB[idx] = b;
+}
+// lam[0] = z0 / sqrt(n) - mean . lam[1:]   (Pi = Q1 R with R = [[sqrt n, sqrt n mean'], [0, Lx']])
+__global__ void finish_lambda_kernel(double *__restrict__ T1, int q, int k, double sqrtn, const double *__restrict__ mean) {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= k) return;
+    double s = T1[(int64_t)l * q] / sqrtn;
+    for (int t = 1; t < q; ++t) s -= mean[t - 1] * T1[t + (int64_t)l * q];
+    T1[(int64_t)l * q] = s;
+}
+
+// returns 0 with *not_pd = 1 when a factorisation met a non-positive pivot (caller may retry with LU)
 static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info *info, int *not_pd) {
-    const int64_t n = M->n;
-    const int k = M->k, q = M->q;
+    const int64_t n = M->n, npad = M->npad;
+    const int k = M->k, q = M->q, d = M->d;
     const double one = 1.0, zero = 0.0, mone = -1.0, mhalf = -0.5;
     *not_pd = 0;
-    const int64_t ld = M->npad;  // 128-padded leading dimension: aligned tiles for the built-in Cholesky
+    const bool builtin = ctx->chol_impl != 1;
+    const int xt = builtin ? (int)round_up(k, 128) : 0;  // extra row tiles: right-hand sides ride along the factorisation
+    const int64_t ld = npad + xt;
     double *Phi, *B;
-    MRBF_TRY(get_buf(ctx, S_PHI, (size_t)ld * ld, &Phi));
-    MRBF_TRY(get_buf(ctx, S_RHS, (size_t)n * k, &B));
-    hipLaunchKernelGGL(rhs_from_values_kernel, dim3(nblk(n * k)), dim3(256), 0, ctx->stream, Y, n, k, B, n);
+    int *dinfo;
+    MRBF_TRY(get_buf(ctx, S_PHI, (size_t)ld * npad, &Phi));
+    MRBF_TRY(get_buf(ctx, S_RHS, (size_t)npad * k, &B));
+    MRBF_TRY(get_buf(ctx, S_INFO, (size_t)4, &dinfo));
+    hipLaunchKernelGGL(rhs_from_values_kernel, dim3(nblk(npad * k)), dim3(256), 0, ctx->stream, Y, n, k, B, npad);
     MRBF_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));  // ev0..ev1 bracket the Gram kernel alone
     MRBF_TRY(launch_gram(ctx, ctx->gram_mode, M->C, M->Xc, M->sq, n, M->npad, M->d, M->dpad, M->kp, Phi, ld));
     MRBF_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
 
-    double *Q1 = nullptr, *Wm = nullptr, *G = nullptr, *R = nullptr, *tau = nullptr, *T1 = nullptr, *scal = nullptr;
+    double *Q1 = nullptr, *Wm = nullptr, *G = nullptr, *T1 = nullptr, *scal = nullptr, *Tall = nullptr;
+    int64_t lt = 0, dq = 0;
     info->mu = 0.0;
     if (q > 0) {
-        MRBF_TRY(get_buf(ctx, S_Q1, (size_t)n * q, &Q1));
-        MRBF_TRY(get_buf(ctx, S_W1, (size_t)n * q, &Wm));
+        MRBF_TRY(get_buf(ctx, S_Q1, (size_t)npad * q, &Q1));
+        MRBF_TRY(get_buf(ctx, S_W1, (size_t)npad * q, &Wm));
         MRBF_TRY(get_buf(ctx, S_G, (size_t)q * q, &G));
-        MRBF_TRY(get_buf(ctx, S_R, (size_t)q * q, &R));
-        MRBF_TRY(get_buf(ctx, S_TAU, (size_t)q, &tau));
         MRBF_TRY(get_buf(ctx, S_T1, (size_t)q * k, &T1));
         MRBF_TRY(get_buf(ctx, S_MISC, (size_t)8, &scal));
-        // thin QR of Pi
-        MRBF_TRY(launch_poly_matrix(ctx, M->C, n, M->d, q, Q1, n));
-        MRBF_BLAS(ctx, rocsolver_dgeqrf(ctx->blas, (int)n, q, Q1, (int)n, tau));
-        hipLaunchKernelGGL(copy_upper_kernel, dim3(nblk((int64_t)q * q)), dim3(256), 0, ctx->stream, Q1, n, q, R);
-        MRBF_BLAS(ctx, rocsolver_dorgqr(ctx->blas, (int)n, q, q, Q1, (int)n, tau));
-        // W1 = Phi Q1 ; G = Q1' W1 ; W = W1 - 1/2 Q1 G
-        MRBF_BLAS(ctx, rocblas_dsymm(ctx->blas, rocblas_side_left, rocblas_fill_lower, (int)n, q, &one, Phi, (int)ld, Q1, (int)n,
-                                     &zero, Wm, (int)n));
+        if (q > 1) {
+            // Cholesky-QR of the centred coordinates: [Xc'Xc ; Xc] -> [Lx ; Xc Lx^-T] by the tall blocked Cholesky
+            dq = round_up(d, 128);
+            lt = dq + npad;
+            MRBF_TRY(get_buf(ctx, S_PI, (size_t)lt * dq, &Tall));
+            MRBF_HIP(ctx, hipMemsetAsync(Tall, 0, (size_t)lt * dq * sizeof(double), ctx->stream));
+            MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_transpose, d, d, (int)n, &one, M->Xc,
+                                         M->dpad, M->Xc, M->dpad, &zero, Tall, (int)lt));
+            MRBF_TRY(launch_pad_identity(ctx, Tall, d, dq, lt));
+            hipLaunchKernelGGL(xc_to_tall_kernel, dim3(nblk(n * d)), dim3(256), 0, ctx->stream, M->Xc, n, d, M->dpad, Tall, lt, dq);
+            MRBF_TRY(potrf_blocked_tall(ctx, dq, lt, Tall, lt, dinfo, nullptr));
+            int hq = 0;
+            MRBF_TRY(read_info(ctx, dinfo, &hq));
+            if (hq != 0) {  // affinely dependent sites: Pi is rank deficient
+                *not_pd = 1;
+                info->factor_info = -2;
+                return 0;
+            }
+        }
+        hipLaunchKernelGGL(build_q1_kernel, dim3(nblk(npad * q)), dim3(256), 0, ctx->stream, Tall, lt, dq, n, npad, q, Q1);
+        MRBF_HIP(ctx, hipMemsetAsync(Wm, 0, (size_t)npad * q * sizeof(double), ctx->stream));
+        // W1 = Phi Q1 (Phi is stored in full) ; G = Q1' W1 ; W = W1 - 1/2 Q1 G
+        MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, (int)n, q, (int)n, &one, Phi, (int)ld,
+                                     Q1, (int)npad, &zero, Wm, (int)npad));
         MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, q, q, (int)n, &one, Q1,
-                                     (int)n, Wm, (int)n, &zero, G, q));
+                                     (int)npad, Wm, (int)npad, &zero, G, q));
         hipLaunchKernelGGL(trace_kernel, dim3(1), dim3(256), 0, ctx->stream, G, q, scal);
-        MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, (int)n, q, q, &mhalf, Q1, (int)n,
-                                     G, q, &one, Wm, (int)n));
-        // K = Phi - Q1 W' - W Q1'   (lower triangle, in place)
-        MRBF_BLAS(ctx, rocblas_dsyr2k(ctx->blas, rocblas_fill_lower, rocblas_operation_none, (int)n, q, &mone, Q1, (int)n, Wm,
-                                      (int)n, &one, Phi, (int)ld));
+        MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, (int)n, q, q, &mhalf, Q1, (int)npad,
+                                     G, q, &one, Wm, (int)npad));
         // mu = trace(P Phi P) / (n - q): the mean eigenvalue of Z' Phi Z, so the shift sits inside the spectrum
         double trG = 0.0;
         MRBF_HIP(ctx, hipMemcpyAsync(&trG, scal, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        double mu = ((double)n * M->kp.phi0 - trG) / (double)std::max<int64_t>(n - q, 1);
+        const double mu = ((double)n * M->kp.phi0 - trG) / (double)std::max<int64_t>(n - q, 1);
         if (!(mu > 0.0) || !std::isfinite(mu)) {
             *not_pd = 1;  // trace <= 0: Z' Phi Z cannot be positive definite
             info->factor_info = -1;
             return 0;
         }
         info->mu = mu;
-        MRBF_BLAS(ctx, rocblas_dsyrk(ctx->blas, rocblas_fill_lower, rocblas_operation_none, (int)n, q, &mu, Q1, (int)n, &one, Phi,
-                                     (int)ld));
+        // K = Phi - Q1 V' - V Q1',  V = W - (mu/2) Q1  ( = P Phi P + mu Q1 Q1' ), lower tile pairs, in place, one kernel
+        const int K2 = (int)round_up(2 * q, 16);
+        double *PA, *PB;
+        MRBF_TRY(get_buf(ctx, S_STAGE_C, (size_t)npad * K2, &PA));
+        MRBF_TRY(get_buf(ctx, S_STAGE_D, (size_t)npad * K2, &PB));
+        hipLaunchKernelGGL(build_panels_kernel, dim3(nblk(npad * K2)), dim3(256), 0, ctx->stream, Q1, Wm, mu, n, npad, q, K2, PA, PB);
+        MRBF_TRY(launch_update_lower(ctx, PA, npad, PB, npad, Phi, ld, npad / 128, K2));
         // B = P Y = Y - Q1 (Q1' Y);  T1 keeps Q1' Y for lam
         MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, q, k, (int)n, &one, Q1,
-                                     (int)n, B, (int)n, &zero, T1, q));
-        MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, (int)n, k, q, &mone, Q1, (int)n,
-                                     T1, q, &one, B, (int)n));
+                                     (int)npad, B, (int)npad, &zero, T1, q));
+        MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, (int)n, k, q, &mone, Q1, (int)npad,
+                                     T1, q, &one, B, (int)npad));
     }
     MRBF_HIP(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
     int hinfo = 0;
-    MRBF_TRY(potrf_lower(ctx, ctx->chol_impl, n, Phi, ld, &hinfo));
-    MRBF_HIP(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+    double *linv_all = nullptr;
+    if (builtin) {
+        MRBF_TRY(get_buf(ctx, S_CHOL_WS, (size_t)npad * 128, &linv_all));
+        MRBF_TRY(launch_pad_identity(ctx, Phi, n, npad, ld));
+        hipLaunchKernelGGL(set_rhs_rows_kernel, dim3(nblk(npad * xt)), dim3(256), 0, ctx->stream, Phi, ld, npad, xt, B, k);
+        MRBF_TRY(potrf_blocked_tall(ctx, npad, npad + xt, Phi, ld, dinfo, linv_all));
+        MRBF_HIP(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+        MRBF_TRY(read_info(ctx, dinfo, &hinfo));
+    } else {
+        MRBF_TRY(potrf_lower(ctx, 1, n, Phi, ld, &hinfo));
+        MRBF_HIP(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+    }
     info->factor_info = hinfo;
     if (hinfo != 0) {
         *not_pd = 1;
         return 0;
     }
-    MRBF_BLAS(ctx, rocsolver_dpotrs(ctx->blas, rocblas_fill_lower, (int)n, k, Phi, (int)ld, B, (int)n));
+    if (builtin) {
+        // forward substitution came out of the factorisation (the extra rows); backward substitution with the stored block inverses
+        hipLaunchKernelGGL(get_rhs_rows_kernel, dim3(nblk(npad * k)), dim3(256), 0, ctx->stream, Phi, ld, npad, B, k);
+        MRBF_TRY(backsolve_blocked(ctx, npad, Phi, ld, linv_all, B, npad, k));
+    } else {
+        MRBF_BLAS(ctx, rocsolver_dpotrs(ctx->blas, rocblas_fill_lower, (int)n, k, Phi, (int)ld, B, (int)npad));
+    }
     if (q > 0) {
         double *T2;
         MRBF_TRY(get_buf(ctx, S_T2, (size_t)q * k, &T2));
         // re-project w (rounding hygiene): w -= Q1 (Q1' w)
         MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, q, k, (int)n, &one, Q1,
-                                     (int)n, B, (int)n, &zero, T2, q));
-        MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, (int)n, k, q, &mone, Q1, (int)n,
-                                     T2, q, &one, B, (int)n));
-        // lam = R^-1 (Q1' Y - (Phi Q1)' w);  (Phi Q1)' w = W' w because Q1' w = 0
+                                     (int)npad, B, (int)npad, &zero, T2, q));
+        MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, (int)n, k, q, &mone, Q1, (int)npad,
+                                     T2, q, &one, B, (int)npad));
+        // z = Q1' Y - (Phi Q1)' w;  (Phi Q1)' w = W' w because Q1' w = 0;  lam = R^-1 z
         MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, q, k, (int)n, &mone, Wm,
-                                     (int)n, B, (int)n, &one, T1, q));
-        MRBF_BLAS(ctx, rocblas_dtrsm(ctx->blas, rocblas_side_left, rocblas_fill_upper, rocblas_operation_none,
-                                     rocblas_diagonal_non_unit, q, k, &one, R, q, T1, q));
+                                     (int)npad, B, (int)npad, &one, T1, q));
+        if (q > 1)
+            MRBF_BLAS(ctx, rocblas_dtrsm(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose,
+                                         rocblas_diagonal_non_unit, d, k, &one, Tall, (int)lt, T1 + 1, q));
+        hipLaunchKernelGGL(finish_lambda_kernel, dim3((k + 63) / 64), dim3(64), 0, ctx->stream, T1, q, k, std::sqrt((double)n), M->mean);
     }
-    hipLaunchKernelGGL(scatter_solution_kernel, dim3(nblk(M->npad * k + (int64_t)q * k)), dim3(256), 0, ctx->stream, B, n, n,
+    hipLaunchKernelGGL(scatter_solution_kernel, dim3(nblk(M->npad * k + (int64_t)q * k)), dim3(256), 0, ctx->stream, B, npad, n,
                        M->npad, k, q, (int64_t)0, M->W, M->Wc, M->lam, T1 ? T1 : B, (int64_t)q);
     MRBF_HIP(ctx, hipGetLastError());
     MRBF_HIP(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
