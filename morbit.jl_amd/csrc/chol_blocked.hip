@@ -23,11 +23,12 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 constexpr int CNB = 128;  // block size of the factorisation
 constexpr int CBK = 16;   // k chunk
 
-enum { UPD_LOWER_SUB = 0, UPD_OVERWRITE = 1, UPD_FULL_SUB = 2 };
+enum { UPD_LOWER_SUB = 0, UPD_OVERWRITE = 1, UPD_FULL_SUB = 2, UPD_COLUMN_SUB = 3 };
 
 // C(i,j) (op)= sum_k A(i,k) * B(j,k).  A: (tiles_i*TM) x K, B: (tiles_j*128) x K, all column-major.
 // MODE LOWER_SUB: square region, grid.x = lower-triangular tile pairs (TM == 128), C -= ..., strictly-upper
 // entries of diagonal tiles left untouched.  OVERWRITE / FULL_SUB: grid = (tiles_i, tiles_j).
+// COLUMN_SUB: one block column whose first row tile is the diagonal tile (grid = (tiles_i, 1)).
 template <int TM, int MODE>
 __global__ __launch_bounds__(256, 2) void chol_update_kernel(const double *__restrict__ A, int64_t lda,
                                                              const double *__restrict__ B, int64_t ldb,
@@ -131,6 +132,8 @@ __global__ __launch_bounds__(256, 2) void chol_update_kernel(const double *__res
                     *dst = acc[j][i][r];
                 } else if (MODE == UPD_FULL_SUB) {
                     *dst = cv[r][i] - acc[j][i][r];
+                } else if (MODE == UPD_COLUMN_SUB) {
+                    if (ti != 0 || gi >= gj) *dst = cv[r][i] - acc[j][i][r];
                 } else {
                     if (ti != tj || gi >= gj) *dst = cv[r][i] - acc[j][i][r];
                 }
@@ -458,37 +461,60 @@ int potrf_blocked_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, i
                     (long long)ncols, (long long)mrows, (long long)lda);
     double *Lone = nullptr;
     if (!linv_all) MRBF_TRY(get_buf(ctx, S_CHOL_WS, (size_t)CNB * CNB, &Lone));
-    MRBF_HIP(ctx, hipMemsetAsync(dinfo, 0, sizeof(int), ctx->stream));
+    // Look-ahead over two streams.  Panel stream P (high priority): D(j), T(j), U1(j) = update of block column j+1
+    // only -- everything step j+1's diagonal block and panel depend on.  Main stream M: U2(j) = update of block
+    // columns >= j+2, the bulk of the flops, which therefore runs UNDER D(j+1) / T(j+1).
+    //   U2(j) needs T(j)                      : M waits evT
+    //   U1(j+1) writes column j+2 like U2(j)  : P waits evU2 before U1(j+1)
+    hipStream_t M = ctx->stream, P = ctx->panel_stream;
+    hipEvent_t evStart = ctx->evx[0], evT = ctx->evx[1], evU2 = ctx->evx[2], evEnd = ctx->evx[3];
+    MRBF_HIP(ctx, hipMemsetAsync(dinfo, 0, sizeof(int), M));
+    MRBF_HIP(ctx, hipEventRecord(evStart, M));
+    MRBF_HIP(ctx, hipStreamWaitEvent(P, evStart, 0));
     const int nb = (int)(ncols / CNB);
+    bool have_u2 = false;
     for (int j = 0; j < nb; ++j) {
         const int64_t c = (int64_t)j * CNB;
         double *Ajj = A + c + c * lda;
         double *Linv = linv_all ? linv_all + (size_t)j * CNB * CNB : Lone;
-        hipLaunchKernelGGL(chol_diag_kernel<false>, dim3(1), dim3(512), 0, ctx->stream, Ajj, lda, Linv, dinfo, (int)c,
+        hipLaunchKernelGGL(chol_diag_kernel<false>, dim3(1), dim3(512), 0, P, Ajj, lda, Linv, dinfo, (int)c,
                            (unsigned long long *)nullptr);
         const int64_t m = mrows - c - CNB;  // rows below the diagonal block
         if (m <= 0) break;
         double *A21 = A + (c + CNB) + c * lda;
         // T: A21 <- A21 * Linv'   (each workgroup owns full rows of the 128-wide panel: in place is safe)
-        hipLaunchKernelGGL((chol_update_kernel<64, UPD_OVERWRITE>), dim3((unsigned)(m / 64), 1), dim3(256), 0, ctx->stream,
-                           A21, lda, Linv, (int64_t)CNB, A21, lda, CNB, dinfo);
-        // U: trailing update.  Square part (rows and columns < ncols): lower-triangular tile pairs.
-        const int64_t mt = (ncols - c - CNB) / CNB;
-        if (mt > 0) {
-            double *A22 = A + (c + CNB) + (c + CNB) * lda;
-            hipLaunchKernelGGL((chol_update_kernel<128, UPD_LOWER_SUB>), dim3((unsigned)(mt * (mt + 1) / 2)), dim3(256), 0,
-                               ctx->stream, A21, lda, A21, lda, A22, lda, CNB, dinfo);
-            // rows below the square: full rectangle  A[ncols:, c+128:ncols] -= A[ncols:, c] A[c+128:ncols, c]'
-            const int64_t mx = (mrows - ncols) / CNB;
+        hipLaunchKernelGGL((chol_update_kernel<64, UPD_OVERWRITE>), dim3((unsigned)(m / 64), 1), dim3(256), 0, P, A21, lda, Linv,
+                           (int64_t)CNB, A21, lda, CNB, dinfo);
+        if (c + CNB >= ncols) break;  // no trailing columns
+        MRBF_HIP(ctx, hipEventRecord(evT, P));
+        // U1: block column j+1, every row tile from the diagonal one down to the last (extra) row
+        if (have_u2) MRBF_HIP(ctx, hipStreamWaitEvent(P, evU2, 0));
+        double *A22 = A + (c + CNB) + (c + CNB) * lda;
+        hipLaunchKernelGGL((chol_update_kernel<128, UPD_COLUMN_SUB>), dim3((unsigned)(m / CNB), 1), dim3(256), 0, P, A21, lda, A21,
+                           lda, A22, lda, CNB, dinfo);
+        // U2: block columns >= j+2
+        const int64_t mt2 = (ncols - c - 2 * CNB) / CNB;
+        if (mt2 > 0) {
+            MRBF_HIP(ctx, hipStreamWaitEvent(M, evT, 0));
+            const double *P2 = A + (c + 2 * CNB) + c * lda;  // panel rows from block row j+2 on
+            double *C2 = A + (c + 2 * CNB) + (c + 2 * CNB) * lda;
+            hipLaunchKernelGGL((chol_update_kernel<128, UPD_LOWER_SUB>), dim3((unsigned)(mt2 * (mt2 + 1) / 2)), dim3(256), 0, M, P2,
+                               lda, P2, lda, C2, lda, CNB, dinfo);
+            const int64_t mx = (mrows - ncols) / CNB;  // rows below the square: full rectangle
             if (mx > 0) {
                 const double *Ax = A + ncols + c * lda;
-                double *Cx = A + ncols + (c + CNB) * lda;
-                hipLaunchKernelGGL((chol_update_kernel<128, UPD_FULL_SUB>), dim3((unsigned)mx, (unsigned)mt), dim3(256), 0,
-                                   ctx->stream, Ax, lda, A21, lda, Cx, lda, CNB, dinfo);
+                double *Cx = A + ncols + (c + 2 * CNB) * lda;
+                hipLaunchKernelGGL((chol_update_kernel<128, UPD_FULL_SUB>), dim3((unsigned)mx, (unsigned)mt2), dim3(256), 0, M, Ax,
+                                   lda, P2, lda, Cx, lda, CNB, dinfo);
             }
+            MRBF_HIP(ctx, hipEventRecord(evU2, M));
+            have_u2 = true;
         }
     }
     MRBF_HIP(ctx, hipGetLastError());
+    // join: later work on the main stream must see the panel stream's results
+    MRBF_HIP(ctx, hipEventRecord(evEnd, P));
+    MRBF_HIP(ctx, hipStreamWaitEvent(M, evEnd, 0));
     return 0;
 }
 
@@ -512,22 +538,22 @@ __device__ __forceinline__ void tile_tdot(const double *__restrict__ Tl, int64_t
         x0[l] = xs[l * CNB + lane];
         x1[l] = xs[l * CNB + 64 + lane];
     }
-    for (int cc = 0; cc < 32; cc += 4) {
-        double t0[4], t1[4];
+    // all 64 loads of this wave's 32 columns are issued before the first use: the tile comes cold from HBM and
+    // the launch sits on a 64-step sequential chain, so memory-level parallelism is what matters here
+    double t0[32], t1[32];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const double *col = Tl + (int64_t)(wave * 32 + cc + q) * ldt;
-            t0[q] = col[lane];
-            t1[q] = col[64 + lane];
-        }
+    for (int q = 0; q < 32; ++q) {
+        const double *col = Tl + (int64_t)(wave * 32 + q) * ldt;
+        t0[q] = col[lane];
+        t1[q] = col[64 + lane];
+    }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < 32; ++q) {
 #pragma unroll
-            for (int l = 0; l < KB; ++l) {
-                double v = fma(t0[q], x0[l], t1[q] * x1[l]);
-                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-                if (lane == 0) res[l * CNB + wave * 32 + cc + q] = v;
-            }
+        for (int l = 0; l < KB; ++l) {
+            double v = fma(t0[q], x0[l], t1[q] * x1[l]);
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            if (lane == 0) res[l * CNB + wave * 32 + q] = v;
         }
     }
 }

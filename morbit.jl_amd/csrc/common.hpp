@@ -49,6 +49,8 @@ struct mrbf_ctx {
     rocblas_handle blas = nullptr;
     mrbf::Buf slots[mrbf::S_NSLOTS];
     hipEvent_t ev[8] = {};
+    hipStream_t panel_stream = nullptr;  // high-priority side stream: diagonal block + panel of step j+1 under step j's trailing update
+    hipEvent_t evx[4] = {};              // cross-stream dependencies of the look-ahead Cholesky
     std::string err;
     // options
     int gram_mode = 0, residual = 1, force_path = 0, chol_impl = 0, eval_impl = 0, timing = 1;

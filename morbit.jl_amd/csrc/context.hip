@@ -163,6 +163,14 @@ int32_t mrbf_init(int32_t device_id, mrbf_ctx **out) {
     rocblas_set_pointer_mode(ctx->blas, rocblas_pointer_mode_host);
     for (auto &ev : ctx->ev)
         if (hipEventCreate(&ev) != hipSuccess) return bail(MRBF_EHIP, "hipEventCreate");
+    {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (hipStreamCreateWithPriority(&ctx->panel_stream, hipStreamNonBlocking, hi) != hipSuccess)
+            return bail(MRBF_EHIP, "hipStreamCreateWithPriority");
+    }
+    for (auto &ev : ctx->evx)
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return bail(MRBF_EHIP, "hipEventCreate");
     *out = ctx;
     return MRBF_OK;
 }
@@ -175,6 +183,12 @@ int32_t mrbf_shutdown(mrbf_ctx *ctx) {
         if (b.p) (void)hipFree(b.p);
     for (auto &ev : ctx->ev)
         if (ev) (void)hipEventDestroy(ev);
+    for (auto &ev : ctx->evx)
+        if (ev) (void)hipEventDestroy(ev);
+    if (ctx->panel_stream) {
+        (void)hipStreamSynchronize(ctx->panel_stream);
+        (void)hipStreamDestroy(ctx->panel_stream);
+    }
     if (ctx->blas) rocblas_destroy_handle(ctx->blas);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
