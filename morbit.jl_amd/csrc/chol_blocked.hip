@@ -24,6 +24,7 @@ constexpr int CNB = 128;  // block size of the factorisation
 constexpr int CBK = 16;   // k chunk
 
 enum { UPD_LOWER_SUB = 0, UPD_OVERWRITE = 1, UPD_FULL_SUB = 2, UPD_COLUMN_SUB = 3 };
+int launch_diag_v4(mrbf_ctx *ctx, hipStream_t st, double *Ajj, int64_t lda, double *Linv, int *dinfo, int col0);  // chol_diag.hip
 
 // C(i,j) (op)= sum_k A(i,k) * B(j,k).  A: (tiles_i*TM) x K, B: (tiles_j*128) x K, all column-major.
 // MODE LOWER_SUB: square region, grid.x = lower-triangular tile pairs (TM == 128), C -= ..., strictly-upper
@@ -33,7 +34,7 @@ template <int TM, int MODE>
 __global__ __launch_bounds__(256, 2) void chol_update_kernel(const double *__restrict__ A, int64_t lda,
                                                              const double *__restrict__ B, int64_t ldb,
                                                              double *__restrict__ C, int64_t ldc, int K,
-                                                             const int *__restrict__ info) {
+                                                             const int *__restrict__ info, int mt_sq = 0) {
     constexpr int LDA_S = TM + 16;   // LDS row strides (doubles); (2*LD) % 64 == 32 -> k and k+1 rows hit disjoint banks
     constexpr int LDB_S = 128 + 16;
     constexpr int NJ = (TM == 128) ? 4 : 2;  // 16-wide j tiles per wave
@@ -46,11 +47,19 @@ __global__ __launch_bounds__(256, 2) void chol_update_kernel(const double *__res
     const int l15 = lane & 15, l4 = lane >> 4;
     int ti, tj;
     if (MODE == UPD_LOWER_SUB) {
-        int t = (int)((sqrt(8.0 * (double)blockIdx.x + 1.0) - 1.0) * 0.5);
-        while ((t + 1) * (t + 2) / 2 <= (int)blockIdx.x) ++t;
-        while (t * (t + 1) / 2 > (int)blockIdx.x) --t;
-        ti = t;
-        tj = blockIdx.x - t * (t + 1) / 2;
+        // trapezoid: lower-triangular tile pairs of the mt_sq x mt_sq square, then full rows of tiles below it
+        const int ntri = mt_sq * (mt_sq + 1) / 2;
+        const int bid = blockIdx.x;
+        if (bid < ntri || mt_sq == 0) {
+            int t = (int)((sqrt(8.0 * (double)bid + 1.0) - 1.0) * 0.5);
+            while ((t + 1) * (t + 2) / 2 <= bid) ++t;
+            while (t * (t + 1) / 2 > bid) --t;
+            ti = t;
+            tj = bid - t * (t + 1) / 2;
+        } else {
+            ti = mt_sq + (bid - ntri) / mt_sq;
+            tj = (bid - ntri) % mt_sq;
+        }
     } else {
         ti = blockIdx.x;
         tj = blockIdx.y;
@@ -133,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void chol_update_kernel(const double *__res
                 } else if (MODE == UPD_FULL_SUB) {
                     *dst = cv[r][i] - acc[j][i][r];
                 } else if (MODE == UPD_COLUMN_SUB) {
-                    if (ti != 0 || gi >= gj) *dst = cv[r][i] - acc[j][i][r];
+                    if (gi >= gj) *dst = cv[r][i] - acc[j][i][r];  // only the diagonal 128 x 128 block has gi < gj
                 } else {
                     if (ti != tj || gi >= gj) *dst = cv[r][i] - acc[j][i][r];
                 }
@@ -424,7 +433,9 @@ int debug_diag(mrbf_ctx *ctx, const double *A128_dev, int reps, float *ms_per_ca
     MRBF_HIP(ctx, hipMemsetAsync(dinfo, 0, sizeof(int), ctx->stream));
     MRBF_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     for (int r = 0; r < reps; ++r)
-        if (with_stamps)
+        if (ctx->diag_impl != 1)
+            launch_diag_v4(ctx, ctx->stream, W + (size_t)r * CNB * CNB, (int64_t)CNB, Linv, dinfo, 0);
+        else if (with_stamps)
             hipLaunchKernelGGL(chol_diag_kernel<true>, dim3(1), dim3(512), 0, ctx->stream, W + (size_t)r * CNB * CNB, (int64_t)CNB, Linv,
                                dinfo, 0, st);
         else
@@ -445,7 +456,7 @@ int launch_update_lower(mrbf_ctx *ctx, const double *A, int64_t lda, const doubl
                         int K) {
     if (nt <= 0 || K <= 0) return 0;
     hipLaunchKernelGGL((chol_update_kernel<128, UPD_LOWER_SUB>), dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256), 0, ctx->stream, A,
-                       lda, B, ldb, C, ldc, K, (const int *)nullptr);
+                       lda, B, ldb, C, ldc, K, (const int *)nullptr, (int)nt);
     MRBF_HIP(ctx, hipGetLastError());
     return 0;
 }
@@ -477,8 +488,11 @@ int potrf_blocked_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, i
         const int64_t c = (int64_t)j * CNB;
         double *Ajj = A + c + c * lda;
         double *Linv = linv_all ? linv_all + (size_t)j * CNB * CNB : Lone;
-        hipLaunchKernelGGL(chol_diag_kernel<false>, dim3(1), dim3(512), 0, P, Ajj, lda, Linv, dinfo, (int)c,
-                           (unsigned long long *)nullptr);
+        if (ctx->diag_impl == 1)
+            hipLaunchKernelGGL(chol_diag_kernel<false>, dim3(1), dim3(512), 0, P, Ajj, lda, Linv, dinfo, (int)c,
+                               (unsigned long long *)nullptr);
+        else
+            launch_diag_v4(ctx, P, Ajj, lda, Linv, dinfo, (int)c);
         const int64_t m = mrows - c - CNB;  // rows below the diagonal block
         if (m <= 0) break;
         double *A21 = A + (c + CNB) + c * lda;
@@ -490,7 +504,7 @@ int potrf_blocked_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, i
         // U1: block column j+1, every row tile from the diagonal one down to the last (extra) row
         if (have_u2) MRBF_HIP(ctx, hipStreamWaitEvent(P, evU2, 0));
         double *A22 = A + (c + CNB) + (c + CNB) * lda;
-        hipLaunchKernelGGL((chol_update_kernel<128, UPD_COLUMN_SUB>), dim3((unsigned)(m / CNB), 1), dim3(256), 0, P, A21, lda, A21,
+        hipLaunchKernelGGL((chol_update_kernel<64, UPD_COLUMN_SUB>), dim3((unsigned)(m / 64), 1), dim3(256), 0, P, A21, lda, A21,
                            lda, A22, lda, CNB, dinfo);
         // U2: block columns >= j+2
         const int64_t mt2 = (ncols - c - 2 * CNB) / CNB;
@@ -498,15 +512,9 @@ int potrf_blocked_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, i
             MRBF_HIP(ctx, hipStreamWaitEvent(M, evT, 0));
             const double *P2 = A + (c + 2 * CNB) + c * lda;  // panel rows from block row j+2 on
             double *C2 = A + (c + 2 * CNB) + (c + 2 * CNB) * lda;
-            hipLaunchKernelGGL((chol_update_kernel<128, UPD_LOWER_SUB>), dim3((unsigned)(mt2 * (mt2 + 1) / 2)), dim3(256), 0, M, P2,
-                               lda, P2, lda, C2, lda, CNB, dinfo);
-            const int64_t mx = (mrows - ncols) / CNB;  // rows below the square: full rectangle
-            if (mx > 0) {
-                const double *Ax = A + ncols + c * lda;
-                double *Cx = A + ncols + (c + 2 * CNB) * lda;
-                hipLaunchKernelGGL((chol_update_kernel<128, UPD_FULL_SUB>), dim3((unsigned)mx, (unsigned)mt2), dim3(256), 0, M, Ax,
-                                   lda, P2, lda, Cx, lda, CNB, dinfo);
-            }
+            const int64_t mx = (mrows - ncols) / CNB;  // extra row tiles below the square ride in the same launch
+            hipLaunchKernelGGL((chol_update_kernel<128, UPD_LOWER_SUB>), dim3((unsigned)(mt2 * (mt2 + 1) / 2 + mx * mt2)), dim3(256), 0,
+                               M, P2, lda, P2, lda, C2, lda, CNB, dinfo, (int)mt2);
             MRBF_HIP(ctx, hipEventRecord(evU2, M));
             have_u2 = true;
         }
@@ -526,35 +534,40 @@ int potrf_blocked(mrbf_ctx *ctx, int64_t n, double *A, int64_t lda, int *dinfo) 
 // Y: npad x k column-major (ld npad), overwritten by x.  Launch i (i = nb-1 .. 0) has i + 1 workgroups: workgroup
 // j < i applies  y_j -= L(i,j)' x_i ; workgroup j == i - 1 then finishes  x_{i-1} = Linv_{i-1}' y_{i-1}  (all later
 // updates of y_{i-1} were applied by earlier launches).  A prologue launch computes x_{nb-1}.
-// res[l][c] = sum_r T(r, c) x_l[r] for one 128 x 128 column-major tile: wave w takes columns 32w .. 32w+31, its lanes
-// span the rows (two coalesced 512-byte reads per column), wave-shuffle reduction per column.
+// res[l][c] = sum_r T(r, c) x_l[r] for one 128 x 128 column-major tile.  The tile is staged through LDS in two
+// 64-row halves with coalesced 512-byte column reads (all loads of a half in flight together); thread (c, g)
+// then sums rows 32g..32g+31 of column c straight from LDS (stride 65: conflict-free), and the two partial sums
+// per column meet in LDS.  No cross-lane shuffles: 64 dependent shuffle chains per tile cost ~16 us.
+constexpr int BS_LD = 65;
 template <int KB>
 __device__ __forceinline__ void tile_tdot(const double *__restrict__ Tl, int64_t ldt, const double *xs /* LDS KB x 128 */,
-                                          double *res /* LDS KB x 128 */) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double x0[KB], x1[KB];
+                                          double *res /* LDS KB x 128 */, double *stage /* LDS 128 x 65 */,
+                                          double *part /* LDS KB x 256 */) {
+    const int tid = threadIdx.x, c = tid & 127, g = tid >> 7;
+    double acc[KB];
 #pragma unroll
-    for (int l = 0; l < KB; ++l) {
-        x0[l] = xs[l * CNB + lane];
-        x1[l] = xs[l * CNB + 64 + lane];
-    }
-    // all 64 loads of this wave's 32 columns are issued before the first use: the tile comes cold from HBM and
-    // the launch sits on a 64-step sequential chain, so memory-level parallelism is what matters here
-    double t0[32], t1[32];
+    for (int l = 0; l < KB; ++l) acc[l] = 0.0;
+    for (int h = 0; h < 2; ++h) {
+        double v[32];
 #pragma unroll
-    for (int q = 0; q < 32; ++q) {
-        const double *col = Tl + (int64_t)(wave * 32 + q) * ldt;
-        t0[q] = col[lane];
-        t1[q] = col[64 + lane];
-    }
+        for (int p = 0; p < 32; ++p) v[p] = Tl[(int64_t)(p * 4 + (tid >> 6)) * ldt + 64 * h + (tid & 63)];
+        __syncthreads();  // previous half consumed
 #pragma unroll
-    for (int q = 0; q < 32; ++q) {
+        for (int p = 0; p < 32; ++p) stage[(p * 4 + (tid >> 6)) * BS_LD + (tid & 63)] = v[p];
+        __syncthreads();
+#pragma unroll 8
+        for (int r = 0; r < 32; ++r) {
+            const double t = stage[c * BS_LD + 32 * g + r];
 #pragma unroll
-        for (int l = 0; l < KB; ++l) {
-            double v = fma(t0[q], x0[l], t1[q] * x1[l]);
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-            if (lane == 0) res[l * CNB + wave * 32 + q] = v;
+            for (int l = 0; l < KB; ++l) acc[l] = fma(t, xs[l * CNB + 64 * h + 32 * g + r], acc[l]);
         }
+    }
+#pragma unroll
+    for (int l = 0; l < KB; ++l) part[l * 256 + tid] = acc[l];
+    __syncthreads();
+    if (g == 0) {
+#pragma unroll
+        for (int l = 0; l < KB; ++l) res[l * CNB + c] = part[l * 256 + c] + part[l * 256 + 128 + c];
     }
 }
 
@@ -564,13 +577,15 @@ __global__ __launch_bounds__(256) void chol_backsolve_kernel(const double *__res
                                                              int prologue) {
     __shared__ double xs[KB * CNB];
     __shared__ double res[KB * CNB];
+    __shared__ double part[KB * 256];
+    __shared__ double stage[CNB * BS_LD];
     const int tid = threadIdx.x;
     const int j = blockIdx.x;
     if (!prologue) {
         // x_i (already final) -> LDS
         for (int t = tid; t < KB * CNB; t += 256) xs[t] = Y[(int64_t)(k0 + t / CNB) * ldy + (int64_t)i * CNB + (t % CNB)];
         __syncthreads();
-        tile_tdot<KB>(L + (int64_t)i * CNB + (int64_t)j * CNB * lda, lda, xs, res);  // tile L(i, j)
+        tile_tdot<KB>(L + (int64_t)i * CNB + (int64_t)j * CNB * lda, lda, xs, res, stage, part);  // tile L(i, j)
         __syncthreads();
         for (int t = tid; t < KB * CNB; t += 256) {
             double *yp = Y + (int64_t)(k0 + t / CNB) * ldy + (int64_t)j * CNB + (t % CNB);
@@ -586,7 +601,7 @@ __global__ __launch_bounds__(256) void chol_backsolve_kernel(const double *__res
     }
     // finish block jb: x = Linv' y  (Linv lower triangular, zeros above the diagonal are stored)
     const int jb = prologue ? i : i - 1;
-    tile_tdot<KB>(linv_all + (size_t)jb * CNB * CNB, CNB, xs, res);
+    tile_tdot<KB>(linv_all + (size_t)jb * CNB * CNB, CNB, xs, res, stage, part);
     __syncthreads();
     for (int t = tid; t < KB * CNB; t += 256) Y[(int64_t)(k0 + t / CNB) * ldy + (int64_t)jb * CNB + (t % CNB)] = res[t];
 }

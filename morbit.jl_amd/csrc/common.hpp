@@ -53,7 +53,7 @@ struct mrbf_ctx {
     hipEvent_t evx[4] = {};              // cross-stream dependencies of the look-ahead Cholesky
     std::string err;
     // options
-    int gram_mode = 0, residual = 1, force_path = 0, chol_impl = 0, eval_impl = 0, timing = 1;
+    int gram_mode = 0, residual = 1, force_path = 0, chol_impl = 0, eval_impl = 0, timing = 1, diag_impl = 0;
 };
 
 struct mrbf_model {

@@ -205,6 +205,7 @@ int32_t mrbf_set_option(mrbf_ctx *ctx, int32_t key, double value) {
         case MRBF_OPT_CHOL_IMPL: ctx->chol_impl = v; break;
         case MRBF_OPT_EVAL_IMPL: ctx->eval_impl = v; break;
         case MRBF_OPT_TIMING: ctx->timing = v; break;
+        case MRBF_OPT_DIAG_IMPL: ctx->diag_impl = v; break;
         default: return fail(ctx, -2, "unknown option key %d", key);
     }
     return MRBF_OK;
@@ -220,6 +221,7 @@ int32_t mrbf_get_option(const mrbf_ctx *ctx, int32_t key, double *value) {
         case MRBF_OPT_CHOL_IMPL: *value = ctx->chol_impl; break;
         case MRBF_OPT_EVAL_IMPL: *value = ctx->eval_impl; break;
         case MRBF_OPT_TIMING: *value = ctx->timing; break;
+        case MRBF_OPT_DIAG_IMPL: *value = ctx->diag_impl; break;
         default: return -2;
     }
     return MRBF_OK;

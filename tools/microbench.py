@@ -20,10 +20,11 @@ for bpc, thr, it in ((1, 256, 4000), (2, 256, 4000), (4, 256, 4000), (1, 256, -4
 G = np.random.default_rng(0).standard_normal((128, 160))
 A128 = np.asfortranarray(G @ G.T / 160 + np.eye(128))
 cyc, rt = ctypes.c_double(), ctypes.c_double()
-for reps in (64, -64):
+for reps, impl in ((64, 1), (-64, 1), (-64, 0)):
+    ctx.set_option(_lib.OPT_DIAG_IMPL, impl)
     ctx.check(ctx.lib.mrbf_debug_diag(ctx.h, _lib.as_ptr(A128), reps, ctypes.byref(ms), ctypes.byref(cyc), ctypes.byref(rt)))
     out["diag_reps%d" % reps] = dict(us_per_call=ms.value * 1e3, shader_cycles=cyc.value, realtime_us=rt.value)
-    print("diag reps", reps, "us/call", ms.value * 1e3, "cycles", cyc.value, "realtime us", rt.value, "clock GHz", cyc.value / max(rt.value, 1e-9) / 1e3, flush=True)
+    print("diag impl", impl, "reps", reps, "us/call", ms.value * 1e3, "cycles", cyc.value, "realtime us", rt.value, "clock GHz", cyc.value / max(rt.value, 1e-9) / 1e3, flush=True)
 cpm = ctypes.c_double()
 for variant in (0, 1, 2, 3):
     for bpc in (1, 2):
