@@ -1,0 +1,259 @@
+// Fused batched surrogate evaluation on the fp64 matrix cores (dpad <= 128).
+//
+// For a block of 64 query points and a run of 64-centre tiles, per tile:
+//   1. S'[c][q] = <cc_c, xc_q>                     MFMA, A operand = centre tile from LDS, B operand = query fragments
+//                                                  kept in registers for the whole kernel
+//   2. s = |xc_q|^2 + |cc_c|^2 - 2 S', phi(s), psi(s);  per output l:  v_l[q] += w_lc phi,  a_lc = w_lc psi
+//   3. G_l'[t][q] += cc_c[t] a_lc                  MFMA: the a_l tile sits in the C/D register layout with the summed
+//                                                  index c on its ROW axis, which is exactly the B-operand layout of the
+//                                                  next MFMA, so phase 2's output feeds phase 3 with no data movement
+// (the structure of a flash-attention forward pass: centres play K and V, the radial function plays softmax).
+// The centre range is split over gridDim.y so that small query batches still fill the chip; a combine kernel sums the
+// splits in a fixed order, adds the polynomial tail and writes  J_l = (sum_c a_lc) xc - G_l + grad p_l.
+#include "radial.hpp"
+
+namespace mrbf {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+constexpr int EQ = 64;  // queries per workgroup
+constexpr int EC = 64;  // centres per tile
+
+template <int KID, bool FAST, int KOUT, int DT, bool JAC>
+__global__ __launch_bounds__(256, (DT <= 4) ? 2 : 1) void eval_fused_kernel(
+    const double *__restrict__ Xq, const double *__restrict__ xsq, const double *__restrict__ Cc, const double *__restrict__ csq,
+    const double *__restrict__ Wc, int64_t npad, int l0, KP kp, int64_t mpad, int tiles_per_split, double *__restrict__ vpart,
+    double *__restrict__ sapart, double *__restrict__ gpart) {
+    constexpr int D = DT * 16, LDC = D + 2;
+    __shared__ __attribute__((aligned(16))) double Cs[EC * LDC];
+    __shared__ double Ws[KOUT * EC];
+    __shared__ double Sq[EC];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int64_t q0 = (int64_t)blockIdx.x * EQ;
+    const int split = blockIdx.y;
+    const int64_t qrow = q0 + wave * 16 + l15;
+
+    // query fragments: B operand of phase 1, k-slice s -> Xq[qrow][4s + l4]
+    double xb[D / 4];
+#pragma unroll
+    for (int s = 0; s < D / 4; ++s) xb[s] = Xq[qrow * D + 4 * s + l4];
+    const double xs = xsq[qrow];
+
+    v4d JT[KOUT][DT];
+    double vsum[KOUT], sasum[KOUT];
+#pragma unroll
+    for (int l = 0; l < KOUT; ++l) {
+        vsum[l] = 0.0;
+        sasum[l] = 0.0;
+#pragma unroll
+        for (int t = 0; t < DT; ++t) JT[l][t] = (v4d){0.0, 0.0, 0.0, 0.0};
+    }
+
+    // centre-tile staging: 64 rows x D doubles, row-major in global (contiguous 64*D*8 bytes); DT v2d per thread
+    const int64_t c_begin = (int64_t)split * tiles_per_split * EC;
+    constexpr int NLD = 2 * DT;  // 64 * D / 2 v2d over 256 threads
+    v2d stg[NLD];
+    auto load_tile = [&](int64_t c0) {
+        const v2d *src = reinterpret_cast<const v2d *>(Cc + c0 * D);
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) stg[u] = src[tid + 256 * u];
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int e = (tid + 256 * u) * 2;  // element index in the 64 x D tile
+            const int row = e / D, col = e % D;
+            *(v2d *)&Cs[row * LDC + col] = stg[u];
+        }
+    };
+    load_tile(c_begin);
+    for (int tile = 0; tile < tiles_per_split; ++tile) {
+        const int64_t c0 = c_begin + (int64_t)tile * EC;
+        __syncthreads();
+        store_tile();
+        if (tid < EC) Sq[tid] = csq[c0 + tid];
+        for (int e = tid; e < KOUT * EC; e += 256) Ws[e] = Wc[(int64_t)(l0 + e / EC) * npad + c0 + (e % EC)];
+        __syncthreads();
+        if (tile + 1 < tiles_per_split) load_tile(c0 + EC);
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            // ---- phase 1
+            v4d S = {0.0, 0.0, 0.0, 0.0};
+            const double *crow = &Cs[(16 * ct + l15) * LDC + l4];
+#pragma unroll
+            for (int s = 0; s < D / 4; ++s) S = __builtin_amdgcn_mfma_f64_16x16x4f64(crow[4 * s], xb[s], S, 0, 0, 0);
+            // ---- phase 2: C/D layout: register r <-> centre c = 16 ct + l4 + 4 r, lane & 15 <-> query
+            v4d Aw[KOUT];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = 16 * ct + l4 + 4 * r;
+                double s2 = fma(-2.0, S[r], xs + Sq[c]);
+                s2 = s2 > 0.0 ? s2 : 0.0;
+                double phi, psi;
+                rbf_phi_psi_t<KID, FAST>(s2, kp, phi, psi);
+#pragma unroll
+                for (int l = 0; l < KOUT; ++l) {
+                    const double w = Ws[l * EC + c];
+                    vsum[l] = fma(w, phi, vsum[l]);
+                    const double a = w * psi;
+                    sasum[l] += a;
+                    Aw[l][r] = a;
+                }
+            }
+            // ---- phase 3: G_l'[t][q] += sum_c Cc[c][t] a_lc
+            if (JAC) {
+#pragma unroll
+                for (int tt = 0; tt < DT; ++tt) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const double cop = Cs[(16 * ct + 4 * s + l4) * LDC + 16 * tt + l15];
+#pragma unroll
+                        for (int l = 0; l < KOUT; ++l) JT[l][tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(cop, Aw[l][s], JT[l][tt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // ---- reduce the value / sum-of-a accumulators over the four lane groups that share a query (l4 = 0..3)
+#pragma unroll
+    for (int l = 0; l < KOUT; ++l) {
+        vsum[l] += __shfl_xor(vsum[l], 16);
+        vsum[l] += __shfl_xor(vsum[l], 32);
+        sasum[l] += __shfl_xor(sasum[l], 16);
+        sasum[l] += __shfl_xor(sasum[l], 32);
+    }
+    if (l4 == 0) {
+#pragma unroll
+        for (int l = 0; l < KOUT; ++l) {
+            vpart[((int64_t)split * mpad + qrow) * KOUT + l] = vsum[l];
+            sapart[((int64_t)split * mpad + qrow) * KOUT + l] = sasum[l];
+        }
+    }
+    if (JAC) {
+        // G tiles -> gpart[split][q][l][t] through an LDS transpose (per wave 16 q x D), coalesced rows of D doubles
+        __syncthreads();
+        double *T = Cs + wave * 16 * LDC;
+#pragma unroll
+        for (int l = 0; l < KOUT; ++l) {
+#pragma unroll
+            for (int tt = 0; tt < DT; ++tt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) T[l15 * LDC + 16 * tt + l4 + 4 * r] = JT[l][tt][r];
+            __syncthreads();
+            for (int e = lane; e < 16 * D; e += 64) {
+                const int qq = e / D, t = e % D;
+                gpart[(((int64_t)split * mpad + q0 + wave * 16 + qq) * KOUT + l) * D + t] = T[qq * LDC + t];
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// vals[p][l0 + l] = sum_s vpart + p_l(x);   jac[p][t*k + l0 + l] = (sum_s sa) xc[p][t] - sum_s G + lam[t+1]
+template <int KOUT>
+__global__ void eval_combine_kernel(const double *__restrict__ vpart, const double *__restrict__ sapart, const double *__restrict__ gpart,
+                                    int nsplit, int64_t mpad, int64_t m, int D, int d, int k, int l0, const double *__restrict__ Xq,
+                                    const double *__restrict__ Xorig, const double *__restrict__ lam, int q, double *__restrict__ vals,
+                                    double *__restrict__ jac) {
+    const int64_t p = blockIdx.x;
+    if (p >= m) return;
+    __shared__ double sa[KOUT];
+    const int tid = threadIdx.x;
+    if (tid < KOUT && l0 + tid < k) {
+        double v = 0.0, a = 0.0;
+        for (int s = 0; s < nsplit; ++s) {
+            v += vpart[((int64_t)s * mpad + p) * KOUT + tid];
+            a += sapart[((int64_t)s * mpad + p) * KOUT + tid];
+        }
+        sa[tid] = a;
+        if (vals) {
+            if (q > 0) v += lam[l0 + tid];
+            for (int t = 1; t < q; ++t) v = fma(lam[(int64_t)t * k + l0 + tid], Xorig[p * d + t - 1], v);
+            vals[p * k + l0 + tid] = v;
+        }
+    }
+    __syncthreads();
+    if (!jac) return;
+    for (int e = tid; e < KOUT * d; e += blockDim.x) {
+        const int l = e / d, t = e % d;
+        if (l0 + l >= k) continue;
+        double g = 0.0;
+        for (int s = 0; s < nsplit; ++s) g += gpart[(((int64_t)s * mpad + p) * KOUT + l) * D + t];
+        double v = fma(sa[l], Xq[p * D + t], -g);
+        if (q > 1) v += lam[(int64_t)(t + 1) * k + l0 + l];
+        jac[p * (int64_t)k * d + (int64_t)t * k + l0 + l] = v;
+    }
+}
+
+template <int KID, bool FAST, int KOUT, int DT>
+static int launch_fused2(mrbf_ctx *ctx, bool want_jac, dim3 grid, const double *Xq, const double *xsq, const mrbf_model *M, int l0,
+                        int64_t mpad, int tps, double *vpart, double *sapart, double *gpart) {
+    if (want_jac)
+        hipLaunchKernelGGL((eval_fused_kernel<KID, FAST, KOUT, DT, true>), grid, dim3(256), 0, ctx->stream, Xq, xsq, M->Xc, M->sq, M->Wc, M->npad,
+                           l0, M->kp, mpad, tps, vpart, sapart, gpart);
+    else
+        hipLaunchKernelGGL((eval_fused_kernel<KID, FAST, KOUT, DT, false>), grid, dim3(256), 0, ctx->stream, Xq, xsq, M->Xc, M->sq, M->Wc, M->npad,
+                           l0, M->kp, mpad, tps, vpart, sapart, gpart);
+    return 0;
+}
+
+template <int KID, int KOUT, int DT>
+static int launch_fused(mrbf_ctx *ctx, bool want_jac, dim3 grid, const double *Xq, const double *xsq, const mrbf_model *M, int l0,
+                        int64_t mpad, int tps, double *vpart, double *sapart, double *gpart) {
+    if (M->kp.fast && (KID == MRBF_MULTIQUADRIC || KID == MRBF_INV_MULTIQUADRIC || KID == MRBF_CUBIC))
+        return launch_fused2<KID, true, KOUT, DT>(ctx, want_jac, grid, Xq, xsq, M, l0, mpad, tps, vpart, sapart, gpart);
+    return launch_fused2<KID, false, KOUT, DT>(ctx, want_jac, grid, Xq, xsq, M, l0, mpad, tps, vpart, sapart, gpart);
+}
+
+int eval_fused(mrbf_ctx *ctx, const mrbf_model *M, int64_t m, const double *X, double *vals, double *jac, mrbf_eval_info *info) {
+    const int d = M->d, k = M->k, q = M->q;
+    const int D = (M->dpad <= 64) ? 64 : 128;
+    if (M->dpad > 128) return fail(ctx, MRBF_EHIP, "eval_fused supports d <= 128");
+    if (D != M->dpad) return fail(ctx, MRBF_EHIP, "eval_fused needs dpad in {64, 128} (got %d)", M->dpad);
+    const int64_t mpad = round_up(m, EQ);
+    const int ntiles = (int)(M->npad / EC);
+    // split the centre range so that at least ~2 workgroups per CU exist
+    int nsplit = 1;
+    while ((mpad / EQ) * nsplit < 512 && nsplit * 2 <= ntiles && ntiles % (nsplit * 2) == 0) nsplit *= 2;
+    const int tps = ntiles / nsplit;
+    double *Xq, *xsq, *vpart, *sapart, *gpart = nullptr;
+    MRBF_TRY(get_buf(ctx, S_EVAL_XC, (size_t)mpad * D, &Xq));
+    MRBF_TRY(get_buf(ctx, S_EVAL_XSQ, (size_t)mpad, &xsq));
+    const int KO = (k >= 2 && D == 64) ? 2 : 1;  // outputs per pass; at D = 128 two outputs would push the accumulators into
+                                                 // AGPRs, where the f64 MFMA runs at half rate (tools/microbench.py)
+    MRBF_TRY(get_buf(ctx, S_EVAL_SA, (size_t)nsplit * mpad * KO * 2, &vpart));
+    sapart = vpart + (size_t)nsplit * mpad * KO;
+    if (jac) MRBF_TRY(get_buf(ctx, S_EVAL_J, (size_t)nsplit * mpad * KO * D, &gpart));
+    const bool timing = ctx->timing && info;
+    if (timing) MRBF_HIP(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+    MRBF_TRY(launch_center_pad(ctx, X, m, d, M->mean, nullptr, Xq, mpad, D, xsq));
+    dim3 grid((unsigned)(mpad / EQ), (unsigned)nsplit);
+    for (int l0 = 0; l0 < k; l0 += KO) {
+        const int ko = std::min(KO, k - l0);
+#define MRBF_EF(KOV, DTV) MRBF_DISPATCH_KID(M->kp.kid, (launch_fused<KID, KOV, DTV>(ctx, jac != nullptr, grid, Xq, xsq, M, l0, mpad, tps, vpart, sapart, gpart)))
+        if (ko == 2) {
+            MRBF_EF(2, 4);
+            hipLaunchKernelGGL(eval_combine_kernel<2>, dim3((unsigned)m), dim3(128), 0, ctx->stream, vpart, sapart, gpart, nsplit, mpad, m, D,
+                               d, k, l0, Xq, X, M->lam, q, vals, jac);
+        } else {
+            if (D == 64) { MRBF_EF(1, 4); } else { MRBF_EF(1, 8); }
+            hipLaunchKernelGGL(eval_combine_kernel<1>, dim3((unsigned)m), dim3(128), 0, ctx->stream, vpart, sapart, gpart, nsplit, mpad, m, D,
+                               d, k, l0, Xq, X, M->lam, q, vals, jac);
+        }
+#undef MRBF_EF
+    }
+    MRBF_HIP(ctx, hipGetLastError());
+    if (timing) {
+        MRBF_HIP(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
+        MRBF_HIP(ctx, hipEventSynchronize(ctx->ev[7]));
+        float t;
+        MRBF_HIP(ctx, hipEventElapsedTime(&t, ctx->ev[4], ctx->ev[7]));
+        info->ms_total = t;
+        info->ms_kernel = t;
+    }
+    return 0;
+}
+
+}  // namespace mrbf

@@ -81,6 +81,27 @@ __device__ __forceinline__ void rbf_phi_psi(double s, const KP &p, double &phi, 
     }
 }
 
+// compile-time variant of the fast/general switch (keeps pow() out of the register budget of the hot kernels)
+template <int KID, bool FAST>
+__device__ __forceinline__ void rbf_phi_psi_t(double s, const KP &p, double &phi, double &psi) {
+    if constexpr (KID == MRBF_MULTIQUADRIC && FAST) {
+        const double r = sqrt(fma(p.a2, s, 1.0));
+        phi = -r;
+        psi = -p.a2 / r;
+    } else if constexpr (KID == MRBF_INV_MULTIQUADRIC && FAST) {
+        const double t = fma(p.a2, s, 1.0);
+        const double r = 1.0 / sqrt(t);
+        phi = r;
+        psi = -p.a2 * r / t;
+    } else if constexpr (KID == MRBF_CUBIC && FAST) {
+        const double r = sqrt(s);
+        phi = p.sgn * s * r;
+        psi = p.sgn * 3.0 * r;
+    } else {
+        rbf_phi_psi<KID>(s, p, phi, psi);
+    }
+}
+
 // host-side dispatch over the kernel id
 #define MRBF_DISPATCH_KID(kid, ...)                                        \
     switch (kid) {                                                         \

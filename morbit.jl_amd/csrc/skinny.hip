@@ -1,0 +1,198 @@
+// Tall-skinny products of the projection / solve steps.  rocBLAS handles these shapes poorly on this device
+// (profiles/r01_*): a 65 x 65 x 8192 dgemm(T,N) takes 260 us, Phi * Q1 (8192 x 65 x 8192) 900 us.
+//
+//   tsmm_tn        C (p x r) = beta C + alpha A' B      A: n x p, B: n x r column-major, n large, p, r <= ~300
+//                  two deterministic stages: row-chunk partials (VALU, 4 x 4 register blocks from LDS tiles), then a
+//                  fixed-order sum over the chunks.
+//   symm_panel     W (n x q) = Phi Q                    Phi: n x n (full storage), Q: n x q column-major, q <= 272
+//                  f64 MFMA, 128-row blocks x all q columns per workgroup, K split over gridDim.y with per-split
+//                  partial panels summed in a second fixed-order pass.
+#include "common.hpp"
+
+namespace mrbf {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+constexpr int TS_RC = 512;  // rows per chunk
+
+// partial[chunk][i + j*p] for the 64 x 64 output block (blockIdx.y, blockIdx.z)
+__global__ __launch_bounds__(256) void tsmm_tn_partial_kernel(const double *__restrict__ A, int64_t lda, const double *__restrict__ B,
+                                                              int64_t ldb, int64_t n, int p, int r, double *__restrict__ part) {
+    __shared__ double As[16][65];
+    __shared__ double Bs[16][65];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int i0 = blockIdx.y * 64, j0 = blockIdx.z * 64;
+    const int64_t k0 = (int64_t)blockIdx.x * TS_RC;
+    const int64_t kend = (k0 + TS_RC < n) ? k0 + TS_RC : n;
+    double acc[4][4] = {};
+    const int lc = tid >> 2, lk = (tid & 3) * 4;  // staging: column lc (0..63), rows lk..lk+3 of the 16-row slice
+    for (int64_t kb = k0; kb < kend; kb += 16) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t k = kb + lk + u;
+            As[lk + u][lc] = (k < kend && i0 + lc < p) ? A[k + (int64_t)(i0 + lc) * lda] : 0.0;
+            Bs[lk + u][lc] = (k < kend && j0 + lc < r) ? B[k + (int64_t)(j0 + lc) * ldb] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            double a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] = As[kk][tx + 16 * u];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) b[v] = Bs[kk][ty + 16 * v];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) acc[u][v] = fma(a[u], b[v], acc[u][v]);
+        }
+        __syncthreads();
+    }
+    double *out = part + (size_t)blockIdx.x * p * r;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int i = i0 + tx + 16 * u, j = j0 + ty + 16 * v;
+            if (i < p && j < r) out[i + (size_t)j * p] = acc[u][v];
+        }
+}
+
+__global__ void tsmm_tn_reduce_kernel(const double *__restrict__ part, int nchunks, int p, int r, double alpha, double beta,
+                                      double *__restrict__ C, int64_t ldc) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= p * r) return;
+    double s = 0.0;
+    for (int c = 0; c < nchunks; ++c) s += part[(size_t)c * p * r + idx];
+    const int i = idx % p, j = idx / p;
+    double *dst = C + i + (int64_t)j * ldc;
+    *dst = (beta == 0.0) ? alpha * s : fma(alpha, s, beta * *dst);
+}
+
+int tsmm_tn(mrbf_ctx *ctx, int64_t n, int p, int r, double alpha, const double *A, int64_t lda, const double *B, int64_t ldb,
+            double beta, double *C, int64_t ldc) {
+    if (p <= 0 || r <= 0) return 0;
+    const int nchunks = (int)((n + TS_RC - 1) / TS_RC);
+    double *part;
+    MRBF_TRY(get_buf(ctx, S_R, (size_t)nchunks * p * r, &part));
+    hipLaunchKernelGGL(tsmm_tn_partial_kernel, dim3(nchunks, (p + 63) / 64, (r + 63) / 64), dim3(256), 0, ctx->stream, A, lda, B, ldb, n,
+                       p, r, part);
+    hipLaunchKernelGGL(tsmm_tn_reduce_kernel, dim3((p * r + 255) / 256), dim3(256), 0, ctx->stream, part, nchunks, p, r, alpha, beta, C,
+                       ldc);
+    MRBF_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+// ---- W = Phi Q on the matrix cores ----------------------------------------------------------------------------------
+// Workgroup (bi, s): rows [128 bi, 128 bi + 128) x all NJT*16 columns, k range of split s.  Wave w owns rows 32w..32w+31
+// (two 16-row tiles) and every column tile.  Operands staged per 16-wide k chunk: Phi chunk 128 x 16 as in the update
+// kernel ([k][i] rows of 144 doubles), Q chunk 16 x (16 NJT) as [k][j].
+template <int NJT>
+__global__ __launch_bounds__(256, 2) void symm_panel_kernel(const double *__restrict__ Phi, int64_t ld, const double *__restrict__ Q,
+                                                            int64_t ldq, int q, int64_t n, int ksplit_len,
+                                                            double *__restrict__ Wpart, int64_t ldw) {
+    constexpr int LDA_S = 128 + 16;
+    constexpr int LDQ_S = NJT * 16 + ((NJT & 1) ? 0 : 16);  // LD % 32 == 16: the two k rows of a 32-lane half hit disjoint banks
+    __shared__ __attribute__((aligned(16))) double As[16 * LDA_S];
+    __shared__ __attribute__((aligned(16))) double Qs[16 * LDQ_S];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int64_t I0 = (int64_t)blockIdx.x * 128;
+    const int64_t kbeg = (int64_t)blockIdx.y * ksplit_len;
+    const int64_t kend = (kbeg + ksplit_len < n) ? kbeg + ksplit_len : n;
+    v4d acc[NJT][2];
+#pragma unroll
+    for (int j = 0; j < NJT; ++j) {
+        acc[j][0] = (v4d){0.0, 0.0, 0.0, 0.0};
+        acc[j][1] = (v4d){0.0, 0.0, 0.0, 0.0};
+    }
+    const int a_i2 = (tid & 63) * 2, a_k0 = tid >> 6;
+    for (int64_t kb = kbeg; kb < kend; kb += 16) {
+        __syncthreads();
+        // Phi(I0 + i, kb + k): column-major, a wave reads one whole column (1 KiB)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = a_k0 + 4 * u;
+            v2d v = {0.0, 0.0};
+            if (kb + k < kend) v = *(const v2d *)(Phi + I0 + a_i2 + (kb + k) * ld);
+            *(v2d *)&As[k * LDA_S + a_i2] = v;
+        }
+        // Q(kb + k, j): for fixed j, 16 consecutive k are contiguous
+        for (int e = tid; e < 16 * NJT * 16; e += 256) {
+            const int k = e & 15, j = e >> 4;
+            Qs[k * LDQ_S + j] = (j < q && kb + k < kend) ? Q[(kb + k) + (int64_t)j * ldq] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            double a[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = As[(kk * 4 + l4) * LDA_S + wave * 32 + i * 16 + l15];
+#pragma unroll
+            for (int j = 0; j < NJT; ++j) {
+                const double b = Qs[(kk * 4 + l4) * LDQ_S + j * 16 + l15];
+                // D[row = column j of W][col = row i of W]: lane & 15 runs along i, contiguous in the column-major output
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(b, a[i], acc[j][i], 0, 0, 0);
+            }
+        }
+    }
+    double *out = Wpart + (size_t)blockIdx.y * ldw * (NJT * 16);
+#pragma unroll
+    for (int j = 0; j < NJT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int gj = j * 16 + l4 + 4 * r;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) out[(I0 + wave * 32 + i * 16 + l15) + (int64_t)gj * ldw] = acc[j][i][r];
+        }
+}
+
+__global__ void symm_panel_reduce_kernel(const double *__restrict__ Wpart, int nsplit, int64_t ldw, int qp, int64_t n, int q,
+                                         double *__restrict__ W, int64_t ldwo) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * q) return;
+    const int64_t i = idx % n;
+    const int j = (int)(idx / n);
+    double s = 0.0;
+    for (int c = 0; c < nsplit; ++c) s += Wpart[(size_t)c * ldw * qp + i + (int64_t)j * ldw];
+    W[i + (int64_t)j * ldwo] = s;
+}
+
+// W (n x q, ld ldwo) = Phi (npad x npad block, ld) * Q (n x q, ldq); rows >= n of W are left untouched
+int symm_panel(mrbf_ctx *ctx, int64_t n, int64_t npad, int q, const double *Phi, int64_t ld, const double *Q, int64_t ldq, double *W,
+               int64_t ldwo) {
+    int njt = (q + 15) / 16;
+    const int choices[] = {1, 2, 3, 5, 9, 17};
+    int pick = -1;
+    for (int c : choices)
+        if (c >= njt) {
+            pick = c;
+            break;
+        }
+    if (pick < 0) return fail(ctx, -4, "symm_panel: q = %d too wide", q);
+    const int nsplit = 8;
+    const int klen = (int)(round_up((n + nsplit - 1) / nsplit, 16));
+    const int qp = pick * 16;
+    double *Wpart;
+    MRBF_TRY(get_buf(ctx, S_EVAL_A, (size_t)nsplit * npad * qp, &Wpart));
+    dim3 grid((unsigned)(npad / 128), nsplit);
+#define MRBF_SP(NJTV) \
+    hipLaunchKernelGGL((symm_panel_kernel<NJTV>), grid, dim3(256), 0, ctx->stream, Phi, ld, Q, ldq, q, n, klen, Wpart, npad)
+    switch (pick) {
+        case 1: MRBF_SP(1); break;
+        case 2: MRBF_SP(2); break;
+        case 3: MRBF_SP(3); break;
+        case 5: MRBF_SP(5); break;
+        case 9: MRBF_SP(9); break;
+        default: MRBF_SP(17); break;
+    }
+#undef MRBF_SP
+    hipLaunchKernelGGL(symm_panel_reduce_kernel, dim3((unsigned)((n * q + 255) / 256)), dim3(256), 0, ctx->stream, Wpart, nsplit, npad,
+                       qp, n, q, W, ldwo);
+    MRBF_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+}  // namespace mrbf

@@ -136,7 +136,8 @@ int build_model_shell(mrbf_ctx *ctx, int64_t n, int d, int k, const double *Cdev
     M->deg = deg;
     M->q = poly_dim(d, deg);
     M->npad = round_up(n, 128);
-    M->dpad = (int)round_up(d, 16);
+    // the fused evaluation kernel is instantiated for row strides 64 and 128; wider problems keep the minimal padding
+    M->dpad = (d <= 64) ? 64 : (d <= 128 ? 128 : (int)round_up(d, 16));
     M->kp = make_kp(kid, a, b);
     auto alloc = [&](double **p, size_t cnt) { return hipMalloc((void **)p, std::max<size_t>(cnt, 2) * sizeof(double)); };
     hipError_t e = hipSuccess;
@@ -267,6 +268,10 @@ int potrf_blocked_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, i
 int backsolve_blocked(mrbf_ctx *ctx, int64_t npad, const double *L, int64_t lda, const double *linv_all, double *Y, int64_t ldy, int k);
 int launch_update_lower(mrbf_ctx *ctx, const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc, int64_t nt, int K);
 int launch_pad_identity(mrbf_ctx *ctx, double *A, int64_t n, int64_t npad, int64_t ld);
+int tsmm_tn(mrbf_ctx *ctx, int64_t n, int p, int r, double alpha, const double *A, int64_t lda, const double *B, int64_t ldb, double beta,
+            double *C, int64_t ldc);  // skinny.hip
+int symm_panel(mrbf_ctx *ctx, int64_t n, int64_t npad, int q, const double *Phi, int64_t ld, const double *Q, int64_t ldq, double *W,
+               int64_t ldwo);  // skinny.hip
 
 // extra row tile(s) of the extended matrix: row npad + l = right-hand side l (a row), zero beyond k
 __global__ void set_rhs_rows_kernel(double *__restrict__ A, int64_t ld, int64_t npad, int xt, const double *__restrict__ B, int k) {
@@ -364,10 +369,9 @@ static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info
             lt = dq + npad;
             MRBF_TRY(get_buf(ctx, S_PI, (size_t)lt * dq, &Tall));
             MRBF_HIP(ctx, hipMemsetAsync(Tall, 0, (size_t)lt * dq * sizeof(double), ctx->stream));
-            MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_transpose, d, d, (int)n, &one, M->Xc,
-                                         M->dpad, M->Xc, M->dpad, &zero, Tall, (int)lt));
-            MRBF_TRY(launch_pad_identity(ctx, Tall, d, dq, lt));
             hipLaunchKernelGGL(xc_to_tall_kernel, dim3(nblk(n * d)), dim3(256), 0, ctx->stream, M->Xc, n, d, M->dpad, Tall, lt, dq);
+            MRBF_TRY(tsmm_tn(ctx, n, d, d, 1.0, Tall + dq, lt, Tall + dq, lt, 0.0, Tall, lt));  // Gx = Xc' Xc
+            MRBF_TRY(launch_pad_identity(ctx, Tall, d, dq, lt));
             MRBF_TRY(potrf_blocked_tall(ctx, dq, lt, Tall, lt, dinfo, nullptr));
             int hq = 0;
             MRBF_TRY(read_info(ctx, dinfo, &hq));
@@ -380,10 +384,8 @@ static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info
         hipLaunchKernelGGL(build_q1_kernel, dim3(nblk(npad * q)), dim3(256), 0, ctx->stream, Tall, lt, dq, n, npad, q, Q1);
         MRBF_HIP(ctx, hipMemsetAsync(Wm, 0, (size_t)npad * q * sizeof(double), ctx->stream));
         // W1 = Phi Q1 (Phi is stored in full) ; G = Q1' W1 ; W = W1 - 1/2 Q1 G
-        MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, (int)n, q, (int)n, &one, Phi, (int)ld,
-                                     Q1, (int)npad, &zero, Wm, (int)npad));
-        MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, q, q, (int)n, &one, Q1,
-                                     (int)npad, Wm, (int)npad, &zero, G, q));
+        MRBF_TRY(symm_panel(ctx, n, npad, q, Phi, ld, Q1, npad, Wm, npad));
+        MRBF_TRY(tsmm_tn(ctx, n, q, q, 1.0, Q1, npad, Wm, npad, 0.0, G, q));
         hipLaunchKernelGGL(trace_kernel, dim3(1), dim3(256), 0, ctx->stream, G, q, scal);
         MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, (int)n, q, q, &mhalf, Q1, (int)npad,
                                      G, q, &one, Wm, (int)npad));
@@ -406,8 +408,7 @@ static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info
         hipLaunchKernelGGL(build_panels_kernel, dim3(nblk(npad * K2)), dim3(256), 0, ctx->stream, Q1, Wm, mu, n, npad, q, K2, PA, PB);
         MRBF_TRY(launch_update_lower(ctx, PA, npad, PB, npad, Phi, ld, npad / 128, K2));
         // B = P Y = Y - Q1 (Q1' Y);  T1 keeps Q1' Y for lam
-        MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, q, k, (int)n, &one, Q1,
-                                     (int)npad, B, (int)npad, &zero, T1, q));
+        MRBF_TRY(tsmm_tn(ctx, n, q, k, 1.0, Q1, npad, B, npad, 0.0, T1, q));
         MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, (int)n, k, q, &mone, Q1, (int)npad,
                                      T1, q, &one, B, (int)npad));
     }
@@ -441,13 +442,11 @@ static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info
         double *T2;
         MRBF_TRY(get_buf(ctx, S_T2, (size_t)q * k, &T2));
         // re-project w (rounding hygiene): w -= Q1 (Q1' w)
-        MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, q, k, (int)n, &one, Q1,
-                                     (int)npad, B, (int)npad, &zero, T2, q));
+        MRBF_TRY(tsmm_tn(ctx, n, q, k, 1.0, Q1, npad, B, npad, 0.0, T2, q));
         MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, (int)n, k, q, &mone, Q1, (int)npad,
                                      T2, q, &one, B, (int)npad));
         // z = Q1' Y - (Phi Q1)' w;  (Phi Q1)' w = W' w because Q1' w = 0;  lam = R^-1 z
-        MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, q, k, (int)n, &mone, Wm,
-                                     (int)npad, B, (int)npad, &one, T1, q));
+        MRBF_TRY(tsmm_tn(ctx, n, q, k, -1.0, Wm, npad, B, npad, 1.0, T1, q));
         if (q > 1)
             MRBF_BLAS(ctx, rocblas_dtrsm(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose,
                                          rocblas_diagonal_non_unit, d, k, &one, Tall, (int)lt, T1 + 1, q));
@@ -483,8 +482,7 @@ static int fit_check(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_inf
         MRBF_TRY(get_buf(ctx, S_PI, (size_t)n * q, &Pi));
         MRBF_TRY(get_buf(ctx, S_T2, (size_t)q * k, &T));
         MRBF_TRY(launch_poly_matrix(ctx, M->C, n, M->d, q, Pi, n));
-        MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, q, k, (int)n, &one, Pi,
-                                     (int)n, M->Wc, (int)M->npad, &zero, T, q));
+        MRBF_TRY(tsmm_tn(ctx, n, q, k, 1.0, Pi, n, M->Wc, M->npad, 0.0, T, q));
         hipLaunchKernelGGL(max_abs_kernel, dim3(1), dim3(256), 0, ctx->stream, T, (int64_t)q * k, scal + 2);
     }
     MRBF_HIP(ctx, hipGetLastError());
