@@ -76,7 +76,8 @@ enum {
     MRBF_OPT_CHOL_IMPL = 4,    /* 0 = library default, 1 = rocSOLVER potrf, 2 = built-in blocked MFMA Cholesky */
     MRBF_OPT_EVAL_IMPL = 5,    /* 0 = default, 1 = GEMM pipeline, 2 = fused MFMA kernel */
     MRBF_OPT_TIMING = 6,       /* 1 = record per-phase hipEvents (default 1) */
-    MRBF_OPT_DIAG_IMPL = 7     /* diagonal-block kernel of the built-in Cholesky: 0 = MFMA-tiled (default), 1 = column sweep */
+    MRBF_OPT_DIAG_IMPL = 7,    /* diagonal-block kernel of the built-in Cholesky: 0 = MFMA-tiled (default), 1 = column sweep */
+    MRBF_OPT_CHOL_WINDOW = 8   /* panels aggregated per trailing update: 0 = size-dependent schedule (default), else 1, 2 or 4 */
 };
 
 typedef struct {

@@ -15,7 +15,7 @@ c_vp = ctypes.c_void_p
 # error codes (mrbf.h)
 MRBF_OK, MRBF_ENOTPD, MRBF_ESINGULAR, MRBF_EHIP, MRBF_EBLAS, MRBF_ENOMEM, MRBF_ENODEVICE, MRBF_ENCCL = range(8)
 PATH_CHOL, PATH_PROJ_CHOL, PATH_LU, PATH_MINNORM = 1, 2, 3, 4
-OPT_GRAM_MODE, OPT_RESIDUAL, OPT_FORCE_PATH, OPT_CHOL_IMPL, OPT_EVAL_IMPL, OPT_TIMING, OPT_DIAG_IMPL = 1, 2, 3, 4, 5, 6, 7
+OPT_GRAM_MODE, OPT_RESIDUAL, OPT_FORCE_PATH, OPT_CHOL_IMPL, OPT_EVAL_IMPL, OPT_TIMING, OPT_DIAG_IMPL, OPT_CHOL_WINDOW = 1, 2, 3, 4, 5, 6, 7, 8
 
 
 class FitInfo(ctypes.Structure):

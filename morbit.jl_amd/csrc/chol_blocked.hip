@@ -34,7 +34,7 @@ template <int TM, int MODE>
 __global__ __launch_bounds__(256, 2) void chol_update_kernel(const double *__restrict__ A, int64_t lda,
                                                              const double *__restrict__ B, int64_t ldb,
                                                              double *__restrict__ C, int64_t ldc, int K,
-                                                             const int *__restrict__ info, int mt_sq = 0) {
+                                                             const int *__restrict__ info, int mt_sq = 0, int ntiles_total = 0) {
     constexpr int LDA_S = TM + 16;   // LDS row strides (doubles); (2*LD) % 64 == 32 -> k and k+1 rows hit disjoint banks
     constexpr int LDB_S = 128 + 16;
     constexpr int NJ = (TM == 128) ? 4 : 2;  // 16-wide j tiles per wave
@@ -43,13 +43,18 @@ __global__ __launch_bounds__(256, 2) void chol_update_kernel(const double *__res
     double *As = smem;
     double *Bs = smem + CBK * LDA_S;
     if (info && *info != 0) return;  // an earlier diagonal block was not positive definite
+    // panel-chain launches (T, U1) share SIMDs with the bulk update's waves: win the issue arbitration
+    if (MODE == UPD_OVERWRITE || MODE == UPD_COLUMN_SUB) __builtin_amdgcn_s_setprio(2);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
+    // LOWER_SUB launches may be persistent: gridDim.x workgroups stride over ntiles tiles (ntiles_total > gridDim.x), which
+    // leaves CU slots free for the panel chain running on the other stream
+    const int tile_end = (MODE == UPD_LOWER_SUB && ntiles_total > 0) ? ntiles_total : (int)blockIdx.x + 1;
+    for (int bid = blockIdx.x; bid < tile_end; bid += gridDim.x) {
     int ti, tj;
     if (MODE == UPD_LOWER_SUB) {
         // trapezoid: lower-triangular tile pairs of the mt_sq x mt_sq square, then full rows of tiles below it
         const int ntri = mt_sq * (mt_sq + 1) / 2;
-        const int bid = blockIdx.x;
         if (bid < ntri || mt_sq == 0) {
             int t = (int)((sqrt(8.0 * (double)bid + 1.0) - 1.0) * 0.5);
             while ((t + 1) * (t + 2) / 2 <= bid) ++t;
@@ -149,6 +154,8 @@ __global__ __launch_bounds__(256, 2) void chol_update_kernel(const double *__res
             }
         }
     }
+    if (bid + (int)gridDim.x < tile_end) __syncthreads();  // LDS reuse by the next tile
+    }  // persistent tile loop
 }
 
 // ---- D: Cholesky of one 128 x 128 diagonal block + inverse of its factor, ONE sweep -------------------------
@@ -477,15 +484,29 @@ int potrf_blocked_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, i
     // columns >= j+2, the bulk of the flops, which therefore runs UNDER D(j+1) / T(j+1).
     //   U2(j) needs T(j)                      : M waits evT
     //   U1(j+1) writes column j+2 like U2(j)  : P waits evU2 before U1(j+1)
-    hipStream_t M = ctx->stream, P = ctx->panel_stream;
+    // M = stream of the trailing updates (the CU-masked bulk stream), P = panel stream, S = the caller's stream
+    hipStream_t S = ctx->stream, M = ctx->bulk_stream, P = ctx->panel_stream;
     hipEvent_t evStart = ctx->evx[0], evT = ctx->evx[1], evU2 = ctx->evx[2], evEnd = ctx->evx[3];
-    MRBF_HIP(ctx, hipMemsetAsync(dinfo, 0, sizeof(int), M));
-    MRBF_HIP(ctx, hipEventRecord(evStart, M));
+    MRBF_HIP(ctx, hipMemsetAsync(dinfo, 0, sizeof(int), S));
+    MRBF_HIP(ctx, hipEventRecord(evStart, S));
     MRBF_HIP(ctx, hipStreamWaitEvent(P, evStart, 0));
+    MRBF_HIP(ctx, hipStreamWaitEvent(M, evStart, 0));
     const int nb = (int)(ncols / CNB);
     bool have_u2 = false;
+    // Panel aggregation: the bulk update U2 is issued once per WINDOW of W panels with K = 128 W (W = 4 while the
+    // trailing matrix is large: a rank-128 update re-streams the whole trailing matrix from HBM for 16 flop/byte,
+    // rank-512 for 64).  Inside a window U1 applies all of the window's finished panels to the next block column.
+    int w0 = 0, W = 1;
     for (int j = 0; j < nb; ++j) {
         const int64_t c = (int64_t)j * CNB;
+        if (j == w0) {
+            const int64_t rem = ncols - c;
+            W = (rem > 4800) ? 4 : (rem > 2400 ? 2 : 1);
+            if (ctx->chol_window > 0) W = ctx->chol_window;
+        }
+        const bool last_in_window = (j == w0 + W - 1) || (j == nb - 1);
+        const int kpan = (int)((j - w0 + 1) * CNB);        // columns of finished panels in this window
+        const int64_t cw = (int64_t)w0 * CNB;               // first column of the window
         double *Ajj = A + c + c * lda;
         double *Linv = linv_all ? linv_all + (size_t)j * CNB * CNB : Lone;
         if (ctx->diag_impl == 1)
@@ -501,28 +522,50 @@ int potrf_blocked_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, i
                            (int64_t)CNB, A21, lda, CNB, dinfo);
         if (c + CNB >= ncols) break;  // no trailing columns
         MRBF_HIP(ctx, hipEventRecord(evT, P));
-        // U1: block column j+1, every row tile from the diagonal one down to the last (extra) row
+        // U1: block column j+1 gets every finished panel of the window (K = kpan), all row tiles down to the last extra row
         if (have_u2) MRBF_HIP(ctx, hipStreamWaitEvent(P, evU2, 0));
+        const double *Pw = A + (c + CNB) + cw * lda;  // rows from block row j+1 on, columns of the window
         double *A22 = A + (c + CNB) + (c + CNB) * lda;
-        hipLaunchKernelGGL((chol_update_kernel<64, UPD_COLUMN_SUB>), dim3((unsigned)(m / 64), 1), dim3(256), 0, P, A21, lda, A21,
-                           lda, A22, lda, CNB, dinfo);
-        // U2: block columns >= j+2
-        const int64_t mt2 = (ncols - c - 2 * CNB) / CNB;
-        if (mt2 > 0) {
-            MRBF_HIP(ctx, hipStreamWaitEvent(M, evT, 0));
-            const double *P2 = A + (c + 2 * CNB) + c * lda;  // panel rows from block row j+2 on
-            double *C2 = A + (c + 2 * CNB) + (c + 2 * CNB) * lda;
-            const int64_t mx = (mrows - ncols) / CNB;  // extra row tiles below the square ride in the same launch
-            hipLaunchKernelGGL((chol_update_kernel<128, UPD_LOWER_SUB>), dim3((unsigned)(mt2 * (mt2 + 1) / 2 + mx * mt2)), dim3(256), 0,
-                               M, P2, lda, P2, lda, C2, lda, CNB, dinfo, (int)mt2);
-            MRBF_HIP(ctx, hipEventRecord(evU2, M));
-            have_u2 = true;
+        hipLaunchKernelGGL((chol_update_kernel<64, UPD_COLUMN_SUB>), dim3((unsigned)(m / 64), 1), dim3(256), 0, P, Pw, lda, Pw, lda,
+                           A22, lda, kpan, dinfo);
+        if (last_in_window) {
+            // U2: block columns >= j+2 get the whole window in one rank-kpan update, in two launches: U2a = the block
+            // columns of the NEXT window (all the next window's U1 launches depend on), U2b = everything beyond, which
+            // then runs under the next window's D / T / U1 chain.
+            const int64_t mt2 = (ncols - c - 2 * CNB) / CNB;
+            if (mt2 > 0) {
+                MRBF_HIP(ctx, hipStreamWaitEvent(M, evT, 0));
+                const int64_t mx = (mrows - ncols) / CNB;  // extra row tiles below the square ride in the same launches
+                const int64_t rem_next = ncols - c - CNB;
+                int Wn = (rem_next > 4800) ? 4 : (rem_next > 2400 ? 2 : 1);
+                if (ctx->chol_window > 0) Wn = ctx->chol_window;
+                const int64_t na = std::min<int64_t>(Wn, mt2);  // block columns of U2a
+                const double *P2 = A + (c + 2 * CNB) + cw * lda;  // window panels, rows from block row j+2 on
+                double *C2 = A + (c + 2 * CNB) + (c + 2 * CNB) * lda;
+                hipLaunchKernelGGL((chol_update_kernel<128, UPD_LOWER_SUB>),
+                                   dim3((unsigned)(na * (na + 1) / 2 + (mt2 - na + mx) * na)), dim3(256), 0, M, P2, lda, P2, lda, C2, lda,
+                                   kpan, dinfo, (int)na);
+                MRBF_HIP(ctx, hipEventRecord(evU2, M));
+                have_u2 = true;
+                const int64_t mb2 = mt2 - na;  // block columns of U2b
+                if (mb2 > 0) {
+                    const double *P3 = P2 + na * CNB;
+                    double *C3 = C2 + na * CNB + na * CNB * lda;
+                    const int64_t nt3 = mb2 * (mb2 + 1) / 2 + mx * mb2;
+                    const int64_t g3 = (ctx->bulk_grid > 0 && nt3 > ctx->bulk_grid) ? ctx->bulk_grid : nt3;
+                    hipLaunchKernelGGL((chol_update_kernel<128, UPD_LOWER_SUB>), dim3((unsigned)g3), dim3(256), 0, M, P3, lda, P3, lda,
+                                       C3, lda, kpan, dinfo, (int)mb2, (int)nt3);
+                }
+            }
+            w0 = j + 1;
         }
     }
     MRBF_HIP(ctx, hipGetLastError());
-    // join: later work on the main stream must see the panel stream's results
+    // join: later work on the caller's stream must see both side streams' results
     MRBF_HIP(ctx, hipEventRecord(evEnd, P));
-    MRBF_HIP(ctx, hipStreamWaitEvent(M, evEnd, 0));
+    MRBF_HIP(ctx, hipStreamWaitEvent(S, evEnd, 0));
+    MRBF_HIP(ctx, hipEventRecord(evStart, M));
+    MRBF_HIP(ctx, hipStreamWaitEvent(S, evStart, 0));
     return 0;
 }
 

@@ -68,6 +68,7 @@ __global__ __launch_bounds__(256, 1) void chol_diag_v4_kernel(double *__restrict
                                                               int *__restrict__ info, int col0) {
     __shared__ __attribute__((aligned(16))) DiagV4Shared sh;
     if (*info != 0) return;
+    __builtin_amdgcn_s_setprio(3);  // latency-critical: outrank the bulk update's waves sharing this CU's SIMDs
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
     if (tid == 0) sh.bad = 0;

@@ -51,9 +51,12 @@ struct mrbf_ctx {
     hipEvent_t ev[8] = {};
     hipStream_t panel_stream = nullptr;  // high-priority side stream: diagonal block + panel of step j+1 under step j's trailing update
     hipEvent_t evx[4] = {};              // cross-stream dependencies of the look-ahead Cholesky
+    hipStream_t bulk_stream = nullptr;   // CU-masked stream for the aggregated trailing updates: leaves CUs free for the panel chain
+    int bulk_masked = 0;
+    int bulk_grid = 384;  // > 0: cap on the workgroups of a bulk trailing update (persistent tile loop)
     std::string err;
     // options
-    int gram_mode = 0, residual = 1, force_path = 0, chol_impl = 0, eval_impl = 0, timing = 1, diag_impl = 0;
+    int gram_mode = 0, residual = 1, force_path = 0, chol_impl = 0, eval_impl = 0, timing = 1, diag_impl = 0, chol_window = 0;
 };
 
 struct mrbf_model {

@@ -171,6 +171,25 @@ int32_t mrbf_init(int32_t device_id, mrbf_ctx **out) {
     }
     for (auto &ev : ctx->evx)
         if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return bail(MRBF_EHIP, "hipEventCreate");
+    {
+        // bulk stream: every XCD keeps its last 4 CUs (32 of 256) out of the mask, so the panel chain's kernels
+        // (1 workgroup for D, ~m/64 for T / U1) always find idle CUs while a rank-512 trailing update is running
+        if (const char *bg = getenv("MRBF_BULK_GRID")) ctx->bulk_grid = atoi(bg);
+        hipDeviceProp_t prop;
+        int ncu = 256;
+        if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) ncu = prop.multiProcessorCount;
+        const char *env = getenv("MRBF_BULK_RESERVE");
+        const int reserve_per_32 = env ? atoi(env) : 0;  // measured: masking costs more than it buys
+        std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+        for (int cu = 0; cu < ncu; ++cu)
+            if ((cu % 32) < 32 - reserve_per_32) mask[cu / 32] |= (1u << (cu % 32));
+        if (reserve_per_32 > 0 && hipExtStreamCreateWithCUMask(&ctx->bulk_stream, (uint32_t)mask.size(), mask.data()) == hipSuccess) {
+            ctx->bulk_masked = 1;
+        } else {
+            (void)hipGetLastError();
+            if (hipStreamCreateWithFlags(&ctx->bulk_stream, hipStreamNonBlocking) != hipSuccess) return bail(MRBF_EHIP, "hipStreamCreate");
+        }
+    }
     *out = ctx;
     return MRBF_OK;
 }
@@ -189,6 +208,10 @@ int32_t mrbf_shutdown(mrbf_ctx *ctx) {
         (void)hipStreamSynchronize(ctx->panel_stream);
         (void)hipStreamDestroy(ctx->panel_stream);
     }
+    if (ctx->bulk_stream) {
+        (void)hipStreamSynchronize(ctx->bulk_stream);
+        (void)hipStreamDestroy(ctx->bulk_stream);
+    }
     if (ctx->blas) rocblas_destroy_handle(ctx->blas);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -206,6 +229,7 @@ int32_t mrbf_set_option(mrbf_ctx *ctx, int32_t key, double value) {
         case MRBF_OPT_EVAL_IMPL: ctx->eval_impl = v; break;
         case MRBF_OPT_TIMING: ctx->timing = v; break;
         case MRBF_OPT_DIAG_IMPL: ctx->diag_impl = v; break;
+        case MRBF_OPT_CHOL_WINDOW: ctx->chol_window = v; break;
         default: return fail(ctx, -2, "unknown option key %d", key);
     }
     return MRBF_OK;
@@ -222,6 +246,7 @@ int32_t mrbf_get_option(const mrbf_ctx *ctx, int32_t key, double *value) {
         case MRBF_OPT_EVAL_IMPL: *value = ctx->eval_impl; break;
         case MRBF_OPT_TIMING: *value = ctx->timing; break;
         case MRBF_OPT_DIAG_IMPL: *value = ctx->diag_impl; break;
+        case MRBF_OPT_CHOL_WINDOW: *value = ctx->chol_window; break;
         default: return -2;
     }
     return MRBF_OK;

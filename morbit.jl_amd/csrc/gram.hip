@@ -28,7 +28,7 @@ __device__ __forceinline__ void tri_decode(int bid, int &ti, int &tj) {
 }
 
 // Xc: npad x dpad centred + zero padded (npad % 128 == 0, dpad % 16 == 0); sq: npad
-template <int KID>
+template <int KID, bool FAST>
 __global__ __launch_bounds__(256, 2) void gram_mfma_kernel(const double *__restrict__ Xc, const double *__restrict__ sq,
                                                            int64_t n, int dpad, double *__restrict__ Phi, int64_t ld,
                                                            KP p, int aligned16) {
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256, 2) void gram_mfma_kernel(const double *__restr
                 double s = fma(-2.0, acc[i][j][r], sqi + sqj[j]);
                 s = s > 0.0 ? s : 0.0;
                 if (gi == gj) s = 0.0;
-                const double v = rbf_phi<KID>(s, p);
+                const double v = rbf_phi_t<KID, FAST>(s, p);
                 acc[i][j][r] = v;
                 if (gi < n && gj < n) Phi[gi * ld + gj] = v;
             }
@@ -209,8 +209,13 @@ int launch_gram(mrbf_ctx *ctx, int mode, const double *C, const double *Xc, cons
         const int64_t nt = (n + GBM - 1) / GBM;  // tiles that hold at least one real row
         const int64_t nb = nt * (nt + 1) / 2;
         const int aligned16 = ((ld & 1) == 0) && ((reinterpret_cast<uintptr_t>(Phi) & 15) == 0);
-        MRBF_DISPATCH_KID(kp.kid, hipLaunchKernelGGL((gram_mfma_kernel<KID>), dim3((unsigned)nb), dim3(256), 0,
-                                                     ctx->stream, Xc, sq, n, dpad, Phi, ld, kp, aligned16));
+        if (kp.fast) {
+            MRBF_DISPATCH_KID(kp.kid, hipLaunchKernelGGL((gram_mfma_kernel<KID, true>), dim3((unsigned)nb), dim3(256), 0,
+                                                         ctx->stream, Xc, sq, n, dpad, Phi, ld, kp, aligned16));
+        } else {
+            MRBF_DISPATCH_KID(kp.kid, hipLaunchKernelGGL((gram_mfma_kernel<KID, false>), dim3((unsigned)nb), dim3(256), 0,
+                                                         ctx->stream, Xc, sq, n, dpad, Phi, ld, kp, aligned16));
+        }
     }
     MRBF_HIP(ctx, hipGetLastError());
     return 0;

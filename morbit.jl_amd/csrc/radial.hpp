@@ -81,22 +81,68 @@ __device__ __forceinline__ void rbf_phi_psi(double s, const KP &p, double &phi, 
     }
 }
 
+// sqrt(t) and 1/sqrt(t) for t > 0 from the hardware reciprocal-square-root estimate + two coupled Newton steps
+// (Goldschmidt): ~8 fp64 ops instead of the ~30 of the correctly rounded library sqrt + divide.  Relative error
+// <= ~2e-16 (not correctly rounded); the epilogues that use it are VALU-bound otherwise.
+__device__ __forceinline__ void fast_sqrt_rsqrt(double t, double &sq, double &rs) {
+    double y = __builtin_amdgcn_rsq(t);          // ~2^-26 accurate
+    double g = t * y;                            // ~sqrt(t)
+    double h = 0.5 * y;
+    double r = fma(-g, h, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    r = fma(-g, h, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    // one correction of the square root itself
+    const double e = fma(-g, g, t);
+    sq = fma(e, h, g);
+    rs = 2.0 * h;
+}
+
+template <int KID, bool FAST>
+__device__ __forceinline__ double rbf_phi_t(double s, const KP &p) {
+    if constexpr (KID == MRBF_MULTIQUADRIC && FAST) {
+        double sq, rs;
+        fast_sqrt_rsqrt(fma(p.a2, s, 1.0), sq, rs);
+        return -sq;
+    } else if constexpr (KID == MRBF_INV_MULTIQUADRIC && FAST) {
+        double sq, rs;
+        fast_sqrt_rsqrt(fma(p.a2, s, 1.0), sq, rs);
+        return rs;
+    } else if constexpr (KID == MRBF_CUBIC && FAST) {
+        if (s <= 0.0) return 0.0;
+        double sq, rs;
+        fast_sqrt_rsqrt(s, sq, rs);
+        return p.sgn * s * sq;
+    } else {
+        return rbf_phi<KID>(s, p);
+    }
+}
+
 // compile-time variant of the fast/general switch (keeps pow() out of the register budget of the hot kernels)
 template <int KID, bool FAST>
 __device__ __forceinline__ void rbf_phi_psi_t(double s, const KP &p, double &phi, double &psi) {
     if constexpr (KID == MRBF_MULTIQUADRIC && FAST) {
-        const double r = sqrt(fma(p.a2, s, 1.0));
-        phi = -r;
-        psi = -p.a2 / r;
+        double sq, rs;
+        fast_sqrt_rsqrt(fma(p.a2, s, 1.0), sq, rs);
+        phi = -sq;
+        psi = -p.a2 * rs;
     } else if constexpr (KID == MRBF_INV_MULTIQUADRIC && FAST) {
-        const double t = fma(p.a2, s, 1.0);
-        const double r = 1.0 / sqrt(t);
-        phi = r;
-        psi = -p.a2 * r / t;
+        double sq, rs;
+        fast_sqrt_rsqrt(fma(p.a2, s, 1.0), sq, rs);
+        phi = rs;
+        psi = -p.a2 * rs * rs * rs;
     } else if constexpr (KID == MRBF_CUBIC && FAST) {
-        const double r = sqrt(s);
-        phi = p.sgn * s * r;
-        psi = p.sgn * 3.0 * r;
+        if (s <= 0.0) {
+            phi = 0.0;
+            psi = 0.0;
+        } else {
+            double sq, rs;
+            fast_sqrt_rsqrt(s, sq, rs);
+            phi = p.sgn * s * sq;
+            psi = p.sgn * 3.0 * sq;
+        }
     } else {
         rbf_phi_psi<KID>(s, p, phi, psi);
     }

@@ -14,7 +14,7 @@ namespace mrbf {
 typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 
-constexpr int TS_RC = 512;  // rows per chunk
+constexpr int TS_RC = 128;  // rows per chunk (many short chunks: these products are latency-bound, not flop-bound)
 
 // partial[chunk][i + j*p] for the 64 x 64 output block (blockIdx.y, blockIdx.z)
 __global__ __launch_bounds__(256) void tsmm_tn_partial_kernel(const double *__restrict__ A, int64_t lda, const double *__restrict__ B,
@@ -108,22 +108,35 @@ __global__ __launch_bounds__(256, 2) void symm_panel_kernel(const double *__rest
         acc[j][1] = (v4d){0.0, 0.0, 0.0, 0.0};
     }
     const int a_i2 = (tid & 63) * 2, a_k0 = tid >> 6;
-    for (int64_t kb = kbeg; kb < kend; kb += 16) {
-        __syncthreads();
-        // Phi(I0 + i, kb + k): column-major, a wave reads one whole column (1 KiB)
+    // register prefetch of the next 16-wide k chunk (Phi: 4 x 16 B per thread, Q: NJT doubles per thread)
+    v2d ra[4];
+    double rq[NJT];
+    auto fetch = [&](int64_t kb) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int k = a_k0 + 4 * u;
-            v2d v = {0.0, 0.0};
-            if (kb + k < kend) v = *(const v2d *)(Phi + I0 + a_i2 + (kb + k) * ld);
-            *(v2d *)&As[k * LDA_S + a_i2] = v;
+            ra[u] = (v2d){0.0, 0.0};
+            if (kb + k < kend) ra[u] = *(const v2d *)(Phi + I0 + a_i2 + (kb + k) * ld);  // a wave reads one whole column (1 KiB)
         }
-        // Q(kb + k, j): for fixed j, 16 consecutive k are contiguous
-        for (int e = tid; e < 16 * NJT * 16; e += 256) {
+#pragma unroll
+        for (int u = 0; u < NJT; ++u) {
+            const int e = tid + 256 * u;  // e < 16 * 16 * NJT
             const int k = e & 15, j = e >> 4;
-            Qs[k * LDQ_S + j] = (j < q && kb + k < kend) ? Q[(kb + k) + (int64_t)j * ldq] : 0.0;
+            rq[u] = (j < q && kb + k < kend) ? Q[(kb + k) + (int64_t)j * ldq] : 0.0;  // 16 consecutive k are contiguous
+        }
+    };
+    fetch(kbeg);
+    for (int64_t kb = kbeg; kb < kend; kb += 16) {
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) *(v2d *)&As[(a_k0 + 4 * u) * LDA_S + a_i2] = ra[u];
+#pragma unroll
+        for (int u = 0; u < NJT; ++u) {
+            const int e = tid + 256 * u;
+            Qs[(e & 15) * LDQ_S + (e >> 4)] = rq[u];
         }
         __syncthreads();
+        if (kb + 16 < kend) fetch(kb + 16);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             double a[2];
