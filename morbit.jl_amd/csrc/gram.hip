@@ -28,8 +28,8 @@ __device__ __forceinline__ void tri_decode(int bid, int &ti, int &tj) {
 }
 
 // Xc: npad x dpad centred + zero padded (npad % 128 == 0, dpad % 16 == 0); sq: npad
-template <int KID, bool FAST>
-__global__ __launch_bounds__(256, 2) void gram_mfma_kernel(const double *__restrict__ Xc, const double *__restrict__ sq,
+template <int KID, bool FAST, int OCC>
+__global__ __launch_bounds__(256, OCC) void gram_mfma_kernel(const double *__restrict__ Xc, const double *__restrict__ sq,
                                                            int64_t n, int dpad, double *__restrict__ Phi, int64_t ld,
                                                            KP p, int aligned16) {
     __shared__ __attribute__((aligned(16))) double smem[2 * GBM * GLD];
@@ -41,7 +41,6 @@ __global__ __launch_bounds__(256, 2) void gram_mfma_kernel(const double *__restr
     int ti, tj;
     tri_decode(blockIdx.x, ti, tj);
     const int64_t I0 = (int64_t)ti * GBM, J0 = (int64_t)tj * GBM;
-
     v4d acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -52,21 +51,30 @@ __global__ __launch_bounds__(256, 2) void gram_mfma_kernel(const double *__restr
     const double *Ap = Xc + (I0 + lr) * dpad + lc;
     const double *Bp = Xc + (J0 + lr) * dpad + lc;
     v2d ra[4], rb[4];
+    if (OCC <= 2) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        ra[u] = *(const v2d *)(Ap + (int64_t)(32 * u) * dpad);
-        rb[u] = *(const v2d *)(Bp + (int64_t)(32 * u) * dpad);
+        for (int u = 0; u < 4; ++u) {
+            ra[u] = *(const v2d *)(Ap + (int64_t)(32 * u) * dpad);
+            rb[u] = *(const v2d *)(Bp + (int64_t)(32 * u) * dpad);
+        }
     }
     const int nkc = dpad / GBK;
     for (int kc = 0; kc < nkc; ++kc) {
         __syncthreads();
+        if (OCC > 2) {  // no register prefetch: three workgroups per CU hide the load latency instead
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                ra[u] = *(const v2d *)(Ap + (int64_t)(32 * u) * dpad + kc * GBK);
+                rb[u] = *(const v2d *)(Bp + (int64_t)(32 * u) * dpad + kc * GBK);
+            }
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             *(v2d *)&As[(lr + 32 * u) * GLD + lc] = ra[u];
             *(v2d *)&Bs[(lr + 32 * u) * GLD + lc] = rb[u];
         }
         __syncthreads();
-        if (kc + 1 < nkc) {
+        if (OCC <= 2 && kc + 1 < nkc) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 ra[u] = *(const v2d *)(Ap + (int64_t)(32 * u) * dpad + (kc + 1) * GBK);
@@ -209,11 +217,15 @@ int launch_gram(mrbf_ctx *ctx, int mode, const double *C, const double *Xc, cons
         const int64_t nt = (n + GBM - 1) / GBM;  // tiles that hold at least one real row
         const int64_t nb = nt * (nt + 1) / 2;
         const int aligned16 = ((ld & 1) == 0) && ((reinterpret_cast<uintptr_t>(Phi) & 15) == 0);
-        if (kp.fast) {
-            MRBF_DISPATCH_KID(kp.kid, hipLaunchKernelGGL((gram_mfma_kernel<KID, true>), dim3((unsigned)nb), dim3(256), 0,
+        static const int occ3 = getenv("MRBF_GRAM_OCC3") ? atoi(getenv("MRBF_GRAM_OCC3")) : 0;
+        if (kp.fast && occ3) {
+            MRBF_DISPATCH_KID(kp.kid, hipLaunchKernelGGL((gram_mfma_kernel<KID, true, 3>), dim3((unsigned)nb), dim3(256), 0,
+                                                         ctx->stream, Xc, sq, n, dpad, Phi, ld, kp, aligned16));
+        } else if (kp.fast) {
+            MRBF_DISPATCH_KID(kp.kid, hipLaunchKernelGGL((gram_mfma_kernel<KID, true, 2>), dim3((unsigned)nb), dim3(256), 0,
                                                          ctx->stream, Xc, sq, n, dpad, Phi, ld, kp, aligned16));
         } else {
-            MRBF_DISPATCH_KID(kp.kid, hipLaunchKernelGGL((gram_mfma_kernel<KID, false>), dim3((unsigned)nb), dim3(256), 0,
+            MRBF_DISPATCH_KID(kp.kid, hipLaunchKernelGGL((gram_mfma_kernel<KID, false, 2>), dim3((unsigned)nb), dim3(256), 0,
                                                          ctx->stream, Xc, sq, n, dpad, Phi, ld, kp, aligned16));
         }
     }
