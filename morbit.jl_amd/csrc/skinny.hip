@@ -91,7 +91,7 @@ int tsmm_tn(mrbf_ctx *ctx, int64_t n, int p, int r, double alpha, const double *
 template <int NJT>
 __global__ __launch_bounds__(256, 2) void symm_panel_kernel(const double *__restrict__ Phi, int64_t ld, const double *__restrict__ Q,
                                                             int64_t ldq, int q, int64_t n, int ksplit_len,
-                                                            double *__restrict__ Wpart, int64_t ldw) {
+                                                            double *__restrict__ Wpart, int64_t ldw, int qp_total) {
     constexpr int LDA_S = 128 + 16;
     constexpr int LDQ_S = NJT * 16 + ((NJT & 1) ? 0 : 16);  // LD % 32 == 16: the two k rows of a 32-lane half hit disjoint banks
     __shared__ __attribute__((aligned(16))) double As[16 * LDA_S];
@@ -101,6 +101,7 @@ __global__ __launch_bounds__(256, 2) void symm_panel_kernel(const double *__rest
     const int64_t I0 = (int64_t)blockIdx.x * 128;
     const int64_t kbeg = (int64_t)blockIdx.y * ksplit_len;
     const int64_t kend = (kbeg + ksplit_len < n) ? kbeg + ksplit_len : n;
+    const int jg0 = blockIdx.z * NJT * 16;  // first column of this workgroup's column group
     v4d acc[NJT][2];
 #pragma unroll
     for (int j = 0; j < NJT; ++j) {
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(256, 2) void symm_panel_kernel(const double *__rest
 #pragma unroll
         for (int u = 0; u < NJT; ++u) {
             const int e = tid + 256 * u;  // e < 16 * 16 * NJT
-            const int k = e & 15, j = e >> 4;
+            const int k = e & 15, j = jg0 + (e >> 4);
             rq[u] = (j < q && kb + k < kend) ? Q[(kb + k) + (int64_t)j * ldq] : 0.0;  // 16 consecutive k are contiguous
         }
     };
@@ -151,12 +152,12 @@ __global__ __launch_bounds__(256, 2) void symm_panel_kernel(const double *__rest
             }
         }
     }
-    double *out = Wpart + (size_t)blockIdx.y * ldw * (NJT * 16);
+    double *out = Wpart + (size_t)blockIdx.y * ldw * qp_total;
 #pragma unroll
     for (int j = 0; j < NJT; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int gj = j * 16 + l4 + 4 * r;
+            const int gj = jg0 + j * 16 + l4 + 4 * r;
 #pragma unroll
             for (int i = 0; i < 2; ++i) out[(I0 + wave * 32 + i * 16 + l15) + (int64_t)gj * ldw] = acc[j][i][r];
         }
@@ -177,29 +178,30 @@ __global__ void symm_panel_reduce_kernel(const double *__restrict__ Wpart, int n
 int symm_panel(mrbf_ctx *ctx, int64_t n, int64_t npad, int q, const double *Phi, int64_t ld, const double *Q, int64_t ldq, double *W,
                int64_t ldwo) {
     int njt = (q + 15) / 16;
-    const int choices[] = {1, 2, 3, 5, 9, 17};
-    int pick = -1;
+    // column tiles per workgroup: at most 9 (144 accumulator VGPRs; 17 would spill into AGPRs, where the f64 MFMA runs at
+    // half rate, and to scratch: measured 27 ms instead of ~4 at q = 257); wider panels are cut into column groups
+    const int choices[] = {1, 2, 3, 5, 9};
+    int pick = 9;
     for (int c : choices)
         if (c >= njt) {
             pick = c;
             break;
         }
-    if (pick < 0) return fail(ctx, -4, "symm_panel: q = %d too wide", q);
+    const int ngroups = (njt + pick - 1) / pick;
     const int nsplit = 8;
     const int klen = (int)(round_up((n + nsplit - 1) / nsplit, 16));
-    const int qp = pick * 16;
+    const int qp = ngroups * pick * 16;
     double *Wpart;
     MRBF_TRY(get_buf(ctx, S_EVAL_A, (size_t)nsplit * npad * qp, &Wpart));
-    dim3 grid((unsigned)(npad / 128), nsplit);
+    dim3 grid((unsigned)(npad / 128), nsplit, ngroups);
 #define MRBF_SP(NJTV) \
-    hipLaunchKernelGGL((symm_panel_kernel<NJTV>), grid, dim3(256), 0, ctx->stream, Phi, ld, Q, ldq, q, n, klen, Wpart, npad)
+    hipLaunchKernelGGL((symm_panel_kernel<NJTV>), grid, dim3(256), 0, ctx->stream, Phi, ld, Q, ldq, q, n, klen, Wpart, npad, qp)
     switch (pick) {
         case 1: MRBF_SP(1); break;
         case 2: MRBF_SP(2); break;
         case 3: MRBF_SP(3); break;
         case 5: MRBF_SP(5); break;
-        case 9: MRBF_SP(9); break;
-        default: MRBF_SP(17); break;
+        default: MRBF_SP(9); break;
     }
 #undef MRBF_SP
     hipLaunchKernelGGL(symm_panel_reduce_kernel, dim3((unsigned)((n * q + 255) / 256)), dim3(256), 0, ctx->stream, Wpart, nsplit, npad,
