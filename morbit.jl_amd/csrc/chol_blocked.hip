@@ -523,7 +523,11 @@ int potrf_blocked_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, i
         if (c + CNB >= ncols) break;  // no trailing columns
         MRBF_HIP(ctx, hipEventRecord(evT, P));
         // U1: block column j+1 gets every finished panel of the window (K = kpan), all row tiles down to the last extra row
-        if (have_u2) MRBF_HIP(ctx, hipStreamWaitEvent(P, evU2, 0));
+        // (a cross-stream wait costs ~10 us even when the event has long fired: wait once per recorded event)
+        if (have_u2) {
+            MRBF_HIP(ctx, hipStreamWaitEvent(P, evU2, 0));
+            have_u2 = false;
+        }
         const double *Pw = A + (c + CNB) + cw * lda;  // rows from block row j+1 on, columns of the window
         double *A22 = A + (c + CNB) + (c + CNB) * lda;
         hipLaunchKernelGGL((chol_update_kernel<64, UPD_COLUMN_SUB>), dim3((unsigned)(m / 64), 1), dim3(256), 0, P, Pw, lda, Pw, lda,

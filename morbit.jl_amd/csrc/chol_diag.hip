@@ -36,10 +36,10 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 }
 
 __device__ __forceinline__ double fast_rsqrt_v4(double x) {
-    double y = __builtin_amdgcn_rsq(x);
+    double y = __builtin_amdgcn_rsq(x);  // ~2^-26 relative: two Newton steps reach full double precision
     const double h = 0.5 * x;
 #pragma unroll
-    for (int it = 0; it < 3; ++it) y = y * fma(-h, y * y, 1.5);
+    for (int it = 0; it < 2; ++it) y = y * fma(-h, y * y, 1.5);
     return y;
 }
 
@@ -49,13 +49,12 @@ __device__ __forceinline__ double opnd(const double *tile, int s, int l15, int l
 // leaf: rows of the 16 x 16 s.p.d. block in lanes 0..15 (a[c], c <= lane valid), identity rows in lanes 16..31
 template <int K>
 __device__ __forceinline__ void leaf_step(double (&a)[16], int &bad, int col0) {
+    // branch-free so that the 16 unrolled steps form one basic block: the scheduler can then start step K+1's
+    // pivot -> rsqrt chain under the remaining column updates of step K
     const double piv = readlane_f64(a[K], K);
-    double rinv = 0.0;
-    if (piv > 0.0) {
-        rinv = fast_rsqrt_v4(piv);
-    } else if (bad == 0) {
-        bad = col0 + K + 1;
-    }
+    const bool ok = piv > 0.0;
+    const double rinv = ok ? fast_rsqrt_v4(ok ? piv : 1.0) : 0.0;
+    bad = (!ok && bad == 0) ? col0 + K + 1 : bad;
     a[K] *= rinv;
 #pragma unroll
     for (int j = K + 1; j < 16; ++j) {
