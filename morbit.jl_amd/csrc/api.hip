@@ -1,5 +1,6 @@
 // extern "C" entry points of include/mrbf.h (argument checking, staging of host buffers, dispatch).
 #include <algorithm>
+#include <mutex>
 #include <thread>
 
 #include "common.hpp"
@@ -21,6 +22,33 @@ static int check_kernel(mrbf_ctx *ctx, int kid, double a, double b, int deg, int
         return fail(ctx, -(argpos + 2), "inverse multiquadric exponent must be positive (got %g)", b);
     if (deg < -1 || deg > 1) return fail(ctx, -(argpos + 3), "polynomial_degree must be -1, 0 or 1 (RbfModel.jl:21), got %d", deg);
     return 0;
+}
+
+// contexts of mrbf_batch_run's worker threads are kept between calls (creating a rocBLAS handle and streams costs tens of
+// milliseconds, more than a whole small problem)
+static std::mutex g_pool_mutex;
+static std::vector<mrbf_ctx *> g_ctx_pool;
+static mrbf_ctx *pool_acquire(int device, int *rc) {
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mutex);
+        for (size_t i = 0; i < g_ctx_pool.size(); ++i)
+            if (g_ctx_pool[i]->device == device) {
+                mrbf_ctx *c = g_ctx_pool[i];
+                g_ctx_pool.erase(g_ctx_pool.begin() + i);
+                *rc = 0;
+                return c;
+            }
+    }
+    mrbf_ctx *c = nullptr;
+    *rc = mrbf_init(device, &c);
+    return c;
+}
+static void pool_release(mrbf_ctx *c) {
+    std::lock_guard<std::mutex> lk(g_pool_mutex);
+    if (g_ctx_pool.size() < 64)
+        g_ctx_pool.push_back(c);
+    else
+        mrbf_shutdown(c);
 }
 
 extern "C" {
@@ -83,7 +111,7 @@ int32_t mrbf_fit(mrbf_ctx *ctx, int64_t n, int32_t d, int32_t k, const double *c
     int rc = fit_model(ctx, M, Y, info);
     if (rc != 0) {
         (void)hipStreamSynchronize(ctx->stream);
-        destroy_model(M);
+        destroy_model(ctx, M);
         return rc;
     }
     if (weights_out) {
@@ -238,7 +266,7 @@ int32_t mrbf_free_model(mrbf_ctx *ctx, mrbf_model *model) {
     if (!model) return MRBF_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    destroy_model(model);
+    destroy_model(ctx, model);
     return MRBF_OK;
 }
 
@@ -254,20 +282,29 @@ int32_t mrbf_batch_run(int32_t n_dev, const int32_t *device_ids, int64_t n_probl
         devs[g] = device_ids ? device_ids[g] : g;
         if (devs[g] < 0 || devs[g] >= visible) return -2;
     }
-    std::vector<int> rcs(n_dev, 0);
-    auto worker = [&](int g) {
-        mrbf_ctx *ctx = nullptr;
-        int rc = mrbf_init(devs[g], &ctx);
+    // small problems are launch-latency bound: several host threads (each with its own context and streams) per GPU keep
+    // more kernels in flight; large problems fill the chip on their own
+    int64_t nmax = 0;
+    for (int64_t p = 0; p < n_problems; ++p) nmax = std::max<int64_t>(nmax, problems[p].n);
+    int per_dev = (nmax <= 2048) ? 4 : 1;
+    if (const char *e = getenv("MRBF_BATCH_WORKERS")) per_dev = std::max(1, atoi(e));
+    per_dev = (int)std::max<int64_t>(1, std::min<int64_t>(per_dev, (n_problems + n_dev - 1) / n_dev));
+    const int n_workers = n_dev * per_dev;
+    std::vector<int> rcs(n_workers, 0);
+    auto worker = [&](int w) {
+        const int g = w % n_dev;
+        int rc = 0;
+        mrbf_ctx *ctx = pool_acquire(devs[g], &rc);
         if (rc != 0) {
-            rcs[g] = rc;
-            for (int64_t p = g; p < n_problems; p += n_dev) {
+            rcs[w] = rc;
+            for (int64_t p = w; p < n_problems; p += n_workers) {
                 std::memset(&results[p], 0, sizeof(mrbf_result));
                 results[p].status = rc;
                 results[p].device = devs[g];
             }
             return;
         }
-        for (int64_t p = g; p < n_problems; p += n_dev) {  // round-robin shard, no exchange between problems
+        for (int64_t p = w; p < n_problems; p += n_workers) {  // round-robin shard (problem p -> GPU p % n_dev), no exchange
             const mrbf_problem &pr = problems[p];
             mrbf_result &res = results[p];
             std::memset(&res, 0, sizeof(res));
@@ -296,13 +333,13 @@ int32_t mrbf_batch_run(int32_t n_dev, const int32_t *device_ids, int64_t n_probl
                 for (size_t i = 0; M && i < (size_t)pr.n * pr.k; ++i) res.checksum_w += wout[i];
             if (M) mrbf_free_model(ctx, M);
         }
-        mrbf_shutdown(ctx);
+        pool_release(ctx);
     };
     std::vector<std::thread> th;
-    for (int g = 0; g < n_dev; ++g) th.emplace_back(worker, g);
+    for (int w = 0; w < n_workers; ++w) th.emplace_back(worker, w);
     for (auto &t : th) t.join();
-    for (int g = 0; g < n_dev; ++g)
-        if (rcs[g] != 0) return rcs[g];
+    for (int w = 0; w < n_workers; ++w)
+        if (rcs[w] != 0) return rcs[w];
     return MRBF_OK;
 }
 

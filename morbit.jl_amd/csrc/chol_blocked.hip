@@ -487,10 +487,16 @@ int potrf_blocked_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, i
     // M = stream of the trailing updates (the CU-masked bulk stream), P = panel stream, S = the caller's stream
     hipStream_t S = ctx->stream, M = ctx->bulk_stream, P = ctx->panel_stream;
     hipEvent_t evStart = ctx->evx[0], evT = ctx->evx[1], evU2 = ctx->evx[2], evEnd = ctx->evx[3];
+    // small factorisations run on the caller's stream alone: every cross-stream wait costs ~10 us, more than the
+    // look-ahead can win back on a handful of panels
+    const bool single = ncols <= 4 * CNB;
+    if (single) M = P = S;
     MRBF_HIP(ctx, hipMemsetAsync(dinfo, 0, sizeof(int), S));
-    MRBF_HIP(ctx, hipEventRecord(evStart, S));
-    MRBF_HIP(ctx, hipStreamWaitEvent(P, evStart, 0));
-    MRBF_HIP(ctx, hipStreamWaitEvent(M, evStart, 0));
+    if (!single) {
+        MRBF_HIP(ctx, hipEventRecord(evStart, S));
+        MRBF_HIP(ctx, hipStreamWaitEvent(P, evStart, 0));
+        MRBF_HIP(ctx, hipStreamWaitEvent(M, evStart, 0));
+    }
     const int nb = (int)(ncols / CNB);
     bool have_u2 = false;
     // Panel aggregation: the bulk update U2 is issued once per WINDOW of W panels with K = 128 W (W = 4 while the
@@ -521,10 +527,10 @@ int potrf_blocked_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, i
         hipLaunchKernelGGL((chol_update_kernel<64, UPD_OVERWRITE>), dim3((unsigned)(m / 64), 1), dim3(256), 0, P, A21, lda, Linv,
                            (int64_t)CNB, A21, lda, CNB, dinfo);
         if (c + CNB >= ncols) break;  // no trailing columns
-        MRBF_HIP(ctx, hipEventRecord(evT, P));
+        if (!single) MRBF_HIP(ctx, hipEventRecord(evT, P));
         // U1: block column j+1 gets every finished panel of the window (K = kpan), all row tiles down to the last extra row
         // (a cross-stream wait costs ~10 us even when the event has long fired: wait once per recorded event)
-        if (have_u2) {
+        if (have_u2 && !single) {
             MRBF_HIP(ctx, hipStreamWaitEvent(P, evU2, 0));
             have_u2 = false;
         }
@@ -538,7 +544,7 @@ int potrf_blocked_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, i
             // then runs under the next window's D / T / U1 chain.
             const int64_t mt2 = (ncols - c - 2 * CNB) / CNB;
             if (mt2 > 0) {
-                MRBF_HIP(ctx, hipStreamWaitEvent(M, evT, 0));
+                if (!single) MRBF_HIP(ctx, hipStreamWaitEvent(M, evT, 0));
                 const int64_t mx = (mrows - ncols) / CNB;  // extra row tiles below the square ride in the same launches
                 const int64_t rem_next = ncols - c - CNB;
                 int Wn = (rem_next > 4800) ? 4 : (rem_next > 2400 ? 2 : 1);
@@ -549,7 +555,7 @@ int potrf_blocked_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, i
                 hipLaunchKernelGGL((chol_update_kernel<128, UPD_LOWER_SUB>),
                                    dim3((unsigned)(na * (na + 1) / 2 + (mt2 - na + mx) * na)), dim3(256), 0, M, P2, lda, P2, lda, C2, lda,
                                    kpan, dinfo, (int)na);
-                MRBF_HIP(ctx, hipEventRecord(evU2, M));
+                if (!single) MRBF_HIP(ctx, hipEventRecord(evU2, M));
                 have_u2 = true;
                 const int64_t mb2 = mt2 - na;  // block columns of U2b
                 if (mb2 > 0) {
@@ -566,10 +572,12 @@ int potrf_blocked_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, i
     }
     MRBF_HIP(ctx, hipGetLastError());
     // join: later work on the caller's stream must see both side streams' results
-    MRBF_HIP(ctx, hipEventRecord(evEnd, P));
-    MRBF_HIP(ctx, hipStreamWaitEvent(S, evEnd, 0));
-    MRBF_HIP(ctx, hipEventRecord(evStart, M));
-    MRBF_HIP(ctx, hipStreamWaitEvent(S, evStart, 0));
+    if (!single) {
+        MRBF_HIP(ctx, hipEventRecord(evEnd, P));
+        MRBF_HIP(ctx, hipStreamWaitEvent(S, evEnd, 0));
+        MRBF_HIP(ctx, hipEventRecord(evStart, M));
+        MRBF_HIP(ctx, hipStreamWaitEvent(S, evStart, 0));
+    }
     return 0;
 }
 

@@ -55,6 +55,8 @@ struct mrbf_ctx {
     int bulk_masked = 0;
     int bulk_grid = 384;  // > 0: cap on the workgroups of a bulk trailing update (persistent tile loop)
     std::string err;
+    std::vector<mrbf::Buf> model_pool;  // released model blocks, reused by the next model of similar size (hipMalloc/hipFree cost
+                                        // ~0.1-0.3 ms each and serialise across host threads)
     // options
     int gram_mode = 0, residual = 1, force_path = 0, chol_impl = 0, eval_impl = 0, timing = 1, diag_impl = 0, chol_window = 0;
 };
@@ -70,6 +72,8 @@ struct mrbf_model {
     double *W = nullptr;     // n x k row-major weights
     double *Wc = nullptr;    // npad x k column-major weights (zero padded) for the GEMM-shaped contractions
     double *lam = nullptr;   // q x k row-major
+    void *block = nullptr;   // one device allocation carved into the arrays above
+    size_t block_bytes = 0;
 };
 
 namespace mrbf {
@@ -127,6 +131,6 @@ int potrf_lower(mrbf_ctx *ctx, int impl, int64_t n, double *A, int64_t lda, int 
 int fit_model(mrbf_ctx *ctx, mrbf_model *M, const double *Ydev, mrbf_fit_info *info);
 int build_model_shell(mrbf_ctx *ctx, int64_t n, int d, int k, const double *Cdev, int kid, double a, double b, int deg,
                       mrbf_model **out);
-void destroy_model(mrbf_model *M);
+void destroy_model(mrbf_ctx *ctx, mrbf_model *M);
 
 }  // namespace mrbf

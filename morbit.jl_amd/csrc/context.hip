@@ -200,6 +200,8 @@ int32_t mrbf_shutdown(mrbf_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (auto &b : ctx->slots)
         if (b.p) (void)hipFree(b.p);
+    for (auto &b : ctx->model_pool)
+        if (b.p) (void)hipFree(b.p);
     for (auto &ev : ctx->ev)
         if (ev) (void)hipEventDestroy(ev);
     for (auto &ev : ctx->evx)

@@ -120,10 +120,21 @@ __global__ void residual_kernel(const double *__restrict__ a, const double *__re
 
 static inline unsigned nblk(int64_t cnt) { return (unsigned)((cnt + 255) / 256); }
 
-void destroy_model(mrbf_model *M) {
+void destroy_model(mrbf_ctx *ctx, mrbf_model *M) {
     if (!M) return;
-    for (double *p : {M->C, M->Xc, M->sq, M->mean, M->W, M->Wc, M->lam})
-        if (p) (void)hipFree(p);
+    if (M->block) {
+        size_t pooled = 0;
+        if (ctx)
+            for (auto &b : ctx->model_pool) pooled += b.bytes;
+        if (ctx && ctx->model_pool.size() < 8 && pooled + M->block_bytes <= (size_t(8) << 30)) {
+            Buf b;
+            b.p = M->block;
+            b.bytes = M->block_bytes;
+            ctx->model_pool.push_back(b);
+        } else {
+            (void)hipFree(M->block);
+        }
+    }
     delete M;
 }
 
@@ -139,19 +150,45 @@ int build_model_shell(mrbf_ctx *ctx, int64_t n, int d, int k, const double *Cdev
     // the fused evaluation kernel is instantiated for row strides 64 and 128; wider problems keep the minimal padding
     M->dpad = (d <= 64) ? 64 : (d <= 128 ? 128 : (int)round_up(d, 16));
     M->kp = make_kp(kid, a, b);
-    auto alloc = [&](double **p, size_t cnt) { return hipMalloc((void **)p, std::max<size_t>(cnt, 2) * sizeof(double)); };
-    hipError_t e = hipSuccess;
-    if (e == hipSuccess) e = alloc(&M->C, (size_t)n * d);
-    if (e == hipSuccess) e = alloc(&M->Xc, (size_t)M->npad * M->dpad);
-    if (e == hipSuccess) e = alloc(&M->sq, (size_t)M->npad);
-    if (e == hipSuccess) e = alloc(&M->mean, (size_t)M->dpad);
-    if (e == hipSuccess) e = alloc(&M->W, (size_t)n * k);
-    if (e == hipSuccess) e = alloc(&M->Wc, (size_t)M->npad * k);
-    if (e == hipSuccess) e = alloc(&M->lam, (size_t)std::max(M->q, 1) * k);
-    if (e != hipSuccess) {
-        destroy_model(M);
-        return fail(ctx, MRBF_ENOMEM, "model allocation failed: %s", hipGetErrorString(e));
+    // one block, carved at 256-byte granularity
+    const size_t cnt[7] = {(size_t)n * d, (size_t)M->npad * M->dpad, (size_t)M->npad, (size_t)M->dpad, (size_t)n * k,
+                           (size_t)M->npad * k, (size_t)std::max(M->q, 1) * k};
+    size_t off[8];
+    off[0] = 0;
+    for (int i = 0; i < 7; ++i) off[i + 1] = off[i] + ((std::max<size_t>(cnt[i], 2) * sizeof(double) + 255) & ~size_t(255));
+    const size_t total = off[7];
+    // reuse a released block when one fits without wasting more than half of it
+    int best = -1;
+    for (int i = 0; i < (int)ctx->model_pool.size(); ++i)
+        if (ctx->model_pool[i].bytes >= total && ctx->model_pool[i].bytes <= 2 * total &&
+            (best < 0 || ctx->model_pool[i].bytes < ctx->model_pool[best].bytes))
+            best = i;
+    if (best >= 0) {
+        M->block = ctx->model_pool[best].p;
+        M->block_bytes = ctx->model_pool[best].bytes;
+        ctx->model_pool.erase(ctx->model_pool.begin() + best);
+    } else {
+        hipError_t e = hipMalloc(&M->block, total);
+        if (e != hipSuccess) {
+            // drop the pool and retry once before giving up
+            for (auto &b : ctx->model_pool) (void)hipFree(b.p);
+            ctx->model_pool.clear();
+            e = hipMalloc(&M->block, total);
+        }
+        if (e != hipSuccess) {
+            delete M;
+            return fail(ctx, MRBF_ENOMEM, "model allocation failed: %s", hipGetErrorString(e));
+        }
+        M->block_bytes = total;
     }
+    char *base = (char *)M->block;
+    M->C = (double *)(base + off[0]);
+    M->Xc = (double *)(base + off[1]);
+    M->sq = (double *)(base + off[2]);
+    M->mean = (double *)(base + off[3]);
+    M->W = (double *)(base + off[4]);
+    M->Wc = (double *)(base + off[5]);
+    M->lam = (double *)(base + off[6]);
     if (Cdev != M->C)
         MRBF_HIP(ctx, hipMemcpyAsync(M->C, Cdev, (size_t)n * d * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     MRBF_TRY(launch_center_pad(ctx, M->C, n, d, nullptr, M->mean, M->Xc, M->npad, M->dpad, M->sq));
@@ -308,11 +345,21 @@ __global__ void build_q1_kernel(const double *__restrict__ Tall, int64_t lt, int
     if (i < n) v = (t == 0) ? 1.0 / sqrt((double)n) : Tall[(dq + i) + (int64_t)(t - 1) * lt];
     Q1[idx] = v;
 }
+// scal[0] = trace(Q1' Phi Q1)  ->  scal[1] = mu = (n phi0 - trace) / (n - q), the mean eigenvalue of Z' Phi Z;
+// flags[2] = 1 when mu is not positive (Z' Phi Z cannot be positive definite).  Kept on the device: no host round trip.
+__global__ void shift_from_trace_kernel(double *__restrict__ scal, double nphi0, double nmq, int *__restrict__ flags) {
+    const double mu = (nphi0 - scal[0]) / nmq;
+    const bool ok = mu > 0.0 && mu < 1e300;
+    scal[1] = ok ? mu : 1.0;
+    flags[2] = ok ? 0 : 1;
+}
+
 // PA = [Q1 | V | 0], PB = [V | Q1 | 0] with V = W - (mu/2) Q1   (npad x K2, ld npad)
-__global__ void build_panels_kernel(const double *__restrict__ Q1, const double *__restrict__ W, double mu, int64_t n, int64_t npad,
-                                    int q, int K2, double *__restrict__ PA, double *__restrict__ PB) {
+__global__ void build_panels_kernel(const double *__restrict__ Q1, const double *__restrict__ W, const double *__restrict__ scal,
+                                    int64_t n, int64_t npad, int q, int K2, double *__restrict__ PA, double *__restrict__ PB) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= npad * K2) return;
+    const double mu = scal[1];
     const int64_t i = idx % npad;
     const int t = (int)(idx / npad);
     double a = 0.0, b = 0.0;
@@ -348,7 +395,8 @@ static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info
     int *dinfo;
     MRBF_TRY(get_buf(ctx, S_PHI, (size_t)ld * npad, &Phi));
     MRBF_TRY(get_buf(ctx, S_RHS, (size_t)npad * k, &B));
-    MRBF_TRY(get_buf(ctx, S_INFO, (size_t)4, &dinfo));
+    MRBF_TRY(get_buf(ctx, S_INFO, (size_t)4, &dinfo));  // [0] main factorisation, [1] Cholesky-QR of the tail, [2] shift not positive
+    MRBF_HIP(ctx, hipMemsetAsync(dinfo, 0, 4 * sizeof(int), ctx->stream));
     hipLaunchKernelGGL(rhs_from_values_kernel, dim3(nblk(npad * k)), dim3(256), 0, ctx->stream, Y, n, k, B, npad);
     MRBF_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));  // ev0..ev1 bracket the Gram kernel alone
     MRBF_TRY(launch_gram(ctx, ctx->gram_mode, M->C, M->Xc, M->sq, n, M->npad, M->d, M->dpad, M->kp, Phi, ld));
@@ -372,14 +420,7 @@ static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info
             hipLaunchKernelGGL(xc_to_tall_kernel, dim3(nblk(n * d)), dim3(256), 0, ctx->stream, M->Xc, n, d, M->dpad, Tall, lt, dq);
             MRBF_TRY(tsmm_tn(ctx, n, d, d, 1.0, Tall + dq, lt, Tall + dq, lt, 0.0, Tall, lt));  // Gx = Xc' Xc
             MRBF_TRY(launch_pad_identity(ctx, Tall, d, dq, lt));
-            MRBF_TRY(potrf_blocked_tall(ctx, dq, lt, Tall, lt, dinfo, nullptr));
-            int hq = 0;
-            MRBF_TRY(read_info(ctx, dinfo, &hq));
-            if (hq != 0) {  // affinely dependent sites: Pi is rank deficient
-                *not_pd = 1;
-                info->factor_info = -2;
-                return 0;
-            }
+            MRBF_TRY(potrf_blocked_tall(ctx, dq, lt, Tall, lt, dinfo + 1, nullptr));  // flag read back with the main one
         }
         hipLaunchKernelGGL(build_q1_kernel, dim3(nblk(npad * q)), dim3(256), 0, ctx->stream, Tall, lt, dq, n, npad, q, Q1);
         MRBF_HIP(ctx, hipMemsetAsync(Wm, 0, (size_t)npad * q * sizeof(double), ctx->stream));
@@ -390,22 +431,14 @@ static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info
         MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, (int)n, q, q, &mhalf, Q1, (int)npad,
                                      G, q, &one, Wm, (int)npad));
         // mu = trace(P Phi P) / (n - q): the mean eigenvalue of Z' Phi Z, so the shift sits inside the spectrum
-        double trG = 0.0;
-        MRBF_HIP(ctx, hipMemcpyAsync(&trG, scal, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        const double mu = ((double)n * M->kp.phi0 - trG) / (double)std::max<int64_t>(n - q, 1);
-        if (!(mu > 0.0) || !std::isfinite(mu)) {
-            *not_pd = 1;  // trace <= 0: Z' Phi Z cannot be positive definite
-            info->factor_info = -1;
-            return 0;
-        }
-        info->mu = mu;
+        hipLaunchKernelGGL(shift_from_trace_kernel, dim3(1), dim3(1), 0, ctx->stream, scal, (double)n * M->kp.phi0,
+                           (double)std::max<int64_t>(n - q, 1), dinfo);
         // K = Phi - Q1 V' - V Q1',  V = W - (mu/2) Q1  ( = P Phi P + mu Q1 Q1' ), lower tile pairs, in place, one kernel
         const int K2 = (int)round_up(2 * q, 16);
         double *PA, *PB;
         MRBF_TRY(get_buf(ctx, S_STAGE_C, (size_t)npad * K2, &PA));
         MRBF_TRY(get_buf(ctx, S_STAGE_D, (size_t)npad * K2, &PB));
-        hipLaunchKernelGGL(build_panels_kernel, dim3(nblk(npad * K2)), dim3(256), 0, ctx->stream, Q1, Wm, mu, n, npad, q, K2, PA, PB);
+        hipLaunchKernelGGL(build_panels_kernel, dim3(nblk(npad * K2)), dim3(256), 0, ctx->stream, Q1, Wm, scal, n, npad, q, K2, PA, PB);
         MRBF_TRY(launch_update_lower(ctx, PA, npad, PB, npad, Phi, ld, npad / 128, K2));
         // B = P Y = Y - Q1 (Q1' Y);  T1 keeps Q1' Y for lam
         MRBF_TRY(tsmm_tn(ctx, n, q, k, 1.0, Q1, npad, B, npad, 0.0, T1, q));
@@ -421,15 +454,37 @@ static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info
         hipLaunchKernelGGL(set_rhs_rows_kernel, dim3(nblk(npad * xt)), dim3(256), 0, ctx->stream, Phi, ld, npad, xt, B, k);
         MRBF_TRY(potrf_blocked_tall(ctx, npad, npad + xt, Phi, ld, dinfo, linv_all));
         MRBF_HIP(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
-        MRBF_TRY(read_info(ctx, dinfo, &hinfo));
     } else {
-        MRBF_TRY(potrf_lower(ctx, 1, n, Phi, ld, &hinfo));
+        int *dpot;
+        MRBF_TRY(get_buf(ctx, S_IPIV, (size_t)4, &dpot));
+        MRBF_BLAS(ctx, rocsolver_dpotrf(ctx->blas, rocblas_fill_lower, (int)n, Phi, (int)ld, dpot));
+        MRBF_HIP(ctx, hipMemcpyAsync(dinfo, dpot, sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
         MRBF_HIP(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
     }
-    info->factor_info = hinfo;
-    if (hinfo != 0) {
-        *not_pd = 1;
-        return 0;
+    {
+        // one host round trip for all the flags of this path (the only synchronisation before the solve)
+        int hflags[4] = {0, 0, 0, 0};
+        double hscal[2] = {0.0, 0.0};
+        MRBF_HIP(ctx, hipMemcpyAsync(hflags, dinfo, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        if (q > 0) MRBF_HIP(ctx, hipMemcpyAsync(hscal, scal, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        hinfo = hflags[0];
+        info->factor_info = hinfo;
+        if (q > 0) info->mu = hscal[1];
+        if (hflags[1] != 0) {  // affinely dependent sites: Pi is rank deficient
+            *not_pd = 1;
+            info->factor_info = -2;
+            return 0;
+        }
+        if (hflags[2] != 0) {  // trace <= 0: Z' Phi Z cannot be positive definite
+            *not_pd = 1;
+            info->factor_info = -1;
+            return 0;
+        }
+        if (hinfo != 0) {
+            *not_pd = 1;
+            return 0;
+        }
     }
     if (builtin) {
         // forward substitution came out of the factorisation (the extra rows); backward substitution with the stored block inverses
