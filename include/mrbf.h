@@ -113,6 +113,12 @@ int32_t mrbf_sync(mrbf_ctx *ctx);
 int32_t mrbf_gram(mrbf_ctx *ctx, int64_t n, int32_t d, const double *centres, int32_t kernel_id, double a, double b,
                   int32_t poly_deg, double *Phi_out, double *Pi_out, float *ms);
 
+/* rectangular kernel block K[i][j] = phi(||x_i - c_j||), m x n row-major -- replaces the per-candidate
+ * kernels(xi) / RBF.make_kernel calls of the round-4 site selection (src/models/RbfModel.jl:421, :487): all candidates
+ * against all current and prospective centres in one launch (difference-form arithmetic, like norm(x - c)). */
+int32_t mrbf_cross_gram(mrbf_ctx *ctx, int64_t m, int64_t n, int32_t d, const double *X, const double *centres, int32_t kernel_id,
+                        double a, double b, double *K_out);
+
 /* Gram assembly + factorisation + solve for all k outputs -- replaces
  * RBF.RBFInterpolationModel(sites, values, kernel, params, poly_deg) in update_model
  * (src/models/RbfModel.jl:759-763).  Keeps centres / weights resident on the device in

@@ -60,6 +60,8 @@ SIGNATURES = {
     "mrbf_sync": (ctypes.c_int32, [c_vp]),
     "mrbf_gram": (ctypes.c_int32, [c_vp, ctypes.c_int64, ctypes.c_int32, c_vp, ctypes.c_int32, ctypes.c_double,
                                    ctypes.c_double, ctypes.c_int32, c_vp, c_vp, c_fp]),
+    "mrbf_cross_gram": (ctypes.c_int32, [c_vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, c_vp, c_vp, ctypes.c_int32, ctypes.c_double,
+                                         ctypes.c_double, c_vp]),
     "mrbf_fit": (ctypes.c_int32, [c_vp, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, c_vp, c_vp, ctypes.c_int32,
                                   ctypes.c_double, ctypes.c_double, ctypes.c_int32, ctypes.POINTER(c_vp), c_vp, c_vp,
                                   ctypes.POINTER(FitInfo)]),

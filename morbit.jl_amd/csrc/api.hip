@@ -90,6 +90,29 @@ int32_t mrbf_gram(mrbf_ctx *ctx, int64_t n, int32_t d, const double *centres, in
     return MRBF_OK;
 }
 
+int32_t mrbf_cross_gram(mrbf_ctx *ctx, int64_t m, int64_t n, int32_t d, const double *X, const double *centres, int32_t kernel_id,
+                        double a, double b, double *K_out) {
+    if (!ctx) return -1;
+    if (m < 0 || m > (int64_t)1 << 24) return fail(ctx, -2, "m out of range");
+    if (n < 0 || n > (int64_t)1 << 24) return fail(ctx, -3, "n out of range");
+    if (d < 1 || d > 4096) return fail(ctx, -4, "d out of range");
+    MRBF_TRY(check_kernel(ctx, kernel_id, a, b, 1, 7));
+    if (m == 0 || n == 0) return MRBF_OK;
+    if (!X) return fail(ctx, -5, "X is NULL");
+    if (!centres) return fail(ctx, -6, "centres is NULL");
+    if (!K_out) return fail(ctx, -10, "K_out is NULL");
+    (void)hipSetDevice(ctx->device);
+    const double *dX, *dC;
+    double *dK;
+    MRBF_TRY(stage_in(ctx, S_STAGE_A, X, (size_t)m * d, &dX));
+    MRBF_TRY(stage_in(ctx, S_STAGE_B, centres, (size_t)n * d, &dC));
+    MRBF_TRY(stage_out(ctx, S_PHI, K_out, (size_t)m * n, &dK));
+    MRBF_TRY(launch_cross_gram(ctx, dX, m, dC, n, d, make_kp(kernel_id, a, b), dK));
+    MRBF_TRY(finish_out(ctx, K_out, dK, (size_t)m * n));
+    MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MRBF_OK;
+}
+
 int32_t mrbf_fit(mrbf_ctx *ctx, int64_t n, int32_t d, int32_t k, const double *centres, const double *values,
                  int32_t kernel_id, double a, double b, int32_t poly_deg, mrbf_model **model, double *weights_out,
                  double *poly_out, mrbf_fit_info *info) {

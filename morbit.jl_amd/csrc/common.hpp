@@ -122,6 +122,7 @@ int launch_transpose(mrbf_ctx *ctx, const double *in, int64_t rows, int64_t cols
 // gram.hip
 int launch_gram(mrbf_ctx *ctx, int mode, const double *C, const double *Xc, const double *sq, int64_t n, int64_t npad,
                 int d, int dpad, const KP &kp, double *Phi, int64_t ld);
+int launch_cross_gram(mrbf_ctx *ctx, const double *X, int64_t m, const double *C, int64_t n, int d, const KP &kp, double *K);
 // eval.hip
 int eval_model(mrbf_ctx *ctx, const mrbf_model *M, int64_t m, const double *Xdev, double *vals_dev, double *jac_dev,
                mrbf_eval_info *info);

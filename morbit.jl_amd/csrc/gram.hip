@@ -204,6 +204,59 @@ __global__ __launch_bounds__(256) void gram_diff_kernel(const double *__restrict
         }
 }
 
+// ---- rectangular kernel block  K[i][j] = phi(||x_i - c_j||), difference form (the reference's kernels(xi) call of round 4,
+// RbfModel.jl:421, for all candidates at once).  X: m x d, C: n x d row-major; K: m x n row-major.
+template <int KID>
+__global__ __launch_bounds__(256) void cross_gram_kernel(const double *__restrict__ X, int64_t m, const double *__restrict__ C, int64_t n,
+                                                         int d, double *__restrict__ K, KP p) {
+    __shared__ double As[64][17];
+    __shared__ double Bs[64][17];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int64_t I0 = (int64_t)blockIdx.y * 64, J0 = (int64_t)blockIdx.x * 64;
+    double acc[4][4] = {};
+    for (int k0 = 0; k0 < d; k0 += 16) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = ty + 16 * u, c = tx;
+            const bool kin = (k0 + c) < d;
+            As[r][c] = (I0 + r < m && kin) ? X[(I0 + r) * d + k0 + c] : 0.0;
+            Bs[r][c] = (J0 + r < n && kin) ? C[(J0 + r) * d + k0 + c] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            double a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] = As[ty + 16 * u][kk];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) b[v] = Bs[tx + 16 * v][kk];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const double df = a[u] - b[v];
+                    acc[u][v] = fma(df, df, acc[u][v]);
+                }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int64_t gi = I0 + ty + 16 * u, gj = J0 + tx + 16 * v;
+            if (gi < m && gj < n) K[gi * n + gj] = rbf_phi<KID>(acc[u][v], p);
+        }
+}
+
+int launch_cross_gram(mrbf_ctx *ctx, const double *X, int64_t m, const double *C, int64_t n, int d, const KP &kp, double *K) {
+    if (m <= 0 || n <= 0) return 0;
+    dim3 grid((unsigned)((n + 63) / 64), (unsigned)((m + 63) / 64));
+    MRBF_DISPATCH_KID(kp.kid, hipLaunchKernelGGL((cross_gram_kernel<KID>), grid, dim3(256), 0, ctx->stream, X, m, C, n, d, K, kp));
+    MRBF_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
 int launch_gram(mrbf_ctx *ctx, int mode, const double *C, const double *Xc, const double *sq, int64_t n, int64_t npad,
                 int d, int dpad, const KP &kp, double *Phi, int64_t ld) {
     if (n <= 0) return 0;

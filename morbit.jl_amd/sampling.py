@@ -1,0 +1,182 @@
+"""Host-side mirror of Morbit's RBF training-site selection around the device kernels.
+
+Mirrors AffinelyIndependentPointFilter / _find_suitable_points (src/models/AffinelyIndependentPoints.jl:14-106,
+src/models/RbfModel.jl:205-238) -- small d x d QRs that stay on the host, SURVEY.md section 8 row a12 -- and _rbf_round4
+(src/models/RbfModel.jl:352-499, row a11).  Round 4's per-candidate kernel vectors `kernels(xi)` (:421) and the second
+Gram assembly `RBF.get_matrices` (:374) are taken from the device in two batched calls (mrbf_gram for the start set,
+mrbf_cross_gram for every candidate against every start site and every other candidate); the Givens / Cholesky
+bookkeeping of Wild's test is sequential O(N^2) host work exactly as in the reference, including its acceptance rule
+tau^2 > (theta_pivot_cholesky^2)^2 and its empty initial Z (RbfModel.jl:370, :391, :452).
+"""
+import ctypes
+import math
+
+import numpy as np
+
+from . import _lib
+from . import rbf_model as rm
+
+
+def _orthogonal_complement_matrix(Y, p=np.inf):
+    Q, _ = np.linalg.qr(Y, mode="complete")
+    Z = Q[:, Y.shape[1]:]
+    if Z.shape[1] > 0:
+        Z = Z / np.linalg.norm(Z, ord=p, axis=0)[None, :]
+    return Z
+
+
+class AffinelyIndependentPointFilter:
+    """Greedy filter: repeatedly the candidate maximising ||Z Z'(xi - x0)||_p, accepted while it exceeds pivot_val."""
+
+    def __init__(self, x_0, seeds, n=None, Y=None, Z=None, p=np.inf, pivot_val=1e-3):
+        self.x_0 = np.asarray(x_0, dtype=np.float64)
+        self.shifted = [np.asarray(s, dtype=np.float64) - self.x_0 for s in seeds]
+        d = self.x_0.size
+        self.n = d if n is None else n
+        assert self.n > 0, "`x_0` must not be empty and `n` must be positive."
+        self.Y = np.empty((d, 0)) if Y is None else np.array(Y, dtype=np.float64)
+        self.Z = np.eye(d) if Z is None else np.array(Z, dtype=np.float64)
+        self.p, self.pivot_val = p, pivot_val
+
+    def collect(self):
+        out = []
+        if not self.shifted:
+            return out
+        i = int(np.argmax([np.linalg.norm(s, ord=self.p) for s in self.shifted]))
+        cand = [c for c in range(len(self.shifted)) if c != i]
+        self.Y = np.hstack([self.Y, self.shifted[i][:, None]])
+        self.Z = _orthogonal_complement_matrix(self.Y, self.p)
+        out.append(i)
+        S = np.array(self.shifted) if self.shifted else np.empty((0, self.x_0.size))
+        while len(out) < self.n and cand:
+            if self.Z.shape[1]:
+                P = (S[cand] @ self.Z) @ self.Z.T                     # all candidates at once: rows Z Z'(xi - x0)
+                vals = np.linalg.norm(P, ord=self.p, axis=1)
+            else:
+                vals = np.zeros(len(cand))
+            b = int(np.argmax(vals))                                   # first maximiser, like the `>` scan of the reference
+            if not vals[b] > self.pivot_val:
+                break
+            best = cand[b]
+            self.Y = np.hstack([self.Y, self.shifted[best][:, None]])
+            self.Z = _orthogonal_complement_matrix(self.Y, self.p)
+            cand.remove(best)
+            out.append(best)
+        return out
+
+
+def results_in_box_indices(sites, lb, ub, exclude_indices=()):
+    """indices of database sites inside the box (Databases.jl:324-327); `sites` is an (N, d) array or list"""
+    ex = set(exclude_indices)
+    lb, ub = np.asarray(lb), np.asarray(ub)
+    return [i for i, s in enumerate(sites) if i not in ex and np.all(lb <= s) and np.all(s <= ub)]
+
+
+def _find_suitable_points(sites, lb, ub, x, x_index, piv_val, already_inspected_indices=(), Y=None, Z=None, n_missing=None,
+                          collect_improving_directions=True):
+    """RbfModel.jl:205-238 -> (filtered_indices, improving_directions, candidate_indices, Y, Z)"""
+    x = np.asarray(x, dtype=np.float64)
+    cand = results_in_box_indices(sites, lb, ub, [x_index, *already_inspected_indices])
+    flt = AffinelyIndependentPointFilter(x, [sites[i] for i in cand], n=x.size if n_missing is None else n_missing, Y=Y, Z=Z,
+                                         p=np.inf, pivot_val=piv_val)
+    picked = [cand[i] for i in flt.collect()]
+    dirs = [flt.Z[:, j].copy() for j in range(flt.Z.shape[1])][::-1] if collect_improving_directions else None
+    return picked, dirs, cand, flt.Y, flt.Z
+
+
+def _nullify_last_row(R):
+    """Givens rotations that zero the appended last row of an upper-triangular R (utilities.jl:437-448)."""
+    R = np.array(R, dtype=np.float64)
+    m, n = R.shape
+    G = np.eye(m)
+    for j in range(min(m - 1, n)):
+        a, b = R[j, j], R[m - 1, j]
+        r = math.hypot(a, b)
+        if r == 0.0:
+            continue
+        c, s = a / r, b / r
+        rj, rm_ = R[j].copy(), R[m - 1].copy()
+        R[j], R[m - 1] = c * rj + s * rm_, -s * rj + c * rm_
+        gj, gm = G[j].copy(), G[m - 1].copy()
+        G[j], G[m - 1] = c * gj + s * gm, -s * gj + c * gm
+    return R, G
+
+
+def cross_gram(cfg, X, C, delta=1.0, ctx=None):
+    """phi(||x_i - c_j||) for all pairs on the device (mrbf_cross_gram)."""
+    ctx = ctx or _lib.default_context()
+    X, C = _lib.host_f64(X), _lib.host_f64(C)
+    m, d = X.shape
+    n = C.shape[0]
+    kid, a, b = rm._get_kernel_params(delta, cfg)
+    K = np.empty((m, n))
+    ctx.check(ctx.lib.mrbf_cross_gram(ctx.h, m, n, d, _lib.as_ptr(X), _lib.as_ptr(C), kid, a, b, _lib.as_ptr(K)))
+    return K
+
+
+def _rbf_round4(sites, lb_2, ub_2, x, delta, indices_found_so_far, cfg, ctx=None, kernel_block=None):
+    """Wild's second selection round (RbfModel.jl:352-499): database indices of additional training sites that keep the
+    Cholesky factors of Z'Phi Z bounded.  `sites` is the database as an (N_db, d) array; candidates are the box members
+    not yet chosen, in database order.  `use_max_points` sampling of fresh random sites is the caller's job (it needs the
+    database); this function handles the database candidates."""
+    sites = np.asarray(sites, dtype=np.float64)
+    d = sites.shape[1]
+    max_points = (d + 1) * (d + 2) // 2 if cfg.max_model_points <= 0 else cfg.max_model_points
+    N = len(indices_found_so_far)
+    cand = results_in_box_indices(sites, lb_2, ub_2, indices_found_so_far)
+    round4 = []
+    if not (N < max_points and cand):
+        return round4
+    chol_pivot = cfg.θ_pivot_cholesky ** 2
+    deg = cfg.polynomial_degree
+    C0 = sites[list(indices_found_so_far)]
+    Xc = sites[cand]
+    if kernel_block is None:
+        # two device calls replace one kernels(xi) call per candidate plus RBF.get_matrices
+        Phi, Pi, _ = rm.get_matrices(cfg, C0, delta, ctx=ctx)
+        Phi = np.array(Phi)
+        K_all = cross_gram(cfg, Xc, np.vstack([C0, Xc]), delta, ctx=ctx)      # candidates x (start set + candidates)
+    else:
+        Phi = kernel_block(C0, C0)
+        Pi = np.hstack([np.ones((N, 1)), C0])[:, : (0 if deg < 0 else (1 if deg == 0 else d + 1))]
+        K_all = kernel_block(Xc, np.vstack([C0, Xc]))
+    q = Pi.shape[1]
+    Q, Rr = (np.linalg.qr(Pi, mode="complete") if q > 0 else (np.eye(N), np.zeros((N, 0))))
+    R = np.vstack([Rr[: min(N, q)], np.zeros((N - min(N, q), q))]) if q > 0 else np.zeros((N, 0))
+    Z = Q[:, N:]                     # empty, as in the reference (RbfModel.jl:391)
+    L = np.zeros((0, 0))
+    Linv = np.zeros((0, 0))
+    phi0 = float(Phi[0, 0])
+    cols = list(range(N))            # columns of K_all that are current centres
+    n0 = N
+    for pos, id_ in enumerate(cand):
+        if N >= max_points:
+            break
+        xi = Xc[pos]
+        phixi = K_all[pos, cols]
+        pixi = np.concatenate([[1.0], xi])[:q]
+        Rxi, G = _nullify_last_row(np.vstack([R, pixi[None, :]]))
+        if deg >= 0 and N < math.comb(d + deg, d):
+            if np.linalg.norm(Rxi[-1, :]) <= np.finfo(float).eps * 10:
+                continue             # the rank of R is not augmented by adding xi
+        gt, gh = G[-1, :-1], G[-1, -1]      # last column of G' without / with its last entry
+        Qg = Q @ gt
+        v = Z.T @ (Phi @ Qg + phixi * gh)
+        sigma = Qg @ Phi @ Qg + 2.0 * gh * (phixi @ Qg) + gh * gh * phi0
+        tau2 = sigma - (np.linalg.norm(Linv @ v) ** 2 if v.size else 0.0)
+        if tau2 > chol_pivot ** 2:
+            round4.append(id_)
+            tau = math.sqrt(tau2)
+            Qn = np.zeros((N + 1, N + 1))
+            Qn[:N, :N] = Q
+            Qn[N, N] = 1.0
+            Q = Qn @ G.T
+            Z = np.block([[Z, Qg[:, None]], [np.zeros((1, Z.shape[1])), np.array([[gh]])]])
+            row = (v @ Linv.T) if v.size else np.zeros(0)
+            L = np.block([[L, np.zeros((L.shape[0], 1))], [row[None, :], np.array([[tau]])]])
+            Linv = np.block([[Linv, np.zeros((Linv.shape[0], 1))], [-(row @ Linv)[None, :] / tau, np.array([[1.0 / tau]])]])
+            R = Rxi
+            Phi = np.block([[Phi, phixi[:, None]], [phixi[None, :], np.array([[phi0]])]])
+            cols.append(n0 + pos)
+            N += 1
+    return round4
