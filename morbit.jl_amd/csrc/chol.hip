@@ -1,6 +1,7 @@
 // Cholesky factorisation (lower) of the n x n s.p.d. system matrix.
 //   impl 1: rocSOLVER dpotrf
-//   impl 2: built-in blocked right-looking Cholesky (chol_blocked.hip)
+//   impl 2: built-in blocked right-looking Cholesky, host-driven launches (chol_blocked.hip)
+//   impl 3: the same factorisation as one persistent launch (chol_mega.hip)
 #include "common.hpp"
 
 namespace mrbf {
@@ -17,7 +18,15 @@ int potrf_lower(mrbf_ctx *ctx, int impl, int64_t n, double *A, int64_t lda, int 
     MRBF_TRY(get_buf(ctx, S_INFO, (size_t)4, &dinfo));
     const int64_t npad = round_up(n, 128);
     if (impl == 0) impl = (lda >= npad) ? 2 : 1;
-    if (impl == 2) {
+    if (impl == 2 || impl == 3) {
+        const int saved = ctx->chol_impl, saved_min = ctx->mega_min;
+        ctx->chol_impl = impl;
+        if (impl == 3) ctx->mega_min = 0;
+        struct Restore {
+            mrbf_ctx *c;
+            int a, b;
+            ~Restore() { c->chol_impl = a; c->mega_min = b; }
+        } restore{ctx, saved, saved_min};
         if (lda < npad) return fail(ctx, MRBF_EHIP, "built-in Cholesky needs lda >= round_up(n,128)");
         MRBF_TRY(launch_pad_identity(ctx, A, n, npad, lda));
         MRBF_TRY(potrf_blocked(ctx, npad, A, lda, dinfo));

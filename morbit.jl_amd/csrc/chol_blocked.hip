@@ -25,6 +25,7 @@ constexpr int CBK = 16;   // k chunk
 
 enum { UPD_LOWER_SUB = 0, UPD_OVERWRITE = 1, UPD_FULL_SUB = 2, UPD_COLUMN_SUB = 3 };
 int launch_diag_v4(mrbf_ctx *ctx, hipStream_t st, double *Ajj, int64_t lda, double *Linv, int *dinfo, int col0);  // chol_diag.hip
+int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int64_t lda, int *dinfo, double *linv_all);  // chol_mega.hip
 
 // C(i,j) (op)= sum_k A(i,k) * B(j,k).  A: (tiles_i*TM) x K, B: (tiles_j*128) x K, all column-major.
 // MODE LOWER_SUB: square region, grid.x = lower-triangular tile pairs (TM == 128), C -= ..., strictly-upper
@@ -477,6 +478,8 @@ int potrf_blocked_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, i
     if (ncols % CNB != 0 || mrows % CNB != 0 || mrows < ncols || (lda & 1) || (reinterpret_cast<uintptr_t>(A) & 15))
         return fail(ctx, MRBF_EHIP, "potrf_blocked needs 128-padded, 16-byte aligned storage (ncols=%lld mrows=%lld lda=%lld)",
                     (long long)ncols, (long long)mrows, (long long)lda);
+    // chol_impl 3: the whole factorisation as one persistent launch (chol_mega.hip)
+    if (ctx->chol_impl == 3 && ncols >= ctx->mega_min) return potrf_mega_tall(ctx, ncols, mrows, A, lda, dinfo, linv_all);
     double *Lone = nullptr;
     if (!linv_all) MRBF_TRY(get_buf(ctx, S_CHOL_WS, (size_t)CNB * CNB, &Lone));
     // Look-ahead over two streams.  Panel stream P (high priority): D(j), T(j), U1(j) = update of block column j+1

@@ -1,0 +1,250 @@
+// Device core of the 128 x 128 diagonal-block factorisation (Cholesky + inverse of the factor), shared by the
+// stand-alone kernel (chol_diag.hip) and the persistent factorisation kernel (chol_mega.hip).
+//
+// The block is cut into 16 x 16 tiles (36 lower tiles).  Every tile lives TRANSPOSED in the f64 MFMA C/D register
+// layout of one of the 4 waves (lane l, register r hold A[16i + (l&15)][16j + (l>>4) + 4r]): in that layout a tile
+// is directly the B operand of the next MFMA (its register r IS k-slice r), so the panel solve
+//        P_i' = inv(L_bb) * A_ib'                (4 MFMAs per tile, A operand = the 16 x 16 leaf inverse from LDS)
+// and the trailing update
+//        A_ij' -= P_j * P_i'                     (4 MFMAs per tile, operands = finished panel tiles from LDS)
+// never move data between lanes.  Only the 16 x 16 leaves are sequential: wave 0 factors them one column at a time
+// with the rows of the leaf in lanes 0..15 and an identity block in lanes 16..31 (the same elimination turns the
+// identity into L_bb^-T, i.e. the leaf inverse is free); columns are broadcast with v_readlane, no LDS, no barrier.
+// After the 8 panels the full 128 x 128 inverse is assembled block column by block column with MFMAs
+//        X_jj = inv(L_jj),   X_ij = -inv(L_ii) * sum_{p=j..i-1} L_ip X_pj.
+#pragma once
+#include "common.hpp"
+
+namespace mrbf {
+namespace diagcore {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) double gf64;  // explicit global address space: global_ (not flat_) loads / stores
+
+constexpr int DNB = 128;
+constexpr int NT = 8;      // 16 x 16 tiles per side
+constexpr int TILE = 256;  // doubles per tile
+// strictly-lower tile (i, j), j < i
+#define MRBF_SIDX(i, j) ((i) * ((i)-1) / 2 + (j))
+// lower tile incl. diagonal (register ownership map)
+#define MRBF_TIDX(i, j) ((i) * ((i) + 1) / 2 + (j))
+
+struct DiagV4Shared {
+    double LT[28 * TILE];  // finished strictly-lower L tiles, [tile][c][row]  (c = column inside the tile): MFMA operand order
+    double IT[NT * TILE];  // leaf inverses transposed: IT[b][a2][a] = inv(L_bb)[a][a2]
+    double Dt[TILE];       // diagonal tile handed to the leaf wave, [col a][row b']
+    int bad;
+};
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double fast_rsqrt_v4(double x) {
+    double y = __builtin_amdgcn_rsq(x);  // ~2^-26 relative: two Newton steps reach full double precision
+    const double h = 0.5 * x;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) y = y * fma(-h, y * y, 1.5);
+    return y;
+}
+
+// operand fetch: element [4s + (l>>4)][l&15] of a 16 x 16 tile stored row-major ([k][c]); conflict-free ds_read_b64
+__device__ __forceinline__ double opnd(const double *tile, int s, int l15, int l4) { return tile[(4 * s + l4) * 16 + l15]; }
+
+// SC1: write-through stores (visible to other workgroups of the same launch after a flag hand-off)
+template <bool SC1>
+__device__ __forceinline__ void gstore(double *p, double v) {
+    if constexpr (SC1)
+        __hip_atomic_store((gf64 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+        *(gf64 *)p = v;
+}
+
+// leaf: rows of the 16 x 16 s.p.d. block in lanes 0..15 (a[c], c <= lane valid), identity rows in lanes 16..31
+template <int K>
+__device__ __forceinline__ void leaf_step(double (&a)[16], int &bad, int col0) {
+    // branch-free so that the 16 unrolled steps form one basic block: the scheduler can then start step K+1's
+    // pivot -> rsqrt chain under the remaining column updates of step K
+    const double piv = readlane_f64(a[K], K);
+    const bool ok = piv > 0.0;
+    const double rinv = ok ? fast_rsqrt_v4(ok ? piv : 1.0) : 0.0;
+    bad = (!ok && bad == 0) ? col0 + K + 1 : bad;
+    a[K] *= rinv;
+#pragma unroll
+    for (int j = K + 1; j < 16; ++j) {
+        const double ljk = readlane_f64(a[K], j);
+        a[j] = fma(-a[K], ljk, a[j]);
+    }
+}
+
+// Factor the 128 x 128 block at A (lower part, column-major, leading dimension lda) in place and write the inverse
+// of the factor to Linv (128 x 128 column-major, zeros above the diagonal).  256 threads.  Returns 0 or the 1-based
+// index (inside the block) of the first non-positive pivot; in that case A / Linv are only partly written.
+template <bool SC1>
+__device__ __forceinline__ int diag_v4_core(double *__restrict__ A, int64_t lda, double *__restrict__ Linv, DiagV4Shared &sh) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    if (tid == 0) sh.bad = 0;
+
+    // ---- load: tile t = TIDX(i,j) belongs to wave t & 3, register slot t >> 2
+    v4d acc[9];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            const int t = MRBF_TIDX(i, j);
+            if ((t & 3) == wave) {
+                v4d v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = *(const gf64 *)&A[(16 * i + l15) + (int64_t)(16 * j + l4 + 4 * r) * lda];
+                acc[t >> 2] = v;
+            }
+        }
+    __syncthreads();
+
+#pragma unroll 1
+    for (int b = 0; b < NT; ++b) {
+        // 1. the owner of the diagonal tile (b,b) hands it to the leaf wave
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int t = MRBF_TIDX(i, i);
+            if (i == b && (t & 3) == wave) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sh.Dt[(l4 + 4 * r) * 16 + l15] = acc[t >> 2][r];
+            }
+        }
+        __syncthreads();
+        // 2. leaf: wave 0, lanes 0..31
+        if (wave == 0) {
+            double a[16];
+            int bad = 0;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                double v;
+                if (lane < 16)
+                    v = (c <= lane) ? sh.Dt[c * 16 + lane] : 0.0;  // A_bb[row = lane][col = c]
+                else
+                    v = (c == lane - 16) ? 1.0 : 0.0;
+                a[c] = v;
+            }
+            leaf_step<0>(a, bad, 16 * b);
+            leaf_step<1>(a, bad, 16 * b);
+            leaf_step<2>(a, bad, 16 * b);
+            leaf_step<3>(a, bad, 16 * b);
+            leaf_step<4>(a, bad, 16 * b);
+            leaf_step<5>(a, bad, 16 * b);
+            leaf_step<6>(a, bad, 16 * b);
+            leaf_step<7>(a, bad, 16 * b);
+            leaf_step<8>(a, bad, 16 * b);
+            leaf_step<9>(a, bad, 16 * b);
+            leaf_step<10>(a, bad, 16 * b);
+            leaf_step<11>(a, bad, 16 * b);
+            leaf_step<12>(a, bad, 16 * b);
+            leaf_step<13>(a, bad, 16 * b);
+            leaf_step<14>(a, bad, 16 * b);
+            leaf_step<15>(a, bad, 16 * b);
+            if (bad && lane == 0) sh.bad = bad;
+            if (lane < 16) {
+                // factor rows -> global (lower part of the diagonal tile)
+#pragma unroll
+                for (int c = 0; c < 16; ++c)
+                    if (c <= lane) gstore<SC1>(&A[(16 * b + lane) + (int64_t)(16 * b + c) * lda], a[c]);
+            } else if (lane < 32) {
+                // lane 16 + r holds (L^-T)[r][c] = inv[c][r]:  IT[b][a2 = r][a = c]
+                const int r = lane - 16;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) sh.IT[b * TILE + r * 16 + c] = (c >= r) ? a[c] : 0.0;
+            }
+        }
+        __syncthreads();
+        if (sh.bad) break;
+        // 3. panel: P_i' = inv(L_bb) * A_ib'  for the owned tiles of block column b
+        const double *itb = &sh.IT[b * TILE];
+        double ia[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) ia[s] = opnd(itb, s, l15, l4);
+#pragma unroll
+        for (int i = 1; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < i; ++j) {
+                const int t = MRBF_TIDX(i, j);
+                if (j == b && (t & 3) == wave) {
+                    v4d p = {0.0, 0.0, 0.0, 0.0};
+                    const v4d m = acc[t >> 2];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) p = __builtin_amdgcn_mfma_f64_16x16x4f64(ia[s], m[s], p, 0, 0, 0);
+                    acc[t >> 2] = p;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        sh.LT[MRBF_SIDX(i, j) * TILE + (l4 + 4 * r) * 16 + l15] = p[r];
+                        gstore<SC1>(&A[(16 * i + l15) + (int64_t)(16 * j + l4 + 4 * r) * lda], p[r]);  // L(i,b), coalesced along rows
+                    }
+                }
+            }
+        __syncthreads();
+        // 4. trailing update of the owned tiles (i,j), i >= j > b:  A_ij' -= P_j * P_i'
+#pragma unroll
+        for (int i = 1; i < NT; ++i)
+#pragma unroll
+            for (int j = 1; j <= i; ++j) {
+                const int t = MRBF_TIDX(i, j);
+                if (j > b && (t & 3) == wave) {
+                    const double *tj_ = &sh.LT[MRBF_SIDX(j, b) * TILE];
+                    const double *ti_ = &sh.LT[MRBF_SIDX(i, b) * TILE];
+                    v4d c = acc[t >> 2];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+                        c = __builtin_amdgcn_mfma_f64_16x16x4f64(-opnd(tj_, s, l15, l4), opnd(ti_, s, l15, l4), c, 0, 0, 0);
+                    acc[t >> 2] = c;
+                }
+            }
+        // (the next iteration's step 1 + barrier orders these register updates before the hand-off)
+    }
+    __syncthreads();
+    const int bad_all = sh.bad;
+    if (bad_all) return bad_all;
+
+    // ---- inverse: wave w assembles block columns w and 7 - w of X = L^-1 in registers, MFMA C/D layout
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int j = half == 0 ? wave : 7 - wave;
+        v4d X[NT];
+        // X_jj = inv(L_jj): C layout element [(l4 + 4r)][l15] = IT[j][l15][l4 + 4r]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) X[0][r] = sh.IT[j * TILE + l15 * 16 + l4 + 4 * r];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gstore<SC1>(&Linv[(16 * j + l4 + 4 * r) + (16 * j + l15) * DNB], X[0][r]);
+#pragma unroll
+        for (int di = 1; di < NT; ++di) {
+            const int i = j + di;
+            if (i < NT) {
+                v4d S = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int dp = 0; dp < di; ++dp) {
+                    const int p = j + dp;
+                    const double *lt = &sh.LT[MRBF_SIDX(i, p) * TILE];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) S = __builtin_amdgcn_mfma_f64_16x16x4f64(opnd(lt, s, l15, l4), X[dp][s], S, 0, 0, 0);
+                }
+                v4d Xi = {0.0, 0.0, 0.0, 0.0};
+                const double *iti = &sh.IT[i * TILE];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) Xi = __builtin_amdgcn_mfma_f64_16x16x4f64(-opnd(iti, s, l15, l4), S[s], Xi, 0, 0, 0);
+                X[di] = Xi;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gstore<SC1>(&Linv[(16 * i + l4 + 4 * r) + (16 * j + l15) * DNB], Xi[r]);
+            }
+        }
+        // zeros above the diagonal of this block column (the panel GEMM reads the full 128 x 128 inverse)
+        for (int e = lane; e < 16 * j * 16; e += 64) {
+            const int row = e % (16 * j), col = e / (16 * j);
+            gstore<SC1>(&Linv[row + (16 * j + col) * DNB], 0.0);
+        }
+    }
+    return 0;
+}
+
+}  // namespace diagcore
+}  // namespace mrbf

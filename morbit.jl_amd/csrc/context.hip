@@ -175,6 +175,12 @@ int32_t mrbf_init(int32_t device_id, mrbf_ctx **out) {
         // bulk stream: every XCD keeps its last 4 CUs (32 of 256) out of the mask, so the panel chain's kernels
         // (1 workgroup for D, ~m/64 for T / U1) always find idle CUs while a rank-512 trailing update is running
         if (const char *bg = getenv("MRBF_BULK_GRID")) ctx->bulk_grid = atoi(bg);
+        if (const char *e = getenv("MRBF_CHOL_IMPL")) ctx->chol_impl = atoi(e);
+        if (const char *e = getenv("MRBF_MEGA_GRID")) ctx->mega_grid = atoi(e);
+        if (const char *e = getenv("MRBF_MEGA_DEDICATED")) ctx->mega_dedicated = atoi(e);
+        if (const char *e = getenv("MRBF_MEGA_LOOK")) ctx->mega_look = atoi(e);
+        if (const char *e = getenv("MRBF_MEGA_MIN")) ctx->mega_min = atoi(e);
+        if (const char *e = getenv("MRBF_MEGA_QUIET")) ctx->mega_quiet = atoi(e);
         hipDeviceProp_t prop;
         int ncu = 256;
         if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) ncu = prop.multiProcessorCount;

@@ -338,13 +338,13 @@ def test_batch_run_matches_single_calls(ctx):
         mod.free()
 
 
-@pytest.mark.parametrize("n", [128, 256, 300, 1024, 1537])
+@pytest.mark.parametrize("n", [128, 256, 300, 1024, 1537, 2700])
 def test_builtin_cholesky_matches_lapack(ctx, n):
     rng = np.random.Generator(np.random.PCG64(n))
     G = rng.standard_normal((n, n + 20))
     A = G @ G.T / n + np.eye(n)
     Lref = np.linalg.cholesky(A)
-    for impl in (1, 2):
+    for impl in (1, 2, 3):
         F = np.asfortranarray(A.copy())
         info, ms = ctypes.c_int32(-7), ctypes.c_float()
         ctx.check(ctx.lib.mrbf_debug_potrf(ctx.h, n, _lib.as_ptr(F), impl, ctypes.byref(info), ctypes.byref(ms)))
@@ -356,18 +356,19 @@ def test_builtin_cholesky_matches_lapack(ctx, n):
     B = A.copy()
     bad = min(n - 1, 200)
     B[bad, bad] = -1.0
-    for impl in (1, 2):
+    for impl in (1, 2, 3):
         F = np.asfortranarray(B.copy())
         info = ctypes.c_int32(0)
         ctx.check(ctx.lib.mrbf_debug_potrf(ctx.h, n, _lib.as_ptr(F), impl, ctypes.byref(info), None))
         assert info.value == bad + 1, (impl, info.value)
 
 
-def test_fit_same_weights_with_both_cholesky_implementations(ctx):
-    C, Y = _synthetic(900, 20, 2, seed=77)
+@pytest.mark.parametrize("n", [900, 2300])
+def test_fit_same_weights_with_all_cholesky_implementations(ctx, n):
+    C, Y = _synthetic(n, 20, 2, seed=77)
     cfg = pkg.RbfConfig(kernel="multiquadric")
     out = []
-    for impl in (1, 2):
+    for impl in (1, 2, 3):
         ctx.set_option(_lib.OPT_CHOL_IMPL, impl)
         try:
             m = pkg.update_model(cfg, C, Y, ctx=ctx)
@@ -377,3 +378,4 @@ def test_fit_same_weights_with_both_cholesky_implementations(ctx):
         out.append(m.weights.copy())
         m.free()
     assert np.abs(out[0] - out[1]).max() < 1e-11 * np.abs(out[0]).max()
+    assert np.abs(out[0] - out[2]).max() < 1e-11 * np.abs(out[0]).max()
