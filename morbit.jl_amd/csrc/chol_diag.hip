@@ -9,7 +9,8 @@ __global__ __launch_bounds__(256, 1) void chol_diag_v4_kernel(double *__restrict
     __shared__ __attribute__((aligned(16))) diagcore::DiagV4Shared sh;
     if (*info != 0) return;
     __builtin_amdgcn_s_setprio(3);  // latency-critical: outrank the bulk update's waves sharing this CU's SIMDs
-    const int bad = diagcore::diag_v4_core<false>(A, lda, Linv, sh);
+    diagcore::v4d acc[9];
+    const int bad = diagcore::diag_v4_core<false, false, false>(A, lda, Linv, sh, acc, nullptr, nullptr);
     if (bad && threadIdx.x == 0) *info = col0 + bad;
 }
 

@@ -79,17 +79,10 @@ __device__ __forceinline__ void leaf_step(double (&a)[16], int &bad, int col0) {
     }
 }
 
-// Factor the 128 x 128 block at A (lower part, column-major, leading dimension lda) in place and write the inverse
-// of the factor to Linv (128 x 128 column-major, zeros above the diagonal).  256 threads.  Returns 0 or the 1-based
-// index (inside the block) of the first non-positive pivot; in that case A / Linv are only partly written.
-template <bool SC1>
-__device__ __forceinline__ int diag_v4_core(double *__restrict__ A, int64_t lda, double *__restrict__ Linv, DiagV4Shared &sh) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// load phase: tile t = TIDX(i,j) belongs to wave t & 3, register slot t >> 2
+__device__ __forceinline__ void diag_v4_load(const double *__restrict__ A, int64_t lda, v4d (&acc)[9]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
-    if (tid == 0) sh.bad = 0;
-
-    // ---- load: tile t = TIDX(i,j) belongs to wave t & 3, register slot t >> 2
-    v4d acc[9];
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
@@ -102,6 +95,21 @@ __device__ __forceinline__ int diag_v4_core(double *__restrict__ A, int64_t lda,
                 acc[t >> 2] = v;
             }
         }
+}
+
+// Factor the 128 x 128 block at A (lower part, column-major, leading dimension lda) in place and write the inverse
+// of the factor to Linv (128 x 128 column-major, zeros above the diagonal).  256 threads.  Returns 0 or the 1-based
+// index (inside the block) of the first non-positive pivot; in that case A / Linv are only partly written.
+// PRELOADED: the caller hands the tile in registers (diag_v4_load layout).  STREAM: the 16 x 16 leaf inverses also go
+// to itg (8 x 256 doubles, [b][k][j] = inv(L_bb)[j][k]) and *prog counts the 16-column panels whose entries of L (and
+// leaf inverse) are visible to other workgroups -- a consumer can run the panel solve of the tiles below in step.
+template <bool SC1, bool STREAM, bool PRELOADED>
+__device__ __forceinline__ int diag_v4_core(double *__restrict__ A, int64_t lda, double *__restrict__ Linv, DiagV4Shared &sh,
+                                            v4d (&acc)[9], double *__restrict__ itg, unsigned *prog) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    if (tid == 0) sh.bad = 0;
+    if (!PRELOADED) diag_v4_load(A, lda, acc);
     __syncthreads();
 
 #pragma unroll 1
@@ -118,6 +126,7 @@ __device__ __forceinline__ int diag_v4_core(double *__restrict__ A, int64_t lda,
         __syncthreads();
         // 2. leaf: wave 0, lanes 0..31
         if (wave == 0) {
+            if (STREAM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             double a[16];
             int bad = 0;
 #pragma unroll
@@ -155,11 +164,20 @@ __device__ __forceinline__ int diag_v4_core(double *__restrict__ A, int64_t lda,
                 // lane 16 + r holds (L^-T)[r][c] = inv[c][r]:  IT[b][a2 = r][a = c]
                 const int r = lane - 16;
 #pragma unroll
-                for (int c = 0; c < 16; ++c) sh.IT[b * TILE + r * 16 + c] = (c >= r) ? a[c] : 0.0;
+                for (int c = 0; c < 16; ++c) {
+                    const double v = (c >= r) ? a[c] : 0.0;
+                    sh.IT[b * TILE + r * 16 + c] = v;
+                    if (STREAM) gstore<true>(&itg[b * TILE + r * 16 + c], v);
+                }
             }
         }
+        // panel b-1's write-through stores were issued before this leaf: waves 1..3 drain them while they wait here anyway
+        // (wave 0 drained its own before the leaf, so the leaf's stores are not waited for on the critical path)
+        if (STREAM && wave != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (sh.bad) break;
+        if (STREAM && b > 0 && tid == 64)
+            __hip_atomic_store((__attribute__((address_space(1))) unsigned *)prog, (unsigned)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // 3. panel: P_i' = inv(L_bb) * A_ib'  for the owned tiles of block column b
         const double *itb = &sh.IT[b * TILE];
         double ia[4];
@@ -202,9 +220,12 @@ __device__ __forceinline__ int diag_v4_core(double *__restrict__ A, int64_t lda,
             }
         // (the next iteration's step 1 + barrier orders these register updates before the hand-off)
     }
+    if (STREAM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int bad_all = sh.bad;
     if (bad_all) return bad_all;
+    if (STREAM && tid == 64)
+        __hip_atomic_store((__attribute__((address_space(1))) unsigned *)prog, (unsigned)NT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     // ---- inverse: wave w assembles block columns w and 7 - w of X = L^-1 in registers, MFMA C/D layout
 #pragma unroll

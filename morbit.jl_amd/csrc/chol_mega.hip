@@ -7,13 +7,18 @@
 // 128 x 128 tile jobs from two in-order queues and hand tiles to each other through flags in memory (hop ~2-3 us):
 //
 //   P(c)      diagonal tile: subtract the in-window panels, Cholesky + inverse of the factor (chol_diag_core.hpp)
+//   S(i,c)    the two tiles right below the diagonal (i = c+1, c+2): the same panel solve, but run in step with P(c) --
+//             P(c) publishes every 16-column panel of L_cc (and its 16 x 16 leaf inverse) as it is finished, S applies
+//             it to its 128 x 128 tile held in registers (MFMA, accumulator-as-operand) and publishes its own 16-column
+//             panel, which P(c+1) folds into the next diagonal tile: the next diagonal factorisation starts ~10 us after
+//             the previous one ends instead of after two dependent 128^3 GEMMs
 //   T(i,c)    panel tile: subtract the in-window panels, then  L(i,c) = X * inv(L_cc)'   (a GEMM with the inverse)
 //   U(i,c,w)  bulk update of tile (i,c), c beyond window w, with the 4 panels of window w  (K = 512, read-modify-write)
 //
-// Windows are 4 block columns: a tile of block column c receives nb(c) = floor((c-1)/4) bulk updates (right-looking,
-// rank 512) and its last 1..4 panels left-looking inside its T / P job (so the panel that has just been finished never
-// has to pass through a bulk job before the next diagonal block can start); the bulk of the flops streams the trailing
-// matrix once per 512 columns.  Panel jobs are claimed in a topological order (column by column, P first, rows
+// Windows are 4 block columns: a tile of block column c receives nb(c) = floor((c-slack)/4) bulk updates (right-looking,
+// rank 512) and its last slack..slack+3 panels left-looking inside its panel job (so a panel that has just been finished never
+// has to pass through a bulk job before the next two diagonal blocks can start); the bulk of the flops streams the
+// trailing matrix once per 512 columns.  Panel jobs are claimed in a topological order (column by column, P first, rows
 // ascending) and only wait for jobs claimed before them.  Bulk jobs sit in one queue per window (block columns
 // ascending); a workgroup takes, among the heads of all queues, the READY job with the smallest block column (the one
 // the diagonal chain needs first); a bulk job therefore (almost) never waits.  Every spin is
@@ -37,21 +42,26 @@ namespace mega {
 constexpr int NB = 128, BK = 16, LDS_LD = NB + 16;  // (2*LD) % 64 == 32: k and k+1 rows of a chunk hit disjoint banks
 constexpr int WIN = 4;                              // block columns per window
 
-enum { JOB_U = 0, JOB_T = 1, JOB_P = 2 };
+enum { JOB_U = 0, JOB_T = 1, JOB_P = 2, JOB_S = 3, JOB_UH = 4 };  // UH: 64-row half of a bulk update (w + 256 * half)
 struct Job {
     short kind, i, c, w;
 };
 // control words (each on its own 128-byte line)
-enum { CTL_QP = 0, CTL_ABORT = 32, CTL_TIMEOUT = 64, CTL_PCOLS = 96, CTL_WORDS = 128 };
+enum { CTL_QP = 0, CTL_ABORT = 32, CTL_TIMEOUT = 64, CTL_PCOLS = 96, CTL_QC = 128, CTL_WORDS = 160 };
 constexpr int QSTRIDE = 32;  // one bulk-queue head per 128-byte line
-__host__ __device__ inline int nbulk_updates(int c) { return c < 1 ? 0 : (c - 1) / WIN; }
+// SLACK: a window's bulk update of block column c is only relied on SLACK chain steps after the window was finished
+// the tiles of the chain jobs (block rows c .. c+2) rely on a window's bulk update later than the other panel tiles
+__host__ __device__ inline int nbulk_updates(int i, int c, int slack, int slack_chain) {
+    const int sl = (i - c <= 2) ? slack_chain : slack;
+    return c < sl ? 0 : (c - sl) / WIN;
+}
 
 struct Args {
     double *A;
     int64_t lda;
     int NT, MT;  // block columns, block rows (MT >= NT: extra rows ride along as panel rows)
     double *linv;  // NT x (128 x 128) inverses of the diagonal blocks of L
-    unsigned *tdone;  // [MT][NT]: tile (i,c) holds its final L entries (i == c: L_cc and its inverse)
+    unsigned *tdone;  // [MT][NT]: 2 when tile (i,c) holds its final L entries (i == c: L_cc and its inverse); 64-row halves add 1 each
     unsigned *ucnt;   // [MT][NT]: bulk updates applied to tile (i,c)
     unsigned *ctl;
     const Job *pjobs;
@@ -60,13 +70,22 @@ struct Args {
     int nbulk;
     const int *wq_start;  // [nwin + 1] first job of each window's queue in bjobs
     unsigned *wq_head;    // [nwin] x QSTRIDE claimed jobs per window
+    double *itg;          // NT x 8 x 256: 16 x 16 leaf inverses of every diagonal block (streamed panel solves)
+    unsigned *dprog;      // [NT] x QSTRIDE: 16-column panels of diagonal block c that are published
+    unsigned *sprog;      // [2][NT] x QSTRIDE: 16-column panels of tile (c + 1 + k, c) that are published
     unsigned *quiet;      // [512] x QSTRIDE per-CU count of chain-critical jobs in flight: the CU's other workgroup pauses
     int nwin;
     int *info;
-    int ndedicated;  // workgroups [0, ndedicated) serve the panel queue only
+    const Job *cjobs;  // chain queue: P(c), S(c+1,c), S(c+2,c) column by column
+    int nchainjobs;
+    int nchain;      // workgroups [0, nchain) serve the chain queue only (their CU partner stays idle)
+    int ndedicated;  // workgroups [nchain, nchain + ndedicated) serve the panel queue only
     int look;        // general workgroups take a panel job of block column c once c < (finished diagonal blocks) + look
     unsigned spin_limit;
     int use_quiet;
+    int slack, slack_chain;
+    unsigned long long *jlog;   // diagnostic launches only: 8 words per job (meta, claim, 5 stage stamps, end), jlog[0] = count
+    int jlog_cap;
     unsigned long long *trace;  // diagnostic launches only: 8 time stamps (10 ns units) per chain job (P(c), T(c+1,c))
 };
 
@@ -77,6 +96,7 @@ struct Shared {
     } u;
     int ok;
     int jkind, jidx;
+    unsigned long long *jrec;  // this job's log record (or null)
     int wlo;  // first window whose queue still holds jobs (monotone, per workgroup)
     int mycu;
 };
@@ -134,73 +154,100 @@ __device__ __forceinline__ void wg_drain() {
 }
 
 // acc(j-part, i-part) += sum_k Bp(j, k) * Ap(i, k) over K columns (multiple of 16): the LDS-tiled MFMA loop of
-// chol_update_kernel<128, *> (16-column chunks staged global -> registers -> LDS, next chunk's loads in flight under
-// the current chunk's 64 MFMAs per wave).  Ap / Bp point at row 0 of the 128-row operand tiles, column 0 of the range.
+// chol_update_kernel<TM, *> (16-column chunks staged global -> registers -> LDS, next chunk's loads in flight under
+// the current chunk's MFMAs).  Ag / Bg point at row 0 of the TM-row / 128-row operand tiles, column 0 of the range.
+// TM = 128: wave (w >> 1, w & 1) owns a 64 x 64 quadrant; TM = 64: wave w owns all 64 rows of columns 32w .. 32w+31.
+template <int TM>
 __device__ __forceinline__ void gemm_acc(const double *__restrict__ Ag, int64_t lda, const double *__restrict__ Bg, int64_t ldb, int K,
-                                         v4d (&acc)[4][4], double *smem) {
+                                         v4d (&acc)[TM / 32][4], double *smem) {
+    constexpr int NJ = TM / 32;              // 16-wide j tiles per wave
+    constexpr int AL = TM / 32;              // v2d loads per thread per A chunk
+    constexpr int AKS = (TM == 128) ? 4 : 8;  // k stride between a thread's A loads
+    // global -> register prefetch depth in chunks.  The 128-row loop is MFMA-bound with one chunk in flight (and has no
+    // registers to spare); the 64-row loop has half the MFMAs per chunk and was bound by the ~2 us load latency.
+    constexpr int PF = (TM == 128) ? 1 : 2;
     double *As = smem;
     double *Bs = smem + BK * LDS_LD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
-    const int ioff = (wave >> 1) * 64, joff = (wave & 1) * 64;
-    const int i2 = (tid & 63) * 2, k0 = tid >> 6;
-    const double *Ap = Ag + i2 + (int64_t)k0 * lda;
-    const double *Bp = Bg + i2 + (int64_t)k0 * ldb;
-    v2d ra[4], rb[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) ra[u] = *(const gv2d *)(Ap + (int64_t)(4 * u) * lda);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) rb[u] = *(const gv2d *)(Bp + (int64_t)(4 * u) * ldb);
+    const int ioff = (TM == 128) ? (wave >> 1) * 64 : 0;
+    const int joff = (TM == 128) ? (wave & 1) * 64 : wave * 32;
+    const int a_i2 = (TM == 128) ? (tid & 63) * 2 : (tid & 31) * 2;
+    const int a_k0 = (TM == 128) ? (tid >> 6) : (tid >> 5);
+    const int b_i2 = (tid & 63) * 2, b_k0 = tid >> 6;
+    const double *Ap = Ag + a_i2 + (int64_t)a_k0 * lda;
+    const double *Bp = Bg + b_i2 + (int64_t)b_k0 * ldb;
+    v2d ra[PF][AL], rb[PF][4];
     const int nkc = K / BK;
-#pragma unroll 1
-    for (int kc = 0; kc < nkc; ++kc) {
-        __syncthreads();
 #pragma unroll
-        for (int u = 0; u < 4; ++u) *(v2d *)&As[(k0 + 4 * u) * LDS_LD + i2] = ra[u];
+    for (int f = 0; f < PF; ++f) {
+        if (f < nkc) {
+            const int64_t ko = (int64_t)f * BK;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) *(v2d *)&Bs[(k0 + 4 * u) * LDS_LD + i2] = rb[u];
-        __syncthreads();
-        if (kc + 1 < nkc) {
-            const int64_t ko = (int64_t)(kc + 1) * BK;
+            for (int u = 0; u < AL; ++u) ra[f][u] = *(const gv2d *)(Ap + (ko + AKS * u) * lda);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) ra[u] = *(const gv2d *)(Ap + (ko + 4 * u) * lda);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) rb[u] = *(const gv2d *)(Bp + (ko + 4 * u) * ldb);
+            for (int u = 0; u < 4; ++u) rb[f][u] = *(const gv2d *)(Bp + (ko + 4 * u) * ldb);
         }
+    }
+#pragma unroll 1
+    for (int kc0 = 0; kc0 < nkc; kc0 += PF) {
 #pragma unroll
-        for (int kk = 0; kk < BK / 4; ++kk) {
-            double av[4], bv[4];
+        for (int f = 0; f < PF; ++f) {
+            const int kc = kc0 + f;
+            if (kc < nkc) {
+                __syncthreads();
 #pragma unroll
-            for (int i = 0; i < 4; ++i) av[i] = As[(kk * 4 + l4) * LDS_LD + ioff + i * 16 + l15];
+                for (int u = 0; u < AL; ++u) *(v2d *)&As[(a_k0 + AKS * u) * LDS_LD + a_i2] = ra[f][u];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bv[j] = Bs[(kk * 4 + l4) * LDS_LD + joff + j * 16 + l15];
-            // D[row = j][col = i]: the lane index (l & 15) runs along i, contiguous in the column-major tile
+                for (int u = 0; u < 4; ++u) *(v2d *)&Bs[(b_k0 + 4 * u) * LDS_LD + b_i2] = rb[f][u];
+                __syncthreads();
+                if (kc + PF < nkc) {
+                    const int64_t ko = (int64_t)(kc + PF) * BK;
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+                    for (int u = 0; u < AL; ++u) ra[f][u] = *(const gv2d *)(Ap + (ko + AKS * u) * lda);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[j], av[i], acc[j][i], 0, 0, 0);
+                    for (int u = 0; u < 4; ++u) rb[f][u] = *(const gv2d *)(Bp + (ko + 4 * u) * ldb);
+                }
+#pragma unroll
+                for (int kk = 0; kk < BK / 4; ++kk) {
+                    double av[4], bv[NJ];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) av[i] = As[(kk * 4 + l4) * LDS_LD + ioff + i * 16 + l15];
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) bv[j] = Bs[(kk * 4 + l4) * LDS_LD + joff + j * 16 + l15];
+                    // D[row = j][col = i]: the lane index (l & 15) runs along i, contiguous in the column-major tile
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            acc[j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[j], av[i], acc[j][i], 0, 0, 0);
+                }
+            }
         }
     }
     __syncthreads();  // the LDS chunk buffers are free again (the caller may overlay them)
 }
 
-__device__ __forceinline__ void zero_acc(v4d (&acc)[4][4]) {
+template <int NJ>
+__device__ __forceinline__ void zero_acc(v4d (&acc)[NJ][4]) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[j][i] = (v4d){0.0, 0.0, 0.0, 0.0};
 }
 
-// C tile epilogue.  SUB: C = C - acc (else C = acc).  LOWER: entries above the diagonal of the tile stay untouched
-// (diagonal tiles).  SC1: write-through stores.  Batches of 16 loads before the first store of a batch (see
+// C tile epilogue (TM x 128).  SUB: C = C - acc (else C = acc).  LOWER: entries above the diagonal of the tile stay
+// untouched (diagonal tiles).  SC1: write-through stores.  Batches of 16 loads before the first store of a batch (see
 // chol_update_kernel: element-wise read-modify-write serialises 64 dependent round trips).
-template <bool SUB, bool LOWER, bool SC1>
-__device__ __forceinline__ void store_tile(double *__restrict__ C, int64_t ldc, const v4d (&acc)[4][4]) {
+template <int TM, bool SUB, bool LOWER, bool SC1>
+__device__ __forceinline__ void store_tile(double *__restrict__ C, int64_t ldc, const v4d (&acc)[TM / 32][4]) {
+    constexpr int NJ = TM / 32;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
-    const int ioff = (wave >> 1) * 64, joff = (wave & 1) * 64;
+    const int ioff = (TM == 128) ? (wave >> 1) * 64 : 0;
+    const int joff = (TM == 128) ? (wave & 1) * 64 : wave * 32;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NJ; ++j) {
         double cv[4][4];
         if (SUB) {
 #pragma unroll
@@ -228,49 +275,123 @@ __device__ __forceinline__ void store_tile(double *__restrict__ C, int64_t ldc, 
     }
 }
 
+#define JLOG(k)                                                             \
+    do {                                                                   \
+        if (sh.jrec && threadIdx.x == 0) sh.jrec[k] = wall_clock64();      \
+    } while (0)
+
 // ---- jobs ------------------------------------------------------------------------------------------------------
+// ucnt counts half tiles: a full 128-row job adds 2, a 64-row job 1; window w of tile (i,c) may start at ucnt >= 2w
+template <int TM>
 __device__ __attribute__((noinline)) bool run_bulk(const Args &a, Shared &sh, const Job jb) {
-    const int i = jb.i, c = jb.c, w = jb.w;
+    const int i = jb.i, c = jb.c, w = jb.w & 255, roff = (TM == 64) ? 64 * (jb.w >> 8) : 0;
     const int pl = WIN * w + WIN - 1;  // last panel of the window: rows finish their panels in order
-    if (!wg_wait(sh, a, a.tdone + (size_t)i * a.NT + pl, 1u, a.tdone + (size_t)c * a.NT + pl, 1u, a.ucnt + (size_t)i * a.NT + c,
-                 (unsigned)w, 0x100u))
+    if (!wg_wait(sh, a, a.tdone + (size_t)i * a.NT + pl, 2u, a.tdone + (size_t)c * a.NT + pl, 2u, a.ucnt + (size_t)i * a.NT + c,
+                 (unsigned)(2 * w), 0x100u))
         return false;
-    v4d acc[4][4];
+    JLOG(2);
+    v4d acc[TM / 32][4];
     zero_acc(acc);
     const int64_t k0 = (int64_t)WIN * w * NB;
-    gemm_acc(a.A + (int64_t)i * NB + k0 * a.lda, a.lda, a.A + (int64_t)c * NB + k0 * a.lda, a.lda, WIN * NB, acc, sh.u.gemm);
-    double *C = a.A + (int64_t)i * NB + (int64_t)c * NB * a.lda;
-    if (i == c)
-        store_tile<true, true, true>(C, a.lda, acc);
+    gemm_acc<TM>(a.A + (int64_t)i * NB + roff + k0 * a.lda, a.lda, a.A + (int64_t)c * NB + k0 * a.lda, a.lda, WIN * NB, acc, sh.u.gemm);
+    double *C = a.A + (int64_t)i * NB + roff + (int64_t)c * NB * a.lda;
+    JLOG(3);
+    if (TM == 128 && i == c)
+        store_tile<TM, true, true, true>(C, a.lda, acc);
     else
-        store_tile<true, false, true>(C, a.lda, acc);
+        store_tile<TM, true, false, true>(C, a.lda, acc);
     wg_drain();
-    if (threadIdx.x == 0) addf(a.ucnt + (size_t)i * a.NT + c, 1u);
+    if (threadIdx.x == 0) addf(a.ucnt + (size_t)i * a.NT + c, TM == 128 ? 2u : 1u);
     return true;
 }
 
-// left-looking part shared by T and P jobs: X = A(i,c) - sum_{p in [4 nb(c), c)} L(i,p) L(c,p)'  (the panels no bulk job applies)
-// written back in place (plain stores: only this workgroup reads X again).  Returns false on abort.
-__device__ __attribute__((noinline)) bool window_part(const Args &a, Shared &sh, int i, int c) {
-    const int wc = nbulk_updates(c), p0 = wc * WIN;
+// left-looking part shared by the panel jobs: X = A(i,c) - sum_{p in [4 nb(c), pend)} L(i,p) L(c,p)'  (panels no bulk job applies)
+// written back in place (plain stores: only this workgroup reads X again).  TM = 64 handles rows [roff, roff + 64) of
+// block row i.  Returns false on abort.
+template <int TM>
+__device__ __attribute__((noinline)) bool window_part(const Args &a, Shared &sh, int i, int c, int pend, int roff,
+                                                      unsigned long long *tr) {
+    const int wc = nbulk_updates(i, c, a.slack, a.slack_chain), p0 = wc * WIN;
     const unsigned *uc = a.ucnt + (size_t)i * a.NT + c;
-    if (p0 == c) return wg_wait(sh, a, uc, (unsigned)wc, nullptr, 0, nullptr, 0, 0x200u);  // c == 0 only
-    v4d acc[4][4];
+    if (p0 >= pend) return wg_wait(sh, a, uc, (unsigned)(2 * wc), nullptr, 0, nullptr, 0, 0x200u);
+    v4d acc[TM / 32][4];
     zero_acc(acc);
-    for (int p = p0; p < c; ++p) {
-        if (!wg_wait(sh, a, a.tdone + (size_t)i * a.NT + p, 1u, a.tdone + (size_t)c * a.NT + p, 1u, p == p0 ? uc : nullptr, (unsigned)wc,
-                     0x210u))
+    for (int p = p0; p < pend; ++p) {
+        if (!wg_wait(sh, a, a.tdone + (size_t)i * a.NT + p, 2u, a.tdone + (size_t)c * a.NT + p, 2u, p == p0 ? uc : nullptr,
+                     (unsigned)(2 * wc), 0x210u))
             return false;
+        if (tr && threadIdx.x == 0) tr[p == p0 ? 5 : 6] = wall_clock64();  // first / latest dependency satisfied
+        JLOG(p == p0 ? 2 : 3);
         const int64_t k0 = (int64_t)p * NB;
-        gemm_acc(a.A + (int64_t)i * NB + k0 * a.lda, a.lda, a.A + (int64_t)c * NB + k0 * a.lda, a.lda, NB, acc, sh.u.gemm);
+        gemm_acc<TM>(a.A + (int64_t)i * NB + roff + k0 * a.lda, a.lda, a.A + (int64_t)c * NB + k0 * a.lda, a.lda, NB, acc, sh.u.gemm);
     }
-    double *C = a.A + (int64_t)i * NB + (int64_t)c * NB * a.lda;
-    if (i == c)
-        store_tile<true, true, false>(C, a.lda, acc);
+    double *C = a.A + (int64_t)i * NB + roff + (int64_t)c * NB * a.lda;
+    if (TM == 128 && i == c)
+        store_tile<TM, true, true, false>(C, a.lda, acc);
     else
-        store_tile<true, false, false>(C, a.lda, acc);
+        store_tile<TM, true, false, false>(C, a.lda, acc);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    return true;
+}
+
+// S(i,c): panel solve of a tile right below the diagonal, in step with the factorisation of the diagonal block.
+// Wave v owns rows 32v .. 32v+31 of the tile as 2 x 8 tiles of 16 x 16 in the MFMA C/D layout (lane l, register r:
+// X[16u + (l & 15)][16q + (l >> 4) + 4r]), which is directly the B operand of the next MFMA.
+__device__ __attribute__((noinline)) bool run_stream(const Args &a, Shared &sh, const Job jb) {
+    const int i = jb.i, c = jb.c;
+    if (!window_part<128>(a, sh, i, c, c, 0, nullptr)) return false;
+    JLOG(4);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    double *C = a.A + (int64_t)i * NB + (int64_t)c * NB * a.lda;
+    const double *Lcc = a.A + (int64_t)c * NB + (int64_t)c * NB * a.lda;
+    const double *itg = a.itg + (size_t)c * 8 * 256;
+    const unsigned *dprog = a.dprog + (size_t)c * QSTRIDE;
+    unsigned *sprog = (i <= c + 2) ? a.sprog + ((size_t)(i - c - 1) * a.NT + c) * QSTRIDE : nullptr;  // only the diagonal job's feeder is followed
+    v4d x[2][8];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                x[u][q][r] = *(const gf64 *)&C[(32 * wave + 16 * u + l15) + (int64_t)(16 * q + l4 + 4 * r) * a.lda];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        if (!wg_wait(sh, a, dprog, (unsigned)(b + 1), nullptr, 0, nullptr, 0, 0x500u)) return false;
+        if (b == 0) JLOG(5);
+        if (b == 7) JLOG(6);
+        double ia[4];
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) ia[s2] = *(const gf64 *)&itg[b * 256 + (4 * s2 + l4) * 16 + l15];
+        double lq[8][4];
+#pragma unroll
+        for (int q = b + 1; q < 8; ++q)
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) lq[q][s2] = *(const gf64 *)&Lcc[(16 * q + l15) + (int64_t)(16 * b + 4 * s2 + l4) * a.lda];
+        v4d xs[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            v4d t = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) t = __builtin_amdgcn_mfma_f64_16x16x4f64(ia[s2], x[u][b][s2], t, 0, 0, 0);
+            xs[u] = t;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st_sc1(&C[(32 * wave + 16 * u + l15) + (int64_t)(16 * b + l4 + 4 * r) * a.lda], t[r]);
+        }
+#pragma unroll
+        for (int q = b + 1; q < 8; ++q)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) x[u][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-lq[q][s2], xs[u][s2], x[u][q], 0, 0, 0);
+        wg_drain();
+        if (threadIdx.x == 0) {
+            if (sprog) stf(sprog, (unsigned)(b + 1));
+            if (b == 7) stf(a.tdone + (size_t)i * a.NT + c, 2u);
+        }
+    }
     return true;
 }
 
@@ -279,47 +400,109 @@ __device__ __attribute__((noinline)) bool window_part(const Args &a, Shared &sh,
         if (tr && threadIdx.x == 0) tr[k] = wall_clock64();                    \
     } while (0)
 
-__device__ __attribute__((noinline)) bool run_panel(const Args &a, Shared &sh, const Job jb) {
-    const int i = jb.i, c = jb.c;
-    unsigned long long *tr = (a.trace && i <= c + 1) ? a.trace + (size_t)(2 * c + (i - c)) * 8 : nullptr;
+__device__ __attribute__((noinline)) bool run_diag(const Args &a, Shared &sh, const Job jb) {
+    const int c = jb.c;
+    unsigned long long *tr = a.trace ? a.trace + (size_t)(2 * c) * 8 : nullptr;
     MEGA_STAMP(0);
-    if (!window_part(a, sh, i, c)) return false;
+    // all panels but the last one (c - 1) through the GEMM loop; the last one is folded in as S(c, c-1) publishes it
+    if (!window_part<128>(a, sh, c, c, c - 1, 0, tr)) return false;
     MEGA_STAMP(1);
-    double *C = a.A + (int64_t)i * NB + (int64_t)c * NB * a.lda;
+    JLOG(4);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    double *C = a.A + (int64_t)c * NB + (int64_t)c * NB * a.lda;
     double *Linv = a.linv + (size_t)c * NB * NB;
-    unsigned *flag = a.tdone + (size_t)i * a.NT + c;
-    if (jb.kind == JOB_P) {
-        __builtin_amdgcn_s_setprio(3);
-        const int bad = diagcore::diag_v4_core<true>(C, a.lda, Linv, sh.u.diag);
-        __builtin_amdgcn_s_setprio(1);
-        if (bad) {
-            if (threadIdx.x == 0) {
-                *(__attribute__((address_space(1))) int *)a.info = c * NB + bad;
-                stf(a.ctl + CTL_ABORT, 1u);
-            }
-            return false;
+    diagcore::v4d acc[9];
+    diagcore::diag_v4_load(C, a.lda, acc);
+    if (c > 0) {
+        const double *Lp = a.A + (int64_t)c * NB + (int64_t)(c - 1) * NB * a.lda;  // tile (c, c-1), produced by S(c, c-1)
+        const unsigned *sprog = a.sprog + (size_t)(c - 1) * QSTRIDE;
+#pragma unroll 1
+        for (int b = 0; b < 8; ++b) {
+            if (!wg_wait(sh, a, sprog, (unsigned)(b + 1), nullptr, 0, nullptr, 0, 0x600u)) return false;
+            double op[8][4];
+#pragma unroll
+            for (int xb = 0; xb < 8; ++xb)
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) op[xb][s2] = *(const gf64 *)&Lp[(16 * xb + l15) + (int64_t)(16 * b + 4 * s2 + l4) * a.lda];
+#pragma unroll
+            for (int ti = 0; ti < 8; ++ti)
+#pragma unroll
+                for (int tj = 0; tj <= ti; ++tj) {
+                    const int t = ti * (ti + 1) / 2 + tj;
+                    if ((t & 3) == wave) {
+#pragma unroll
+                        for (int s2 = 0; s2 < 4; ++s2)
+                            acc[t >> 2] = __builtin_amdgcn_mfma_f64_16x16x4f64(-op[tj][s2], op[ti][s2], acc[t >> 2], 0, 0, 0);
+                    }
+                }
         }
-        MEGA_STAMP(2);
-        wg_drain();
-        if (threadIdx.x == 0) {
-            stf(flag, 1u);
-            addf(a.ctl + CTL_PCOLS, 1u);
-        }
-        MEGA_STAMP(3);
-        return true;
     }
-    // T: L(i,c) = X * inv(L_cc)'
-    if (!wg_wait(sh, a, a.tdone + (size_t)c * a.NT + c, 1u, nullptr, 0, nullptr, 0, 0x300u)) return false;
     MEGA_STAMP(2);
-    v4d acc[4][4];
-    zero_acc(acc);
-    gemm_acc(C, a.lda, Linv, NB, NB, acc, sh.u.gemm);  // every wave's loads of X are complete behind the loop's last barrier
+    JLOG(5);
+    __builtin_amdgcn_s_setprio(3);
+    const int bad = diagcore::diag_v4_core<true, true, true>(C, a.lda, Linv, sh.u.diag, acc, a.itg + (size_t)c * 8 * 256,
+                                                             a.dprog + (size_t)c * QSTRIDE);
+    __builtin_amdgcn_s_setprio(1);
+    if (bad) {
+        if (threadIdx.x == 0) {
+            *(__attribute__((address_space(1))) int *)a.info = c * NB + bad;
+            stf(a.ctl + CTL_ABORT, 1u);
+        }
+        return false;
+    }
     MEGA_STAMP(3);
-    store_tile<false, false, true>(C, a.lda, acc);
+    JLOG(6);
     wg_drain();
-    if (threadIdx.x == 0) stf(flag, 1u);
+    if (threadIdx.x == 0) {
+        stf(a.tdone + (size_t)c * a.NT + c, 2u);
+        addf(a.ctl + CTL_PCOLS, 1u);
+    }
     MEGA_STAMP(4);
     return true;
+}
+
+// T(i, half, c): rows [64 half, 64 half + 64) of tile (i,c).  Half-height tiles keep a row's column-to-column recurrence
+// L(i,c-1) -> update -> solve -> L(i,c) (two dependent 64 x 128 x 128 GEMMs on one CU that is shared with a bulk job)
+// faster than the diagonal chain; with 128-row tiles the rows fall behind it.
+__device__ __attribute__((noinline)) bool run_panel(const Args &a, Shared &sh, const Job jb) {
+    const int i = jb.i, c = jb.c, roff = 64 * jb.w;
+    if (!window_part<64>(a, sh, i, c, c, roff, nullptr)) return false;
+    JLOG(4);
+    double *C = a.A + (int64_t)i * NB + roff + (int64_t)c * NB * a.lda;
+    double *Linv = a.linv + (size_t)c * NB * NB;
+    // L(i,c) = X * inv(L_cc)'
+    if (!wg_wait(sh, a, a.tdone + (size_t)c * a.NT + c, 2u, nullptr, 0, nullptr, 0, 0x300u)) return false;
+    JLOG(5);
+    v4d acc[2][4];
+    zero_acc(acc);
+    gemm_acc<64>(C, a.lda, Linv, NB, NB, acc, sh.u.gemm);  // every wave's loads of X are complete behind the loop's last barrier
+    store_tile<64, false, false, true>(C, a.lda, acc);
+    wg_drain();
+    if (threadIdx.x == 0) addf(a.tdone + (size_t)i * a.NT + c, 1u);
+    return true;
+}
+
+__device__ __forceinline__ void jlog_begin(const Args &a, Shared &sh, const Job jb) {
+    if (threadIdx.x == 0) {
+        unsigned long long *r = nullptr;
+        if (a.jlog) {
+            const unsigned long long n = __hip_atomic_fetch_add((__attribute__((address_space(1))) unsigned long long *)a.jlog, 1ull,
+                                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (n < (unsigned long long)a.jlog_cap) {
+                r = a.jlog + 8 + n * 8;
+                r[0] = (unsigned long long)(unsigned short)jb.kind | ((unsigned long long)(unsigned short)jb.i << 8) |
+                       ((unsigned long long)(unsigned short)jb.c << 24) | ((unsigned long long)(unsigned short)jb.w << 40) |
+                       ((unsigned long long)blockIdx.x << 52);
+                r[1] = wall_clock64();
+            }
+        }
+        sh.jrec = r;
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void jlog_end(Shared &sh) {
+    if (sh.jrec && threadIdx.x == 0) sh.jrec[7] = wall_clock64();
 }
 
 // wave 0: among the heads of the window queues [wlo, wlo + 64) find the ready job with the smallest block column and
@@ -351,9 +534,9 @@ __device__ __forceinline__ int pick_bulk(const Args &a, Shared &sh) {
         unsigned key = 0xffffffffu;
         if (has) {
             const Job jb = a.bjobs[base + (int)h];
-            const int pl = WIN * jb.w + WIN - 1;
-            if (ldf(a.tdone + (size_t)jb.i * a.NT + pl) && ldf(a.tdone + (size_t)jb.c * a.NT + pl) &&
-                ldf(a.ucnt + (size_t)jb.i * a.NT + jb.c) >= (unsigned)jb.w)
+            const int jw = jb.w & 255, pl = WIN * jw + WIN - 1;
+            if (ldf(a.tdone + (size_t)jb.i * a.NT + pl) >= 2u && ldf(a.tdone + (size_t)jb.c * a.NT + pl) >= 2u &&
+                ldf(a.ucnt + (size_t)jb.i * a.NT + jb.c) >= (unsigned)(2 * jw))
                 key = ((unsigned)jb.c << 16) | (unsigned)lane;
         }
         unsigned best = key;
@@ -380,8 +563,9 @@ __device__ __forceinline__ int pick_bulk(const Args &a, Shared &sh) {
 
 __global__ __launch_bounds__(256, 2) void potrf_mega_kernel(const Args a) {
     __shared__ __attribute__((aligned(16))) Shared sh;
-    const bool dedicated = (int)blockIdx.x < a.ndedicated;
-    if (dedicated) __builtin_amdgcn_s_setprio(2);
+    const bool chain = (int)blockIdx.x < a.nchain;
+    const bool dedicated = !chain && (int)blockIdx.x < a.nchain + a.ndedicated;
+    if (chain || dedicated) __builtin_amdgcn_s_setprio(2);
     if (threadIdx.x == 0) {
         sh.wlo = 0;
         // (XCC, shader engine, CU) of this workgroup: a 512-workgroup launch puts exactly two workgroups on each of the 256 CUs
@@ -391,6 +575,31 @@ __global__ __launch_bounds__(256, 2) void potrf_mega_kernel(const Args a) {
     }
     __syncthreads();
     unsigned *myquiet = a.quiet + (size_t)sh.mycu * QSTRIDE;
+    if (chain) {
+        // chain workgroups only run the diagonal / streamed jobs, in order; the CU's other workgroup (if it is a general
+        // one) stays idle for the whole launch, so the latency-bound chain never shares its SIMDs
+        if (a.use_quiet && threadIdx.x == 0) addf(myquiet, 1u);
+        while (true) {
+            if (threadIdx.x == 0) {
+                int idx = -1;
+                if (!ldf(a.ctl + CTL_ABORT)) {
+                    const unsigned got = addf(a.ctl + CTL_QC, 1u);
+                    if (got < (unsigned)a.nchainjobs) idx = (int)got;
+                }
+                sh.jidx = idx;
+            }
+            __syncthreads();
+            const int idx = sh.jidx;
+            __syncthreads();
+            if (idx < 0) break;
+            const Job jb = a.cjobs[idx];
+            jlog_begin(a, sh, jb);
+            if (!(jb.kind == JOB_P ? run_diag(a, sh, jb) : run_stream(a, sh, jb))) break;
+            jlog_end(sh);
+        }
+        if (a.use_quiet && threadIdx.x == 0) addf(myquiet, 0xffffffffu);
+        return;
+    }
     unsigned idle = 0;
     int nidle = 0;
     while (true) {
@@ -458,16 +667,20 @@ __global__ __launch_bounds__(256, 2) void potrf_mega_kernel(const Args a) {
         idle = 0;
         nidle = 0;
         bool ok;
+        const unsigned long long tj0 = a.trace ? wall_clock64() : 0ull;
+        jlog_begin(a, sh, kind == 1 ? a.pjobs[idx] : a.bjobs[idx]);
         if (kind == 1) {
-            const Job jb = a.pjobs[idx];
-            const bool critical = a.use_quiet && jb.i <= jb.c + 1;  // the diagonal tile and the tile below it
-            if (critical && threadIdx.x == 0) addf(myquiet, 1u);
             if (!dedicated) __builtin_amdgcn_s_setprio(1);
-            ok = run_panel(a, sh, jb);
+            ok = run_panel(a, sh, a.pjobs[idx]);
             if (!dedicated) __builtin_amdgcn_s_setprio(0);
-            if (critical && threadIdx.x == 0) addf(myquiet, 0xffffffffu);
         } else {
-            ok = run_bulk(a, sh, a.bjobs[idx]);
+            ok = a.bjobs[idx].kind == JOB_UH ? run_bulk<64>(a, sh, a.bjobs[idx]) : run_bulk<128>(a, sh, a.bjobs[idx]);
+        }
+        jlog_end(sh);
+        if (a.trace && threadIdx.x == 0) {
+            unsigned long long *u = a.trace + (size_t)a.NT * 16 + (size_t)blockIdx.x * 4;
+            u[kind == 1 ? 1 : 0] += wall_clock64() - tj0;
+            u[kind == 1 ? 3 : 2] += 1;
         }
         if (!ok) break;
     }
@@ -499,18 +712,36 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
     } else {
         MRBF_TRY(get_buf(ctx, S_CHOL_WS, (size_t)NT * NB * NB, &a.linv));
     }
+    MRBF_TRY(get_buf(ctx, S_MEGA_IT, (size_t)NT * 8 * 256, &a.itg));
     // job tables (cached per shape)
-    if (ctx->mega_nt != NT || ctx->mega_mt != MT) {
+    const int slack = std::max(1, ctx->mega_slack), slack_chain = std::max(slack, ctx->mega_slack_chain);
+    if (ctx->mega_nt != NT || ctx->mega_mt != MT || ctx->mega_tab_slack != slack + 100 * ctx->mega_half_cols + 10000 * slack_chain) {
+        ctx->mega_tab_slack = slack + 100 * ctx->mega_half_cols + 10000 * slack_chain;
         std::vector<Job> pj, bj;
+        std::vector<Job> cj;
         for (int c = 0; c < NT; ++c) {
-            pj.push_back(Job{JOB_P, (short)c, (short)c, (short)nbulk_updates(c)});
-            for (int i = c + 1; i < MT; ++i) pj.push_back(Job{JOB_T, (short)i, (short)c, (short)nbulk_updates(c)});
+            cj.push_back(Job{JOB_P, (short)c, (short)c, (short)0});
+            for (int i = c + 1; i < MT; ++i) {
+                if (i <= c + 2)
+                    cj.push_back(Job{JOB_S, (short)i, (short)c, (short)0});
+                else
+                    for (int h = 0; h < 2; ++h) pj.push_back(Job{JOB_T, (short)i, (short)c, (short)h});
+            }
         }
         std::vector<int> wqs;
-        for (int w = 0; nbulk_updates(NT - 1) > w; ++w) {
+        for (int w = 0; nbulk_updates(MT, NT - 1, slack, slack_chain) > w; ++w) {
             wqs.push_back((int)bj.size());
-            for (int c = WIN * (w + 1) + 1; c < NT; ++c)
-                for (int i = c; i < MT; ++i) bj.push_back(Job{JOB_U, (short)i, (short)c, (short)w});
+            for (int c = WIN * (w + 1) + slack; c < NT; ++c)
+                for (int i = c; i < MT; ++i) {
+                    if (nbulk_updates(i, c, slack, slack_chain) <= w) continue;  // this window reaches the tile inside its panel job
+                    const bool half = i != c && c < WIN * (w + 1) + slack + ctx->mega_half_cols;
+                    if (half) {
+                        bj.push_back(Job{JOB_UH, (short)i, (short)c, (short)w});
+                        bj.push_back(Job{JOB_UH, (short)i, (short)c, (short)(w + 256)});
+                    } else {
+                        bj.push_back(Job{JOB_U, (short)i, (short)c, (short)w});
+                    }
+                }
         }
         wqs.push_back((int)bj.size());
         int *dwq;
@@ -518,8 +749,10 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
         MRBF_HIP(ctx, hipMemcpyAsync(dwq, wqs.data(), wqs.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
         ctx->mega_nwin = (int)wqs.size() - 1;
         Job *dj;
-        MRBF_TRY(get_buf(ctx, S_MEGA_JOBS, pj.size() + bj.size() + 1, &dj));
-        MRBF_HIP(ctx, hipMemcpyAsync(dj, pj.data(), pj.size() * sizeof(Job), hipMemcpyHostToDevice, ctx->stream));
+        MRBF_TRY(get_buf(ctx, S_MEGA_JOBS, pj.size() + bj.size() + cj.size() + 1, &dj));
+        if (!pj.empty()) MRBF_HIP(ctx, hipMemcpyAsync(dj, pj.data(), pj.size() * sizeof(Job), hipMemcpyHostToDevice, ctx->stream));
+        MRBF_HIP(ctx, hipMemcpyAsync(dj + pj.size() + bj.size(), cj.data(), cj.size() * sizeof(Job), hipMemcpyHostToDevice, ctx->stream));
+        ctx->mega_nchainjobs = (int)cj.size();
         if (!bj.empty())
             MRBF_HIP(ctx, hipMemcpyAsync(dj + pj.size(), bj.data(), bj.size() * sizeof(Job), hipMemcpyHostToDevice, ctx->stream));
         MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the host vectors die here
@@ -529,7 +762,9 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
         ctx->mega_nbulk = (int)bj.size();
     }
     Job *dj;
-    MRBF_TRY(get_buf(ctx, S_MEGA_JOBS, (size_t)ctx->mega_npanel + ctx->mega_nbulk + 1, &dj));
+    MRBF_TRY(get_buf(ctx, S_MEGA_JOBS, (size_t)ctx->mega_npanel + ctx->mega_nbulk + ctx->mega_nchainjobs + 1, &dj));
+    a.cjobs = dj + ctx->mega_npanel + ctx->mega_nbulk;
+    a.nchainjobs = ctx->mega_nchainjobs;
     a.pjobs = dj;
     a.npanel = ctx->mega_npanel;
     a.bjobs = dj + ctx->mega_npanel;
@@ -539,7 +774,7 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
     MRBF_TRY(get_buf(ctx, S_MEGA_WQ, (size_t)a.nwin + 1, &dwq));
     a.wq_start = dwq;
     // flags: one block, zeroed before every launch
-    const size_t nfl = ((size_t)CTL_WORDS + (size_t)QSTRIDE * (a.nwin + 1) + (size_t)QSTRIDE * 512 + 2 * (size_t)MT * NT + 3) / 4 * 4;
+    const size_t nfl = ((size_t)CTL_WORDS + (size_t)QSTRIDE * (a.nwin + 1) + (size_t)QSTRIDE * 512 + (size_t)QSTRIDE * 3 * NT + 2 * (size_t)MT * NT + 3) / 4 * 4;
     unsigned *fl;
     MRBF_TRY(get_buf(ctx, S_MEGA_FLAGS, nfl, &fl));
     MRBF_HIP(ctx, hipMemsetAsync(fl, 0, nfl * sizeof(unsigned), ctx->stream));
@@ -547,21 +782,50 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
     a.ctl = fl;
     a.wq_head = fl + CTL_WORDS;
     a.quiet = a.wq_head + (size_t)QSTRIDE * (a.nwin + 1);
-    a.tdone = a.quiet + (size_t)QSTRIDE * 512;
+    a.dprog = a.quiet + (size_t)QSTRIDE * 512;
+    a.sprog = a.dprog + (size_t)QSTRIDE * NT;
+    a.tdone = a.sprog + (size_t)QSTRIDE * 2 * NT;
     a.ucnt = a.tdone + (size_t)MT * NT;
     a.info = dinfo;
+    a.nchain = ctx->mega_chain;
     a.ndedicated = ctx->mega_dedicated;
     a.look = ctx->mega_look;
     a.use_quiet = ctx->mega_quiet;
+    a.slack = slack;
+    a.slack_chain = slack_chain;
     a.spin_limit = 4000000u;  // x ~0.1-0.3 us per poll: gives up after ~1 s without progress
     const int grid = ctx->mega_grid;
-    if (a.ndedicated >= grid) a.ndedicated = grid / 2;
+    if (a.nchain < 1) a.nchain = 1;
+    if (a.nchain + a.ndedicated >= grid) a.ndedicated = std::max(0, grid / 2 - a.nchain);
     const char *trace_path = getenv("MRBF_MEGA_TRACE");
     if (trace_path) {
-        MRBF_TRY(get_buf(ctx, S_MISC, (size_t)NT * 2 * 8 + 8, &a.trace));
-        MRBF_HIP(ctx, hipMemsetAsync(a.trace, 0, ((size_t)NT * 2 * 8 + 8) * sizeof(unsigned long long), ctx->stream));
+        MRBF_TRY(get_buf(ctx, S_MISC, (size_t)NT * 16 + 4 * 1024, &a.trace));
+        MRBF_HIP(ctx, hipMemsetAsync(a.trace, 0, ((size_t)NT * 16 + 4 * 1024) * sizeof(unsigned long long), ctx->stream));
+    }
+    const char *jlog_path = getenv("MRBF_MEGA_JLOG");
+    if (jlog_path) {
+        a.jlog_cap = ctx->mega_npanel + ctx->mega_nbulk + ctx->mega_nchainjobs + 16;
+        MRBF_TRY(get_buf(ctx, S_STAGE_D, (size_t)8 * a.jlog_cap + 16, &a.jlog));
+        MRBF_HIP(ctx, hipMemsetAsync(a.jlog, 0, ((size_t)8 * a.jlog_cap + 16) * sizeof(unsigned long long), ctx->stream));
     }
     hipLaunchKernelGGL(potrf_mega_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, a);
+    if (jlog_path) {
+        std::vector<unsigned long long> h((size_t)8 * a.jlog_cap + 16);
+        MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        MRBF_HIP(ctx, hipMemcpy(h.data(), a.jlog, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        if (FILE *f = fopen(jlog_path, "w")) {
+            const unsigned long long n = std::min<unsigned long long>(h[0], (unsigned long long)a.jlog_cap);
+            unsigned long long t0 = ~0ull;
+            for (unsigned long long j = 0; j < n; ++j) t0 = std::min(t0, h[8 + 8 * j + 1]);
+            for (unsigned long long j = 0; j < n; ++j) {
+                const unsigned long long *r = &h[8 + 8 * j];
+                fprintf(f, "%llu %llu %llu %llu %llu", r[0] & 0xff, (r[0] >> 8) & 0xffff, (r[0] >> 24) & 0xffff, (r[0] >> 40) & 0xfff, r[0] >> 52);
+                for (int k = 1; k < 8; ++k) fprintf(f, " %.2f", r[k] ? (double)(r[k] - t0) * 0.01 : -1.0);
+                fprintf(f, "\n");
+            }
+            fclose(f);
+        }
+    }
     MRBF_HIP(ctx, hipGetLastError());
     if (trace_path) {
         std::vector<unsigned long long> h((size_t)NT * 2 * 8);
@@ -574,6 +838,18 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
                 for (int k = 0; k < 16; ++k) fprintf(f, " %.2f", h[(size_t)c * 16 + k] ? (double)(h[(size_t)c * 16 + k] - t0) * 0.01 : -1.0);
                 fprintf(f, "\n");
             }
+            std::vector<unsigned long long> u(4 * 1024);
+            (void)hipMemcpy(u.data(), a.trace + (size_t)NT * 16, u.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+            double tb = 0, tp = 0;
+            unsigned long long nb = 0, np = 0;
+            for (int g = 0; g < grid && g < 1024; ++g) {
+                tb += (double)u[4 * g] * 0.01;
+                tp += (double)u[4 * g + 1] * 0.01;
+                nb += u[4 * g + 2];
+                np += u[4 * g + 3];
+            }
+            fprintf(f, "# util: bulk %.1f us over %llu jobs (%.1f us/job), panel %.1f us over %llu jobs (%.1f us/job), grid %d\n", tb, nb,
+                    nb ? tb / nb : 0.0, tp, np, np ? tp / np : 0.0, grid);
             fclose(f);
         }
     }

@@ -33,7 +33,7 @@ inline int poly_dim(int d, int deg) { return deg < 0 ? 0 : (deg == 0 ? 1 : d + 1
 enum Slot {
     S_XC = 0, S_SQ, S_MEAN, S_PHI, S_PI, S_Q1, S_W1, S_G, S_R, S_TAU, S_RHS, S_T1, S_T2, S_IPIV, S_INFO,
     S_STAGE_A, S_STAGE_B, S_STAGE_C, S_STAGE_D, S_EVAL_E, S_EVAL_A, S_EVAL_J, S_EVAL_SA, S_EVAL_XC, S_EVAL_XSQ,
-    S_OUT_A, S_OUT_B, S_CHOL_WS, S_MISC, S_MEGA_JOBS, S_MEGA_FLAGS, S_MEGA_WQ, S_NSLOTS
+    S_OUT_A, S_OUT_B, S_CHOL_WS, S_MISC, S_MEGA_JOBS, S_MEGA_FLAGS, S_MEGA_WQ, S_MEGA_IT, S_NSLOTS
 };
 struct Buf {
     void *p = nullptr;
@@ -55,8 +55,8 @@ struct mrbf_ctx {
     int bulk_masked = 0;
     int bulk_grid = 384;  // > 0: cap on the workgroups of a bulk trailing update (persistent tile loop)
     // persistent factorisation (chol_mega.hip): cached job tables + launch geometry
-    int mega_nt = 0, mega_mt = 0, mega_npanel = 0, mega_nbulk = 0, mega_nwin = 0;
-    int mega_grid = 512, mega_dedicated = 64, mega_look = 1, mega_min = 1024, mega_quiet = 1;
+    int mega_nt = 0, mega_mt = 0, mega_npanel = 0, mega_nbulk = 0, mega_nwin = 0, mega_nchainjobs = 0;
+    int mega_grid = 512, mega_dedicated = 64, mega_look = 1, mega_min = 1024, mega_quiet = 1, mega_chain = 12, mega_slack = 3, mega_slack_chain = 6, mega_tab_slack = -1, mega_half_cols = 0;
     std::string err;
     std::vector<mrbf::Buf> model_pool;  // released model blocks, reused by the next model of similar size (hipMalloc/hipFree cost
                                         // ~0.1-0.3 ms each and serialise across host threads)

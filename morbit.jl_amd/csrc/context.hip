@@ -181,6 +181,10 @@ int32_t mrbf_init(int32_t device_id, mrbf_ctx **out) {
         if (const char *e = getenv("MRBF_MEGA_LOOK")) ctx->mega_look = atoi(e);
         if (const char *e = getenv("MRBF_MEGA_MIN")) ctx->mega_min = atoi(e);
         if (const char *e = getenv("MRBF_MEGA_QUIET")) ctx->mega_quiet = atoi(e);
+        if (const char *e = getenv("MRBF_MEGA_CHAIN")) ctx->mega_chain = atoi(e);
+        if (const char *e = getenv("MRBF_MEGA_SLACK")) ctx->mega_slack = atoi(e);
+        if (const char *e = getenv("MRBF_MEGA_SLACK_CHAIN")) ctx->mega_slack_chain = atoi(e);
+        if (const char *e = getenv("MRBF_MEGA_HALF_COLS")) ctx->mega_half_cols = atoi(e);
         hipDeviceProp_t prop;
         int ncu = 256;
         if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) ncu = prop.multiProcessorCount;

@@ -1,17 +1,15 @@
-"""Print the chain breakdown of one traced persistent factorisation (MRBF_MEGA_TRACE=file)."""
+"""Print the chain breakdown of one traced persistent factorisation (MRBF_MEGA_TRACE=file).
+Stamps per diagonal job P(c): 0 claimed, 1 GEMM-loop part done, 2 last panel folded in (factorisation starts), 3 factor + inverse done,
+4 published."""
 import sys
 import numpy as np
 rows = np.loadtxt(sys.argv[1])
 c = rows[:, 0]
 P = rows[:, 1:9]
-T = rows[:, 9:17]
 def d(a, b):
     return np.where((a >= 0) & (b >= 0), b - a, np.nan)
-print("P: wait+window_part  diag  publish | T: window_part  wait_P  gemm  store+publish | step")
-step = np.diff(P[:, 3])
+step = np.diff(P[:, 2])
+print("  c   wait+gemm  fold-in  factor+inv  publish | start-of-factor  step | first-dep-ready last-dep-ready (relative to start of factor)")
 for k in range(len(c)):
-    print(f"{int(c[k]):3d}  P {d(P[k,0],P[k,1]):7.1f} {d(P[k,1],P[k,2]):6.1f} {d(P[k,2],P[k,3]):5.1f} |"
-          f" T {d(T[k,0],T[k,1]):7.1f} {d(T[k,1],T[k,2]):6.1f} {d(T[k,2],T[k,3]):6.1f} {d(T[k,3],T[k,4]):5.1f} |"
-          f" Pdone {P[k,3]:8.1f} Tdone {T[k,4]:8.1f} Pstart {P[k,0]:8.1f} Tstart {T[k,0]:8.1f} step {step[k-1] if k else 0:6.1f}")
-print("median step", np.nanmedian(step), "median diag", np.nanmedian(d(P[:,1],P[:,2])), "median Tgemm", np.nanmedian(d(T[:,2],T[:,3])),
-      "Tdone->next P after-window", np.nanmedian(P[1:,1]-T[:-1,4]), "Pdone->T gemm start", np.nanmedian(T[:,2]-P[:,3]))
+    print(f"{int(c[k]):3d}  {d(P[k,0],P[k,1]):8.1f} {d(P[k,1],P[k,2]):8.1f} {d(P[k,2],P[k,3]):8.1f} {d(P[k,3],P[k,4]):6.1f} | {P[k,2]:9.1f} {step[k-1] if k else 0:7.1f} | {P[k,5]-P[k,2] if P[k,5]>=0 else float('nan'):8.1f} {P[k,6]-P[k,2] if P[k,6]>=0 else float('nan'):8.1f}")
+print("median step", np.nanmedian(step), "mean step", np.nanmean(step), "median factor+inv", np.nanmedian(d(P[:, 2], P[:, 3])), "total", P[-1, 4])
