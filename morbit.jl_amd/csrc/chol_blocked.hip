@@ -478,8 +478,9 @@ int potrf_blocked_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, i
     if (ncols % CNB != 0 || mrows % CNB != 0 || mrows < ncols || (lda & 1) || (reinterpret_cast<uintptr_t>(A) & 15))
         return fail(ctx, MRBF_EHIP, "potrf_blocked needs 128-padded, 16-byte aligned storage (ncols=%lld mrows=%lld lda=%lld)",
                     (long long)ncols, (long long)mrows, (long long)lda);
-    // chol_impl 3: the whole factorisation as one persistent launch (chol_mega.hip)
-    if (ctx->chol_impl == 3 && ncols >= ctx->mega_min) return potrf_mega_tall(ctx, ncols, mrows, A, lda, dinfo, linv_all);
+    // chol_impl 3 (and the default, 0, from mega_min columns on): the whole factorisation as one persistent launch (chol_mega.hip);
+    // chol_impl 2 forces the host-driven launches below
+    if ((ctx->chol_impl == 3 || ctx->chol_impl == 0) && ncols >= ctx->mega_min) return potrf_mega_tall(ctx, ncols, mrows, A, lda, dinfo, linv_all);
     double *Lone = nullptr;
     if (!linv_all) MRBF_TRY(get_buf(ctx, S_CHOL_WS, (size_t)CNB * CNB, &Lone));
     // Look-ahead over two streams.  Panel stream P (high priority): D(j), T(j), U1(j) = update of block column j+1

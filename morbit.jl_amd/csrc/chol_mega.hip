@@ -120,6 +120,8 @@ __device__ __forceinline__ bool poll_ge(const unsigned *f, unsigned want, const 
     while (ldf(f) < want) {
         if (ldf(a.ctl + CTL_ABORT)) return false;
         if (++spins > a.spin_limit) {
+            stf(a.ctl + CTL_TIMEOUT + 1, (unsigned)(f - a.ctl));  // which word (diagnostics)
+            stf(a.ctl + CTL_TIMEOUT + 2, want);
             stf(a.ctl + CTL_TIMEOUT, code);
             stf(a.ctl + CTL_ABORT, 1u);
             return false;
@@ -729,7 +731,10 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
             }
         }
         std::vector<int> wqs;
-        for (int w = 0; nbulk_updates(MT, NT - 1, slack, slack_chain) > w; ++w) {
+        int nwin_max = 0;  // windows that reach at least one tile through a bulk job
+        for (int c = 0; c < NT; ++c)
+            for (int i = c; i < MT; ++i) nwin_max = std::max(nwin_max, nbulk_updates(i, c, slack, slack_chain));
+        for (int w = 0; w < nwin_max; ++w) {
             wqs.push_back((int)bj.size());
             for (int c = WIN * (w + 1) + slack; c < NT; ++c)
                 for (int i = c; i < MT; ++i) {
@@ -855,6 +860,21 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
     }
     // a launch that gave up reports through dinfo as well
     hipLaunchKernelGGL(mega_status_kernel, dim3(1), dim3(1), 0, ctx->stream, (const unsigned *)fl, dinfo);
+    if (getenv("MRBF_MEGA_DEBUG")) {
+        unsigned h[CTL_WORDS];
+        MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        MRBF_HIP(ctx, hipMemcpy(h, fl, sizeof(h), hipMemcpyDeviceToHost));
+        if (h[CTL_TIMEOUT]) {
+            const long off = (long)h[CTL_TIMEOUT + 1];
+            const long t0 = a.tdone - a.ctl, u0 = a.ucnt - a.ctl, d0 = a.dprog - a.ctl, s0 = a.sprog - a.ctl;
+            fprintf(stderr, "mega timeout code 0x%x word %ld want %u: ", h[CTL_TIMEOUT], off, h[CTL_TIMEOUT + 2]);
+            if (off >= u0) fprintf(stderr, "ucnt[%ld][%ld]", (off - u0) / NT, (off - u0) % NT);
+            else if (off >= t0) fprintf(stderr, "tdone[%ld][%ld]", (off - t0) / NT, (off - t0) % NT);
+            else if (off >= s0) fprintf(stderr, "sprog[%ld][%ld]", (off - s0) / QSTRIDE / NT, (off - s0) / QSTRIDE % NT);
+            else if (off >= d0) fprintf(stderr, "dprog[%ld]", (off - d0) / QSTRIDE);
+            fprintf(stderr, "  (NT %d MT %d pcols %u qpanel %u/%d qchain %u/%d)\n", NT, MT, h[CTL_PCOLS], h[CTL_QP], a.npanel, h[CTL_QC], a.nchainjobs);
+        }
+    }
     MRBF_HIP(ctx, hipGetLastError());
     return 0;
 }

@@ -469,6 +469,8 @@ static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info
         if (q > 0) MRBF_HIP(ctx, hipMemcpyAsync(hscal, scal, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
         hinfo = hflags[0];
+        if (hinfo < 0)  // the persistent factorisation gave up on a dependency (bounded spin): never observed, never silent
+            return fail(ctx, MRBF_EHIP, "persistent Cholesky gave up (code 0x%x); set MRBF_CHOL_IMPL=2 for the host-driven factorisation", -hinfo);
         info->factor_info = hinfo;
         if (q > 0) info->mu = hscal[1];
         if (hflags[1] != 0) {  // affinely dependent sites: Pi is rank deficient

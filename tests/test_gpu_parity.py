@@ -338,7 +338,7 @@ def test_batch_run_matches_single_calls(ctx):
         mod.free()
 
 
-@pytest.mark.parametrize("n", [128, 256, 300, 1024, 1537, 2700])
+@pytest.mark.parametrize("n", [128, 256, 300, 1024, 1537, 2200, 2700, 3500])
 def test_builtin_cholesky_matches_lapack(ctx, n):
     rng = np.random.Generator(np.random.PCG64(n))
     G = rng.standard_normal((n, n + 20))
@@ -363,7 +363,7 @@ def test_builtin_cholesky_matches_lapack(ctx, n):
         assert info.value == bad + 1, (impl, info.value)
 
 
-@pytest.mark.parametrize("n", [900, 2300])
+@pytest.mark.parametrize("n", [900, 1300, 1800, 2300, 2900])
 def test_fit_same_weights_with_all_cholesky_implementations(ctx, n):
     C, Y = _synthetic(n, 20, 2, seed=77)
     cfg = pkg.RbfConfig(kernel="multiquadric")
