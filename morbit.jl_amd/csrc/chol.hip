@@ -17,7 +17,7 @@ int potrf_lower(mrbf_ctx *ctx, int impl, int64_t n, double *A, int64_t lda, int 
     int *dinfo;
     MRBF_TRY(get_buf(ctx, S_INFO, (size_t)4, &dinfo));
     const int64_t npad = round_up(n, 128);
-    if (impl == 0) impl = (lda >= npad) ? (npad >= ctx->mega_min ? 3 : 2) : 1;
+    if (impl == 0) impl = (lda >= npad) ? ((npad >= ctx->mega_min && npad <= ctx->mega_max) ? 3 : 2) : 1;
     if (impl == 2 || impl == 3) {
         const int saved = ctx->chol_impl, saved_min = ctx->mega_min;
         ctx->chol_impl = impl;

@@ -480,7 +480,10 @@ int potrf_blocked_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, i
                     (long long)ncols, (long long)mrows, (long long)lda);
     // chol_impl 3 (and the default, 0, from mega_min columns on): the whole factorisation as one persistent launch (chol_mega.hip);
     // chol_impl 2 forces the host-driven launches below
-    if ((ctx->chol_impl == 3 || ctx->chol_impl == 0) && ncols >= ctx->mega_min) return potrf_mega_tall(ctx, ncols, mrows, A, lda, dinfo, linv_all);
+    // (measured: the persistent launch wins from 384 up to ~14000 columns; beyond that the factorisation is throughput-bound and
+    // the host-driven rank-512 updates below are ~8 % faster -- DESIGN.md section 3)
+    if ((ctx->chol_impl == 3 || (ctx->chol_impl == 0 && ncols <= ctx->mega_max)) && ncols >= ctx->mega_min)
+        return potrf_mega_tall(ctx, ncols, mrows, A, lda, dinfo, linv_all);
     double *Lone = nullptr;
     if (!linv_all) MRBF_TRY(get_buf(ctx, S_CHOL_WS, (size_t)CNB * CNB, &Lone));
     // Look-ahead over two streams.  Panel stream P (high priority): D(j), T(j), U1(j) = update of block column j+1

@@ -1,0 +1,80 @@
+"""Turn rocprofv3 outputs (rocpd sqlite databases) into the summaries committed under profiles/.
+
+  python tools/profile_summary.py stats  <results.db> <out.csv> [invocations]
+  python tools/profile_summary.py pmc    <write.db> <fetch.db> <out_prefix> <invocations> [config]
+
+pmc: per-kernel sums of WRITE_SIZE / FETCH_SIZE (unit KB; FETCH_SIZE doubled on gfx950, which tallies 128-byte requests
+as 64 bytes -- /opt/skills/guides/MI355X_MICROARCH.md, HBM / rocprofv3 section), grouped into the bench phases, per
+build+solve+eval cycle, written to <out_prefix>_write_summary.csv / _fetch_summary.csv and merged into
+profiles/pmc_traffic.json under the config key."""
+import csv
+import json
+import os
+import sqlite3
+import sys
+
+PHASES = [
+    ("gram", ("gram_mfma_kernel", "gram_diff_kernel")),
+    ("factor", ("potrf_mega_kernel", "mega_status_kernel", "chol_update_kernel<128, 0>", "chol_update_kernel<64", "chol_diag")),
+    ("eval", ("eval_fused_kernel", "eval_combine_kernel", "eval_rows_kernel", "jac_assemble_kernel")),
+    ("solve", ("chol_backsolve_kernel", "get_rhs_rows", "scatter_solution", "finish_lambda", "residual_kernel", "max_abs")),
+]
+
+
+def phase_of(name):
+    for ph, keys in PHASES:
+        if any(k in name for k in keys):
+            return ph
+    return "project_misc"
+
+
+def stats(db, out, inv):
+    con = sqlite3.connect(db)
+    rows = con.execute("select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) from kernels group by name order by 3 desc").fetchall()
+    tot = sum(r[2] for r in rows)
+    with open(out, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "CallsPerCycle", "MsPerCycle"])
+        for r in rows:
+            w.writerow([r[0], r[1], r[2], round(r[3], 1), round(100 * r[2] / tot, 3), r[4], r[5], round(r[1] / inv, 2), round(r[2] / 1e6 / inv, 4)])
+    print("wrote", out, "kernel time per cycle %.3f ms" % (tot / 1e6 / inv))
+
+
+def pmc_sum(db, counter):
+    con = sqlite3.connect(db)
+    return con.execute("select name, count(*), sum(counter_value) from pmc_events where counter_name = ? group by name order by 3 desc", (counter,)).fetchall()
+
+
+def pmc(wdb, fdb, prefix, inv, config):
+    out = {}
+    detail = {}
+    for db, counter, tag, scale in ((wdb, "WRITE_SIZE", "write", 1.0), (fdb, "FETCH_SIZE", "fetch", 2.0)):
+        rows = pmc_sum(db, counter)
+        with open(f"{prefix}_{tag}_summary.csv", "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["Name", "Dispatches", f"{counter}_KB_sum", "BytesPerCycle" + ("_x2_gfx950" if scale == 2.0 else ""), "Phase"])
+            for name, cnt, val in rows:
+                b = val * 1024.0 * scale / inv
+                ph = phase_of(name)
+                w.writerow([name, cnt, val, round(b, 1), ph])
+                detail.setdefault(ph, {"write_bytes": 0.0, "fetch_bytes_corrected": 0.0})
+                detail[ph]["write_bytes" if tag == "write" else "fetch_bytes_corrected"] += b
+    for ph, d in detail.items():
+        d["total"] = d["write_bytes"] + d["fetch_bytes_corrected"]
+        out[ph] = d["total"]
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "pmc_traffic.json")
+    cur = json.load(open(path)) if os.path.exists(path) else {}
+    cur[config] = out
+    cur["_note"] = ("HBM-side bytes per cycle (gram, factor: one launch per cycle) from rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE in separate "
+                    "passes; counter unit KB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B)")
+    cur.setdefault("_detail", {})
+    cur["_detail"] = {config: detail}
+    json.dump(cur, open(path, "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "stats":
+        stats(sys.argv[2], sys.argv[3], float(sys.argv[4]) if len(sys.argv) > 4 else 1.0)
+    else:
+        pmc(sys.argv[2], sys.argv[3], sys.argv[4], float(sys.argv[5]), sys.argv[6] if len(sys.argv) > 6 else "C3")
