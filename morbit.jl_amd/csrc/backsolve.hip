@@ -1,0 +1,166 @@
+// Backward substitution  L' x = y  for k right-hand sides as ONE persistent launch.
+//
+// chol_blocked.hip's backsolve_blocked issues one launch per block row (64 dependent launches x 11 us at n = 8192:
+// profiles/r01_d_kernel_stats.csv).  Here workgroup j owns block j of the unknowns: it subtracts L(i,j)' x_i for
+// i = nb-1 .. j+1 as the x_i are published, then finishes x_j = inv(L_jj)' y_j (stored block inverses) and publishes it.
+// Only the last two products of a workgroup are on the critical path (x_{j+1} has just been published); their tiles,
+// L(j+1,j) and inv(L_jj), are fetched into REGISTERS before the wait, each thread holding 32 consecutive rows of one
+// column, so after the flag the product is 32 x k FMAs per thread and one LDS reduction -- a step of the chain costs a
+// flag hand-off plus ~1 us instead of a kernel boundary plus two LDS-staged tile passes.
+// Hand-off (MI355X: XCD L2s are not coherent): x_j is stored write-through (sc1), the workgroup drains and meets at a
+// barrier, one lane stores the flag with an agent-scope atomic; consumers poll the flag and read x_j with sc1 loads.
+#include "common.hpp"
+
+namespace mrbf {
+
+namespace bsolve {
+
+constexpr int NB = 128, NTHR = 512, RPT = 32;  // rows per thread: thread (c = t & 127, g = t >> 7) holds rows 32g .. 32g+31 of column c
+typedef double v2d __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) unsigned gu32;
+typedef __attribute__((address_space(1))) double gf64;
+typedef __attribute__((address_space(1))) v2d gv2d;
+
+template <int KB>
+struct Shared {
+    double xs[KB][NB];       // the published x_i (or y_j for the final product)
+    double y[KB][NB];        // this workgroup's running right-hand side
+    double part[KB][4][NB];  // partial sums of the 4 row groups
+    int ok;
+};
+
+__device__ __forceinline__ void load_tile(const double *__restrict__ T, int64_t ldt, v2d (&r)[RPT / 2]) {
+    const int c = threadIdx.x & 127, g = threadIdx.x >> 7;
+    const double *p = T + (int64_t)c * ldt + RPT * g;
+#pragma unroll
+    for (int u = 0; u < RPT / 2; ++u) r[u] = *(const gv2d *)(p + 2 * u);
+}
+
+// y -= T' xs  (all threads; T in registers)
+template <int KB>
+__device__ __forceinline__ void tile_product(Shared<KB> &sh, const v2d (&r)[RPT / 2]) {
+    const int c = threadIdx.x & 127, g = threadIdx.x >> 7;
+    double acc[KB];
+#pragma unroll
+    for (int l = 0; l < KB; ++l) acc[l] = 0.0;
+#pragma unroll
+    for (int u = 0; u < RPT / 2; ++u) {
+#pragma unroll
+        for (int l = 0; l < KB; ++l) {
+            acc[l] = fma(r[u][0], sh.xs[l][RPT * g + 2 * u], acc[l]);
+            acc[l] = fma(r[u][1], sh.xs[l][RPT * g + 2 * u + 1], acc[l]);
+        }
+    }
+#pragma unroll
+    for (int l = 0; l < KB; ++l) sh.part[l][g][c] = acc[l];
+    __syncthreads();
+    if (g == 0) {
+#pragma unroll
+        for (int l = 0; l < KB; ++l) sh.y[l][c] -= (sh.part[l][0][c] + sh.part[l][1][c]) + (sh.part[l][2][c] + sh.part[l][3][c]);
+    }
+}
+
+template <int KB>
+__global__ __launch_bounds__(NTHR, 1) void backsolve_persistent_kernel(const double *__restrict__ L, int64_t lda, const double *__restrict__ linv_all,
+                                                                        double *__restrict__ Y, int64_t ldy, int k0, int nb, unsigned *flags,
+                                                                        unsigned epoch, unsigned spin_limit) {
+    __shared__ Shared<KB> sh;
+    const int j = blockIdx.x, tid = threadIdx.x;
+    const int c = tid & 127, g = tid >> 7;
+    // y_j
+    if (tid < KB * NB) sh.y[tid / NB][tid % NB] = *(const gf64 *)&Y[(int64_t)(k0 + tid / NB) * ldy + (int64_t)j * NB + (tid % NB)];
+    // tiles of the critical path first, into registers
+    v2d tnext[RPT / 2], tinv[RPT / 2];
+    if (j + 1 < nb) load_tile(L + (int64_t)(j + 1) * NB + (int64_t)j * NB * lda, lda, tnext);
+    load_tile(linv_all + (size_t)j * NB * NB, NB, tinv);
+    __syncthreads();
+    for (int i = nb - 1; i > j; --i) {
+        v2d ts[RPT / 2];
+        if (i > j + 1) load_tile(L + (int64_t)i * NB + (int64_t)j * NB * lda, lda, ts);  // in flight under the wait
+        if (tid == 0) {
+            int ok = 1;
+            unsigned spins = 0;
+            while (__hip_atomic_load((const gu32 *)(flags + i * 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+                if (++spins > spin_limit) {
+                    ok = 0;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            sh.ok = ok;
+        }
+        __syncthreads();
+        if (!sh.ok) return;  // (bounded spin; the caller checks the result's residual)
+        // x_i: write-through by its producer, read past the L1 (sc1)
+        if (tid < KB * NB)
+            sh.xs[tid / NB][tid % NB] =
+                __hip_atomic_load((const gf64 *)&Y[(int64_t)(k0 + tid / NB) * ldy + (int64_t)i * NB + (tid % NB)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (i > j + 1)
+            tile_product<KB>(sh, ts);
+        else
+            tile_product<KB>(sh, tnext);
+        __syncthreads();
+    }
+    // x_j = inv(L_jj)' y_j
+    {
+        double acc[KB];
+#pragma unroll
+        for (int l = 0; l < KB; ++l) acc[l] = 0.0;
+#pragma unroll
+        for (int u = 0; u < RPT / 2; ++u) {
+#pragma unroll
+            for (int l = 0; l < KB; ++l) {
+                acc[l] = fma(tinv[u][0], sh.y[l][RPT * g + 2 * u], acc[l]);
+                acc[l] = fma(tinv[u][1], sh.y[l][RPT * g + 2 * u + 1], acc[l]);
+            }
+        }
+#pragma unroll
+        for (int l = 0; l < KB; ++l) sh.part[l][g][c] = acc[l];
+        __syncthreads();
+        if (g == 0) {
+#pragma unroll
+            for (int l = 0; l < KB; ++l) {
+                const double s = (sh.part[l][0][c] + sh.part[l][1][c]) + (sh.part[l][2][c] + sh.part[l][3][c]);
+                __hip_atomic_store((gf64 *)&Y[(int64_t)(k0 + l) * ldy + (int64_t)j * NB + c], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store((gu32 *)(flags + j * 32), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+}  // namespace bsolve
+
+int backsolve_blocked(mrbf_ctx *ctx, int64_t npad, const double *L, int64_t lda, const double *linv_all, double *Y, int64_t ldy, int k);
+
+// Same contract as backsolve_blocked (chol_blocked.hip): Y (npad x k, column-major, ld ldy) is overwritten by the solution.
+int backsolve_persistent(mrbf_ctx *ctx, int64_t npad, const double *L, int64_t lda, const double *linv_all, double *Y, int64_t ldy, int k) {
+    using namespace bsolve;
+    const int nb = (int)(npad / NB);
+    static const int force_old = getenv("MRBF_BACKSOLVE_LAUNCHES") ? atoi(getenv("MRBF_BACKSOLVE_LAUNCHES")) : 0;
+    // every workgroup must be resident (one 512-thread workgroup per block column): fall back beyond the CU count
+    hipDeviceProp_t prop;
+    int ncu = 256;
+    if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) ncu = prop.multiProcessorCount;
+    if (force_old || nb < 3 || nb > ncu - 8 || (lda & 1) || (reinterpret_cast<uintptr_t>(L) & 15))
+        return backsolve_blocked(ctx, npad, L, lda, linv_all, Y, ldy, k);
+    unsigned *flags;
+    MRBF_TRY(get_buf(ctx, S_BSOLVE_FLAGS, (size_t)nb * 32, &flags));
+    MRBF_HIP(ctx, hipMemsetAsync(flags, 0, (size_t)nb * 32 * sizeof(unsigned), ctx->stream));
+    unsigned epoch = 0;
+    for (int k0 = 0; k0 < k; k0 += 4) {
+        const int kb = std::min(4, k - k0);
+        ++epoch;
+#define MRBF_BSP(KBV)                                                                                                          \
+    hipLaunchKernelGGL((backsolve_persistent_kernel<KBV>), dim3((unsigned)nb), dim3(NTHR), 0, ctx->stream, L, lda, linv_all, Y, ldy, k0, nb, \
+                       flags, epoch, 20000000u)
+        if (kb == 1) MRBF_BSP(1); else if (kb == 2) MRBF_BSP(2); else if (kb == 3) MRBF_BSP(3); else MRBF_BSP(4);
+#undef MRBF_BSP
+    }
+    MRBF_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+}  // namespace mrbf

@@ -5,17 +5,18 @@
 namespace mrbf {
 
 __global__ __launch_bounds__(256, 1) void chol_diag_v4_kernel(double *__restrict__ A, int64_t lda, double *__restrict__ Linv,
-                                                              int *__restrict__ info, int col0) {
+                                                              int *__restrict__ info, int col0, int dbg) {
     __shared__ __attribute__((aligned(16))) diagcore::DiagV4Shared sh;
     if (*info != 0) return;
     __builtin_amdgcn_s_setprio(3);  // latency-critical: outrank the bulk update's waves sharing this CU's SIMDs
-    diagcore::v4d acc[9];
-    const int bad = diagcore::diag_v4_core<false, false, false>(A, lda, Linv, sh, acc, nullptr, nullptr);
+    diagcore::v4d acc[diagcore::NSLOT];
+    const int bad = diagcore::diag_v4_core<false, false, false>(A, lda, Linv, sh, acc, nullptr, nullptr, dbg);
     if (bad && threadIdx.x == 0) *info = col0 + bad;
 }
 
 int launch_diag_v4(mrbf_ctx *ctx, hipStream_t st, double *Ajj, int64_t lda, double *Linv, int *dinfo, int col0) {
-    hipLaunchKernelGGL(chol_diag_v4_kernel, dim3(1), dim3(256), 0, st, Ajj, lda, Linv, dinfo, col0);
+    static const int dbg = getenv("MRBF_DIAG_DBG") ? atoi(getenv("MRBF_DIAG_DBG")) : 0;
+    hipLaunchKernelGGL(chol_diag_v4_kernel, dim3(1), dim3(256), 0, st, Ajj, lda, Linv, dinfo, col0, dbg);
     return 0;
 }
 

@@ -29,6 +29,13 @@ constexpr int TILE = 256;  // doubles per tile
 // lower tile incl. diagonal (register ownership map)
 #define MRBF_TIDX(i, j) ((i) * ((i) + 1) / 2 + (j))
 
+// Register ownership of the 36 lower tiles: wave 0 holds the 8 diagonal tiles (slot = i) and runs the sequential leaves;
+// waves 1..3 hold the 28 off-diagonal tiles round-robin (slot = index / 3) and run the panel solves and trailing updates,
+// which therefore overlap with the next leaf (look-ahead inside the block).
+__host__ __device__ constexpr int tile_owner(int i, int j) { return i == j ? 0 : 1 + MRBF_SIDX(i, j) % 3; }
+__host__ __device__ constexpr int tile_slot(int i, int j) { return i == j ? i : MRBF_SIDX(i, j) / 3; }
+constexpr int NSLOT = 10;
+
 struct DiagV4Shared {
     double LT[28 * TILE];  // finished strictly-lower L tiles, [tile][c][row]  (c = column inside the tile): MFMA operand order
     double IT[NT * TILE];  // leaf inverses transposed: IT[b][a2][a] = inv(L_bb)[a][a2]
@@ -79,20 +86,19 @@ __device__ __forceinline__ void leaf_step(double (&a)[16], int &bad, int col0) {
     }
 }
 
-// load phase: tile t = TIDX(i,j) belongs to wave t & 3, register slot t >> 2
-__device__ __forceinline__ void diag_v4_load(const double *__restrict__ A, int64_t lda, v4d (&acc)[9]) {
+// load phase (ownership: tile_owner / tile_slot)
+__device__ __forceinline__ void diag_v4_load(const double *__restrict__ A, int64_t lda, v4d (&acc)[NSLOT]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = 0; j <= i; ++j) {
-            const int t = MRBF_TIDX(i, j);
-            if ((t & 3) == wave) {
+            if (tile_owner(i, j) == wave) {
                 v4d v;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = *(const gf64 *)&A[(16 * i + l15) + (int64_t)(16 * j + l4 + 4 * r) * lda];
-                acc[t >> 2] = v;
+                acc[tile_slot(i, j)] = v;
             }
         }
 }
@@ -105,7 +111,7 @@ __device__ __forceinline__ void diag_v4_load(const double *__restrict__ A, int64
 // leaf inverse) are visible to other workgroups -- a consumer can run the panel solve of the tiles below in step.
 template <bool SC1, bool STREAM, bool PRELOADED>
 __device__ __forceinline__ int diag_v4_core(double *__restrict__ A, int64_t lda, double *__restrict__ Linv, DiagV4Shared &sh,
-                                            v4d (&acc)[9], double *__restrict__ itg, unsigned *prog) {
+                                            v4d (&acc)[NSLOT], double *__restrict__ itg, unsigned *prog, int dbg = 0) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
     if (tid == 0) sh.bad = 0;
@@ -114,19 +120,27 @@ __device__ __forceinline__ int diag_v4_core(double *__restrict__ A, int64_t lda,
 
 #pragma unroll 1
     for (int b = 0; b < NT; ++b) {
-        // 1. the owner of the diagonal tile (b,b) hands it to the leaf wave
-#pragma unroll
-        for (int i = 0; i < NT; ++i) {
-            const int t = MRBF_TIDX(i, i);
-            if (i == b && (t & 3) == wave) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) sh.Dt[(l4 + 4 * r) * 16 + l15] = acc[t >> 2][r];
-            }
-        }
-        __syncthreads();
-        // 2. leaf: wave 0, lanes 0..31
         if (wave == 0) {
-            if (STREAM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // ---- wave 0: finish diagonal tile (b,b) with panel b-1 (the only update the next leaf waits for), then the leaf
+            if (STREAM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own write-through stores of the previous leaf
+#pragma unroll
+            for (int i = 1; i < NT; ++i)
+                if (i == b) {
+                    const double *pi_ = &sh.LT[MRBF_SIDX(i, i - 1) * TILE];
+                    v4d c = acc[i];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+                        c = __builtin_amdgcn_mfma_f64_16x16x4f64(-opnd(pi_, s, l15, l4), opnd(pi_, s, l15, l4), c, 0, 0, 0);
+                    acc[i] = c;
+                }
+            // C/D layout -> leaf layout through LDS (wave-local: LDS operations of one wave complete in order)
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+                if (i == b) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sh.Dt[(l4 + 4 * r) * 16 + l15] = acc[i][r];
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             double a[16];
             int bad = 0;
 #pragma unroll
@@ -138,6 +152,7 @@ __device__ __forceinline__ int diag_v4_core(double *__restrict__ A, int64_t lda,
                     v = (c == lane - 16) ? 1.0 : 0.0;
                 a[c] = v;
             }
+            if (!(dbg & 2)) {
             leaf_step<0>(a, bad, 16 * b);
             leaf_step<1>(a, bad, 16 * b);
             leaf_step<2>(a, bad, 16 * b);
@@ -154,6 +169,7 @@ __device__ __forceinline__ int diag_v4_core(double *__restrict__ A, int64_t lda,
             leaf_step<13>(a, bad, 16 * b);
             leaf_step<14>(a, bad, 16 * b);
             leaf_step<15>(a, bad, 16 * b);
+            }
             if (bad && lane == 0) sh.bad = bad;
             if (lane < 16) {
                 // factor rows -> global (lower part of the diagonal tile)
@@ -170,60 +186,91 @@ __device__ __forceinline__ int diag_v4_core(double *__restrict__ A, int64_t lda,
                     if (STREAM) gstore<true>(&itg[b * TILE + r * 16 + c], v);
                 }
             }
+        } else {
+            // ---- waves 1..3 (meanwhile): the rest of panel b-1's trailing update, off-diagonal tiles (i,j), i > j > b
+            //      (block column b was brought up to date before the previous barrier)
+#pragma unroll
+            for (int i = 2; i < NT; ++i)
+#pragma unroll
+                for (int j = 1; j < i; ++j) {
+                    if (b > 0 && j > b && tile_owner(i, j) == wave) {
+                        const double *tj_ = &sh.LT[(j * (j - 1) / 2 + (b - 1)) * TILE];
+                        const double *ti_ = &sh.LT[(i * (i - 1) / 2 + (b - 1)) * TILE];
+                        v4d c = acc[tile_slot(i, j)];
+#pragma unroll
+                        for (int s = 0; s < 4; ++s)
+                            c = __builtin_amdgcn_mfma_f64_16x16x4f64(-opnd(tj_, s, l15, l4), opnd(ti_, s, l15, l4), c, 0, 0, 0);
+                        acc[tile_slot(i, j)] = c;
+                    }
+                }
+            // panel b-1's write-through stores were issued a leaf ago: draining them here costs nothing
+            if (STREAM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        // panel b-1's write-through stores were issued before this leaf: waves 1..3 drain them while they wait here anyway
-        // (wave 0 drained its own before the leaf, so the leaf's stores are not waited for on the critical path)
-        if (STREAM && wave != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        __syncthreads();  // X: leaf inverse IT[b] visible
         if (sh.bad) break;
         if (STREAM && b > 0 && tid == 64)
             __hip_atomic_store((__attribute__((address_space(1))) unsigned *)prog, (unsigned)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // 3. panel: P_i' = inv(L_bb) * A_ib'  for the owned tiles of block column b
-        const double *itb = &sh.IT[b * TILE];
-        double ia[4];
+        if (wave != 0) {
+            // ---- panel: P_i' = inv(L_bb) * A_ib'  for the owned tiles of block column b
+            const double *itb = &sh.IT[b * TILE];
+            double ia[4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) ia[s] = opnd(itb, s, l15, l4);
+            for (int s = 0; s < 4; ++s) ia[s] = opnd(itb, s, l15, l4);
 #pragma unroll
-        for (int i = 1; i < NT; ++i)
+            for (int i = 1; i < NT; ++i)
 #pragma unroll
-            for (int j = 0; j < i; ++j) {
-                const int t = MRBF_TIDX(i, j);
-                if (j == b && (t & 3) == wave) {
-                    v4d p = {0.0, 0.0, 0.0, 0.0};
-                    const v4d m = acc[t >> 2];
+                for (int j = 0; j < i; ++j) {
+                    if (j == b && tile_owner(i, j) == wave) {
+                        v4d p = {0.0, 0.0, 0.0, 0.0};
+                        const v4d m = acc[tile_slot(i, j)];
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) p = __builtin_amdgcn_mfma_f64_16x16x4f64(ia[s], m[s], p, 0, 0, 0);
-                    acc[t >> 2] = p;
+                        for (int s = 0; s < 4; ++s) p = __builtin_amdgcn_mfma_f64_16x16x4f64(ia[s], m[s], p, 0, 0, 0);
+                        acc[tile_slot(i, j)] = p;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        sh.LT[MRBF_SIDX(i, j) * TILE + (l4 + 4 * r) * 16 + l15] = p[r];
-                        gstore<SC1>(&A[(16 * i + l15) + (int64_t)(16 * j + l4 + 4 * r) * lda], p[r]);  // L(i,b), coalesced along rows
+                        for (int r = 0; r < 4; ++r) {
+                            sh.LT[MRBF_SIDX(i, j) * TILE + (l4 + 4 * r) * 16 + l15] = p[r];
+                            gstore<SC1>(&A[(16 * i + l15) + (int64_t)(16 * j + l4 + 4 * r) * lda], p[r]);  // L(i,b), coalesced along rows
+                        }
                     }
                 }
-            }
-        __syncthreads();
-        // 4. trailing update of the owned tiles (i,j), i >= j > b:  A_ij' -= P_j * P_i'
+        } else {
+            // ---- wave 0 (meanwhile): panel b-1 on the diagonal tiles it has not reached yet, (j,j), j > b
 #pragma unroll
-        for (int i = 1; i < NT; ++i)
-#pragma unroll
-            for (int j = 1; j <= i; ++j) {
-                const int t = MRBF_TIDX(i, j);
-                if (j > b && (t & 3) == wave) {
-                    const double *tj_ = &sh.LT[MRBF_SIDX(j, b) * TILE];
-                    const double *ti_ = &sh.LT[MRBF_SIDX(i, b) * TILE];
-                    v4d c = acc[t >> 2];
+            for (int j = 2; j < NT; ++j) {
+                if (b > 0 && j > b) {
+                    const double *pj_ = &sh.LT[(j * (j - 1) / 2 + (b - 1)) * TILE];
+                    v4d c = acc[j];
 #pragma unroll
                     for (int s = 0; s < 4; ++s)
-                        c = __builtin_amdgcn_mfma_f64_16x16x4f64(-opnd(tj_, s, l15, l4), opnd(ti_, s, l15, l4), c, 0, 0, 0);
-                    acc[t >> 2] = c;
+                        c = __builtin_amdgcn_mfma_f64_16x16x4f64(-opnd(pj_, s, l15, l4), opnd(pj_, s, l15, l4), c, 0, 0, 0);
+                    acc[j] = c;
                 }
             }
-        // (the next iteration's step 1 + barrier orders these register updates before the hand-off)
+        }
+        __syncthreads();  // Y: panel tiles of block column b in LT
+        if (wave != 0) {
+            // bring block column b+1 up to date first: the next panel solve needs it right after the next leaf
+#pragma unroll
+            for (int i = 2; i < NT; ++i)
+#pragma unroll
+                for (int j = 1; j < i; ++j) {
+                    if (j == b + 1 && tile_owner(i, j) == wave) {
+                        const double *tj_ = &sh.LT[(j * (j - 1) / 2 + b) * TILE];
+                        const double *ti_ = &sh.LT[(i * (i - 1) / 2 + b) * TILE];
+                        v4d c = acc[tile_slot(i, j)];
+#pragma unroll
+                        for (int s = 0; s < 4; ++s)
+                            c = __builtin_amdgcn_mfma_f64_16x16x4f64(-opnd(tj_, s, l15, l4), opnd(ti_, s, l15, l4), c, 0, 0, 0);
+                        acc[tile_slot(i, j)] = c;
+                    }
+                }
+        }
     }
     if (STREAM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int bad_all = sh.bad;
     if (bad_all) return bad_all;
+    if (dbg & 1) return 0;  // timing experiments: no inverse
     if (STREAM && tid == 64)
         __hip_atomic_store((__attribute__((address_space(1))) unsigned *)prog, (unsigned)NT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 

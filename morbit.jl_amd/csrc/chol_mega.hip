@@ -414,7 +414,7 @@ __device__ __attribute__((noinline)) bool run_diag(const Args &a, Shared &sh, co
     const int l15 = lane & 15, l4 = lane >> 4;
     double *C = a.A + (int64_t)c * NB + (int64_t)c * NB * a.lda;
     double *Linv = a.linv + (size_t)c * NB * NB;
-    diagcore::v4d acc[9];
+    diagcore::v4d acc[diagcore::NSLOT];
     diagcore::diag_v4_load(C, a.lda, acc);
     if (c > 0) {
         const double *Lp = a.A + (int64_t)c * NB + (int64_t)(c - 1) * NB * a.lda;  // tile (c, c-1), produced by S(c, c-1)
@@ -431,11 +431,11 @@ __device__ __attribute__((noinline)) bool run_diag(const Args &a, Shared &sh, co
             for (int ti = 0; ti < 8; ++ti)
 #pragma unroll
                 for (int tj = 0; tj <= ti; ++tj) {
-                    const int t = ti * (ti + 1) / 2 + tj;
-                    if ((t & 3) == wave) {
+                    if (diagcore::tile_owner(ti, tj) == wave) {
 #pragma unroll
                         for (int s2 = 0; s2 < 4; ++s2)
-                            acc[t >> 2] = __builtin_amdgcn_mfma_f64_16x16x4f64(-op[tj][s2], op[ti][s2], acc[t >> 2], 0, 0, 0);
+                            acc[diagcore::tile_slot(ti, tj)] =
+                                __builtin_amdgcn_mfma_f64_16x16x4f64(-op[tj][s2], op[ti][s2], acc[diagcore::tile_slot(ti, tj)], 0, 0, 0);
                     }
                 }
         }

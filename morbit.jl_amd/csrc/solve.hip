@@ -303,6 +303,7 @@ static int fit_minnorm(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_i
 // ---- Cholesky paths ------------------------------------------------------------------------------
 int potrf_blocked_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int64_t lda, int *dinfo, double *linv_all);
 int backsolve_blocked(mrbf_ctx *ctx, int64_t npad, const double *L, int64_t lda, const double *linv_all, double *Y, int64_t ldy, int k);
+int backsolve_persistent(mrbf_ctx *ctx, int64_t npad, const double *L, int64_t lda, const double *linv_all, double *Y, int64_t ldy, int k);  // backsolve.hip
 int launch_update_lower(mrbf_ctx *ctx, const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc, int64_t nt, int K);
 int launch_pad_identity(mrbf_ctx *ctx, double *A, int64_t n, int64_t npad, int64_t ld);
 int tsmm_tn(mrbf_ctx *ctx, int64_t n, int p, int r, double alpha, const double *A, int64_t lda, const double *B, int64_t ldb, double beta,
@@ -491,7 +492,7 @@ static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info
     if (builtin) {
         // forward substitution came out of the factorisation (the extra rows); backward substitution with the stored block inverses
         hipLaunchKernelGGL(get_rhs_rows_kernel, dim3(nblk(npad * k)), dim3(256), 0, ctx->stream, Phi, ld, npad, B, k);
-        MRBF_TRY(backsolve_blocked(ctx, npad, Phi, ld, linv_all, B, npad, k));
+        MRBF_TRY(backsolve_persistent(ctx, npad, Phi, ld, linv_all, B, npad, k));
     } else {
         MRBF_BLAS(ctx, rocsolver_dpotrs(ctx->blas, rocblas_fill_lower, (int)n, k, Phi, (int)ld, B, (int)npad));
     }
