@@ -1,0 +1,290 @@
+"""Population-batched Pascoletti-Serafini descent step.
+
+Mirrors the reference's `PascolettiSerafiniConfig`, `_get_global_dir`, `_ps_max_evals`, `compute_local_ideal_point`,
+`_ps_optimization` and `get_criticality(::PascolettiSerafiniConfig, ...)` (src/descent.jl:320-581).  The reference hands
+one-point closures to NLopt's GN_ISRES (descent.jl:385, :505): every candidate costs k sweeps over all n centres.  NLopt is
+not part of this path; the subproblem solver is owned here -- an ISRES-style (mu, lambda) evolution strategy with
+stochastic ranking (Runarsson & Yao 2005, the algorithm behind GN_ISRES; population 20 (dim + 1) and survivor fraction
+1/7 as NLopt's defaults) whose whole generation is evaluated by ONE batched surrogate call
+(`eval_container_objectives_at_scaled_sites` -> `mrbf_eval`).  The k single-objective minimisations of the local ideal
+point run as k populations side by side in the same batched calls.
+
+Parity with the reference is NOT the NLopt trajectory (random, and NLopt's own stream) but the contract of
+`get_criticality`: the problem solved (variables chi = [t; x], t in [-1, 0], x in [lb_eff, ub_eff], objective t,
+constraints m_l(x) - m_l(x_n) - t r_l <= 0, descent.jl:434-447, :478-510), the evaluation budgets (`_ps_max_evals`,
+descent.jl:414-432), the start value t0 = -0.5 (:555), the criticality short-cut `any(r .<= 0)` (:546-549), the failure
+fallback (:571-572) and the returned tuple `omega = |tau|, (x_trial, mx_trial, step length in the inf-norm)` (:573-579).
+A returned point is always feasible for the subproblem (tau <= 0 means no modelled objective gets worse along r).
+"""
+from dataclasses import dataclass, field
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+
+
+@dataclass
+class PascolettiSerafiniConfig:
+    """descent.jl:324-350 (same fields and defaults; the algorithm symbols are kept for interface compatibility)."""
+    reference_point: Sequence[float] = field(default_factory=list)
+    reference_direction: Sequence[float] = field(default_factory=list)
+    trust_region_factor: float = 1.0
+    max_ps_problem_evals: int = -1
+    max_ps_polish_evals: int = -1
+    max_ideal_point_problem_evals: int = -1
+    main_algo: str = "GN_ISRES"
+    reference_algo: str = "GN_ISRES"
+    reference_trust_region_factor: float = 1.1
+    ps_polish_algo: Optional[str] = None
+
+    def __post_init__(self):
+        assert all(v > 0 for v in self.reference_direction), "The components of the `reference_direction` cannot be negative."
+
+
+def _get_global_dir(cfg, fx):
+    """descent.jl:360-368"""
+    if len(cfg.reference_direction):
+        return np.asarray(cfg.reference_direction, dtype=np.float64)
+    if len(cfg.reference_point):
+        return np.asarray(fx, dtype=np.float64) - np.asarray(cfg.reference_point, dtype=np.float64)
+    return None
+
+
+def _ps_max_evals(desc_cfg, n_vars):
+    """descent.jl:414-432"""
+    max_evals = 500 * (n_vars + 1) if desc_cfg.max_ps_problem_evals < 0 else desc_cfg.max_ps_problem_evals
+    if desc_cfg.ps_polish_algo is None:
+        return max_evals, 0
+    if desc_cfg.max_ps_polish_evals < 0:
+        g = int(np.floor(max_evals * 3 / 4))
+        return g, max_evals - g
+    return max_evals, desc_cfg.max_ps_polish_evals
+
+
+# ---- ISRES, a whole generation per evaluation call ------------------------------------------------------------------
+def _stochastic_ranking(f, phi, rng, pf=0.45):
+    """Runarsson & Yao's stochastic ranking: adjacent individuals are compared by objective when both are feasible or with
+    probability pf, else by constraint violation.  The lambda bubble sweeps are run as odd-even transposition sweeps (all
+    disjoint adjacent pairs of a phase at once) so that a generation costs O(lambda) vectorised steps on the host."""
+    lam = f.shape[0]
+    idx = np.arange(lam)
+    for sweep in range(lam):
+        swapped = False
+        for start in (0, 1):
+            a = idx[start:lam - 1:2]
+            b = idx[start + 1:lam:2]
+            if a.size == 0:
+                continue
+            u = rng.random(a.size)
+            by_f = ((phi[a] == 0.0) & (phi[b] == 0.0)) | (u < pf)
+            worse = np.where(by_f, f[a] > f[b], phi[a] > phi[b])
+            if worse.any():
+                swapped = True
+                na, nb = np.where(worse, b, a), np.where(worse, a, b)
+                idx[start:lam - 1:2], idx[start + 1:lam:2] = na, nb
+        if not swapped:
+            break
+    return idx
+
+
+class _Isres:
+    """State of one (mu, lambda) run; `ask()` gives the generation to evaluate, `tell(f, g)` ranks it and breeds the next one."""
+
+    def __init__(self, lb, ub, x0, max_evals, rng, xtol_rel=1e-3):
+        self.lb, self.ub = np.asarray(lb, dtype=np.float64), np.asarray(ub, dtype=np.float64)
+        n = self.lb.size
+        self.n, self.rng, self.max_evals, self.xtol_rel = n, rng, max_evals, xtol_rel
+        self.lam = 20 * (n + 1)
+        self.mu = int(np.ceil(self.lam / 7.0))
+        span = self.ub - self.lb
+        self.X = self.lb + rng.random((self.lam, n)) * span
+        self.X[0] = np.clip(np.asarray(x0, dtype=np.float64), self.lb, self.ub)
+        self.S = np.tile(span / np.sqrt(n), (self.lam, 1))
+        self.tau = 1.0 / np.sqrt(2.0 * np.sqrt(n))     # phi = 1 (expected rate of convergence)
+        self.taup = 1.0 / np.sqrt(2.0 * n)
+        self.alpha, self.gamma = 0.2, 0.85
+        self.evals = 0
+        self.best_x, self.best_f, self.best_phi = self.X[0].copy(), np.inf, np.inf
+        self.done = False
+
+    def ask(self):
+        budget = self.max_evals - self.evals
+        return self.X[: max(0, min(self.lam, budget))]
+
+    def tell(self, f, G):
+        """f: (m,) objective, G: (m, n_constraints) constraint values (<= 0 feasible) for the first m individuals of the generation."""
+        m = f.shape[0]
+        self.evals += m
+        if m == 0:
+            self.done = True
+            return
+        phi = np.sum(np.maximum(G, 0.0) ** 2, axis=1) if G.size else np.zeros(m)
+        bad = ~np.isfinite(f) | ~np.isfinite(phi)
+        f = np.where(bad, np.inf, f)
+        phi = np.where(bad, np.inf, phi)
+        # best-so-far: feasible beats infeasible, then the objective (NLopt keeps the best feasible point it has seen)
+        for j in range(m):
+            better = (phi[j] < self.best_phi) if (phi[j] > 0.0 or self.best_phi > 0.0) else (f[j] < self.best_f)
+            if phi[j] == 0.0 and self.best_phi > 0.0:
+                better = True
+            if better:
+                self.best_x, self.best_f, self.best_phi = self.X[j].copy(), float(f[j]), float(phi[j])
+        if self.evals >= self.max_evals or m < self.lam:
+            self.done = True
+            return
+        order = _stochastic_ranking(f, phi, self.rng)
+        P, PS = self.X[order[: self.mu]], self.S[order[: self.mu]]
+        # stop like NLopt's xtol_rel on the survivors
+        if np.all(np.ptp(P, axis=0) <= self.xtol_rel * np.maximum(np.abs(P[0]), 1e-300)):
+            self.done = True
+            return
+        lam, mu, n = self.lam, self.mu, self.n
+        par = np.arange(lam) % mu
+        Xn, Sn = P[par].copy(), PS[par].copy()
+        # differential variation along the direction towards the best individual (first mu - 1 offspring)
+        nd = mu - 1
+        if nd > 0:
+            xd = P[:nd] + self.gamma * (P[0][None, :] - P[1:nd + 1])
+            inside = (xd >= self.lb) & (xd <= self.ub)
+            Xn[:nd] = np.where(inside, xd, P[:nd])
+        # log-normal self-adaptive mutation for the rest, re-drawing components that leave the box (10 tries, then the parent's)
+        m = lam - nd
+        pr = par[nd:]
+        s = PS[pr] * np.exp(self.taup * self.rng.standard_normal((m, 1)) + self.tau * self.rng.standard_normal((m, n)))
+        s = np.minimum(s, (self.ub - self.lb) / np.sqrt(n))
+        xm = P[pr] + s * self.rng.standard_normal((m, n))
+        for _ in range(10):
+            out = (xm < self.lb) | (xm > self.ub)
+            if not out.any():
+                break
+            xm = np.where(out, P[pr] + s * self.rng.standard_normal((m, n)), xm)
+        xm = np.where((xm < self.lb) | (xm > self.ub), P[pr], xm)
+        Xn[nd:] = xm
+        Sn[nd:] = PS[pr] + self.alpha * (s - PS[pr])  # exponential smoothing
+        self.X, self.S = Xn, Sn
+
+
+def _run_populations(runs, evaluate):
+    """Advance several ISRES runs in lock step; `evaluate(list of (m_r, n) arrays) -> list of (f_r, G_r)` is called once per
+    generation for all runs together (one batched surrogate sweep).  Returns the number of batched calls."""
+    calls = 0
+    while not all(r.done for r in runs):
+        asks = [r.ask() if not r.done else r.X[:0] for r in runs]
+        results = evaluate(asks)
+        calls += 1
+        for r, (f, G) in zip(runs, results):
+            if not r.done:
+                r.tell(np.asarray(f, dtype=np.float64), np.asarray(G, dtype=np.float64))
+    return calls
+
+
+def compute_local_ideal_point(x_n, lb_eff, ub_eff, eval_objectives: Callable, n_out, max_evals, rng,
+                              eval_constraints: Optional[Callable] = None, stats=None):
+    """descent.jl:404-412: the k minima of the single objectives over the local box -- k populations, one batched call per generation.
+    eval_objectives(X) -> (m, k); eval_constraints(X) -> (m, n_c) with <= 0 feasible (optional)."""
+    runs = [_Isres(lb_eff, ub_eff, x_n, max_evals, np.random.default_rng(rng.integers(2 ** 63))) for _ in range(n_out)]
+
+    def evaluate(asks):
+        sizes = [a.shape[0] for a in asks]
+        X = np.vstack(asks) if sum(sizes) else np.empty((0, len(x_n)))
+        F = eval_objectives(X) if X.shape[0] else np.empty((0, n_out))
+        G = eval_constraints(X) if (eval_constraints is not None and X.shape[0]) else np.empty((X.shape[0], 0))
+        out, o = [], 0
+        for l, m in enumerate(sizes):
+            out.append((F[o:o + m, l], G[o:o + m]))
+            o += m
+        return out
+
+    calls = _run_populations(runs, evaluate)
+    if stats is not None:
+        stats["ideal_point_calls"] = calls
+        stats["ideal_point_evals"] = sum(r.evals for r in runs)
+    return np.array([r.best_f for r in runs])
+
+
+def _ps_optimization(t0, x, lb, ub, eval_objectives: Callable, mx, r, max_evals, rng, eval_constraints=None, stats=None):
+    """descent.jl:478-510 with the constraint functions of :434-447 folded in: minimise t over chi = [t; x]."""
+    lbc = np.concatenate([[-1.0], np.asarray(lb, dtype=np.float64)])
+    ubc = np.concatenate([[0.0], np.asarray(ub, dtype=np.float64)])
+    run = _Isres(lbc, ubc, np.concatenate([[t0], x]), max_evals, rng)
+    mx, r = np.asarray(mx, dtype=np.float64), np.asarray(r, dtype=np.float64)
+
+    def evaluate(asks):
+        chi = asks[0]
+        if chi.shape[0] == 0:
+            return [(np.empty(0), np.empty((0, mx.size)))]
+        X = np.ascontiguousarray(chi[:, 1:])
+        F = eval_objectives(X)
+        G = F - mx[None, :] - chi[:, :1] * r[None, :]          # m_l(x) - m_l(x_n) - t r_l <= 0
+        if eval_constraints is not None:
+            G = np.hstack([G, eval_constraints(X)])
+        return [(chi[:, 0].copy(), G)]
+
+    calls = _run_populations([run], evaluate)
+    if stats is not None:
+        stats["ps_calls"] = calls
+        stats["ps_evals"] = run.evals
+    if run.best_phi > 0.0 or not np.isfinite(run.best_f):
+        return np.nan, np.full(len(x), np.nan), "FAILURE"
+    return run.best_f, run.best_x[1:].copy(), ("MAXEVAL_REACHED" if run.evals >= max_evals else "XTOL_REACHED")
+
+
+def _polish(tau, x_min, lb, ub, eval_objectives, eval_jacobians, mx, r, max_evals):
+    """Gradient polish of the PS solution (the reference hands a local NLopt algorithm, descent.jl:560-569): projected steps on
+    chi = [t; x] that keep every iterate feasible; each trial costs one batched value + Jacobian call."""
+    t, x = float(tau), np.array(x_min, dtype=np.float64)
+    evals = 0
+    while evals < max_evals:
+        F = eval_objectives(x[None, :])[0]
+        J = eval_jacobians(x[None, :])[0]                      # k x d
+        evals += 1
+        # direction that decreases the largest scaled objective excess: steepest descent of max_l (m_l - mx_l)/r_l
+        act = int(np.argmax((F - mx) / r))
+        d = -J[act] / r[act]
+        if np.linalg.norm(d) == 0.0:
+            break
+        step, improved = 1.0, False
+        for _ in range(20):
+            xt = np.clip(x + step * d, lb, ub)
+            Ft = eval_objectives(xt[None, :])[0]
+            evals += 1
+            tt = float(np.clip(np.max((Ft - mx) / r), -1.0, 0.0))
+            if np.all(Ft - mx - tt * r <= 1e-14) and tt < t - 1e-12:
+                x, t, improved = xt, tt, True
+                break
+            step *= 0.5
+            if evals >= max_evals:
+                break
+        if not improved:
+            break
+    return t, x, "SUCCESS"
+
+
+def get_criticality(desc_cfg, x, x_n, fx_n, lb_eff, ub_eff, eval_objectives: Callable, eval_jacobians: Optional[Callable] = None,
+                    eval_constraints: Optional[Callable] = None, rng=None, stats=None):
+    """descent.jl:512-581.  `x` / `x_n`: scaled iterate and the point the step starts from (the same unless a normal step was taken);
+    `fx_n`: true objective values at x_n; `eval_objectives(X) -> (m, k)` surrogate values (e.g.
+    `lambda X: eval_container_objectives_at_scaled_sites(sc, scal, X)`).  Returns `(0, x_n, mx, 0)` when critical, else
+    `(omega, (x_trial, mx_trial, step_length))` exactly like the reference."""
+    rng = np.random.default_rng(0) if rng is None else rng
+    x, x_n = np.asarray(x, dtype=np.float64), np.asarray(x_n, dtype=np.float64)
+    n_vars = x_n.size
+    r = _get_global_dir(desc_cfg, fx_n)
+    max_evals_ip = 500 * (n_vars + 1) if desc_cfg.max_ideal_point_problem_evals < 0 else desc_cfg.max_ideal_point_problem_evals
+    mx = np.asarray(eval_objectives(x_n[None, :])[0], dtype=np.float64)
+    if r is None:
+        ideal = compute_local_ideal_point(x_n, lb_eff, ub_eff, eval_objectives, mx.size, max_evals_ip, rng, eval_constraints, stats)
+        r = np.asarray(fx_n, dtype=np.float64) - ideal
+    if np.any(r <= 0):
+        return 0, x_n.copy(), mx, 0
+    g_evals, l_evals = _ps_max_evals(desc_cfg, n_vars)
+    tau, x_min, ret = _ps_optimization(-0.5, x_n, lb_eff, ub_eff, eval_objectives, mx, r, g_evals, rng, eval_constraints, stats)
+    fail = ret == "FAILURE" or not np.isfinite(tau) or np.any(np.isnan(x_min))
+    if l_evals > 0 and not fail and eval_jacobians is not None:
+        t2, x2, ret2 = _polish(tau, x_min, np.asarray(lb_eff), np.asarray(ub_eff), eval_objectives, eval_jacobians, mx, r, l_evals)
+        if ret2 != "FAILURE" and np.isfinite(t2) and not np.any(np.isnan(x2)):
+            tau, x_min = t2, x2
+    if fail:
+        return 0, x.copy(), mx, 0
+    omega = abs(float(tau))
+    mx_trial = np.asarray(eval_objectives(x_min[None, :])[0], dtype=np.float64)
+    return omega, (x_min, mx_trial, float(np.linalg.norm(x - x_min, ord=np.inf)))

@@ -1,0 +1,135 @@
+"""Population-batched Pascoletti-Serafini step (morbit.jl_amd/pascoletti_serafini.py) against the contract of
+descent.jl:512-581.  CPU tests drive it with analytic models; the GPU test with a fitted RBF container."""
+import importlib
+
+import numpy as np
+import pytest
+
+import morbit  # noqa: F401
+
+pkg = importlib.import_module("morbit.jl_amd")
+ps = importlib.import_module("morbit.jl_amd.pascoletti_serafini")
+
+
+def _quadratics(centres):
+    C = np.asarray(centres, dtype=np.float64)
+
+    def f(X):
+        X = np.atleast_2d(X)
+        return np.stack([np.sum((X - c) ** 2, axis=1) for c in C], axis=1)
+
+    def jac(X):
+        X = np.atleast_2d(X)
+        return np.stack([2.0 * (X - c) for c in C], axis=1)
+
+    return f, jac
+
+
+def test_config_mirror_and_budgets():
+    cfg = ps.PascolettiSerafiniConfig()
+    assert cfg.main_algo == "GN_ISRES" and cfg.reference_trust_region_factor == 1.1 and cfg.ps_polish_algo is None
+    with pytest.raises(AssertionError):
+        ps.PascolettiSerafiniConfig(reference_direction=[1.0, -1.0])
+    assert ps._ps_max_evals(cfg, 3) == (2000, 0)                                         # 500 (n+1), no polish
+    assert ps._ps_max_evals(ps.PascolettiSerafiniConfig(ps_polish_algo="LD_MMA"), 3) == (1500, 500)
+    assert ps._ps_max_evals(ps.PascolettiSerafiniConfig(ps_polish_algo="LD_MMA", max_ps_polish_evals=7, max_ps_problem_evals=100), 3) == (100, 7)
+    assert ps._get_global_dir(cfg, [1.0, 2.0]) is None
+    assert np.array_equal(ps._get_global_dir(ps.PascolettiSerafiniConfig(reference_direction=[1.0, 2.0]), [5.0, 5.0]), [1.0, 2.0])
+    assert np.array_equal(ps._get_global_dir(ps.PascolettiSerafiniConfig(reference_point=[1.0, 2.0]), [5.0, 5.0]), [4.0, 3.0])
+
+
+def test_isres_generation_batches_and_constrained_optimum():
+    # min x0 + x1  s.t.  1 - x0 x1 <= 0 in [0, 4]^2  -> (1, 1), value 2
+    rng = np.random.default_rng(1)
+    run = ps._Isres([0.0, 0.0], [4.0, 4.0], [3.0, 3.0], 6000, rng)
+    sizes = []
+
+    def evaluate(asks):
+        X = asks[0]
+        sizes.append(X.shape[0])
+        return [(X[:, 0] + X[:, 1], (1.0 - X[:, 0] * X[:, 1])[:, None])]
+
+    calls = ps._run_populations([run], evaluate)
+    assert calls == len(sizes) and max(sizes) == 60 and run.evals <= 6000      # population 20 (n + 1), one call per generation
+    assert run.best_phi == 0.0 and abs(run.best_f - 2.0) < 5e-2
+    assert np.all(run.best_x >= 0) and np.all(run.best_x <= 4) and run.best_x[0] * run.best_x[1] >= 1.0
+
+
+def test_local_ideal_point_runs_all_objectives_side_by_side():
+    f, _ = _quadratics([[0.2, 0.2], [0.8, 0.6]])
+    calls = []
+
+    def ev(X):
+        calls.append(X.shape[0])
+        return f(X)
+
+    stats = {}
+    ideal = ps.compute_local_ideal_point(np.array([0.5, 0.5]), [0.3, 0.3], [0.7, 0.7], ev, 2, 1500, np.random.default_rng(3), stats=stats)
+    # minima over the box: objective 0 at (0.3, 0.3) -> 0.02; objective 1 at (0.7, 0.6) -> 0.01
+    assert np.allclose(ideal, [0.02, 0.01], atol=2e-3)
+    assert stats["ideal_point_calls"] == len(calls) and max(calls) == 2 * 60    # both populations in one batched call
+
+
+@pytest.mark.parametrize("polish", [False, True])
+def test_get_criticality_contract(polish):
+    f, jac = _quadratics([[0.2, 0.2, 0.5], [0.8, 0.6, 0.5]])
+    x = np.array([0.5, 0.9, 0.5])
+    lb, ub = x - 0.2, x + 0.2
+    cfg = ps.PascolettiSerafiniConfig(ps_polish_algo="LD_MMA" if polish else None)
+    stats = {}
+    omega, rest = ps.get_criticality(cfg, x, x, f(x)[0], lb, ub, f, eval_jacobians=jac, rng=np.random.default_rng(5), stats=stats)[:2]
+    x_trial, mx_trial, sl = rest
+    mx = f(x)[0]
+    assert 0 < omega <= 1.0
+    assert np.all(x_trial >= lb - 1e-15) and np.all(x_trial <= ub + 1e-15)
+    assert np.allclose(mx_trial, f(x_trial)[0]) and sl == pytest.approx(np.abs(x - x_trial).max())
+    # feasibility of the subproblem at tau = -omega: every modelled objective improves by at least omega * r_l
+    ideal = ps.compute_local_ideal_point(x, lb, ub, f, 2, 2000, np.random.default_rng(5))
+    r = mx - ideal
+    assert np.all(mx_trial - mx + omega * r <= 5e-3 * np.abs(r) + 1e-12)
+    assert np.all(mx_trial < mx)
+    assert stats["ps_evals"] <= 500 * 4 and stats["ps_calls"] <= stats["ps_evals"] // 80 + 2   # ~ one call per 80-point generation
+
+
+def test_critical_point_and_given_direction():
+    f, _ = _quadratics([[0.5, 0.5]])
+    x = np.array([0.5, 0.5])            # the minimiser of the single objective: ideal point == f(x) -> r = 0 -> critical
+    out = ps.get_criticality(ps.PascolettiSerafiniConfig(), x, x, f(x)[0], x - 0.1, x + 0.1, f, rng=np.random.default_rng(0))
+    assert out[0] == 0 and np.array_equal(out[1], x) and out[3] == 0
+    # a user-supplied direction skips the ideal-point runs
+    f2, _ = _quadratics([[0.0, 0.0], [1.0, 0.0]])
+    x = np.array([0.5, 0.4])
+    stats = {}
+    omega, (xt, mt, sl) = ps.get_criticality(ps.PascolettiSerafiniConfig(reference_direction=[1.0, 1.0]), x, x, f2(x)[0], x - 0.3, x + 0.3,
+                                             f2, rng=np.random.default_rng(2), stats=stats)
+    assert "ideal_point_calls" not in stats and omega > 0 and np.all(mt <= f2(x)[0] - omega + 1e-6)
+
+
+@pytest.mark.gpu
+def test_ps_step_on_device_container():
+    from conftest import has_gpu
+    assert has_gpu()
+    rng = np.random.default_rng(4)
+    d, n = 4, 200
+    C = rng.random((n, d))
+    Y = np.stack([np.sum((C - 0.3) ** 2, axis=1), np.sum((C - 0.7) ** 2, axis=1)], axis=1)
+    mod = pkg.update_model(pkg.RbfConfig(kernel="cubic"), C, Y)
+    sur = pkg.surrogates.RefSurrogate(mod, [0, 1])
+    sc = pkg.surrogates.SurrogateContainer(objectives=[sur])
+    launches = []
+
+    def ev(X):
+        launches.append(X.shape[0])
+        return pkg.surrogates.eval_container_objectives_at_scaled_sites(sc, None, X)
+
+    x = np.full(d, 0.5) + 0.05
+    lb, ub = x - 0.15, x + 0.15
+    fx = ev(x[None, :])[0]
+    stats = {}
+    omega, (xt, mt, sl) = ps.get_criticality(ps.PascolettiSerafiniConfig(max_ps_problem_evals=1500, max_ideal_point_problem_evals=1500),
+                                             x, x, fx, lb, ub, ev, rng=np.random.default_rng(9), stats=stats)
+    assert omega > 0 and np.all(mt < fx) and np.all(xt >= lb) and np.all(xt <= ub)
+    assert np.allclose(mt, ev(xt[None, :])[0], rtol=1e-12, atol=1e-12)
+    # one surrogate sweep per generation: the number of launches is ~ evaluations / population, not evaluations
+    assert len(launches) < 60 and sum(launches) > 2500
+    mod.free()
