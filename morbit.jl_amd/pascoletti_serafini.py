@@ -89,7 +89,7 @@ def _stochastic_ranking(f, phi, rng, pf=0.45):
 class _Isres:
     """State of one (mu, lambda) run; `ask()` gives the generation to evaluate, `tell(f, g)` ranks it and breeds the next one."""
 
-    def __init__(self, lb, ub, x0, max_evals, rng, xtol_rel=1e-3):
+    def __init__(self, lb, ub, x0, max_evals, rng, xtol_rel=1e-3, extra_starts=()):
         self.lb, self.ub = np.asarray(lb, dtype=np.float64), np.asarray(ub, dtype=np.float64)
         n = self.lb.size
         self.n, self.rng, self.max_evals, self.xtol_rel = n, rng, max_evals, xtol_rel
@@ -98,6 +98,8 @@ class _Isres:
         span = self.ub - self.lb
         self.X = self.lb + rng.random((self.lam, n)) * span
         self.X[0] = np.clip(np.asarray(x0, dtype=np.float64), self.lb, self.ub)
+        for j, xs in enumerate(extra_starts):
+            self.X[1 + j] = np.clip(np.asarray(xs, dtype=np.float64), self.lb, self.ub)
         self.S = np.tile(span / np.sqrt(n), (self.lam, 1))
         self.tau = 1.0 / np.sqrt(2.0 * np.sqrt(n))     # phi = 1 (expected rate of convergence)
         self.taup = 1.0 / np.sqrt(2.0 * n)
@@ -205,7 +207,9 @@ def _ps_optimization(t0, x, lb, ub, eval_objectives: Callable, mx, r, max_evals,
     """descent.jl:478-510 with the constraint functions of :434-447 folded in: minimise t over chi = [t; x]."""
     lbc = np.concatenate([[-1.0], np.asarray(lb, dtype=np.float64)])
     ubc = np.concatenate([[0.0], np.asarray(ub, dtype=np.float64)])
-    run = _Isres(lbc, ubc, np.concatenate([[t0], x]), max_evals, rng)
+    # besides the reference's start [t0; x] the population holds [0; x], which is always feasible (m(x) - m(x) - 0 r = 0): the
+    # step can then never fail for lack of a feasible individual, and tau <= 0 always
+    run = _Isres(lbc, ubc, np.concatenate([[t0], x]), max_evals, rng, extra_starts=[np.concatenate([[0.0], x])])
     mx, r = np.asarray(mx, dtype=np.float64), np.asarray(r, dtype=np.float64)
 
     def evaluate(asks):

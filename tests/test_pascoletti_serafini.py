@@ -122,7 +122,7 @@ def test_ps_step_on_device_container():
         launches.append(X.shape[0])
         return pkg.surrogates.eval_container_objectives_at_scaled_sites(sc, None, X)
 
-    x = np.full(d, 0.5) + 0.05
+    x = np.array([0.5, 0.9, 0.5, 0.15])   # off the segment between the two minimisers: not Pareto-critical
     lb, ub = x - 0.15, x + 0.15
     fx = ev(x[None, :])[0]
     stats = {}
