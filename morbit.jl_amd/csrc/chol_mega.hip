@@ -50,10 +50,14 @@ struct Job {
 enum { CTL_QP = 0, CTL_ABORT = 32, CTL_TIMEOUT = 64, CTL_PCOLS = 96, CTL_QC = 128, CTL_WORDS = 160 };
 constexpr int QSTRIDE = 32;  // one bulk-queue head per 128-byte line
 // SLACK: a window's bulk update of block column c is only relied on SLACK chain steps after the window was finished
-// the tiles of the chain jobs (block rows c .. c+2) rely on a window's bulk update later than the other panel tiles
-__host__ __device__ inline int nbulk_updates(int i, int c, int slack, int slack_chain) {
-    const int sl = (i - c <= 2) ? slack_chain : slack;
-    return c < sl ? 0 : (c - sl) / WIN;
+// Window w covers the panels [wstart(w), wstart(w+1)): the first window is shorter (`first` panels) so that bulk work
+// exists early in the launch, all others hold WIN panels.
+__host__ __device__ inline int wstart(int w, int first) { return w <= 0 ? 0 : first + WIN * (w - 1); }
+// number of windows that reach tile (i,c) through bulk jobs: those closed at least `slack` chain steps before column c; the
+// tiles of the chain jobs (block rows c .. c+2) rely on a window's bulk update later than the other panel tiles
+__host__ __device__ inline int nbulk_updates(int i, int c, int slack, int slack_chain, int first) {
+    const int t = c - ((i - c <= 2) ? slack_chain : slack);
+    return t < first ? 0 : (t - first) / WIN + 1;
 }
 
 struct Args {
@@ -83,7 +87,7 @@ struct Args {
     int look;        // general workgroups take a panel job of block column c once c < (finished diagonal blocks) + look
     unsigned spin_limit;
     int use_quiet;
-    int slack, slack_chain;
+    int slack, slack_chain, first;
     unsigned long long *jlog;   // diagnostic launches only: 8 words per job (meta, claim, 5 stage stamps, end), jlog[0] = count
     int jlog_cap;
     unsigned long long *trace;  // diagnostic launches only: 8 time stamps (10 ns units) per chain job (P(c), T(c+1,c))
@@ -287,15 +291,16 @@ __device__ __forceinline__ void store_tile(double *__restrict__ C, int64_t ldc, 
 template <int TM>
 __device__ __attribute__((noinline)) bool run_bulk(const Args &a, Shared &sh, const Job jb) {
     const int i = jb.i, c = jb.c, w = jb.w & 255, roff = (TM == 64) ? 64 * (jb.w >> 8) : 0;
-    const int pl = WIN * w + WIN - 1;  // last panel of the window: rows finish their panels in order
+    const int pl = wstart(w + 1, a.first) - 1;  // last panel of the window: rows finish their panels in order
     if (!wg_wait(sh, a, a.tdone + (size_t)i * a.NT + pl, 2u, a.tdone + (size_t)c * a.NT + pl, 2u, a.ucnt + (size_t)i * a.NT + c,
                  (unsigned)(2 * w), 0x100u))
         return false;
     JLOG(2);
     v4d acc[TM / 32][4];
     zero_acc(acc);
-    const int64_t k0 = (int64_t)WIN * w * NB;
-    gemm_acc<TM>(a.A + (int64_t)i * NB + roff + k0 * a.lda, a.lda, a.A + (int64_t)c * NB + k0 * a.lda, a.lda, WIN * NB, acc, sh.u.gemm);
+    const int64_t k0 = (int64_t)wstart(w, a.first) * NB;
+    gemm_acc<TM>(a.A + (int64_t)i * NB + roff + k0 * a.lda, a.lda, a.A + (int64_t)c * NB + k0 * a.lda, a.lda,
+                 (wstart(w + 1, a.first) - wstart(w, a.first)) * NB, acc, sh.u.gemm);
     double *C = a.A + (int64_t)i * NB + roff + (int64_t)c * NB * a.lda;
     JLOG(3);
     if (TM == 128 && i == c)
@@ -313,7 +318,7 @@ __device__ __attribute__((noinline)) bool run_bulk(const Args &a, Shared &sh, co
 template <int TM>
 __device__ __attribute__((noinline)) bool window_part(const Args &a, Shared &sh, int i, int c, int pend, int roff,
                                                       unsigned long long *tr) {
-    const int wc = nbulk_updates(i, c, a.slack, a.slack_chain), p0 = wc * WIN;
+    const int wc = nbulk_updates(i, c, a.slack, a.slack_chain, a.first), p0 = wstart(wc, a.first);
     const unsigned *uc = a.ucnt + (size_t)i * a.NT + c;
     if (p0 >= pend) return wg_wait(sh, a, uc, (unsigned)(2 * wc), nullptr, 0, nullptr, 0, 0x200u);
     v4d acc[TM / 32][4];
@@ -536,7 +541,7 @@ __device__ __forceinline__ int pick_bulk(const Args &a, Shared &sh) {
         unsigned key = 0xffffffffu;
         if (has) {
             const Job jb = a.bjobs[base + (int)h];
-            const int jw = jb.w & 255, pl = WIN * jw + WIN - 1;
+            const int jw = jb.w & 255, pl = wstart(jw + 1, a.first) - 1;
             if (ldf(a.tdone + (size_t)jb.i * a.NT + pl) >= 2u && ldf(a.tdone + (size_t)jb.c * a.NT + pl) >= 2u &&
                 ldf(a.ucnt + (size_t)jb.i * a.NT + jb.c) >= (unsigned)(2 * jw))
                 key = ((unsigned)jb.c << 16) | (unsigned)lane;
@@ -717,8 +722,9 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
     MRBF_TRY(get_buf(ctx, S_MEGA_IT, (size_t)NT * 8 * 256, &a.itg));
     // job tables (cached per shape)
     const int slack = std::max(1, ctx->mega_slack), slack_chain = std::max(slack, ctx->mega_slack_chain);
-    if (ctx->mega_nt != NT || ctx->mega_mt != MT || ctx->mega_tab_slack != slack + 100 * ctx->mega_half_cols + 10000 * slack_chain) {
-        ctx->mega_tab_slack = slack + 100 * ctx->mega_half_cols + 10000 * slack_chain;
+    const int first = std::min(WIN, std::max(1, ctx->mega_first_window));
+    if (ctx->mega_nt != NT || ctx->mega_mt != MT || ctx->mega_tab_slack != slack + 100 * ctx->mega_half_cols + 10000 * slack_chain + 1000000 * first) {
+        ctx->mega_tab_slack = slack + 100 * ctx->mega_half_cols + 10000 * slack_chain + 1000000 * first;
         std::vector<Job> pj, bj;
         std::vector<Job> cj;
         for (int c = 0; c < NT; ++c) {
@@ -733,13 +739,13 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
         std::vector<int> wqs;
         int nwin_max = 0;  // windows that reach at least one tile through a bulk job
         for (int c = 0; c < NT; ++c)
-            for (int i = c; i < MT; ++i) nwin_max = std::max(nwin_max, nbulk_updates(i, c, slack, slack_chain));
+            for (int i = c; i < MT; ++i) nwin_max = std::max(nwin_max, nbulk_updates(i, c, slack, slack_chain, first));
         for (int w = 0; w < nwin_max; ++w) {
             wqs.push_back((int)bj.size());
-            for (int c = WIN * (w + 1) + slack; c < NT; ++c)
+            for (int c = 0; c < NT; ++c)
                 for (int i = c; i < MT; ++i) {
-                    if (nbulk_updates(i, c, slack, slack_chain) <= w) continue;  // this window reaches the tile inside its panel job
-                    const bool half = i != c && c < WIN * (w + 1) + slack + ctx->mega_half_cols;
+                    if (nbulk_updates(i, c, slack, slack_chain, first) <= w) continue;  // this window reaches the tile inside its panel job
+                    const bool half = i != c && c < wstart(w + 1, first) + slack + ctx->mega_half_cols;
                     if (half) {
                         bj.push_back(Job{JOB_UH, (short)i, (short)c, (short)w});
                         bj.push_back(Job{JOB_UH, (short)i, (short)c, (short)(w + 256)});
@@ -798,6 +804,7 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
     a.use_quiet = ctx->mega_quiet;
     a.slack = slack;
     a.slack_chain = slack_chain;
+    a.first = first;
     a.spin_limit = 4000000u;  // x ~0.1-0.3 us per poll: gives up after ~1 s without progress
     const int grid = ctx->mega_grid;
     if (a.nchain < 1) a.nchain = 1;
