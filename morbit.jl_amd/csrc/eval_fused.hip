@@ -53,6 +53,9 @@ __global__ __launch_bounds__(256, (DT <= 4) ? 2 : 1) void eval_fused_kernel(
 
     // centre-tile staging: 64 rows x D doubles, row-major in global (contiguous 64*D*8 bytes); DT v2d per thread
     const int64_t c_begin = (int64_t)split * tiles_per_split * EC;
+    // the centre range is cut into gridDim.y nearly equal pieces (the last one may be shorter)
+    const int ntiles_all = (int)(npad / EC);
+    const int my_tiles = min(tiles_per_split, ntiles_all - split * tiles_per_split);
     constexpr int NLD = 2 * DT;  // 64 * D / 2 v2d over 256 threads
     v2d stg[NLD];
     auto load_tile = [&](int64_t c0) {
@@ -69,14 +72,14 @@ __global__ __launch_bounds__(256, (DT <= 4) ? 2 : 1) void eval_fused_kernel(
         }
     };
     load_tile(c_begin);
-    for (int tile = 0; tile < tiles_per_split; ++tile) {
+    for (int tile = 0; tile < my_tiles; ++tile) {
         const int64_t c0 = c_begin + (int64_t)tile * EC;
         __syncthreads();
         store_tile();
         if (tid < EC) Sq[tid] = csq[c0 + tid];
         for (int e = tid; e < KOUT * EC; e += 256) Ws[e] = Wc[(int64_t)(l0 + e / EC) * npad + c0 + (e % EC)];
         __syncthreads();
-        if (tile + 1 < tiles_per_split) load_tile(c0 + EC);
+        if (tile + 1 < my_tiles) load_tile(c0 + EC);
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
             // ---- phase 1
@@ -214,10 +217,29 @@ int eval_fused(mrbf_ctx *ctx, const mrbf_model *M, int64_t m, const double *X, d
     if (D != M->dpad) return fail(ctx, MRBF_EHIP, "eval_fused needs dpad in {64, 128} (got %d)", M->dpad);
     const int64_t mpad = round_up(m, EQ);
     const int ntiles = (int)(M->npad / EC);
-    // split the centre range so that at least ~2 workgroups per CU exist
+    // Split the centre range so that the grid fills the resident workgroup slots (2 per CU) in whole rounds: the cost of a
+    // split count is (rounds of workgroups) x (tiles per workgroup) plus the combine pass, which reads one partial per split.
+    // (C3: 157 query tiles -> 3 splits of 43 tiles = 471 workgroups in one round, instead of 4 x 32 tiles in two rounds.)
+    hipDeviceProp_t prop;
+    int slots = 512;
+    if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) slots = 2 * prop.multiProcessorCount;
+    const int64_t qtiles = mpad / EQ;
     int nsplit = 1;
-    while ((mpad / EQ) * nsplit < 512 && nsplit * 2 <= ntiles && ntiles % (nsplit * 2) == 0) nsplit *= 2;
-    const int tps = ntiles / nsplit;
+    double best_cost = 1e300;
+    for (int s = 1; s <= std::min(ntiles, 32); ++s) {
+        const int tps_s = (ntiles + s - 1) / s;
+        if ((int64_t)(s - 1) * tps_s >= ntiles) continue;  // the last piece would be empty
+        const double rounds = std::ceil((double)(qtiles * s) / slots);
+        const double cost = rounds * tps_s + 0.75 * s;
+        if (cost < best_cost) {
+            best_cost = cost;
+            nsplit = s;
+        }
+    }
+    static const int force_split = getenv("MRBF_EVAL_NSPLIT") ? atoi(getenv("MRBF_EVAL_NSPLIT")) : 0;
+    if (force_split > 0 && force_split <= ntiles && (int64_t)(force_split - 1) * ((ntiles + force_split - 1) / force_split) < ntiles)
+        nsplit = force_split;
+    const int tps = (ntiles + nsplit - 1) / nsplit;
     double *Xq, *xsq, *vpart, *sapart, *gpart = nullptr;
     MRBF_TRY(get_buf(ctx, S_EVAL_XC, (size_t)mpad * D, &Xq));
     MRBF_TRY(get_buf(ctx, S_EVAL_XSQ, (size_t)mpad, &xsq));
