@@ -40,7 +40,7 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 namespace mega {
 
 constexpr int NB = 128, BK = 16, LDS_LD = NB + 16;  // (2*LD) % 64 == 32: k and k+1 rows of a chunk hit disjoint banks
-constexpr int WIN = 4;                              // block columns per window
+constexpr int WIN_DEFAULT = 4;                      // block columns per window (Args::win)
 
 enum { JOB_U = 0, JOB_T = 1, JOB_P = 2, JOB_S = 3, JOB_UH = 4 };  // UH: 64-row half of a bulk update (w + 256 * half)
 struct Job {
@@ -51,13 +51,13 @@ enum { CTL_QP = 0, CTL_ABORT = 32, CTL_TIMEOUT = 64, CTL_PCOLS = 96, CTL_QC = 12
 constexpr int QSTRIDE = 32;  // one bulk-queue head per 128-byte line
 // SLACK: a window's bulk update of block column c is only relied on SLACK chain steps after the window was finished
 // Window w covers the panels [wstart(w), wstart(w+1)): the first window is shorter (`first` panels) so that bulk work
-// exists early in the launch, all others hold WIN panels.
-__host__ __device__ inline int wstart(int w, int first) { return w <= 0 ? 0 : first + WIN * (w - 1); }
+// exists early in the launch, all others hold `win` panels.
+__host__ __device__ inline int wstart(int w, int first, int win) { return w <= 0 ? 0 : first + win * (w - 1); }
 // number of windows that reach tile (i,c) through bulk jobs: those closed at least `slack` chain steps before column c; the
 // tiles of the chain jobs (block rows c .. c+2) rely on a window's bulk update later than the other panel tiles
-__host__ __device__ inline int nbulk_updates(int i, int c, int slack, int slack_chain, int first) {
+__host__ __device__ inline int nbulk_updates(int i, int c, int slack, int slack_chain, int first, int win) {
     const int t = c - ((i - c <= 2) ? slack_chain : slack);
-    return t < first ? 0 : (t - first) / WIN + 1;
+    return t < first ? 0 : (t - first) / win + 1;
 }
 
 struct Args {
@@ -87,7 +87,7 @@ struct Args {
     int look;        // general workgroups take a panel job of block column c once c < (finished diagonal blocks) + look
     unsigned spin_limit;
     int use_quiet;
-    int slack, slack_chain, first;
+    int slack, slack_chain, first, win;
     unsigned long long *jlog;   // diagnostic launches only: 8 words per job (meta, claim, 5 stage stamps, end), jlog[0] = count
     int jlog_cap;
     unsigned long long *trace;  // diagnostic launches only: 8 time stamps (10 ns units) per chain job (P(c), T(c+1,c))
@@ -291,16 +291,16 @@ __device__ __forceinline__ void store_tile(double *__restrict__ C, int64_t ldc, 
 template <int TM>
 __device__ __attribute__((noinline)) bool run_bulk(const Args &a, Shared &sh, const Job jb) {
     const int i = jb.i, c = jb.c, w = jb.w & 255, roff = (TM == 64) ? 64 * (jb.w >> 8) : 0;
-    const int pl = wstart(w + 1, a.first) - 1;  // last panel of the window: rows finish their panels in order
+    const int pl = wstart(w + 1, a.first, a.win) - 1;  // last panel of the window: rows finish their panels in order
     if (!wg_wait(sh, a, a.tdone + (size_t)i * a.NT + pl, 2u, a.tdone + (size_t)c * a.NT + pl, 2u, a.ucnt + (size_t)i * a.NT + c,
                  (unsigned)(2 * w), 0x100u))
         return false;
     JLOG(2);
     v4d acc[TM / 32][4];
     zero_acc(acc);
-    const int64_t k0 = (int64_t)wstart(w, a.first) * NB;
+    const int64_t k0 = (int64_t)wstart(w, a.first, a.win) * NB;
     gemm_acc<TM>(a.A + (int64_t)i * NB + roff + k0 * a.lda, a.lda, a.A + (int64_t)c * NB + k0 * a.lda, a.lda,
-                 (wstart(w + 1, a.first) - wstart(w, a.first)) * NB, acc, sh.u.gemm);
+                 (wstart(w + 1, a.first, a.win) - wstart(w, a.first, a.win)) * NB, acc, sh.u.gemm);
     double *C = a.A + (int64_t)i * NB + roff + (int64_t)c * NB * a.lda;
     JLOG(3);
     if (TM == 128 && i == c)
@@ -318,7 +318,7 @@ __device__ __attribute__((noinline)) bool run_bulk(const Args &a, Shared &sh, co
 template <int TM>
 __device__ __attribute__((noinline)) bool window_part(const Args &a, Shared &sh, int i, int c, int pend, int roff,
                                                       unsigned long long *tr) {
-    const int wc = nbulk_updates(i, c, a.slack, a.slack_chain, a.first), p0 = wstart(wc, a.first);
+    const int wc = nbulk_updates(i, c, a.slack, a.slack_chain, a.first, a.win), p0 = wstart(wc, a.first, a.win);
     const unsigned *uc = a.ucnt + (size_t)i * a.NT + c;
     if (p0 >= pend) return wg_wait(sh, a, uc, (unsigned)(2 * wc), nullptr, 0, nullptr, 0, 0x200u);
     v4d acc[TM / 32][4];
@@ -541,7 +541,7 @@ __device__ __forceinline__ int pick_bulk(const Args &a, Shared &sh) {
         unsigned key = 0xffffffffu;
         if (has) {
             const Job jb = a.bjobs[base + (int)h];
-            const int jw = jb.w & 255, pl = wstart(jw + 1, a.first) - 1;
+            const int jw = jb.w & 255, pl = wstart(jw + 1, a.first, a.win) - 1;
             if (ldf(a.tdone + (size_t)jb.i * a.NT + pl) >= 2u && ldf(a.tdone + (size_t)jb.c * a.NT + pl) >= 2u &&
                 ldf(a.ucnt + (size_t)jb.i * a.NT + jb.c) >= (unsigned)(2 * jw))
                 key = ((unsigned)jb.c << 16) | (unsigned)lane;
@@ -625,8 +625,14 @@ __global__ __launch_bounds__(256, 2) void potrf_mega_kernel(const Args a) {
                 if (panel_left) {
                     if (dedicated || a.ndedicated == 0)
                         want_panel = true;
-                    else
-                        want_panel = a.pjobs[ph].c < (int)ldf(a.ctl + CTL_PCOLS) + a.look;
+                    else {
+                        // general workgroups only take the head panel job if its bulk updates are in: they are the ones that
+                        // run bulk jobs, and must never all sit inside panel jobs waiting for bulk updates
+                        const Job hj = a.pjobs[ph];
+                        want_panel = hj.c < (int)ldf(a.ctl + CTL_PCOLS) + a.look &&
+                                     ldf(a.ucnt + (size_t)hj.i * a.NT + hj.c) >=
+                                         2u * (unsigned)nbulk_updates(hj.i, hj.c, a.slack, a.slack_chain, a.first, a.win);
+                    }
                 }
                 if (want_panel) {
                     unsigned got = 0;
@@ -722,9 +728,11 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
     MRBF_TRY(get_buf(ctx, S_MEGA_IT, (size_t)NT * 8 * 256, &a.itg));
     // job tables (cached per shape)
     const int slack = std::max(1, ctx->mega_slack), slack_chain = std::max(slack, ctx->mega_slack_chain);
-    const int first = std::min(WIN, std::max(1, ctx->mega_first_window));
-    if (ctx->mega_nt != NT || ctx->mega_mt != MT || ctx->mega_tab_slack != slack + 100 * ctx->mega_half_cols + 10000 * slack_chain + 1000000 * first) {
-        ctx->mega_tab_slack = slack + 100 * ctx->mega_half_cols + 10000 * slack_chain + 1000000 * first;
+    // longer windows for large matrices (measured: n = 16384: 33.8 / 31.7 / 30.8 ms with 4 / 6 / 8 panels per window; n = 8192: the same)
+    const int win = std::max(1, ctx->mega_win > 0 ? ctx->mega_win : (NT >= 88 ? 8 : (NT >= 56 ? 6 : WIN_DEFAULT)));
+    const int first = std::min(win, std::max(1, ctx->mega_first_window));
+    if (ctx->mega_nt != NT || ctx->mega_mt != MT || ctx->mega_tab_slack != slack + 100 * ctx->mega_half_cols + 10000 * slack_chain + 1000000 * first + 10000000 * win) {
+        ctx->mega_tab_slack = slack + 100 * ctx->mega_half_cols + 10000 * slack_chain + 1000000 * first + 10000000 * win;
         std::vector<Job> pj, bj;
         std::vector<Job> cj;
         for (int c = 0; c < NT; ++c) {
@@ -739,13 +747,13 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
         std::vector<int> wqs;
         int nwin_max = 0;  // windows that reach at least one tile through a bulk job
         for (int c = 0; c < NT; ++c)
-            for (int i = c; i < MT; ++i) nwin_max = std::max(nwin_max, nbulk_updates(i, c, slack, slack_chain, first));
+            for (int i = c; i < MT; ++i) nwin_max = std::max(nwin_max, nbulk_updates(i, c, slack, slack_chain, first, win));
         for (int w = 0; w < nwin_max; ++w) {
             wqs.push_back((int)bj.size());
             for (int c = 0; c < NT; ++c)
                 for (int i = c; i < MT; ++i) {
-                    if (nbulk_updates(i, c, slack, slack_chain, first) <= w) continue;  // this window reaches the tile inside its panel job
-                    const bool half = i != c && c < wstart(w + 1, first) + slack + ctx->mega_half_cols;
+                    if (nbulk_updates(i, c, slack, slack_chain, first, win) <= w) continue;  // this window reaches the tile inside its panel job
+                    const bool half = i != c && c < wstart(w + 1, first, win) + slack + ctx->mega_half_cols;
                     if (half) {
                         bj.push_back(Job{JOB_UH, (short)i, (short)c, (short)w});
                         bj.push_back(Job{JOB_UH, (short)i, (short)c, (short)(w + 256)});
@@ -805,6 +813,7 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
     a.slack = slack;
     a.slack_chain = slack_chain;
     a.first = first;
+    a.win = win;
     a.spin_limit = 4000000u;  // x ~0.1-0.3 us per poll: gives up after ~1 s without progress
     const int grid = ctx->mega_grid;
     if (a.nchain < 1) a.nchain = 1;
