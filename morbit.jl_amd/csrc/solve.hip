@@ -462,33 +462,6 @@ static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info
         MRBF_HIP(ctx, hipMemcpyAsync(dinfo, dpot, sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
         MRBF_HIP(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
     }
-    {
-        // one host round trip for all the flags of this path (the only synchronisation before the solve)
-        int hflags[4] = {0, 0, 0, 0};
-        double hscal[2] = {0.0, 0.0};
-        MRBF_HIP(ctx, hipMemcpyAsync(hflags, dinfo, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        if (q > 0) MRBF_HIP(ctx, hipMemcpyAsync(hscal, scal, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        hinfo = hflags[0];
-        if (hinfo < 0)  // the persistent factorisation gave up on a dependency (bounded spin): never observed, never silent
-            return fail(ctx, MRBF_EHIP, "persistent Cholesky gave up (code 0x%x); set MRBF_CHOL_IMPL=2 for the host-driven factorisation", -hinfo);
-        info->factor_info = hinfo;
-        if (q > 0) info->mu = hscal[1];
-        if (hflags[1] != 0) {  // affinely dependent sites: Pi is rank deficient
-            *not_pd = 1;
-            info->factor_info = -2;
-            return 0;
-        }
-        if (hflags[2] != 0) {  // trace <= 0: Z' Phi Z cannot be positive definite
-            *not_pd = 1;
-            info->factor_info = -1;
-            return 0;
-        }
-        if (hinfo != 0) {
-            *not_pd = 1;
-            return 0;
-        }
-    }
     if (builtin) {
         // forward substitution came out of the factorisation (the extra rows); backward substitution with the stored block inverses
         hipLaunchKernelGGL(get_rhs_rows_kernel, dim3(nblk(npad * k)), dim3(256), 0, ctx->stream, Phi, ld, npad, B, k);
@@ -514,6 +487,35 @@ static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info
                        M->npad, k, q, (int64_t)0, M->W, M->Wc, M->lam, T1 ? T1 : B, (int64_t)q);
     MRBF_HIP(ctx, hipGetLastError());
     MRBF_HIP(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+    {
+        // one host round trip for all the flags of this path, AFTER the solve has been enqueued: the solve kernels run on whatever
+        // the factorisation left (they terminate on any input); if a flag is set their output is discarded and the caller falls
+        // back to the LU path, which re-assembles Phi.  Reading the flags before the solve cost ~100 us of idle GPU per fit.
+        int hflags[4] = {0, 0, 0, 0};
+        double hscal[2] = {0.0, 0.0};
+        MRBF_HIP(ctx, hipMemcpyAsync(hflags, dinfo, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        if (q > 0) MRBF_HIP(ctx, hipMemcpyAsync(hscal, scal, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        hinfo = hflags[0];
+        if (hinfo < 0)  // the persistent factorisation gave up on a dependency (bounded spin): never observed, never silent
+            return fail(ctx, MRBF_EHIP, "persistent Cholesky gave up (code 0x%x); set MRBF_CHOL_IMPL=2 for the host-driven factorisation", -hinfo);
+        info->factor_info = hinfo;
+        if (q > 0) info->mu = hscal[1];
+        if (hflags[1] != 0) {  // affinely dependent sites: Pi is rank deficient
+            *not_pd = 1;
+            info->factor_info = -2;
+            return 0;
+        }
+        if (hflags[2] != 0) {  // trace <= 0: Z' Phi Z cannot be positive definite
+            *not_pd = 1;
+            info->factor_info = -1;
+            return 0;
+        }
+        if (hinfo != 0) {
+            *not_pd = 1;
+            return 0;
+        }
+    }
     MRBF_HIP(ctx, hipEventSynchronize(ctx->ev[4]));
     MRBF_HIP(ctx, hipEventElapsedTime(&info->ms_gram, ctx->ev[0], ctx->ev[1]));
     MRBF_HIP(ctx, hipEventElapsedTime(&info->ms_project, ctx->ev[1], ctx->ev[2]));
