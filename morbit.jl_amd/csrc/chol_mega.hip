@@ -87,7 +87,7 @@ struct Args {
     int look;        // general workgroups take a panel job of block column c once c < (finished diagonal blocks) + look
     unsigned spin_limit;
     int use_quiet;
-    int slack, slack_chain, first, win;
+    int slack, slack_chain, first, win, wbias;
     unsigned long long *jlog;   // diagnostic launches only: 8 words per job (meta, claim, 5 stage stamps, end), jlog[0] = count
     int jlog_cap;
     unsigned long long *trace;  // diagnostic launches only: 8 time stamps (10 ns units) per chain job (P(c), T(c+1,c))
@@ -544,7 +544,7 @@ __device__ __forceinline__ int pick_bulk(const Args &a, Shared &sh) {
             const int jw = jb.w & 255, pl = wstart(jw + 1, a.first, a.win) - 1;
             if (ldf(a.tdone + (size_t)jb.i * a.NT + pl) >= 2u && ldf(a.tdone + (size_t)jb.c * a.NT + pl) >= 2u &&
                 ldf(a.ucnt + (size_t)jb.i * a.NT + jb.c) >= (unsigned)(2 * jw))
-                key = ((unsigned)jb.c << 16) | (unsigned)lane;
+                key = ((unsigned)(jb.c + a.wbias * lane) << 16) | (unsigned)lane;  // newer windows trail the older ones by wbias columns
         }
         unsigned best = key;
 #pragma unroll
@@ -814,6 +814,7 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
     a.slack_chain = slack_chain;
     a.first = first;
     a.win = win;
+    a.wbias = ctx->mega_wbias;
     a.spin_limit = 4000000u;  // x ~0.1-0.3 us per poll: gives up after ~1 s without progress
     const int grid = ctx->mega_grid;
     if (a.nchain < 1) a.nchain = 1;

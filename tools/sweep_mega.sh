@@ -1,2 +1,1 @@
-for ded in 16 32 64 96; do for look in 1 2; do echo "ded=$ded look=$look"; MRBF_MEGA_DEDICATED=$ded MRBF_MEGA_LOOK=$look timeout -k 10 200 python tools/mega_check.py 8192 3 3 2>&1 | grep "n="; done; done
-for sl in "2 6" "3 6" "4 6" "3 5" "3 8"; do set -- $sl; echo "slack=$1 chain=$2"; MRBF_MEGA_SLACK=$1 MRBF_MEGA_SLACK_CHAIN=$2 timeout -k 10 200 python tools/mega_check.py 8192 3 3 2>&1 | grep "n="; done
+for wb in 0 1 2 4 8; do echo "wbias=$wb"; MRBF_MEGA_WBIAS=$wb timeout -k 10 200 python tools/mega_check.py 8192,16384 3 3 2>&1 | grep "n="; done
