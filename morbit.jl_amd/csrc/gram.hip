@@ -257,6 +257,121 @@ int launch_cross_gram(mrbf_ctx *ctx, const double *X, int64_t m, const double *C
     return 0;
 }
 
+// ---- 64-row variant: four workgroups per CU --------------------------------------------------------------------------
+// A wave that issues stores into a saturated memory path stalls at issue, so a workgroup's store phase only overlaps with
+// OTHER workgroups' MFMA / radial-function phases.  With 128 x 128 tiles (128 accumulator registers)
+// two workgroups fit on a CU and the kernel reaches 3.5 TB/s; a pure-store kernel with the same tiling writes 5.3-5.5 TB/s.
+// Here a workgroup computes rows [64 h, 64 h + 64) of tile pair (ti, tj) -- 64 accumulator registers, four workgroups per
+// CU -- so that some workgroup is storing at (almost) any time.  Wave w owns columns 32 w .. 32 w + 31 of the tile.
+template <int KID, bool FAST>
+__global__ __launch_bounds__(256, 4) void gram_mfma64_kernel(const double *__restrict__ Xc, const double *__restrict__ sq, int64_t n,
+                                                             int dpad, double *__restrict__ Phi, int64_t ld, KP p, int aligned16) {
+    __shared__ __attribute__((aligned(16))) double smem[(64 + GBM) * GLD];
+    double *As = smem;             // 64 rows
+    double *Bs = smem + 64 * GLD;  // 128 rows
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    int ti, tj;
+    tri_decode(blockIdx.x >> 1, ti, tj);
+    const int half = blockIdx.x & 1;
+    const int64_t I0 = (int64_t)ti * GBM + 64 * half, J0 = (int64_t)tj * GBM;
+    v4d acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+    const int lr = tid >> 3, lc = (tid & 7) * 2;  // 32 rows x 8 column pairs per pass
+    const double *Ap = Xc + (I0 + lr) * dpad + lc;
+    const double *Bp = Xc + (J0 + lr) * dpad + lc;
+    v2d ra[2], rb[4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) ra[u] = *(const v2d *)(Ap + (int64_t)(32 * u) * dpad);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) rb[u] = *(const v2d *)(Bp + (int64_t)(32 * u) * dpad);
+    const int nkc = dpad / GBK;
+    for (int kc = 0; kc < nkc; ++kc) {
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 2; ++u) *(v2d *)&As[(lr + 32 * u) * GLD + lc] = ra[u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) *(v2d *)&Bs[(lr + 32 * u) * GLD + lc] = rb[u];
+        __syncthreads();
+        if (kc + 1 < nkc) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) ra[u] = *(const v2d *)(Ap + (int64_t)(32 * u) * dpad + (kc + 1) * GBK);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) rb[u] = *(const v2d *)(Bp + (int64_t)(32 * u) * dpad + (kc + 1) * GBK);
+        }
+#pragma unroll
+        for (int kk = 0; kk < GBK / 4; ++kk) {
+            double a[4], b[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = As[(i * 16 + l15) * GLD + kk * 4 + l4];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = Bs[(wave * 32 + j * 16 + l15) * GLD + kk * 4 + l4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // epilogue (f64 MFMA C/D layout: col = lane & 15 -> j, row = (lane >> 4) + 4 reg -> i)
+    double sqj[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) sqj[j] = sq[J0 + wave * 32 + j * 16 + l15];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t gi = I0 + i * 16 + l4 + 4 * r;
+            const double sqi = sq[gi];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int64_t gj = J0 + wave * 32 + j * 16 + l15;
+                double s = fma(-2.0, acc[i][j][r], sqi + sqj[j]);
+                s = s > 0.0 ? s : 0.0;
+                if (gi == gj) s = 0.0;
+                const double v = rbf_phi_t<KID, FAST>(s, p);
+                acc[i][j][r] = v;
+                if (gi < n && gj < n) Phi[gi * ld + gj] = v;
+            }
+        }
+    }
+    if (ti == tj) return;  // diagonal tile: the full square was computed, nothing to mirror
+    // mirrored block through an LDS transpose: wave-private 32 x 16 strips
+    double *T = smem + wave * (32 * GLD);
+    __syncthreads();  // every wave has finished reading As / Bs
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) T[(j * 16 + l15) * GLD + l4 + 4 * r] = acc[i][j][r];
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0); the strip is private to the wave and LDS operations of a wave are in order
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int jl = it * 8 + (lane >> 3), il = 2 * (lane & 7);
+            const v2d v = *(const v2d *)&T[jl * GLD + il];
+            const int64_t gj = J0 + wave * 32 + jl;
+            const int64_t gi = I0 + i * 16 + il;
+            if (gj < n) {
+                double *dst = Phi + gj * ld + gi;
+                if (gi + 1 < n) {
+                    if (aligned16) {
+                        *(v2d *)dst = v;
+                    } else {
+                        dst[0] = v.x;
+                        dst[1] = v.y;
+                    }
+                } else if (gi < n) {
+                    dst[0] = v.x;
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // reads of the strip done before the next pass overwrites it
+    }
+}
+
 int launch_gram(mrbf_ctx *ctx, int mode, const double *C, const double *Xc, const double *sq, int64_t n, int64_t npad,
                 int d, int dpad, const KP &kp, double *Phi, int64_t ld) {
     if (n <= 0) return 0;
@@ -271,7 +386,11 @@ int launch_gram(mrbf_ctx *ctx, int mode, const double *C, const double *Xc, cons
         const int64_t nb = nt * (nt + 1) / 2;
         const int aligned16 = ((ld & 1) == 0) && ((reinterpret_cast<uintptr_t>(Phi) & 15) == 0);
         static const int occ3 = getenv("MRBF_GRAM_OCC3") ? atoi(getenv("MRBF_GRAM_OCC3")) : 0;
-        if (kp.fast && occ3) {
+        static const int rows64 = getenv("MRBF_GRAM_ROWS64") ? atoi(getenv("MRBF_GRAM_ROWS64")) : 1;
+        if (kp.fast && rows64 && nb >= 512) {
+            MRBF_DISPATCH_KID(kp.kid, hipLaunchKernelGGL((gram_mfma64_kernel<KID, true>), dim3((unsigned)(2 * nb)), dim3(256), 0, ctx->stream,
+                                                         Xc, sq, n, dpad, Phi, ld, kp, aligned16));
+        } else if (kp.fast && occ3) {
             MRBF_DISPATCH_KID(kp.kid, hipLaunchKernelGGL((gram_mfma_kernel<KID, true, 3>), dim3((unsigned)nb), dim3(256), 0,
                                                          ctx->stream, Xc, sq, n, dpad, Phi, ld, kp, aligned16));
         } else if (kp.fast) {
