@@ -399,19 +399,29 @@ static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info
     MRBF_TRY(get_buf(ctx, S_INFO, (size_t)4, &dinfo));  // [0] main factorisation, [1] Cholesky-QR of the tail, [2] shift not positive
     MRBF_HIP(ctx, hipMemsetAsync(dinfo, 0, 4 * sizeof(int), ctx->stream));
     hipLaunchKernelGGL(rhs_from_values_kernel, dim3(nblk(npad * k)), dim3(256), 0, ctx->stream, Y, n, k, B, npad);
-    MRBF_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));  // ev0..ev1 bracket the Gram kernel alone
-    MRBF_TRY(launch_gram(ctx, ctx->gram_mode, M->C, M->Xc, M->sq, n, M->npad, M->d, M->dpad, M->kp, Phi, ld));
-    MRBF_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
-
     double *Q1 = nullptr, *Wm = nullptr, *G = nullptr, *T1 = nullptr, *scal = nullptr, *Tall = nullptr;
     int64_t lt = 0, dq = 0;
     info->mu = 0.0;
+    // The orthonormal basis Q1 of the polynomial tail depends on the centred coordinates only, not on Phi: its chain of small
+    // latency-bound kernels (Xc'Xc, 128 x 128 Cholesky, panel solve: ~150 us) runs on a side stream UNDER the Gram kernel.
+    hipStream_t main_stream = ctx->stream;
+    const bool side = q > 0 && ctx->panel_stream && ctx->panel_stream != main_stream && n >= 2048;
     if (q > 0) {
         MRBF_TRY(get_buf(ctx, S_Q1, (size_t)npad * q, &Q1));
         MRBF_TRY(get_buf(ctx, S_W1, (size_t)npad * q, &Wm));
         MRBF_TRY(get_buf(ctx, S_G, (size_t)q * q, &G));
         MRBF_TRY(get_buf(ctx, S_T1, (size_t)q * k, &T1));
         MRBF_TRY(get_buf(ctx, S_MISC, (size_t)8, &scal));
+        if (side) {
+            MRBF_HIP(ctx, hipEventRecord(ctx->evx[0], main_stream));
+            MRBF_HIP(ctx, hipStreamWaitEvent(ctx->panel_stream, ctx->evx[0], 0));
+            ctx->stream = ctx->panel_stream;
+        }
+        struct RestoreStream {
+            mrbf_ctx *c;
+            hipStream_t s;
+            ~RestoreStream() { c->stream = s; }
+        } restore{ctx, main_stream};
         if (q > 1) {
             // Cholesky-QR of the centred coordinates: [Xc'Xc ; Xc] -> [Lx ; Xc Lx^-T] by the tall blocked Cholesky
             dq = round_up(d, 128);
@@ -425,6 +435,14 @@ static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info
         }
         hipLaunchKernelGGL(build_q1_kernel, dim3(nblk(npad * q)), dim3(256), 0, ctx->stream, Tall, lt, dq, n, npad, q, Q1);
         MRBF_HIP(ctx, hipMemsetAsync(Wm, 0, (size_t)npad * q * sizeof(double), ctx->stream));
+        if (side) MRBF_HIP(ctx, hipEventRecord(ctx->evx[1], ctx->stream));
+    }
+    ctx->stream = main_stream;
+    MRBF_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));  // ev0..ev1 bracket the Gram kernel alone
+    MRBF_TRY(launch_gram(ctx, ctx->gram_mode, M->C, M->Xc, M->sq, n, M->npad, M->d, M->dpad, M->kp, Phi, ld));
+    MRBF_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    if (side) MRBF_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->evx[1], 0));
+    if (q > 0) {
         // W1 = Phi Q1 (Phi is stored in full) ; G = Q1' W1 ; W = W1 - 1/2 Q1 G
         MRBF_TRY(symm_panel(ctx, n, npad, q, Phi, ld, Q1, npad, Wm, npad));
         MRBF_TRY(tsmm_tn(ctx, n, q, q, 1.0, Q1, npad, Wm, npad, 0.0, G, q));
