@@ -14,7 +14,7 @@ import sqlite3
 import sys
 
 PHASES = [
-    ("gram", ("gram_mfma_kernel", "gram_diff_kernel")),
+    ("gram", ("gram_mfma", "gram_diff_kernel")),
     ("factor", ("potrf_mega_kernel", "mega_status_kernel", "chol_update_kernel<128, 0>", "chol_update_kernel<64", "chol_diag")),
     ("eval", ("eval_fused_kernel", "eval_combine_kernel", "eval_rows_kernel", "jac_assemble_kernel")),
     ("solve", ("chol_backsolve_kernel", "backsolve_persistent_kernel", "get_rhs_rows", "scatter_solution", "finish_lambda", "residual_kernel", "max_abs")),
