@@ -3,26 +3,31 @@
 // chol_blocked.hip drives the factorisation from the host: per 128-column step a diagonal kernel, a panel kernel, a
 // block-column update and (per window) bulk updates on three streams.  At n = 8192 its run time IS the dependent
 // chain of those launches (64 x ~128 us: profiles/r01_c_kernel_stats.csv) -- every hop pays a kernel boundary and a
-// cross-stream event (~10 us each).  Here the whole factorisation is ONE launch of resident workgroups that pull
-// 128 x 128 tile jobs from two in-order queues and hand tiles to each other through flags in memory (hop ~2-3 us):
+// cross-stream event (~10 us each).  Here the whole factorisation is ONE launch of resident workgroups (two per CU) that
+// pull 128 x 128 tile jobs from queues and hand tiles to each other through flags in memory (hop ~2-3 us):
 //
-//   P(c)      diagonal tile: subtract the in-window panels, Cholesky + inverse of the factor (chol_diag_core.hpp)
-//   S(i,c)    the two tiles right below the diagonal (i = c+1, c+2): the same panel solve, but run in step with P(c) --
-//             P(c) publishes every 16-column panel of L_cc (and its 16 x 16 leaf inverse) as it is finished, S applies
-//             it to its 128 x 128 tile held in registers (MFMA, accumulator-as-operand) and publishes its own 16-column
-//             panel, which P(c+1) folds into the next diagonal tile: the next diagonal factorisation starts ~10 us after
-//             the previous one ends instead of after two dependent 128^3 GEMMs
-//   T(i,c)    panel tile: subtract the in-window panels, then  L(i,c) = X * inv(L_cc)'   (a GEMM with the inverse)
-//   U(i,c,w)  bulk update of tile (i,c), c beyond window w, with the 4 panels of window w  (K = 512, read-modify-write)
+//   P(c)      diagonal tile: left-looking part over the newest panels, the last one folded in 16 columns at a time as
+//             S(c, c-1) publishes it, then Cholesky + inverse of the factor (chol_diag_core.hpp), which itself publishes
+//             every finished 16-column panel of L_cc and its 16 x 16 leaf inverse
+//   S(i,c)    the two tiles right below the diagonal (i = c+1, c+2): the panel solve run in step with P(c) -- each
+//             published panel is applied to the 128 x 128 tile held in registers (MFMA, accumulator-as-operand), the tile's
+//             own 16-column panel published in turn: the next diagonal factorisation starts ~10 us after the previous
+//             one ends instead of after two dependent 128^3 GEMMs
+//   T(i,h,c)  the other panel tiles in 64-row halves: left-looking part, then  L(i,c) = X * inv(L_cc)'  (a GEMM with the
+//             stored inverse).  Half height keeps a row's column-to-column recurrence faster than the diagonal chain.
+//   U(i,c,w)  bulk update of tile (i,c) with the panels of window w  (K = 128 x window length, read-modify-write)
 //
-// Windows are 4 block columns: a tile of block column c receives nb(c) = floor((c-slack)/4) bulk updates (right-looking,
-// rank 512) and its last slack..slack+3 panels left-looking inside its panel job (so a panel that has just been finished never
-// has to pass through a bulk job before the next two diagonal blocks can start); the bulk of the flops streams the
-// trailing matrix once per 512 columns.  Panel jobs are claimed in a topological order (column by column, P first, rows
-// ascending) and only wait for jobs claimed before them.  Bulk jobs sit in one queue per window (block columns
-// ascending); a workgroup takes, among the heads of all queues, the READY job with the smallest block column (the one
-// the diagonal chain needs first); a bulk job therefore (almost) never waits.  Every spin is
-// bounded and gives up through the abort word; the launch drains for any number of resident workgroups.
+// Windows hold `win` block columns (the first one `first`): a tile of block column c receives the windows that were
+// closed at least `slack` chain steps before c as bulk jobs (right-looking, rank 512..1024) and takes the newer panels
+// left-looking inside its own panel job, so a panel that has just been finished never has to pass through a bulk job
+// before the next diagonal blocks can start; the bulk of the flops streams the trailing matrix once per window.
+// Three pools of workgroups: `nchain` serve the chain queue (P, S jobs, in order; their CU partner pauses), `ndedicated`
+// serve the panel queue (T jobs, column by column, rows ascending) and may wait inside a job, all others take the head of
+// the panel queue when it can run (diagonal block at most `look` steps away AND its bulk updates in), else a bulk job: bulk
+// jobs sit in one queue per window (block columns ascending); among the heads of all queues the READY job with the smallest
+// block column (the one the diagonal chain needs first, newer windows trailing by `wbias` columns) is taken.  Every job only
+// waits for jobs that were claimed before it in its queue or that another pool is guaranteed to run; every spin is bounded
+// and gives up through the abort word (negative *dinfo); the launch drains for any number of resident workgroups.
 //
 // Hand-off between workgroups (MI355X: per-XCD L2s are not coherent, a CU's L1 is never refreshed): every store of a
 // tile another workgroup will read is a write-through (sc1) store, every storing wave drains (s_waitcnt vmcnt(0)),
@@ -49,7 +54,6 @@ struct Job {
 // control words (each on its own 128-byte line)
 enum { CTL_QP = 0, CTL_ABORT = 32, CTL_TIMEOUT = 64, CTL_PCOLS = 96, CTL_QC = 128, CTL_WORDS = 160 };
 constexpr int QSTRIDE = 32;  // one bulk-queue head per 128-byte line
-// SLACK: a window's bulk update of block column c is only relied on SLACK chain steps after the window was finished
 // Window w covers the panels [wstart(w), wstart(w+1)): the first window is shorter (`first` panels) so that bulk work
 // exists early in the launch, all others hold `win` panels.
 __host__ __device__ inline int wstart(int w, int first, int win) { return w <= 0 ? 0 : first + win * (w - 1); }
