@@ -454,6 +454,14 @@ int debug_diag(mrbf_ctx *ctx, const double *A128_dev, int reps, float *ms_per_ca
     float t;
     MRBF_HIP(ctx, hipEventElapsedTime(&t, ctx->ev[0], ctx->ev[1]));
     *ms_per_call = t / reps;
+    if (const char *e = getenv("MRBF_DIAG_DBG")) {
+        if (atoi(e) & 4) {  // per-segment cycle counters of the last launch (chol_diag_core.hpp)
+            double seg[6];
+            MRBF_HIP(ctx, hipMemcpy(seg, Linv, sizeof(seg), hipMemcpyDeviceToHost));
+            fprintf(stderr, "diag segments (wave 0, cycles over 8 panels): pre-leaf %.0f leaf %.0f post-leaf %.0f wait-X %.0f deferred %.0f wait-Y %.0f\n",
+                    seg[0], seg[1], seg[2], seg[3], seg[4], seg[5]);
+        }
+    }
     MRBF_HIP(ctx, hipMemcpy(stamps_host, st, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return 0;
 }

@@ -40,6 +40,7 @@ struct DiagV4Shared {
     double LT[28 * TILE];  // finished strictly-lower L tiles, [tile][c][row]  (c = column inside the tile): MFMA operand order
     double IT[NT * TILE];  // leaf inverses transposed: IT[b][a2][a] = inv(L_bb)[a][a2]
     double Dt[TILE];       // diagonal tile handed to the leaf wave, [col a][row b']
+    double Lb[TILE];       // factored diagonal leaf [col][row]: stored to global memory by another wave, off the leaf wave's path
     int bad;
 };
 
@@ -115,8 +116,18 @@ __device__ __forceinline__ int diag_v4_core(double *__restrict__ A, int64_t lda,
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
     if (tid == 0) sh.bad = 0;
+    unsigned long long tseg[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;  // timing experiments (dbg & 4): wave 0's cycles per segment
+#define MRBF_DSEG(k)                                         \
+    do {                                                     \
+        if (dbg & 4) {                                       \
+            const unsigned long long now_ = __builtin_readcyclecounter(); \
+            tseg[k] += now_ - tlast;                         \
+            tlast = now_;                                    \
+        }                                                    \
+    } while (0)
     if (!PRELOADED) diag_v4_load(A, lda, acc);
     __syncthreads();
+    if (dbg & 4) tlast = __builtin_readcyclecounter();
 
 #pragma unroll 1
     for (int b = 0; b < NT; ++b) {
@@ -143,6 +154,7 @@ __device__ __forceinline__ int diag_v4_core(double *__restrict__ A, int64_t lda,
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             double a[16];
             int bad = 0;
+            MRBF_DSEG(0);
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
                 double v;
@@ -170,21 +182,18 @@ __device__ __forceinline__ int diag_v4_core(double *__restrict__ A, int64_t lda,
             leaf_step<14>(a, bad, 16 * b);
             leaf_step<15>(a, bad, 16 * b);
             }
+            MRBF_DSEG(1);
             if (bad && lane == 0) sh.bad = bad;
+            // the leaf wave only writes LDS; waves 1 / 2 move the factored leaf and (STREAM) its inverse to global memory after
+            // the barrier (32 predicated 8-byte global stores cost the leaf wave ~0.9 us per panel)
             if (lane < 16) {
-                // factor rows -> global (lower part of the diagonal tile)
 #pragma unroll
-                for (int c = 0; c < 16; ++c)
-                    if (c <= lane) gstore<SC1>(&A[(16 * b + lane) + (int64_t)(16 * b + c) * lda], a[c]);
+                for (int c = 0; c < 16; ++c) sh.Lb[c * 16 + lane] = a[c];
             } else if (lane < 32) {
                 // lane 16 + r holds (L^-T)[r][c] = inv[c][r]:  IT[b][a2 = r][a = c]
                 const int r = lane - 16;
 #pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    const double v = (c >= r) ? a[c] : 0.0;
-                    sh.IT[b * TILE + r * 16 + c] = v;
-                    if (STREAM) gstore<true>(&itg[b * TILE + r * 16 + c], v);
-                }
+                for (int c = 0; c < 16; ++c) sh.IT[b * TILE + r * 16 + c] = (c >= r) ? a[c] : 0.0;
             }
         } else {
             // ---- waves 1..3 (meanwhile): the rest of panel b-1's trailing update, off-diagonal tiles (i,j), i > j > b
@@ -206,10 +215,23 @@ __device__ __forceinline__ int diag_v4_core(double *__restrict__ A, int64_t lda,
             // panel b-1's write-through stores were issued a leaf ago: draining them here costs nothing
             if (STREAM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        if (wave == 0) MRBF_DSEG(2);
         __syncthreads();  // X: leaf inverse IT[b] visible
+        if (wave == 0) MRBF_DSEG(3);
         if (sh.bad) break;
         if (STREAM && b > 0 && tid == 64)
             __hip_atomic_store((__attribute__((address_space(1))) unsigned *)prog, (unsigned)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (wave == 1) {
+            // factored leaf -> global (lower part of the diagonal tile), coalesced along rows
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = l4 + 4 * r;
+                if (c <= l15) gstore<SC1>(&A[(16 * b + l15) + (int64_t)(16 * b + c) * lda], sh.Lb[c * 16 + l15]);
+            }
+        } else if (STREAM && wave == 2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gstore<true>(&itg[b * TILE + (l4 + 4 * r) * 16 + l15], sh.IT[b * TILE + (l4 + 4 * r) * 16 + l15]);
+        }
         if (wave != 0) {
             // ---- panel: P_i' = inv(L_bb) * A_ib'  for the owned tiles of block column b
             const double *itb = &sh.IT[b * TILE];
@@ -227,10 +249,7 @@ __device__ __forceinline__ int diag_v4_core(double *__restrict__ A, int64_t lda,
                         for (int s = 0; s < 4; ++s) p = __builtin_amdgcn_mfma_f64_16x16x4f64(ia[s], m[s], p, 0, 0, 0);
                         acc[tile_slot(i, j)] = p;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            sh.LT[MRBF_SIDX(i, j) * TILE + (l4 + 4 * r) * 16 + l15] = p[r];
-                            gstore<SC1>(&A[(16 * i + l15) + (int64_t)(16 * j + l4 + 4 * r) * lda], p[r]);  // L(i,b), coalesced along rows
-                        }
+                        for (int r = 0; r < 4; ++r) sh.LT[MRBF_SIDX(i, j) * TILE + (l4 + 4 * r) * 16 + l15] = p[r];
                     }
                 }
         } else {
@@ -247,8 +266,21 @@ __device__ __forceinline__ int diag_v4_core(double *__restrict__ A, int64_t lda,
                 }
             }
         }
+        if (wave == 0) MRBF_DSEG(4);
         __syncthreads();  // Y: panel tiles of block column b in LT
+        if (wave == 0) MRBF_DSEG(5);
         if (wave != 0) {
+            // L(i,b) -> global, behind the barrier the leaf wave waits at (coalesced along rows)
+#pragma unroll
+            for (int i = 1; i < NT; ++i)
+#pragma unroll
+                for (int j = 0; j < i; ++j) {
+                    if (j == b && tile_owner(i, j) == wave) {
+                        const v4d pt = acc[tile_slot(i, j)];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) gstore<SC1>(&A[(16 * i + l15) + (int64_t)(16 * j + l4 + 4 * r) * lda], pt[r]);
+                    }
+                }
             // bring block column b+1 up to date first: the next panel solve needs it right after the next leaf
 #pragma unroll
             for (int i = 2; i < NT; ++i)
@@ -270,6 +302,9 @@ __device__ __forceinline__ int diag_v4_core(double *__restrict__ A, int64_t lda,
     __syncthreads();
     const int bad_all = sh.bad;
     if (bad_all) return bad_all;
+    if ((dbg & 4) && tid == 0) {
+        for (int k = 0; k < 6; ++k) Linv[k] = (double)tseg[k];
+    }
     if (dbg & 1) return 0;  // timing experiments: no inverse
     if (STREAM && tid == 64)
         __hip_atomic_store((__attribute__((address_space(1))) unsigned *)prog, (unsigned)NT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
