@@ -70,9 +70,49 @@ __global__ void tsmm_tn_reduce_kernel(const double *__restrict__ part, int nchun
     *dst = (beta == 0.0) ? alpha * s : fma(alpha, s, beta * *dst);
 }
 
+// r <= 4 output columns (Q1' w, W' w: p x k from n rows): one workgroup per output row i, each thread strides down column i of
+// A and the r columns of B, fixed-order tree reduction in LDS -- one ~6 us launch instead of a partial + a reduce kernel (44 us).
+template <int R>
+__global__ __launch_bounds__(256) void tsmm_tn_skinny_kernel(const double *__restrict__ A, int64_t lda, const double *__restrict__ B,
+                                                             int64_t ldb, int64_t n, double alpha, double beta, double *__restrict__ C,
+                                                             int64_t ldc) {
+    __shared__ double red[R][256];
+    const int i = blockIdx.x, tid = threadIdx.x;
+    const double *a = A + (int64_t)i * lda;
+    double acc[R];
+#pragma unroll
+    for (int l = 0; l < R; ++l) acc[l] = 0.0;
+    for (int64_t k = tid; k < n; k += 256) {
+        const double av = a[k];
+#pragma unroll
+        for (int l = 0; l < R; ++l) acc[l] = fma(av, B[k + (int64_t)l * ldb], acc[l]);
+    }
+#pragma unroll
+    for (int l = 0; l < R; ++l) red[l][tid] = acc[l];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) {
+#pragma unroll
+            for (int l = 0; l < R; ++l) red[l][tid] += red[l][tid + s];
+        }
+        __syncthreads();
+    }
+    if (tid < R) {
+        double *dst = C + i + (int64_t)tid * ldc;
+        *dst = (beta == 0.0) ? alpha * red[tid][0] : fma(alpha, red[tid][0], beta * *dst);
+    }
+}
+
 int tsmm_tn(mrbf_ctx *ctx, int64_t n, int p, int r, double alpha, const double *A, int64_t lda, const double *B, int64_t ldb,
             double beta, double *C, int64_t ldc) {
     if (p <= 0 || r <= 0) return 0;
+    if (r <= 4 && p <= 4096) {
+#define MRBF_TSK(RV) hipLaunchKernelGGL((tsmm_tn_skinny_kernel<RV>), dim3((unsigned)p), dim3(256), 0, ctx->stream, A, lda, B, ldb, n, alpha, beta, C, ldc)
+        if (r == 1) MRBF_TSK(1); else if (r == 2) MRBF_TSK(2); else if (r == 3) MRBF_TSK(3); else MRBF_TSK(4);
+#undef MRBF_TSK
+        MRBF_HIP(ctx, hipGetLastError());
+        return 0;
+    }
     const int nchunks = (int)((n + TS_RC - 1) / TS_RC);
     double *part;
     MRBF_TRY(get_buf(ctx, S_R, (size_t)nchunks * p * r, &part));

@@ -383,6 +383,39 @@ __global__ void finish_lambda_kernel(double *__restrict__ T1, int q, int k, doub
     T1[(int64_t)l * q] = s;
 }
 
+// B(n x k) -= Q(n x q) T(q x k)  (all column-major): the rank-q correction of the weights, one thread per entry
+__global__ void sub_qt_kernel(double *__restrict__ B, int64_t ldb, const double *__restrict__ Q, int64_t ldq, const double *__restrict__ T,
+                              int64_t n, int q, int k) {
+    const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (idx >= n * k) return;
+    const int64_t row = idx % n;
+    const int l = (int)(idx / n);
+    double s = 0.0;
+    for (int t = 0; t < q; ++t) s = fma(Q[row + (int64_t)t * ldq], T[t + (int64_t)l * q], s);
+    B[row + (int64_t)l * ldb] -= s;
+}
+
+// x = L^-T b for the d x d lower factor of the Cholesky-QR (d <= 256) and k right-hand sides, in place in X (ld ldx): one
+// workgroup, thread j owns unknown j, back substitution over the columns of L' (64 us of rocBLAS small-trsm launch otherwise)
+__global__ __launch_bounds__(256) void trsm_lt_small_kernel(const double *__restrict__ L, int64_t ldl, int d, double *__restrict__ X,
+                                                            int64_t ldx, int k) {
+    __shared__ double xs[256];
+    const int j = threadIdx.x;
+    for (int l = 0; l < k; ++l) {
+        double v = j < d ? X[j + (int64_t)l * ldx] : 0.0;
+        for (int c = d - 1; c >= 0; --c) {
+            if (j == c) {
+                v /= L[c + (int64_t)c * ldl];
+                xs[c] = v;
+            }
+            __syncthreads();
+            if (j < c) v -= L[c + (int64_t)j * ldl] * xs[c];  // (L')(j, c) = L(c, j)
+            __syncthreads();
+        }
+        if (j < d) X[j + (int64_t)l * ldx] = v;
+    }
+}
+
 // returns 0 with *not_pd = 1 when a factorisation met a non-positive pivot (caller may retry with LU)
 static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info *info, int *not_pd) {
     const int64_t n = M->n, npad = M->npad;
@@ -461,8 +494,7 @@ static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info
         MRBF_TRY(launch_update_lower(ctx, PA, npad, PB, npad, Phi, ld, npad / 128, K2));
         // B = P Y = Y - Q1 (Q1' Y);  T1 keeps Q1' Y for lam
         MRBF_TRY(tsmm_tn(ctx, n, q, k, 1.0, Q1, npad, B, npad, 0.0, T1, q));
-        MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, (int)n, k, q, &mone, Q1, (int)npad,
-                                     T1, q, &one, B, (int)npad));
+        hipLaunchKernelGGL(sub_qt_kernel, dim3(nblk(n * k)), dim3(256), 0, ctx->stream, B, npad, Q1, npad, T1, n, q, k);
     }
     MRBF_HIP(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
     int hinfo = 0;
@@ -492,13 +524,16 @@ static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info
         MRBF_TRY(get_buf(ctx, S_T2, (size_t)q * k, &T2));
         // re-project w (rounding hygiene): w -= Q1 (Q1' w)
         MRBF_TRY(tsmm_tn(ctx, n, q, k, 1.0, Q1, npad, B, npad, 0.0, T2, q));
-        MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, (int)n, k, q, &mone, Q1, (int)npad,
-                                     T2, q, &one, B, (int)npad));
+        hipLaunchKernelGGL(sub_qt_kernel, dim3(nblk(n * k)), dim3(256), 0, ctx->stream, B, npad, Q1, npad, T2, n, q, k);
         // z = Q1' Y - (Phi Q1)' w;  (Phi Q1)' w = W' w because Q1' w = 0;  lam = R^-1 z
         MRBF_TRY(tsmm_tn(ctx, n, q, k, -1.0, Wm, npad, B, npad, 1.0, T1, q));
-        if (q > 1)
-            MRBF_BLAS(ctx, rocblas_dtrsm(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose,
-                                         rocblas_diagonal_non_unit, d, k, &one, Tall, (int)lt, T1 + 1, q));
+        if (q > 1) {
+            if (d <= 256)
+                hipLaunchKernelGGL(trsm_lt_small_kernel, dim3(1), dim3(256), 0, ctx->stream, Tall, lt, d, T1 + 1, (int64_t)q, k);
+            else
+                MRBF_BLAS(ctx, rocblas_dtrsm(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose,
+                                             rocblas_diagonal_non_unit, d, k, &one, Tall, (int)lt, T1 + 1, q));
+        }
         hipLaunchKernelGGL(finish_lambda_kernel, dim3((k + 63) / 64), dim3(64), 0, ctx->stream, T1, q, k, std::sqrt((double)n), M->mean);
     }
     hipLaunchKernelGGL(scatter_solution_kernel, dim3(nblk(M->npad * k + (int64_t)q * k)), dim3(256), 0, ctx->stream, B, npad, n,
