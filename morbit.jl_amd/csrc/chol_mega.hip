@@ -157,6 +157,22 @@ __device__ __forceinline__ bool wg_wait(Shared &sh, const Args &a, const unsigne
     return ok;
 }
 
+// Wait until *f >= want and return the value observed (flags only grow): a consumer that is behind its producer learns how
+// far it may run without waiting again -- one poll, one acquire, two barriers for several 16-column steps.  0 on abort.
+__device__ __forceinline__ unsigned wg_wait_val(Shared &sh, const Args &a, const unsigned *f, unsigned want, unsigned code) {
+    if (threadIdx.x == 0) {
+        unsigned v = 0;
+        if (poll_ge(f, want, a, code)) v = ldf(f);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        sh.ok = (int)v;
+    }
+    __syncthreads();
+    const unsigned v = (unsigned)sh.ok;
+    __syncthreads();
+    return v;
+}
+
 // publish: every storing wave has drained its write-through stores, then one lane sets the word
 __device__ __forceinline__ void wg_drain() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -368,9 +384,13 @@ __device__ __attribute__((noinline)) bool run_stream(const Args &a, Shared &sh, 
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 x[u][q][r] = *(const gf64 *)&C[(32 * wave + 16 * u + l15) + (int64_t)(16 * q + l4 + 4 * r) * a.lda];
+    unsigned have = 0;  // panels of the diagonal block known to be published
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
-        if (!wg_wait(sh, a, dprog, (unsigned)(b + 1), nullptr, 0, nullptr, 0, 0x500u)) return false;
+        if (have < (unsigned)(b + 1)) {
+            have = wg_wait_val(sh, a, dprog, (unsigned)(b + 1), 0x500u);
+            if (!have) return false;
+        }
         if (b == 0) JLOG(5);
         if (b == 7) JLOG(6);
         double ia[4];
@@ -397,10 +417,14 @@ __device__ __attribute__((noinline)) bool run_stream(const Args &a, Shared &sh, 
             for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int s2 = 0; s2 < 4; ++s2) x[u][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-lq[q][s2], xs[u][s2], x[u][q], 0, 0, 0);
-        wg_drain();
-        if (threadIdx.x == 0) {
-            if (sprog) stf(sprog, (unsigned)(b + 1));
-            if (b == 7) stf(a.tdone + (size_t)i * a.NT + c, 2u);
+        // publish the finished 16-column panel -- unless the diagonal block is already complete and this job is only catching
+        // up: then one drain + publish at the end serves the (waiting) consumer better than eight
+        if (have < 8u || b == 7) {
+            wg_drain();
+            if (threadIdx.x == 0) {
+                if (sprog) stf(sprog, (unsigned)(b + 1));
+                if (b == 7) stf(a.tdone + (size_t)i * a.NT + c, 2u);
+            }
         }
     }
     return true;
@@ -428,9 +452,13 @@ __device__ __attribute__((noinline)) bool run_diag(const Args &a, Shared &sh, co
     if (c > 0) {
         const double *Lp = a.A + (int64_t)c * NB + (int64_t)(c - 1) * NB * a.lda;  // tile (c, c-1), produced by S(c, c-1)
         const unsigned *sprog = a.sprog + (size_t)(c - 1) * QSTRIDE;
+        unsigned have = 0;  // 16-column panels of tile (c, c-1) known to be published
 #pragma unroll 1
         for (int b = 0; b < 8; ++b) {
-            if (!wg_wait(sh, a, sprog, (unsigned)(b + 1), nullptr, 0, nullptr, 0, 0x600u)) return false;
+            if (have < (unsigned)(b + 1)) {
+                have = wg_wait_val(sh, a, sprog, (unsigned)(b + 1), 0x600u);
+                if (!have) return false;
+            }
             double op[8][4];
 #pragma unroll
             for (int xb = 0; xb < 8; ++xb)
