@@ -59,8 +59,8 @@ constexpr int QSTRIDE = 32;  // one bulk-queue head per 128-byte line
 __host__ __device__ inline int wstart(int w, int first, int win) { return w <= 0 ? 0 : first + win * (w - 1); }
 // number of windows that reach tile (i,c) through bulk jobs: those closed at least `slack` chain steps before column c; the
 // tiles of the chain jobs (block rows c .. c+2) rely on a window's bulk update later than the other panel tiles
-__host__ __device__ inline int nbulk_updates(int i, int c, int slack, int slack_chain, int first, int win) {
-    const int t = c - ((i - c <= 2) ? slack_chain : slack);
+__host__ __device__ inline int nbulk_updates(int i, int c, int slack, int slack_chain, int first, int win, int srows = 2) {
+    const int t = c - ((i - c <= srows) ? slack_chain : slack);
     return t < first ? 0 : (t - first) / win + 1;
 }
 
@@ -91,7 +91,7 @@ struct Args {
     int look;        // general workgroups take a panel job of block column c once c < (finished diagonal blocks) + look
     unsigned spin_limit;
     int use_quiet;
-    int slack, slack_chain, first, win, wbias;
+    int slack, slack_chain, first, win, wbias, srows;
     unsigned long long *jlog;   // diagnostic launches only: 8 words per job (meta, claim, 5 stage stamps, end), jlog[0] = count
     int jlog_cap;
     unsigned long long *trace;  // diagnostic launches only: 8 time stamps (10 ns units) per chain job (P(c), T(c+1,c))
@@ -338,7 +338,7 @@ __device__ __attribute__((noinline)) bool run_bulk(const Args &a, Shared &sh, co
 template <int TM>
 __device__ __attribute__((noinline)) bool window_part(const Args &a, Shared &sh, int i, int c, int pend, int roff,
                                                       unsigned long long *tr) {
-    const int wc = nbulk_updates(i, c, a.slack, a.slack_chain, a.first, a.win), p0 = wstart(wc, a.first, a.win);
+    const int wc = nbulk_updates(i, c, a.slack, a.slack_chain, a.first, a.win, a.srows), p0 = wstart(wc, a.first, a.win);
     const unsigned *uc = a.ucnt + (size_t)i * a.NT + c;
     if (p0 >= pend) return wg_wait(sh, a, uc, (unsigned)(2 * wc), nullptr, 0, nullptr, 0, 0x200u);
     v4d acc[TM / 32][4];
@@ -375,7 +375,7 @@ __device__ __attribute__((noinline)) bool run_stream(const Args &a, Shared &sh, 
     const double *Lcc = a.A + (int64_t)c * NB + (int64_t)c * NB * a.lda;
     const double *itg = a.itg + (size_t)c * 8 * 256;
     const unsigned *dprog = a.dprog + (size_t)c * QSTRIDE;
-    unsigned *sprog = (i <= c + 2) ? a.sprog + ((size_t)(i - c - 1) * a.NT + c) * QSTRIDE : nullptr;  // only the diagonal job's feeder is followed
+    unsigned *sprog = (i == c + 1) ? a.sprog + (size_t)c * QSTRIDE : nullptr;  // only the diagonal job's feeder is followed
     v4d x[2][8];
 #pragma unroll
     for (int u = 0; u < 2; ++u)
@@ -663,7 +663,7 @@ __global__ __launch_bounds__(256, 2) void potrf_mega_kernel(const Args a) {
                         const Job hj = a.pjobs[ph];
                         want_panel = hj.c < (int)ldf(a.ctl + CTL_PCOLS) + a.look &&
                                      ldf(a.ucnt + (size_t)hj.i * a.NT + hj.c) >=
-                                         2u * (unsigned)nbulk_updates(hj.i, hj.c, a.slack, a.slack_chain, a.first, a.win);
+                                         2u * (unsigned)nbulk_updates(hj.i, hj.c, a.slack, a.slack_chain, a.first, a.win, a.srows);
                     }
                 }
                 if (want_panel) {
@@ -763,14 +763,15 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
     // longer windows for large matrices (measured: n = 16384: 33.8 / 31.7 / 30.8 ms with 4 / 6 / 8 panels per window; n = 8192: the same)
     const int win = std::max(1, ctx->mega_win > 0 ? ctx->mega_win : (NT >= 88 ? 8 : (NT >= 56 ? 6 : WIN_DEFAULT)));
     const int first = std::min(win, std::max(1, ctx->mega_first_window));
-    if (ctx->mega_nt != NT || ctx->mega_mt != MT || ctx->mega_tab_slack != slack + 100 * ctx->mega_half_cols + 10000 * slack_chain + 1000000 * first + 10000000 * win) {
-        ctx->mega_tab_slack = slack + 100 * ctx->mega_half_cols + 10000 * slack_chain + 1000000 * first + 10000000 * win;
+    const int srows = std::max(1, ctx->mega_srows);  // streamed tiles below each diagonal block
+    if (ctx->mega_nt != NT || ctx->mega_mt != MT || ctx->mega_tab_slack != slack + 100 * ctx->mega_half_cols + 10000 * slack_chain + 1000000 * first + 10000000 * win + 100000000 * srows) {
+        ctx->mega_tab_slack = slack + 100 * ctx->mega_half_cols + 10000 * slack_chain + 1000000 * first + 10000000 * win + 100000000 * srows;
         std::vector<Job> pj, bj;
         std::vector<Job> cj;
         for (int c = 0; c < NT; ++c) {
             cj.push_back(Job{JOB_P, (short)c, (short)c, (short)0});
             for (int i = c + 1; i < MT; ++i) {
-                if (i <= c + 2)
+                if (i <= c + srows)
                     cj.push_back(Job{JOB_S, (short)i, (short)c, (short)0});
                 else
                     for (int h = 0; h < 2; ++h) pj.push_back(Job{JOB_T, (short)i, (short)c, (short)h});
@@ -779,12 +780,12 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
         std::vector<int> wqs;
         int nwin_max = 0;  // windows that reach at least one tile through a bulk job
         for (int c = 0; c < NT; ++c)
-            for (int i = c; i < MT; ++i) nwin_max = std::max(nwin_max, nbulk_updates(i, c, slack, slack_chain, first, win));
+            for (int i = c; i < MT; ++i) nwin_max = std::max(nwin_max, nbulk_updates(i, c, slack, slack_chain, first, win, srows));
         for (int w = 0; w < nwin_max; ++w) {
             wqs.push_back((int)bj.size());
             for (int c = 0; c < NT; ++c)
                 for (int i = c; i < MT; ++i) {
-                    if (nbulk_updates(i, c, slack, slack_chain, first, win) <= w) continue;  // this window reaches the tile inside its panel job
+                    if (nbulk_updates(i, c, slack, slack_chain, first, win, srows) <= w) continue;  // this window reaches the tile inside its panel job
                     const bool half = i != c && c < wstart(w + 1, first, win) + slack + ctx->mega_half_cols;
                     if (half) {
                         bj.push_back(Job{JOB_UH, (short)i, (short)c, (short)w});
@@ -847,6 +848,7 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
     a.first = first;
     a.win = win;
     a.wbias = ctx->mega_wbias;
+    a.srows = srows;
     a.spin_limit = 4000000u;  // x ~0.1-0.3 us per poll: gives up after ~1 s without progress
     const int grid = ctx->mega_grid;
     if (a.nchain < 1) a.nchain = 1;

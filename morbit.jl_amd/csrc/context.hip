@@ -188,6 +188,7 @@ int32_t mrbf_init(int32_t device_id, mrbf_ctx **out) {
         if (const char *e = getenv("MRBF_MEGA_FIRST_WINDOW")) ctx->mega_first_window = atoi(e);
         if (const char *e = getenv("MRBF_MEGA_WIN")) ctx->mega_win = atoi(e);
         if (const char *e = getenv("MRBF_MEGA_WBIAS")) ctx->mega_wbias = atoi(e);
+        if (const char *e = getenv("MRBF_MEGA_SROWS")) ctx->mega_srows = atoi(e);
         if (const char *e = getenv("MRBF_MEGA_MAX")) ctx->mega_max = atoi(e);
         hipDeviceProp_t prop;
         int ncu = 256;
