@@ -171,6 +171,30 @@ def test_medium_sizes_against_oracle(ctx, kernel, deg, n, d):
     mod.free()
 
 
+@pytest.mark.parametrize("kernel,deg,n,d,k", [("gaussian", -1, 1300, 10, 5), ("multiquadric", 1, 1100, 24, 9), ("inv_multiquadric", 0, 2100, 6, 3),
+                                             ("gaussian", 1, 777, 40, 1), ("multiquadric", 1, 1536, 64, 4)])
+def test_persistent_factor_and_backsolve_many_outputs(ctx, kernel, deg, n, d, k):
+    # n >= 512 goes through the one-launch factorisation; k > 4 needs two passes of the persistent backward substitution
+    rng = np.random.Generator(np.random.PCG64(n + 7 * k))
+    C = rng.random((n, d))
+    Y = np.stack([np.sin((j + 1) * C.sum(axis=1) / d) + 0.1 * j for j in range(k)], axis=1)
+    X = rng.random((21, d))
+    cfg = pkg.RbfConfig(kernel=kernel, polynomial_degree=deg)
+    kid, a, b = pkg.rbf_model._get_kernel_params(1.0, cfg)
+    ref = orc.fit(C, Y, kid, a, b, deg)
+    mod = pkg.update_model(cfg, C, Y, ctx=ctx)
+    V, J = mod.eval_sites(X, want_values=True, want_jac=True)
+    assert mod.info["path"] in (_lib.PATH_CHOL, _lib.PATH_PROJ_CHOL)
+    assert mod.info["rel_residual"] < 1e-9
+    assert np.abs(V - ref.values(X)).max() / max(1.0, np.abs(V).max()) < 1e-8
+    assert np.abs(J - ref.jacs(X)).max() / max(1.0, np.abs(J).max()) < 1e-8
+    # every output solved with the same factor: column-wise agreement with a single-output fit
+    m1 = pkg.update_model(cfg, C, Y[:, k - 1:k], ctx=ctx)
+    assert np.abs(m1.weights[:, 0] - mod.weights[:, k - 1]).max() <= 1e-9 * max(1.0, np.abs(mod.weights).max())
+    m1.free()
+    mod.free()
+
+
 def test_solve_paths_agree(ctx):
     # the same problem through projected Cholesky and through LU on the saddle system
     C, Y = _synthetic(500, 12, 2, seed=11)
