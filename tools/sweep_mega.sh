@@ -1,1 +1,8 @@
-for sr in 2 3 4; do for ch in 12 20; do echo "srows=$sr chain=$ch"; MRBF_MEGA_DEBUG=1 MRBF_MEGA_SROWS=$sr MRBF_MEGA_CHAIN=$ch timeout -k 10 200 python tools/mega_check.py 4096,8192 3 3 2>&1 | grep "n=\|mega"; done; done
+#!/bin/bash
+# Parameter sweeps of the persistent factorisation (environment knobs of chol_mega.hip / context.hip), e.g.
+#   MRBF_MEGA_SLACK, MRBF_MEGA_SLACK_CHAIN, MRBF_MEGA_WIN, MRBF_MEGA_WBIAS, MRBF_MEGA_DEDICATED, MRBF_MEGA_CHAIN, MRBF_MEGA_LOOK,
+#   MRBF_MEGA_FIRST_WINDOW, MRBF_MEGA_SROWS; MRBF_MEGA_DEBUG=1 prints which dependency a bounded spin gave up on.
+for wb in 0 2 4 8; do
+    echo "wbias=$wb"
+    MRBF_MEGA_WBIAS=$wb timeout -k 10 200 python tools/mega_check.py 8192,16384 3 3 2>&1 | grep "n="
+done
