@@ -850,7 +850,8 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
     a.wbias = ctx->mega_wbias;
     a.srows = srows;
     a.spin_limit = 4000000u;  // x ~0.1-0.3 us per poll: gives up after ~1 s without progress
-    const int grid = ctx->mega_grid;
+    // small matrices: one workgroup per CU is plenty (and leaves room for other contexts' launches: mrbf_batch_run)
+    const int grid = (NT <= 16 && ctx->mega_grid > 256) ? 256 : ctx->mega_grid;
     if (a.nchain < 1) a.nchain = 1;
     if (a.nchain + a.ndedicated >= grid) a.ndedicated = std::max(0, grid / 2 - a.nchain);
     const char *trace_path = getenv("MRBF_MEGA_TRACE");
