@@ -343,14 +343,30 @@ __device__ __attribute__((noinline)) bool window_part(const Args &a, Shared &sh,
     if (p0 >= pend) return wg_wait(sh, a, uc, (unsigned)(2 * wc), nullptr, 0, nullptr, 0, 0x200u);
     v4d acc[TM / 32][4];
     zero_acc(acc);
-    for (int p = p0; p < pend; ++p) {
-        if (!wg_wait(sh, a, a.tdone + (size_t)i * a.NT + p, 2u, a.tdone + (size_t)c * a.NT + p, 2u, p == p0 ? uc : nullptr,
-                     (unsigned)(2 * wc), 0x210u))
-            return false;
+    for (int p = p0; p < pend;) {
+        // wait for panel p, then take every further panel that is already finished in the same GEMM call (contiguous columns):
+        // one poll / acquire / pipeline start for the run instead of one per panel
+        if (threadIdx.x == 0) {
+            bool ok = poll_ge(a.tdone + (size_t)i * a.NT + p, 2u, a, 0x210u) && poll_ge(a.tdone + (size_t)c * a.NT + p, 2u, a, 0x211u) &&
+                      (p != p0 || poll_ge(uc, (unsigned)(2 * wc), a, 0x212u));
+            int run = 0;
+            if (ok) {
+                run = 1;
+                while (p + run < pend && ldf(a.tdone + (size_t)i * a.NT + p + run) >= 2u && ldf(a.tdone + (size_t)c * a.NT + p + run) >= 2u) ++run;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            sh.ok = run;
+        }
+        __syncthreads();
+        const int run = sh.ok;
+        __syncthreads();
+        if (run == 0) return false;
         if (tr && threadIdx.x == 0) tr[p == p0 ? 5 : 6] = wall_clock64();  // first / latest dependency satisfied
         JLOG(p == p0 ? 2 : 3);
         const int64_t k0 = (int64_t)p * NB;
-        gemm_acc<TM>(a.A + (int64_t)i * NB + roff + k0 * a.lda, a.lda, a.A + (int64_t)c * NB + k0 * a.lda, a.lda, NB, acc, sh.u.gemm);
+        gemm_acc<TM>(a.A + (int64_t)i * NB + roff + k0 * a.lda, a.lda, a.A + (int64_t)c * NB + k0 * a.lda, a.lda, run * NB, acc, sh.u.gemm);
+        p += run;
     }
     double *C = a.A + (int64_t)i * NB + roff + (int64_t)c * NB * a.lda;
     if (TM == 128 && i == c)
