@@ -141,9 +141,7 @@ int backsolve_persistent(mrbf_ctx *ctx, int64_t npad, const double *L, int64_t l
     const int nb = (int)(npad / NB);
     static const int force_old = getenv("MRBF_BACKSOLVE_LAUNCHES") ? atoi(getenv("MRBF_BACKSOLVE_LAUNCHES")) : 0;
     // every workgroup must be resident (one 512-thread workgroup per block column): fall back beyond the CU count
-    hipDeviceProp_t prop;
-    int ncu = 256;
-    if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) ncu = prop.multiProcessorCount;
+    const int ncu = ctx->ncu;
     if (force_old || nb < 3 || nb > ncu - 8 || (lda & 1) || (reinterpret_cast<uintptr_t>(L) & 15))
         return backsolve_blocked(ctx, npad, L, lda, linv_all, Y, ldy, k);
     unsigned *flags;

@@ -44,6 +44,7 @@ struct Buf {
 
 struct mrbf_ctx {
     int device = 0;
+    int ncu = 256;  // compute units of the device (queried once at init)
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     rocblas_handle blas = nullptr;

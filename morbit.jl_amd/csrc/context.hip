@@ -193,6 +193,7 @@ int32_t mrbf_init(int32_t device_id, mrbf_ctx **out) {
         hipDeviceProp_t prop;
         int ncu = 256;
         if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) ncu = prop.multiProcessorCount;
+        ctx->ncu = ncu;
         const char *env = getenv("MRBF_BULK_RESERVE");
         const int reserve_per_32 = env ? atoi(env) : 0;  // measured: masking costs more than it buys
         std::vector<uint32_t> mask((ncu + 31) / 32, 0u);

@@ -220,9 +220,7 @@ int eval_fused(mrbf_ctx *ctx, const mrbf_model *M, int64_t m, const double *X, d
     // Split the centre range so that the grid fills the resident workgroup slots (2 per CU) in whole rounds: the cost of a
     // split count is (rounds of workgroups) x (tiles per workgroup) plus the combine pass, which reads one partial per split.
     // (C3: 157 query tiles -> 3 splits of 43 tiles = 471 workgroups in one round, instead of 4 x 32 tiles in two rounds.)
-    hipDeviceProp_t prop;
-    int slots = 512;
-    if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) slots = 2 * prop.multiProcessorCount;
+    const int slots = 2 * ctx->ncu;
     const int64_t qtiles = mpad / EQ;
     int nsplit = 1;
     double best_cost = 1e300;
