@@ -195,6 +195,15 @@ int32_t mrbf_debug_mfma_asm(mrbf_ctx *ctx, int32_t variant, int32_t blocks_per_c
                             double *cycles_per_mfma);
 int32_t mrbf_debug_dgemm(mrbf_ctx *ctx, int32_t m, int32_t n, int32_t k, float *ms, double *tflops);
 
+/* ---- host-side helper of the Pascoletti-Serafini subproblem solver -------------------------------------------------
+ * Stochastic ranking of one ISRES generation (Runarsson & Yao): lam sweeps over adjacent individuals, compared by
+ * objective f when both are feasible (phi == 0) or with probability pf, else by constraint violation phi; stops after a
+ * sweep without a swap.  Replaces what NLopt's GN_ISRES does internally for `_ps_optimization` /
+ * `compute_local_ideal_point` (src/descent.jl:369-387, :478-510); the generation itself is evaluated by ONE mrbf_eval.
+ * u: lam * (lam - 1) uniform random numbers in [0,1) (sweep-major), idx_out: the ranked permutation (best first).
+ * Pure host code (no ctx, no device). */
+int32_t mrbf_stochastic_rank(int32_t lam, const double *f, const double *phi, const double *u, double pf, int32_t *idx_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -82,6 +82,7 @@ SIGNATURES = {
     "mrbf_debug_mfma_peak": (ctypes.c_int32, [c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_fp, c_dp]),
     "mrbf_debug_mfma_asm": (ctypes.c_int32, [c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_fp, c_dp, c_dp]),
     "mrbf_debug_dgemm": (ctypes.c_int32, [c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_fp, c_dp]),
+    "mrbf_stochastic_rank": (ctypes.c_int32, [ctypes.c_int32, c_vp, c_vp, c_vp, ctypes.c_double, c_vp]),
 }
 
 _LIB = None

@@ -367,3 +367,28 @@ int32_t mrbf_batch_run(int32_t n_dev, const int32_t *device_ids, int64_t n_probl
 }
 
 }  // extern "C"
+
+extern "C" int32_t mrbf_stochastic_rank(int32_t lam, const double *f, const double *phi, const double *u, double pf, int32_t *idx_out) {
+    if (lam <= 0) return -1;
+    if (!f) return -2;
+    if (!phi) return -3;
+    if (!u) return -4;
+    if (!idx_out) return -6;
+    for (int32_t i = 0; i < lam; ++i) idx_out[i] = i;
+    for (int32_t sweep = 0; sweep < lam; ++sweep) {
+        bool swapped = false;
+        const double *us = u + (size_t)sweep * (size_t)(lam - 1);
+        for (int32_t j = 0; j + 1 < lam; ++j) {
+            const int32_t a = idx_out[j], b = idx_out[j + 1];
+            const bool by_f = (phi[a] == 0.0 && phi[b] == 0.0) || us[j] < pf;
+            const bool worse = by_f ? (f[a] > f[b]) : (phi[a] > phi[b]);
+            if (worse) {
+                idx_out[j] = b;
+                idx_out[j + 1] = a;
+                swapped = true;
+            }
+        }
+        if (!swapped) break;
+    }
+    return MRBF_OK;
+}

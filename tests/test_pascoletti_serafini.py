@@ -38,6 +38,19 @@ def test_config_mirror_and_budgets():
     assert np.array_equal(ps._get_global_dir(ps.PascolettiSerafiniConfig(reference_point=[1.0, 2.0]), [5.0, 5.0]), [4.0, 3.0])
 
 
+def test_stochastic_rank_helper_properties():
+    rng = np.random.default_rng(0)
+    f = rng.standard_normal(40)
+    # all feasible: a plain sort by objective, whatever the random numbers
+    idx = ps._stochastic_ranking(f, np.zeros(40), rng)
+    assert np.array_equal(np.sort(idx), np.arange(40)) and np.all(np.diff(f[idx]) >= 0)
+    # pf = 0: infeasible pairs are compared by violation only -> feasible individuals (sorted by f) first, then by violation
+    phi = np.where(np.arange(40) % 3 == 0, rng.random(40) + 0.1, 0.0)
+    idx = ps._stochastic_ranking(f, phi, rng, pf=0.0)
+    nfeas = int((phi == 0).sum())
+    assert np.all(phi[idx[:nfeas]] == 0) and np.all(np.diff(f[idx[:nfeas]]) >= 0) and np.all(np.diff(phi[idx[nfeas:]]) >= 0)
+
+
 def test_isres_generation_batches_and_constrained_optimum():
     # min x0 + x1  s.t.  1 - x0 x1 <= 0 in [0, 4]^2  -> (1, 1), value 2
     rng = np.random.default_rng(1)
