@@ -1,21 +1,32 @@
 #!/usr/bin/env python3
 """bench.py -- RBF build+solve+eval cycles/sec (BASELINE.json metric) on N MI355X GPUs of one node.
 
-One STEP = one cycle of the hot path on one batch of synthetic input already resident in HBM:
+One CYCLE = the hot path on one problem whose inputs are already resident in HBM:
     mrbf_fit  (Gram assembly -> projection -> Cholesky -> solve for k right-hand sides)
   + mrbf_eval (values + Jacobians at m query points)
-Default workload = BASELINE.json configs[2] ("C3": d=64, n=8192 centres, multiquadric, degree-1 tail, k=2,
-m=10000 evals, 1 GPU) -- the configuration the north-star targets are quoted on.  With N > 1 every rank
-runs its own independent problem of that size (the path shards by problem, no data-path collective);
-`value` = cycles of all ranks / wall time of the slowest rank.
+Workloads (morbit.jl_amd/workloads.py):
+  --config C3 (default)  BASELINE.json configs[2]: d=64, n=8192, multiquadric, degree-1 tail, k=2, m=10000 -- the configuration the
+                         north-star targets are quoted on.  One STEP = one cycle per rank: with N > 1 every rank runs its own
+                         independent problem of that size (the path shards by problem, no data-path collective): weak scaling,
+                         `value` = cycles of all ranks / wall time of the slowest rank.
+  --config C4 | C5       the many-start workloads: one STEP = the whole batch (64 ZDT1 starts / --problems P of the 256 C5 problems),
+                         problem p on rank p % N, one all_gather of the fixed-size result records per step (the only collective):
+                         strong scaling, `value` = problems of the batch / wall time of the slowest rank.
+  --config C2            single build+solve (no evaluations)
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2|C3|C4|C5] [--no-cpu-baseline]
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2|C3|C4|C5] [--problems P] [--no-cpu-baseline]
+With --gpus N > 1 and no torch.distributed environment the script launches the N ranks itself (python -m torch.distributed.run,
+rendezvous on 127.0.0.1) BEFORE anything touches a GPU, and exits with the launcher's code; under an external
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` it runs as one rank.
+  --dry-run              launcher / sharding / gather rehearsal on CPU (gloo, no GPU, no engine): prints the JSON line with
+                         "dry_run": true and value null.  Used by tests/test_bench_launch.py.
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,211 +35,328 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-CONFIGS = {  # BASELINE.json configs -> sizes
-    "C2": dict(kernel="gaussian", n=2048, d=32, k=1, m=0, deg=1, seed=2,
-               desc="C2: d=32 n=2048 gaussian deg1 k=1, single build+solve"),
-    "C3": dict(kernel="multiquadric", n=8192, d=64, k=2, m=10000, deg=1, seed=3,
-               desc="C3: d=64 n=8192 multiquadric deg1 k=2, build+solve + 10000 evals (values+Jacobians)"),
-    "C4": dict(kernel="cubic", n=257, d=128, k=2, m=6450, deg=1, seed=40,
-               desc="C4: ZDT1-shaped d=128 n=257 cubic deg1 k=2, build+solve + 6450 evals per start"),
-    "C5": dict(kernel="cubic", n=16384, d=256, k=2, m=1024, deg=1, seed=1000,
-               desc="C5: d=256 n=16384 cubic deg1 k=2, build+solve + 1024 evals"),
-}
-HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (~6.3 TB/s achievable)
 FP64_MFMA_PEAK_TF = 78.6   # MI355X FP64 matrix peak (spec; v_mfma_f64_16x16x4_f64 = 16 FMA/clk/SIMD x 1024 SIMD x 2.4 GHz)
 
 
-def synth(cfg, rank):
-    rng = np.random.Generator(np.random.PCG64(cfg["seed"] + 7919 * rank))
-    n, d, k, m = cfg["n"], cfg["d"], cfg["k"], cfg["m"]
-    C = rng.random((n, d))
-    if cfg["kernel"] == "cubic" and d == 128:  # ZDT1 (formulas from MultiObjectiveProblems.jl)
-        f1 = C[:, 0]
-        g = 1.0 + 9.0 * C[:, 1:].sum(axis=1) / (d - 1)
-        Y = np.stack([f1, g * (1.0 - np.sqrt(f1 / g))], axis=1)
-    else:
-        cols = [((C - 1.0) ** 2).sum(axis=1) / d, ((C + 1.0) ** 2).sum(axis=1) / d]
-        Y = np.stack(cols[:k], axis=1)
-    X = np.random.Generator(np.random.PCG64(cfg["seed"] + 1 + 7919 * rank)).random((max(m, 1), d))
-    return C, Y, X
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", default="C3", choices=["C2", "C3", "C4", "C5"])
+    ap.add_argument("--problems", type=int, default=None, help="problems per step of the many-start configs (default: C4 64, C5 8 per rank)")
+    ap.add_argument("--workers", type=int, default=0, help="host threads (contexts) per rank for the many-start configs (default: 4 for n <= 2048, else 1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-run", action="store_true")
+    ap.add_argument("--gram-mode", type=int, default=0)
+    ap.add_argument("--chol-impl", type=int, default=0)
+    ap.add_argument("--eval-impl", type=int, default=0)
+    return ap.parse_args()
 
 
-def algorithmic(cfg):
-    """SURVEY.md section 8d per-unit figures for one cycle"""
-    n, d, k, m = cfg["n"], cfg["d"], cfg["k"], cfg["m"]
-    q = 0 if cfg["deg"] < 0 else (1 if cfg["deg"] == 0 else d + 1)
-    return dict(
-        gram_bytes=8.0 * n * d + 8.0 * n * n,                        # read centres once + write full Phi
-        gram_flops=float(n) * n * d,                                 # GEMM form on the lower triangle (2 * n^2/2 * d)
-        factor_flops=n ** 3 / 3.0,                                   # potrf
-        project_flops=4.0 * n * n * q,                               # symm + syr2k (+ syrk 1 n^2 q not counted)
-        solve_flops=2.0 * n * n * k,
-        eval_flops=float(m) * n * (3 * d + 2 * k + 2 * k * d),
-        eval_bytes=8.0 * (n * d + n * k + m * d + m * k + m * k * d),
-    )
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
 
-def cpu_baseline(cfg, C, Y, X):
-    """The oracle ("port"), vectorised NumPy + LAPACK on the host cores, on a bounded sample of the same workload:
-    the full fit (assembly + dense LU of the saddle system, as the reference's `\\`) and min(m, 1024) evaluations,
-    eval time scaled to m."""
-    from oracle import rbf_oracle as orc
+def spawn_ranks(args):
+    """N > 1 without a launcher: start the ranks as children of this (GPU-free) process and return their exit code"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // args.gpus)))
+    return subprocess.call(cmd, env=env)
 
+
+# ---- CPU baselines (the oracle is the checker and the timed baseline, never the product) ---------------------------------
+def blas_threads():
     try:
         from threadpoolctl import threadpool_info
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+        return max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
     except Exception:
-        cores = os.cpu_count() or 1
+        return os.cpu_count() or 1
+
+
+def cpu_baselines(cfg, C, Y, X):
+    """Both modes of BASELINE.md section 2 on a bounded sample of the same workload, LAPACK LU shared between them:
+       port      vectorised NumPy assembly (thread pool) + LAPACK dgesv + batched evaluation             -> `cpu_baseline`
+       faithful  the reference's call pattern, single-threaded loops of the C restatement: per-pair norm(x - c) assembly, the same
+                 dgesv, evaluation ONE point and ONE output per closure call, value and gradient sweeps separate
+                 (AbstractSurrogateInterface.jl:98-106)                                                  -> `cpu_baseline_faithful`"""
+    import scipy.linalg
+    from oracle import c_oracle
+    from oracle import rbf_oracle as orc
+
     kid = orc.KERNEL_IDS[cfg["kernel"]]
     a, b = orc.kernel_params(cfg["kernel"])
+    n, m, k, deg = cfg["n"], cfg["m"], cfg["k"], cfg["deg"]
+    cores = int(blas_threads())
+    scipy.linalg.solve(np.eye(256) + 0.01 * np.ones((256, 256)), np.ones((256, 2)), check_finite=False)  # LAPACK / thread pool start-up is not timed
     t0 = time.perf_counter()
-    mod = orc.fit(C, Y, kid, a, b, cfg["deg"])
-    t_fit = time.perf_counter() - t0
-    ms = min(cfg["m"], 1024)
-    t_eval = 0.0
+    Phi, Pi = orc.gram(C, kid, a, b, deg)
+    t_asm_port = time.perf_counter() - t0
+    q = Pi.shape[1]
+    S = orc.saddle_matrix(Phi, Pi)
+    rhs = np.vstack([Y, np.zeros((q, k))])
+    t0 = time.perf_counter()
+    sol = scipy.linalg.solve(S, rhs, assume_a="gen", check_finite=False)
+    t_lu = time.perf_counter() - t0
+    del S
+    mod = orc.OracleModel(C, sol[:n].copy(), sol[n:].copy(), kid, a, b, deg)
+    ms = min(m, 1024)
+    t_eval_port = 0.0
     if ms > 0:
         t0 = time.perf_counter()
         mod.values(X[:ms])
         mod.jacs(X[:ms])
-        t_eval = (time.perf_counter() - t0) * (cfg["m"] / ms)
-    cyc = t_fit + t_eval
-    return dict(value=1.0 / cyc, unit="cycles/s", cores=int(cores), kind="port",
-                sample="full fit n=%d (NumPy assembly + LAPACK dgesv) %.2fs + %d of %d evals (values+Jacobians) scaled %.2fs"
-                       % (cfg["n"], t_fit, ms, cfg["m"], t_eval)), mod
+        t_eval_port = (time.perf_counter() - t0) * (m / ms)
+    port = dict(value=1.0 / (t_asm_port + t_lu + t_eval_port), unit="cycles/s", cores=cores, kind="port", blas_threads=cores,
+                sample="full fit n=%d: NumPy assembly %.2fs + LAPACK dgesv (N=%d) %.2fs; %d of %d evals (values+Jacobians, batched) "
+                       "scaled to %.2fs" % (n, t_asm_port, n + q, t_lu, ms, m, t_eval_port))
+    # faithful mode: bounded samples, scaled (assembly is O(rows), evaluation O(points))
+    rows = min(n, max(64, int(2.0e9 / max(1, n * cfg["d"]))))           # ~2e9 scalar pair-dimension steps
+    t0 = time.perf_counter()
+    c_oracle.gram_cols(C, kid, a, b, rows)
+    t_asm_f = (time.perf_counter() - t0) * (n / rows)
+    mf = min(m, 64)
+    t_eval_f = 0.0
+    if mf > 0:
+        t0 = time.perf_counter()
+        c_oracle.eval_loop(C, mod.w, mod.lam, kid, a, b, deg, X[:mf], want_jac=True)
+        t_eval_f = (time.perf_counter() - t0) * (m / mf)
+    faithful = dict(value=1.0 / (t_asm_f + t_lu + t_eval_f), unit="cycles/s", cores=1, kind="port", blas_threads=cores,
+                    sample="single-threaded C loops: per-pair norm assembly of %d of %d rows scaled to %.2fs + the same LAPACK dgesv %.2fs "
+                           "(%d BLAS threads, as Julia's `\\`); %d of %d points, one output per closure call, value and gradient sweeps "
+                           "separate, scaled to %.2fs" % (rows, n, t_asm_f, t_lu, cores, mf, m, t_eval_f))
+    return port, faithful
 
 
+# ---- one rank ----------------------------------------------------------------------------------------------------------
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="C3", choices=sorted(CONFIGS))
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gram-mode", type=int, default=0)
-    ap.add_argument("--chol-impl", type=int, default=0)
-    ap.add_argument("--eval-impl", type=int, default=0)
-    args = ap.parse_args()
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))  # nothing below has run: no GPU call in the parent
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d; launch with --nproc-per-node == --gpus (or let bench.py spawn the ranks)"
+                         % (args.gpus, world))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
+    from morbit.jl_amd import manystart
+    from morbit.jl_amd import workloads as wl
+
+    cfg = wl.CONFIGS[args.config]
+    many = args.config in ("C4", "C5")
+    steps = args.steps if args.steps is not None else (3 if args.config == "C5" else (5 if many else 200))
+    warmup = args.warmup if args.warmup is not None else (1 if many else 5)
+    n, d, k, m = cfg["n"], cfg["d"], cfg["k"], cfg["m"]
+    if many:
+        P = args.problems if args.problems is not None else (cfg["problems"] if args.config == "C4" else 8 * world)
+    else:
+        P = world  # one problem per rank per step
+    mine = manystart.shard_indices(P, rank, world)  # problem p -> rank p % world
+
+    dry = args.dry_run
+    if not dry and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
-    torch.cuda.set_device(local_rank)
+    device = "cpu" if dry else "cuda"
+    if not dry:
+        torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
-
-    import morbit.jl_amd as pkg
-    from morbit.jl_amd import _lib
-
-    cfg = CONFIGS[args.config]
-    n, d, k, m = cfg["n"], cfg["d"], cfg["k"], cfg["m"]
-    C, Y, X = synth(cfg, rank)
-    rcfg = pkg.RbfConfig(kernel=cfg["kernel"], polynomial_degree=cfg["deg"])
-    kid, a, b = pkg.rbf_model._get_kernel_params(1.0, rcfg)
-
-    # inputs + outputs resident in HBM before the timed region
-    dC = torch.from_numpy(C).cuda()
-    dY = torch.from_numpy(Y).cuda()
-    dX = torch.from_numpy(X).cuda()
-    dV = torch.empty((max(m, 1), k), dtype=torch.float64, device="cuda")
-    dJ = torch.empty((max(m, 1), d, k), dtype=torch.float64, device="cuda")
-    torch.cuda.synchronize()
-
-    ctx = pkg.Context(local_rank)
-    ctx.set_option(_lib.OPT_GRAM_MODE, args.gram_mode)
-    ctx.set_option(_lib.OPT_CHOL_IMPL, args.chol_impl)
-    ctx.set_option(_lib.OPT_EVAL_IMPL, args.eval_impl)
-    lib = ctx.lib
-    finfo, einfo = _lib.FitInfo(), _lib.EvalInfo()
-
-    def cycle():
-        h = _lib.c_vp()
-        ctx.check(lib.mrbf_fit(ctx.h, n, d, k, _lib.as_ptr(dC), _lib.as_ptr(dY), kid, a, b, cfg["deg"], ctypes.byref(h),
-                               None, None, ctypes.byref(finfo)))
-        if m > 0:
-            ctx.check(lib.mrbf_eval(ctx.h, h, m, _lib.as_ptr(dX), _lib.as_ptr(dV), _lib.as_ptr(dJ), ctypes.byref(einfo)))
-        ctx.check(lib.mrbf_free_model(ctx.h, h))
-
-    # one checked cycle (residual through the eval kernels), then the timed loop without the extra check
-    ctx.set_option(_lib.OPT_RESIDUAL, 1)
-    cycle()
-    check = dict(path=finfo.path, rel_residual=finfo.rel_residual, max_pitw=finfo.max_pitw)
-    assert finfo.rel_residual < 1e-9, "fit residual too large: %r" % (check,)
-    ctx.set_option(_lib.OPT_RESIDUAL, 0)
-    for _ in range(args.warmup):
-        cycle()
+        if dry:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not dry:
+            torch.cuda.synchronize()
 
-    phases = {p: 0.0 for p in ("gram", "project", "factor", "solve", "eval")}
+    PH = ("gram", "project", "factor", "solve", "eval")
+    check = {}
+    workers = []
+    nworkers = 1
+    if dry:
+        class DryWorker:
+            phases = {p: 0.0 for p in PH}
+            fallbacks = 0
+
+            def cycle(self, p):
+                time.sleep(0.001)
+                return [float(p), 0.0, 2.0, 0.0, 0.0, 0.0, 1.0, 0.0]
+        workers = [DryWorker()]
+    else:
+        import morbit.jl_amd as pkg
+        from morbit.jl_amd import _lib
+
+        rcfg = pkg.RbfConfig(kernel=cfg["kernel"], polynomial_degree=cfg["deg"])
+        kid, a, b = pkg.rbf_model._get_kernel_params(1.0, rcfg)
+        # inputs of this rank's problems resident in HBM before the timed region
+        host, dev = {}, {}
+        for p in mine:
+            C, Y, X = wl.problem(args.config, p)
+            if p == mine[0]:
+                host[p] = (C, Y, X)
+            dev[p] = (torch.from_numpy(C).cuda(), torch.from_numpy(Y).cuda(), torch.from_numpy(X).cuda())
+        torch.cuda.synchronize()
+        # small problems are launch-latency bound: several host threads, each with its own context (stream, workspace), keep
+        # more kernels in flight on the GPU -- the mrbf_batch_run arrangement (api.hip), here with device-resident inputs
+        nworkers = args.workers if args.workers > 0 else (4 if (many and n <= 2048) else 1)
+        nworkers = max(1, min(nworkers, max(1, len(mine))))
+
+        class Worker:
+            def __init__(self):
+                self.ctx = pkg.Context(local_rank)
+                self.ctx.set_option(_lib.OPT_GRAM_MODE, args.gram_mode)
+                self.ctx.set_option(_lib.OPT_CHOL_IMPL, args.chol_impl)
+                self.ctx.set_option(_lib.OPT_EVAL_IMPL, args.eval_impl)
+                self.finfo, self.einfo = _lib.FitInfo(), _lib.EvalInfo()
+                self.dV = torch.empty((max(m, 1), k), dtype=torch.float64, device="cuda")
+                self.dJ = torch.empty((max(m, 1), d, k), dtype=torch.float64, device="cuda")
+                self.dW = torch.empty((n, k), dtype=torch.float64, device="cuda")
+                self.sums = torch.empty(2, dtype=torch.float64, device="cuda")
+                self.phases = {p: 0.0 for p in PH}
+                self.fallbacks = 0
+
+            def cycle(self, p):
+                ctx, lib, finfo, einfo = self.ctx, self.ctx.lib, self.finfo, self.einfo
+                dC, dY, dX = dev[p]
+                h = _lib.c_vp()
+                ctx.check(lib.mrbf_fit(ctx.h, n, d, k, _lib.as_ptr(dC), _lib.as_ptr(dY), kid, a, b, cfg["deg"], ctypes.byref(h),
+                                       _lib.as_ptr(self.dW) if many else None, None, ctypes.byref(finfo)))
+                if m > 0:
+                    ctx.check(lib.mrbf_eval(ctx.h, h, m, _lib.as_ptr(dX), _lib.as_ptr(self.dV), _lib.as_ptr(self.dJ), ctypes.byref(einfo)))
+                ctx.check(lib.mrbf_free_model(ctx.h, h))
+                ph = self.phases
+                ph["gram"] += finfo.ms_gram
+                ph["project"] += finfo.ms_project
+                ph["factor"] += finfo.ms_factor
+                ph["solve"] += finfo.ms_solve
+                ph["eval"] += einfo.ms_total if m > 0 else 0.0
+                if finfo.fallbacks & ~_lib.FB_LU:
+                    self.fallbacks += 1
+                return [float(p), 0.0, float(finfo.path), float(finfo.rel_residual), 0.0, 0.0, finfo.ms_total, einfo.ms_total if m > 0 else 0.0]
+
+        workers = [Worker() for _ in range(nworkers)]
+        # one checked cycle per rank (residual through the eval kernels), then the timed loop without the extra check
+        w0 = workers[0]
+        w0.ctx.set_option(_lib.OPT_RESIDUAL, 1)
+        if mine:
+            w0.cycle(mine[0])
+            check.update(path=w0.finfo.path, rel_residual=w0.finfo.rel_residual, max_pitw=w0.finfo.max_pitw)
+            assert w0.finfo.rel_residual < 1e-9, "fit residual too large: %r" % (check,)
+        for w in workers:
+            w.ctx.set_option(_lib.OPT_RESIDUAL, 0)
+
+    pool = None
+    if len(workers) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(len(workers))
+
+    def step():
+        if pool is None:
+            recs = [workers[0].cycle(p) for p in mine]
+        else:  # worker w takes this rank's problems w, w + nworkers, ... (ctypes releases the GIL inside the library)
+            parts = list(pool.map(lambda wi: [workers[wi].cycle(p) for p in mine[wi::len(workers)]], range(len(workers))))
+            recs = [r for part in parts for r in part]
+        if many:  # the batch's only collective: fixed-size records, gathered to every rank
+            local = np.asarray(recs, dtype=np.float64).reshape(-1, manystart.RECORD_LEN)
+            return manystart.gather_records(local, P, device=device)
+        return None
+
+    for _ in range(warmup):
+        step()
+    for w in workers:
+        for p in PH:
+            w.phases[p] = 0.0
+        w.fallbacks = 0
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        cycle()
-        phases["gram"] += finfo.ms_gram
-        phases["project"] += finfo.ms_project
-        phases["factor"] += finfo.ms_factor
-        phases["solve"] += finfo.ms_solve
-        phases["eval"] += einfo.ms_total if m > 0 else 0.0
+    table = None
+    for _ in range(steps):
+        table = step()
     barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed_local = time.perf_counter() - t0
+    elapsed = elapsed_local
+    rank_times = [elapsed_local]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    for p in phases:
-        phases[p] /= args.steps  # ms per launch, hipEvents on the library's stream inside the timed region
+        t = torch.tensor([elapsed_local], dtype=torch.float64, device=device)
+        allt = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        rank_times = [float(x.item()) for x in allt]
+        elapsed = max(rank_times)
+    ncyc = max(1, steps * len(mine))
+    # ms per launch, hipEvents on the library's stream inside the timed region (rank 0's problems)
+    phases = {p: sum(w.phases[p] for w in workers) / ncyc for p in PH}
+    nfb = sum(w.fallbacks for w in workers)
+    if nfb:
+        check["fits_with_fallback"] = nfb
 
     if rank == 0:
-        alg = algorithmic(cfg)
-        kernels = {
-            "gram": dict(bound="hbm", achieved=alg["gram_bytes"] / (phases["gram"] * 1e-3) / 1e9, peak=HBM_PEAK_GBS,
-                         unit="GB/s", ms=phases["gram"]),
-            "factor": dict(bound="mfma", achieved=alg["factor_flops"] / (phases["factor"] * 1e-3) / 1e12,
-                           peak=FP64_MFMA_PEAK_TF, unit="TFLOP/s", ms=phases["factor"]),
-            "project": dict(bound="mfma", achieved=alg["project_flops"] / max(phases["project"], 1e-9) / 1e9,
-                            peak=FP64_MFMA_PEAK_TF, unit="TFLOP/s", ms=phases["project"]),
-        }
-        if m > 0:
-            kernels["eval"] = dict(bound="mfma", achieved=alg["eval_flops"] / (phases["eval"] * 1e-3) / 1e12,
-                                   peak=FP64_MFMA_PEAK_TF, unit="TFLOP/s", ms=phases["eval"])
-        for kd in kernels.values():
-            kd["frac"] = kd["achieved"] / kd["peak"]
-        dom = max(("gram", "factor", "eval") if m > 0 else ("gram", "factor"), key=lambda p: phases[p])
-        roof = dict(kernels[dom])
-        roof["kernel"] = dom
-        roof["traffic"] = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                roof["traffic"] = json.load(open(pmc)).get(args.config, {}).get(dom)
-            except Exception:
-                pass
+        alg = wl.algorithmic(args.config)
         out = {
-            "metric": "RBF build+solve+eval cycles/sec", "value": world * args.steps / elapsed, "unit": "cycles/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "metric": "RBF build+solve+eval cycles/sec", "value": None if dry else P * steps / elapsed, "unit": "cycles/s",
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
+            "higher_is_better": True, "scaling": "strong" if many else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": cfg["desc"], "n": n, "d": d, "k": k, "m": m, "kernel": cfg["kernel"],
-                       "polynomial_degree": cfg["deg"], "problems_per_step": world, "parallelism": "problem-sharded x%d" % world},
-            "roofline": roof, "kernels": kernels, "phases_ms": phases, "check": check,
+                       "polynomial_degree": cfg["deg"], "problems_per_step": P, "contexts_per_gpu": len(workers),
+                       "parallelism": "problem-sharded x%d (problem p on rank p %% %d%s)" % (world, world, ", one all_gather of records per step" if many else "")},
+            "rank_seconds": rank_times, "rank_imbalance": max(rank_times) / max(min(rank_times), 1e-12),
         }
-        if not args.no_cpu_baseline and world == 1:
-            cb, _ = cpu_baseline(cfg, C, Y, X)
-            out["cpu_baseline"] = cb
-        print(json.dumps(out))
+        if dry:
+            out["dry_run"] = True
+        if many and table is not None:
+            out["records"] = {"gathered": int(table.shape[0]), "failed": int(np.sum(table[:, 1] != 0)),
+                              "worst_rel_residual": float(np.nanmax(table[:, 3])) if table.shape[0] else None}
+            assert table.shape[0] == P and np.array_equal(table[:, 0], np.arange(P)), "record gather lost problems"
+        if not dry:
+            kernels = {
+                "gram": dict(bound="hbm", achieved=alg["gram_bytes"] / (phases["gram"] * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", ms=phases["gram"]),
+                "factor": dict(bound="mfma", achieved=alg["factor_flops"] / (phases["factor"] * 1e-3) / 1e12, peak=FP64_MFMA_PEAK_TF,
+                               unit="TFLOP/s", ms=phases["factor"]),
+                "project": dict(bound="hbm", achieved=alg["project_bytes"] / max(phases["project"], 1e-9) / 1e6, peak=HBM_PEAK_GBS, unit="GB/s",
+                                ms=phases["project"], flops_tf=alg["project_flops"] / max(phases["project"], 1e-9) / 1e9),
+            }
+            if m > 0:
+                kernels["eval"] = dict(bound="mfma", achieved=alg["eval_flops"] / (phases["eval"] * 1e-3) / 1e12, peak=FP64_MFMA_PEAK_TF,
+                                       unit="TFLOP/s", ms=phases["eval"])
+            for kd in kernels.values():
+                kd["frac"] = kd["achieved"] / kd["peak"]
+            dom = max(("gram", "factor", "eval") if m > 0 else ("gram", "factor"), key=lambda p: phases[p])
+            roof = dict(kernels[dom])
+            roof["kernel"] = dom
+            roof["traffic"] = None
+            pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(pmc):
+                try:
+                    roof["traffic"] = json.load(open(pmc)).get(args.config, {}).get(dom)
+                except Exception:
+                    pass
+            out.update({"roofline": roof, "kernels": kernels, "phases_ms": phases, "check": check})
+            if not args.no_cpu_baseline and world == 1 and args.config in ("C2", "C3", "C4"):
+                C, Y, X = host[mine[0]]
+                port, faithful = cpu_baselines(cfg, C, Y, X)
+                out["cpu_baseline"] = port
+                out["cpu_baseline_faithful"] = faithful
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
+    if pool is not None:
+        pool.shutdown()
+    for w in workers:
+        if hasattr(w, "ctx"):
+            w.ctx.close()
 
 
 if __name__ == "__main__":

@@ -78,7 +78,18 @@ enum {
     MRBF_OPT_EVAL_IMPL = 5,    /* 0 = default, 1 = GEMM pipeline, 2 = fused MFMA kernel */
     MRBF_OPT_TIMING = 6,       /* 1 = record per-phase hipEvents (default 1) */
     MRBF_OPT_DIAG_IMPL = 7,    /* diagonal-block kernel of the built-in Cholesky: 0 = MFMA-tiled (default), 1 = column sweep */
-    MRBF_OPT_CHOL_WINDOW = 8   /* panels aggregated per trailing update: 0 = size-dependent schedule (default), else 1, 2 or 4 */
+    MRBF_OPT_CHOL_WINDOW = 8,  /* panels aggregated per trailing update: 0 = size-dependent schedule (default), else 1, 2 or 4 */
+    MRBF_OPT_SPIN_MS = 9,      /* wall-clock limit (ms) a persistent kernel waits on one dependency without progress before it gives up
+                                  and the call falls back to the host-driven GPU path (default 1000) */
+    MRBF_OPT_DEBUG_FAULT = 10  /* test hook: bit 0 = one workgroup of the persistent factorisation skips a publish, bit 1 = one workgroup of
+                                  the persistent backward substitution does (the next fit must fall back and still return the right weights) */
+};
+
+/* bits of mrbf_fit_info.fallbacks: a GPU path that was abandoned for another GPU path inside the same call (rc stays 0) */
+enum {
+    MRBF_FB_CHOL_HOST_DRIVEN = 1, /* persistent Cholesky gave up on a dependency -> re-assembled, host-driven blocked Cholesky */
+    MRBF_FB_BACKSOLVE_BLOCKED = 2, /* persistent backward substitution gave up -> one launch per block row */
+    MRBF_FB_LU = 4                /* Cholesky met a non-positive pivot / rank-deficient tail -> LU of the saddle system */
 };
 
 typedef struct {
@@ -89,6 +100,8 @@ typedef struct {
     double max_pitw;      /* max |Pi' w|; NaN if disabled */
     double mu;            /* shift used by the projected Cholesky (0 otherwise) */
     float ms_gram, ms_project, ms_factor, ms_solve, ms_check, ms_total; /* hipEvent times on the ctx stream */
+    int32_t fallbacks;    /* MRBF_FB_* bits */
+    int32_t giveup_code;  /* diagnostic code of the last give-up (0 if none) */
 } mrbf_fit_info;
 
 typedef struct {

@@ -16,13 +16,16 @@ c_vp = ctypes.c_void_p
 MRBF_OK, MRBF_ENOTPD, MRBF_ESINGULAR, MRBF_EHIP, MRBF_EBLAS, MRBF_ENOMEM, MRBF_ENODEVICE, MRBF_ENCCL = range(8)
 PATH_CHOL, PATH_PROJ_CHOL, PATH_LU, PATH_MINNORM = 1, 2, 3, 4
 OPT_GRAM_MODE, OPT_RESIDUAL, OPT_FORCE_PATH, OPT_CHOL_IMPL, OPT_EVAL_IMPL, OPT_TIMING, OPT_DIAG_IMPL, OPT_CHOL_WINDOW = 1, 2, 3, 4, 5, 6, 7, 8
+OPT_SPIN_MS, OPT_DEBUG_FAULT = 9, 10
+FB_CHOL_HOST_DRIVEN, FB_BACKSOLVE_BLOCKED, FB_LU = 1, 2, 4
 
 
 class FitInfo(ctypes.Structure):
     _fields_ = [("path", ctypes.c_int32), ("factor_info", ctypes.c_int32), ("n", ctypes.c_int32), ("q", ctypes.c_int32),
                 ("rel_residual", ctypes.c_double), ("max_pitw", ctypes.c_double), ("mu", ctypes.c_double),
                 ("ms_gram", ctypes.c_float), ("ms_project", ctypes.c_float), ("ms_factor", ctypes.c_float),
-                ("ms_solve", ctypes.c_float), ("ms_check", ctypes.c_float), ("ms_total", ctypes.c_float)]
+                ("ms_solve", ctypes.c_float), ("ms_check", ctypes.c_float), ("ms_total", ctypes.c_float),
+                ("fallbacks", ctypes.c_int32), ("giveup_code", ctypes.c_int32)]
 
     def asdict(self):
         return {f: getattr(self, f) for f, _ in self._fields_}

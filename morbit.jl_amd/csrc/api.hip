@@ -137,19 +137,21 @@ int32_t mrbf_fit(mrbf_ctx *ctx, int64_t n, int32_t d, int32_t k, const double *c
         destroy_model(ctx, M);
         return rc;
     }
-    if (weights_out) {
-        if (is_device_ptr(weights_out))
-            MRBF_HIP(ctx, hipMemcpyAsync(weights_out, M->W, (size_t)n * k * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-        else
-            MRBF_HIP(ctx, hipMemcpyAsync(weights_out, M->W, (size_t)n * k * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    auto copy_out = [&]() -> int {
+        if (weights_out)
+            MRBF_HIP(ctx, hipMemcpyAsync(weights_out, M->W, (size_t)n * k * sizeof(double),
+                                         is_device_ptr(weights_out) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+        if (poly_out && M->q > 0)
+            MRBF_HIP(ctx, hipMemcpyAsync(poly_out, M->lam, (size_t)M->q * k * sizeof(double),
+                                         is_device_ptr(poly_out) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+        MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return 0;
+    };
+    rc = copy_out();
+    if (rc != 0) {  // the model is not handed out: release it
+        destroy_model(ctx, M);
+        return rc;
     }
-    if (poly_out && M->q > 0) {
-        if (is_device_ptr(poly_out))
-            MRBF_HIP(ctx, hipMemcpyAsync(poly_out, M->lam, (size_t)M->q * k * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-        else
-            MRBF_HIP(ctx, hipMemcpyAsync(poly_out, M->lam, (size_t)M->q * k * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    }
-    MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *model = M;
     return MRBF_OK;
 }
@@ -174,13 +176,21 @@ int32_t mrbf_model_from_coeffs(mrbf_ctx *ctx, int64_t n, int32_t d, int32_t k, c
     if (q > 0) MRBF_TRY(stage_in(ctx, S_STAGE_C, poly, (size_t)q * k, &L));
     mrbf_model *M = nullptr;
     MRBF_TRY(build_model_shell(ctx, n, d, k, C, kernel_id, a, b, poly_deg, &M));
-    MRBF_HIP(ctx, hipMemcpyAsync(M->W, W, (size_t)n * k * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-    MRBF_HIP(ctx, hipMemsetAsync(M->Wc, 0, (size_t)M->npad * k * sizeof(double), ctx->stream));
-    for (int l = 0; l < k; ++l)  // strided copy W[:, l] -> Wc[:, l]
-        MRBF_HIP(ctx, hipMemcpy2DAsync(M->Wc + (size_t)l * M->npad, sizeof(double), W + l, (size_t)k * sizeof(double),
-                                       sizeof(double), (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
-    if (q > 0) MRBF_HIP(ctx, hipMemcpyAsync(M->lam, L, (size_t)q * k * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-    MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    auto fill = [&]() -> int {
+        MRBF_HIP(ctx, hipMemcpyAsync(M->W, W, (size_t)n * k * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        MRBF_HIP(ctx, hipMemsetAsync(M->Wc, 0, (size_t)M->npad * k * sizeof(double), ctx->stream));
+        for (int l = 0; l < k; ++l)  // strided copy W[:, l] -> Wc[:, l]
+            MRBF_HIP(ctx, hipMemcpy2DAsync(M->Wc + (size_t)l * M->npad, sizeof(double), W + l, (size_t)k * sizeof(double),
+                                           sizeof(double), (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
+        if (q > 0) MRBF_HIP(ctx, hipMemcpyAsync(M->lam, L, (size_t)q * k * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return 0;
+    };
+    const int rc = fill();
+    if (rc != 0) {
+        destroy_model(ctx, M);
+        return rc;
+    }
     *model = M;
     return MRBF_OK;
 }

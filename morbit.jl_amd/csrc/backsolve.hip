@@ -63,10 +63,13 @@ __device__ __forceinline__ void tile_product(Shared<KB> &sh, const v2d (&r)[RPT 
 template <int KB>
 __global__ __launch_bounds__(NTHR, 1) void backsolve_persistent_kernel(const double *__restrict__ L, int64_t lda, const double *__restrict__ linv_all,
                                                                         double *__restrict__ Y, int64_t ldy, int k0, int nb, unsigned *flags,
-                                                                        unsigned epoch, unsigned spin_limit) {
+                                                                        unsigned epoch, unsigned long long spin_ticks, int *status, int fault) {
     __shared__ Shared<KB> sh;
-    const int j = blockIdx.x, tid = threadIdx.x;
+    // block nb-1 (which depends on nothing) is dispatched first, block 0 last: every workgroup only waits for workgroups that were
+    // dispatched BEFORE it, so the launch drains at any residency (other kernels holding CUs, several contexts on one GPU)
+    const int j = nb - 1 - (int)blockIdx.x, tid = threadIdx.x;
     const int c = tid & 127, g = tid >> 7;
+    unsigned *abortw = flags + (size_t)nb * 32;
     // y_j
     if (tid < KB * NB) sh.y[tid / NB][tid % NB] = *(const gf64 *)&Y[(int64_t)(k0 + tid / NB) * ldy + (int64_t)j * NB + (tid % NB)];
     // tiles of the critical path first, into registers
@@ -80,17 +83,29 @@ __global__ __launch_bounds__(NTHR, 1) void backsolve_persistent_kernel(const dou
         if (tid == 0) {
             int ok = 1;
             unsigned spins = 0;
+            unsigned long long t0 = 0;
             while (__hip_atomic_load((const gu32 *)(flags + i * 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
-                if (++spins > spin_limit) {
-                    ok = 0;
-                    break;
+                if ((++spins & 63u) == 0u) {
+                    // somebody else gave up: stop at once instead of timing out one dependant after the other
+                    if (__hip_atomic_load((const gu32 *)abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                        ok = 0;
+                        break;
+                    }
+                    const unsigned long long now = wall_clock64();
+                    if (t0 == 0) t0 = now;
+                    if (now - t0 > spin_ticks) {
+                        __hip_atomic_store((gu32 *)abortw, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        *(__attribute__((address_space(1))) int *)status = 0x700 + (i & 0xff);  // read back with the factorisation's flags
+                        ok = 0;
+                        break;
+                    }
                 }
                 __builtin_amdgcn_s_sleep(2);
             }
             sh.ok = ok;
         }
         __syncthreads();
-        if (!sh.ok) return;  // (bounded spin; the caller checks the result's residual)
+        if (!sh.ok) return;  // gave up: the abort word is set, the host re-runs the solve with backsolve_blocked
         // x_i: write-through by its producer, read past the L1 (sc1)
         if (tid < KB * NB)
             sh.xs[tid / NB][tid % NB] =
@@ -102,6 +117,7 @@ __global__ __launch_bounds__(NTHR, 1) void backsolve_persistent_kernel(const dou
             tile_product<KB>(sh, tnext);
         __syncthreads();
     }
+    if (fault && j == nb / 2) return;  // test hook: this block's solution is never published
     // x_j = inv(L_jj)' y_j
     {
         double acc[KB];
@@ -136,7 +152,10 @@ __global__ __launch_bounds__(NTHR, 1) void backsolve_persistent_kernel(const dou
 int backsolve_blocked(mrbf_ctx *ctx, int64_t npad, const double *L, int64_t lda, const double *linv_all, double *Y, int64_t ldy, int k);
 
 // Same contract as backsolve_blocked (chol_blocked.hip): Y (npad x k, column-major, ld ldy) is overwritten by the solution.
-int backsolve_persistent(mrbf_ctx *ctx, int64_t npad, const double *L, int64_t lda, const double *linv_all, double *Y, int64_t ldy, int k) {
+// *status (device int, zeroed by the caller) receives a non-zero code when a workgroup gave up on a dependency; Y is then
+// partly overwritten and the caller must restore the right-hand sides and use backsolve_blocked.
+int backsolve_persistent(mrbf_ctx *ctx, int64_t npad, const double *L, int64_t lda, const double *linv_all, double *Y, int64_t ldy, int k,
+                         int *status) {
     using namespace bsolve;
     const int nb = (int)(npad / NB);
     static const int force_old = getenv("MRBF_BACKSOLVE_LAUNCHES") ? atoi(getenv("MRBF_BACKSOLVE_LAUNCHES")) : 0;
@@ -145,15 +164,17 @@ int backsolve_persistent(mrbf_ctx *ctx, int64_t npad, const double *L, int64_t l
     if (force_old || nb < 3 || nb > ncu - 8 || (lda & 1) || (reinterpret_cast<uintptr_t>(L) & 15))
         return backsolve_blocked(ctx, npad, L, lda, linv_all, Y, ldy, k);
     unsigned *flags;
-    MRBF_TRY(get_buf(ctx, S_BSOLVE_FLAGS, (size_t)nb * 32, &flags));
-    MRBF_HIP(ctx, hipMemsetAsync(flags, 0, (size_t)nb * 32 * sizeof(unsigned), ctx->stream));
+    MRBF_TRY(get_buf(ctx, S_BSOLVE_FLAGS, (size_t)(nb + 1) * 32, &flags));  // one 128-byte line per block + the abort word
+    MRBF_HIP(ctx, hipMemsetAsync(flags, 0, (size_t)(nb + 1) * 32 * sizeof(unsigned), ctx->stream));
+    const unsigned long long spin_ticks = (unsigned long long)std::max(1, ctx->spin_ms) * 100000ull;  // wall_clock64: 100 MHz
+    const int fault = (ctx->debug_fault & 2) ? 1 : 0;
     unsigned epoch = 0;
     for (int k0 = 0; k0 < k; k0 += 4) {
         const int kb = std::min(4, k - k0);
         ++epoch;
 #define MRBF_BSP(KBV)                                                                                                          \
     hipLaunchKernelGGL((backsolve_persistent_kernel<KBV>), dim3((unsigned)nb), dim3(NTHR), 0, ctx->stream, L, lda, linv_all, Y, ldy, k0, nb, \
-                       flags, epoch, 20000000u)
+                       flags, epoch, spin_ticks, status, fault)
         if (kb == 1) MRBF_BSP(1); else if (kb == 2) MRBF_BSP(2); else if (kb == 3) MRBF_BSP(3); else MRBF_BSP(4);
 #undef MRBF_BSP
     }

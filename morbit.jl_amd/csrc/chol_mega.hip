@@ -89,7 +89,8 @@ struct Args {
     int nchain;      // workgroups [0, nchain) serve the chain queue only (their CU partner stays idle)
     int ndedicated;  // workgroups [nchain, nchain + ndedicated) serve the panel queue only
     int look;        // general workgroups take a panel job of block column c once c < (finished diagonal blocks) + look
-    unsigned spin_limit;
+    unsigned long long spin_ticks;  // wall_clock64 ticks (10 ns) one wait may last without the awaited word changing
+    int fault;                      // test hook: the last block row's first panel job of column 0 never publishes its tile
     int use_quiet;
     int slack, slack_chain, first, win, wbias, srows;
     unsigned long long *jlog;   // diagnostic launches only: 8 words per job (meta, claim, 5 stage stamps, end), jlog[0] = count
@@ -123,16 +124,26 @@ __device__ __forceinline__ unsigned addf(unsigned *p, unsigned v) {
 __device__ __forceinline__ void st_sc1(double *p, double v) { __hip_atomic_store((gf64 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // thread 0: spin until *f >= want (bounded); false on abort / timeout
+// (the bound is wall-clock time since the awaited word last changed, read every 256 polls: a healthy launch that merely shares the
+// chip with other kernels is slow, not stuck)
 __device__ __forceinline__ bool poll_ge(const unsigned *f, unsigned want, const Args &a, unsigned code) {
-    unsigned spins = 0;
-    while (ldf(f) < want) {
+    unsigned spins = 0, last = 0xffffffffu;
+    unsigned long long t0 = 0;
+    unsigned cur;
+    while ((cur = ldf(f)) < want) {
         if (ldf(a.ctl + CTL_ABORT)) return false;
-        if (++spins > a.spin_limit) {
-            stf(a.ctl + CTL_TIMEOUT + 1, (unsigned)(f - a.ctl));  // which word (diagnostics)
-            stf(a.ctl + CTL_TIMEOUT + 2, want);
-            stf(a.ctl + CTL_TIMEOUT, code);
-            stf(a.ctl + CTL_ABORT, 1u);
-            return false;
+        if ((++spins & 255u) == 0u) {
+            const unsigned long long now = wall_clock64();
+            if (cur != last || t0 == 0) {
+                last = cur;
+                t0 = now;
+            } else if (now - t0 > a.spin_ticks) {
+                stf(a.ctl + CTL_TIMEOUT + 1, (unsigned)(f - a.ctl));  // which word (diagnostics)
+                stf(a.ctl + CTL_TIMEOUT + 2, want);
+                stf(a.ctl + CTL_TIMEOUT, code);
+                stf(a.ctl + CTL_ABORT, 1u);
+                return false;
+            }
         }
         __builtin_amdgcn_s_sleep(4);
     }
@@ -534,6 +545,7 @@ __device__ __attribute__((noinline)) bool run_panel(const Args &a, Shared &sh, c
     gemm_acc<64>(C, a.lda, Linv, NB, NB, acc, sh.u.gemm);  // every wave's loads of X are complete behind the loop's last barrier
     store_tile<64, false, false, true>(C, a.lda, acc);
     wg_drain();
+    if (a.fault && i == a.MT - 1 && c == 0 && jb.w == 0) return true;  // test hook: this half tile is never published
     if (threadIdx.x == 0) addf(a.tdone + (size_t)i * a.NT + c, 1u);
     return true;
 }
@@ -655,7 +667,7 @@ __global__ __launch_bounds__(256, 2) void potrf_mega_kernel(const Args a) {
         if (a.use_quiet && threadIdx.x == 0) addf(myquiet, 0xffffffffu);
         return;
     }
-    unsigned idle = 0;
+    unsigned long long idle_t0 = 0;  // start of the current run of idle scans
     int nidle = 0;
     while (true) {
         if (threadIdx.x < 64) {
@@ -665,7 +677,7 @@ __global__ __launch_bounds__(256, 2) void potrf_mega_kernel(const Args a) {
                 kind = -2;
             } else if (!dedicated && a.use_quiet && ldf(myquiet) != 0) {
                 kind = -1;  // the CU's other workgroup runs a chain-critical job: leave it the SIMDs
-                idle = 0;
+                idle_t0 = 0;
             } else {
                 const unsigned ph = ldf(a.ctl + CTL_QP);
                 panel_left = ph < (unsigned)a.npanel;
@@ -701,12 +713,18 @@ __global__ __launch_bounds__(256, 2) void potrf_mega_kernel(const Args a) {
                 } else {
                     kind = -2;  // dedicated workgroup, panel queue drained
                 }
-                if (kind == -1 && ++idle > a.spin_limit) {
-                    if (threadIdx.x == 0) {
-                        stf(a.ctl + CTL_TIMEOUT, 0x400u);
-                        stf(a.ctl + CTL_ABORT, 1u);
+                if (kind == -1) {
+                    // nothing ready for this workgroup: give up only after 4 x the dependency limit of wall-clock time (others may
+                    // be inside long jobs; a stuck launch is reported by the waiting job itself long before)
+                    const unsigned long long now = wall_clock64();
+                    if (idle_t0 == 0) idle_t0 = now;
+                    if (now - idle_t0 > 4ull * a.spin_ticks) {
+                        if (threadIdx.x == 0) {
+                            stf(a.ctl + CTL_TIMEOUT, 0x400u);
+                            stf(a.ctl + CTL_ABORT, 1u);
+                        }
+                        kind = -2;
                     }
-                    kind = -2;
                 }
             }
             if (threadIdx.x == 0) {
@@ -725,7 +743,7 @@ __global__ __launch_bounds__(256, 2) void potrf_mega_kernel(const Args a) {
             for (int r = 0; r < reps; ++r) __builtin_amdgcn_s_sleep(64);
             continue;
         }
-        idle = 0;
+        idle_t0 = 0;
         nidle = 0;
         bool ok;
         const unsigned long long tj0 = a.trace ? wall_clock64() : 0ull;
@@ -865,20 +883,21 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
     a.win = win;
     a.wbias = ctx->mega_wbias;
     a.srows = srows;
-    a.spin_limit = 4000000u;  // x ~0.1-0.3 us per poll: gives up after ~1 s without progress
+    a.spin_ticks = (unsigned long long)std::max(1, ctx->spin_ms) * 100000ull;  // wall_clock64 runs at 100 MHz
+    a.fault = (ctx->debug_fault & 1) && MT > 1;
     // small matrices: one workgroup per CU is plenty (and leaves room for other contexts' launches: mrbf_batch_run)
     const int grid = (NT <= 16 && ctx->mega_grid > 256) ? 256 : ctx->mega_grid;
     if (a.nchain < 1) a.nchain = 1;
     if (a.nchain + a.ndedicated >= grid) a.ndedicated = std::max(0, grid / 2 - a.nchain);
     const char *trace_path = getenv("MRBF_MEGA_TRACE");
     if (trace_path) {
-        MRBF_TRY(get_buf(ctx, S_MISC, (size_t)NT * 16 + 4 * 1024, &a.trace));
+        MRBF_TRY(get_buf(ctx, S_MEGA_TRACE, (size_t)NT * 16 + 4 * 1024, &a.trace));
         MRBF_HIP(ctx, hipMemsetAsync(a.trace, 0, ((size_t)NT * 16 + 4 * 1024) * sizeof(unsigned long long), ctx->stream));
     }
     const char *jlog_path = getenv("MRBF_MEGA_JLOG");
     if (jlog_path) {
         a.jlog_cap = ctx->mega_npanel + ctx->mega_nbulk + ctx->mega_nchainjobs + 16;
-        MRBF_TRY(get_buf(ctx, S_STAGE_D, (size_t)8 * a.jlog_cap + 16, &a.jlog));
+        MRBF_TRY(get_buf(ctx, S_MEGA_JLOG, (size_t)8 * a.jlog_cap + 16, &a.jlog));
         MRBF_HIP(ctx, hipMemsetAsync(a.jlog, 0, ((size_t)8 * a.jlog_cap + 16) * sizeof(unsigned long long), ctx->stream));
     }
     hipLaunchKernelGGL(potrf_mega_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, a);

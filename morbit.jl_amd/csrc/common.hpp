@@ -33,7 +33,8 @@ inline int poly_dim(int d, int deg) { return deg < 0 ? 0 : (deg == 0 ? 1 : d + 1
 enum Slot {
     S_XC = 0, S_SQ, S_MEAN, S_PHI, S_PI, S_Q1, S_W1, S_G, S_R, S_TAU, S_RHS, S_T1, S_T2, S_IPIV, S_INFO,
     S_STAGE_A, S_STAGE_B, S_STAGE_C, S_STAGE_D, S_EVAL_E, S_EVAL_A, S_EVAL_J, S_EVAL_SA, S_EVAL_XC, S_EVAL_XSQ,
-    S_OUT_A, S_OUT_B, S_CHOL_WS, S_MISC, S_MEGA_JOBS, S_MEGA_FLAGS, S_MEGA_WQ, S_MEGA_IT, S_BSOLVE_FLAGS, S_NSLOTS
+    S_OUT_A, S_OUT_B, S_CHOL_WS, S_MISC, S_MEGA_JOBS, S_MEGA_FLAGS, S_MEGA_WQ, S_MEGA_IT, S_BSOLVE_FLAGS, S_MEGA_TRACE, S_MEGA_JLOG,
+    S_T1W, S_NSLOTS
 };
 struct Buf {
     void *p = nullptr;
@@ -63,6 +64,9 @@ struct mrbf_ctx {
                                         // ~0.1-0.3 ms each and serialise across host threads)
     // options
     int gram_mode = 0, residual = 1, force_path = 0, chol_impl = 0, eval_impl = 0, timing = 1, diag_impl = 0, chol_window = 0;
+    // bounded spins of the persistent kernels: wall-clock limit without progress (ms); debug_fault makes ONE workgroup of the named
+    // kernel skip a publish so that the give-up paths can be tested deterministically (bit 0: factorisation, bit 1: backward substitution)
+    int spin_ms = 1000, debug_fault = 0;
 };
 
 struct mrbf_model {

@@ -190,6 +190,7 @@ int32_t mrbf_init(int32_t device_id, mrbf_ctx **out) {
         if (const char *e = getenv("MRBF_MEGA_WBIAS")) ctx->mega_wbias = atoi(e);
         if (const char *e = getenv("MRBF_MEGA_SROWS")) ctx->mega_srows = atoi(e);
         if (const char *e = getenv("MRBF_MEGA_MAX")) ctx->mega_max = atoi(e);
+        if (const char *e = getenv("MRBF_SPIN_MS")) ctx->spin_ms = std::max(1, atoi(e));
         hipDeviceProp_t prop;
         int ncu = 256;
         if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) ncu = prop.multiProcessorCount;
@@ -248,6 +249,8 @@ int32_t mrbf_set_option(mrbf_ctx *ctx, int32_t key, double value) {
         case MRBF_OPT_TIMING: ctx->timing = v; break;
         case MRBF_OPT_DIAG_IMPL: ctx->diag_impl = v; break;
         case MRBF_OPT_CHOL_WINDOW: ctx->chol_window = v; break;
+        case MRBF_OPT_SPIN_MS: ctx->spin_ms = v > 0 ? v : 1000; break;
+        case MRBF_OPT_DEBUG_FAULT: ctx->debug_fault = v; break;
         default: return fail(ctx, -2, "unknown option key %d", key);
     }
     return MRBF_OK;
@@ -265,6 +268,8 @@ int32_t mrbf_get_option(const mrbf_ctx *ctx, int32_t key, double *value) {
         case MRBF_OPT_TIMING: *value = ctx->timing; break;
         case MRBF_OPT_DIAG_IMPL: *value = ctx->diag_impl; break;
         case MRBF_OPT_CHOL_WINDOW: *value = ctx->chol_window; break;
+        case MRBF_OPT_SPIN_MS: *value = ctx->spin_ms; break;
+        case MRBF_OPT_DEBUG_FAULT: *value = ctx->debug_fault; break;
         default: return -2;
     }
     return MRBF_OK;

@@ -189,9 +189,17 @@ int build_model_shell(mrbf_ctx *ctx, int64_t n, int d, int k, const double *Cdev
     M->W = (double *)(base + off[4]);
     M->Wc = (double *)(base + off[5]);
     M->lam = (double *)(base + off[6]);
-    if (Cdev != M->C)
-        MRBF_HIP(ctx, hipMemcpyAsync(M->C, Cdev, (size_t)n * d * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-    MRBF_TRY(launch_center_pad(ctx, M->C, n, d, nullptr, M->mean, M->Xc, M->npad, M->dpad, M->sq));
+    auto init = [&]() -> int {
+        if (Cdev != M->C)
+            MRBF_HIP(ctx, hipMemcpyAsync(M->C, Cdev, (size_t)n * d * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        MRBF_TRY(launch_center_pad(ctx, M->C, n, d, nullptr, M->mean, M->Xc, M->npad, M->dpad, M->sq));
+        return 0;
+    };
+    const int rc = init();
+    if (rc != 0) {
+        destroy_model(ctx, M);
+        return rc;
+    }
     *out = M;
     return 0;
 }
@@ -303,7 +311,8 @@ static int fit_minnorm(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_i
 // ---- Cholesky paths ------------------------------------------------------------------------------
 int potrf_blocked_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int64_t lda, int *dinfo, double *linv_all);
 int backsolve_blocked(mrbf_ctx *ctx, int64_t npad, const double *L, int64_t lda, const double *linv_all, double *Y, int64_t ldy, int k);
-int backsolve_persistent(mrbf_ctx *ctx, int64_t npad, const double *L, int64_t lda, const double *linv_all, double *Y, int64_t ldy, int k);  // backsolve.hip
+int backsolve_persistent(mrbf_ctx *ctx, int64_t npad, const double *L, int64_t lda, const double *linv_all, double *Y, int64_t ldy, int k,
+                         int *status);  // backsolve.hip
 int launch_update_lower(mrbf_ctx *ctx, const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc, int64_t nt, int K);
 int launch_pad_identity(mrbf_ctx *ctx, double *A, int64_t n, int64_t npad, int64_t ld);
 int tsmm_tn(mrbf_ctx *ctx, int64_t n, int p, int r, double alpha, const double *A, int64_t lda, const double *B, int64_t ldb, double beta,
@@ -416,12 +425,14 @@ __global__ __launch_bounds__(256) void trsm_lt_small_kernel(const double *__rest
     }
 }
 
-// returns 0 with *not_pd = 1 when a factorisation met a non-positive pivot (caller may retry with LU)
-static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info *info, int *not_pd) {
+// returns 0 with *not_pd = 1 when a factorisation met a non-positive pivot (caller may retry with LU), and 0 with *gave_up = 1
+// when the persistent factorisation abandoned a dependency (caller re-runs this function with the host-driven factorisation)
+static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info *info, int *not_pd, int *gave_up) {
     const int64_t n = M->n, npad = M->npad;
     const int k = M->k, q = M->q, d = M->d;
     const double one = 1.0, zero = 0.0, mone = -1.0, mhalf = -0.5;
     *not_pd = 0;
+    *gave_up = 0;
     const bool builtin = ctx->chol_impl != 1;
     const int xt = builtin ? (int)round_up(k, 128) : 0;  // extra row tiles: right-hand sides ride along the factorisation
     const int64_t ld = npad + xt;
@@ -429,7 +440,7 @@ static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info
     int *dinfo;
     MRBF_TRY(get_buf(ctx, S_PHI, (size_t)ld * npad, &Phi));
     MRBF_TRY(get_buf(ctx, S_RHS, (size_t)npad * k, &B));
-    MRBF_TRY(get_buf(ctx, S_INFO, (size_t)4, &dinfo));  // [0] main factorisation, [1] Cholesky-QR of the tail, [2] shift not positive
+    MRBF_TRY(get_buf(ctx, S_INFO, (size_t)4, &dinfo));  // [0] main factorisation, [1] Cholesky-QR of the tail, [2] shift not positive, [3] backward substitution gave up
     MRBF_HIP(ctx, hipMemsetAsync(dinfo, 0, 4 * sizeof(int), ctx->stream));
     hipLaunchKernelGGL(rhs_from_values_kernel, dim3(nblk(npad * k)), dim3(256), 0, ctx->stream, Y, n, k, B, npad);
     double *Q1 = nullptr, *Wm = nullptr, *G = nullptr, *T1 = nullptr, *scal = nullptr, *Tall = nullptr;
@@ -512,33 +523,44 @@ static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info
         MRBF_HIP(ctx, hipMemcpyAsync(dinfo, dpot, sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
         MRBF_HIP(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
     }
-    if (builtin) {
-        // forward substitution came out of the factorisation (the extra rows); backward substitution with the stored block inverses
-        hipLaunchKernelGGL(get_rhs_rows_kernel, dim3(nblk(npad * k)), dim3(256), 0, ctx->stream, Phi, ld, npad, B, k);
-        MRBF_TRY(backsolve_persistent(ctx, npad, Phi, ld, linv_all, B, npad, k));
-    } else {
-        MRBF_BLAS(ctx, rocsolver_dpotrs(ctx->blas, rocblas_fill_lower, (int)n, k, Phi, (int)ld, B, (int)npad));
-    }
-    if (q > 0) {
-        double *T2;
-        MRBF_TRY(get_buf(ctx, S_T2, (size_t)q * k, &T2));
-        // re-project w (rounding hygiene): w -= Q1 (Q1' w)
-        MRBF_TRY(tsmm_tn(ctx, n, q, k, 1.0, Q1, npad, B, npad, 0.0, T2, q));
-        hipLaunchKernelGGL(sub_qt_kernel, dim3(nblk(n * k)), dim3(256), 0, ctx->stream, B, npad, Q1, npad, T2, n, q, k);
-        // z = Q1' Y - (Phi Q1)' w;  (Phi Q1)' w = W' w because Q1' w = 0;  lam = R^-1 z
-        MRBF_TRY(tsmm_tn(ctx, n, q, k, -1.0, Wm, npad, B, npad, 1.0, T1, q));
-        if (q > 1) {
-            if (d <= 256)
-                hipLaunchKernelGGL(trsm_lt_small_kernel, dim3(1), dim3(256), 0, ctx->stream, Tall, lt, d, T1 + 1, (int64_t)q, k);
+    // everything after the factorisation, re-runnable: the right-hand sides are re-read from the extra rows, T1 is copied first
+    double *T1w = nullptr;
+    if (q > 0) MRBF_TRY(get_buf(ctx, S_T1W, (size_t)q * k, &T1w));
+    auto solve_tail = [&](bool persistent) -> int {
+        if (builtin) {
+            // forward substitution came out of the factorisation (the extra rows); backward substitution with the stored block inverses
+            hipLaunchKernelGGL(get_rhs_rows_kernel, dim3(nblk(npad * k)), dim3(256), 0, ctx->stream, Phi, ld, npad, B, k);
+            if (persistent)
+                MRBF_TRY(backsolve_persistent(ctx, npad, Phi, ld, linv_all, B, npad, k, dinfo + 3));
             else
-                MRBF_BLAS(ctx, rocblas_dtrsm(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose,
-                                             rocblas_diagonal_non_unit, d, k, &one, Tall, (int)lt, T1 + 1, q));
+                MRBF_TRY(backsolve_blocked(ctx, npad, Phi, ld, linv_all, B, npad, k));
+        } else {
+            MRBF_BLAS(ctx, rocsolver_dpotrs(ctx->blas, rocblas_fill_lower, (int)n, k, Phi, (int)ld, B, (int)npad));
         }
-        hipLaunchKernelGGL(finish_lambda_kernel, dim3((k + 63) / 64), dim3(64), 0, ctx->stream, T1, q, k, std::sqrt((double)n), M->mean);
-    }
-    hipLaunchKernelGGL(scatter_solution_kernel, dim3(nblk(M->npad * k + (int64_t)q * k)), dim3(256), 0, ctx->stream, B, npad, n,
-                       M->npad, k, q, (int64_t)0, M->W, M->Wc, M->lam, T1 ? T1 : B, (int64_t)q);
-    MRBF_HIP(ctx, hipGetLastError());
+        if (q > 0) {
+            double *T2;
+            MRBF_TRY(get_buf(ctx, S_T2, (size_t)q * k, &T2));
+            MRBF_HIP(ctx, hipMemcpyAsync(T1w, T1, (size_t)q * k * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+            // re-project w (rounding hygiene): w -= Q1 (Q1' w)
+            MRBF_TRY(tsmm_tn(ctx, n, q, k, 1.0, Q1, npad, B, npad, 0.0, T2, q));
+            hipLaunchKernelGGL(sub_qt_kernel, dim3(nblk(n * k)), dim3(256), 0, ctx->stream, B, npad, Q1, npad, T2, n, q, k);
+            // z = Q1' Y - (Phi Q1)' w;  (Phi Q1)' w = W' w because Q1' w = 0;  lam = R^-1 z
+            MRBF_TRY(tsmm_tn(ctx, n, q, k, -1.0, Wm, npad, B, npad, 1.0, T1w, q));
+            if (q > 1) {
+                if (d <= 256)
+                    hipLaunchKernelGGL(trsm_lt_small_kernel, dim3(1), dim3(256), 0, ctx->stream, Tall, lt, d, T1w + 1, (int64_t)q, k);
+                else
+                    MRBF_BLAS(ctx, rocblas_dtrsm(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose,
+                                                 rocblas_diagonal_non_unit, d, k, &one, Tall, (int)lt, T1w + 1, q));
+            }
+            hipLaunchKernelGGL(finish_lambda_kernel, dim3((k + 63) / 64), dim3(64), 0, ctx->stream, T1w, q, k, std::sqrt((double)n), M->mean);
+        }
+        hipLaunchKernelGGL(scatter_solution_kernel, dim3(nblk(M->npad * k + (int64_t)q * k)), dim3(256), 0, ctx->stream, B, npad, n,
+                           M->npad, k, q, (int64_t)0, M->W, M->Wc, M->lam, T1w ? T1w : B, (int64_t)q);
+        MRBF_HIP(ctx, hipGetLastError());
+        return 0;
+    };
+    MRBF_TRY(solve_tail(true));
     MRBF_HIP(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
     {
         // one host round trip for all the flags of this path, AFTER the solve has been enqueued: the solve kernels run on whatever
@@ -550,8 +572,13 @@ static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info
         if (q > 0) MRBF_HIP(ctx, hipMemcpyAsync(hscal, scal, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
         hinfo = hflags[0];
-        if (hinfo < 0)  // the persistent factorisation gave up on a dependency (bounded spin): never observed, never silent
-            return fail(ctx, MRBF_EHIP, "persistent Cholesky gave up (code 0x%x); set MRBF_CHOL_IMPL=2 for the host-driven factorisation", -hinfo);
+        if (hinfo < 0) {
+            // the persistent factorisation gave up on a dependency (bounded wait): the matrix is half factored, the caller
+            // re-assembles it and factors with the host-driven launches (same kernels, no inter-workgroup waits)
+            *gave_up = 1;
+            info->giveup_code = -hinfo;
+            return 0;
+        }
         info->factor_info = hinfo;
         if (q > 0) info->mu = hscal[1];
         if (hflags[1] != 0) {  // affinely dependent sites: Pi is rank deficient
@@ -567,6 +594,13 @@ static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info
         if (hinfo != 0) {
             *not_pd = 1;
             return 0;
+        }
+        if (hflags[3] != 0) {
+            // the persistent backward substitution gave up: the factor is intact, redo the solve with one launch per block row
+            info->fallbacks |= MRBF_FB_BACKSOLVE_BLOCKED;
+            info->giveup_code = hflags[3];
+            MRBF_TRY(solve_tail(false));
+            MRBF_HIP(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
         }
     }
     MRBF_HIP(ctx, hipEventSynchronize(ctx->ev[4]));
@@ -625,9 +659,20 @@ int fit_model(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info *info
     if (path == MRBF_PATH_MINNORM) {
         MRBF_TRY(fit_minnorm(ctx, M, Y, info));
     } else if (path != MRBF_PATH_LU) {
-        int not_pd = 0;
-        MRBF_TRY(fit_chol(ctx, M, Y, info, &not_pd));
+        int not_pd = 0, gave_up = 0;
+        MRBF_TRY(fit_chol(ctx, M, Y, info, &not_pd, &gave_up));
+        if (gave_up) {
+            // same call, same GPU: re-assemble and factor with the host-driven blocked Cholesky (chol_impl 2)
+            const int saved = ctx->chol_impl;
+            ctx->chol_impl = 2;
+            info->fallbacks |= MRBF_FB_CHOL_HOST_DRIVEN;
+            const int rc2 = fit_chol(ctx, M, Y, info, &not_pd, &gave_up);
+            ctx->chol_impl = saved;
+            if (rc2 != 0) return rc2;
+            if (gave_up) return fail(ctx, MRBF_EHIP, "host-driven Cholesky reported a give-up code (0x%x)", info->giveup_code);
+        }
         if (not_pd) {
+            info->fallbacks |= MRBF_FB_LU;
             if (ctx->force_path != 0)
                 return fail(ctx, MRBF_ENOTPD, "Cholesky path forced but the matrix is not positive definite (info = %d)",
                             info->factor_info);

@@ -114,23 +114,40 @@ def cross_gram(cfg, X, C, delta=1.0, ctx=None):
     return K
 
 
-def _rbf_round4(sites, lb_2, ub_2, x, delta, indices_found_so_far, cfg, ctx=None, kernel_block=None):
+def _rand_box_point(lb, ub, rng):
+    """utilities.jl:303: uniform point of the box"""
+    lb, ub = np.asarray(lb, dtype=np.float64), np.asarray(ub, dtype=np.float64)
+    return lb + (ub - lb) * rng.random(lb.size)
+
+
+def _rbf_round4(sites, lb_2, ub_2, x, delta, indices_found_so_far, cfg, ctx=None, kernel_block=None, rng=None, new_sites=None):
     """Wild's second selection round (RbfModel.jl:352-499): database indices of additional training sites that keep the
     Cholesky factors of Z'Phi Z bounded.  `sites` is the database as an (N_db, d) array; candidates are the box members
-    not yet chosen, in database order.  `use_max_points` sampling of fresh random sites is the caller's job (it needs the
-    database); this function handles the database candidates."""
+    not yet chosen, in database order.  With `cfg.use_max_points` random box points are tried once the database candidates
+    are used up (RbfModel.jl:405-416, at most 10 max_points + 1 of them); an accepted one is appended to the list `new_sites`
+    (the caller's `new_result!`, :455-457) and gets the index len(sites) + its position there."""
     sites = np.asarray(sites, dtype=np.float64)
     d = sites.shape[1]
     max_points = (d + 1) * (d + 2) // 2 if cfg.max_model_points <= 0 else cfg.max_model_points
     N = len(indices_found_so_far)
     cand = results_in_box_indices(sites, lb_2, ub_2, indices_found_so_far)
     round4 = []
-    if not (N < max_points and cand):
+    if not (N < max_points and (cand or cfg.use_max_points)):
         return round4
+    if cfg.use_max_points:
+        # the random points the loop may need, drawn up front so that their kernel values ride in the same batched device call
+        # (the reference draws them one by one from the global RNG; the sequence of box points is the same)
+        rng = np.random.default_rng() if rng is None else rng
+        max_tries = 10 * max_points
+        fresh = np.array([_rand_box_point(lb_2, ub_2, rng) for _ in range(max_tries + 1)])
+        new_sites = [] if new_sites is None else new_sites
+    else:
+        fresh = np.empty((0, d))
     chol_pivot = cfg.θ_pivot_cholesky ** 2
     deg = cfg.polynomial_degree
     C0 = sites[list(indices_found_so_far)]
-    Xc = sites[cand]
+    Xc = np.vstack([sites[cand], fresh]) if len(cand) else fresh
+    ids = list(cand) + [-1] * fresh.shape[0]
     if kernel_block is None:
         # two device calls replace one kernels(xi) call per candidate plus RBF.get_matrices
         Phi, Pi, _ = rm.get_matrices(cfg, C0, delta, ctx=ctx)
@@ -149,7 +166,7 @@ def _rbf_round4(sites, lb_2, ub_2, x, delta, indices_found_so_far, cfg, ctx=None
     phi0 = float(Phi[0, 0])
     cols = list(range(N))            # columns of K_all that are current centres
     n0 = N
-    for pos, id_ in enumerate(cand):
+    for pos, id_ in enumerate(ids):
         if N >= max_points:
             break
         xi = Xc[pos]
@@ -165,6 +182,9 @@ def _rbf_round4(sites, lb_2, ub_2, x, delta, indices_found_so_far, cfg, ctx=None
         sigma = Qg @ Phi @ Qg + 2.0 * gh * (phixi @ Qg) + gh * gh * phi0
         tau2 = sigma - (np.linalg.norm(Linv @ v) ** 2 if v.size else 0.0)
         if tau2 > chol_pivot ** 2:
+            if id_ < 0:  # a fresh random site: stored by the caller (new_result!, RbfModel.jl:455-457)
+                new_sites.append(xi.copy())
+                id_ = sites.shape[0] + len(new_sites) - 1
             round4.append(id_)
             tau = math.sqrt(tau2)
             Qn = np.zeros((N + 1, N + 1))

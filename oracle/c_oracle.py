@@ -28,6 +28,10 @@ def lib():
         L.orc_gram.restype = None
         L.orc_gram.argtypes = [ctypes.c_int, ctypes.c_int, _dp, ctypes.c_int, ctypes.c_double, ctypes.c_double,
                                ctypes.c_int, _dp, _dp]
+        L.orc_gram_mt.restype = None
+        L.orc_gram_mt.argtypes = L.orc_gram.argtypes + [ctypes.c_int]
+        L.orc_gram_cols.restype = None
+        L.orc_gram_cols.argtypes = [ctypes.c_int, ctypes.c_int, _dp, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_int, _dp]
         L.orc_fit.restype = ctypes.c_int
         L.orc_fit.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp, _dp, ctypes.c_int, ctypes.c_double,
                               ctypes.c_double, ctypes.c_int, _dp, _dp]
@@ -42,14 +46,24 @@ def _p(a):
     return a.ctypes.data_as(_dp)
 
 
-def gram(C, kid, a, b, deg):
+def gram(C, kid, a, b, deg, threads=1):
+    """Phi, Pi with the per-pair norm(x - c) loop; threads > 1 spreads the columns over OpenMP threads (same arithmetic)."""
     C = np.ascontiguousarray(C, dtype=np.float64)
     n, d = C.shape
     q = 0 if deg < 0 else (1 if deg == 0 else d + 1)
     Phi = np.empty((n, n), order="F")
     Pi = np.empty((n, max(q, 1)), order="F")
-    lib().orc_gram(n, d, _p(C), kid, a, b, deg, _p(Phi), _p(Pi))
+    lib().orc_gram_mt(n, d, _p(C), kid, a, b, deg, _p(Phi), _p(Pi), int(threads))
     return Phi, Pi[:, :q]
+
+
+def gram_cols(C, kid, a, b, cols):
+    """first `cols` columns of Phi, faithful single-threaded per-pair loop (bounded sample for the CPU baseline)"""
+    C = np.ascontiguousarray(C, dtype=np.float64)
+    n, d = C.shape
+    out = np.empty((n, cols), order="F")
+    lib().orc_gram_cols(n, d, _p(C), kid, a, b, int(cols), _p(out))
+    return out
 
 
 def fit(C, Y, kid, a, b, deg):

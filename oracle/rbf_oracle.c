@@ -85,6 +85,34 @@ void orc_gram(int n, int d, const double *C, int kid, double a, double b, int de
                 Pi[(size_t)t * n + i] = (t == 0) ? 1.0 : C[(size_t)i * d + (t - 1)];
 }
 
+/* the same per-pair loop spread over `threads` OpenMP threads (columns are independent; the arithmetic of every entry is
+ * unchanged).  threads <= 1 is the faithful single-threaded mode above; the tests use more threads only to keep the
+ * n = 16384 oracle affordable. */
+void orc_gram_mt(int n, int d, const double *C, int kid, double a, double b, int deg, double *Phi, double *Pi, int threads) {
+    if (threads <= 1) {
+        orc_gram(n, d, C, kid, a, b, deg, Phi, Pi);
+        return;
+    }
+    int q = orc_poly_dim(d, deg);
+    const double phi0 = orc_phi(kid, a, b, 0.0);
+#pragma omp parallel for schedule(dynamic, 8) num_threads(threads)
+    for (int j = 0; j < n; ++j)
+        for (int i = 0; i < n; ++i)
+            Phi[(size_t)j * n + i] = (i == j) ? phi0 : orc_phi(kid, a, b, dist(C + (size_t)i * d, C + (size_t)j * d, d));
+    if (Pi)
+        for (int i = 0; i < n; ++i)
+            for (int t = 0; t < q; ++t)
+                Pi[(size_t)t * n + i] = (t == 0) ? 1.0 : C[(size_t)i * d + (t - 1)];
+}
+
+/* the first `cols` columns of Phi (n x cols, column-major) with the faithful per-pair loop: a bounded sample of the assembly
+ * for bench.py's cpu_baseline (cost is proportional to the columns computed) */
+void orc_gram_cols(int n, int d, const double *C, int kid, double a, double b, int cols, double *out) {
+    for (int j = 0; j < cols; ++j)
+        for (int i = 0; i < n; ++i)
+            out[(size_t)j * n + i] = (i == j) ? orc_phi(kid, a, b, 0.0) : orc_phi(kid, a, b, dist(C + (size_t)i * d, C + (size_t)j * d, d));
+}
+
 /* dgesv restated: LU with partial pivoting, A is N x N column-major, B is N x nrhs column-major.
  * returns 0, or j+1 when U(j,j) is exactly zero. */
 int orc_lu_solve(int N, int nrhs, double *A, double *B) {

@@ -84,6 +84,11 @@ def make_cases():
     X = rng.random((5, 3))
     cases.append(dict(name="mq_beta1p5", C=C, Y=Y, X=X, kid=2, a=0.9, b=1.5, deg=1))
     cases.append(dict(name="imq_beta1", C=C, Y=Y, X=X, kid=1, a=1.1, b=1.0, deg=0))
+    # C1 again with a shape parameter that bounds the conditioning: shape_parameter = "2/Δ" with the
+    # trust-region radius Δ = 0.2 of the sample box, i.e. alpha = 10 -> cond ~ 5e4, so the 1e-10 weight tolerance of
+    # BASELINE.json applies outright (with the package default alpha = 1 the 20 sites in a box of radius 0.2 give cond 5.7e11)
+    c1 = next(c for c in cases if c["name"] == "c1_two_parabolas")
+    cases.append(dict(name="c1_two_parabolas_shape_2_over_delta", C=c1["C"], Y=c1["Y"], X=c1["X"], kid=2, a=2.0 / 0.2, b=0.5, deg=1))
     return cases
 
 

@@ -44,7 +44,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 def test_struct_layouts_match_header():
     from morbit.jl_amd import _lib
 
-    assert ctypes.sizeof(_lib.FitInfo) == 4 * 4 + 3 * 8 + 6 * 4 == 64
+    assert ctypes.sizeof(_lib.FitInfo) == 4 * 4 + 3 * 8 + 6 * 4 + 2 * 4 == 72
     assert ctypes.sizeof(_lib.EvalInfo) == 16
     assert ctypes.sizeof(_lib.Problem) == 2 * 8 + 4 * 4 + 2 * 8 + 7 * 8 == 104
     assert _lib.Result.fit.offset == 8

@@ -1,9 +1,10 @@
 """GPU parity tests (run with -m gpu on the MI355X box): the HIP path through the C ABI against the
 CPU oracle, the committed golden fixtures, and size-independent properties at BASELINE.json sizes.
 
-Tolerances (BASELINE.json north_star): 1e-10 relative on interpolation weights, 1e-8 on surrogate
-values -- with a conditioning allowance for the weights (weight parity is conditioning
-limited; two backward-stable solvers differ by ~ eps * cond).
+Tolerances (BASELINE.json north_star): 1e-10 relative on interpolation weights, 1e-8 on surrogate values.
+Weights: asserted at 1e-10 outright on every case with cond < 1e6; on every case (any conditioning) the GPU
+solution must solve the oracle's saddle system with a normwise backward error <= 50 eps; the (two) cases above
+1e-10 are listed with the reason in gpurun_out/parity_report.json and bounded by cond x measured backward error.
 """
 import ctypes
 import json
@@ -91,8 +92,22 @@ def test_gram_matches_golden(ctx, golden, mode):
     REPORT["gram_worst_rel_err_mode%d" % mode] = worst
 
 
+def _backward_error(c, W, Lam):
+    """normwise backward error of [W; Lam] in the ORACLE's saddle system (Rigal-Gaches, Frobenius norms):
+    ||S x - b|| / (||S|| ||x|| + ||b||) -- a conditioning-free measure: <= c * eps for any backward-stable solver."""
+    S = orc.saddle_matrix(c["Phi"], c["Pi"])
+    q = c["Pi"].shape[1]
+    x = np.vstack([W, np.asarray(Lam).reshape(q, W.shape[1])])
+    b = np.vstack([c["Y"].reshape(W.shape[0], -1), np.zeros((q, W.shape[1]))])
+    return float(np.linalg.norm(S @ x - b) / (np.linalg.norm(S) * np.linalg.norm(x) + np.linalg.norm(b)))
+
+
+W_TOL = 1e-10          # BASELINE.json north_star: interpolation weights, relative
+WELL_CONDITIONED = 1e6  # below this condition number the 1e-10 bar is asserted outright (observed <= 1e-12 there)
+
+
 def test_fit_and_eval_match_golden(ctx, golden):
-    rows = []
+    rows, exceeded = [], []
     for c in golden:
         rc, mod = raw_fit(ctx, c["C"], c["Y"], c["kid"], c["a"], c["b"], c["deg"])
         assert rc == 0, (c["name"], rc, ctx.lib.mrbf_last_error(ctx.h))
@@ -101,17 +116,42 @@ def test_fit_and_eval_match_golden(ctx, golden):
         ew = np.abs(mod.weights - c["W"]).max() / max(np.abs(c["W"]).max(), 1e-300)
         ev = np.abs(V - c["V"]).max() / max(1.0, np.abs(c["V"]).max())
         ej = np.abs(J - c["J"]).max() / max(1.0, np.abs(c["J"]).max())
-        rows.append(dict(name=c["name"], path=mod.info["path"], cond=cond, w=ew, v=ev, j=ej, res=mod.info["rel_residual"]))
-        assert ew < max(1e-10, 100 * EPS * cond), (c["name"], ew, cond)
-        assert ev < max(1e-8, 1e-3 * EPS * cond), (c["name"], ev, cond)
-        assert ej < max(1e-8, 1e-1 * EPS * cond), (c["name"], ej, cond)
-        assert mod.info["rel_residual"] < max(1e-11, 10 * EPS * cond), (c["name"], mod.info)
+        under = c["C"].shape[0] < c["Pi"].shape[1]
+        be = _backward_error(c, mod.weights, mod.poly)
+        be_oracle = _backward_error(c, c["W"], c["Lam"])
+        rows.append(dict(name=c["name"], path=mod.info["path"], cond=cond, w=ew, v=ev, j=ej, res=mod.info["rel_residual"],
+                         backward_error=be, backward_error_oracle=be_oracle))
+        # (1) conditioning-free: the GPU solution solves the oracle's system to working precision
+        assert be <= 50 * EPS, (c["name"], be)
+        # (2) the north-star weight tolerance, outright, wherever the problem is well conditioned
+        if cond < WELL_CONDITIONED and not under:
+            assert ew < W_TOL, (c["name"], ew, cond)
+        elif ew >= W_TOL:
+            # ill-conditioned: two backward-stable solutions differ by <= cond * (sum of backward errors) -- standard
+            # perturbation theory, asserted with the MEASURED backward errors instead of a blanket eps * cond window
+            xg, xo = np.vstack([mod.weights, mod.poly]), np.vstack([c["W"], c["Lam"]])
+            ef = np.linalg.norm(xg - xo) / np.linalg.norm(xo)
+            assert ef <= 4 * cond * (be + be_oracle), (c["name"], ef, cond, be, be_oracle)
+            exceeded.append(dict(name=c["name"], weight_err=ew, cond=cond, backward_error=be, why=(
+                "cond %.1e: the oracle's LU and the GPU's projected Cholesky are both backward stable (backward errors %.1e / %.1e); "
+                "their weights differ by <= cond * backward error; values %.1e and Jacobians %.1e still meet 1e-8"
+                % (cond, be_oracle, be, ev, ej))))
+        assert ev < 1e-8, (c["name"], ev, cond)
+        assert ej < 1e-8, (c["name"], ej, cond)
+        assert mod.info["rel_residual"] < 1e-11, (c["name"], mod.info)
         if mod.q:
-            assert mod.info["max_pitw"] < max(1e-10, 100 * EPS * cond) * max(1.0, np.abs(c["W"]).max()), c["name"]
+            assert mod.info["max_pitw"] < 1e3 * EPS * max(1.0, np.abs(c["W"]).max()) * max(1.0, np.abs(c["Pi"]).max()) * c["C"].shape[0], \
+                (c["name"], mod.info["max_pitw"])
+        assert mod.info["fallbacks"] in (0, _lib.FB_LU), (c["name"], mod.info)
         mod.free()
     REPORT["golden"] = rows
+    REPORT["weights_above_1e-10"] = exceeded
     paths = {r["path"] for r in rows}
     assert paths == {1, 2, 3}, paths  # all three solve paths are exercised by the grid
+    # only the two known ill-conditioned cases may exceed 1e-10; BASELINE config C1 with a bounded-conditioning shape meets it outright
+    assert {e["name"] for e in exceeded} <= {"c1_two_parabolas", "mq_beta1p5"}, exceeded
+    c1b = next(r for r in rows if r["name"] == "c1_two_parabolas_shape_2_over_delta")
+    assert c1b["w"] < W_TOL and c1b["cond"] < WELL_CONDITIONED
 
 
 def test_eval_from_golden_coeffs_isolated_from_solve(ctx, golden):
@@ -163,10 +203,21 @@ def test_medium_sizes_against_oracle(ctx, kernel, deg, n, d):
     ew = np.abs(mod.weights - ref.w).max() / np.abs(ref.w).max()
     ev = np.abs(V - ref.values(X)).max() / max(1.0, np.abs(V).max())
     ej = np.abs(J - ref.jacs(X)).max() / max(1.0, np.abs(J).max())
-    REPORT["medium_%s_deg%d_n%d_d%d" % (kernel, deg, n, d)] = dict(path=mod.info["path"], w=ew, v=ev, j=ej,
-                                                                  res=mod.info["rel_residual"], mu=mod.info["mu"])
+    key = "medium_%s_deg%d_n%d_d%d" % (kernel, deg, n, d)
+    REPORT[key] = dict(path=mod.info["path"], w=ew, v=ev, j=ej, res=mod.info["rel_residual"], mu=mod.info["mu"])
     assert ev < 1e-8 and ej < 1e-8, (ev, ej)
-    assert ew < 1e-7, ew  # conditioning-limited; the exact bound is asserted on the golden grid
+    # weights: conditioning-free check -- the GPU weights solve the oracle's saddle system to working precision
+    Phi, Pi = orc.gram(C, kid, a, b, deg)
+    case = dict(Phi=Phi, Pi=Pi, Y=Y)
+    be = _backward_error(case, mod.weights, mod.poly)
+    be_o = _backward_error(case, ref.w, ref.lam)
+    cond = float(np.linalg.cond(orc.saddle_matrix(Phi, Pi)))
+    REPORT[key].update(cond=cond, backward_error=be, backward_error_oracle=be_o)
+    assert be <= 50 * EPS, be
+    xg, xo = np.vstack([mod.weights, mod.poly]), np.vstack([ref.w, ref.lam])
+    assert ew < W_TOL or np.linalg.norm(xg - xo) / np.linalg.norm(xo) <= 4 * cond * (be + be_o), (ew, cond, be, be_o)
+    if cond < WELL_CONDITIONED:
+        assert ew < W_TOL, (ew, cond)
     assert mod.info["rel_residual"] < 1e-10
     mod.free()
 
@@ -241,8 +292,15 @@ def test_error_codes_and_edge_cases(ctx):
     mm.free()
     # exactly singular square system (duplicate site): MRBF_ESINGULAR, like Julia's `\` throwing SingularException
     Cd = np.vstack([C[:10], C[:1]])
-    rc, _ = raw_fit(ctx, Cd, np.vstack([Y[:10], Y[:1]]), 0, 3.0, 0.0, -1)
-    assert rc in (_lib.MRBF_ESINGULAR, 0)
+    # (cubic, no tail -> LU path; two identical rows of the saddle matrix give an exactly zero pivot in partial pivoting)
+    Yd = np.vstack([Y[:10], Y[:1]])
+    rc, md = raw_fit(ctx, Cd, Yd, 0, 3.0, 0.0, -1)
+    if rc != 0:   # exactly zero pivot: the documented error code and message, no model handed out
+        assert rc == _lib.MRBF_ESINGULAR and md is None and b"singular" in ctx.lib.mrbf_last_error(ctx.h)
+    else:         # rounding left a tiny pivot (Julia's `\` does not throw either then): the consistent system must be solved
+        assert md.info["path"] == _lib.PATH_LU and np.isfinite(md.weights).all()
+        assert np.abs(pkg.eval_models_at_sites(md, None, Cd) - Yd).max() < 1e-6 * max(1.0, np.abs(Yd).max())
+        md.free()
     # one site, no tail: the 1 x 1 system
     rc, mod = raw_fit(ctx, C[:1], Y[:1], 4, 1.0, 0.0, -1)
     assert rc == 0 and abs(mod.weights[0, 0] - Y[0, 0]) < 1e-15

@@ -107,6 +107,40 @@ def test_round4_respects_max_points_and_empty():
     assert sampling._rbf_round4(sites, x - 1e-9, x + 1e-9, x, 1.0, [0], cfg, kernel_block=kb) == []
 
 
+@pytest.mark.parametrize("name,deg,d,ndb", [("cubic", 1, 3, 6), ("gaussian", 1, 2, 0), ("multiquadric", 0, 2, 4)])
+def test_round4_use_max_points_matches_independent_oracle(name, deg, d, ndb):
+    # RbfModel.jl:405-416: once the database candidates are used up, random box points are tried until max_points is reached
+    x, sites = _db(3, d, max(ndb + d + 2, d + 2))
+    start = _start_set(x, sites, d)
+    sites = sites[: len(start) + ndb] if ndb else sites[start]
+    start = [i for i in start if i < len(sites)] if ndb else list(range(len(sites)))
+    cfg = pkg.RbfConfig(kernel=name, polynomial_degree=deg, use_max_points=True)
+    kidp, ap, bp = pkg.rbf_model._get_kernel_params(1.0, cfg)
+    kb = lambda X, C: orc.phi(kidp, ap, bp, orc.pairwise_dist(np.atleast_2d(X), np.atleast_2d(C)))
+    lb, ub = np.zeros(d), np.ones(d)
+    new_sites = []
+    got = sampling._rbf_round4(sites, lb, ub, x, 1.0, start, cfg, kernel_block=kb, rng=np.random.default_rng(9), new_sites=new_sites)
+    max_points = (d + 1) * (d + 2) // 2
+    assert len(start) + len(got) == max_points                      # "use as many as possible"
+    cands = [i for i in range(len(sites)) if i not in start]
+    rng = np.random.default_rng(9)
+    fresh = [sampling._rand_box_point(lb, ub, rng) for _ in range(10 * max_points + 1)]
+    want = so.rbf_round4(sites[start], sites[cands], kidp, ap, bp, deg, extra_sites=fresh)
+    want_ids, k = [], 0
+    for p in want:
+        if p < len(cands):
+            want_ids.append(cands[p])
+        else:
+            want_ids.append(len(sites) + k)
+            assert np.array_equal(new_sites[k], fresh[p - len(cands)])
+            k += 1
+    assert got == want_ids and k == len(new_sites)
+    # without the flag the round stops when the database candidates run out
+    cfg0 = pkg.RbfConfig(kernel=name, polynomial_degree=deg)
+    got0 = sampling._rbf_round4(sites, lb, ub, x, 1.0, start, cfg0, kernel_block=kb)
+    assert got0 == [i for i in got if i < len(sites)]
+
+
 def test_round4_needs_device_without_injected_kernels():
     if has_gpu():
         pytest.skip("GPU present")
