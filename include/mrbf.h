@@ -209,6 +209,37 @@ int32_t mrbf_debug_mfma_asm(mrbf_ctx *ctx, int32_t variant, int32_t blocks_per_c
                             double *cycles_per_mfma);
 int32_t mrbf_debug_dgemm(mrbf_ctx *ctx, int32_t m, int32_t n, int32_t k, float *ms, double *tflops);
 
+/* ---- Pascoletti-Serafini descent step with the subproblem solver on the device ----------------------------------------
+ * Replaces, for objectives that share ONE grouped RBF model and carry no modelled constraints, the NLopt runs inside
+ * get_criticality(::PascolettiSerafiniConfig, ...) (src/descent.jl:512-581): compute_local_ideal_point (:404-412, k runs of
+ * _min_component :369-387) when no direction is given, and _ps_optimization (:478-510) with the constraint functions of
+ * :434-447 (chi = [t; x], t in [-1,0], x in [lb_eff, ub_eff], minimise t subject to m_l(x) - m_l(x_n) - t r_l <= 0).
+ * Population state, ranking and breeding live on the device; one batched surrogate sweep evaluates a whole generation of
+ * all runs.  x_n, lb_eff, ub_eff: d; fx_n (true objective values at x_n, used for r = fx_n - ideal) and r_or_null (the direction
+ * of _get_global_dir, :360-368): k, host or device.  Outputs x_trial (d), mx_trial (k), r_out (k, may be NULL).
+ * info.status: MRBF_PS_OK -> omega = |info.tau| (:573-579); MRBF_PS_CRITICAL -> some r_l <= 0 (:546-549): x_trial = x_n,
+ * mx_trial = m(x_n), tau = 0; MRBF_PS_FAILURE -> no feasible point (:571-572), outputs as for CRITICAL. */
+enum { MRBF_PS_OK = 0, MRBF_PS_CRITICAL = 1, MRBF_PS_FAILURE = 2 };
+typedef struct {
+    int32_t max_ideal_evals;  /* per objective; < 0: 500 (d + 1)   (descent.jl:527) */
+    int32_t max_ps_evals;     /* < 0: 500 (d + 1); the caller applies _ps_max_evals' 3/4 split (descent.jl:414-432) */
+    int32_t max_polish_evals; /* 0: no polish (ps_polish_algo = nothing) */
+    int32_t reserved;
+    uint64_t seed;            /* counter-based generator key: same seed, same step */
+    double t0;                /* start value of t, -0.5 in the reference (descent.jl:555) */
+    double xtol_rel;          /* <= 0: 1e-3 (descent.jl:379, :485) */
+} mrbf_ps_options;
+typedef struct {
+    int32_t status;           /* MRBF_PS_* */
+    int32_t generations;      /* batched generations over all runs */
+    int32_t evals_ideal, evals_ps, evals_polish; /* surrogate evaluations spent */
+    float ms_total;           /* hipEvent time of the whole step on the ctx stream */
+    double tau;
+} mrbf_ps_info;
+int32_t mrbf_ps_step(mrbf_ctx *ctx, const mrbf_model *model, const double *x_n, const double *lb_eff, const double *ub_eff,
+                     const double *fx_n, const double *r_or_null, const mrbf_ps_options *opts, double *x_trial, double *mx_trial,
+                     double *r_out, mrbf_ps_info *info);
+
 /* ---- host-side helper of the Pascoletti-Serafini subproblem solver -------------------------------------------------
  * Stochastic ranking of one ISRES generation (Runarsson & Yao): lam sweeps over adjacent individuals, compared by
  * objective f when both are feasible (phi == 0) or with probability pf, else by constraint violation phi; stops after a

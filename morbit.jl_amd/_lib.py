@@ -39,6 +39,22 @@ class EvalInfo(ctypes.Structure):
         return {f: getattr(self, f) for f, _ in self._fields_}
 
 
+class PsOptions(ctypes.Structure):
+    _fields_ = [("max_ideal_evals", ctypes.c_int32), ("max_ps_evals", ctypes.c_int32), ("max_polish_evals", ctypes.c_int32),
+                ("reserved", ctypes.c_int32), ("seed", ctypes.c_uint64), ("t0", ctypes.c_double), ("xtol_rel", ctypes.c_double)]
+
+
+class PsInfo(ctypes.Structure):
+    _fields_ = [("status", ctypes.c_int32), ("generations", ctypes.c_int32), ("evals_ideal", ctypes.c_int32),
+                ("evals_ps", ctypes.c_int32), ("evals_polish", ctypes.c_int32), ("ms_total", ctypes.c_float), ("tau", ctypes.c_double)]
+
+    def asdict(self):
+        return {f: getattr(self, f) for f, _ in self._fields_}
+
+
+PS_OK, PS_CRITICAL, PS_FAILURE = 0, 1, 2
+
+
 class Problem(ctypes.Structure):
     _fields_ = [("n", ctypes.c_int64), ("m", ctypes.c_int64), ("d", ctypes.c_int32), ("k", ctypes.c_int32),
                 ("kernel_id", ctypes.c_int32), ("poly_deg", ctypes.c_int32), ("a", ctypes.c_double), ("b", ctypes.c_double),
@@ -86,6 +102,8 @@ SIGNATURES = {
     "mrbf_debug_mfma_asm": (ctypes.c_int32, [c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_fp, c_dp, c_dp]),
     "mrbf_debug_dgemm": (ctypes.c_int32, [c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_fp, c_dp]),
     "mrbf_stochastic_rank": (ctypes.c_int32, [ctypes.c_int32, c_vp, c_vp, c_vp, ctypes.c_double, c_vp]),
+    "mrbf_ps_step": (ctypes.c_int32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(PsOptions), c_vp, c_vp, c_vp,
+                                      ctypes.POINTER(PsInfo)]),
 }
 
 _LIB = None

@@ -43,6 +43,8 @@ def _single_model(sc):
     objs = sc.lists["objective"]
     if not objs:
         return None
+    if any(isinstance(s, sg.CompositeSurrogate) for s in objs):
+        return None  # the outer functions are evaluated on the host: general batched route
     inner = objs[0].model if isinstance(objs[0], sg.RefSurrogate) else objs[0]
     idx = []
     for s in objs:

@@ -253,6 +253,37 @@ def _polish(tau, x_min, lb, ub, eval_objectives, eval_jacobians, mx, r, max_eval
     return t, x, "SUCCESS"
 
 
+def get_criticality_device(desc_cfg, model, x, x_n, fx_n, lb_eff, ub_eff, seed=0, stats=None):
+    """descent.jl:512-581 with the whole subproblem solver on the device (`mrbf_ps_step`): for objectives that are the outputs
+    of ONE grouped RbfModel `model` and no modelled constraints.  Same returns as `get_criticality`."""
+    import ctypes
+
+    from . import _lib
+
+    ctx = model.ctx
+    x, x_n = np.ascontiguousarray(x, dtype=np.float64), np.ascontiguousarray(x_n, dtype=np.float64)
+    d, k = x_n.size, model.num_outputs
+    lb, ub = np.ascontiguousarray(lb_eff, dtype=np.float64), np.ascontiguousarray(ub_eff, dtype=np.float64)
+    fx = np.ascontiguousarray(fx_n, dtype=np.float64)
+    r = _get_global_dir(desc_cfg, fx)
+    r = None if r is None else np.ascontiguousarray(r, dtype=np.float64)
+    g_evals, l_evals = _ps_max_evals(desc_cfg, d)
+    opts = _lib.PsOptions(max_ideal_evals=int(desc_cfg.max_ideal_point_problem_evals), max_ps_evals=int(g_evals),
+                          max_polish_evals=int(l_evals), reserved=0, seed=int(seed) & (2 ** 64 - 1), t0=-0.5, xtol_rel=1e-3)
+    info = _lib.PsInfo()
+    xt, mt, r_out = np.empty(d), np.empty(k), np.empty(k)
+    ctx.check(ctx.lib.mrbf_ps_step(ctx.h, model.model, _lib.as_ptr(x_n), _lib.as_ptr(lb), _lib.as_ptr(ub), _lib.as_ptr(fx), _lib.as_ptr(r),
+                                   ctypes.byref(opts), _lib.as_ptr(xt), _lib.as_ptr(mt), _lib.as_ptr(r_out), ctypes.byref(info)))
+    if stats is not None:
+        stats.update(info.asdict())
+        stats["r"] = r_out.copy()
+    if info.status == _lib.PS_CRITICAL:
+        return 0, x_n.copy(), mt, 0          # descent.jl:546-549
+    if info.status == _lib.PS_FAILURE:
+        return 0, x.copy(), mt, 0            # descent.jl:571-572
+    return abs(float(info.tau)), (xt, mt, float(np.linalg.norm(x - xt, ord=np.inf)))
+
+
 def get_criticality(desc_cfg, x, x_n, fx_n, lb_eff, ub_eff, eval_objectives: Callable, eval_jacobians: Optional[Callable] = None,
                     eval_constraints: Optional[Callable] = None, rng=None, stats=None):
     """descent.jl:512-581.  `x` / `x_n`: scaled iterate and the point the step starts from (the same unless a normal step was taken);

@@ -1,6 +1,6 @@
 """Host-side mirror of the surrogate dispatch layer the descent code calls.
 
-Mirrors /root/reference/src/AbstractSurrogateInterface.jl (RefSurrogate :122-134, :159-229;
+Mirrors /root/reference/src/AbstractSurrogateInterface.jl (RefSurrogate :122-134, CompositeSurrogate :136-154, :159-229;
 _get_optim_handle :98-106) and /root/reference/src/SurrogateContainer.jl (eval / Jacobian dispatch
 :220-269) for RBF models, and adds the batched `..._at_scaled_sites` twins.
 Unlike the reference, the k objectives that share one grouped RbfModel cost ONE device sweep, not k.
@@ -23,7 +23,56 @@ class RefSurrogate:
         return len(self.output_indices)
 
 
+class IdentityScaler:
+    """stand-in for an AbstractVarScaler that leaves the variables alone (untransform = identity, unit Jacobian)"""
+
+    def untransform(self, x_scaled):
+        return np.asarray(x_scaled, dtype=np.float64)
+
+    def jacobian_of_unscaling(self, n_vars=None):
+        return None  # identity
+
+
+class CompositeSurrogate:
+    """CompositeSurrogate(model_ref, outer_ref, inner_output_indices) -- AbstractSurrogateInterface.jl:136-154: models
+    f(x) = phi([T(x); g(x)]) with g the selected outputs of the (grouped) inner surrogate, T the affine unscaling of x and phi
+    an outer vector function that is evaluated exactly.  `outer` mirrors the two calls the reference makes on its
+    AbstractVecFun: `outer.eval(xi)` (eval_vfun, :189-191) and `outer.jacobian(xi)` (_get_jacobian, :226) with xi = [t; g]."""
+
+    def __init__(self, model, outer, inner_output_indices, num_outputs=None, nl_index=None):
+        self.model = model
+        self.outer = outer
+        self.inner_output_indices = list(inner_output_indices)
+        self.nl_index = nl_index
+        self._num_outputs = num_outputs
+
+    @property
+    def num_outputs(self):
+        if self._num_outputs is None:
+            self._num_outputs = int(getattr(self.outer, "num_outputs"))
+        return self._num_outputs
+
+    # the two host-side pieces of the chain rule, shared by the single-site API and the batched twins
+    def _xi(self, scal, x_scaled, g):
+        t = (scal or IdentityScaler()).untransform(x_scaled)
+        return np.concatenate([np.asarray(t, dtype=np.float64), np.asarray(g, dtype=np.float64)])  # _eval_inner, :175-188
+
+    def _chain(self, scal, x_scaled, xi, Dg, rows=None):
+        """_composite_jac (:193-207): Df = D_t phi J_unscale + D_g phi Dg"""
+        Dphi = np.atleast_2d(np.asarray(self.outer.jacobian(xi), dtype=np.float64))
+        if rows is not None:
+            Dphi = Dphi[rows]
+        n = len(x_scaled)
+        J = (scal or IdentityScaler()).jacobian_of_unscaling()
+        Dt = Dphi[:, :n] if J is None else Dphi[:, :n] @ np.asarray(J, dtype=np.float64)
+        return Dt + Dphi[:, n:] @ Dg
+
+
 def eval_models(sur, scal, x_hat, ell=None):
+    if isinstance(sur, CompositeSurrogate):  # AbstractSurrogateInterface.jl:189-191
+        g = rm.eval_models(sur.model, scal, x_hat, sur.inner_output_indices)
+        v = np.asarray(sur.outer.eval(sur._xi(scal, x_hat, g)), dtype=np.float64)
+        return v if ell is None else v[ell]
     if isinstance(sur, RefSurrogate):  # AbstractSurrogateInterface.jl:159-164
         idx = sur.output_indices if ell is None else np.asarray(sur.output_indices)[ell]
         return rm.eval_models(sur.model, scal, x_hat, idx)
@@ -31,12 +80,18 @@ def eval_models(sur, scal, x_hat, ell=None):
 
 
 def get_gradient(sur, scal, x_hat, ell):
+    if isinstance(sur, CompositeSurrogate):  # AbstractSurrogateInterface.jl:209-215
+        return get_jacobian(sur, scal, x_hat, [ell])[0]
     if isinstance(sur, RefSurrogate):
         return rm.get_gradient(sur.model, scal, x_hat, sur.output_indices[ell])
     return rm.get_gradient(sur, scal, x_hat, ell)
 
 
 def get_jacobian(sur, scal, x_hat, rows=None):
+    if isinstance(sur, CompositeSurrogate):  # AbstractSurrogateInterface.jl:224-229: one inner sweep gives g and Dg
+        V, Jm = sur.model.eval_sites(np.asarray(x_hat, dtype=np.float64)[None, :], want_values=True, want_jac=True)
+        g, Dg = V[0][sur.inner_output_indices], Jm[0][sur.inner_output_indices]
+        return sur._chain(scal, x_hat, sur._xi(scal, x_hat, g), Dg, rows)
     if isinstance(sur, RefSurrogate):  # AbstractSurrogateInterface.jl:217-219
         idx = sur.output_indices if rows is None else list(np.asarray(sur.output_indices)[rows])
         return rm.get_jacobian(sur.model, scal, x_hat, idx)
@@ -66,7 +121,7 @@ class SurrogateContainer:
 
     def fully_linear(self, kind=None):
         kinds = [kind] if kind else list(self.lists)
-        return all(rm.fully_linear(s.model if isinstance(s, RefSurrogate) else s) for kd in kinds for s in self.lists[kd])
+        return all(rm.fully_linear(s.model if isinstance(s, (RefSurrogate, CompositeSurrogate)) else s) for kd in kinds for s in self.lists[kd])
 
     # ---- single site (reference API)
     def _eval_at_site(self, kind, scal, x_scaled):
@@ -81,13 +136,13 @@ class SurrogateContainer:
             return np.empty((0, len(x_scaled)), dtype=_MIN_PRECISION)  # SurrogateContainer.jl:259
         return self._jac_at_sites(kind, scal, np.asarray(x_scaled, dtype=np.float64)[None, :])[0]
 
-    # ---- batched twins: one device sweep per distinct inner model
+    # ---- batched twins: one device sweep per distinct inner model (RefSurrogates select columns, CompositeSurrogates apply their
+    #      outer function / chain rule row by row on the host: the outer function is exact and cheap, the sweep is the cost)
     def _grouped(self, kind):
         groups = {}
         for pos, s in enumerate(self.lists[kind]):
-            inner = s.model if isinstance(s, RefSurrogate) else s
-            idx = s.output_indices if isinstance(s, RefSurrogate) else list(range(inner.num_outputs))
-            groups.setdefault(id(inner), (inner, []))[1].append((pos, idx))
+            inner = s.model if isinstance(s, (RefSurrogate, CompositeSurrogate)) else s
+            groups.setdefault(id(inner), (inner, []))[1].append((pos, s))
         return groups.values()
 
     def _layout(self, kind):
@@ -100,8 +155,13 @@ class SurrogateContainer:
         out = np.empty((X.shape[0], offs[-1]))
         for inner, members in self._grouped(kind):
             V = rm.eval_models_at_sites(inner, scal, X)
-            for pos, idx in members:
-                out[:, offs[pos]:offs[pos + 1]] = V[:, idx]
+            for pos, s in members:
+                if isinstance(s, CompositeSurrogate):
+                    for p in range(X.shape[0]):
+                        out[p, offs[pos]:offs[pos + 1]] = s.outer.eval(s._xi(scal, X[p], V[p, s.inner_output_indices]))
+                else:
+                    idx = s.output_indices if isinstance(s, RefSurrogate) else list(range(inner.num_outputs))
+                    out[:, offs[pos]:offs[pos + 1]] = V[:, idx]
         return out
 
     def _jac_at_sites(self, kind, scal, X):
@@ -109,9 +169,17 @@ class SurrogateContainer:
         offs = self._layout(kind)
         out = np.empty((X.shape[0], offs[-1], X.shape[1]))
         for inner, members in self._grouped(kind):
-            J = rm.get_jacobians_at_sites(inner, scal, X)
-            for pos, idx in members:
-                out[:, offs[pos]:offs[pos + 1], :] = J[:, idx, :]
+            need_vals = any(isinstance(s, CompositeSurrogate) for _, s in members)
+            V, J = inner.eval_sites(X, want_values=need_vals, want_jac=True)
+            J = np.ascontiguousarray(J)
+            for pos, s in members:
+                if isinstance(s, CompositeSurrogate):
+                    ii = s.inner_output_indices
+                    for p in range(X.shape[0]):
+                        out[p, offs[pos]:offs[pos + 1], :] = s._chain(scal, X[p], s._xi(scal, X[p], V[p, ii]), J[p][ii])
+                else:
+                    idx = s.output_indices if isinstance(s, RefSurrogate) else list(range(inner.num_outputs))
+                    out[:, offs[pos]:offs[pos + 1], :] = J[:, idx, :]
         return out
 
     def _optim_handles(self, kind, scal):

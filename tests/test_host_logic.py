@@ -115,3 +115,60 @@ def test_backtrack_general_route_matches_reference_loop(two_models):
             assert i == ri and np.array_equal(xp, rxp) and np.array_equal(step, rstep) and np.allclose(mxp, rmxp)
     assert descent._armijo_condition(True, np.array([1.0, 1.0]), np.array([0.5, 1.0]), 1.0, 1.0, 1e-6) is False
     assert descent._armijo_condition(False, np.array([1.0, 2.0]), np.array([1.5, 1.0]), 1.0, 1.0, 1e-6) is True
+
+
+class _Outer:
+    """phi(xi) = [xi[0] * g0 + g1^2, sin(g0) + sum(t)] on xi = [t (3); g (2)] -- an exactly evaluated outer function"""
+    num_outputs = 2
+
+    def eval(self, xi):
+        t, g = xi[:3], xi[3:]
+        return np.array([t[0] * g[0] + g[1] ** 2, np.sin(g[0]) + t.sum()])
+
+    def jacobian(self, xi):
+        t, g = xi[:3], xi[3:]
+        return np.array([[g[0], 0.0, 0.0, t[0], 2.0 * g[1]], [1.0, 1.0, 1.0, np.cos(g[0]), 0.0]])
+
+
+class _Scaler:
+    """affine unscaling t = lb + w * x (AbstractVarScaler surface used by CompositeSurrogate)"""
+    lb, w = np.array([1.0, -2.0, 0.5]), np.array([2.0, 3.0, 0.25])
+
+    def untransform(self, x):
+        return self.lb + self.w * np.asarray(x)
+
+    def jacobian_of_unscaling(self):
+        return np.diag(self.w)
+
+
+def test_composite_surrogate_chain_rule_and_batched_twins(two_models):
+    # AbstractSurrogateInterface.jl:136-154, :175-229: f(x) = phi([T(x); g(x)]),  Df = D_t phi J + D_g phi Dg
+    m3, m1 = two_models
+    comp = surrogates.CompositeSurrogate(m3, _Outer(), [2, 0])
+    scal = _Scaler()
+    x = np.array([0.3, 0.5, 0.7])
+    g = m3.ref.value(x)[[2, 0]]
+    xi = np.concatenate([scal.untransform(x), g])
+    assert np.allclose(surrogates.eval_models(comp, scal, x), _Outer().eval(xi))
+    J = surrogates.get_jacobian(comp, scal, x)
+    h = 1e-6
+    fd = np.stack([(surrogates.eval_models(comp, scal, x + h * e) - surrogates.eval_models(comp, scal, x - h * e)) / (2 * h) for e in np.eye(3)], axis=1)
+    assert np.allclose(J, fd, atol=1e-6)
+    assert np.array_equal(surrogates.get_gradient(comp, scal, x, 1), J[1]) and np.array_equal(surrogates.get_jacobian(comp, scal, x, [1]), J[1:])
+    # scal = None: identity unscaling
+    assert np.allclose(surrogates.eval_models(comp, None, x), _Outer().eval(np.concatenate([x, g])))
+    # in a container next to a RefSurrogate of the same grouped model: ONE sweep for values, one for Jacobians
+    sc = surrogates.SurrogateContainer(objectives=[surrogates.RefSurrogate(m3, [1]), comp], nl_ineq_constraints=[comp])
+    X = np.random.default_rng(2).random((4, 3))
+    before = m3.sweeps
+    V = surrogates.eval_container_objectives_at_scaled_sites(sc, scal, X)
+    assert m3.sweeps == before + 1 and V.shape == (4, 3)
+    for p in range(4):
+        assert np.allclose(V[p, 1:], surrogates.eval_models(comp, scal, X[p])) and np.isclose(V[p, 0], m3.ref.value(X[p])[1])
+    JJ = surrogates.eval_container_objectives_jacobian_at_scaled_sites(sc, scal, X)
+    for p in range(4):
+        assert np.allclose(JJ[p, 1:], surrogates.get_jacobian(comp, scal, X[p])) and np.allclose(JJ[p, 0], m3.ref.jac(X[p])[1])
+    assert np.allclose(surrogates.eval_container_nl_ineq_constraints_at_scaled_site(sc, scal, x), surrogates.eval_models(comp, scal, x))
+    assert sc.fully_linear()
+    # the backtracking twin takes the general batched route for composites
+    assert descent._single_model(sc) is None

@@ -146,3 +146,75 @@ def test_ps_step_on_device_container():
     # one surrogate sweep per generation: the number of launches is ~ evaluations / population, not evaluations
     assert len(launches) < 60 and sum(launches) > 2500
     mod.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,n,given_dir", [(4, 200, False), (12, 512, False), (6, 300, True)])
+def test_ps_step_with_the_solver_on_the_device(d, n, given_dir):
+    """mrbf_ps_step: population state, ranking and breeding on the device.  Asserted: the contract of get_criticality
+    (descent.jl:512-581) -- budgets, feasibility of the returned point for the subproblem, omega = |tau|, trial point inside
+    the box, model values of the trial point -- and that the device solver is at least as good as the host-loop mirror."""
+    rng = np.random.default_rng(4 + d)
+    C = rng.random((n, d))
+    Y = np.stack([np.sum((C - 0.3) ** 2, axis=1), np.sum((C - 0.7) ** 2, axis=1) + 0.1 * np.sin(5 * C[:, 0])], axis=1)
+    mod = pkg.update_model(pkg.RbfConfig(kernel="cubic"), C, Y)
+    ev = lambda X: pkg.eval_models_at_sites(mod, None, X)
+    x = np.full(d, 0.5)
+    x[1], x[3] = 0.85, 0.2
+    lb, ub = x - 0.12, x + 0.12
+    fx = ev(x[None, :])[0]
+    cfg = ps.PascolettiSerafiniConfig(reference_direction=[1.0, 0.5]) if given_dir else ps.PascolettiSerafiniConfig()
+    stats = {}
+    omega, (xt, mt, sl) = ps.get_criticality_device(cfg, mod, x, x, fx, lb, ub, seed=11, stats=stats)
+    r = stats["r"]
+    assert stats["status"] == 0 and omega == abs(stats["tau"]) and omega > 0
+    assert np.all(xt >= lb) and np.all(xt <= ub) and abs(sl - np.abs(x - xt).max()) < 1e-15
+    assert np.allclose(mt, ev(xt[None, :])[0], rtol=0, atol=1e-12)
+    # feasible for the subproblem: m_l(x_trial) - m_l(x_n) - tau r_l <= 0 (descent.jl:443), so every objective improves by >= omega r_l
+    assert np.all(mt - fx + omega * r <= 1e-9 * max(1.0, np.abs(fx).max()))
+    # budgets (descent.jl:416, :527): never more evaluations than allowed; one batched sweep per generation
+    assert stats["evals_ps"] <= 500 * (d + 1)
+    if given_dir:
+        assert stats["evals_ideal"] == 0 and np.array_equal(r, [1.0, 0.5])
+    else:
+        assert 0 < stats["evals_ideal"] <= 2 * 500 * (d + 1) and np.all(r > 0)
+    assert stats["generations"] <= (stats["evals_ideal"] + stats["evals_ps"]) // (20 * (d + 1)) + 4
+    # same seed, same step (counter-based generator); another seed, another trajectory but the same contract
+    stats2 = {}
+    omega2, (xt2, _, _) = ps.get_criticality_device(cfg, mod, x, x, fx, lb, ub, seed=11, stats=stats2)
+    assert omega2 == omega and np.array_equal(xt2, xt)
+    # at least as good as the host-loop mirror on the same problem with the same direction (both are stochastic: 20 % slack)
+    cfg_r = ps.PascolettiSerafiniConfig(reference_direction=list(r))
+    omega_h, _ = ps.get_criticality(cfg_r, x, x, fx, lb, ub, ev, rng=np.random.default_rng(3))[:2]
+    omega_d, _ = ps.get_criticality_device(cfg_r, mod, x, x, fx, lb, ub, seed=5)[:2]
+    assert omega_d >= 0.8 * omega_h, (omega_d, omega_h)
+    print("PS step d=%d: %.2f ms on the device, %d evaluations in %d generations, omega %.4f (host mirror %.4f)"
+          % (d, stats["ms_total"], stats["evals_ideal"] + stats["evals_ps"], stats["generations"], omega_d, omega_h))
+    mod.free()
+
+
+@pytest.mark.gpu
+def test_ps_step_device_critical_and_argument_errors():
+    rng = np.random.default_rng(1)
+    C = rng.random((150, 3))
+    Y = np.sum((C - 0.5) ** 2, axis=1, keepdims=True)       # one objective, minimiser inside the box
+    mod = pkg.update_model(pkg.RbfConfig(kernel="cubic"), C, Y)
+    ev = lambda X: pkg.eval_models_at_sites(mod, None, X)
+    # the model's own minimiser over the box is (numerically) x itself when f(x_n) is set to the model minimum: r <= 0 -> critical
+    x = np.full(3, 0.5)
+    fx = ev(x[None, :])[0] - 1.0                             # pretend the true value is below every model value in the box
+    out = ps.get_criticality_device(ps.PascolettiSerafiniConfig(), mod, x, x, fx, x - 0.05, x + 0.05, seed=1)
+    assert out[0] == 0 and np.array_equal(out[1], x) and out[3] == 0 and np.allclose(out[2], ev(x[None, :])[0], atol=1e-13)
+    from morbit.jl_amd import _lib
+    import ctypes
+    ctx = mod.ctx
+    opts, info = _lib.PsOptions(-1, -1, 0, 0, 1, -0.5, 1e-3), _lib.PsInfo()
+    buf = np.zeros(3)
+    args = lambda **kw: [kw.get("x", _lib.as_ptr(x)), kw.get("lb", _lib.as_ptr(x - 0.1)), kw.get("ub", _lib.as_ptr(x + 0.1)), _lib.as_ptr(fx), None]
+    f = ctx.lib.mrbf_ps_step
+    assert f(ctx.h, None, *args(), ctypes.byref(opts), _lib.as_ptr(buf), _lib.as_ptr(buf), None, ctypes.byref(info)) == -2
+    assert f(ctx.h, mod.model, *args(x=None), ctypes.byref(opts), _lib.as_ptr(buf), _lib.as_ptr(buf), None, ctypes.byref(info)) == -3
+    assert f(ctx.h, mod.model, *args(lb=_lib.as_ptr(x + 1.0)), ctypes.byref(opts), _lib.as_ptr(buf), _lib.as_ptr(buf), None, ctypes.byref(info)) == -4
+    bad = _lib.PsOptions(-1, -1, 0, 0, 1, 0.5, 1e-3)
+    assert f(ctx.h, mod.model, *args(), ctypes.byref(bad), _lib.as_ptr(buf), _lib.as_ptr(buf), None, ctypes.byref(info)) == -8
+    mod.free()

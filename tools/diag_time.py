@@ -1,5 +1,5 @@
 import sys, ctypes, numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import morbit, importlib
 pkg = importlib.import_module("morbit.jl_amd")
 from morbit.jl_amd import _lib

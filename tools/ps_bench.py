@@ -2,7 +2,7 @@
 (what the reference's NLopt callbacks amount to), C4-shaped surrogate (d = 12, n = 512 centres, k = 2)."""
 import sys, time
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import morbit, importlib
 pkg = importlib.import_module("morbit.jl_amd")
 ps = importlib.import_module("morbit.jl_amd.pascoletti_serafini")
@@ -35,3 +35,12 @@ for j in range(m):
     ev(x[None, :] + 1e-3 * j)
 t1 = time.perf_counter() - t0
 print(f"one-point calls: {m / t1:.0f} evaluations/s -> batched / one-point = {calls['pts'] / wall / (m / t1):.1f}x")
+# the same step with the subproblem solver on the device (mrbf_ps_step): population state, ranking and breeding in device memory
+for rep in range(3):
+    st = {}
+    t0 = time.perf_counter()
+    om = ps.get_criticality_device(ps.PascolettiSerafiniConfig(), mod, x, x, fx, lb, ub, seed=rep, stats=st)[0]
+    wall_d = time.perf_counter() - t0
+    ne = st["evals_ideal"] + st["evals_ps"]
+    print(f"device solver: omega {om:.4f}; {ne} evaluations in {st['generations']} generations; wall {wall_d * 1e3:.2f} ms (device events {st['ms_total']:.2f} ms) "
+          f"-> {ne / wall_d:.0f} evaluations/s")
