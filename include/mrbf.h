@@ -65,7 +65,8 @@ enum {
     MRBF_PATH_CHOL = 1,      /* Phi SPD, no tail: potrf(Phi) */
     MRBF_PATH_PROJ_CHOL = 2, /* tail + conditionally p.d. kernel: potrf(P Phi P + mu Q1 Q1') on null(Pi') */
     MRBF_PATH_LU = 3,        /* indefinite saddle system [Phi Pi; Pi' 0]: getrf */
-    MRBF_PATH_MINNORM = 4    /* n < q (fewer sites than tail terms): minimum-norm solution by SVD */
+    MRBF_PATH_MINNORM = 4,   /* n < q (fewer sites than tail terms): minimum-norm solution by SVD */
+    MRBF_PATH_ROUND4 = 5     /* mrbf_fit_from_round4: two triangular solves with the factor the site selection left behind */
 };
 
 /* mrbf_set_option keys */
@@ -165,6 +166,26 @@ int32_t mrbf_eval(mrbf_ctx *ctx, const mrbf_model *model, int64_t m, const doubl
 int32_t mrbf_backtrack(mrbf_ctx *ctx, const mrbf_model *model, const double *x, const double *dir, double step0,
                        double omega, int32_t strict, double const_rhs, double shrink, double min_stepsize,
                        int32_t max_loops, double *x_plus, double *mx_plus, double *step, int32_t *n_loops);
+
+/* ---- round 4 of the training-site selection on the device, with factor reuse -------------------------------------------
+ * mrbf_round4 replaces _rbf_round4 (src/models/RbfModel.jl:352-499): start_sites (n0 x d, the sites found so far -- centre and
+ * rounds 1-3 -- which must carry the polynomial tail: n0 >= q, full rank) and cand_sites (mc x d, the database candidates in
+ * database order; with use_max_points the caller appends the random box points of :405-416) -> positions (into cand_sites) of
+ * the accepted sites in acceptance order.  Acceptance test as in the reference: tau^2 > (theta_pivot_cholesky^2)^2 (:370, :452),
+ * at most max_points sites in total (<= 0: (d+1)(d+2)/2, :356).  The kernel vectors of ALL candidates, the reference's
+ * kernels(xi) / get_matrices calls (:374, :421), are three batched launches; the selection is a left-looking Cholesky
+ * factorisation that skips the rejected columns (round4.hip).  *state (may be NULL) keeps the factors.
+ * mrbf_fit_from_round4: the model on (start sites, accepted sites) -- values ((n0 + n_accepted) x k row-major, in that order)
+ * -- from the kept factor instead of a new factorisation (the reference's TODO at RbfModel.jl:657-660); needs n0 == q
+ * (returns -2 otherwise: use mrbf_fit).  info.path = MRBF_PATH_ROUND4. */
+typedef struct mrbf_round4_state mrbf_round4_state;
+int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const double *start_sites, int64_t mc, const double *cand_sites,
+                    int32_t kernel_id, double a, double b, int32_t poly_deg, int32_t max_points, double theta_pivot_cholesky,
+                    int32_t *accepted_out, int32_t *n_accepted, mrbf_round4_state **state);
+int32_t mrbf_fit_from_round4(mrbf_ctx *ctx, const mrbf_round4_state *state, int32_t k, const double *values, mrbf_model **model,
+                             double *weights_out, double *poly_out, mrbf_fit_info *info);
+int32_t mrbf_round4_sites(const mrbf_round4_state *state, int64_t *n0, int64_t *n_candidates, int32_t *n_accepted);
+int32_t mrbf_free_round4(mrbf_ctx *ctx, mrbf_round4_state *state);
 
 int32_t mrbf_model_dims(const mrbf_model *model, int64_t *n, int32_t *d, int32_t *k, int32_t *q);
 int32_t mrbf_free_model(mrbf_ctx *ctx, mrbf_model *model);

@@ -14,7 +14,7 @@ c_vp = ctypes.c_void_p
 
 # error codes (mrbf.h)
 MRBF_OK, MRBF_ENOTPD, MRBF_ESINGULAR, MRBF_EHIP, MRBF_EBLAS, MRBF_ENOMEM, MRBF_ENODEVICE, MRBF_ENCCL = range(8)
-PATH_CHOL, PATH_PROJ_CHOL, PATH_LU, PATH_MINNORM = 1, 2, 3, 4
+PATH_CHOL, PATH_PROJ_CHOL, PATH_LU, PATH_MINNORM, PATH_ROUND4 = 1, 2, 3, 4, 5
 OPT_GRAM_MODE, OPT_RESIDUAL, OPT_FORCE_PATH, OPT_CHOL_IMPL, OPT_EVAL_IMPL, OPT_TIMING, OPT_DIAG_IMPL, OPT_CHOL_WINDOW = 1, 2, 3, 4, 5, 6, 7, 8
 OPT_SPIN_MS, OPT_DEBUG_FAULT = 9, 10
 FB_CHOL_HOST_DRIVEN, FB_BACKSOLVE_BLOCKED, FB_LU = 1, 2, 4
@@ -91,6 +91,11 @@ SIGNATURES = {
     "mrbf_backtrack": (ctypes.c_int32, [c_vp, c_vp, c_vp, c_vp, ctypes.c_double, ctypes.c_double, ctypes.c_int32,
                                         ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int32, c_vp, c_vp,
                                         c_vp, c_ip]),
+    "mrbf_round4": (ctypes.c_int32, [c_vp, ctypes.c_int64, ctypes.c_int32, c_vp, ctypes.c_int64, c_vp, ctypes.c_int32, ctypes.c_double,
+                                     ctypes.c_double, ctypes.c_int32, ctypes.c_int32, ctypes.c_double, c_vp, c_ip, ctypes.POINTER(c_vp)]),
+    "mrbf_fit_from_round4": (ctypes.c_int32, [c_vp, c_vp, ctypes.c_int32, c_vp, ctypes.POINTER(c_vp), c_vp, c_vp, ctypes.POINTER(FitInfo)]),
+    "mrbf_round4_sites": (ctypes.c_int32, [c_vp, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), c_ip]),
+    "mrbf_free_round4": (ctypes.c_int32, [c_vp, c_vp]),
     "mrbf_model_dims": (ctypes.c_int32, [c_vp, ctypes.POINTER(ctypes.c_int64), c_ip, c_ip, c_ip]),
     "mrbf_free_model": (ctypes.c_int32, [c_vp, c_vp]),
     "mrbf_batch_run": (ctypes.c_int32, [ctypes.c_int32, c_ip, ctypes.c_int64, ctypes.POINTER(Problem),

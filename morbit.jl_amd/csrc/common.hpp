@@ -141,5 +141,6 @@ int fit_model(mrbf_ctx *ctx, mrbf_model *M, const double *Ydev, mrbf_fit_info *i
 int build_model_shell(mrbf_ctx *ctx, int64_t n, int d, int k, const double *Cdev, int kid, double a, double b, int deg,
                       mrbf_model **out);
 void destroy_model(mrbf_ctx *ctx, mrbf_model *M);
+int fit_check(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info *info);
 
 }  // namespace mrbf

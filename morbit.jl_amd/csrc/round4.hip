@@ -1,0 +1,432 @@
+// Round 4 of the training-site selection on the device, with factor reuse for the fit -- replaces _rbf_round4
+// (/root/reference/src/models/RbfModel.jl:352-499, Givens helper src/utilities.jl:437-448) and, when the training set is exactly
+// (start set + round-4 sites), the dense solve inside RBF.RBFInterpolationModel (RbfModel.jl:759-763) -- the reference's own TODO
+// at RbfModel.jl:657-660.
+//
+// The reference tests candidate xi by  tau^2 = sigma - ||L^-1 v||^2 > (theta_pivot_cholesky^2)^2,  the last pivot of the Cholesky
+// factorisation of Z' Phi Z when xi's null-space direction is appended to Z (Z empty at the start, RbfModel.jl:391), and keeps
+// Q (by Givens rotations), Z, L, L^-1 and Phi up to date by re-concatenating dense matrices per accepted site.  The same
+// quantity without Q, R, Z:  the null-space directions added this round are  w(v) = [-Pi0 G0^-1 P' v ; v]  (G0 = Pi0' Pi0, P the
+// polynomial rows of the accepted sites), so with the kernel
+//     kappa(xi, eta) = phi(xi, eta) - lam(xi)' phi(X0, eta) - phi(xi, X0) lam(eta) + lam(xi)' Phi00 lam(eta),   lam(xi) = Pi0 G0^-1 pi(xi)
+// one has  w' Phi w = v' K v  and  w' w = v' H v,  H = I + P G0^-1 P',  hence
+//     tau^2(xi | accepted) = s_K(xi) / s_H(xi),
+// the ratio of the running Cholesky pivots of K = kappa(candidates, candidates) and of H when xi joins the accepted set.  That
+// makes round 4 a left-looking Cholesky factorisation of K in candidate order that SKIPS the columns whose pivot ratio fails the
+// test: one GEMM chain builds K for all candidates at once, one kernel walks the candidates (s_H from a q x q matrix updated
+// by Sherman-Morrison), and the factor of the accepted block is exactly what the fit needs:
+//     K_acc v = Y_acc - Lam_acc Y_0,   w_0 = -Lam_acc' v,   Pi0 lambda = Y_0 - Phi00 w_0 - Phi0a v        (start set unisolvent: N0 = q)
+// so the fit costs two triangular solves instead of an n^3 / 3 factorisation.  Checked against an independent from-scratch
+// restatement (oracle/sampling_oracle.py) in tests/test_sampling.py.
+#include "radial.hpp"
+
+namespace mrbf {
+
+int launch_cross_gram(mrbf_ctx *ctx, const double *X, int64_t m, const double *C, int64_t n, int d, const KP &kp, double *K);
+int launch_poly_matrix(mrbf_ctx *ctx, const double *C, int64_t n, int d, int q, double *Pi, int64_t ldpi);
+int build_model_shell(mrbf_ctx *ctx, int64_t n, int d, int k, const double *Cdev, int kid, double a, double b, int deg, mrbf_model **out);
+void destroy_model(mrbf_ctx *ctx, mrbf_model *M);
+int fit_check(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info *info);
+
+}  // namespace mrbf
+
+struct mrbf_round4_state {
+    int64_t n0 = 0, mc = 0;
+    int d = 0, q = 0, deg = -1, kid = 0, nacc = 0, maxacc = 0;
+    double a = 0, b = 0;
+    void *block = nullptr;  // one device allocation carved into the arrays below
+    double *C0 = nullptr, *Xc = nullptr;           // n0 x d, mc x d row-major
+    double *Phi00 = nullptr, *P0c = nullptr;       // n0 x n0; phi(X0, candidates) n0 x mc column-major
+    double *Pi0 = nullptr;                         // n0 x q column-major
+    double *LamT = nullptr;                        // n0 x mc column-major: column j = lam(xi_j)
+    double *K = nullptr, *LK = nullptr, *diagK = nullptr;  // mc x mc kappa matrix; mc x maxacc factor columns; running pivots
+    double *Prow = nullptr, *Ginv = nullptr;       // mc x q row-major polynomial rows; q x q
+    int *acc = nullptr;                            // accepted candidate positions, acceptance order; acc[maxacc] = count
+};
+
+namespace mrbf {
+namespace r4 {
+
+// Prow[i*q + t] = [1, x_i][t]
+__global__ void poly_rows_kernel(const double *__restrict__ X, int64_t m, int d, int q, double *__restrict__ P) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= m * q) return;
+    const int64_t i = idx / q;
+    const int t = (int)(idx % q);
+    P[idx] = (t == 0) ? 1.0 : X[i * d + (t - 1)];
+}
+__global__ void identity_kernel(double *__restrict__ A, int q) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < q * q) A[idx] = (idx % q == idx / q) ? 1.0 : 0.0;
+}
+// K = Phicc - E - E' + Q  (all mc x mc; Phicc symmetric), diag -> diagK
+__global__ void kappa_kernel(const double *__restrict__ Phicc, const double *__restrict__ E, const double *__restrict__ Q, int64_t mc,
+                             double *__restrict__ K, double *__restrict__ diagK, int have_tail) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= mc * mc) return;
+    const int64_t i = idx % mc, j = idx / mc;
+    double v = Phicc[idx];
+    if (have_tail) v = (v - E[i + j * mc]) - E[j + i * mc] + 0.5 * (Q[i + j * mc] + Q[j + i * mc]);
+    K[idx] = v;
+    if (i == j) diagK[i] = v;
+}
+
+// The walk over the candidates: ONE workgroup (the recurrence is sequential in the accepted sites; per accepted site the new
+// factor column is an mc x nacc matrix-vector product, coalesced over the rows).
+constexpr int SEL_THREADS = 1024;
+__global__ __launch_bounds__(SEL_THREADS) void select_kernel(int64_t mc, int n0, int q, int max_points, double thr, const double *__restrict__ K,
+                                                             double *__restrict__ LK, double *__restrict__ diagK,
+                                                             const double *__restrict__ Prow, double *__restrict__ Ginv, int *__restrict__ acc,
+                                                             int maxacc) {
+    extern __shared__ double smem[];  // Li[maxacc] | g[q] | pi[q] | red[SEL_THREADS / 64]
+    double *Li = smem, *g = Li + maxacc, *pi = g + (q > 0 ? q : 1), *red = pi + (q > 0 ? q : 1);
+    __shared__ int s_acc;
+    __shared__ double s_pk, s_ph;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int nacc = 0;
+    for (int64_t i = 0; i < mc; ++i) {
+        if (n0 + nacc >= max_points || nacc >= maxacc) break;
+        __syncthreads();  // the previous candidate's decision words have been read by everybody
+        // s_H = 1 + pi' Ginv pi
+        double ph = 1.0;
+        if (q > 0) {
+            for (int t = tid; t < q; t += SEL_THREADS) pi[t] = Prow[i * q + t];
+            __syncthreads();
+            double part = 0.0;
+            for (int t = tid; t < q; t += SEL_THREADS) {
+                double s = 0.0;
+                for (int u = 0; u < q; ++u) s = fma(Ginv[t + (int64_t)u * q], pi[u], s);  // Ginv symmetric: column access is coalesced
+                g[t] = s;
+                part = fma(pi[t], s, part);
+            }
+            for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+            if (lane == 0) red[wave] = part;
+            __syncthreads();
+            if (tid == 0) {
+                double s = 0.0;
+                for (int w = 0; w < SEL_THREADS / 64; ++w) s += red[w];
+                s_ph = 1.0 + s;
+            }
+        }
+        if (tid == 0) {
+            const double pk = diagK[i];
+            if (q == 0) s_ph = 1.0;
+            s_pk = pk;
+            const double tau2 = pk / s_ph;
+            s_acc = (pk > 0.0 && tau2 > thr && tau2 < 1e300) ? 1 : 0;  // tau^2 > (theta^2)^2, RbfModel.jl:370, :452 (NaN fails)
+        }
+        __syncthreads();
+        ph = s_ph;
+        if (!s_acc) continue;
+        const double pk = s_pk, rs = 1.0 / sqrt(pk);
+        for (int a2 = tid; a2 < nacc; a2 += SEL_THREADS) Li[a2] = LK[i + (int64_t)a2 * mc];
+        __syncthreads();
+        double *col = LK + (int64_t)nacc * mc;
+        for (int64_t r = tid; r < mc; r += SEL_THREADS) {
+            double v = 0.0;
+            if (r > i) {
+                double s = 0.0;
+                for (int a2 = 0; a2 < nacc; ++a2) s = fma(LK[r + (int64_t)a2 * mc], Li[a2], s);
+                v = (K[r + i * mc] - s) * rs;
+                diagK[r] -= v * v;
+            } else if (r == i) {
+                v = pk * rs;
+            }
+            col[r] = v;
+        }
+        // Ginv <- Ginv - g g' / s_H   (Sherman-Morrison for G + pi pi')
+        if (q > 0)
+            for (int e = tid; e < q * q; e += SEL_THREADS) Ginv[e] -= g[e % q] * g[e / q] / ph;
+        if (tid == 0) acc[nacc] = (int)i;
+        ++nacc;
+        __threadfence();
+        __syncthreads();
+    }
+    if (tid == 0) acc[maxacc] = nacc;
+}
+
+// gathers for the fit: LaT (n0 x j) = columns acc of LamT; P0a (n0 x j) = columns acc of P0c; Lacc (j x j lower) = rows acc of LK
+__global__ void gather_cols_kernel(const double *__restrict__ src, int64_t rows, const int *__restrict__ acc, int j, double *__restrict__ dst) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * j) return;
+    const int64_t r = idx % rows;
+    const int c = (int)(idx / rows);
+    dst[idx] = src[r + (int64_t)acc[c] * rows];
+}
+__global__ void gather_factor_kernel(const double *__restrict__ LK, int64_t mc, const int *__restrict__ acc, int j, double *__restrict__ L) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= j * j) return;
+    const int p = idx % j, a2 = idx / j;
+    L[idx] = (p >= a2) ? LK[acc[p] + (int64_t)a2 * mc] : 0.0;
+}
+// values (n0 + j) x k row-major -> Y0 (n0 x k), Ya (j x k) column-major
+__global__ void split_values_kernel(const double *__restrict__ Y, int n0, int j, int k, double *__restrict__ Y0, double *__restrict__ Ya) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (n0 + j) * k) return;
+    const int i = idx / k, l = idx % k;
+    if (i < n0)
+        Y0[i + l * n0] = Y[idx];
+    else
+        Ya[(i - n0) + l * j] = Y[idx];
+}
+// W row-major (n0 + j) x k and Wc (npad x k column-major, zero padded) from w0 (n0 x k), v (j x k) column-major; lam (q x k row-major) from lamc
+__global__ void pack_solution_kernel(const double *__restrict__ w0, const double *__restrict__ v, const double *__restrict__ lamc, int n0, int j,
+                                     int k, int q, int64_t npad, double *__restrict__ W, double *__restrict__ Wc, double *__restrict__ lam) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < npad * k) {
+        const int64_t i = idx % npad;
+        const int l = (int)(idx / npad);
+        const double val = (i < n0) ? w0[i + (int64_t)l * n0] : ((i < n0 + j) ? v[(i - n0) + (int64_t)l * j] : 0.0);
+        Wc[idx] = val;
+        if (i < n0 + j) W[i * k + l] = val;
+    } else if (idx < npad * k + (int64_t)q * k) {
+        const int64_t e = idx - npad * k;
+        const int t = (int)(e % q), l = (int)(e / q);
+        lam[(int64_t)t * k + l] = lamc[t + (int64_t)l * q];
+    }
+}
+__global__ void concat_sites_kernel(const double *__restrict__ C0, const double *__restrict__ Xc, const int *__restrict__ acc, int n0, int j, int d,
+                                    double *__restrict__ S) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (n0 + j) * d) return;
+    const int i = idx / d, t = idx % d;
+    S[idx] = (i < n0) ? C0[idx] : Xc[(int64_t)acc[i - n0] * d + t];
+}
+
+static inline unsigned nb(int64_t c) { return (unsigned)((c + 255) / 256); }
+
+}  // namespace r4
+}  // namespace mrbf
+
+using namespace mrbf;
+
+extern "C" int32_t mrbf_free_round4(mrbf_ctx *ctx, mrbf_round4_state *st) {
+    if (!ctx) return -1;
+    if (!st) return MRBF_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (st->block) (void)hipFree(st->block);
+    delete st;
+    return MRBF_OK;
+}
+
+extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const double *start_sites, int64_t mc, const double *cand_sites,
+                               int32_t kernel_id, double a, double b, int32_t poly_deg, int32_t max_points, double theta_pivot_cholesky,
+                               int32_t *accepted_out, int32_t *n_accepted, mrbf_round4_state **state_out) {
+    using namespace r4;
+    if (!ctx) return -1;
+    if (n0 < 1 || n0 > 8192) return fail(ctx, -2, "n0 = %lld out of range", (long long)n0);
+    if (d < 1 || d > 1024) return fail(ctx, -3, "d = %d out of range", d);
+    if (!start_sites) return fail(ctx, -4, "start_sites is NULL");
+    if (mc < 0 || mc > 30000) return fail(ctx, -5, "mc = %lld out of range", (long long)mc);
+    if (mc > 0 && !cand_sites) return fail(ctx, -6, "cand_sites is NULL");
+    if (kernel_id < 0 || kernel_id > 4) return fail(ctx, -7, "kernel_id out of range");
+    if (poly_deg < -1 || poly_deg > 1) return fail(ctx, -10, "polynomial_degree must be -1, 0 or 1");
+    if (!n_accepted) return fail(ctx, -14, "n_accepted is NULL");
+    if (state_out) *state_out = nullptr;
+    *n_accepted = 0;
+    (void)hipSetDevice(ctx->device);
+    const int q = poly_dim(d, poly_deg);
+    if (max_points <= 0) max_points = (d + 1) * (d + 2) / 2;  // RbfModel.jl:356
+    if (n0 < q)
+        return fail(ctx, -2, "round 4 on the device needs a start set that carries the polynomial tail (n0 = %lld < q = %d): use the host mirror",
+                    (long long)n0, q);
+    if (mc == 0 || n0 >= max_points) return MRBF_OK;  // nothing to select (RbfModel.jl:368)
+    const int maxacc = (int)std::min<int64_t>(mc, (int64_t)max_points - n0);
+    // one allocation for everything that outlives the call
+    auto *st = new mrbf_round4_state();
+    st->n0 = n0; st->mc = mc; st->d = d; st->q = q; st->deg = poly_deg; st->kid = kernel_id; st->a = a; st->b = b; st->maxacc = maxacc;
+    const size_t cnt[11] = {(size_t)n0 * d, (size_t)mc * d, (size_t)n0 * n0, (size_t)n0 * mc, (size_t)n0 * std::max(q, 1), (size_t)n0 * mc,
+                            (size_t)mc * mc, (size_t)mc * maxacc, (size_t)mc, (size_t)mc * std::max(q, 1), (size_t)std::max(q, 1) * std::max(q, 1)};
+    size_t off[12];
+    off[0] = 0;
+    for (int i = 0; i < 11; ++i) off[i + 1] = off[i] + ((cnt[i] * sizeof(double) + 255) & ~size_t(255));
+    const size_t total = off[11] + ((size_t)(maxacc + 1) * sizeof(int) + 255);
+    if (hipMalloc(&st->block, total) != hipSuccess) {
+        delete st;
+        return fail(ctx, MRBF_ENOMEM, "round 4 state allocation of %zu bytes failed", total);
+    }
+    char *base = (char *)st->block;
+    st->C0 = (double *)(base + off[0]); st->Xc = (double *)(base + off[1]); st->Phi00 = (double *)(base + off[2]);
+    st->P0c = (double *)(base + off[3]); st->Pi0 = (double *)(base + off[4]); st->LamT = (double *)(base + off[5]);
+    st->K = (double *)(base + off[6]); st->LK = (double *)(base + off[7]); st->diagK = (double *)(base + off[8]);
+    st->Prow = (double *)(base + off[9]); st->Ginv = (double *)(base + off[10]); st->acc = (int *)(base + off[11]);
+    auto run = [&]() -> int {
+        const KP kp = make_kp(kernel_id, a, b);
+        const double one = 1.0, zero = 0.0;
+        hipStream_t s = ctx->stream;
+        MRBF_HIP(ctx, hipMemcpyAsync(st->C0, start_sites, (size_t)n0 * d * sizeof(double), hipMemcpyDefault, s));
+        MRBF_HIP(ctx, hipMemcpyAsync(st->Xc, cand_sites, (size_t)mc * d * sizeof(double), hipMemcpyDefault, s));
+        // kernel blocks (difference-form arithmetic, like norm(x - c)): Phi00, phi(candidates, X0) (= P0c as n0 x mc column-major), Phicc
+        double *Phicc, *E, *Qm, *F, *T;
+        MRBF_TRY(get_buf(ctx, S_PHI, (size_t)mc * mc, &Phicc));
+        MRBF_TRY(launch_cross_gram(ctx, st->C0, n0, st->C0, n0, d, kp, st->Phi00));
+        MRBF_TRY(launch_cross_gram(ctx, st->Xc, mc, st->C0, n0, d, kp, st->P0c));
+        MRBF_TRY(launch_cross_gram(ctx, st->Xc, mc, st->Xc, mc, d, kp, Phicc));
+        if (q > 0) {
+            MRBF_TRY(get_buf(ctx, S_STAGE_C, (size_t)mc * mc, &E));
+            MRBF_TRY(get_buf(ctx, S_STAGE_D, (size_t)mc * mc, &Qm));
+            MRBF_TRY(get_buf(ctx, S_W1, (size_t)n0 * mc, &F));
+            MRBF_TRY(get_buf(ctx, S_T1, (size_t)q * std::max<int64_t>(mc, q), &T));
+            int *dinfo;
+            MRBF_TRY(get_buf(ctx, S_INFO, (size_t)4, &dinfo));
+            MRBF_TRY(launch_poly_matrix(ctx, st->C0, n0, d, q, st->Pi0, n0));
+            hipLaunchKernelGGL(poly_rows_kernel, dim3(nb(mc * q)), dim3(256), 0, s, st->Xc, mc, d, q, st->Prow);
+            // G0 = Pi0' Pi0 (q x q), its Cholesky factor, Ginv = G0^-1, T = G0^-1 P' (q x mc), LamT = Pi0 T (n0 x mc)
+            double *G0;
+            MRBF_TRY(get_buf(ctx, S_G, (size_t)q * q, &G0));
+            MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, q, q, (int)n0, &one, st->Pi0, (int)n0,
+                                         st->Pi0, (int)n0, &zero, G0, q));
+            MRBF_BLAS(ctx, rocsolver_dpotrf(ctx->blas, rocblas_fill_lower, q, G0, q, dinfo));
+            int hinfo = 0;
+            MRBF_HIP(ctx, hipMemcpyAsync(&hinfo, dinfo, sizeof(int), hipMemcpyDeviceToHost, s));
+            MRBF_HIP(ctx, hipStreamSynchronize(s));
+            if (hinfo != 0) return fail(ctx, MRBF_ESINGULAR, "the start set's polynomial matrix is rank deficient (potrf info %d): use the host mirror", hinfo);
+            hipLaunchKernelGGL(identity_kernel, dim3(nb(q * q)), dim3(256), 0, s, st->Ginv, q);
+            MRBF_BLAS(ctx, rocsolver_dpotrs(ctx->blas, rocblas_fill_lower, q, q, G0, q, st->Ginv, q));
+            // Prow (mc x q row-major) is P' (q x mc) column-major
+            MRBF_HIP(ctx, hipMemcpyAsync(T, st->Prow, (size_t)q * mc * sizeof(double), hipMemcpyDeviceToDevice, s));
+            MRBF_BLAS(ctx, rocsolver_dpotrs(ctx->blas, rocblas_fill_lower, q, (int)mc, G0, q, T, q));
+            MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, (int)n0, (int)mc, q, &one, st->Pi0, (int)n0, T, q,
+                                         &zero, st->LamT, (int)n0));
+            // E = Lam Phi0c = LamT' P0c ; F = Phi00 LamT ; Q = LamT' F
+            MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, (int)mc, (int)mc, (int)n0, &one, st->LamT,
+                                         (int)n0, st->P0c, (int)n0, &zero, E, (int)mc));
+            MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, (int)n0, (int)mc, (int)n0, &one, st->Phi00, (int)n0,
+                                         st->LamT, (int)n0, &zero, F, (int)n0));
+            MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, (int)mc, (int)mc, (int)n0, &one, st->LamT,
+                                         (int)n0, F, (int)n0, &zero, Qm, (int)mc));
+        } else {
+            E = Qm = Phicc;
+        }
+        hipLaunchKernelGGL(kappa_kernel, dim3(nb(mc * mc)), dim3(256), 0, s, Phicc, E, Qm, mc, st->K, st->diagK, q > 0 ? 1 : 0);
+        const double thr = (theta_pivot_cholesky * theta_pivot_cholesky) * (theta_pivot_cholesky * theta_pivot_cholesky);
+        const size_t shm = ((size_t)maxacc + 2 * (size_t)std::max(q, 1) + SEL_THREADS / 64) * sizeof(double);
+        if (shm > 150 * 1024) return fail(ctx, -11, "round 4: max_points - n0 = %d too large for the selection kernel", maxacc);
+        MRBF_HIP(ctx, hipFuncSetAttribute((const void *)select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        hipLaunchKernelGGL(select_kernel, dim3(1), dim3(SEL_THREADS), shm, s, mc, (int)n0, q, (int)max_points, thr, st->K, st->LK, st->diagK, st->Prow,
+                           st->Ginv, st->acc, maxacc);
+        MRBF_HIP(ctx, hipGetLastError());
+        std::vector<int> hacc((size_t)maxacc + 1);
+        MRBF_HIP(ctx, hipMemcpyAsync(hacc.data(), st->acc, hacc.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+        MRBF_HIP(ctx, hipStreamSynchronize(s));
+        st->nacc = hacc[maxacc];
+        *n_accepted = st->nacc;
+        if (accepted_out)
+            for (int i = 0; i < st->nacc; ++i) accepted_out[i] = hacc[i];
+        return 0;
+    };
+    const int rc = run();
+    if (rc != 0 || !state_out) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(st->block);
+        delete st;
+        return rc;
+    }
+    *state_out = st;
+    return MRBF_OK;
+}
+
+extern "C" int32_t mrbf_fit_from_round4(mrbf_ctx *ctx, const mrbf_round4_state *st, int32_t k, const double *values, mrbf_model **model,
+                                        double *weights_out, double *poly_out, mrbf_fit_info *info) {
+    using namespace r4;
+    if (!ctx) return -1;
+    if (!st) return fail(ctx, -2, "state is NULL");
+    if (k < 1 || k > 1024) return fail(ctx, -3, "k = %d out of range", k);
+    if (!values) return fail(ctx, -4, "values is NULL");
+    if (!model) return fail(ctx, -5, "model is NULL");
+    *model = nullptr;
+    if (st->n0 != st->q)
+        return fail(ctx, -2, "factor reuse needs a unisolvent start set (n0 = %lld, q = %d): the start set's own null-space directions are not "
+                             "part of the round-4 factor; use mrbf_fit", (long long)st->n0, st->q);
+    (void)hipSetDevice(ctx->device);
+    const int n0 = (int)st->n0, j = st->nacc, q = st->q, d = st->d;
+    const int64_t n = n0 + j, mc = st->mc;
+    mrbf_fit_info local;
+    if (!info) info = &local;
+    std::memset(info, 0, sizeof(*info));
+    info->n = (int32_t)n;
+    info->q = q;
+    info->path = MRBF_PATH_ROUND4;
+    info->rel_residual = NAN;
+    info->max_pitw = NAN;
+    hipStream_t s = ctx->stream;
+    const double one = 1.0, zero = 0.0, mone = -1.0;
+    const double *Y;
+    MRBF_TRY(stage_in(ctx, S_STAGE_B, values, (size_t)n * k, &Y));
+    double *S;
+    MRBF_TRY(get_buf(ctx, S_STAGE_A, (size_t)n * d, &S));
+    MRBF_HIP(ctx, hipEventRecord(ctx->ev[5], s));
+    hipLaunchKernelGGL(concat_sites_kernel, dim3(nb(n * d)), dim3(256), 0, s, st->C0, st->Xc, st->acc, n0, j, d, S);
+    mrbf_model *M = nullptr;
+    MRBF_TRY(build_model_shell(ctx, n, d, k, S, st->kid, st->a, st->b, st->deg, &M));
+    auto run = [&]() -> int {
+        double *Y0, *Ya, *LaT, *P0a, *Lacc, *w0, *rhs, *PiLU;
+        int *ipiv, *dinfo;
+        MRBF_TRY(get_buf(ctx, S_RHS, (size_t)n * k + (size_t)n0 * k * 2 + k, &Y0));
+        Ya = Y0 + (size_t)n0 * k;
+        w0 = Ya + (size_t)std::max(j, 1) * k;
+        rhs = w0 + (size_t)n0 * k;
+        MRBF_TRY(get_buf(ctx, S_Q1, (size_t)n0 * std::max(j, 1) * 2, &LaT));
+        P0a = LaT + (size_t)n0 * std::max(j, 1);
+        MRBF_TRY(get_buf(ctx, S_G, (size_t)std::max(j, 1) * std::max(j, 1) + (size_t)q * q, &Lacc));
+        PiLU = Lacc + (size_t)std::max(j, 1) * std::max(j, 1);
+        MRBF_TRY(get_buf(ctx, S_IPIV, (size_t)q + 4, &ipiv));
+        MRBF_TRY(get_buf(ctx, S_INFO, (size_t)4, &dinfo));
+        hipLaunchKernelGGL(split_values_kernel, dim3(nb(n * k)), dim3(256), 0, s, Y, n0, j, k, Y0, Ya);
+        MRBF_HIP(ctx, hipMemcpyAsync(rhs, Y0, (size_t)n0 * k * sizeof(double), hipMemcpyDeviceToDevice, s));
+        MRBF_HIP(ctx, hipMemsetAsync(w0, 0, (size_t)n0 * k * sizeof(double), s));
+        if (j > 0) {
+            hipLaunchKernelGGL(gather_cols_kernel, dim3(nb((int64_t)n0 * j)), dim3(256), 0, s, st->LamT, (int64_t)n0, st->acc, j, LaT);
+            hipLaunchKernelGGL(gather_cols_kernel, dim3(nb((int64_t)n0 * j)), dim3(256), 0, s, st->P0c, (int64_t)n0, st->acc, j, P0a);
+            hipLaunchKernelGGL(gather_factor_kernel, dim3(nb((int64_t)j * j)), dim3(256), 0, s, st->LK, mc, st->acc, j, Lacc);
+            // Ya <- Ya - Lam_acc Y0 ;  v = K_acc^-1 (..) by the two triangular solves with the round-4 factor
+            MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, j, k, n0, &mone, LaT, n0, Y0, n0, &one, Ya, j));
+            MRBF_BLAS(ctx, rocblas_dtrsm(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, j, k, &one,
+                                         Lacc, j, Ya, j));
+            MRBF_BLAS(ctx, rocblas_dtrsm(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, j, k,
+                                         &one, Lacc, j, Ya, j));
+            // w0 = -Lam_acc' v ;  rhs = Y0 - Phi00 w0 - Phi0a v
+            MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, n0, k, j, &mone, LaT, n0, Ya, j, &zero, w0, n0));
+            MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, n0, k, n0, &mone, st->Phi00, n0, w0, n0, &one, rhs, n0));
+            MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, n0, k, j, &mone, P0a, n0, Ya, j, &one, rhs, n0));
+        }
+        // Pi0 lambda = rhs  (Pi0 square, unisolvent start set)
+        if (q > 0) {
+            MRBF_HIP(ctx, hipMemcpyAsync(PiLU, st->Pi0, (size_t)q * q * sizeof(double), hipMemcpyDeviceToDevice, s));
+            MRBF_BLAS(ctx, rocsolver_dgesv(ctx->blas, q, k, PiLU, q, ipiv, rhs, q, dinfo));
+            int hinfo = 0;
+            MRBF_HIP(ctx, hipMemcpyAsync(&hinfo, dinfo, sizeof(int), hipMemcpyDeviceToHost, s));
+            MRBF_HIP(ctx, hipStreamSynchronize(s));
+            info->factor_info = hinfo;
+            if (hinfo != 0) return fail(ctx, MRBF_ESINGULAR, "start set is not unisolvent (gesv info %d)", hinfo);
+        }
+        hipLaunchKernelGGL(pack_solution_kernel, dim3(nb(M->npad * k + (int64_t)q * k)), dim3(256), 0, s, w0, Ya, rhs, n0, j, k, q, M->npad, M->W,
+                           M->Wc, M->lam);
+        MRBF_HIP(ctx, hipGetLastError());
+        MRBF_HIP(ctx, hipEventRecord(ctx->ev[6], s));
+        if (ctx->residual) MRBF_TRY(fit_check(ctx, M, Y, info));
+        if (weights_out) MRBF_HIP(ctx, hipMemcpyAsync(weights_out, M->W, (size_t)n * k * sizeof(double), hipMemcpyDefault, s));
+        if (poly_out && q > 0) MRBF_HIP(ctx, hipMemcpyAsync(poly_out, M->lam, (size_t)q * k * sizeof(double), hipMemcpyDefault, s));
+        MRBF_HIP(ctx, hipStreamSynchronize(s));
+        MRBF_HIP(ctx, hipEventElapsedTime(&info->ms_solve, ctx->ev[5], ctx->ev[6]));
+        info->ms_total = info->ms_solve;
+        return 0;
+    };
+    const int rc = run();
+    if (rc != 0) {
+        (void)hipStreamSynchronize(s);
+        destroy_model(ctx, M);
+        return rc;
+    }
+    *model = M;
+    return MRBF_OK;
+}
+
+extern "C" int32_t mrbf_round4_sites(const mrbf_round4_state *st, int64_t *n0, int64_t *n_candidates, int32_t *n_accepted) {
+    if (!st) return -1;
+    if (n0) *n0 = st->n0;
+    if (n_candidates) *n_candidates = st->mc;
+    if (n_accepted) *n_accepted = st->nacc;
+    return MRBF_OK;
+}

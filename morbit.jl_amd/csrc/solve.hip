@@ -613,7 +613,7 @@ static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info
 }
 
 // residual ||s(C) - Y|| / ||Y|| through the evaluation kernels (an independent code path), and max |Pi' w|
-static int fit_check(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info *info) {
+int fit_check(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info *info) {
     const int64_t n = M->n;
     const int k = M->k, q = M->q;
     double *V, *scal;

@@ -120,6 +120,67 @@ def _rand_box_point(lb, ub, rng):
     return lb + (ub - lb) * rng.random(lb.size)
 
 
+class Round4State:
+    """the factors mrbf_round4 left on the device (start sites, candidates, accepted positions, kappa-factor): hand it to
+    `fit_from_round4` to get the model on (start sites + accepted sites) without a new factorisation"""
+
+    def __init__(self, ctx, handle, cfg, delta, start_sites, cand_sites, accepted):
+        self.ctx, self.handle, self.cfg, self.delta = ctx, handle, cfg, delta
+        self.start_sites, self.cand_sites, self.accepted = start_sites, cand_sites, list(accepted)
+
+    @property
+    def training_sites(self):
+        return np.vstack([self.start_sites, self.cand_sites[self.accepted]]) if self.accepted else self.start_sites.copy()
+
+    def free(self):
+        if self.handle is not None and self.ctx.h:
+            self.ctx.lib.mrbf_free_round4(self.ctx.h, self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def rbf_round4_device(cfg, start_sites, cand_sites, delta=1.0, ctx=None, keep_state=False):
+    """_rbf_round4's selection (RbfModel.jl:352-499) as ONE device call: positions (into cand_sites) of the accepted sites in
+    acceptance order [, Round4State].  Raises MrbfError(-2 / ESINGULAR) when the start set does not carry the polynomial tail."""
+    ctx = ctx or _lib.default_context()
+    C0, Xc = _lib.host_f64(start_sites), _lib.host_f64(cand_sites)
+    n0, d = C0.shape
+    mc = Xc.shape[0]
+    kid, a, b = rm._get_kernel_params(delta, cfg)
+    acc = np.zeros(max(mc, 1), dtype=np.int32)
+    nacc = ctypes.c_int32()
+    h = _lib.c_vp()
+    ctx.check(ctx.lib.mrbf_round4(ctx.h, n0, d, _lib.as_ptr(C0), mc, _lib.as_ptr(Xc) if mc else None, kid, a, b, cfg.polynomial_degree,
+                                  int(cfg.max_model_points), float(cfg.θ_pivot_cholesky), _lib.as_ptr(acc), ctypes.byref(nacc),
+                                  ctypes.byref(h) if keep_state else None))
+    accepted = [int(v) for v in acc[: nacc.value]]
+    if keep_state:
+        return accepted, Round4State(ctx, h if h.value else None, cfg, delta, C0, Xc.reshape(mc, d), accepted)
+    return accepted
+
+
+def fit_from_round4(state, training_values, fully_linear=False):
+    """update_model (RbfModel.jl:743-767) for the training set (start sites + sites accepted by round 4) from the factor round 4
+    left on the device -- the reference's TODO at RbfModel.jl:657-660.  `training_values`: (n0 + n_accepted) x k in that order."""
+    ctx = state.ctx
+    S = state.training_sites
+    n, d = S.shape
+    Y = _lib.host_f64(training_values).reshape(n, -1)
+    k = Y.shape[1]
+    q = 0 if state.cfg.polynomial_degree < 0 else (1 if state.cfg.polynomial_degree == 0 else d + 1)
+    W, L = np.empty((n, k)), np.empty((max(q, 1), k))
+    h, info = _lib.c_vp(), _lib.FitInfo()
+    if state.handle is None:  # nothing was selected / no state kept: the ordinary fit
+        return rm.update_model(state.cfg, S, Y, state.delta, fully_linear, ctx=ctx)
+    ctx.check(ctx.lib.mrbf_fit_from_round4(ctx.h, state.handle, k, _lib.as_ptr(Y), ctypes.byref(h), _lib.as_ptr(W), _lib.as_ptr(L), ctypes.byref(info)))
+    return rm.RbfModel(ctx, h, n, d, k, q, fully_linear, W, L[:q], info.asdict())
+
+
 def _rbf_round4(sites, lb_2, ub_2, x, delta, indices_found_so_far, cfg, ctx=None, kernel_block=None, rng=None, new_sites=None):
     """Wild's second selection round (RbfModel.jl:352-499): database indices of additional training sites that keep the
     Cholesky factors of Z'Phi Z bounded.  `sites` is the database as an (N_db, d) array; candidates are the box members
@@ -148,6 +209,23 @@ def _rbf_round4(sites, lb_2, ub_2, x, delta, indices_found_so_far, cfg, ctx=None
     C0 = sites[list(indices_found_so_far)]
     Xc = np.vstack([sites[cand], fresh]) if len(cand) else fresh
     ids = list(cand) + [-1] * fresh.shape[0]
+    if kernel_block is None:
+        # the whole selection as one device call (round4.hip); the incremental host bookkeeping below only remains for start sets
+        # that do not carry the polynomial tail (n0 < q or rank deficient), which the device path refuses
+        try:
+            accepted = rbf_round4_device(cfg, C0, Xc, delta, ctx=ctx)
+        except _lib.MrbfError as e:
+            if e.code not in (-2, _lib.MRBF_ESINGULAR):
+                raise
+            accepted = None
+        if accepted is not None:
+            for pos in accepted:
+                id_ = ids[pos]
+                if id_ < 0:
+                    new_sites.append(Xc[pos].copy())
+                    id_ = sites.shape[0] + len(new_sites) - 1
+                round4.append(id_)
+            return round4
     if kernel_block is None:
         # two device calls replace one kernels(xi) call per candidate plus RBF.get_matrices
         Phi, Pi, _ = rm.get_matrices(cfg, C0, delta, ctx=ctx)

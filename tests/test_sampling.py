@@ -178,3 +178,103 @@ def test_cross_gram_shapes_and_errors():
     # identical points give exactly phi(0)
     K = sampling.cross_gram(_cfg("gaussian", 1), C[:5], C[:5])
     assert np.all(np.diag(K) == 1.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,deg,d,ndb", [("cubic", 1, 3, 6), ("gaussian", 1, 2, 0), ("multiquadric", 0, 2, 4)])
+def test_round4_use_max_points_on_device(name, deg, d, ndb):
+    x, sites = _db(3, d, max(ndb + d + 2, d + 2))
+    start = _start_set(x, sites, d)
+    sites = sites[: len(start) + ndb] if ndb else sites[start]
+    start = [i for i in start if i < len(sites)] if ndb else list(range(len(sites)))
+    cfg = pkg.RbfConfig(kernel=name, polynomial_degree=deg, use_max_points=True)
+    kidp, ap, bp = pkg.rbf_model._get_kernel_params(1.0, cfg)
+    lb, ub = np.zeros(d), np.ones(d)
+    new_sites = []
+    got = sampling._rbf_round4(sites, lb, ub, x, 1.0, start, cfg, rng=np.random.default_rng(9), new_sites=new_sites)
+    max_points = (d + 1) * (d + 2) // 2
+    assert len(start) + len(got) == max_points
+    cands = [i for i in range(len(sites)) if i not in start]
+    rng = np.random.default_rng(9)
+    fresh = [sampling._rand_box_point(lb, ub, rng) for _ in range(10 * max_points + 1)]
+    want = so.rbf_round4(sites[start], sites[cands], kidp, ap, bp, deg, extra_sites=fresh)
+    want_ids = [cands[p] if p < len(cands) else len(sites) + k for k, p in zip(np.cumsum([p >= len(cands) for p in want]) - 1, want)]
+    assert got == want_ids
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,deg,d,n,k", [("cubic", 1, 3, 60, 2), ("multiquadric", 1, 6, 400, 3), ("gaussian", 1, 10, 1500, 1),
+                                            ("thin_plate_spline", 1, 2, 30, 2), ("cubic", 1, 24, 3000, 2)])
+def test_round4_device_selection_and_factor_reuse(name, deg, d, n, k):
+    """mrbf_round4 against the independent from-scratch oracle (selection), and mrbf_fit_from_round4 against the oracle's dense
+    LU of the saddle system on (start + accepted) sites (weights, values, Jacobians at the north-star tolerances): the n^3/3
+    factorisation of the fit is replaced by two triangular solves with the factor the selection left behind."""
+    rng = np.random.default_rng(100 + d)
+    x = np.full(d, 0.5)
+    sites = np.vstack([x, rng.random((n, d))])
+    start = _start_set(x, sites, d)
+    assert len(start) == d + 1
+    cands = [i for i in range(len(sites)) if i not in start]
+    cfg = _cfg(name, deg, mp=min((d + 1) * (d + 2) // 2, 2 * d + 1 if d > 10 else 10 ** 6))
+    kidp, ap, bp = pkg.rbf_model._get_kernel_params(1.0, cfg)
+    accepted, st = sampling.rbf_round4_device(cfg, sites[start], sites[cands], 1.0, keep_state=True)
+    mp = (d + 1) * (d + 2) // 2 if cfg.max_model_points <= 0 else cfg.max_model_points
+    if n <= 400:   # the oracle re-factorises per candidate: O(candidates * N^3)
+        want = so.rbf_round4(sites[start], sites[cands], kidp, ap, bp, deg, max_points=mp)
+        assert accepted == want
+    assert len(accepted) == min(mp - len(start), len(cands)) or n <= 400   # generic sites: every candidate passes until max_points
+    assert accepted == sorted(accepted)
+    S = st.training_sites
+    Y = np.stack([(S ** 2).sum(axis=1), np.sin(S.sum(axis=1)), S[:, 0] - S[:, -1]][:k], axis=1)
+    mod = sampling.fit_from_round4(st, Y)
+    assert mod.info["path"] == _lib_path_round4() and mod.n == S.shape[0]
+    ref = orc.fit(S, Y, kidp, ap, bp, deg)
+    Phi, Pi = orc.gram(S, kidp, ap, bp, deg)
+    cond = float(np.linalg.cond(orc.saddle_matrix(Phi, Pi)))
+    X = rng.random((17, d))
+    V, J = mod.eval_sites(X, want_values=True, want_jac=True)
+    ew = np.abs(mod.weights - ref.w).max() / np.abs(ref.w).max()
+    ev = np.abs(V - ref.values(X)).max() / max(1.0, np.abs(V).max())
+    ej = np.abs(J - ref.jacs(X)).max() / max(1.0, np.abs(J).max())
+    assert mod.info["rel_residual"] < 1e-10, mod.info
+    assert ev < 1e-8 and ej < 1e-8, (ev, ej)
+    assert ew < 1e-10 or ew < 100 * np.finfo(float).eps * cond, (ew, cond)
+    # the same model as the ordinary fit on the same sites
+    full = pkg.update_model(cfg, S, Y)
+    assert np.abs(full.weights - mod.weights).max() <= max(1e-10, 100 * np.finfo(float).eps * cond) * np.abs(full.weights).max()
+    print("round 4 on the device d=%d: %d of %d candidates accepted, fit from the kept factor %.3f ms (ordinary fit %.3f ms), weights vs oracle %.1e (cond %.1e)"
+          % (d, len(accepted), len(cands), mod.info["ms_total"], full.info["ms_total"], ew, cond))
+    full.free()
+    mod.free()
+    st.free()
+
+
+def _lib_path_round4():
+    from morbit.jl_amd import _lib
+    return _lib.PATH_ROUND4
+
+
+@pytest.mark.gpu
+def test_round4_device_refusals():
+    from morbit.jl_amd import _lib
+    x, sites = _db(5, 3, 30)
+    cfg = _cfg("cubic", 1)
+    # a start set that does not carry the tail (n0 < q): refused with -2, the mirror then takes the host bookkeeping
+    with pytest.raises(pkg.MrbfError) as ei:
+        sampling.rbf_round4_device(cfg, sites[:2], sites[2:])
+    assert ei.value.code == -2
+    # affinely dependent start set (4 collinear sites in 3-D): rank-deficient polynomial matrix
+    line = np.array([[0.1 * t, 0.2 * t, 0.3 * t] for t in range(1, 5)])
+    with pytest.raises(pkg.MrbfError) as ei:
+        sampling.rbf_round4_device(cfg, line, sites[2:])
+    assert ei.value.code == _lib.MRBF_ESINGULAR
+    # max_points already reached / no candidates: nothing selected, no state
+    assert sampling.rbf_round4_device(_cfg("cubic", 1, mp=4), sites[:4], sites[4:]) == []
+    assert sampling.rbf_round4_device(cfg, sites[:4], np.empty((0, 3))) == []
+    # factor reuse needs n0 == q: five start sites in 3-D
+    acc, st = sampling.rbf_round4_device(cfg, sites[:5], sites[5:], keep_state=True)
+    S = st.training_sites
+    with pytest.raises(pkg.MrbfError) as ei:
+        sampling.fit_from_round4(st, np.zeros((S.shape[0], 1)))
+    assert ei.value.code == -2
+    st.free()
