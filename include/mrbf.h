@@ -167,6 +167,15 @@ int32_t mrbf_backtrack(mrbf_ctx *ctx, const mrbf_model *model, const double *x, 
                        double omega, int32_t strict, double const_rhs, double shrink, double min_stepsize,
                        int32_t max_loops, double *x_plus, double *mx_plus, double *step, int32_t *n_loops);
 
+/* ---- rounds 1-2 of the training-site selection: the candidate scan of the affinely-independent-point filter ------------
+ * val(xi) = || Z (Z' (xi - x0)) ||_p for all candidates at once and the first maximiser -- replaces the loop over
+ * filter.candidate_indices in Base.iterate(::AffinelyIndependentPointFilter, n) (src/models/AffinelyIndependentPoints.jl:71-106).
+ * shifted: mc x d row-major rows xi - x0 (host or device; already chosen sites: pass a zero row); Z: d x dz column-major, the
+ * p-normalised complement basis of AffinelyIndependentPoints.jl:4-12 (the caller's d x d QR); p_is_inf: 1 = inf-norm (the
+ * filter's default in _find_suitable_points, RbfModel.jl:226), 0 = 2-norm.  vals_out (mc) may be NULL. */
+int32_t mrbf_affine_scores(mrbf_ctx *ctx, int64_t mc, int32_t d, int32_t dz, const double *shifted, const double *Z, int32_t p_is_inf,
+                           double *vals_out, int64_t *argmax, double *maxval);
+
 /* ---- round 4 of the training-site selection on the device, with factor reuse -------------------------------------------
  * mrbf_round4 replaces _rbf_round4 (src/models/RbfModel.jl:352-499): start_sites (n0 x d, the sites found so far -- centre and
  * rounds 1-3 -- which must carry the polynomial tail: n0 >= q, full rank) and cand_sites (mc x d, the database candidates in

@@ -91,6 +91,8 @@ SIGNATURES = {
     "mrbf_backtrack": (ctypes.c_int32, [c_vp, c_vp, c_vp, c_vp, ctypes.c_double, ctypes.c_double, ctypes.c_int32,
                                         ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int32, c_vp, c_vp,
                                         c_vp, c_ip]),
+    "mrbf_affine_scores": (ctypes.c_int32, [c_vp, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, c_vp, c_vp, ctypes.c_int32, c_vp,
+                                            ctypes.POINTER(ctypes.c_int64), c_dp]),
     "mrbf_round4": (ctypes.c_int32, [c_vp, ctypes.c_int64, ctypes.c_int32, c_vp, ctypes.c_int64, c_vp, ctypes.c_int32, ctypes.c_double,
                                      ctypes.c_double, ctypes.c_int32, ctypes.c_int32, ctypes.c_double, c_vp, c_ip, ctypes.POINTER(c_vp)]),
     "mrbf_fit_from_round4": (ctypes.c_int32, [c_vp, c_vp, ctypes.c_int32, c_vp, ctypes.POINTER(c_vp), c_vp, c_vp, ctypes.POINTER(FitInfo)]),

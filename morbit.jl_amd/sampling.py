@@ -28,7 +28,7 @@ def _orthogonal_complement_matrix(Y, p=np.inf):
 class AffinelyIndependentPointFilter:
     """Greedy filter: repeatedly the candidate maximising ||Z Z'(xi - x0)||_p, accepted while it exceeds pivot_val."""
 
-    def __init__(self, x_0, seeds, n=None, Y=None, Z=None, p=np.inf, pivot_val=1e-3):
+    def __init__(self, x_0, seeds, n=None, Y=None, Z=None, p=np.inf, pivot_val=1e-3, ctx=None, device_threshold=4096):
         self.x_0 = np.asarray(x_0, dtype=np.float64)
         self.shifted = [np.asarray(s, dtype=np.float64) - self.x_0 for s in seeds]
         d = self.x_0.size
@@ -37,6 +37,17 @@ class AffinelyIndependentPointFilter:
         self.Y = np.empty((d, 0)) if Y is None else np.array(Y, dtype=np.float64)
         self.Z = np.eye(d) if Z is None else np.array(Z, dtype=np.float64)
         self.p, self.pivot_val = p, pivot_val
+        # databases with many sites in the box: the candidate scan (two tall products + a reduction per pick) runs on the device
+        # (mrbf_affine_scores); below the threshold the host's BLAS is faster than a launch
+        self.ctx, self.device_threshold = ctx, device_threshold
+
+    def _scores_device(self, S):
+        ctx = self.ctx or _lib.default_context()
+        Z = np.asfortranarray(self.Z)
+        best, val = ctypes.c_int64(-1), ctypes.c_double()
+        ctx.check(ctx.lib.mrbf_affine_scores(ctx.h, S.shape[0], S.shape[1], Z.shape[1], _lib.as_ptr(S), _lib.as_ptr(Z) if Z.shape[1] else None,
+                                             1 if np.isinf(self.p) else 0, None, ctypes.byref(best), ctypes.byref(val)))
+        return int(best.value), float(val.value)
 
     def collect(self):
         out = []
@@ -48,7 +59,21 @@ class AffinelyIndependentPointFilter:
         self.Z = _orthogonal_complement_matrix(self.Y, self.p)
         out.append(i)
         S = np.array(self.shifted) if self.shifted else np.empty((0, self.x_0.size))
+        on_device = self.ctx is not None or len(cand) >= self.device_threshold
+        if on_device:
+            Sd = np.ascontiguousarray(S, dtype=np.float64)
+            Sd[i] = 0.0   # chosen sites score 0 (the reference removes them from the candidate list)
         while len(out) < self.n and cand:
+            if on_device:
+                best, vb = self._scores_device(Sd)
+                if best < 0 or not vb > self.pivot_val:
+                    break
+                self.Y = np.hstack([self.Y, self.shifted[best][:, None]])
+                self.Z = _orthogonal_complement_matrix(self.Y, self.p)
+                cand.remove(best)
+                Sd[best] = 0.0
+                out.append(best)
+                continue
             if self.Z.shape[1]:
                 P = (S[cand] @ self.Z) @ self.Z.T                     # all candidates at once: rows Z Z'(xi - x0)
                 vals = np.linalg.norm(P, ord=self.p, axis=1)

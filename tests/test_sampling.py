@@ -278,3 +278,37 @@ def test_round4_device_refusals():
         sampling.fit_from_round4(st, np.zeros((S.shape[0], 1)))
     assert ei.value.code == -2
     st.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,n,piv", [(2, 20, 0.1), (5, 400, 0.3), (10, 20000, 0.05), (3, 3, 1e-3)])
+def test_affinely_independent_filter_on_device(d, n, piv):
+    # the candidate scan of AffinelyIndependentPoints.jl:71-106 through mrbf_affine_scores: same picks, in the same order
+    x, sites = _db(40 + d, d, n)
+    want, Yw, _ = so.affinely_independent_indices(x, sites[1:], d, piv)
+    flt = sampling.AffinelyIndependentPointFilter(x, sites[1:], n=d, pivot_val=piv, ctx=pkg.default_context())
+    got = flt.collect()
+    assert got == want
+    np.testing.assert_allclose(flt.Y, Yw, atol=0)
+    # scores of one scan against NumPy, first maximiser on ties (duplicated rows), 2-norm variant
+    from morbit.jl_amd import _lib
+    import ctypes
+    ctx = pkg.default_context()
+    rng = np.random.default_rng(d)
+    S = rng.standard_normal((max(n, 8), d))
+    S[5] = S[2]
+    Z = so.orthogonal_complement_matrix(rng.standard_normal((d, max(d // 2, 1))))
+    for p_inf in (1, 0):
+        vals = np.empty(S.shape[0])
+        best, val = ctypes.c_int64(), ctypes.c_double()
+        Zf = np.asfortranarray(Z)
+        ctx.check(ctx.lib.mrbf_affine_scores(ctx.h, S.shape[0], d, Z.shape[1], _lib.as_ptr(S), _lib.as_ptr(Zf), p_inf, _lib.as_ptr(vals),
+                                             ctypes.byref(best), ctypes.byref(val)))
+        ref = np.linalg.norm((S @ Z) @ Z.T, ord=np.inf if p_inf else 2, axis=1)
+        np.testing.assert_allclose(vals, ref, rtol=1e-12, atol=1e-14)
+        assert best.value == int(np.argmax(vals)) and val.value == vals[best.value]
+    # identical rows 2 and 5: the first one wins when they are the maximum
+    Sm = np.zeros((8, d))
+    Sm[2] = Sm[5] = 3.0
+    ctx.check(ctx.lib.mrbf_affine_scores(ctx.h, 8, d, d, _lib.as_ptr(Sm), _lib.as_ptr(np.asfortranarray(np.eye(d))), 1, None, ctypes.byref(best), ctypes.byref(val)))
+    assert best.value == 2 and val.value == 3.0
