@@ -48,6 +48,8 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.EvalInfo) == 16
     assert ctypes.sizeof(_lib.Problem) == 2 * 8 + 4 * 4 + 2 * 8 + 7 * 8 == 104
     assert _lib.Result.fit.offset == 8
+    assert ctypes.sizeof(_lib.PsOptions) == 40 and ctypes.sizeof(_lib.PsInfo) == 32 and _lib.PsInfo.tau.offset == 24
+    assert ctypes.sizeof(_lib.Result) == 8 + 72 + 8 + 16
 
 
 def test_version_and_no_cpu_fallback(lib):
