@@ -317,7 +317,7 @@ def main():
             out["dry_run"] = True
         if many and table is not None:
             out["records"] = {"gathered": int(table.shape[0]), "failed": int(np.sum(table[:, 1] != 0)),
-                              "worst_rel_residual": float(np.nanmax(table[:, 3])) if table.shape[0] else None}
+                              "worst_rel_residual": (float(np.nanmax(table[:, 3])) if np.isfinite(table[:, 3]).any() else None)}
             assert table.shape[0] == P and np.array_equal(table[:, 0], np.arange(P)), "record gather lost problems"
         if not dry:
             kernels = {

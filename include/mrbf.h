@@ -79,7 +79,7 @@ enum {
     MRBF_OPT_EVAL_IMPL = 5,    /* 0 = default, 1 = GEMM pipeline, 2 = fused MFMA kernel */
     MRBF_OPT_TIMING = 6,       /* 1 = record per-phase hipEvents (default 1) */
     MRBF_OPT_DIAG_IMPL = 7,    /* diagonal-block kernel of the built-in Cholesky: 0 = MFMA-tiled (default), 1 = column sweep (host-driven
-                                  factorisation only), 3 = MFMA-tiled with wave-specialised roles and LDS flags (experiment, no faster) */
+                                  factorisation only) */
     MRBF_OPT_CHOL_WINDOW = 8,  /* panels aggregated per trailing update: 0 = size-dependent schedule (default), else 1, 2 or 4 */
     MRBF_OPT_SPIN_MS = 9,      /* wall-clock limit (ms) a persistent kernel waits on one dependency without progress before it gives up
                                   and the call falls back to the host-driven GPU path (default 1000) */

@@ -91,7 +91,6 @@ struct Args {
     int look;        // general workgroups take a panel job of block column c once c < (finished diagonal blocks) + look
     unsigned long long spin_ticks;  // wall_clock64 ticks (10 ns) one wait may last without the awaited word changing
     int fault;                      // test hook: the last block row's first panel job of column 0 never publishes its tile
-    int diag_v5;                    // 1: wave-specialised diagonal-block core (chol_diag_core.hpp, v5), 0: barrier-based v4
     int use_quiet;
     int slack, slack_chain, first, win, wbias, srows;
     unsigned long long *jlog;   // diagnostic launches only: 8 words per job (meta, claim, 5 stage stamps, end), jlog[0] = count
@@ -103,7 +102,6 @@ struct Shared {
     union {
         double gemm[2 * BK * LDS_LD];
         diagcore::DiagV4Shared diag;
-        diagcore::DiagV5Shared diag5;
     } u;
     int ok;
     int jkind, jidx;
@@ -534,110 +532,6 @@ __device__ __attribute__((noinline)) bool run_diag(const Args &a, Shared &sh, co
     return true;
 }
 
-// ---- v5 diagonal job: the two wave roles of chol_diag_core.hpp's v5 as separate functions (own register allocation each).
-// Both run the same sequence of workgroup-wide waits / barriers: the streamed fold of panel c-1 (one wg_wait_val per batch of
-// published 16-column panels), two start-up barriers, then their barrier-free loops.
-__device__ __attribute__((noinline)) bool diag5_leaf_role(const Args &a, Shared &sh, int c) {
-    if (c > 0) {
-        const unsigned *sprog = a.sprog + (size_t)(c - 1) * QSTRIDE;
-        unsigned have = 0;
-#pragma unroll 1
-        for (int b = 0; b < 8; ++b) {
-            if (have < (unsigned)(b + 1)) {
-                have = wg_wait_val(sh, a, sprog, (unsigned)(b + 1), 0x600u);
-                if (!have) return false;
-            }
-        }
-    }
-    diagcore::diag5_init_flags(sh.u.diag5);
-    __syncthreads();
-    __syncthreads();
-    __builtin_amdgcn_s_setprio(3);
-    diagcore::diag5_leaf_loop(sh.u.diag5, nullptr);
-    return true;
-}
-
-__device__ __attribute__((noinline)) bool diag5_update_role(const Args &a, Shared &sh, int c) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int l15 = lane & 15, l4 = lane >> 4;
-    double *C = a.A + (int64_t)c * NB + (int64_t)c * NB * a.lda;
-    diagcore::v4d acc[diagcore::NSLOT5];
-    diagcore::diag_v5_load(C, a.lda, acc);
-    if (c > 0) {
-        const double *Lp = a.A + (int64_t)c * NB + (int64_t)(c - 1) * NB * a.lda;  // tile (c, c-1), produced by S(c, c-1)
-        const unsigned *sprog = a.sprog + (size_t)(c - 1) * QSTRIDE;
-        unsigned have = 0;  // 16-column panels of tile (c, c-1) known to be published
-#pragma unroll 1
-        for (int b = 0; b < 8; ++b) {
-            if (have < (unsigned)(b + 1)) {
-                have = wg_wait_val(sh, a, sprog, (unsigned)(b + 1), 0x600u);
-                if (!have) return false;
-            }
-            double op[8][4];
-#pragma unroll
-            for (int xb = 0; xb < 8; ++xb)
-#pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2) op[xb][s2] = *(const gf64 *)&Lp[(16 * xb + l15) + (int64_t)(16 * b + 4 * s2 + l4) * a.lda];
-#pragma unroll
-            for (int ti = 0; ti < 8; ++ti)
-#pragma unroll
-                for (int tj = 0; tj <= ti; ++tj) {
-                    if (diagcore::owner5(ti) == wave) {
-#pragma unroll
-                        for (int s2 = 0; s2 < 4; ++s2)
-                            acc[diagcore::slot5(ti, tj)] =
-                                __builtin_amdgcn_mfma_f64_16x16x4f64(-op[tj][s2], op[ti][s2], acc[diagcore::slot5(ti, tj)], 0, 0, 0);
-                    }
-                }
-        }
-    }
-    __syncthreads();  // flags are zero (leaf role) before anybody sets one
-    diagcore::diag5_stage_first(sh.u.diag5, acc);
-    __syncthreads();
-    __builtin_amdgcn_s_setprio(3);
-    diagcore::diag5_update_loop<true, true>(C, a.lda, sh.u.diag5, acc, a.itg + (size_t)c * 8 * 256, a.dprog + (size_t)c * QSTRIDE, nullptr);
-    return true;
-}
-
-__device__ __attribute__((noinline)) bool run_diag5(const Args &a, Shared &sh, const Job jb) {
-    const int c = jb.c;
-    unsigned long long *tr = a.trace ? a.trace + (size_t)(2 * c) * 8 : nullptr;
-    MEGA_STAMP(0);
-    // all panels but the last one (c - 1) through the GEMM loop; the last one is folded in as S(c, c-1) publishes it
-    if (!window_part<128>(a, sh, c, c, c - 1, 0, tr)) return false;
-    MEGA_STAMP(1);
-    JLOG(4);
-    const int wave = threadIdx.x >> 6;
-    double *C = a.A + (int64_t)c * NB + (int64_t)c * NB * a.lda;
-    double *Linv = a.linv + (size_t)c * NB * NB;
-    JLOG(5);
-    const bool ok = (wave == 0) ? diag5_leaf_role(a, sh, c) : diag5_update_role(a, sh, c);
-    __builtin_amdgcn_s_setprio(1);
-    if (!ok) return false;  // (abort / timeout inside a workgroup-wide wait: every wave saw the same result)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    const int bad = sh.u.diag5.bad;
-    if (bad) {
-        if (threadIdx.x == 0) {
-            *(__attribute__((address_space(1))) int *)a.info = c * NB + bad;
-            stf(a.ctl + CTL_ABORT, 1u);
-        }
-        return false;
-    }
-    if (threadIdx.x == 64) stf(a.dprog + (size_t)c * QSTRIDE, 8u);
-    MEGA_STAMP(3);
-    diagcore::diag5_inverse<true>(Linv, sh.u.diag5);
-    JLOG(6);
-    wg_drain();
-    if (threadIdx.x == 0) {
-        stf(a.tdone + (size_t)c * a.NT + c, 2u);
-        addf(a.ctl + CTL_PCOLS, 1u);
-    }
-    MEGA_STAMP(4);
-    (void)C;
-    return true;
-}
-
 // T(i, half, c): rows [64 half, 64 half + 64) of tile (i,c).  Half-height tiles keep a row's column-to-column recurrence
 // L(i,c-1) -> update -> solve -> L(i,c) (two dependent 64 x 128 x 128 GEMMs on one CU that is shared with a bulk job)
 // faster than the diagonal chain; with 128-row tiles the rows fall behind it.
@@ -771,7 +665,7 @@ __global__ __launch_bounds__(256, 2) void potrf_mega_kernel(const Args a) {
             if (idx < 0) break;
             const Job jb = a.cjobs[idx];
             jlog_begin(a, sh, jb);
-            if (!(jb.kind == JOB_P ? (a.diag_v5 ? run_diag5(a, sh, jb) : run_diag(a, sh, jb)) : run_stream(a, sh, jb))) break;
+            if (!(jb.kind == JOB_P ? run_diag(a, sh, jb) : run_stream(a, sh, jb))) break;
             jlog_end(sh);
         }
         if (a.use_quiet && threadIdx.x == 0) addf(myquiet, 0xffffffffu);
@@ -995,7 +889,6 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
     a.srows = srows;
     a.spin_ticks = (unsigned long long)std::max(1, ctx->spin_ms) * 100000ull;  // wall_clock64 runs at 100 MHz
     a.fault = (ctx->debug_fault & 1) && MT > 1;
-    a.diag_v5 = ctx->diag_impl == 3 ? 1 : 0;  // experimental: measured no faster than v4 inside this kernel
     // small matrices: one workgroup per CU is plenty (and leaves room for other contexts' launches: mrbf_batch_run)
     const int grid = (NT <= 16 && ctx->mega_grid > 256) ? 256 : ctx->mega_grid;
     if (a.nchain < 1) a.nchain = 1;

@@ -445,30 +445,6 @@ def test_builtin_cholesky_matches_lapack(ctx, n):
         assert info.value == bad + 1, (impl, info.value)
 
 
-@pytest.mark.parametrize("n", [256, 1536])
-def test_wave_specialised_diagonal_kernel_matches_lapack(ctx, n):
-    # MRBF_OPT_DIAG_IMPL = 3 (chol_diag_core.hpp v5: leaf wave + update waves, LDS flags) through both drivers
-    rng = np.random.Generator(np.random.PCG64(n + 1))
-    G = rng.standard_normal((n, n + 20))
-    A = G @ G.T / n + np.eye(n)
-    Lref = np.linalg.cholesky(A)
-    ctx.set_option(_lib.OPT_DIAG_IMPL, 3)
-    try:
-        for impl in (2, 3):
-            F = np.asfortranarray(A.copy())
-            info = ctypes.c_int32(-7)
-            ctx.check(ctx.lib.mrbf_debug_potrf(ctx.h, n, _lib.as_ptr(F), impl, ctypes.byref(info), None))
-            assert info.value == 0
-            assert np.abs(np.tril(F) - Lref).max() < 1e-12 * np.abs(Lref).max()
-        B = A.copy()
-        B[100, 100] = -1.0
-        F = np.asfortranarray(B)
-        ctx.check(ctx.lib.mrbf_debug_potrf(ctx.h, n, _lib.as_ptr(F), 3, ctypes.byref(info), None))
-        assert info.value == 101
-    finally:
-        ctx.set_option(_lib.OPT_DIAG_IMPL, 0)
-
-
 @pytest.mark.parametrize("n", [900, 1300, 1800, 2300, 2900])
 def test_fit_same_weights_with_all_cholesky_implementations(ctx, n):
     C, Y = _synthetic(n, 20, 2, seed=77)

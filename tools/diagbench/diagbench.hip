@@ -1,5 +1,5 @@
-// Stand-alone timing of the 128 x 128 diagonal-block cores (chol_diag_core.hpp): v4 (workgroup barriers) against v5 (wave-specialised,
-// LDS flags), one workgroup, with v5's per-step cycle stamps.  Build:
+// Stand-alone timing of the 128 x 128 diagonal-block core (chol_diag_core.hpp), one workgroup.  (Round 2 also timed a wave-specialised
+// variant with LDS flags instead of workgroup barriers here: 54-59 us per block against 55-57 us, not kept -- DESIGN.md section 3.)  Build:
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I/opt/rocm/include -I../../morbit.jl_amd/csrc -o diagbench diagbench.hip
 #include "chol_diag_core.hpp"
 
@@ -10,22 +10,16 @@ using namespace mrbf;
 
 template <int V>
 __global__ __launch_bounds__(256, 2) void k(double *A, double *Linv, int *info, unsigned long long *ts, int reps) {
-    __shared__ __attribute__((aligned(16))) union {
+    __shared__ __attribute__((aligned(16))) struct {
         diagcore::DiagV4Shared s4;
-        diagcore::DiagV5Shared s5;
     } sh;
     __builtin_amdgcn_s_setprio(3);
     for (int r = 0; r < reps; ++r) {
         double *Ar = A + (size_t)r * 128 * 128;
         const unsigned long long t0 = __builtin_readcyclecounter();
         int bad;
-        if (V == 4) {
-            diagcore::v4d acc[diagcore::NSLOT];
-            bad = diagcore::diag_v4_core<true, false, false>(Ar, 128, Linv, sh.s4, acc, nullptr, nullptr, 0);
-        } else {
-            diagcore::v4d acc[diagcore::NSLOT5];
-            bad = diagcore::diag_v5_core<true, false, false>(Ar, 128, Linv, sh.s5, acc, nullptr, nullptr, r == reps - 1 ? ts + 8 : nullptr);
-        }
+        diagcore::v4d acc[diagcore::NSLOT];
+        bad = diagcore::diag_v4_core<true, false, false>(Ar, 128, Linv, sh.s4, acc, nullptr, nullptr, 0);
         __syncthreads();
         if (threadIdx.x == 0) {
             ts[0] += __builtin_readcyclecounter() - t0;
@@ -53,7 +47,7 @@ int main() {
     hipMalloc(&dL, 128 * 128 * 8);
     hipMalloc(&dinfo, 4);
     hipMalloc(&dts, 64 * 8);
-    for (int v = 4; v <= 5; ++v) {
+    for (int v = 4; v <= 4; ++v) {
         for (int r = 0; r < reps; ++r) std::copy(A.begin(), A.end(), all.begin() + (size_t)r * 128 * 128);
         hipMemcpy(dA, all.data(), all.size() * 8, hipMemcpyHostToDevice);
         hipMemset(dinfo, 0, 4);
@@ -62,10 +56,7 @@ int main() {
         hipEventCreate(&e0);
         hipEventCreate(&e1);
         hipEventRecord(e0, 0);
-        if (v == 4)
-            hipLaunchKernelGGL(k<4>, dim3(1), dim3(256), 0, 0, dA, dL, dinfo, dts, reps);
-        else
-            hipLaunchKernelGGL(k<5>, dim3(1), dim3(256), 0, 0, dA, dL, dinfo, dts, reps);
+        hipLaunchKernelGGL(k<4>, dim3(1), dim3(256), 0, 0, dA, dL, dinfo, dts, reps);
         hipEventRecord(e1, 0);
         hipEventSynchronize(e1);
         float ms;
@@ -88,12 +79,6 @@ int main() {
             }
         printf("v%d: %.2f us per block (events), %.0f cycles per block (shader clock), info %d, |LL'-A| %.1e |Linv L - I| %.1e\n", v,
                ms * 1e3 / reps, (double)ts[0] / reps, info, e, ei);
-        if (v == 5) {
-            printf("   step: leaf start -> leaf end | update wave sees leaf | next tile handed over   (cycles from the first leaf start)\n");
-            for (int b = 0; b < 8; ++b)
-                printf("   b=%d  %8lld %8lld | %8lld | %8lld\n", b, (long long)(ts[8 + 4 * b] - ts[8]), (long long)(ts[8 + 4 * b + 1] - ts[8]),
-                       (long long)(ts[8 + 4 * b + 2] - ts[8]), (long long)(ts[8 + 4 * b + 3] - ts[8]));
-        }
     }
     return 0;
 }
