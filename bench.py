@@ -227,6 +227,7 @@ def main():
                 self.sums = torch.empty(2, dtype=torch.float64, device="cuda")
                 self.phases = {p: 0.0 for p in PH}
                 self.fallbacks = 0
+                self.factor_ms = []   # per cycle: spread of the dominant kernel (a stalled persistent launch must show up here)
 
             def cycle(self, p):
                 ctx, lib, finfo, einfo = self.ctx, self.ctx.lib, self.finfo, self.einfo
@@ -241,6 +242,7 @@ def main():
                 ph["gram"] += finfo.ms_gram
                 ph["project"] += finfo.ms_project
                 ph["factor"] += finfo.ms_factor
+                self.factor_ms.append(float(finfo.ms_factor))
                 ph["solve"] += finfo.ms_solve
                 ph["eval"] += einfo.ms_total if m > 0 else 0.0
                 if finfo.fallbacks & ~_lib.FB_LU:
@@ -280,6 +282,8 @@ def main():
         for p in PH:
             w.phases[p] = 0.0
         w.fallbacks = 0
+        if hasattr(w, "factor_ms"):
+            w.factor_ms.clear()
     barrier()
     t0 = time.perf_counter()
     table = None
@@ -301,6 +305,10 @@ def main():
     nfb = sum(w.fallbacks for w in workers)
     if nfb:
         check["fits_with_fallback"] = nfb
+    fm = sorted(v for w in workers for v in getattr(w, "factor_ms", []))
+    if fm:
+        med = fm[len(fm) // 2]
+        check["factor_ms"] = dict(min=fm[0], median=med, max=fm[-1], slow_launches=sum(1 for v in fm if v > 1.5 * med))
 
     if rank == 0:
         alg = wl.algorithmic(args.config)

@@ -265,15 +265,23 @@ int launch_cross_gram(mrbf_ctx *ctx, const double *X, int64_t m, const double *C
 // CU -- so that some workgroup is storing at (almost) any time.  Wave w owns columns 32 w .. 32 w + 31 of the tile.
 template <int KID, bool FAST>
 __global__ __launch_bounds__(256, 4) void gram_mfma64_kernel(const double *__restrict__ Xc, const double *__restrict__ sq, int64_t n,
-                                                             int dpad, double *__restrict__ Phi, int64_t ld, KP p, int aligned16) {
+                                                             int dpad, double *__restrict__ Phi, int64_t ld, KP p, int aligned16, int npairs,
+                                                             int remap) {
     __shared__ __attribute__((aligned(16))) double smem[(64 + GBM) * GLD];
     double *As = smem;             // 64 rows
     double *Bs = smem + 64 * GLD;  // 128 rows
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
+    // workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8): keep the two halves of a tile pair, which stage the same
+    // 128 centre rows J, on ONE XCD's L2 (blocks b and b + 8), and give an XCD every eighth pair of a tile row (shared rows I)
     int ti, tj;
-    tri_decode(blockIdx.x >> 1, ti, tj);
-    const int half = blockIdx.x & 1;
+    const int xb = blockIdx.x & 7, grp = blockIdx.x >> 3;
+    int pair = xb + 8 * (grp >> 1), half = grp & 1;
+    if (remap == 0 || pair >= npairs) {  // tail of a grid that is not a multiple of 16: the plain order
+        pair = blockIdx.x >> 1;
+        half = blockIdx.x & 1;
+    }
+    tri_decode(pair, ti, tj);
     const int64_t I0 = (int64_t)ti * GBM + 64 * half, J0 = (int64_t)tj * GBM;
     v4d acc[4][2];
 #pragma unroll
@@ -388,8 +396,11 @@ int launch_gram(mrbf_ctx *ctx, int mode, const double *C, const double *Xc, cons
         static const int occ3 = getenv("MRBF_GRAM_OCC3") ? atoi(getenv("MRBF_GRAM_OCC3")) : 0;
         static const int rows64 = getenv("MRBF_GRAM_ROWS64") ? atoi(getenv("MRBF_GRAM_ROWS64")) : 1;
         if (kp.fast && rows64 && nb >= 512) {
+            // the remap needs whole groups of 16 blocks (8 pairs x 2 halves); a ragged tail falls back to the plain order inside the kernel
+            static const int remap_env = getenv("MRBF_GRAM_REMAP") ? atoi(getenv("MRBF_GRAM_REMAP")) : 1;
+            const int remap = (remap_env && nb % 8 == 0) ? 1 : 0;
             MRBF_DISPATCH_KID(kp.kid, hipLaunchKernelGGL((gram_mfma64_kernel<KID, true>), dim3((unsigned)(2 * nb)), dim3(256), 0, ctx->stream,
-                                                         Xc, sq, n, dpad, Phi, ld, kp, aligned16));
+                                                         Xc, sq, n, dpad, Phi, ld, kp, aligned16, (int)nb, remap));
         } else if (kp.fast && occ3) {
             MRBF_DISPATCH_KID(kp.kid, hipLaunchKernelGGL((gram_mfma_kernel<KID, true, 3>), dim3((unsigned)nb), dim3(256), 0,
                                                          ctx->stream, Xc, sq, n, dpad, Phi, ld, kp, aligned16));
