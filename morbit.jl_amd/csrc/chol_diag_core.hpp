@@ -119,14 +119,19 @@ __device__ __forceinline__ void diag_v4_load(const double *__restrict__ A, int64
 // leaf inverse) are visible to other workgroups -- a consumer can run the panel solve of the tiles below in step.
 template <bool SC1, bool STREAM, bool PRELOADED>
 __device__ __forceinline__ int diag_v4_core(double *__restrict__ A, int64_t lda, double *__restrict__ Linv, DiagV4Shared &sh,
-                                            v4d (&acc)[NSLOT], double *__restrict__ itg, unsigned *prog, int dbg = 0) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l15 = lane & 15, l4 = lane >> 4;
+                                            v4d (&acc)[NSLOT], double *__restrict__ itg, unsigned *prog, int dbg = 0,
+                                            unsigned long long *segout = nullptr) {
+    // the wave index is uniform: as a scalar the role branches below are s_cbranch instead of exec-mask juggling
+    const int tid = threadIdx.x, lane_ = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (tid == 0) sh.bad = 0;
-    unsigned long long tseg[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;  // timing experiments (dbg & 4): wave 0's cycles per segment
+    // timing experiments (dbg & 4): cycles per segment of one wave -- wave 0 (segments: pre-leaf, leaf, post-leaf, barrier X,
+    // look-ahead, barrier Y) or, with dbg & 8, wave (dbg >> 4) & 3 (rest of the trailing update, store drain, barrier X, leaf /
+    // inverse stores + operand fetch, panel solve, barrier Y, panel stores + next column's update)
+    unsigned long long tseg[7] = {0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+    const int tw = (dbg & 8) ? (dbg >> 4) & 3 : 0;
 #define MRBF_DSEG(k)                                         \
     do {                                                     \
-        if (dbg & 4) {                                       \
+        if ((dbg & 4) && wave == tw) {                       \
             const unsigned long long now_ = __builtin_readcyclecounter(); \
             tseg[k] += now_ - tlast;                         \
             tlast = now_;                                    \
@@ -138,6 +143,13 @@ __device__ __forceinline__ int diag_v4_core(double *__restrict__ A, int64_t lda,
 
 #pragma unroll 1
     for (int b = 0; b < NT; ++b) {
+        // per-iteration opaque copy of the lane index: everything derived from it (LDS addresses of 28 tiles, lane masks, the
+        // identity rows of the leaf) is otherwise hoisted out of this loop, spilled, and reloaded behind s_waitcnt vmcnt(0) --
+        // i.e. behind the write-through stores of the previous panel -- in the middle of the sequential chain (measured: the
+        // wave that stores the leaf spent ~2800 cycles per panel there)
+        int lane = lane_;
+        asm volatile("" : "+v"(lane));
+        const int l15 = lane & 15, l4 = lane >> 4;
         if (wave == 0) {
             // ---- wave 0: finish diagonal tile (b,b) with panel b-1 (the only update the next leaf waits for), then the leaf
             if (STREAM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own write-through stores of the previous leaf
@@ -219,12 +231,17 @@ __device__ __forceinline__ int diag_v4_core(double *__restrict__ A, int64_t lda,
                         acc[tile_slot(i, j)] = c;
                     }
                 }
+            MRBF_DSEG(0);
             // panel b-1's write-through stores were issued a leaf ago: draining them here costs nothing
             if (STREAM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            MRBF_DSEG(1);
         }
         if (wave == 0) MRBF_DSEG(2);
         __syncthreads();  // X: leaf inverse IT[b] visible
-        if (wave == 0) MRBF_DSEG(3);
+        if (wave == 0)
+            MRBF_DSEG(3);
+        else
+            MRBF_DSEG(2);
         if (sh.bad) break;
         if (STREAM && b > 0 && tid == 64)
             __hip_atomic_store((__attribute__((address_space(1))) unsigned *)prog, (unsigned)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -245,6 +262,10 @@ __device__ __forceinline__ int diag_v4_core(double *__restrict__ A, int64_t lda,
             double ia[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) ia[s] = opnd(itb, s, l15, l4);
+            if (dbg & 8) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                MRBF_DSEG(3);
+            }
 #pragma unroll
             for (int i = 1; i < NT; ++i)
 #pragma unroll
@@ -273,9 +294,9 @@ __device__ __forceinline__ int diag_v4_core(double *__restrict__ A, int64_t lda,
                 }
             }
         }
-        if (wave == 0) MRBF_DSEG(4);
+        MRBF_DSEG(4);
         __syncthreads();  // Y: panel tiles of block column b in LT
-        if (wave == 0) MRBF_DSEG(5);
+        MRBF_DSEG(5);
         if (wave != 0) {
             // L(i,b) -> global, behind the barrier the leaf wave waits at (coalesced along rows)
 #pragma unroll
@@ -303,14 +324,21 @@ __device__ __forceinline__ int diag_v4_core(double *__restrict__ A, int64_t lda,
                         acc[tile_slot(i, j)] = c;
                     }
                 }
+            MRBF_DSEG(6);
         }
     }
     if (STREAM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    const int lane = lane_, l15 = lane & 15, l4 = lane >> 4;
     const int bad_all = sh.bad;
     if (bad_all) return bad_all;
-    if ((dbg & 4) && tid == 0) {
-        for (int k = 0; k < 6; ++k) Linv[k] = (double)tseg[k];
+    if ((dbg & 4) && lane_ == 0 && wave == tw) {
+        for (int k = 0; k < (segout ? 7 : 6); ++k) {
+            if (segout)
+                segout[k] = tseg[k];
+            else
+                Linv[k] = (double)tseg[k];
+        }
     }
     if (dbg & 1) return 0;  // timing experiments: no inverse
     if (STREAM && tid == 64)
@@ -353,6 +381,7 @@ __device__ __forceinline__ int diag_v4_core(double *__restrict__ A, int64_t lda,
             gstore<SC1>(&Linv[row + (16 * j + col) * DNB], 0.0);
         }
     }
+    if ((dbg & 4) && tid == 0 && tw == 0 && segout) segout[6] = __builtin_readcyclecounter() - tlast;  // the inverse, wave 0's share
     return 0;
 }
 

@@ -95,6 +95,7 @@ struct Args {
     int slack, slack_chain, first, win, wbias, srows;
     unsigned long long *jlog;   // diagnostic launches only: 8 words per job (meta, claim, 5 stage stamps, end), jlog[0] = count
     int jlog_cap;
+    int trace_dbg;              // diagnostic launches only: dbg word of the diagonal core (4 = time wave 0, 4 + 8 + 16 w = time wave w)
     unsigned long long *trace;  // diagnostic launches only: 8 time stamps (10 ns units) per chain job (P(c), T(c+1,c))
 };
 
@@ -321,7 +322,8 @@ __device__ __forceinline__ void store_tile(double *__restrict__ C, int64_t ldc, 
 // ucnt counts half tiles: a full 128-row job adds 2, a 64-row job 1; window w of tile (i,c) may start at ucnt >= 2w
 template <int TM>
 __device__ __attribute__((noinline)) bool run_bulk(const Args &a, Shared &sh, const Job jb) {
-    const int i = jb.i, c = jb.c, w = jb.w & 255, roff = (TM == 64) ? 64 * (jb.w >> 8) : 0;
+    const int i = __builtin_amdgcn_readfirstlane(jb.i), c = __builtin_amdgcn_readfirstlane(jb.c), jw = __builtin_amdgcn_readfirstlane(jb.w);
+    const int w = jw & 255, roff = (TM == 64) ? 64 * (jw >> 8) : 0;
     const int pl = wstart(w + 1, a.first, a.win) - 1;  // last panel of the window: rows finish their panels in order
     if (!wg_wait(sh, a, a.tdone + (size_t)i * a.NT + pl, 2u, a.tdone + (size_t)c * a.NT + pl, 2u, a.ucnt + (size_t)i * a.NT + c,
                  (unsigned)(2 * w), 0x100u))
@@ -347,7 +349,7 @@ __device__ __attribute__((noinline)) bool run_bulk(const Args &a, Shared &sh, co
 // written back in place (plain stores: only this workgroup reads X again).  TM = 64 handles rows [roff, roff + 64) of
 // block row i.  Returns false on abort.
 template <int TM>
-__device__ __attribute__((noinline)) bool window_part(const Args &a, Shared &sh, int i, int c, int pend, int roff,
+__device__ __forceinline__ bool window_part(const Args &a, Shared &sh, int i, int c, int pend, int roff,
                                                       unsigned long long *tr) {
     const int wc = nbulk_updates(i, c, a.slack, a.slack_chain, a.first, a.win, a.srows), p0 = wstart(wc, a.first, a.win);
     const unsigned *uc = a.ucnt + (size_t)i * a.NT + c;
@@ -397,7 +399,7 @@ __device__ __attribute__((noinline)) bool window_part(const Args &a, Shared &sh,
 // Wave v owns rows 32v .. 32v+31 of the tile as 2 x 8 tiles of 16 x 16 in the MFMA C/D layout (lane l, register r:
 // X[16u + (l & 15)][16q + (l >> 4) + 4r]), which is directly the B operand of the next MFMA.
 __device__ __attribute__((noinline)) bool run_stream(const Args &a, Shared &sh, const Job jb) {
-    const int i = jb.i, c = jb.c;
+    const int i = __builtin_amdgcn_readfirstlane(jb.i), c = __builtin_amdgcn_readfirstlane(jb.c);  // uniform: addresses and flags in SGPRs
     if (!window_part<128>(a, sh, i, c, c, 0, nullptr)) return false;
     JLOG(4);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -466,9 +468,12 @@ __device__ __attribute__((noinline)) bool run_stream(const Args &a, Shared &sh, 
         if (tr && threadIdx.x == 0) tr[k] = wall_clock64();                    \
     } while (0)
 
+// TRACED: diagnostic launches (time stamps of the job, cycle counts of one wave of the diagonal core)
+template <bool TRACED>
 __device__ __attribute__((noinline)) bool run_diag(const Args &a, Shared &sh, const Job jb) {
-    const int c = jb.c;
-    unsigned long long *tr = a.trace ? a.trace + (size_t)(2 * c) * 8 : nullptr;
+    const int c = __builtin_amdgcn_readfirstlane(jb.c);  // uniform: tile / flag addresses stay in SGPRs (spilled VGPR addresses used to
+                                                         // be reloaded behind s_waitcnt vmcnt(0), i.e. behind the write-through stores)
+    unsigned long long *tr = TRACED ? a.trace + (size_t)(2 * c) * 8 : nullptr;
     MEGA_STAMP(0);
     // all panels but the last one (c - 1) through the GEMM loop; the last one is folded in as S(c, c-1) publishes it
     if (!window_part<128>(a, sh, c, c, c - 1, 0, tr)) return false;
@@ -511,8 +516,13 @@ __device__ __attribute__((noinline)) bool run_diag(const Args &a, Shared &sh, co
     MEGA_STAMP(2);
     JLOG(5);
     __builtin_amdgcn_s_setprio(3);
-    const int bad = diagcore::diag_v4_core<true, true, true>(C, a.lda, Linv, sh.u.diag, acc, a.itg + (size_t)c * 8 * 256,
-                                                             a.dprog + (size_t)c * QSTRIDE);
+    int bad;
+    if constexpr (TRACED)
+        bad = diagcore::diag_v4_core<true, true, true>(C, a.lda, Linv, sh.u.diag, acc, a.itg + (size_t)c * 8 * 256,
+                                                       a.dprog + (size_t)c * QSTRIDE, a.trace_dbg, tr + 8);
+    else
+        bad = diagcore::diag_v4_core<true, true, true>(C, a.lda, Linv, sh.u.diag, acc, a.itg + (size_t)c * 8 * 256,
+                                                       a.dprog + (size_t)c * QSTRIDE);
     __builtin_amdgcn_s_setprio(1);
     if (bad) {
         if (threadIdx.x == 0) {
@@ -536,7 +546,7 @@ __device__ __attribute__((noinline)) bool run_diag(const Args &a, Shared &sh, co
 // L(i,c-1) -> update -> solve -> L(i,c) (two dependent 64 x 128 x 128 GEMMs on one CU that is shared with a bulk job)
 // faster than the diagonal chain; with 128-row tiles the rows fall behind it.
 __device__ __attribute__((noinline)) bool run_panel(const Args &a, Shared &sh, const Job jb) {
-    const int i = jb.i, c = jb.c, roff = 64 * jb.w;
+    const int i = __builtin_amdgcn_readfirstlane(jb.i), c = __builtin_amdgcn_readfirstlane(jb.c), roff = 64 * __builtin_amdgcn_readfirstlane(jb.w);
     if (!window_part<64>(a, sh, i, c, c, roff, nullptr)) return false;
     JLOG(4);
     double *C = a.A + (int64_t)i * NB + roff + (int64_t)c * NB * a.lda;
@@ -549,7 +559,7 @@ __device__ __attribute__((noinline)) bool run_panel(const Args &a, Shared &sh, c
     gemm_acc<64>(C, a.lda, Linv, NB, NB, acc, sh.u.gemm);  // every wave's loads of X are complete behind the loop's last barrier
     store_tile<64, false, false, true>(C, a.lda, acc);
     wg_drain();
-    if (a.fault && i == a.MT - 1 && c == 0 && jb.w == 0) return true;  // test hook: this half tile is never published
+    if (a.fault && i == a.MT - 1 && c == 0 && roff == 0) return true;  // test hook: this half tile is never published
     if (threadIdx.x == 0) addf(a.tdone + (size_t)i * a.NT + c, 1u);
     return true;
 }
@@ -665,7 +675,7 @@ __global__ __launch_bounds__(256, 2) void potrf_mega_kernel(const Args a) {
             if (idx < 0) break;
             const Job jb = a.cjobs[idx];
             jlog_begin(a, sh, jb);
-            if (!(jb.kind == JOB_P ? run_diag(a, sh, jb) : run_stream(a, sh, jb))) break;
+            if (!(jb.kind == JOB_P ? (a.trace ? run_diag<true>(a, sh, jb) : run_diag<false>(a, sh, jb)) : run_stream(a, sh, jb))) break;
             jlog_end(sh);
         }
         if (a.use_quiet && threadIdx.x == 0) addf(myquiet, 0xffffffffu);
@@ -895,6 +905,7 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
     if (a.nchain + a.ndedicated >= grid) a.ndedicated = std::max(0, grid / 2 - a.nchain);
     const char *trace_path = getenv("MRBF_MEGA_TRACE");
     if (trace_path) {
+        a.trace_dbg = getenv("MRBF_MEGA_TRACE_WAVE") ? 12 + 16 * (atoi(getenv("MRBF_MEGA_TRACE_WAVE")) & 3) : 4;
         MRBF_TRY(get_buf(ctx, S_MEGA_TRACE, (size_t)NT * 16 + 4 * 1024, &a.trace));
         MRBF_HIP(ctx, hipMemsetAsync(a.trace, 0, ((size_t)NT * 16 + 4 * 1024) * sizeof(unsigned long long), ctx->stream));
     }
@@ -931,7 +942,8 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
             const unsigned long long t0 = h[0];
             for (int c = 0; c < NT; ++c) {
                 fprintf(f, "%d", c);
-                for (int k = 0; k < 16; ++k) fprintf(f, " %.2f", h[(size_t)c * 16 + k] ? (double)(h[(size_t)c * 16 + k] - t0) * 0.01 : -1.0);
+                for (int k = 0; k < 8; ++k) fprintf(f, " %.2f", h[(size_t)c * 16 + k] ? (double)(h[(size_t)c * 16 + k] - t0) * 0.01 : -1.0);
+                for (int k = 8; k < 16; ++k) fprintf(f, " %.0f", (double)h[(size_t)c * 16 + k]);  // cycle counts, not time stamps
                 fprintf(f, "\n");
             }
             std::vector<unsigned long long> u(4 * 1024);

@@ -4,22 +4,24 @@
 #include "chol_diag_core.hpp"
 
 #include <cstdio>
+#include <cstdlib>
 #include <random>
 #include <vector>
 using namespace mrbf;
 
 template <int V>
-__global__ __launch_bounds__(256, 2) void k(double *A, double *Linv, int *info, unsigned long long *ts, int reps) {
+__global__ __launch_bounds__(256, 2) void k(double *A, double *Linv, int *info, unsigned long long *ts, int reps, int dbg) {
     __shared__ __attribute__((aligned(16))) struct {
         diagcore::DiagV4Shared s4;
     } sh;
     __builtin_amdgcn_s_setprio(3);
+    if ((threadIdx.x & 63) == 0) ts[16 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_getreg((31 << 11) | 4);  // HW_REG_HW_ID
     for (int r = 0; r < reps; ++r) {
         double *Ar = A + (size_t)r * 128 * 128;
         const unsigned long long t0 = __builtin_readcyclecounter();
         int bad;
         diagcore::v4d acc[diagcore::NSLOT];
-        bad = diagcore::diag_v4_core<true, false, false>(Ar, 128, Linv, sh.s4, acc, nullptr, nullptr, 0);
+        bad = diagcore::diag_v4_core<true, false, false>(Ar, 128, Linv, sh.s4, acc, nullptr, nullptr, dbg);
         __syncthreads();
         if (threadIdx.x == 0) {
             ts[0] += __builtin_readcyclecounter() - t0;
@@ -28,8 +30,9 @@ __global__ __launch_bounds__(256, 2) void k(double *A, double *Linv, int *info, 
     }
 }
 
-int main() {
-    const int reps = 64;
+int main(int argc, char **argv) {
+    const int dbg = argc > 1 ? atoi(argv[1]) : 0;  // 4: per-segment cycles of the leaf wave (no inverse check then)
+    const int reps = dbg ? 1 : 64;
     std::mt19937_64 g(1);
     std::normal_distribution<double> nd;
     std::vector<double> G(128 * 160), A(128 * 128), all((size_t)reps * 128 * 128), L(128 * 128), Li(128 * 128);
@@ -56,7 +59,7 @@ int main() {
         hipEventCreate(&e0);
         hipEventCreate(&e1);
         hipEventRecord(e0, 0);
-        hipLaunchKernelGGL(k<4>, dim3(1), dim3(256), 0, 0, dA, dL, dinfo, dts, reps);
+        hipLaunchKernelGGL(k<4>, dim3(1), dim3(256), 0, 0, dA, dL, dinfo, dts, reps, dbg);
         hipEventRecord(e1, 0);
         hipEventSynchronize(e1);
         float ms;
@@ -77,6 +80,11 @@ int main() {
                 e = std::max(e, std::fabs(s - A[i + j * 128]));
                 ei = std::max(ei, std::fabs(t - (i == j)));
             }
+        if (dbg & 4)
+            printf("leaf wave cycles over 8 panels: pre-leaf %.0f, leaf %.0f, post-leaf LDS %.0f, barrier X %.0f, look-ahead work %.0f, barrier Y %.0f\n", Li[0], Li[1], Li[2], Li[3], Li[4], Li[5]);
+        printf("wave -> simd:");
+        for (int w = 0; w < 4; ++w) printf(" %llu(cu %llu)", (ts[16 + w] >> 4) & 3, (ts[16 + w] >> 8) & 15);
+        printf("\n");
         printf("v%d: %.2f us per block (events), %.0f cycles per block (shader clock), info %d, |LL'-A| %.1e |Linv L - I| %.1e\n", v,
                ms * 1e3 / reps, (double)ts[0] / reps, info, e, ei);
     }

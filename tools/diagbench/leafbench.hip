@@ -1,0 +1,148 @@
+// Latency of one column step of the 16 x 16 leaf factorisation, one wave, variants (round 2 experiment, NOT kept in the product).
+// Idea: in the MFMA C/D layout column K of the leaf is register K >> 2 of lane group K & 3 -- exactly k-slice K & 3 of an MFMA
+// operand -- so the rank-1 update of the whole leaf is one v_mfma_f64_16x16x4 with the other k-slices zero and nothing crosses
+// lanes but the pivot.  Measured on MI355X (cycles per column): MFMA leaf without inverse 185, with inverse 261-319, round-1
+// leaf (v_readlane broadcasts, inverse included) 191: a dependent f64 MFMA costs ~117 cycles and occupies the SIMD's f64 pipe,
+// so the one-instruction update does not beat 15 readlane + fma pairs.  Build:
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I/opt/rocm/include -I../../morbit.jl_amd/csrc -I../../include -o leafbench leafbench.hip
+#include "chol_diag_core.hpp"
+
+#include <cstdio>
+#include <vector>
+using namespace mrbf;
+using diagcore::v4d;
+
+// round-1 leaf: rows in lanes 0..15, identity rows in lanes 16..31, one register per column, v_readlane broadcasts
+template <int K>
+__device__ __forceinline__ void old_step(double (&a)[16]) {
+    const double piv = diagcore::readlane_f64(a[K], K);
+    const double rinv = diagcore::fast_rsqrt_v4(piv);
+    a[K] *= rinv;
+#pragma unroll
+    for (int j = K + 1; j < 16; ++j) {
+        const double ljk = diagcore::readlane_f64(a[K], j);
+        a[j] = fma(-a[K], ljk, a[j]);
+    }
+}
+__global__ __launch_bounds__(64) void kold(const double *A, double *out, unsigned long long *ts, int reps) {
+    const int lane = threadIdx.x;
+    double a0[16], acc = 0.0;
+    for (int c = 0; c < 16; ++c) a0[c] = lane < 16 ? (c <= lane ? A[lane + 16 * c] : 0.0) : (c == lane - 16 ? 1.0 : 0.0);
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < reps; ++it) {
+        double a[16];
+        for (int c = 0; c < 16; ++c) a[c] = a0[c];
+        old_step<0>(a); old_step<1>(a); old_step<2>(a); old_step<3>(a); old_step<4>(a); old_step<5>(a); old_step<6>(a); old_step<7>(a);
+        old_step<8>(a); old_step<9>(a); old_step<10>(a); old_step<11>(a); old_step<12>(a); old_step<13>(a); old_step<14>(a); old_step<15>(a);
+        for (int c = 0; c < 16; ++c) acc += a[c];
+        a0[0] += acc * 1e-300;
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    out[lane] = acc;
+    if (lane == 0) ts[5] = t1 - t0;
+}
+
+template <int V, int K>
+__device__ __forceinline__ void step(v4d &T, v4d &Y, v4d &Lr, v4d &Yf, double &ps, double &pu, int &bad, int l15, int l4) {
+    constexpr int g = K & 3, r = K >> 2;
+    if constexpr (V == 0) {
+        // T -= l l' and the same column operation on an identity tile (-> L^-T), the second MFMA held back by one column
+        const double piv = diagcore::readlane_f64(T[r], 16 * g + K);
+        __builtin_amdgcn_sched_barrier(0);
+        if (K > 0) Y = __builtin_amdgcn_mfma_f64_16x16x4f64(-ps, pu, Y, 0, 0, 0);
+        const double rinv = diagcore::fast_rsqrt_v4(piv);
+        const bool ing = l4 == g;
+        const double lv = T[r] * rinv;
+        const double ls = (ing && l15 > K) ? lv : 0.0;
+        if (K < 15) T = __builtin_amdgcn_mfma_f64_16x16x4f64(-ls, ls, T, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        const double u = ing ? Y[r] * rinv : 0.0;
+        Lr[r] = (ing && l15 >= K) ? lv : Lr[r];
+        Yf[r] = ing ? u : Yf[r];
+        ps = ls;
+        pu = u;
+    } else if constexpr (V == 1) {  // no inverse
+        const double piv = diagcore::readlane_f64(T[r], 16 * g + K);
+        const double rinv = diagcore::fast_rsqrt_v4(piv);
+        const bool ing = l4 == g;
+        const double lv = T[r] * rinv;
+        Lr[r] = (ing && l15 >= K) ? lv : Lr[r];
+        const double ls = (ing && l15 > K) ? lv : 0.0;
+        T = __builtin_amdgcn_mfma_f64_16x16x4f64(-ls, ls, T, 0, 0, 0);
+    } else if constexpr (V == 2) {  // no rsqrt chain: readlane -> mul -> mfma
+        const double piv = diagcore::readlane_f64(T[r], 16 * g + K);
+        const bool ing = l4 == g;
+        const double lv = T[r] * piv;
+        const double ls = (ing && l15 > K) ? lv : 0.0;
+        T = __builtin_amdgcn_mfma_f64_16x16x4f64(-ls, ls, T, 0, 0, 0);
+    } else if constexpr (V == 3) {  // mfma -> mfma through one VALU op (no readlane)
+        const double lv = T[r] * 0.5;
+        T = __builtin_amdgcn_mfma_f64_16x16x4f64(-lv, lv, T, 0, 0, 0);
+    } else if constexpr (V == 4) {  // 4x4x4 f64 mfma chain through one VALU op
+        const double lv = T[0] * 0.5;
+        const double o = __builtin_amdgcn_mfma_f64_4x4x4f64(-lv, lv, T[0], 0, 0, 0);
+        T[0] = o;
+    }
+}
+
+template <int V>
+__global__ __launch_bounds__(64) void k(const double *A, double *out, unsigned long long *ts, int reps) {
+    const int lane = threadIdx.x, l15 = lane & 15, l4 = lane >> 4;
+    v4d T0;
+    for (int r = 0; r < 4; ++r) T0[r] = A[l15 + (l4 + 4 * r) * 16];
+    v4d acc = {0, 0, 0, 0};
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < reps; ++it) {
+        v4d T = T0, Y, Lr = {0, 0, 0, 0}, Yf = {0, 0, 0, 0};
+        for (int r = 0; r < 4; ++r) Y[r] = (l15 == l4 + 4 * r) ? 1.0 : 0.0;
+        int bad = 0;
+        double ps = 0.0, pu = 0.0;
+        step<V, 0>(T, Y, Lr, Yf, ps, pu, bad, l15, l4);
+        step<V, 1>(T, Y, Lr, Yf, ps, pu, bad, l15, l4);
+        step<V, 2>(T, Y, Lr, Yf, ps, pu, bad, l15, l4);
+        step<V, 3>(T, Y, Lr, Yf, ps, pu, bad, l15, l4);
+        step<V, 4>(T, Y, Lr, Yf, ps, pu, bad, l15, l4);
+        step<V, 5>(T, Y, Lr, Yf, ps, pu, bad, l15, l4);
+        step<V, 6>(T, Y, Lr, Yf, ps, pu, bad, l15, l4);
+        step<V, 7>(T, Y, Lr, Yf, ps, pu, bad, l15, l4);
+        step<V, 8>(T, Y, Lr, Yf, ps, pu, bad, l15, l4);
+        step<V, 9>(T, Y, Lr, Yf, ps, pu, bad, l15, l4);
+        step<V, 10>(T, Y, Lr, Yf, ps, pu, bad, l15, l4);
+        step<V, 11>(T, Y, Lr, Yf, ps, pu, bad, l15, l4);
+        step<V, 12>(T, Y, Lr, Yf, ps, pu, bad, l15, l4);
+        step<V, 13>(T, Y, Lr, Yf, ps, pu, bad, l15, l4);
+        step<V, 14>(T, Y, Lr, Yf, ps, pu, bad, l15, l4);
+        step<V, 15>(T, Y, Lr, Yf, ps, pu, bad, l15, l4);
+        for (int r = 0; r < 4; ++r) acc[r] += Lr[r] + Yf[r] + T[r] * 1e-300;
+        T0[0] += acc[0] * 1e-300;  // keep the iterations dependent
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    for (int r = 0; r < 4; ++r) out[lane * 4 + r] = acc[r];
+    if (lane == 0) ts[V] = t1 - t0;
+}
+
+int main() {
+    std::vector<double> A(256);
+    for (int i = 0; i < 16; ++i)
+        for (int j = 0; j < 16; ++j) A[i + 16 * j] = (i == j ? 20.0 : 0.0) + 1.0 / (1 + i + j);
+    double *dA, *dout;
+    unsigned long long *dts;
+    hipMalloc(&dA, 256 * 8);
+    hipMalloc(&dout, 256 * 8);
+    hipMalloc(&dts, 64);
+    hipMemcpy(dA, A.data(), 256 * 8, hipMemcpyHostToDevice);
+    hipMemset(dts, 0, 64);
+    const int reps = 2000;
+    hipLaunchKernelGGL(k<0>, dim3(1), dim3(64), 0, 0, dA, dout, dts, reps);
+    hipLaunchKernelGGL(k<1>, dim3(1), dim3(64), 0, 0, dA, dout, dts, reps);
+    hipLaunchKernelGGL(k<2>, dim3(1), dim3(64), 0, 0, dA, dout, dts, reps);
+    hipLaunchKernelGGL(k<3>, dim3(1), dim3(64), 0, 0, dA, dout, dts, reps);
+    hipLaunchKernelGGL(k<4>, dim3(1), dim3(64), 0, 0, dA, dout, dts, reps);
+    hipLaunchKernelGGL(kold, dim3(1), dim3(64), 0, 0, dA, dout, dts, reps);
+    hipDeviceSynchronize();
+    unsigned long long ts[8];
+    hipMemcpy(ts, dts, 64, hipMemcpyDeviceToHost);
+    const char *names[6] = {"full step (T and Y mfma)", "no inverse", "readlane -> mul -> mfma", "mul -> mfma 16x16x4", "mul -> mfma 4x4x4", "round-1 leaf (readlane, with inverse)"};
+    for (int v = 0; v < 6; ++v) printf("%-28s %.1f cycles per column step\n", names[v], (double)ts[v] / reps / 16);
+    return 0;
+}

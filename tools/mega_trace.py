@@ -13,3 +13,17 @@ print("  c   wait+gemm  fold-in  factor+inv  publish | start-of-factor  step | f
 for k in range(len(c)):
     print(f"{int(c[k]):3d}  {d(P[k,0],P[k,1]):8.1f} {d(P[k,1],P[k,2]):8.1f} {d(P[k,2],P[k,3]):8.1f} {d(P[k,3],P[k,4]):6.1f} | {P[k,2]:9.1f} {step[k-1] if k else 0:7.1f} | {P[k,5]-P[k,2] if P[k,5]>=0 else float('nan'):8.1f} {P[k,6]-P[k,2] if P[k,6]>=0 else float('nan'):8.1f}")
 print("median step", np.nanmedian(step), "mean step", np.nanmean(step), "median factor+inv", np.nanmedian(d(P[:, 2], P[:, 3])), "total", P[-1, 4])
+
+S = rows[:, 9:16]
+if np.any(S > 0):
+    # second half of the record: cycle counts of the leaf wave inside the diagonal core (sums over the 8 panels), raw ticks of the shader clock
+    import os
+    names = ["pre-leaf", "leaf", "post-leaf", "barrier X", "look-ahead", "barrier Y", "tail+inverse"]
+    if os.environ.get("MRBF_MEGA_TRACE_WAVE"):
+        names = ["trailing rest", "store drain", "barrier X", "stores+operand", "panel solve", "barrier Y", "panel stores+next col"]
+    med = np.median(S[1:], axis=0)
+    tot = med.sum()
+    fac = np.nanmedian(d(P[:, 2], P[:, 3]))
+    print("diag core, leaf wave, median cycles per block (x = share; factor+inv median %.1f us -> %.0f cycles/us):" % (fac, tot / fac))
+    for n, m in zip(names, med):
+        print(f"  {n:12s} {m:9.0f}  {m/tot:5.2f}  ~{m/tot*fac:5.1f} us")
