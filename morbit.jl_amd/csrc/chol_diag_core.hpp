@@ -341,8 +341,10 @@ __device__ __forceinline__ int diag_v4_core(double *__restrict__ A, int64_t lda,
         }
     }
     if (dbg & 1) return 0;  // timing experiments: no inverse
-    if (STREAM && tid == 64)
+    if (STREAM && tid == 64) {
         __hip_atomic_store((__attribute__((address_space(1))) unsigned *)prog, (unsigned)NT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((dbg & 4) && segout) segout[7] = wall_clock64();  // all eight panels published
+    }
 
     // ---- inverse: wave w assembles block columns w and 7 - w of X = L^-1 in registers, MFMA C/D layout
 #pragma unroll

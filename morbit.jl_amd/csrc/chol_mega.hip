@@ -9,10 +9,13 @@
 //   P(c)      diagonal tile: left-looking part over the newest panels, the last one folded in 16 columns at a time as
 //             S(c, c-1) publishes it, then Cholesky + inverse of the factor (chol_diag_core.hpp), which itself publishes
 //             every finished 16-column panel of L_cc and its 16 x 16 leaf inverse
-//   S(i,c)    the two tiles right below the diagonal (i = c+1, c+2): the panel solve run in step with P(c) -- each
+//   S(i,c)    the `srows` tiles right below the diagonal (i = c+1 ..): the panel solve run in step with P(c) -- each
 //             published panel is applied to the 128 x 128 tile held in registers (MFMA, accumulator-as-operand), the tile's
 //             own 16-column panel published in turn: the next diagonal factorisation starts ~10 us after the previous
-//             one ends instead of after two dependent 128^3 GEMMs
+//             one ends instead of after two dependent 128^3 GEMMs.  Like P, an S job takes the newest panel (c-1) of its
+//             left-looking part 16 columns at a time from the S jobs of the previous block column as THEY publish it: a
+//             128^3 update is 14 us of one CU's matrix pipe, and taken in one piece after the previous column had finished
+//             it made every S job start ~25 us into P(c) and end ~14 us after it (job log r02, tools/mega_gap.py)
 //   T(i,h,c)  the other panel tiles in 64-row halves: left-looking part, then  L(i,c) = X * inv(L_cc)'  (a GEMM with the
 //             stored inverse).  Half height keeps a row's column-to-column recurrence faster than the diagonal chain.
 //   U(i,c,w)  bulk update of tile (i,c) with the panels of window w  (K = 128 x window length, read-modify-write)
@@ -80,7 +83,7 @@ struct Args {
     unsigned *wq_head;    // [nwin] x QSTRIDE claimed jobs per window
     double *itg;          // NT x 8 x 256: 16 x 16 leaf inverses of every diagonal block (streamed panel solves)
     unsigned *dprog;      // [NT] x QSTRIDE: 16-column panels of diagonal block c that are published
-    unsigned *sprog;      // [2][NT] x QSTRIDE: 16-column panels of tile (c + 1 + k, c) that are published
+    unsigned *sprog;      // [srows][NT] x QSTRIDE: 16-column panels of tile (c + 1 + k, c) that are published
     unsigned *quiet;      // [512] x QSTRIDE per-CU count of chain-critical jobs in flight: the CU's other workgroup pauses
     int nwin;
     int *info;
@@ -175,6 +178,24 @@ __device__ __forceinline__ unsigned wg_wait_val(Shared &sh, const Args &a, const
     if (threadIdx.x == 0) {
         unsigned v = 0;
         if (poll_ge(f, want, a, code)) v = ldf(f);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        sh.ok = (int)v;
+    }
+    __syncthreads();
+    const unsigned v = (unsigned)sh.ok;
+    __syncthreads();
+    return v;
+}
+
+// Same for two producers that are followed in step: waits until both words are >= want, returns the smaller of the two values.
+__device__ __forceinline__ unsigned wg_wait_val2(Shared &sh, const Args &a, const unsigned *f0, const unsigned *f1, unsigned want, unsigned code) {
+    if (threadIdx.x == 0) {
+        unsigned v = 0;
+        if (poll_ge(f0, want, a, code) && poll_ge(f1, want, a, code + 1)) {
+            const unsigned v0 = ldf(f0), v1 = ldf(f1);
+            v = v0 < v1 ? v0 : v1;
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         sh.ok = (int)v;
@@ -400,15 +421,16 @@ __device__ __forceinline__ bool window_part(const Args &a, Shared &sh, int i, in
 // X[16u + (l & 15)][16q + (l >> 4) + 4r]), which is directly the B operand of the next MFMA.
 __device__ __attribute__((noinline)) bool run_stream(const Args &a, Shared &sh, const Job jb) {
     const int i = __builtin_amdgcn_readfirstlane(jb.i), c = __builtin_amdgcn_readfirstlane(jb.c);  // uniform: addresses and flags in SGPRs
-    if (!window_part<128>(a, sh, i, c, c, 0, nullptr)) return false;
+    // all left-looking panels but the newest (c - 1) through the GEMM loop, in place
+    if (!window_part<128>(a, sh, i, c, c > 0 ? c - 1 : 0, 0, nullptr)) return false;
     JLOG(4);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l15 = lane & 15, l4 = lane >> 4;
     double *C = a.A + (int64_t)i * NB + (int64_t)c * NB * a.lda;
     const double *Lcc = a.A + (int64_t)c * NB + (int64_t)c * NB * a.lda;
     const double *itg = a.itg + (size_t)c * 8 * 256;
     const unsigned *dprog = a.dprog + (size_t)c * QSTRIDE;
-    unsigned *sprog = (i == c + 1) ? a.sprog + (size_t)c * QSTRIDE : nullptr;  // only the diagonal job's feeder is followed
+    unsigned *sprog = a.sprog + ((size_t)(i - c - 1) * a.NT + c) * QSTRIDE;
     v4d x[2][8];
 #pragma unroll
     for (int u = 0; u < 2; ++u)
@@ -417,6 +439,39 @@ __device__ __attribute__((noinline)) bool run_stream(const Args &a, Shared &sh, 
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 x[u][q][r] = *(const gf64 *)&C[(32 * wave + 16 * u + l15) + (int64_t)(16 * q + l4 + 4 * r) * a.lda];
+    if (c > 0) {
+        // X -= L(i,c-1) L(c,c-1)', 16 columns at a time: L(c,c-1) is the first streamed tile of block column c-1, L(i,c-1) the
+        // (i-c+1)-th one, or -- the last S row -- a T tile that is awaited whole
+        const double *Lr = a.A + (int64_t)i * NB + (int64_t)(c - 1) * NB * a.lda;
+        const double *Lc = a.A + (int64_t)c * NB + (int64_t)(c - 1) * NB * a.lda;
+        const unsigned *fc = a.sprog + (size_t)(c - 1) * QSTRIDE;
+        const bool row_streamed = i - c < a.srows;
+        const unsigned *fr = a.sprog + ((size_t)(i - c) * a.NT + (c - 1)) * QSTRIDE;
+        if (!row_streamed && !wg_wait(sh, a, a.tdone + (size_t)i * a.NT + (c - 1), 2u, nullptr, 0, nullptr, 0, 0x520u)) return false;
+        unsigned got = 0;
+#pragma unroll 1
+        for (int b = 0; b < 8; ++b) {
+            if (got < (unsigned)(b + 1)) {
+                got = row_streamed ? wg_wait_val2(sh, a, fr, fc, (unsigned)(b + 1), 0x510u) : wg_wait_val(sh, a, fc, (unsigned)(b + 1), 0x512u);
+                if (!got) return false;
+            }
+            double opc[8][4], opr[2][4];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) opr[u][s2] = *(const gf64 *)&Lr[(32 * wave + 16 * u + l15) + (int64_t)(16 * b + 4 * s2 + l4) * a.lda];
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) opc[q][s2] = *(const gf64 *)&Lc[(16 * q + l15) + (int64_t)(16 * b + 4 * s2 + l4) * a.lda];
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int s2 = 0; s2 < 4; ++s2) x[u][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-opc[q][s2], opr[u][s2], x[u][q], 0, 0, 0);
+        }
+    }
     unsigned have = 0;  // panels of the diagonal block known to be published
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
@@ -455,7 +510,7 @@ __device__ __attribute__((noinline)) bool run_stream(const Args &a, Shared &sh, 
         if (have < 8u || b == 7) {
             wg_drain();
             if (threadIdx.x == 0) {
-                if (sprog) stf(sprog, (unsigned)(b + 1));
+                stf(sprog, (unsigned)(b + 1));
                 if (b == 7) stf(a.tdone + (size_t)i * a.NT + c, 2u);
             }
         }
@@ -874,7 +929,7 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
     MRBF_TRY(get_buf(ctx, S_MEGA_WQ, (size_t)a.nwin + 1, &dwq));
     a.wq_start = dwq;
     // flags: one block, zeroed before every launch
-    const size_t nfl = ((size_t)CTL_WORDS + (size_t)QSTRIDE * (a.nwin + 1) + (size_t)QSTRIDE * 512 + (size_t)QSTRIDE * 3 * NT + 2 * (size_t)MT * NT + 3) / 4 * 4;
+    const size_t nfl = ((size_t)CTL_WORDS + (size_t)QSTRIDE * (a.nwin + 1) + (size_t)QSTRIDE * 512 + (size_t)QSTRIDE * (1 + srows) * NT + 2 * (size_t)MT * NT + 3) / 4 * 4;
     unsigned *fl;
     MRBF_TRY(get_buf(ctx, S_MEGA_FLAGS, nfl, &fl));
     MRBF_HIP(ctx, hipMemsetAsync(fl, 0, nfl * sizeof(unsigned), ctx->stream));
@@ -884,7 +939,7 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
     a.quiet = a.wq_head + (size_t)QSTRIDE * (a.nwin + 1);
     a.dprog = a.quiet + (size_t)QSTRIDE * 512;
     a.sprog = a.dprog + (size_t)QSTRIDE * NT;
-    a.tdone = a.sprog + (size_t)QSTRIDE * 2 * NT;
+    a.tdone = a.sprog + (size_t)QSTRIDE * srows * NT;
     a.ucnt = a.tdone + (size_t)MT * NT;
     a.info = dinfo;
     a.nchain = ctx->mega_chain;
@@ -943,7 +998,8 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
             for (int c = 0; c < NT; ++c) {
                 fprintf(f, "%d", c);
                 for (int k = 0; k < 8; ++k) fprintf(f, " %.2f", h[(size_t)c * 16 + k] ? (double)(h[(size_t)c * 16 + k] - t0) * 0.01 : -1.0);
-                for (int k = 8; k < 16; ++k) fprintf(f, " %.0f", (double)h[(size_t)c * 16 + k]);  // cycle counts, not time stamps
+                for (int k = 8; k < 15; ++k) fprintf(f, " %.0f", (double)h[(size_t)c * 16 + k]);  // cycle counts, not time stamps
+                fprintf(f, " %.2f", h[(size_t)c * 16 + 15] ? (double)(h[(size_t)c * 16 + 15] - t0) * 0.01 : -1.0);  // last panel published
                 fprintf(f, "\n");
             }
             std::vector<unsigned long long> u(4 * 1024);

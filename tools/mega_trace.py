@@ -27,3 +27,10 @@ if np.any(S > 0):
     print("diag core, leaf wave, median cycles per block (x = share; factor+inv median %.1f us -> %.0f cycles/us):" % (fac, tot / fac))
     for n, m in zip(names, med):
         print(f"  {n:12s} {m:9.0f}  {m/tot:5.2f}  ~{m/tot*fac:5.1f} us")
+
+    pub = rows[:, 16]
+    if np.any(pub > 0):
+        gap = P[1:, 2] - pub[:-1]    # last panel of P(c) published -> P(c+1) starts its factorisation
+        core = pub - P[:, 2]          # start of the factorisation -> last panel published
+        print("start of factorisation -> last panel published: median %.1f us;  published -> next block's factorisation starts: median %.1f us (min %.1f, max %.1f)"
+              % (np.median(core), np.median(gap), gap.min(), gap.max()))
