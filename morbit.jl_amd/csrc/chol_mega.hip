@@ -405,6 +405,7 @@ __device__ __forceinline__ bool window_part(const Args &a, Shared &sh, int i, in
         p += run;
     }
     // the bulk updates of this tile must be in memory before it is read back
+    if (tr && threadIdx.x == 0) tr[7] = wall_clock64();  // GEMM part done, waiting for the tile's bulk updates
     if (!wg_wait(sh, a, uc, (unsigned)(2 * wc), nullptr, 0, nullptr, 0, 0x212u)) return false;
     double *C = a.A + (int64_t)i * NB + roff + (int64_t)c * NB * a.lda;
     if (TM == 128 && i == c)
@@ -534,7 +535,7 @@ __device__ __attribute__((noinline)) bool run_diag(const Args &a, Shared &sh, co
     if (!window_part<128>(a, sh, c, c, c - 1, 0, tr)) return false;
     MEGA_STAMP(1);
     JLOG(4);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l15 = lane & 15, l4 = lane >> 4;
     double *C = a.A + (int64_t)c * NB + (int64_t)c * NB * a.lda;
     double *Linv = a.linv + (size_t)c * NB * NB;

@@ -12,6 +12,12 @@ step = np.diff(P[:, 2])
 print("  c   wait+gemm  fold-in  factor+inv  publish | start-of-factor  step | first-dep-ready last-dep-ready (relative to start of factor)")
 for k in range(len(c)):
     print(f"{int(c[k]):3d}  {d(P[k,0],P[k,1]):8.1f} {d(P[k,1],P[k,2]):8.1f} {d(P[k,2],P[k,3]):8.1f} {d(P[k,3],P[k,4]):6.1f} | {P[k,2]:9.1f} {step[k-1] if k else 0:7.1f} | {P[k,5]-P[k,2] if P[k,5]>=0 else float('nan'):8.1f} {P[k,6]-P[k,2] if P[k,6]>=0 else float('nan'):8.1f}")
+if np.any(P[:, 7] > 0):
+    w = d(P[:, 7], P[:, 1])
+    print("left-looking GEMM done -> tile written back (wait for the bulk updates + read-modify-write): median %.1f us, max %.1f; per column:" % (np.nanmedian(w), np.nanmax(w)))
+    print(" ".join(f"{x:.0f}" for x in w))
+    print("tile written back -> factorisation starts (streamed fold of the last panel):")
+    print(" ".join(f"{x:.0f}" for x in d(P[:, 1], P[:, 2])))
 print("median step", np.nanmedian(step), "mean step", np.nanmean(step), "median factor+inv", np.nanmedian(d(P[:, 2], P[:, 3])), "total", P[-1, 4])
 
 S = rows[:, 9:16]
