@@ -334,6 +334,25 @@ __device__ __forceinline__ void store_tile(double *__restrict__ C, int64_t ldc, 
     }
 }
 
+// acc = -C in the layout of store_tile (a bulk job starts from the tile instead of ending with a read-modify-write: the
+// four dependent load / store round trips of the epilogue become one load burst under the pipeline's prologue)
+template <int TM>
+__device__ __forceinline__ void load_tile_neg(const double *__restrict__ C, int64_t ldc, v4d (&acc)[TM / 32][4]) {
+    constexpr int NJ = TM / 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int ioff = (TM == 128) ? (wave >> 1) * 64 : 0;
+    const int joff = (TM == 128) ? (wave & 1) * 64 : wave * 32;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t gj = joff + j * 16 + l4 + 4 * r;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[j][i][r] = -*(const gf64 *)&C[(ioff + i * 16 + l15) + gj * ldc];
+        }
+}
+
 #define JLOG(k)                                                             \
     do {                                                                   \
         if (sh.jrec && threadIdx.x == 0) sh.jrec[k] = wall_clock64();      \
@@ -351,16 +370,20 @@ __device__ __attribute__((noinline)) bool run_bulk(const Args &a, Shared &sh, co
         return false;
     JLOG(2);
     v4d acc[TM / 32][4];
-    zero_acc(acc);
+    double *C = a.A + (int64_t)i * NB + roff + (int64_t)c * NB * a.lda;
+    load_tile_neg<TM>(C, a.lda, acc);  // the tile's earlier bulk updates are in (ucnt, awaited above)
     const int64_t k0 = (int64_t)wstart(w, a.first, a.win) * NB;
     gemm_acc<TM>(a.A + (int64_t)i * NB + roff + k0 * a.lda, a.lda, a.A + (int64_t)c * NB + k0 * a.lda, a.lda,
                  (wstart(w + 1, a.first, a.win) - wstart(w, a.first, a.win)) * NB, acc, sh.u.gemm);
-    double *C = a.A + (int64_t)i * NB + roff + (int64_t)c * NB * a.lda;
     JLOG(3);
+#pragma unroll
+    for (int j = 0; j < TM / 32; ++j)
+#pragma unroll
+        for (int i2 = 0; i2 < 4; ++i2) acc[j][i2] = -acc[j][i2];
     if (TM == 128 && i == c)
-        store_tile<TM, true, true, true>(C, a.lda, acc);
+        store_tile<TM, false, true, true>(C, a.lda, acc);
     else
-        store_tile<TM, true, false, true>(C, a.lda, acc);
+        store_tile<TM, false, false, true>(C, a.lda, acc);
     wg_drain();
     if (threadIdx.x == 0) addf(a.ucnt + (size_t)i * a.NT + c, TM == 128 ? 2u : 1u);
     return true;
