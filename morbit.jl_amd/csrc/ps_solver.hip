@@ -99,6 +99,8 @@ __global__ __launch_bounds__(256) void ps_init_kernel(Args a, const double *xn, 
         }
         R.X[0][e] = v;
         R.S[0][e] = (hi - lo) / sqrt((double)n);
+        const int skip = R.kind == 1 ? 1 : 0;  // the evaluation batch holds the x part of every individual of every run
+        if (j >= skip) a.Xeval[(size_t)(R.off + i) * a.d + (j - skip)] = v;
     }
     if (threadIdx.x == 0) {
         R.best[n] = INFINITY;
@@ -106,17 +108,6 @@ __global__ __launch_bounds__(256) void ps_init_kernel(Args a, const double *xn, 
         R.stat[0] = 0;
         R.stat[1] = 0;
         R.stat[2] = 0;
-    }
-}
-
-// the evaluation batch: the x part of every individual of every run
-__global__ __launch_bounds__(256) void ps_gather_kernel(Args a) {
-    const Run &R = a.runs[blockIdx.y];
-    const int n = R.nvar, d = a.d, skip = R.kind == 1 ? 1 : 0;
-    const double *X = R.X[a.gen & 1];
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < R.lam * d; e += gridDim.x * 256) {
-        const int i = e / d, j = e % d;
-        a.Xeval[(size_t)(R.off + i) * d + j] = X[(size_t)i * n + skip + j];
     }
 }
 
@@ -220,9 +211,49 @@ __global__ __launch_bounds__(256) void ps_step_kernel(Args a) {
     //      probability 0.45, else by the constraint violation (Runarsson & Yao)
     // (the records themselves are swapped -- one LDS round trip per phase instead of an index indirection; one Philox call feeds
     //  four phases of a pair; one barrier per phase; the no-swap exit is tested every 16 phases)
+    // If no individual inside the budget violates a constraint (always so for the ideal-point runs, usually so late in a PS run)
+    // every comparison of the pairwise rule is decided by (violation, objective) whatever is drawn, and lam phases of the stable
+    // transposition sort end in THE sorted order (ties by index): a bitonic network over the padded array reaches the same
+    // order in log2(N) (log2(N) + 1) / 2 phases (45 instead of 260 at lam = 260).
+    __shared__ int s_infeas;
+    if (tid == 0) s_infeas = 0;
+    __syncthreads();
+    for (int i = tid; i < lam; i += 256)
+        if (sphi[i] > 0.0 && sphi[i] < INFINITY) s_infeas = 1;
+    __syncthreads();
+    const bool plain_sort = s_infeas == 0 && !(a.dbg & 4);
+    if (plain_sort && !(a.dbg & 1)) {
+        int N = 1;
+        while (N < lam) N <<= 1;
+        for (int i = lam + tid; i < N; i += 256) {
+            sf[i] = INFINITY;
+            sphi[i] = INFINITY;
+            sidx[i] = 0x7fffffff;
+        }
+        __syncthreads();
+        for (int kk = 2; kk <= N; kk <<= 1)
+            for (int j = kk >> 1; j > 0; j >>= 1) {
+                for (int t = tid; t < N / 2; t += 256) {
+                    const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;  // the t-th pair of this stage
+                    const double fa = sf[i], fb = sf[l], pa = sphi[i], pb = sphi[l];
+                    const int ia = sidx[i], ib = sidx[l];
+                    const bool greater = pa > pb || (pa == pb && (fa > fb || (fa == fb && ia > ib)));
+                    const bool up = (i & kk) == 0;
+                    if (greater == up) {
+                        sf[i] = fb;
+                        sf[l] = fa;
+                        sphi[i] = pb;
+                        sphi[l] = pa;
+                        sidx[i] = ib;
+                        sidx[l] = ia;
+                    }
+                }
+                __syncthreads();
+            }
+    }
     if (tid == 0) s_swapped = 1;
     __syncthreads();
-    for (int ph0 = 0; ph0 < ((a.dbg & 1) ? 0 : lam); ph0 += 4) {
+    for (int ph0 = 0; ph0 < (((a.dbg & 1) || plain_sort) ? 0 : lam); ph0 += 4) {
         if ((ph0 & 15) == 0) {
             const int sw = s_swapped;
             __syncthreads();
@@ -292,6 +323,8 @@ __global__ __launch_bounds__(256) void ps_step_kernel(Args a) {
         const int par = sidx[o % mu];
         const double *xp = X + (size_t)par * n, *sp = S + (size_t)par * n;
         double *xo = Xn + (size_t)o * n, *so = Sn + (size_t)o * n;
+        const int skip = R.kind == 1 ? 1 : 0;
+        double *xe = a.Xeval + (size_t)(R.off + o) * a.d;  // next generation's row of the evaluation batch (x part)
         if (o < nd) {
             // differential variation towards the best individual; kept only if it stays inside the box
             const double *xb = X + (size_t)sidx[0] * n, *xq = X + (size_t)sidx[o + 1] * n;
@@ -301,8 +334,10 @@ __global__ __launch_bounds__(256) void ps_step_kernel(Args a) {
                 inside = inside && v >= lo_at(c) && v <= hi_at(c);
             }
             for (int c = 0; c < n; ++c) {
-                xo[c] = inside ? xp[c] + gamma * (xb[c] - xq[c]) : xp[c];
+                const double v = inside ? xp[c] + gamma * (xb[c] - xq[c]) : xp[c];
+                xo[c] = v;
                 so[c] = sp[c];
+                if (c >= skip) xe[c - skip] = v;
             }
         } else {
             double u0, u1, zg, z1;
@@ -321,6 +356,7 @@ __global__ __launch_bounds__(256) void ps_step_kernel(Args a) {
                 }
                 if (v < lo || v > hi) v = xp[c];
                 xo[c] = v;
+                if (c >= skip) xe[c - skip] = v;
                 so[c] = sp[c] + alpha * (s - sp[c]);  // exponential smoothing
             }
         }
@@ -465,7 +501,6 @@ extern "C" int32_t mrbf_ps_step(mrbf_ctx *ctx, const mrbf_model *model, const do
         std::vector<int> hstat((size_t)4 * a.nruns);
         for (int g = 0; g < max_gens; ++g) {
             a.gen = g;
-            hipLaunchKernelGGL(ps_gather_kernel, dim3(8, (unsigned)a.nruns), dim3(256), 0, ctx->stream, a);
             MRBF_TRY(eval_model(ctx, model, rows_now, a.Xeval, const_cast<double *>(a.F), nullptr, nullptr));
             hipLaunchKernelGGL(ps_step_kernel, dim3((unsigned)a.nruns), dim3(256), 0, ctx->stream, a);
             if ((g & 7) == 7 || g + 1 == max_gens) {  // status words every 8 generations: stop when every run is done

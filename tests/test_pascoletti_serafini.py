@@ -183,6 +183,15 @@ def test_ps_step_with_the_solver_on_the_device(d, n, given_dir):
     stats2 = {}
     omega2, (xt2, _, _) = ps.get_criticality_device(cfg, mod, x, x, fx, lb, ub, seed=11, stats=stats2)
     assert omega2 == omega and np.array_equal(xt2, xt)
+    # generations without an infeasible individual are ranked by a bitonic network instead of the transposition phases: the
+    # order (hence the whole trajectory) must be the same as with the phases everywhere (MRBF_PS_DBG=4 switches the network off)
+    import os
+    os.environ["MRBF_PS_DBG"] = "4"
+    try:
+        omega3, (xt3, _, _) = ps.get_criticality_device(cfg, mod, x, x, fx, lb, ub, seed=11)
+    finally:
+        del os.environ["MRBF_PS_DBG"]
+    assert omega3 == omega and np.array_equal(xt3, xt)
     # at least as good as the host-loop mirror on the same problem with the same direction (both are stochastic: 20 % slack)
     cfg_r = ps.PascolettiSerafiniConfig(reference_direction=list(r))
     omega_h, _ = ps.get_criticality(cfg_r, x, x, fx, lb, ub, ev, rng=np.random.default_rng(3))[:2]
