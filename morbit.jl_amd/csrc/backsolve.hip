@@ -7,8 +7,11 @@
 // L(j+1,j) and inv(L_jj), are fetched into REGISTERS before the wait, each thread holding 32 consecutive rows of one
 // column, so after the flag the product is 32 x k FMAs per thread and one LDS reduction -- a step of the chain costs a
 // flag hand-off plus ~1 us instead of a kernel boundary plus two LDS-staged tile passes.
-// Hand-off (MI355X: XCD L2s are not coherent): x_j is stored write-through (sc1), the workgroup drains and meets at a
-// barrier, one lane stores the flag with an agent-scope atomic; consumers poll the flag and read x_j with sc1 loads.
+// Hand-off (MI355X: XCD L2s are not coherent): the data is its own flag.  x_j goes to an exchange buffer that the host
+// filled with an all-ones pattern (a NaN no arithmetic produces); the producer's threads store their entries write-through
+// (sc1) and are done -- no drain, no barrier, no flag store; each consumer thread polls ITS entry with sc1 loads until it is
+// no longer the pattern.  A step of the chain loses the producer's ~1.5 us store drain and one ~1 us flag round trip
+// (round 2: 6.2 -> ~4 us per step).
 #include "common.hpp"
 
 namespace mrbf {
@@ -63,7 +66,8 @@ __device__ __forceinline__ void tile_product(Shared<KB> &sh, const v2d (&r)[RPT 
 template <int KB>
 __global__ __launch_bounds__(NTHR, 1) void backsolve_persistent_kernel(const double *__restrict__ L, int64_t lda, const double *__restrict__ linv_all,
                                                                         double *__restrict__ Y, int64_t ldy, int k0, int nb, unsigned *flags,
-                                                                        unsigned epoch, unsigned long long spin_ticks, int *status, int fault) {
+                                                                        unsigned epoch, unsigned long long spin_ticks, int *status, int fault,
+                                                                        double *__restrict__ xb) {
     __shared__ Shared<KB> sh;
     // block nb-1 (which depends on nothing) is dispatched first, block 0 last: every workgroup only waits for workgroups that were
     // dispatched BEFORE it, so the launch drains at any residency (other kernels holding CUs, several contexts on one GPU)
@@ -76,19 +80,23 @@ __global__ __launch_bounds__(NTHR, 1) void backsolve_persistent_kernel(const dou
     v2d tnext[RPT / 2], tinv[RPT / 2];
     if (j + 1 < nb) load_tile(L + (int64_t)(j + 1) * NB + (int64_t)j * NB * lda, lda, tnext);
     load_tile(linv_all + (size_t)j * NB * NB, NB, tinv);
+    if (tid == 0) sh.ok = 1;
     __syncthreads();
     for (int i = nb - 1; i > j; --i) {
         v2d ts[RPT / 2];
         if (i > j + 1) load_tile(L + (int64_t)i * NB + (int64_t)j * NB * lda, lda, ts);  // in flight under the wait
-        if (tid == 0) {
-            int ok = 1;
+        // x_i: every thread of the first KB * 128 polls its own entry of the exchange buffer (write-through by the producer, read
+        // past the L1) until it is no longer the fill pattern
+        if (tid < KB * NB) {
+            const gf64 *src = (const gf64 *)&xb[((size_t)i * KB + tid / NB) * NB + (tid % NB)];
+            double v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             unsigned spins = 0;
             unsigned long long t0 = 0;
-            while (__hip_atomic_load((const gu32 *)(flags + i * 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+            while (__double_as_longlong(v) == -1ll) {
                 if ((++spins & 63u) == 0u) {
                     // somebody else gave up: stop at once instead of timing out one dependant after the other
                     if (__hip_atomic_load((const gu32 *)abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-                        ok = 0;
+                        sh.ok = 0;
                         break;
                     }
                     const unsigned long long now = wall_clock64();
@@ -96,21 +104,17 @@ __global__ __launch_bounds__(NTHR, 1) void backsolve_persistent_kernel(const dou
                     if (now - t0 > spin_ticks) {
                         __hip_atomic_store((gu32 *)abortw, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         *(__attribute__((address_space(1))) int *)status = 0x700 + (i & 0xff);  // read back with the factorisation's flags
-                        ok = 0;
+                        sh.ok = 0;
                         break;
                     }
                 }
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(1);
+                v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            sh.ok = ok;
+            sh.xs[tid / NB][tid % NB] = v;
         }
         __syncthreads();
         if (!sh.ok) return;  // gave up: the abort word is set, the host re-runs the solve with backsolve_blocked
-        // x_i: write-through by its producer, read past the L1 (sc1)
-        if (tid < KB * NB)
-            sh.xs[tid / NB][tid % NB] =
-                __hip_atomic_load((const gf64 *)&Y[(int64_t)(k0 + tid / NB) * ldy + (int64_t)i * NB + (tid % NB)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
         if (i > j + 1)
             tile_product<KB>(sh, ts);
         else
@@ -137,13 +141,12 @@ __global__ __launch_bounds__(NTHR, 1) void backsolve_persistent_kernel(const dou
         if (g == 0) {
 #pragma unroll
             for (int l = 0; l < KB; ++l) {
-                const double s = (sh.part[l][0][c] + sh.part[l][1][c]) + (sh.part[l][2][c] + sh.part[l][3][c]);
-                __hip_atomic_store((gf64 *)&Y[(int64_t)(k0 + l) * ldy + (int64_t)j * NB + c], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                double s = (sh.part[l][0][c] + sh.part[l][1][c]) + (sh.part[l][2][c] + sh.part[l][3][c]);
+                if (__double_as_longlong(s) == -1ll) s = __longlong_as_double(0x7ff8000000000000ll);  // never publish the fill pattern
+                __hip_atomic_store((gf64 *)&xb[((size_t)j * KB + l) * NB + c], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the hand-off
+                Y[(int64_t)(k0 + l) * ldy + (int64_t)j * NB + c] = s;                                                         // the result
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store((gu32 *)(flags + j * 32), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -168,13 +171,16 @@ int backsolve_persistent(mrbf_ctx *ctx, int64_t npad, const double *L, int64_t l
     MRBF_HIP(ctx, hipMemsetAsync(flags, 0, (size_t)(nb + 1) * 32 * sizeof(unsigned), ctx->stream));
     const unsigned long long spin_ticks = (unsigned long long)std::max(1, ctx->spin_ms) * 100000ull;  // wall_clock64: 100 MHz
     const int fault = (ctx->debug_fault & 2) ? 1 : 0;
+    double *xb;
+    MRBF_TRY(get_buf(ctx, S_BSOLVE_X, (size_t)nb * 4 * NB, &xb));
     unsigned epoch = 0;
     for (int k0 = 0; k0 < k; k0 += 4) {
         const int kb = std::min(4, k - k0);
         ++epoch;
+        MRBF_HIP(ctx, hipMemsetAsync(xb, 0xff, (size_t)nb * 4 * NB * sizeof(double), ctx->stream));  // "not published yet"
 #define MRBF_BSP(KBV)                                                                                                          \
     hipLaunchKernelGGL((backsolve_persistent_kernel<KBV>), dim3((unsigned)nb), dim3(NTHR), 0, ctx->stream, L, lda, linv_all, Y, ldy, k0, nb, \
-                       flags, epoch, spin_ticks, status, fault)
+                       flags, epoch, spin_ticks, status, fault, xb)
         if (kb == 1) MRBF_BSP(1); else if (kb == 2) MRBF_BSP(2); else if (kb == 3) MRBF_BSP(3); else MRBF_BSP(4);
 #undef MRBF_BSP
     }
