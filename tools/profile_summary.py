@@ -21,7 +21,13 @@ PHASES = [
 ]
 
 
+MEGA = False  # set when the trace holds the persistent factorisation: the blocked-Cholesky kernels then belong to the projection
+              # (rank-2q update of K, Cholesky-QR of the tail basis), not to the factorisation
+
+
 def phase_of(name):
+    if MEGA and ("chol_update_kernel" in name or "chol_diag" in name):
+        return "project_misc"
     for ph, keys in PHASES:
         if any(k in name for k in keys):
             return ph
@@ -46,6 +52,8 @@ def pmc_sum(db, counter):
 
 
 def pmc(wdb, fdb, prefix, inv, config):
+    global MEGA
+    MEGA = any("potrf_mega_kernel" in r[0] for r in pmc_sum(wdb, "WRITE_SIZE"))
     out = {}
     detail = {}
     for db, counter, tag, scale in ((wdb, "WRITE_SIZE", "write", 1.0), (fdb, "FETCH_SIZE", "fetch", 2.0)):
