@@ -24,6 +24,8 @@ typedef __attribute__((address_space(1))) double gf64;  // explicit global addre
 constexpr int DNB = 128;
 constexpr int NT = 8;      // 16 x 16 tiles per side
 constexpr int TILE = 256;  // doubles per tile
+constexpr int ITLD = 17;   // row stride of a leaf inverse in LDS: the leaf wave writes rows, the panel waves read columns, both conflict-free
+constexpr int ITS = 16 * ITLD;
 // strictly-lower tile (i, j), j < i
 #define MRBF_SIDX(i, j) ((i) * ((i)-1) / 2 + (j))
 // lower tile incl. diagonal (register ownership map)
@@ -38,8 +40,9 @@ constexpr int NSLOT = 10;
 
 struct DiagV4Shared {
     double LT[28 * TILE];  // finished strictly-lower L tiles, [tile][c][row]  (c = column inside the tile): MFMA operand order
-    double IT[NT * TILE];  // leaf inverses transposed: IT[b][a2][a] = inv(L_bb)[a][a2]
-    double Dt[TILE];       // diagonal tile handed to the leaf wave, [col a][row b']
+    double IT[NT * ITS];   // leaf inverses transposed: IT[b][a2 * ITLD + a] = inv(L_bb)[a][a2]
+    double Dt[2 * TILE];   // diagonal tile handed to the leaf wave, [col a][32 rows]: rows 0..15 the tile, rows 16..31 the identity
+                           // (written once): the leaf wave's 32 lanes load their rows of [A_bb ; I] with one unconditional read per column
     double Lb[TILE];       // factored diagonal leaf [col][row]: stored to global memory by another wave, off the leaf wave's path
     int bad;
 };
@@ -138,6 +141,7 @@ __device__ __forceinline__ int diag_v4_core(double *__restrict__ A, int64_t lda,
         }                                                    \
     } while (0)
     if (!PRELOADED) diag_v4_load(A, lda, acc);
+    if (tid < 256) sh.Dt[(tid >> 4) * 32 + 16 + (tid & 15)] = ((tid >> 4) == (tid & 15)) ? 1.0 : 0.0;
     __syncthreads();
     if (dbg & 4) tlast = __builtin_readcyclecounter();
 
@@ -168,21 +172,16 @@ __device__ __forceinline__ int diag_v4_core(double *__restrict__ A, int64_t lda,
             for (int i = 0; i < NT; ++i)
                 if (i == b) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) sh.Dt[(l4 + 4 * r) * 16 + l15] = acc[i][r];
+                    for (int r = 0; r < 4; ++r) sh.Dt[(l4 + 4 * r) * 32 + l15] = acc[i][r];
                 }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             double a[16];
             int bad = 0;
             MRBF_DSEG(0);
+            // (entries above the diagonal of A_bb are whatever the tile held there: they stay in their own lanes and are never
+            //  broadcast -- the pivots and multipliers are read from lanes >= the column index only)
 #pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                double v;
-                if (lane < 16)
-                    v = (c <= lane) ? sh.Dt[c * 16 + lane] : 0.0;  // A_bb[row = lane][col = c]
-                else
-                    v = (c == lane - 16) ? 1.0 : 0.0;
-                a[c] = v;
-            }
+            for (int c = 0; c < 16; ++c) a[c] = sh.Dt[c * 32 + (lane & 31)];
             if (!(dbg & 2)) {
             leaf_step<0>(a, bad, 16 * b);
             leaf_step<1>(a, bad, 16 * b);
@@ -212,7 +211,7 @@ __device__ __forceinline__ int diag_v4_core(double *__restrict__ A, int64_t lda,
                 // lane 16 + r holds (L^-T)[r][c] = inv[c][r]:  IT[b][a2 = r][a = c]
                 const int r = lane - 16;
 #pragma unroll
-                for (int c = 0; c < 16; ++c) sh.IT[b * TILE + r * 16 + c] = (c >= r) ? a[c] : 0.0;
+                for (int c = 0; c < 16; ++c) sh.IT[b * ITS + r * ITLD + c] = (c >= r) ? a[c] : 0.0;
             }
         } else {
             // ---- waves 1..3 (meanwhile): the rest of panel b-1's trailing update, off-diagonal tiles (i,j), i > j > b
@@ -254,14 +253,14 @@ __device__ __forceinline__ int diag_v4_core(double *__restrict__ A, int64_t lda,
             }
         } else if (STREAM && wave == 2) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) gstore<true>(&itg[b * TILE + (l4 + 4 * r) * 16 + l15], sh.IT[b * TILE + (l4 + 4 * r) * 16 + l15]);
+            for (int r = 0; r < 4; ++r) gstore<true>(&itg[b * TILE + (l4 + 4 * r) * 16 + l15], sh.IT[b * ITS + (l4 + 4 * r) * ITLD + l15]);
         }
         if (wave != 0) {
             // ---- panel: P_i' = inv(L_bb) * A_ib'  for the owned tiles of block column b
-            const double *itb = &sh.IT[b * TILE];
+            const double *itb = &sh.IT[b * ITS];
             double ia[4];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) ia[s] = opnd(itb, s, l15, l4);
+            for (int s = 0; s < 4; ++s) ia[s] = itb[(4 * s + l4) * ITLD + l15];
             if (dbg & 8) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 MRBF_DSEG(3);
@@ -353,7 +352,7 @@ __device__ __forceinline__ int diag_v4_core(double *__restrict__ A, int64_t lda,
         v4d X[NT];
         // X_jj = inv(L_jj): C layout element [(l4 + 4r)][l15] = IT[j][l15][l4 + 4r]
 #pragma unroll
-        for (int r = 0; r < 4; ++r) X[0][r] = sh.IT[j * TILE + l15 * 16 + l4 + 4 * r];
+        for (int r = 0; r < 4; ++r) X[0][r] = sh.IT[j * ITS + l15 * ITLD + l4 + 4 * r];
 #pragma unroll
         for (int r = 0; r < 4; ++r) gstore<SC1>(&Linv[(16 * j + l4 + 4 * r) + (16 * j + l15) * DNB], X[0][r]);
 #pragma unroll
@@ -369,9 +368,9 @@ __device__ __forceinline__ int diag_v4_core(double *__restrict__ A, int64_t lda,
                     for (int s = 0; s < 4; ++s) S = __builtin_amdgcn_mfma_f64_16x16x4f64(opnd(lt, s, l15, l4), X[dp][s], S, 0, 0, 0);
                 }
                 v4d Xi = {0.0, 0.0, 0.0, 0.0};
-                const double *iti = &sh.IT[i * TILE];
+                const double *iti = &sh.IT[i * ITS];
 #pragma unroll
-                for (int s = 0; s < 4; ++s) Xi = __builtin_amdgcn_mfma_f64_16x16x4f64(-opnd(iti, s, l15, l4), S[s], Xi, 0, 0, 0);
+                for (int s = 0; s < 4; ++s) Xi = __builtin_amdgcn_mfma_f64_16x16x4f64(-iti[(4 * s + l4) * ITLD + l15], S[s], Xi, 0, 0, 0);
                 X[di] = Xi;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) gstore<SC1>(&Linv[(16 * i + l4 + 4 * r) + (16 * j + l15) * DNB], Xi[r]);
