@@ -529,14 +529,14 @@ __device__ __attribute__((noinline)) bool run_stream(const Args &a, Shared &sh, 
             for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int s2 = 0; s2 < 4; ++s2) x[u][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-lq[q][s2], xs[u][s2], x[u][q], 0, 0, 0);
-        // publish the finished 16-column panel -- unless the diagonal block is already complete and this job is only catching
-        // up: then one drain + publish at the end serves the (waiting) consumer better than eight
-        if (have < 8u || b == 7) {
-            wg_drain();
-            if (threadIdx.x == 0) {
-                stf(sprog, (unsigned)(b + 1));
-                if (b == 7) stf(a.tdone + (size_t)i * a.NT + c, 2u);
-            }
+        // publish the finished 16-column panel, also when this job is only catching up with a diagonal block that is already
+        // complete: its consumers (the next diagonal job, the next column's streamed jobs) fold panel by panel at ~3 us each and
+        // would otherwise start all eight after this job's end (seen as 17-23 us instead of 3 us between the end of S(c+1,c) and
+        // the start of P(c+1): trace r02)
+        wg_drain();
+        if (threadIdx.x == 0) {
+            stf(sprog, (unsigned)(b + 1));
+            if (b == 7) stf(a.tdone + (size_t)i * a.NT + c, 2u);
         }
     }
     return true;
