@@ -35,7 +35,8 @@ template <int TM, int MODE>
 __global__ __launch_bounds__(256, 2) void chol_update_kernel(const double *__restrict__ A, int64_t lda,
                                                              const double *__restrict__ B, int64_t ldb,
                                                              double *__restrict__ C, int64_t ldc, int K,
-                                                             const int *__restrict__ info, int mt_sq = 0, int ntiles_total = 0) {
+                                                             const int *__restrict__ info, int mt_sq = 0, int ntiles_total = 0,
+                                                             const double *__restrict__ cvec = nullptr, double cs = 0.0, int64_t cn = 0) {
     constexpr int LDA_S = TM + 16;   // LDS row strides (doubles); (2*LD) % 64 == 32 -> k and k+1 rows hit disjoint banks
     constexpr int LDB_S = 128 + 16;
     constexpr int NJ = (TM == 128) ? 4 : 2;  // 16-wide j tiles per wave
@@ -125,9 +126,29 @@ __global__ __launch_bounds__(256, 2) void chol_update_kernel(const double *__res
     // epilogue (f64 C/D map: col = lane & 15 -> i, row = (lane >> 4) + 4 r -> j).  The read-modify-write is done in
     // batches of 16 values (all loads of a batch issued before its first store): element-wise `*dst -= acc` makes the
     // compiler serialise 64 dependent load -> store round trips, because it cannot prove the addresses distinct.
+    // cvec: the rank-2 term of a constant column, C -= cs (e v' + v e') with e = 1 on the first cn rows: applied here instead of
+    // spending two of the K columns (and a whole 16-column chunk of MFMAs) on it.  Row / column values fetched once per thread.
+    double cvi[4] = {0.0, 0.0, 0.0, 0.0}, cei[4] = {0.0, 0.0, 0.0, 0.0};
+    if (MODE == UPD_LOWER_SUB && cvec) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t gi = I0 + ioff + i * 16 + l15;
+            cvi[i] = cs * cvec[gi];
+            cei[i] = gi < cn ? cs : 0.0;
+        }
+    }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         double cv[4][4];
+        double cvj[4] = {0.0, 0.0, 0.0, 0.0}, cej[4] = {0.0, 0.0, 0.0, 0.0};
+        if (MODE == UPD_LOWER_SUB && cvec) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t gj = J0 + joff + j * 16 + l4 + 4 * r;
+                cvj[r] = cvec[gj];
+                cej[r] = gj < cn ? 1.0 : 0.0;
+            }
+        }
         if (MODE != UPD_OVERWRITE) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -150,7 +171,9 @@ __global__ __launch_bounds__(256, 2) void chol_update_kernel(const double *__res
                 } else if (MODE == UPD_COLUMN_SUB) {
                     if (gi >= gj) *dst = cv[r][i] - acc[j][i][r];  // only the diagonal 128 x 128 block has gi < gj
                 } else {
-                    if (ti != tj || gi >= gj) *dst = cv[r][i] - acc[j][i][r];
+                    double x = acc[j][i][r];
+                    if (cvec) x += fma(cei[i], cvj[r], cvi[i] * cej[r]);  // cs (e_i v_j + v_i e_j)
+                    if (ti != tj || gi >= gj) *dst = cv[r][i] - x;
                 }
             }
         }
@@ -469,10 +492,10 @@ int debug_diag(mrbf_ctx *ctx, const double *A128_dev, int reps, float *ms_per_ca
 // C(lower tile pairs of an nt x nt tile grid) -= A B'  with K a multiple of 16 (the projection's rank-2q update
 // of Phi reuses the trailing-update kernel)
 int launch_update_lower(mrbf_ctx *ctx, const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc, int64_t nt,
-                        int K) {
+                        int K, const double *cvec, double cs, int64_t cn) {
     if (nt <= 0 || K <= 0) return 0;
     hipLaunchKernelGGL((chol_update_kernel<128, UPD_LOWER_SUB>), dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256), 0, ctx->stream, A,
-                       lda, B, ldb, C, ldc, K, (const int *)nullptr, (int)nt);
+                       lda, B, ldb, C, ldc, K, (const int *)nullptr, (int)nt, 0, cvec, cs, cn);
     MRBF_HIP(ctx, hipGetLastError());
     return 0;
 }

@@ -128,7 +128,9 @@ int tsmm_tn(mrbf_ctx *ctx, int64_t n, int p, int r, double alpha, const double *
 // Workgroup (bi, s): rows [128 bi, 128 bi + 128) x all NJT*16 columns, k range of split s.  Wave w owns rows 32w..32w+31
 // (two 16-row tiles) and every column tile.  Operands staged per 16-wide k chunk: Phi chunk 128 x 16 as in the update
 // kernel ([k][i] rows of 144 doubles), Q chunk 16 x (16 NJT) as [k][j].
-template <int NJT>
+// CF: additionally the row sums of Phi over this workgroup's k range (the product with a constant column, which then needs no
+// MFMA column tile: q = 65 = 1 + 64 runs with 4 column tiles instead of 5) -> column qp_total - 16 of the partial result.
+template <int NJT, bool CF>
 __global__ __launch_bounds__(256, 2) void symm_panel_kernel(const double *__restrict__ Phi, int64_t ld, const double *__restrict__ Q,
                                                             int64_t ldq, int q, int64_t n, int ksplit_len,
                                                             double *__restrict__ Wpart, int64_t ldw, int qp_total) {
@@ -149,35 +151,57 @@ __global__ __launch_bounds__(256, 2) void symm_panel_kernel(const double *__rest
         acc[j][1] = (v4d){0.0, 0.0, 0.0, 0.0};
     }
     const int a_i2 = (tid & 63) * 2, a_k0 = tid >> 6;
-    // register prefetch of the next 16-wide k chunk (Phi: 4 x 16 B per thread, Q: NJT doubles per thread)
-    v2d ra[4];
-    double rq[NJT];
-    auto fetch = [&](int64_t kb) {
+    // register prefetch, PF chunks of 16 columns ahead (Phi: 4 x 16 B per thread and chunk, Q: NJT doubles): with one chunk in flight
+    // the loop was bound by the ~2.5 us a chunk takes to arrive -- 16 KB per workgroup in flight is ~3 TB/s over the chip (measured
+    // 2.6), the MFMAs of a chunk take ~1 us
+    constexpr int PF = 3;
+    v2d ra[PF][4];
+    double rq[PF][NJT];
+    auto fetch = [&](int64_t kb, int slot) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int k = a_k0 + 4 * u;
-            ra[u] = (v2d){0.0, 0.0};
-            if (kb + k < kend) ra[u] = *(const v2d *)(Phi + I0 + a_i2 + (kb + k) * ld);  // a wave reads one whole column (1 KiB)
-        }
+        for (int f = 0; f < PF; ++f) {
+            if (f == slot) {
 #pragma unroll
-        for (int u = 0; u < NJT; ++u) {
-            const int e = tid + 256 * u;  // e < 16 * 16 * NJT
-            const int k = e & 15, j = jg0 + (e >> 4);
-            rq[u] = (j < q && kb + k < kend) ? Q[(kb + k) + (int64_t)j * ldq] : 0.0;  // 16 consecutive k are contiguous
+                for (int u = 0; u < 4; ++u) {
+                    const int k = a_k0 + 4 * u;
+                    ra[f][u] = (v2d){0.0, 0.0};
+                    if (kb + k < kend) ra[f][u] = *(const v2d *)(Phi + I0 + a_i2 + (kb + k) * ld);  // a wave reads one whole column (1 KiB)
+                }
+#pragma unroll
+                for (int u = 0; u < NJT; ++u) {
+                    const int e = tid + 256 * u;  // e < 16 * 16 * NJT
+                    const int k = e & 15, j = jg0 + (e >> 4);
+                    rq[f][u] = (j < q && kb + k < kend) ? Q[(kb + k) + (int64_t)j * ldq] : 0.0;  // 16 consecutive k are contiguous
+                }
+            }
         }
     };
-    fetch(kbeg);
-    for (int64_t kb = kbeg; kb < kend; kb += 16) {
-        __syncthreads();
 #pragma unroll
-        for (int u = 0; u < 4; ++u) *(v2d *)&As[(a_k0 + 4 * u) * LDA_S + a_i2] = ra[u];
+    for (int f = 0; f < PF; ++f) fetch(kbeg + 16 * f, f);
+    double rs0 = 0.0, rs1 = 0.0;  // CF: this thread's share of the row sums of rows a_i2, a_i2 + 1
+#pragma unroll 1
+    for (int64_t kb0 = kbeg; kb0 < kend; kb0 += 16 * PF) {
 #pragma unroll
-        for (int u = 0; u < NJT; ++u) {
-            const int e = tid + 256 * u;
-            Qs[(e & 15) * LDQ_S + (e >> 4)] = rq[u];
-        }
-        __syncthreads();
-        if (kb + 16 < kend) fetch(kb + 16);
+        for (int f = 0; f < PF; ++f) {
+            const int64_t kb = kb0 + 16 * f;
+            if (kb >= kend) break;
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 4; ++u) *(v2d *)&As[(a_k0 + 4 * u) * LDA_S + a_i2] = ra[f][u];
+            if (CF) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    rs0 += ra[f][u][0];
+                    rs1 += ra[f][u][1];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < NJT; ++u) {
+                const int e = tid + 256 * u;
+                Qs[(e & 15) * LDQ_S + (e >> 4)] = rq[f][u];
+            }
+            __syncthreads();
+            if (kb + 16 * PF < kend) fetch(kb + 16 * PF, f);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             double a[2];
@@ -191,8 +215,16 @@ __global__ __launch_bounds__(256, 2) void symm_panel_kernel(const double *__rest
                 for (int i = 0; i < 2; ++i) acc[j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(b, a[i], acc[j][i], 0, 0, 0);
             }
         }
+        }
     }
     double *out = Wpart + (size_t)blockIdx.y * ldw * qp_total;
+    if (CF && blockIdx.z == 0) {
+        __syncthreads();
+        As[a_k0 * LDA_S + a_i2] = rs0;
+        As[a_k0 * LDA_S + a_i2 + 1] = rs1;
+        __syncthreads();
+        if (tid < 128) out[(I0 + tid) + (int64_t)(qp_total - 16) * ldw] = (As[tid] + As[LDA_S + tid]) + (As[2 * LDA_S + tid] + As[3 * LDA_S + tid]);
+    }
 #pragma unroll
     for (int j = 0; j < NJT; ++j)
 #pragma unroll
@@ -203,24 +235,30 @@ __global__ __launch_bounds__(256, 2) void symm_panel_kernel(const double *__rest
         }
 }
 
+// cf: column 0 of W is the row-sum column (qp - 16 of the partial results) times cscale, column j >= 1 is partial column j - 1
 __global__ void symm_panel_reduce_kernel(const double *__restrict__ Wpart, int nsplit, int64_t ldw, int qp, int64_t n, int q,
-                                         double *__restrict__ W, int64_t ldwo) {
+                                         double *__restrict__ W, int64_t ldwo, int cf, double cscale) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n * q) return;
     const int64_t i = idx % n;
     const int j = (int)(idx / n);
+    const int jp = cf ? (j == 0 ? qp - 16 : j - 1) : j;
     double s = 0.0;
-    for (int c = 0; c < nsplit; ++c) s += Wpart[(size_t)c * ldw * qp + i + (int64_t)j * ldw];
-    W[i + (int64_t)j * ldwo] = s;
+    for (int c = 0; c < nsplit; ++c) s += Wpart[(size_t)c * ldw * qp + i + (int64_t)jp * ldw];
+    W[i + (int64_t)j * ldwo] = (cf && j == 0) ? s * cscale : s;
 }
 
-// W (n x q, ld ldwo) = Phi (npad x npad block, ld) * Q (n x q, ldq); rows >= n of W are left untouched
+// W (n x q, ld ldwo) = Phi (npad x npad block, ld) * Q (n x q, ldq); rows >= n of W are left untouched.
+// const_first: column 0 of Q is the constant cval on rows < n (its product is cval x the row sums of Phi, taken along the way).
 int symm_panel(mrbf_ctx *ctx, int64_t n, int64_t npad, int q, const double *Phi, int64_t ld, const double *Q, int64_t ldq, double *W,
-               int64_t ldwo) {
-    int njt = (q + 15) / 16;
+               int64_t ldwo, bool const_first, double cval) {
+    // the row-sum route only when it saves a column tile
+    const bool cf = const_first && q > 1 && (q - 1 + 15) / 16 < (q + 15) / 16;
+    const int qm = cf ? q - 1 : q;  // columns that go through the matrix cores
+    int njt = (qm + 15) / 16;
     // column tiles per workgroup: at most 9 (144 accumulator VGPRs; 17 would spill into AGPRs, where the f64 MFMA runs at
     // half rate, and to scratch: measured 27 ms instead of ~4 at q = 257); wider panels are cut into column groups
-    const int choices[] = {1, 2, 3, 5, 9};
+    const int choices[] = {1, 2, 3, 4, 5, 9};
     int pick = 9;
     for (int c : choices)
         if (c >= njt) {
@@ -231,22 +269,29 @@ int symm_panel(mrbf_ctx *ctx, int64_t n, int64_t npad, int q, const double *Phi,
     static const int nsplit_env = getenv("MRBF_SYMM_SPLIT") ? atoi(getenv("MRBF_SYMM_SPLIT")) : 0;
     const int nsplit = nsplit_env > 0 ? nsplit_env : 8;
     const int klen = (int)(round_up((n + nsplit - 1) / nsplit, 16));
-    const int qp = ngroups * pick * 16;
+    const int qp = ngroups * pick * 16 + (cf ? 16 : 0);
     double *Wpart;
     MRBF_TRY(get_buf(ctx, S_EVAL_A, (size_t)nsplit * npad * qp, &Wpart));
     dim3 grid((unsigned)(npad / 128), nsplit, ngroups);
-#define MRBF_SP(NJTV) \
-    hipLaunchKernelGGL((symm_panel_kernel<NJTV>), grid, dim3(256), 0, ctx->stream, Phi, ld, Q, ldq, q, n, klen, Wpart, npad, qp)
+    const double *Qm = cf ? Q + ldq : Q;
+#define MRBF_SP(NJTV)                                                                                                                  \
+    do {                                                                                                                               \
+        if (cf)                                                                                                                        \
+            hipLaunchKernelGGL((symm_panel_kernel<NJTV, true>), grid, dim3(256), 0, ctx->stream, Phi, ld, Qm, ldq, qm, n, klen, Wpart, npad, qp); \
+        else                                                                                                                           \
+            hipLaunchKernelGGL((symm_panel_kernel<NJTV, false>), grid, dim3(256), 0, ctx->stream, Phi, ld, Qm, ldq, qm, n, klen, Wpart, npad, qp); \
+    } while (0)
     switch (pick) {
         case 1: MRBF_SP(1); break;
         case 2: MRBF_SP(2); break;
         case 3: MRBF_SP(3); break;
+        case 4: MRBF_SP(4); break;
         case 5: MRBF_SP(5); break;
         default: MRBF_SP(9); break;
     }
 #undef MRBF_SP
     hipLaunchKernelGGL(symm_panel_reduce_kernel, dim3((unsigned)((n * q + 255) / 256)), dim3(256), 0, ctx->stream, Wpart, nsplit, npad,
-                       qp, n, q, W, ldwo);
+                       qp, n, q, W, ldwo, cf ? 1 : 0, cval);
     MRBF_HIP(ctx, hipGetLastError());
     return 0;
 }

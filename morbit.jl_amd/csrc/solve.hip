@@ -313,12 +313,13 @@ int potrf_blocked_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, i
 int backsolve_blocked(mrbf_ctx *ctx, int64_t npad, const double *L, int64_t lda, const double *linv_all, double *Y, int64_t ldy, int k);
 int backsolve_persistent(mrbf_ctx *ctx, int64_t npad, const double *L, int64_t lda, const double *linv_all, double *Y, int64_t ldy, int k,
                          int *status);  // backsolve.hip
-int launch_update_lower(mrbf_ctx *ctx, const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc, int64_t nt, int K);
+int launch_update_lower(mrbf_ctx *ctx, const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc, int64_t nt, int K,
+                        const double *cvec, double cs, int64_t cn);
 int launch_pad_identity(mrbf_ctx *ctx, double *A, int64_t n, int64_t npad, int64_t ld);
 int tsmm_tn(mrbf_ctx *ctx, int64_t n, int p, int r, double alpha, const double *A, int64_t lda, const double *B, int64_t ldb, double beta,
             double *C, int64_t ldc);  // skinny.hip
 int symm_panel(mrbf_ctx *ctx, int64_t n, int64_t npad, int q, const double *Phi, int64_t ld, const double *Q, int64_t ldq, double *W,
-               int64_t ldwo);  // skinny.hip
+               int64_t ldwo, bool const_first, double cval);  // skinny.hip
 
 // extra row tile(s) of the extended matrix: row npad + l = right-hand side l (a row), zero beyond k
 __global__ void set_rhs_rows_kernel(double *__restrict__ A, int64_t ld, int64_t npad, int xt, const double *__restrict__ B, int k) {
@@ -365,23 +366,29 @@ __global__ void shift_from_trace_kernel(double *__restrict__ scal, double nphi0,
 }
 
 // PA = [Q1 | V | 0], PB = [V | Q1 | 0] with V = W - (mu/2) Q1   (npad x K2, ld npad)
+// Panels of the rank-2q update K = Phi - Q1 V' - V Q1',  V = W - (mu/2) Q1:  PA = [Q | V], PB = [V | Q] (K2 columns, zero padded).
+// skip = 1: the first column of Q1 is the constant 1/sqrt(n); its rank-2 term goes through the update kernel's epilogue (v0 = the
+// first column of V), the panels hold columns 1 .. q-1 only -- with q = 65 that is K2 = 128 instead of 144.
 __global__ void build_panels_kernel(const double *__restrict__ Q1, const double *__restrict__ W, const double *__restrict__ scal,
-                                    int64_t n, int64_t npad, int q, int K2, double *__restrict__ PA, double *__restrict__ PB) {
+                                    int64_t n, int64_t npad, int q, int K2, int skip, double *__restrict__ PA, double *__restrict__ PB,
+                                    double *__restrict__ v0) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= npad * K2) return;
     const double mu = scal[1];
     const int64_t i = idx % npad;
     const int t = (int)(idx / npad);
+    const int qq = q - skip;
     double a = 0.0, b = 0.0;
-    if (i < n && t < 2 * q) {
-        const int tt = t % q;
+    if (i < n && t < 2 * qq) {
+        const int tt = t % qq + skip;
         const double qv = Q1[i + (int64_t)tt * npad];
         const double vv = fma(-0.5 * mu, qv, W[i + (int64_t)tt * npad]);
-        a = (t < q) ? qv : vv;
-        b = (t < q) ? vv : qv;
+        a = (t < qq) ? qv : vv;
+        b = (t < qq) ? vv : qv;
     }
     PA[idx] = a;
     PB[idx] = b;
+    if (skip && t == 0) v0[i] = (i < n) ? fma(-0.5 * mu, Q1[i], W[i]) : 0.0;
 }
 // lam[0] = z0 / sqrt(n) - mean . lam[1:]   (Pi = Q1 R with R = [[sqrt n, sqrt n mean'], [0, Lx']])
 __global__ void finish_lambda_kernel(double *__restrict__ T1, int q, int k, double sqrtn, const double *__restrict__ mean) {
@@ -488,7 +495,7 @@ static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info
     if (side) MRBF_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->evx[1], 0));
     if (q > 0) {
         // W1 = Phi Q1 (Phi is stored in full) ; G = Q1' W1 ; W = W1 - 1/2 Q1 G
-        MRBF_TRY(symm_panel(ctx, n, npad, q, Phi, ld, Q1, npad, Wm, npad));
+        MRBF_TRY(symm_panel(ctx, n, npad, q, Phi, ld, Q1, npad, Wm, npad, true, 1.0 / std::sqrt((double)n)));  // column 0 of Q1 is 1/sqrt(n)
         MRBF_TRY(tsmm_tn(ctx, n, q, q, 1.0, Q1, npad, Wm, npad, 0.0, G, q));
         hipLaunchKernelGGL(trace_kernel, dim3(1), dim3(256), 0, ctx->stream, G, q, scal);
         MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, (int)n, q, q, &mhalf, Q1, (int)npad,
@@ -497,12 +504,15 @@ static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info
         hipLaunchKernelGGL(shift_from_trace_kernel, dim3(1), dim3(1), 0, ctx->stream, scal, (double)n * M->kp.phi0,
                            (double)std::max<int64_t>(n - q, 1), dinfo);
         // K = Phi - Q1 V' - V Q1',  V = W - (mu/2) Q1  ( = P Phi P + mu Q1 Q1' ), lower tile pairs, in place, one kernel
-        const int K2 = (int)round_up(2 * q, 16);
-        double *PA, *PB;
+        // (the constant first column of Q1 is applied in the update's epilogue when that saves a 16-column chunk)
+        const int skip = (q > 1 && round_up(2 * (q - 1), 16) < round_up(2 * q, 16)) ? 1 : 0;
+        const int K2 = (int)round_up(2 * (q - skip), 16);
+        double *PA, *PB, *v0 = nullptr;
         MRBF_TRY(get_buf(ctx, S_STAGE_C, (size_t)npad * K2, &PA));
         MRBF_TRY(get_buf(ctx, S_STAGE_D, (size_t)npad * K2, &PB));
-        hipLaunchKernelGGL(build_panels_kernel, dim3(nblk(npad * K2)), dim3(256), 0, ctx->stream, Q1, Wm, scal, n, npad, q, K2, PA, PB);
-        MRBF_TRY(launch_update_lower(ctx, PA, npad, PB, npad, Phi, ld, npad / 128, K2));
+        if (skip) MRBF_TRY(get_buf(ctx, S_V0, (size_t)npad, &v0));
+        hipLaunchKernelGGL(build_panels_kernel, dim3(nblk(npad * K2)), dim3(256), 0, ctx->stream, Q1, Wm, scal, n, npad, q, K2, skip, PA, PB, v0);
+        MRBF_TRY(launch_update_lower(ctx, PA, npad, PB, npad, Phi, ld, npad / 128, K2, v0, 1.0 / std::sqrt((double)n), n));
         // B = P Y = Y - Q1 (Q1' Y);  T1 keeps Q1' Y for lam
         MRBF_TRY(tsmm_tn(ctx, n, q, k, 1.0, Q1, npad, B, npad, 0.0, T1, q));
         hipLaunchKernelGGL(sub_qt_kernel, dim3(nblk(n * k)), dim3(256), 0, ctx->stream, B, npad, Q1, npad, T1, n, q, k);
