@@ -505,6 +505,8 @@ __device__ __attribute__((noinline)) bool run_stream(const Args &a, Shared &sh, 
         }
         if (b == 0) JLOG(5);
         if (b == 7) JLOG(6);
+        unsigned long long *str = (a.trace && i == c + 1) ? a.trace + (size_t)a.NT * 16 + 4 * 1024 + (size_t)c * 16 + 2 * b : nullptr;
+        if (str && threadIdx.x == 0) str[0] = wall_clock64();  // panel b of the diagonal block seen
         double ia[4];
 #pragma unroll
         for (int s2 = 0; s2 < 4; ++s2) ia[s2] = *(const gf64 *)&itg[b * 256 + (4 * s2 + l4) * 16 + l15];
@@ -537,6 +539,7 @@ __device__ __attribute__((noinline)) bool run_stream(const Args &a, Shared &sh, 
         if (threadIdx.x == 0) {
             stf(sprog, (unsigned)(b + 1));
             if (b == 7) stf(a.tdone + (size_t)i * a.NT + c, 2u);
+            if (str) str[1] = wall_clock64();  // own panel b published
         }
     }
     return true;
@@ -886,11 +889,20 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
     }
     MRBF_TRY(get_buf(ctx, S_MEGA_IT, (size_t)NT * 8 * 256, &a.itg));
     // job tables (cached per shape)
-    const int slack = std::max(1, ctx->mega_slack), slack_chain = std::max(slack, ctx->mega_slack_chain);
+    // Streamed tile rows below the diagonal, chain workgroups and the chain tiles' slack by size (measured, tools/sweep_sizes.sh): a
+    // streamed row takes its predecessor column's panel in step instead of in one 14-us piece after a T job, which shortens the
+    // dependency loop T(c+2,c-1) -> S(c+2,c) -> S(c+2,c+1) -> P(c+2) that paces chain-bound sizes (n <= 6144: 5-8 % with five rows);
+    // every streamed row is one more resident job per column in flight (and one more paused CU partner), which the saturated middle of
+    // large matrices pays for (n = 8192: three rows, n >= 12288: two).  Environment / option values override.
+    const int NTq = (int)(ncols / NB);
+    const int srows_auto = NTq <= 48 ? 5 : (NTq <= 96 ? 3 : 2);
+    const int chain_auto = NTq <= 48 ? 32 : (NTq <= 96 ? 20 : 12);
+    const int slack_chain_auto = (NTq > 48 && NTq <= 96) ? 7 : 6;
+    const int slack = std::max(1, ctx->mega_slack), slack_chain = std::max(slack, ctx->mega_slack_chain > 0 ? ctx->mega_slack_chain : slack_chain_auto);
     // longer windows for large matrices (measured: n = 16384: 33.8 / 31.7 / 30.8 ms with 4 / 6 / 8 panels per window; n = 8192: the same)
     const int win = std::max(1, ctx->mega_win > 0 ? ctx->mega_win : (NT >= 88 ? 8 : (NT >= 56 ? 6 : WIN_DEFAULT)));
     const int first = std::min(win, std::max(1, ctx->mega_first_window));
-    const int srows = std::max(1, ctx->mega_srows);  // streamed tiles below each diagonal block
+    const int srows = ctx->mega_srows > 0 ? ctx->mega_srows : srows_auto;  // streamed tiles below each diagonal block
     if (ctx->mega_nt != NT || ctx->mega_mt != MT || ctx->mega_tab_slack != slack + 100 * ctx->mega_half_cols + 10000 * slack_chain + 1000000 * first + 10000000 * win + 100000000 * srows) {
         ctx->mega_tab_slack = slack + 100 * ctx->mega_half_cols + 10000 * slack_chain + 1000000 * first + 10000000 * win + 100000000 * srows;
         std::vector<Job> pj, bj;
@@ -966,7 +978,7 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
     a.tdone = a.sprog + (size_t)QSTRIDE * srows * NT;
     a.ucnt = a.tdone + (size_t)MT * NT;
     a.info = dinfo;
-    a.nchain = ctx->mega_chain;
+    a.nchain = ctx->mega_chain > 0 ? ctx->mega_chain : chain_auto;
     a.ndedicated = ctx->mega_dedicated;
     a.look = ctx->mega_look;
     a.use_quiet = ctx->mega_quiet;
@@ -985,8 +997,8 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
     const char *trace_path = getenv("MRBF_MEGA_TRACE");
     if (trace_path) {
         a.trace_dbg = getenv("MRBF_MEGA_TRACE_WAVE") ? 12 + 16 * (atoi(getenv("MRBF_MEGA_TRACE_WAVE")) & 3) : 4;
-        MRBF_TRY(get_buf(ctx, S_MEGA_TRACE, (size_t)NT * 16 + 4 * 1024, &a.trace));
-        MRBF_HIP(ctx, hipMemsetAsync(a.trace, 0, ((size_t)NT * 16 + 4 * 1024) * sizeof(unsigned long long), ctx->stream));
+        MRBF_TRY(get_buf(ctx, S_MEGA_TRACE, (size_t)NT * 32 + 4 * 1024, &a.trace));
+        MRBF_HIP(ctx, hipMemsetAsync(a.trace, 0, ((size_t)NT * 32 + 4 * 1024) * sizeof(unsigned long long), ctx->stream));
     }
     const char *jlog_path = getenv("MRBF_MEGA_JLOG");
     if (jlog_path) {
@@ -1035,6 +1047,15 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
                 tp += (double)u[4 * g + 1] * 0.01;
                 nb += u[4 * g + 2];
                 np += u[4 * g + 3];
+            }
+            {
+                std::vector<unsigned long long> ss((size_t)NT * 16);
+                (void)hipMemcpy(ss.data(), a.trace + (size_t)NT * 16 + 4 * 1024, ss.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+                for (int c2 = 0; c2 < NT; ++c2) {
+                    fprintf(f, "#S %d", c2);
+                    for (int k2 = 0; k2 < 16; ++k2) fprintf(f, " %.2f", ss[(size_t)c2 * 16 + k2] ? (double)(ss[(size_t)c2 * 16 + k2] - t0) * 0.01 : -1.0);
+                    fprintf(f, "\n");
+                }
             }
             fprintf(f, "# util: bulk %.1f us over %llu jobs (%.1f us/job), panel %.1f us over %llu jobs (%.1f us/job), grid %d\n", tb, nb,
                     nb ? tb / nb : 0.0, tp, np, np ? tp / np : 0.0, grid);

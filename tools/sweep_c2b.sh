@@ -1,0 +1,10 @@
+#!/bin/bash
+run() { echo -n "$* : "; env "$@" timeout -k 10 100 python bench.py --config C2 --steps 300 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys;o=json.loads(sys.stdin.read());print(round(o['value'],1), round(o['phases_ms']['factor'],4))"; }
+run MRBF_X=0
+run MRBF_MEGA_SROWS=3 MRBF_MEGA_CHAIN=16
+run MRBF_MEGA_SROWS=3 MRBF_MEGA_CHAIN=20
+run MRBF_MEGA_SROWS=3 MRBF_MEGA_CHAIN=24
+run MRBF_MEGA_SROWS=4 MRBF_MEGA_CHAIN=24
+run MRBF_MEGA_SROWS=3 MRBF_MEGA_CHAIN=20 MRBF_MEGA_SLACK_CHAIN=7
+run MRBF_MEGA_SROWS=3 MRBF_MEGA_CHAIN=20 MRBF_MEGA_DEDICATED=32
