@@ -126,6 +126,19 @@ __device__ __forceinline__ unsigned addf(unsigned *p, unsigned v) {
     return __hip_atomic_fetch_add((gu32 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void st_sc1(double *p, double v) { __hip_atomic_store((gf64 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// Args lives in memory (the job functions are not inlined): a field read after an atomic store is RE-LOADED, and the reload's
+// s_waitcnt vmcnt(0) also waits for that store -- eight write-through stores of a streamed step each waited for the previous one
+// to reach memory (~0.35 us apiece, 2.6 us of every 4.5-us step: per-step stamps, r02).  The hot fields are therefore copied into
+// scalar registers once per job.
+__device__ __forceinline__ int64_t uni64(int64_t v) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)v);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)v >> 32));
+    return (int64_t)(((unsigned long long)hi << 32) | lo);
+}
+template <class T>
+__device__ __forceinline__ T *uni_ptr(T *q) {
+    return reinterpret_cast<T *>(uni64(reinterpret_cast<int64_t>(q)));
+}
 
 // thread 0: spin until *f >= want (bounded); false on abort / timeout
 // (the bound is wall-clock time since the awaited word last changed, read every 256 polls: a healthy launch that merely shares the
@@ -362,6 +375,8 @@ __device__ __forceinline__ void load_tile_neg(const double *__restrict__ C, int6
 // ucnt counts half tiles: a full 128-row job adds 2, a 64-row job 1; window w of tile (i,c) may start at ucnt >= 2w
 template <int TM>
 __device__ __attribute__((noinline)) bool run_bulk(const Args &a, Shared &sh, const Job jb) {
+    const int64_t lda = uni64(a.lda);
+    double *const A = uni_ptr(a.A);
     const int i = __builtin_amdgcn_readfirstlane(jb.i), c = __builtin_amdgcn_readfirstlane(jb.c), jw = __builtin_amdgcn_readfirstlane(jb.w);
     const int w = jw & 255, roff = (TM == 64) ? 64 * (jw >> 8) : 0;
     const int pl = wstart(w + 1, a.first, a.win) - 1;  // last panel of the window: rows finish their panels in order
@@ -370,10 +385,10 @@ __device__ __attribute__((noinline)) bool run_bulk(const Args &a, Shared &sh, co
         return false;
     JLOG(2);
     v4d acc[TM / 32][4];
-    double *C = a.A + (int64_t)i * NB + roff + (int64_t)c * NB * a.lda;
-    load_tile_neg<TM>(C, a.lda, acc);  // the tile's earlier bulk updates are in (ucnt, awaited above)
+    double *C = A + (int64_t)i * NB + roff + (int64_t)c * NB * lda;
+    load_tile_neg<TM>(C, lda, acc);  // the tile's earlier bulk updates are in (ucnt, awaited above)
     const int64_t k0 = (int64_t)wstart(w, a.first, a.win) * NB;
-    gemm_acc<TM>(a.A + (int64_t)i * NB + roff + k0 * a.lda, a.lda, a.A + (int64_t)c * NB + k0 * a.lda, a.lda,
+    gemm_acc<TM>(A + (int64_t)i * NB + roff + k0 * lda, lda, A + (int64_t)c * NB + k0 * lda, lda,
                  (wstart(w + 1, a.first, a.win) - wstart(w, a.first, a.win)) * NB, acc, sh.u.gemm);
     JLOG(3);
 #pragma unroll
@@ -381,9 +396,9 @@ __device__ __attribute__((noinline)) bool run_bulk(const Args &a, Shared &sh, co
 #pragma unroll
         for (int i2 = 0; i2 < 4; ++i2) acc[j][i2] = -acc[j][i2];
     if (TM == 128 && i == c)
-        store_tile<TM, false, true, true>(C, a.lda, acc);
+        store_tile<TM, false, true, true>(C, lda, acc);
     else
-        store_tile<TM, false, false, true>(C, a.lda, acc);
+        store_tile<TM, false, false, true>(C, lda, acc);
     wg_drain();
     if (threadIdx.x == 0) addf(a.ucnt + (size_t)i * a.NT + c, TM == 128 ? 2u : 1u);
     return true;
@@ -395,6 +410,8 @@ __device__ __attribute__((noinline)) bool run_bulk(const Args &a, Shared &sh, co
 template <int TM>
 __device__ __forceinline__ bool window_part(const Args &a, Shared &sh, int i, int c, int pend, int roff,
                                                       unsigned long long *tr) {
+    const int64_t lda = uni64(a.lda);
+    double *const A = uni_ptr(a.A);
     const int wc = nbulk_updates(i, c, a.slack, a.slack_chain, a.first, a.win, a.srows), p0 = wstart(wc, a.first, a.win);
     const unsigned *uc = a.ucnt + (size_t)i * a.NT + c;
     if (p0 >= pend) return wg_wait(sh, a, uc, (unsigned)(2 * wc), nullptr, 0, nullptr, 0, 0x200u);
@@ -424,17 +441,17 @@ __device__ __forceinline__ bool window_part(const Args &a, Shared &sh, int i, in
         if (tr && threadIdx.x == 0) tr[p == p0 ? 5 : 6] = wall_clock64();  // first / latest dependency satisfied
         JLOG(p == p0 ? 2 : 3);
         const int64_t k0 = (int64_t)p * NB;
-        gemm_acc<TM>(a.A + (int64_t)i * NB + roff + k0 * a.lda, a.lda, a.A + (int64_t)c * NB + k0 * a.lda, a.lda, run * NB, acc, sh.u.gemm);
+        gemm_acc<TM>(A + (int64_t)i * NB + roff + k0 * lda, lda, A + (int64_t)c * NB + k0 * lda, lda, run * NB, acc, sh.u.gemm);
         p += run;
     }
     // the bulk updates of this tile must be in memory before it is read back
     if (tr && threadIdx.x == 0) tr[7] = wall_clock64();  // GEMM part done, waiting for the tile's bulk updates
     if (!wg_wait(sh, a, uc, (unsigned)(2 * wc), nullptr, 0, nullptr, 0, 0x212u)) return false;
-    double *C = a.A + (int64_t)i * NB + roff + (int64_t)c * NB * a.lda;
+    double *C = A + (int64_t)i * NB + roff + (int64_t)c * NB * lda;
     if (TM == 128 && i == c)
-        store_tile<TM, true, true, false>(C, a.lda, acc);
+        store_tile<TM, true, true, false>(C, lda, acc);
     else
-        store_tile<TM, true, false, false>(C, a.lda, acc);
+        store_tile<TM, true, false, false>(C, lda, acc);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     return true;
@@ -444,17 +461,19 @@ __device__ __forceinline__ bool window_part(const Args &a, Shared &sh, int i, in
 // Wave v owns rows 32v .. 32v+31 of the tile as 2 x 8 tiles of 16 x 16 in the MFMA C/D layout (lane l, register r:
 // X[16u + (l & 15)][16q + (l >> 4) + 4r]), which is directly the B operand of the next MFMA.
 __device__ __attribute__((noinline)) bool run_stream(const Args &a, Shared &sh, const Job jb) {
+    const int64_t lda = uni64(a.lda);
+    double *const A = uni_ptr(a.A);
     const int i = __builtin_amdgcn_readfirstlane(jb.i), c = __builtin_amdgcn_readfirstlane(jb.c);  // uniform: addresses and flags in SGPRs
     // all left-looking panels but the newest (c - 1) through the GEMM loop, in place
     if (!window_part<128>(a, sh, i, c, c > 0 ? c - 1 : 0, 0, nullptr)) return false;
     JLOG(4);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l15 = lane & 15, l4 = lane >> 4;
-    double *C = a.A + (int64_t)i * NB + (int64_t)c * NB * a.lda;
-    const double *Lcc = a.A + (int64_t)c * NB + (int64_t)c * NB * a.lda;
-    const double *itg = a.itg + (size_t)c * 8 * 256;
-    const unsigned *dprog = a.dprog + (size_t)c * QSTRIDE;
-    unsigned *sprog = a.sprog + ((size_t)(i - c - 1) * a.NT + c) * QSTRIDE;
+    double *C = A + (int64_t)i * NB + (int64_t)c * NB * lda;
+    const double *Lcc = A + (int64_t)c * NB + (int64_t)c * NB * lda;
+    const double *itg = uni_ptr(a.itg + (size_t)c * 8 * 256);
+    const unsigned *dprog = uni_ptr(a.dprog + (size_t)c * QSTRIDE);
+    unsigned *sprog = uni_ptr(a.sprog + ((size_t)(i - c - 1) * a.NT + c) * QSTRIDE);
     v4d x[2][8];
 #pragma unroll
     for (int u = 0; u < 2; ++u)
@@ -462,12 +481,12 @@ __device__ __attribute__((noinline)) bool run_stream(const Args &a, Shared &sh, 
         for (int q = 0; q < 8; ++q)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                x[u][q][r] = *(const gf64 *)&C[(32 * wave + 16 * u + l15) + (int64_t)(16 * q + l4 + 4 * r) * a.lda];
+                x[u][q][r] = *(const gf64 *)&C[(32 * wave + 16 * u + l15) + (int64_t)(16 * q + l4 + 4 * r) * lda];
     if (c > 0) {
         // X -= L(i,c-1) L(c,c-1)', 16 columns at a time: L(c,c-1) is the first streamed tile of block column c-1, L(i,c-1) the
         // (i-c+1)-th one, or -- the last S row -- a T tile that is awaited whole
-        const double *Lr = a.A + (int64_t)i * NB + (int64_t)(c - 1) * NB * a.lda;
-        const double *Lc = a.A + (int64_t)c * NB + (int64_t)(c - 1) * NB * a.lda;
+        const double *Lr = A + (int64_t)i * NB + (int64_t)(c - 1) * NB * lda;
+        const double *Lc = A + (int64_t)c * NB + (int64_t)(c - 1) * NB * lda;
         const unsigned *fc = a.sprog + (size_t)(c - 1) * QSTRIDE;
         const bool row_streamed = i - c < a.srows;
         const unsigned *fr = a.sprog + ((size_t)(i - c) * a.NT + (c - 1)) * QSTRIDE;
@@ -483,11 +502,11 @@ __device__ __attribute__((noinline)) bool run_stream(const Args &a, Shared &sh, 
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2) opr[u][s2] = *(const gf64 *)&Lr[(32 * wave + 16 * u + l15) + (int64_t)(16 * b + 4 * s2 + l4) * a.lda];
+                for (int s2 = 0; s2 < 4; ++s2) opr[u][s2] = *(const gf64 *)&Lr[(32 * wave + 16 * u + l15) + (int64_t)(16 * b + 4 * s2 + l4) * lda];
 #pragma unroll
             for (int q = 0; q < 8; ++q)
 #pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2) opc[q][s2] = *(const gf64 *)&Lc[(16 * q + l15) + (int64_t)(16 * b + 4 * s2 + l4) * a.lda];
+                for (int s2 = 0; s2 < 4; ++s2) opc[q][s2] = *(const gf64 *)&Lc[(16 * q + l15) + (int64_t)(16 * b + 4 * s2 + l4) * lda];
 #pragma unroll
             for (int q = 0; q < 8; ++q)
 #pragma unroll
@@ -496,6 +515,8 @@ __device__ __attribute__((noinline)) bool run_stream(const Args &a, Shared &sh, 
                     for (int s2 = 0; s2 < 4; ++s2) x[u][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-opc[q][s2], opr[u][s2], x[u][q], 0, 0, 0);
         }
     }
+    unsigned long long *const strbase = (a.trace && i == c + 1) ? uni_ptr(a.trace + (size_t)a.NT * 16 + 4 * 1024 + (size_t)c * 64) : nullptr;
+    unsigned *const tdone_ic = uni_ptr(a.tdone + (size_t)i * a.NT + c);
     unsigned have = 0;  // panels of the diagonal block known to be published
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
@@ -505,16 +526,20 @@ __device__ __attribute__((noinline)) bool run_stream(const Args &a, Shared &sh, 
         }
         if (b == 0) JLOG(5);
         if (b == 7) JLOG(6);
-        unsigned long long *str = (a.trace && i == c + 1) ? a.trace + (size_t)a.NT * 16 + 4 * 1024 + (size_t)c * 16 + 2 * b : nullptr;
+        // per-step opaque copies of the lane coordinates: the store / operand addresses derived from them are otherwise computed
+        // once for all eight (unrolled) steps, spilled, and reloaded between the write-through stores behind s_waitcnt vmcnt(0)
+        int l15s = l15, l4s = l4;
+        asm volatile("" : "+v"(l15s), "+v"(l4s));
+        unsigned long long *str = strbase ? strbase + 8 * b : nullptr;
         if (str && threadIdx.x == 0) str[0] = wall_clock64();  // panel b of the diagonal block seen
         double ia[4];
 #pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2) ia[s2] = *(const gf64 *)&itg[b * 256 + (4 * s2 + l4) * 16 + l15];
+        for (int s2 = 0; s2 < 4; ++s2) ia[s2] = *(const gf64 *)&itg[b * 256 + (4 * s2 + l4s) * 16 + l15s];
         double lq[8][4];
 #pragma unroll
         for (int q = b + 1; q < 8; ++q)
 #pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2) lq[q][s2] = *(const gf64 *)&Lcc[(16 * q + l15) + (int64_t)(16 * b + 4 * s2 + l4) * a.lda];
+            for (int s2 = 0; s2 < 4; ++s2) lq[q][s2] = *(const gf64 *)&Lcc[(16 * q + l15s) + (int64_t)(16 * b + 4 * s2 + l4s) * lda];
         v4d xs[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -523,7 +548,7 @@ __device__ __attribute__((noinline)) bool run_stream(const Args &a, Shared &sh, 
             for (int s2 = 0; s2 < 4; ++s2) t = __builtin_amdgcn_mfma_f64_16x16x4f64(ia[s2], x[u][b][s2], t, 0, 0, 0);
             xs[u] = t;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) st_sc1(&C[(32 * wave + 16 * u + l15) + (int64_t)(16 * b + l4 + 4 * r) * a.lda], t[r]);
+            for (int r = 0; r < 4; ++r) st_sc1(&C[(32 * wave + 16 * u + l15s) + (int64_t)(16 * b + l4s + 4 * r) * lda], t[r]);
         }
 #pragma unroll
         for (int q = b + 1; q < 8; ++q)
@@ -538,8 +563,8 @@ __device__ __attribute__((noinline)) bool run_stream(const Args &a, Shared &sh, 
         wg_drain();
         if (threadIdx.x == 0) {
             stf(sprog, (unsigned)(b + 1));
-            if (b == 7) stf(a.tdone + (size_t)i * a.NT + c, 2u);
-            if (str) str[1] = wall_clock64();  // own panel b published
+            if (b == 7) stf(tdone_ic, 2u);
+            if (str) str[5] = wall_clock64();  // own panel b published
         }
     }
     return true;
@@ -553,6 +578,8 @@ __device__ __attribute__((noinline)) bool run_stream(const Args &a, Shared &sh, 
 // TRACED: diagnostic launches (time stamps of the job, cycle counts of one wave of the diagonal core)
 template <bool TRACED>
 __device__ __attribute__((noinline)) bool run_diag(const Args &a, Shared &sh, const Job jb) {
+    const int64_t lda = uni64(a.lda);
+    double *const A = uni_ptr(a.A);
     const int c = __builtin_amdgcn_readfirstlane(jb.c);  // uniform: tile / flag addresses stay in SGPRs (spilled VGPR addresses used to
                                                          // be reloaded behind s_waitcnt vmcnt(0), i.e. behind the write-through stores)
     unsigned long long *tr = TRACED ? a.trace + (size_t)(2 * c) * 8 : nullptr;
@@ -563,12 +590,12 @@ __device__ __attribute__((noinline)) bool run_diag(const Args &a, Shared &sh, co
     JLOG(4);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l15 = lane & 15, l4 = lane >> 4;
-    double *C = a.A + (int64_t)c * NB + (int64_t)c * NB * a.lda;
+    double *C = A + (int64_t)c * NB + (int64_t)c * NB * lda;
     double *Linv = a.linv + (size_t)c * NB * NB;
     diagcore::v4d acc[diagcore::NSLOT];
-    diagcore::diag_v4_load(C, a.lda, acc);
+    diagcore::diag_v4_load(C, lda, acc);
     if (c > 0) {
-        const double *Lp = a.A + (int64_t)c * NB + (int64_t)(c - 1) * NB * a.lda;  // tile (c, c-1), produced by S(c, c-1)
+        const double *Lp = A + (int64_t)c * NB + (int64_t)(c - 1) * NB * lda;  // tile (c, c-1), produced by S(c, c-1)
         const unsigned *sprog = a.sprog + (size_t)(c - 1) * QSTRIDE;
         unsigned have = 0;  // 16-column panels of tile (c, c-1) known to be published
 #pragma unroll 1
@@ -581,7 +608,7 @@ __device__ __attribute__((noinline)) bool run_diag(const Args &a, Shared &sh, co
 #pragma unroll
             for (int xb = 0; xb < 8; ++xb)
 #pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2) op[xb][s2] = *(const gf64 *)&Lp[(16 * xb + l15) + (int64_t)(16 * b + 4 * s2 + l4) * a.lda];
+                for (int s2 = 0; s2 < 4; ++s2) op[xb][s2] = *(const gf64 *)&Lp[(16 * xb + l15) + (int64_t)(16 * b + 4 * s2 + l4) * lda];
 #pragma unroll
             for (int ti = 0; ti < 8; ++ti)
 #pragma unroll
@@ -600,10 +627,10 @@ __device__ __attribute__((noinline)) bool run_diag(const Args &a, Shared &sh, co
     __builtin_amdgcn_s_setprio(3);
     int bad;
     if constexpr (TRACED)
-        bad = diagcore::diag_v4_core<true, true, true>(C, a.lda, Linv, sh.u.diag, acc, a.itg + (size_t)c * 8 * 256,
+        bad = diagcore::diag_v4_core<true, true, true>(C, lda, Linv, sh.u.diag, acc, a.itg + (size_t)c * 8 * 256,
                                                        a.dprog + (size_t)c * QSTRIDE, a.trace_dbg, tr + 8);
     else
-        bad = diagcore::diag_v4_core<true, true, true>(C, a.lda, Linv, sh.u.diag, acc, a.itg + (size_t)c * 8 * 256,
+        bad = diagcore::diag_v4_core<true, true, true>(C, lda, Linv, sh.u.diag, acc, a.itg + (size_t)c * 8 * 256,
                                                        a.dprog + (size_t)c * QSTRIDE);
     __builtin_amdgcn_s_setprio(1);
     if (bad) {
@@ -628,18 +655,20 @@ __device__ __attribute__((noinline)) bool run_diag(const Args &a, Shared &sh, co
 // L(i,c-1) -> update -> solve -> L(i,c) (two dependent 64 x 128 x 128 GEMMs on one CU that is shared with a bulk job)
 // faster than the diagonal chain; with 128-row tiles the rows fall behind it.
 __device__ __attribute__((noinline)) bool run_panel(const Args &a, Shared &sh, const Job jb) {
+    const int64_t lda = uni64(a.lda);
+    double *const A = uni_ptr(a.A);
     const int i = __builtin_amdgcn_readfirstlane(jb.i), c = __builtin_amdgcn_readfirstlane(jb.c), roff = 64 * __builtin_amdgcn_readfirstlane(jb.w);
     if (!window_part<64>(a, sh, i, c, c, roff, nullptr)) return false;
     JLOG(4);
-    double *C = a.A + (int64_t)i * NB + roff + (int64_t)c * NB * a.lda;
+    double *C = A + (int64_t)i * NB + roff + (int64_t)c * NB * lda;
     double *Linv = a.linv + (size_t)c * NB * NB;
     // L(i,c) = X * inv(L_cc)'
     if (!wg_wait(sh, a, a.tdone + (size_t)c * a.NT + c, 2u, nullptr, 0, nullptr, 0, 0x300u)) return false;
     JLOG(5);
     v4d acc[2][4];
     zero_acc(acc);
-    gemm_acc<64>(C, a.lda, Linv, NB, NB, acc, sh.u.gemm);  // every wave's loads of X are complete behind the loop's last barrier
-    store_tile<64, false, false, true>(C, a.lda, acc);
+    gemm_acc<64>(C, lda, Linv, NB, NB, acc, sh.u.gemm);  // every wave's loads of X are complete behind the loop's last barrier
+    store_tile<64, false, false, true>(C, lda, acc);
     wg_drain();
     if (a.fault && i == a.MT - 1 && c == 0 && roff == 0) return true;  // test hook: this half tile is never published
     if (threadIdx.x == 0) addf(a.tdone + (size_t)i * a.NT + c, 1u);
@@ -997,8 +1026,8 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
     const char *trace_path = getenv("MRBF_MEGA_TRACE");
     if (trace_path) {
         a.trace_dbg = getenv("MRBF_MEGA_TRACE_WAVE") ? 12 + 16 * (atoi(getenv("MRBF_MEGA_TRACE_WAVE")) & 3) : 4;
-        MRBF_TRY(get_buf(ctx, S_MEGA_TRACE, (size_t)NT * 32 + 4 * 1024, &a.trace));
-        MRBF_HIP(ctx, hipMemsetAsync(a.trace, 0, ((size_t)NT * 32 + 4 * 1024) * sizeof(unsigned long long), ctx->stream));
+        MRBF_TRY(get_buf(ctx, S_MEGA_TRACE, (size_t)NT * 80 + 4 * 1024, &a.trace));
+        MRBF_HIP(ctx, hipMemsetAsync(a.trace, 0, ((size_t)NT * 80 + 4 * 1024) * sizeof(unsigned long long), ctx->stream));
     }
     const char *jlog_path = getenv("MRBF_MEGA_JLOG");
     if (jlog_path) {
@@ -1049,11 +1078,14 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
                 np += u[4 * g + 3];
             }
             {
-                std::vector<unsigned long long> ss((size_t)NT * 16);
+                std::vector<unsigned long long> ss((size_t)NT * 64);
                 (void)hipMemcpy(ss.data(), a.trace + (size_t)NT * 16 + 4 * 1024, ss.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
                 for (int c2 = 0; c2 < NT; ++c2) {
                     fprintf(f, "#S %d", c2);
-                    for (int k2 = 0; k2 < 16; ++k2) fprintf(f, " %.2f", ss[(size_t)c2 * 16 + k2] ? (double)(ss[(size_t)c2 * 16 + k2] - t0) * 0.01 : -1.0);
+                    for (int k2 = 0; k2 < 64; ++k2) {
+                        if ((k2 & 7) > 5) continue;  // per step: seen, operands in, -, MFMAs issued, drained, published
+                        fprintf(f, " %.2f", ss[(size_t)c2 * 64 + k2] ? (double)(ss[(size_t)c2 * 64 + k2] - t0) * 0.01 : -1.0);
+                    }
                     fprintf(f, "\n");
                 }
             }
