@@ -85,10 +85,11 @@ template <int K>
 __device__ __forceinline__ void leaf_step(double (&a)[16], int &bad, int col0) {
     // branch-free so that the 16 unrolled steps form one basic block: the scheduler can then start step K+1's
     // pivot -> rsqrt chain under the remaining column updates of step K
+    // The pivot test stays off the pivot -> rsqrt -> scale chain: a non-positive pivot just lets NaNs through this block (every
+    // later test then fails too, the first failure is the one recorded) and the caller aborts on the flag.
     const double piv = readlane_f64(a[K], K);
-    const bool ok = piv > 0.0;
-    const double rinv = ok ? fast_rsqrt_v4(ok ? piv : 1.0) : 0.0;
-    bad = (!ok && bad == 0) ? col0 + K + 1 : bad;
+    const double rinv = fast_rsqrt_v4(piv);
+    bad = (!(piv > 0.0) && bad == 0) ? col0 + K + 1 : bad;
     a[K] *= rinv;
 #pragma unroll
     for (int j = K + 1; j < 16; ++j) {
