@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void symm_panel_kernel(const double *__rest
     // register prefetch, PF chunks of 16 columns ahead (Phi: 4 x 16 B per thread and chunk, Q: NJT doubles): with one chunk in flight
     // the loop was bound by the ~2.5 us a chunk takes to arrive -- 16 KB per workgroup in flight is ~3 TB/s over the chip (measured
     // 2.6), the MFMAs of a chunk take ~1 us
-    constexpr int PF = 3;
+    constexpr int PF = (NJT <= 5) ? 3 : 1;  // nine column tiles leave no registers for a deeper prefetch (C5: 6.2 -> 10.5 ms with three)
     v2d ra[PF][4];
     double rq[PF][NJT];
     auto fetch = [&](int64_t kb, int slot) {
