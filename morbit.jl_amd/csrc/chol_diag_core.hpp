@@ -387,5 +387,252 @@ __device__ __forceinline__ int diag_v4_core(double *__restrict__ A, int64_t lda,
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// v6: the same factorisation with ONE workgroup barrier per 16-column panel and the leaf wave on a short leash.
+//
+// In v4 the leaf wave owns all eight diagonal tiles and meets the other waves twice per panel (X: leaf inverse visible, Y: panel
+// tiles visible): per panel it spends 1.8 us in the leaf and 2.8 us around it (its own look-ahead updates of the later diagonal
+// tiles, the panel solve of the other waves it waits for at Y, the update of the next diagonal tile from LDS).  Here the leaf
+// wave only ever holds three tiles -- D_b = (b,b), S_b = (b+1,b), D_{b+1} -- and computes what its next leaf needs itself:
+//     leaf(D_b) | barrier M_b | take S_b, D_{b+1} over from their owners (through LDS; they carry the panels <= b-2), apply
+//     panel b-1 to both, S_b <- inv(L_bb) S_b = L(b+1,b), D_{b+1} -= L(b+1,b) L(b+1,b)' from registers, next leaf.
+// The update waves (1..3) own every other tile; between M_b and M_{b+1} they apply panel b-1 to their tiles (column b first),
+// solve column b's panel tiles (i >= b+2) with the leaf inverse, hand (b+2,b+1) and (b+2,b+2) over, store.  Whatever the leaf
+// wave needs from them is one panel old, so it never waits for this step's work: ~3.2 us per panel instead of 4.6.
+// STREAM semantics (itg, *prog) as in v4; the leaf inverses stay in LDS for two panels only and the final inverse is assembled
+// from itg (global), which makes room for the double-buffered hand-over tiles.  Mega kernel only (PRELOADED, STREAM).
+__host__ __device__ constexpr bool v6_leafwave(int i, int j) { return i <= 1; }  // (0,0), (1,0), (1,1) start in the leaf wave
+__host__ __device__ constexpr int v6_index(int i, int j) { return MRBF_TIDX(i, j) - 3; }  // the other 33 lower tiles, row-major
+__host__ __device__ constexpr int v6_owner(int i, int j) { return v6_leafwave(i, j) ? 0 : 1 + v6_index(i, j) % 3; }
+__host__ __device__ constexpr int v6_slot(int i, int j) { return v6_leafwave(i, j) ? MRBF_TIDX(i, j) : v6_index(i, j) / 3; }
+constexpr int NSLOT6 = 11;
+
+struct DiagV6Shared {
+    double LT[28 * TILE];  // strictly-lower tiles: final L (operand order) -- or, before that, the raw tile handed to the leaf wave
+    double IT[2 * ITS];    // leaf inverses of the current and the previous panel (padded rows)
+    double Dt[2 * TILE];   // leaf hand-over: [col][32 rows], rows 16..31 the identity
+    double Lb[2 * TILE];   // factored leaves (double-buffered: the storing wave reads one while the next is written)
+    double DH[2 * TILE];   // diagonal tiles on their way to the leaf wave (double-buffered)
+    int bad;
+};
+
+__device__ __forceinline__ void diag_v6_load(const double *__restrict__ A, int64_t lda, v4d (&acc)[NSLOT6]) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l15 = lane & 15, l4 = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            if (v6_owner(i, j) == wave) {
+                v4d v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = *(const gf64 *)&A[(16 * i + l15) + (int64_t)(16 * j + l4 + 4 * r) * lda];
+                acc[v6_slot(i, j)] = v;
+            }
+        }
+}
+
+// tile (i,j) -= L(i,p) L(j,p)' with both operands from LT
+__device__ __forceinline__ void v6_update(v4d &c, const double *LT, int i, int j, int p, int l15, int l4) {
+    const double *ti_ = &LT[MRBF_SIDX(i, p) * TILE];
+    const double *tj_ = &LT[MRBF_SIDX(j, p) * TILE];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) c = __builtin_amdgcn_mfma_f64_16x16x4f64(-opnd(tj_, s, l15, l4), opnd(ti_, s, l15, l4), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ int diag_v6_core(double *__restrict__ A, int64_t lda, double *__restrict__ Linv, DiagV6Shared &sh,
+                                            v4d (&acc)[NSLOT6], double *__restrict__ itg, unsigned *prog,
+                                            unsigned long long *pubstamp = nullptr) {
+    const int tid = threadIdx.x, lane_ = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid == 0) sh.bad = 0;
+    if (tid < 256) sh.Dt[(tid >> 4) * 32 + 16 + (tid & 15)] = ((tid >> 4) == (tid & 15)) ? 1.0 : 0.0;
+    __syncthreads();
+    v4d Dc = acc[0], Sc = acc[1], Dn = acc[2];  // leaf wave: (0,0), (1,0), (1,1)
+
+#pragma unroll 1
+    for (int b = 0; b < NT; ++b) {
+        int lane = lane_;
+        asm volatile("" : "+v"(lane));  // nothing derived from the lane index is hoisted out of the loop (and spilled)
+        const int l15 = lane & 15, l4 = lane >> 4;
+        const int bb = b & 1;
+        if (wave == 0) {
+            // ---- leaf b
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sh.Dt[(l4 + 4 * r) * 32 + l15] = Dc[r];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            double a[16];
+            int bad = 0;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) a[c] = sh.Dt[c * 32 + (lane & 31)];
+            leaf_step<0>(a, bad, 16 * b);
+            leaf_step<1>(a, bad, 16 * b);
+            leaf_step<2>(a, bad, 16 * b);
+            leaf_step<3>(a, bad, 16 * b);
+            leaf_step<4>(a, bad, 16 * b);
+            leaf_step<5>(a, bad, 16 * b);
+            leaf_step<6>(a, bad, 16 * b);
+            leaf_step<7>(a, bad, 16 * b);
+            leaf_step<8>(a, bad, 16 * b);
+            leaf_step<9>(a, bad, 16 * b);
+            leaf_step<10>(a, bad, 16 * b);
+            leaf_step<11>(a, bad, 16 * b);
+            leaf_step<12>(a, bad, 16 * b);
+            leaf_step<13>(a, bad, 16 * b);
+            leaf_step<14>(a, bad, 16 * b);
+            leaf_step<15>(a, bad, 16 * b);
+            if (bad && lane == 0) sh.bad = bad;
+            if (lane < 16) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) sh.Lb[bb * TILE + c * 16 + lane] = a[c];
+            } else if (lane < 32) {
+                const int r = lane - 16;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) sh.IT[bb * ITS + r * ITLD + c] = (c >= r) ? a[c] : 0.0;
+            }
+        }
+        // every wave: its write-through stores of the previous panel (L tiles, leaf, inverse) are out before the panel is published
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // M_b
+        if (sh.bad) break;
+        if (b > 0 && tid == 64)
+            __hip_atomic_store((__attribute__((address_space(1))) unsigned *)prog, (unsigned)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (wave == 0) {
+            if (b < NT - 1) {
+                if (b > 0) {
+                    // take (b+1,b) and (b+1,b+1) over (they carry the panels <= b-2) and apply panel b-1
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        Sc[r] = sh.LT[MRBF_SIDX(b + 1, b) * TILE + (l4 + 4 * r) * 16 + l15];
+                        Dn[r] = sh.DH[((b - 1) & 1) * TILE + (l4 + 4 * r) * 16 + l15];
+                    }
+                    v6_update(Sc, sh.LT, b + 1, b, b - 1, l15, l4);
+                    v6_update(Dn, sh.LT, b + 1, b + 1, b - 1, l15, l4);
+                }
+                // L(b+1,b) = tile * inv(L_bb)'  (transposed layout: P' = inv(L_bb) * tile')
+                const double *itb = &sh.IT[bb * ITS];
+                v4d p = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int s = 0; s < 4; ++s) p = __builtin_amdgcn_mfma_f64_16x16x4f64(itb[(4 * s + l4) * ITLD + l15], Sc[s], p, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    sh.LT[MRBF_SIDX(b + 1, b) * TILE + (l4 + 4 * r) * 16 + l15] = p[r];
+                    gstore<true>(&A[(16 * (b + 1) + l15) + (int64_t)(16 * b + l4 + 4 * r) * lda], p[r]);
+                }
+                // next diagonal tile -= L(b+1,b) L(b+1,b)': both operands are the registers just computed
+#pragma unroll
+                for (int s = 0; s < 4; ++s) Dn = __builtin_amdgcn_mfma_f64_16x16x4f64(-p[s], p[s], Dn, 0, 0, 0);
+                Dc = Dn;
+            }
+        } else {
+            // ---- update waves, phase b
+            if (wave == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = l4 + 4 * r;
+                    if (c <= l15) gstore<true>(&A[(16 * b + l15) + (int64_t)(16 * b + c) * lda], sh.Lb[bb * TILE + c * 16 + l15]);
+                }
+            } else if (wave == 2) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gstore<true>(&itg[b * TILE + (l4 + 4 * r) * 16 + l15], sh.IT[bb * ITS + (l4 + 4 * r) * ITLD + l15]);
+            }
+            // panel b-1 on this wave's tiles of block column b, then their panel solve
+            const double *itb = &sh.IT[bb * ITS];
+            double ia[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) ia[s] = itb[(4 * s + l4) * ITLD + l15];
+#pragma unroll
+            for (int i = 2; i < NT; ++i)
+#pragma unroll
+                for (int j = 0; j <= i - 2; ++j) {
+                    if (j == b && v6_owner(i, j) == wave) {
+                        v4d m = acc[v6_slot(i, j)];
+                        if (b > 0) v6_update(m, sh.LT, i, j, b - 1, l15, l4);
+                        v4d p = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) p = __builtin_amdgcn_mfma_f64_16x16x4f64(ia[s], m[s], p, 0, 0, 0);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            sh.LT[MRBF_SIDX(i, j) * TILE + (l4 + 4 * r) * 16 + l15] = p[r];
+                            gstore<true>(&A[(16 * i + l15) + (int64_t)(16 * j + l4 + 4 * r) * lda], p[r]);
+                        }
+                    }
+                }
+            // panel b-1 on the two tiles the leaf wave takes over after the next barrier, and their hand-over
+#pragma unroll
+            for (int i = 2; i < NT; ++i) {
+                if (i == b + 2) {
+                    if (v6_owner(i, i - 1) == wave) {  // (b+2, b+1)
+                        v4d m = acc[v6_slot(i, i - 1)];
+                        if (b > 0) v6_update(m, sh.LT, i, i - 1, b - 1, l15, l4);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sh.LT[MRBF_SIDX(i, i - 1) * TILE + (l4 + 4 * r) * 16 + l15] = m[r];
+                    }
+                    if (v6_owner(i, i) == wave) {  // (b+2, b+2)
+                        v4d m = acc[v6_slot(i, i)];
+                        if (b > 0) v6_update(m, sh.LT, i, i, b - 1, l15, l4);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sh.DH[bb * TILE + (l4 + 4 * r) * 16 + l15] = m[r];
+                    }
+                }
+            }
+            // panel b-1 on everything else this wave still owns: tiles (i,j) with j >= b+1 that are not on their way to the leaf wave
+            if (b > 0) {
+#pragma unroll
+                for (int i = 3; i < NT; ++i)
+#pragma unroll
+                    for (int j = 1; j <= i; ++j) {
+                        if (j >= b + 1 && i >= b + 3 && v6_owner(i, j) == wave) v6_update(acc[v6_slot(i, j)], sh.LT, i, j, b - 1, l15, l4);
+                    }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int lane = lane_, l15 = lane & 15, l4 = lane >> 4;
+    const int bad_all = sh.bad;
+    if (bad_all) return bad_all;
+    if (tid == 64) {
+        __hip_atomic_store((__attribute__((address_space(1))) unsigned *)prog, (unsigned)NT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (pubstamp) *pubstamp = wall_clock64();  // all eight panels published (diagnostic launches)
+    }
+    // ---- inverse: as in v4, the leaf inverses read back from itg (this workgroup's own write-through stores, drained above)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int j = half == 0 ? wave : 7 - wave;
+        v4d X[NT];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) X[0][r] = *(const gf64 *)&itg[j * TILE + l15 * 16 + l4 + 4 * r];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gstore<true>(&Linv[(16 * j + l4 + 4 * r) + (16 * j + l15) * DNB], X[0][r]);
+#pragma unroll
+        for (int di = 1; di < NT; ++di) {
+            const int i = j + di;
+            if (i < NT) {
+                v4d S = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int dp = 0; dp < di; ++dp) {
+                    const int p = j + dp;
+                    const double *lt = &sh.LT[MRBF_SIDX(i, p) * TILE];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) S = __builtin_amdgcn_mfma_f64_16x16x4f64(opnd(lt, s, l15, l4), X[dp][s], S, 0, 0, 0);
+                }
+                v4d Xi = {0.0, 0.0, 0.0, 0.0};
+                const double *iti = itg + i * TILE;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) Xi = __builtin_amdgcn_mfma_f64_16x16x4f64(-*(const gf64 *)&iti[(4 * s + l4) * 16 + l15], S[s], Xi, 0, 0, 0);
+                X[di] = Xi;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gstore<true>(&Linv[(16 * i + l4 + 4 * r) + (16 * j + l15) * DNB], Xi[r]);
+            }
+        }
+        for (int e = lane; e < 16 * j * 16; e += 64) {
+            const int row = e % (16 * j), col = e / (16 * j);
+            gstore<true>(&Linv[row + (16 * j + col) * DNB], 0.0);
+        }
+    }
+    return 0;
+}
+
 }  // namespace diagcore
 }  // namespace mrbf

@@ -98,6 +98,7 @@ struct Args {
     int slack, slack_chain, first, win, wbias, srows;
     unsigned long long *jlog;   // diagnostic launches only: 8 words per job (meta, claim, 5 stage stamps, end), jlog[0] = count
     int jlog_cap;
+    int pstream;                // panels the diagonal job takes in step from streamed producers (1 or 2)
     int trace_dbg;              // diagnostic launches only: dbg word of the diagonal core (4 = time wave 0, 4 + 8 + 16 w = time wave w)
     unsigned long long *trace;  // diagnostic launches only: 8 time stamps (10 ns units) per chain job (P(c), T(c+1,c))
 };
@@ -105,7 +106,7 @@ struct Args {
 struct Shared {
     union {
         double gemm[2 * BK * LDS_LD];
-        diagcore::DiagV4Shared diag;
+        diagcore::DiagV6Shared diag;
     } u;
     int ok;
     int jkind, jidx;
@@ -584,20 +585,28 @@ __device__ __attribute__((noinline)) bool run_diag(const Args &a, Shared &sh, co
                                                          // be reloaded behind s_waitcnt vmcnt(0), i.e. behind the write-through stores)
     unsigned long long *tr = TRACED ? a.trace + (size_t)(2 * c) * 8 : nullptr;
     MEGA_STAMP(0);
-    // all panels but the last one (c - 1) through the GEMM loop; the last one is folded in as S(c, c-1) publishes it
-    if (!window_part<128>(a, sh, c, c, c - 1, 0, tr)) return false;
+    // All panels but the last `pstream` through the GEMM loop; the last ones (tiles (c, c-1), (c, c-2): streamed tiles of their
+    // block columns) are folded in 16 columns at a time as their producers publish them.  Two on chain-bound sizes: with one, tile
+    // (c, c-2) -- final a few us after P(c-2) -- still went through a 128^3 GEMM, the read-modify-write and eight catch-up folds
+    // (46 us) between the end of S(c, c-2) and the start of P(c), which paced the chain at 38 us per column once the diagonal
+    // block itself took 27.  (On large matrices the early read-modify-write would wait for bulk updates: one there.)
+    const int pstream = c < a.pstream ? c : a.pstream;
+    if (!window_part<128>(a, sh, c, c, c - pstream, 0, tr)) return false;
     MEGA_STAMP(1);
     JLOG(4);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l15 = lane & 15, l4 = lane >> 4;
     double *C = A + (int64_t)c * NB + (int64_t)c * NB * lda;
     double *Linv = a.linv + (size_t)c * NB * NB;
-    diagcore::v4d acc[diagcore::NSLOT];
-    diagcore::diag_v4_load(C, lda, acc);
-    if (c > 0) {
-        const double *Lp = A + (int64_t)c * NB + (int64_t)(c - 1) * NB * lda;  // tile (c, c-1), produced by S(c, c-1)
-        const unsigned *sprog = a.sprog + (size_t)(c - 1) * QSTRIDE;
-        unsigned have = 0;  // 16-column panels of tile (c, c-1) known to be published
+    diagcore::v4d acc[diagcore::NSLOT6];
+    diagcore::diag_v6_load(C, lda, acc);
+#pragma unroll 1
+    for (int pp = c - pstream; pp < c; ++pp) {
+        const double *Lp = A + (int64_t)c * NB + (int64_t)pp * NB * lda;                       // tile (c, pp), produced by S(c, pp),
+        const unsigned *sprog = uni_ptr(a.sprog + ((size_t)(c - pp - 1) * a.NT + pp) * QSTRIDE);  // the (c-pp)-th streamed tile of column pp
+        unsigned have = 0;  // 16-column panels of tile (c, pp) known to be published
+        // (operands straight from global memory into registers, per wave: staging the panel through LDS once per workgroup, with
+        //  the next panel prefetched, was slower -- two more barriers per panel and LDS operand latency in front of every MFMA)
 #pragma unroll 1
         for (int b = 0; b < 8; ++b) {
             if (have < (unsigned)(b + 1)) {
@@ -613,11 +622,11 @@ __device__ __attribute__((noinline)) bool run_diag(const Args &a, Shared &sh, co
             for (int ti = 0; ti < 8; ++ti)
 #pragma unroll
                 for (int tj = 0; tj <= ti; ++tj) {
-                    if (diagcore::tile_owner(ti, tj) == wave) {
+                    if (diagcore::v6_owner(ti, tj) == wave) {
 #pragma unroll
                         for (int s2 = 0; s2 < 4; ++s2)
-                            acc[diagcore::tile_slot(ti, tj)] =
-                                __builtin_amdgcn_mfma_f64_16x16x4f64(-op[tj][s2], op[ti][s2], acc[diagcore::tile_slot(ti, tj)], 0, 0, 0);
+                            acc[diagcore::v6_slot(ti, tj)] =
+                                __builtin_amdgcn_mfma_f64_16x16x4f64(-op[tj][s2], op[ti][s2], acc[diagcore::v6_slot(ti, tj)], 0, 0, 0);
                     }
                 }
         }
@@ -625,13 +634,8 @@ __device__ __attribute__((noinline)) bool run_diag(const Args &a, Shared &sh, co
     MEGA_STAMP(2);
     JLOG(5);
     __builtin_amdgcn_s_setprio(3);
-    int bad;
-    if constexpr (TRACED)
-        bad = diagcore::diag_v4_core<true, true, true>(C, lda, Linv, sh.u.diag, acc, a.itg + (size_t)c * 8 * 256,
-                                                       a.dprog + (size_t)c * QSTRIDE, a.trace_dbg, tr + 8);
-    else
-        bad = diagcore::diag_v4_core<true, true, true>(C, lda, Linv, sh.u.diag, acc, a.itg + (size_t)c * 8 * 256,
-                                                       a.dprog + (size_t)c * QSTRIDE);
+    const int bad = diagcore::diag_v6_core(C, lda, Linv, sh.u.diag, acc, a.itg + (size_t)c * 8 * 256, a.dprog + (size_t)c * QSTRIDE,
+                                           TRACED ? tr + 15 : nullptr);
     __builtin_amdgcn_s_setprio(1);
     if (bad) {
         if (threadIdx.x == 0) {
@@ -1017,6 +1021,7 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
     a.win = win;
     a.wbias = ctx->mega_wbias;
     a.srows = srows;
+    a.pstream = ctx->mega_pstream > 0 ? std::min(ctx->mega_pstream, srows) : (NTq <= 48 && srows >= 2 ? 2 : 1);
     a.spin_ticks = (unsigned long long)std::max(1, ctx->spin_ms) * 100000ull;  // wall_clock64 runs at 100 MHz
     a.fault = (ctx->debug_fault & 1) && MT > 1;
     // small matrices: one workgroup per CU is plenty (and leaves room for other contexts' launches: mrbf_batch_run)

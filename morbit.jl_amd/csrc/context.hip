@@ -189,6 +189,7 @@ int32_t mrbf_init(int32_t device_id, mrbf_ctx **out) {
         if (const char *e = getenv("MRBF_MEGA_WIN")) ctx->mega_win = atoi(e);
         if (const char *e = getenv("MRBF_MEGA_WBIAS")) ctx->mega_wbias = atoi(e);
         if (const char *e = getenv("MRBF_MEGA_SROWS")) ctx->mega_srows = atoi(e);
+        if (const char *e = getenv("MRBF_MEGA_PSTREAM")) ctx->mega_pstream = atoi(e);
         if (const char *e = getenv("MRBF_MEGA_MAX")) ctx->mega_max = atoi(e);
         if (const char *e = getenv("MRBF_SPIN_MS")) ctx->spin_ms = std::max(1, atoi(e));
         hipDeviceProp_t prop;
