@@ -444,9 +444,17 @@ __device__ __forceinline__ int diag_v6_core(double *__restrict__ A, int64_t lda,
                                             v4d (&acc)[NSLOT6], double *__restrict__ itg, unsigned *prog,
                                             unsigned long long *pubstamp = nullptr) {
     const int tid = threadIdx.x, lane_ = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (tid == 0) sh.bad = 0;
-    if (tid < 256) sh.Dt[(tid >> 4) * 32 + 16 + (tid & 15)] = ((tid >> 4) == (tid & 15)) ? 1.0 : 0.0;
-    __syncthreads();
+    // No barrier on entry: the leaf wave prepares what only it uses (failure word, identity rows) and starts the first leaf while the
+    // other waves may still be folding the caller's last panel into their tiles; they meet at M_0.  (The caller's LDS use ended
+    // behind a barrier.)
+    if (wave == 0) {
+        if (tid == 0) sh.bad = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = lane_ + 64 * u;
+            sh.Dt[(e >> 4) * 32 + 16 + (e & 15)] = ((e >> 4) == (e & 15)) ? 1.0 : 0.0;
+        }
+    }
     v4d Dc = acc[0], Sc = acc[1], Dn = acc[2];  // leaf wave: (0,0), (1,0), (1,1)
 
 #pragma unroll 1

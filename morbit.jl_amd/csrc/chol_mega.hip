@@ -614,10 +614,14 @@ __device__ __attribute__((noinline)) bool run_diag(const Args &a, Shared &sh, co
                 if (!have) return false;
             }
             double op[8][4];
+            // (the leaf wave's three tiles only need the first two row blocks: it is through its fold -- and, after the last panel,
+            //  into its first leaf -- while the others still work on their eleven tiles each)
 #pragma unroll
             for (int xb = 0; xb < 8; ++xb)
+                if (xb < 2 || wave != 0) {
 #pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2) op[xb][s2] = *(const gf64 *)&Lp[(16 * xb + l15) + (int64_t)(16 * b + 4 * s2 + l4) * lda];
+                    for (int s2 = 0; s2 < 4; ++s2) op[xb][s2] = *(const gf64 *)&Lp[(16 * xb + l15) + (int64_t)(16 * b + 4 * s2 + l4) * lda];
+                }
 #pragma unroll
             for (int ti = 0; ti < 8; ++ti)
 #pragma unroll
