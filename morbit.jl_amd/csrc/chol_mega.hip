@@ -551,12 +551,15 @@ __device__ __attribute__((noinline)) bool run_stream(const Args &a, Shared &sh, 
 #pragma unroll
             for (int r = 0; r < 4; ++r) st_sc1(&C[(32 * wave + 16 * u + l15s) + (int64_t)(16 * b + l4s + 4 * r) * lda], t[r]);
         }
-#pragma unroll
-        for (int q = b + 1; q < 8; ++q)
+        // the next step only needs block column b + 1 brought up to date: that one before the panel is published, the others after
+        // (the early steps carry up to 56 MFMAs per wave, 1.6 us, which the consumers of this panel need not wait for)
+        if (b < 7) {
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2) x[u][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-lq[q][s2], xs[u][s2], x[u][q], 0, 0, 0);
+                for (int s2 = 0; s2 < 4; ++s2) x[u][b + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(-lq[b + 1][s2], xs[u][s2], x[u][b + 1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         // publish the finished 16-column panel, also when this job is only catching up with a diagonal block that is already
         // complete: its consumers (the next diagonal job, the next column's streamed jobs) fold panel by panel at ~3 us each and
         // would otherwise start all eight after this job's end (seen as 17-23 us instead of 3 us between the end of S(c+1,c) and
@@ -567,6 +570,13 @@ __device__ __attribute__((noinline)) bool run_stream(const Args &a, Shared &sh, 
             if (b == 7) stf(tdone_ic, 2u);
             if (str) str[5] = wall_clock64();  // own panel b published
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = b + 2; q < 8; ++q)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) x[u][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-lq[q][s2], xs[u][s2], x[u][q], 0, 0, 0);
     }
     return true;
 }
