@@ -74,7 +74,7 @@ enum {
     MRBF_OPT_GRAM_MODE = 1,    /* 0 = MFMA GEMM-form (default), 1 = VALU difference-form (reference arithmetic) */
     MRBF_OPT_RESIDUAL = 2,     /* 1 = compute rel_residual / max|Pi'w| after a fit (default 1) */
     MRBF_OPT_FORCE_PATH = 3,   /* 0 = automatic, else one of MRBF_PATH_* */
-    MRBF_OPT_CHOL_IMPL = 4,    /* 0 = library default (3 from 512 columns on, else 2), 1 = rocSOLVER potrf, 2 = built-in blocked MFMA Cholesky driven by
+    MRBF_OPT_CHOL_IMPL = 4,    /* 0 = library default (3 from 256 columns on, else 2), 1 = rocSOLVER potrf, 2 = built-in blocked MFMA Cholesky driven by
                                   host launches, 3 = the same factorisation as one persistent launch */
     MRBF_OPT_EVAL_IMPL = 5,    /* 0 = default, 1 = GEMM pipeline, 2 = fused MFMA kernel */
     MRBF_OPT_TIMING = 6,       /* 1 = record per-phase hipEvents (default 1) */

@@ -511,7 +511,8 @@ int potrf_blocked_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, i
                     (long long)ncols, (long long)mrows, (long long)lda);
     // chol_impl 3 (and the default, 0, from mega_min columns on): the whole factorisation as one persistent launch (chol_mega.hip);
     // chol_impl 2 forces the host-driven launches below
-    // (measured: the persistent launch wins from 384 columns on: n = 8192 5.2 vs 8.2 ms, n = 16384 30.8 vs 35.6 ms)
+    // (measured, end of round 2: the persistent launch wins from 256 columns on -- n = 256: 0.107 vs 0.142 ms, 384: 0.138 vs 0.242,
+    //  8192: 4.4 vs 8.2, 16384: 27 vs 35.6; a single 128-column block is faster as one diagonal kernel + panel launch)
     if ((ctx->chol_impl == 3 || (ctx->chol_impl == 0 && ncols <= ctx->mega_max)) && ncols >= ctx->mega_min)
         return potrf_mega_tall(ctx, ncols, mrows, A, lda, dinfo, linv_all);
     double *Lone = nullptr;

@@ -58,7 +58,7 @@ struct mrbf_ctx {
     int bulk_grid = 384;  // > 0: cap on the workgroups of a bulk trailing update (persistent tile loop)
     // persistent factorisation (chol_mega.hip): cached job tables + launch geometry
     int mega_nt = 0, mega_mt = 0, mega_npanel = 0, mega_nbulk = 0, mega_nwin = 0, mega_nchainjobs = 0;
-    int mega_grid = 512, mega_dedicated = 64, mega_look = 2, mega_min = 512, mega_max = 32768, mega_quiet = 1, mega_chain = 0, mega_slack = 3, mega_slack_chain = 0, mega_tab_slack = -1, mega_half_cols = 0, mega_first_window = 1, mega_win = 0, mega_wbias = 4, mega_pstream = 0, mega_srows = 0;  // chain, slack_chain, srows: 0 = by matrix size (potrf_mega_tall)
+    int mega_grid = 512, mega_dedicated = 64, mega_look = 2, mega_min = 256, mega_max = 32768, mega_quiet = 1, mega_chain = 0, mega_slack = 3, mega_slack_chain = 0, mega_tab_slack = -1, mega_half_cols = 0, mega_first_window = 1, mega_win = 0, mega_wbias = 4, mega_pstream = 0, mega_srows = 0;  // chain, slack_chain, srows: 0 = by matrix size (potrf_mega_tall)
     std::string err;
     std::vector<mrbf::Buf> model_pool;  // released model blocks, reused by the next model of similar size (hipMalloc/hipFree cost
                                         // ~0.1-0.3 ms each and serialise across host threads)
