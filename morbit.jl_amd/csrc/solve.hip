@@ -411,6 +411,27 @@ __global__ void sub_qt_kernel(double *__restrict__ B, int64_t ldb, const double 
     B[row + (int64_t)l * ldb] -= s;
 }
 
+// x = L^-T b through the stored inverse of the factor (d <= 128: one diagonal block, whose inverse the factorisation produced
+// anyway): X[j] = sum_{i >= j} inv[i][j] b[i] -- one pass instead of d dependent steps.  inv: 128 x 128 column-major, zero above.
+__global__ __launch_bounds__(256) void apply_linv_t_kernel(const double *__restrict__ inv, int d, double *__restrict__ X, int64_t ldx, int k) {
+    __shared__ double bs[128];
+    const int j = threadIdx.x & 127, half = threadIdx.x >> 7;  // two threads per unknown: rows i = j + half, j + half + 2, ...
+    __shared__ double part[2][128];
+    for (int l = 0; l < k; ++l) {
+        __syncthreads();
+        if (threadIdx.x < 128) bs[threadIdx.x] = threadIdx.x < d ? X[threadIdx.x + (int64_t)l * ldx] : 0.0;
+        __syncthreads();
+        double v = 0.0;
+        if (j < d) {
+            const double *col = inv + (int64_t)j * 128;  // column j of the inverse: rows i >= j
+            for (int i = j + half; i < d; i += 2) v = fma(col[i], bs[i], v);
+        }
+        part[half][j] = v;
+        __syncthreads();
+        if (half == 0 && j < d) X[j + (int64_t)l * ldx] = part[0][j] + part[1][j];
+    }
+}
+
 // x = L^-T b for the d x d lower factor of the Cholesky-QR (d <= 256) and k right-hand sides, in place in X (ld ldx): one
 // workgroup, thread j owns unknown j, back substitution over the columns of L' (64 us of rocBLAS small-trsm launch otherwise)
 __global__ __launch_bounds__(256) void trsm_lt_small_kernel(const double *__restrict__ L, int64_t ldl, int d, double *__restrict__ X,
@@ -450,7 +471,7 @@ static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info
     MRBF_TRY(get_buf(ctx, S_INFO, (size_t)4, &dinfo));  // [0] main factorisation, [1] Cholesky-QR of the tail, [2] shift not positive, [3] backward substitution gave up
     MRBF_HIP(ctx, hipMemsetAsync(dinfo, 0, 4 * sizeof(int), ctx->stream));
     hipLaunchKernelGGL(rhs_from_values_kernel, dim3(nblk(npad * k)), dim3(256), 0, ctx->stream, Y, n, k, B, npad);
-    double *Q1 = nullptr, *Wm = nullptr, *G = nullptr, *T1 = nullptr, *scal = nullptr, *Tall = nullptr;
+    double *Q1 = nullptr, *Wm = nullptr, *G = nullptr, *T1 = nullptr, *scal = nullptr, *Tall = nullptr, *LxInv = nullptr;
     int64_t lt = 0, dq = 0;
     info->mu = 0.0;
     // The orthonormal basis Q1 of the polynomial tail depends on the centred coordinates only, not on Phi: its chain of small
@@ -482,7 +503,9 @@ static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info
             hipLaunchKernelGGL(xc_to_tall_kernel, dim3(nblk(n * d)), dim3(256), 0, ctx->stream, M->Xc, n, d, M->dpad, Tall, lt, dq);
             MRBF_TRY(tsmm_tn(ctx, n, d, d, 1.0, Tall + dq, lt, Tall + dq, lt, 0.0, Tall, lt));  // Gx = Xc' Xc
             MRBF_TRY(launch_pad_identity(ctx, Tall, d, dq, lt));
-            MRBF_TRY(potrf_blocked_tall(ctx, dq, lt, Tall, lt, dinfo + 1, nullptr));  // flag read back with the main one
+            // (one diagonal block: its inverse is kept for the tail coefficients of the solve)
+            if (dq == 128) MRBF_TRY(get_buf(ctx, S_QR_INV, (size_t)128 * 128, &LxInv));
+            MRBF_TRY(potrf_blocked_tall(ctx, dq, lt, Tall, lt, dinfo + 1, LxInv));  // flag read back with the main one
         }
         hipLaunchKernelGGL(build_q1_kernel, dim3(nblk(npad * q)), dim3(256), 0, ctx->stream, Tall, lt, dq, n, npad, q, Q1);
         MRBF_HIP(ctx, hipMemsetAsync(Wm, 0, (size_t)npad * q * sizeof(double), ctx->stream));
@@ -557,7 +580,9 @@ static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info
             // z = Q1' Y - (Phi Q1)' w;  (Phi Q1)' w = W' w because Q1' w = 0;  lam = R^-1 z
             MRBF_TRY(tsmm_tn(ctx, n, q, k, -1.0, Wm, npad, B, npad, 1.0, T1w, q));
             if (q > 1) {
-                if (d <= 256)
+                if (LxInv)
+                    hipLaunchKernelGGL(apply_linv_t_kernel, dim3(1), dim3(256), 0, ctx->stream, LxInv, d, T1w + 1, (int64_t)q, k);
+                else if (d <= 256)
                     hipLaunchKernelGGL(trsm_lt_small_kernel, dim3(1), dim3(256), 0, ctx->stream, Tall, lt, d, T1w + 1, (int64_t)q, k);
                 else
                     MRBF_BLAS(ctx, rocblas_dtrsm(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose,
