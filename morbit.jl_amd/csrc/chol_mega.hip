@@ -6,9 +6,10 @@
 // cross-stream event (~10 us each).  Here the whole factorisation is ONE launch of resident workgroups (two per CU) that
 // pull 128 x 128 tile jobs from queues and hand tiles to each other through flags in memory (hop ~2-3 us):
 //
-//   P(c)      diagonal tile: left-looking part over the newest panels, the last one folded in 16 columns at a time as
-//             S(c, c-1) publishes it, then Cholesky + inverse of the factor (chol_diag_core.hpp), which itself publishes
-//             every finished 16-column panel of L_cc and its 16 x 16 leaf inverse
+//   P(c)      diagonal tile: left-looking part over the newest panels, the last one (on chain-bound sizes the last two) folded
+//             in 16 columns at a time as S(c, c-1) / S(c, c-2) publish them, then Cholesky + inverse of the factor
+//             (chol_diag_core.hpp, diag_v6_core: one barrier per 16-column panel), which itself publishes every finished
+//             16-column panel of L_cc and its 16 x 16 leaf inverse
 //   S(i,c)    the `srows` tiles right below the diagonal (i = c+1 ..): the panel solve run in step with P(c) -- each
 //             published panel is applied to the 128 x 128 tile held in registers (MFMA, accumulator-as-operand), the tile's
 //             own 16-column panel published in turn: the next diagonal factorisation starts ~10 us after the previous
@@ -24,6 +25,7 @@
 // closed at least `slack` chain steps before c as bulk jobs (right-looking, rank 512..1024) and takes the newer panels
 // left-looking inside its own panel job, so a panel that has just been finished never has to pass through a bulk job
 // before the next diagonal blocks can start; the bulk of the flops streams the trailing matrix once per window.
+// (`srows`, `nchain` and the chain tiles' slack are chosen by matrix size in potrf_mega_tall.)
 // Three pools of workgroups: `nchain` serve the chain queue (P, S jobs, in order; their CU partner pauses), `ndedicated`
 // serve the panel queue (T jobs, column by column, rows ascending) and may wait inside a job, all others take the head of
 // the panel queue when it can run (diagonal block at most `look` steps away AND its bulk updates in), else a bulk job: bulk
