@@ -155,14 +155,19 @@ __global__ __launch_bounds__(256, (DT <= 4) ? 2 : 1) void eval_fused_kernel(
 }
 
 // vals[p][l0 + l] = sum_s vpart + p_l(x);   jac[p][t*k + l0 + l] = (sum_s sa) xc[p][t] - sum_s G + lam[t+1]
+// One workgroup of 128 threads per query point.  The polynomial tail of the value -- a dot product over d coordinates per output --
+// is spread over the threads that also produce the Jacobian entries and summed in a fixed order through LDS (it used to be a serial
+// d-term loop of one thread per output, the critical path of the whole workgroup: 54 us for 10^4 points at d = 64, 92 us at d = 128).
 template <int KOUT>
-__global__ void eval_combine_kernel(const double *__restrict__ vpart, const double *__restrict__ sapart, const double *__restrict__ gpart,
-                                    int nsplit, int64_t mpad, int64_t m, int D, int d, int k, int l0, const double *__restrict__ Xq,
-                                    const double *__restrict__ Xorig, const double *__restrict__ lam, int q, double *__restrict__ vals,
-                                    double *__restrict__ jac) {
+__global__ __launch_bounds__(128) void eval_combine_kernel(const double *__restrict__ vpart, const double *__restrict__ sapart,
+                                                           const double *__restrict__ gpart, int nsplit, int64_t mpad, int64_t m, int D, int d,
+                                                           int k, int l0, const double *__restrict__ Xq, const double *__restrict__ Xorig,
+                                                           const double *__restrict__ lam, int q, double *__restrict__ vals,
+                                                           double *__restrict__ jac) {
     const int64_t p = blockIdx.x;
     if (p >= m) return;
-    __shared__ double sa[KOUT];
+    __shared__ double sa[KOUT], sv[KOUT];
+    __shared__ double pdot[KOUT][128];
     const int tid = threadIdx.x;
     if (tid < KOUT && l0 + tid < k) {
         double v = 0.0, a = 0.0;
@@ -171,13 +176,30 @@ __global__ void eval_combine_kernel(const double *__restrict__ vpart, const doub
             a += sapart[((int64_t)s * mpad + p) * KOUT + tid];
         }
         sa[tid] = a;
-        if (vals) {
-            if (q > 0) v += lam[l0 + tid];
-            for (int t = 1; t < q; ++t) v = fma(lam[(int64_t)t * k + l0 + tid], Xorig[p * d + t - 1], v);
-            vals[p * k + l0 + tid] = v;
+        sv[tid] = v;
+    }
+    // partial dot products lam[t+1][l] * x[t] over this thread's coordinates t = tid, tid + 128, ...
+    if (vals && q > 1) {
+#pragma unroll
+        for (int l = 0; l < KOUT; ++l) {
+            double acc = 0.0;
+            if (l0 + l < k)
+                for (int t = tid; t < d; t += 128) acc = fma(lam[(int64_t)(t + 1) * k + l0 + l], Xorig[p * d + t], acc);
+            pdot[l][tid] = acc;
         }
     }
     __syncthreads();
+    if (vals && tid < KOUT && l0 + tid < k) {
+        double v = sv[tid];
+        if (q > 0) v += lam[l0 + tid];
+        if (q > 1) {
+            const int nt = d < 128 ? d : 128;
+            double dsum = 0.0;
+            for (int t = 0; t < nt; ++t) dsum += pdot[tid][t];  // fixed order
+            v += dsum;
+        }
+        vals[p * k + l0 + tid] = v;
+    }
     if (!jac) return;
     for (int e = tid; e < KOUT * d; e += blockDim.x) {
         const int l = e / d, t = e % d;
