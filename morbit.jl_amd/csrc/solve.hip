@@ -391,24 +391,46 @@ __global__ void build_panels_kernel(const double *__restrict__ Q1, const double 
     if (skip && t == 0) v0[i] = (i < n) ? fma(-0.5 * mu, Q1[i], W[i]) : 0.0;
 }
 // lam[0] = z0 / sqrt(n) - mean . lam[1:]   (Pi = Q1 R with R = [[sqrt n, sqrt n mean'], [0, Lx']])
-__global__ void finish_lambda_kernel(double *__restrict__ T1, int q, int k, double sqrtn, const double *__restrict__ mean) {
-    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+// one workgroup of 64 threads per output: the dot product with the mean is spread over the lanes and summed in a fixed order (a
+// serial q-term loop of one thread took 8-27 us)
+__global__ __launch_bounds__(64) void finish_lambda_kernel(double *__restrict__ T1, int q, int k, double sqrtn, const double *__restrict__ mean) {
+    __shared__ double part[64];
+    const int l = blockIdx.x, tid = threadIdx.x;
     if (l >= k) return;
-    double s = T1[(int64_t)l * q] / sqrtn;
-    for (int t = 1; t < q; ++t) s -= mean[t - 1] * T1[t + (int64_t)l * q];
-    T1[(int64_t)l * q] = s;
+    double acc = 0.0;
+    for (int t = 1 + tid; t < q; t += 64) acc = fma(mean[t - 1], T1[t + (int64_t)l * q], acc);
+    part[tid] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        double dsum = 0.0;
+        for (int u = 0; u < 64; ++u) dsum += part[u];
+        T1[(int64_t)l * q] = T1[(int64_t)l * q] / sqrtn - dsum;
+    }
 }
 
-// B(n x k) -= Q(n x q) T(q x k)  (all column-major): the rank-q correction of the weights, one thread per entry
-__global__ void sub_qt_kernel(double *__restrict__ B, int64_t ldb, const double *__restrict__ Q, int64_t ldq, const double *__restrict__ T,
-                              int64_t n, int q, int k) {
-    const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (idx >= n * k) return;
-    const int64_t row = idx % n;
-    const int l = (int)(idx / n);
-    double s = 0.0;
-    for (int t = 0; t < q; ++t) s = fma(Q[row + (int64_t)t * ldq], T[t + (int64_t)l * q], s);
-    B[row + (int64_t)l * ldb] -= s;
+// B(n x k) -= Q(n x q) T(q x k)  (all column-major): the rank-q correction of the weights.  Workgroup = 64 rows x 4 groups of
+// columns t (t = g, g + 4, ...), the four partial sums added in a fixed order (one thread per entry with a serial q-term loop was
+// bound by q dependent load latencies: 17-49 us)
+__global__ __launch_bounds__(256) void sub_qt_kernel(double *__restrict__ B, int64_t ldb, const double *__restrict__ Q, int64_t ldq,
+                                                     const double *__restrict__ T, int64_t n, int q, int k) {
+    __shared__ double part[4][64];
+    const int r = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int64_t row = (int64_t)blockIdx.x * 64 + r;
+    for (int l = 0; l < k; ++l) {
+        double s0 = 0.0, s1 = 0.0;
+        if (row < n) {
+            int t = g;
+            for (; t + 4 < q; t += 8) {
+                s0 = fma(Q[row + (int64_t)t * ldq], T[t + (int64_t)l * q], s0);
+                s1 = fma(Q[row + (int64_t)(t + 4) * ldq], T[t + 4 + (int64_t)l * q], s1);
+            }
+            if (t < q) s0 = fma(Q[row + (int64_t)t * ldq], T[t + (int64_t)l * q], s0);
+        }
+        __syncthreads();
+        part[g][r] = s0 + s1;
+        __syncthreads();
+        if (g == 0 && row < n) B[row + (int64_t)l * ldb] -= (part[0][r] + part[1][r]) + (part[2][r] + part[3][r]);
+    }
 }
 
 // x = L^-T b through the stored inverse of the factor (d <= 128: one diagonal block, whose inverse the factorisation produced
@@ -538,7 +560,7 @@ static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info
         MRBF_TRY(launch_update_lower(ctx, PA, npad, PB, npad, Phi, ld, npad / 128, K2, v0, 1.0 / std::sqrt((double)n), n));
         // B = P Y = Y - Q1 (Q1' Y);  T1 keeps Q1' Y for lam
         MRBF_TRY(tsmm_tn(ctx, n, q, k, 1.0, Q1, npad, B, npad, 0.0, T1, q));
-        hipLaunchKernelGGL(sub_qt_kernel, dim3(nblk(n * k)), dim3(256), 0, ctx->stream, B, npad, Q1, npad, T1, n, q, k);
+        hipLaunchKernelGGL(sub_qt_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, ctx->stream, B, npad, Q1, npad, T1, n, q, k);
     }
     MRBF_HIP(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
     int hinfo = 0;
@@ -576,7 +598,7 @@ static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info
             MRBF_HIP(ctx, hipMemcpyAsync(T1w, T1, (size_t)q * k * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
             // re-project w (rounding hygiene): w -= Q1 (Q1' w)
             MRBF_TRY(tsmm_tn(ctx, n, q, k, 1.0, Q1, npad, B, npad, 0.0, T2, q));
-            hipLaunchKernelGGL(sub_qt_kernel, dim3(nblk(n * k)), dim3(256), 0, ctx->stream, B, npad, Q1, npad, T2, n, q, k);
+            hipLaunchKernelGGL(sub_qt_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, ctx->stream, B, npad, Q1, npad, T2, n, q, k);
             // z = Q1' Y - (Phi Q1)' w;  (Phi Q1)' w = W' w because Q1' w = 0;  lam = R^-1 z
             MRBF_TRY(tsmm_tn(ctx, n, q, k, -1.0, Wm, npad, B, npad, 1.0, T1w, q));
             if (q > 1) {
@@ -588,7 +610,7 @@ static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info
                     MRBF_BLAS(ctx, rocblas_dtrsm(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose,
                                                  rocblas_diagonal_non_unit, d, k, &one, Tall, (int)lt, T1w + 1, q));
             }
-            hipLaunchKernelGGL(finish_lambda_kernel, dim3((k + 63) / 64), dim3(64), 0, ctx->stream, T1w, q, k, std::sqrt((double)n), M->mean);
+            hipLaunchKernelGGL(finish_lambda_kernel, dim3((unsigned)k), dim3(64), 0, ctx->stream, T1w, q, k, std::sqrt((double)n), M->mean);
         }
         hipLaunchKernelGGL(scatter_solution_kernel, dim3(nblk(M->npad * k + (int64_t)q * k)), dim3(256), 0, ctx->stream, B, npad, n,
                            M->npad, k, q, (int64_t)0, M->W, M->Wc, M->lam, T1w ? T1w : B, (int64_t)q);
