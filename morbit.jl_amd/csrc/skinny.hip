@@ -63,8 +63,17 @@ __global__ void tsmm_tn_reduce_kernel(const double *__restrict__ part, int nchun
                                       double *__restrict__ C, int64_t ldc) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= p * r) return;
-    double s = 0.0;
-    for (int c = 0; c < nchunks; ++c) s += part[(size_t)c * p * r + idx];
+    // eight independent partial sums (fixed assignment c % 8, fixed final order): the loads of a thread are in flight together instead
+    // of one dependent ~1 us load after the other (64 chunks: 18 us)
+    double sp[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    const size_t pr = (size_t)p * r;
+    int c = 0;
+    for (; c + 8 <= nchunks; c += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sp[u] += part[(size_t)(c + u) * pr + idx];
+    }
+    for (int u = 0; c + u < nchunks; ++u) sp[u] += part[(size_t)(c + u) * pr + idx];
+    const double s = ((sp[0] + sp[1]) + (sp[2] + sp[3])) + ((sp[4] + sp[5]) + (sp[6] + sp[7]));
     const int i = idx % p, j = idx / p;
     double *dst = C + i + (int64_t)j * ldc;
     *dst = (beta == 0.0) ? alpha * s : fma(alpha, s, beta * *dst);
