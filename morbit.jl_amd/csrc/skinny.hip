@@ -91,7 +91,22 @@ __global__ __launch_bounds__(256) void tsmm_tn_skinny_kernel(const double *__res
     double acc[R];
 #pragma unroll
     for (int l = 0; l < R; ++l) acc[l] = 0.0;
-    for (int64_t k = tid; k < n; k += 256) {
+    // four strides at a time, all their loads issued before the first use (a stride per iteration is one dependent load latency each)
+    int64_t k = tid;
+    for (; k + 3 * 256 < n; k += 4 * 256) {
+        double av[4], bv[4][R];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            av[u] = a[k + 256 * u];
+#pragma unroll
+            for (int l = 0; l < R; ++l) bv[u][l] = B[k + 256 * u + (int64_t)l * ldb];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int l = 0; l < R; ++l) acc[l] = fma(av[u], bv[u][l], acc[l]);
+    }
+    for (; k < n; k += 256) {
         const double av = a[k];
 #pragma unroll
         for (int l = 0; l < R; ++l) acc[l] = fma(av, B[k + (int64_t)l * ldb], acc[l]);
