@@ -270,6 +270,59 @@ int32_t mrbf_ps_step(mrbf_ctx *ctx, const mrbf_model *model, const double *x_n, 
                      const double *fx_n, const double *r_or_null, const mrbf_ps_options *opts, double *x_trial, double *mx_trial,
                      double *r_out, mrbf_ps_info *info);
 
+/* The same step for a whole SurrogateContainer: objectives and modelled constraints spread over several grouped RBF models
+ * (src/SurrogateContainer.jl:48-64), the nonlinear (in)equality constraint handles of descent.jl:389-402 / :448-466 and the MOP's
+ * linear constraints in scaled variables (transformed_linear_eq/ineq_constraints, src/AbstractMOPInterface.jl:463-495).
+ * roles: one entry per output row of every model, concatenated in model order: l >= 0 -> this row is objective l of the
+ * container's objective vector; MRBF_ROLE_EQ / MRBF_ROLE_INEQ -> modelled constraint h(x) = 0 / g(x) <= 0; MRBF_ROLE_NONE ->
+ * not used.  A_eq (n_lin_eq x d row-major), b_eq: A x = b; A_ineq, b_ineq: A x <= b (host or device; may be NULL when the
+ * count is 0).  An equality counts as satisfied when |h| <= eq_tol (< 0: 1e-8; NLopt's default tolerance 0 would make every
+ * point infeasible).  The ideal-point runs (descent.jl:404-412) carry the same constraints.  fx_n, r, mx_trial, r_out have
+ * n_objectives entries.  Limits of the device path: mrbf_dispatch_ps. */
+enum { MRBF_ROLE_NONE = -1, MRBF_ROLE_EQ = -2, MRBF_ROLE_INEQ = -3 };
+typedef struct {
+    int32_t n_models, n_objectives;
+    const mrbf_model *const *models;
+    const int32_t *roles;
+    int32_t n_lin_eq, n_lin_ineq;
+    const double *A_eq, *b_eq, *A_ineq, *b_ineq;
+    double eq_tol;
+} mrbf_ps_problem;
+int32_t mrbf_ps_step_problem(mrbf_ctx *ctx, const mrbf_ps_problem *problem, const double *x_n, const double *lb_eff,
+                             const double *ub_eff, const double *fx_n, const double *r_or_null, const mrbf_ps_options *opts,
+                             double *x_trial, double *mx_trial, double *r_out, mrbf_ps_info *info);
+
+/* ---- the decision table of the host bindings ---------------------------------------------------------------------------
+ * Which implementation a binding (morbit.jl_amd/julia/HipRbf.jl, the Python mirror) takes for one call of Morbit's interface:
+ * the device entry point (MRBF_DISPATCH_DEVICE) or Morbit's own method on the same arguments (MRBF_DISPATCH_REFERENCE; Julia:
+ * `invoke` of the generic method, Python: the host mirror).  Pure host code (no ctx, no GPU), so both bindings make exactly the
+ * same decisions and the CPU tests pin them.  A binding never raises because a size limit was hit.
+ *   mrbf_dispatch_ps         get_criticality(::PascolettiSerafiniConfig, ...) (src/descent.jl:512-581).  n_foreign = objectives or
+ *                            modelled constraints that are not RefSurrogate rows of a device model (CompositeSurrogate,
+ *                            ExactModel, Taylor / Lagrange models); n_nl_constraints = modelled constraint rows, n_lin_constraints =
+ *                            linear constraint rows of the MOP.
+ *   mrbf_dispatch_backtrack  _backtrack (src/descent.jl:150-185): device iff the objectives are the outputs, in order, of ONE
+ *                            device model (then mrbf_backtrack applies); otherwise the reference loop (on batched container
+ *                            sweeps where the binding has them).
+ *   mrbf_dispatch_affine     candidate scan of the affinely-independent-point filter (AffinelyIndependentPoints.jl:71-106).
+ *   mrbf_dispatch_round4     _rbf_round4 (src/models/RbfModel.jl:352-499): device iff the start set can carry the tail (n0 >= q)
+ *                            and there are candidates.
+ *   mrbf_dispatch_fit        update_model (RbfModel.jl:743-767): MRBF_FIT_FROM_ROUND4 iff a kept round-4 state describes exactly
+ *                            the training set (state_n0 + state_n_accepted == n_training, same sites in the same order:
+ *                            same_sites != 0) with a unisolvent start set (state_n0 == q) and at least one accepted site.
+ *   mrbf_dispatch_after      the return code rc of a device entry point (MRBF_ENTRY_*) that means "take the reference method
+ *                            for this call" (start set without the tail or rank deficient, limits of the device path) rather
+ *                            than an error: 1 = fall back, 0 = rc is what it says. */
+enum { MRBF_DISPATCH_REFERENCE = 0, MRBF_DISPATCH_DEVICE = 1 };
+enum { MRBF_FIT_FULL = 0, MRBF_FIT_FROM_ROUND4 = 1 };
+enum { MRBF_ENTRY_ROUND4 = 1, MRBF_ENTRY_FIT_FROM_ROUND4 = 2, MRBF_ENTRY_PS_STEP = 3, MRBF_ENTRY_BACKTRACK = 4, MRBF_ENTRY_AFFINE = 5 };
+int32_t mrbf_dispatch_ps(int32_t d, int32_t k, int32_t n_models, int32_t n_nl_constraints, int32_t n_lin_constraints, int32_t n_foreign);
+int32_t mrbf_dispatch_backtrack(int32_t n_objective_models, int32_t n_foreign, int32_t outputs_in_order);
+int32_t mrbf_dispatch_affine(int64_t n_candidates, int32_t d);
+int32_t mrbf_dispatch_round4(int64_t n0, int32_t d, int32_t poly_deg, int64_t n_candidates);
+int32_t mrbf_dispatch_fit(int64_t n_training, int64_t state_n0, int32_t state_q, int32_t state_n_accepted, int32_t same_sites);
+int32_t mrbf_dispatch_after(int32_t entry, int32_t rc);
+
 /* ---- host-side helper of the Pascoletti-Serafini subproblem solver -------------------------------------------------
  * Stochastic ranking of one ISRES generation (Runarsson & Yao): lam sweeps over adjacent individuals, compared by
  * objective f when both are feasible (phi == 0) or with probability pf, else by constraint violation phi; stops after a

@@ -53,6 +53,17 @@ class PsInfo(ctypes.Structure):
 
 
 PS_OK, PS_CRITICAL, PS_FAILURE = 0, 1, 2
+ROLE_NONE, ROLE_EQ, ROLE_INEQ = -1, -2, -3
+DISPATCH_REFERENCE, DISPATCH_DEVICE = 0, 1
+FIT_FULL, FIT_FROM_ROUND4 = 0, 1
+ENTRY_ROUND4, ENTRY_FIT_FROM_ROUND4, ENTRY_PS_STEP, ENTRY_BACKTRACK, ENTRY_AFFINE = 1, 2, 3, 4, 5
+
+
+class PsProblem(ctypes.Structure):
+    _fields_ = [("n_models", ctypes.c_int32), ("n_objectives", ctypes.c_int32), ("models", ctypes.POINTER(ctypes.c_void_p)),
+                ("roles", ctypes.POINTER(ctypes.c_int32)), ("n_lin_eq", ctypes.c_int32), ("n_lin_ineq", ctypes.c_int32),
+                ("A_eq", ctypes.c_void_p), ("b_eq", ctypes.c_void_p), ("A_ineq", ctypes.c_void_p), ("b_ineq", ctypes.c_void_p),
+                ("eq_tol", ctypes.c_double)]
 
 
 class Problem(ctypes.Structure):
@@ -111,6 +122,14 @@ SIGNATURES = {
     "mrbf_stochastic_rank": (ctypes.c_int32, [ctypes.c_int32, c_vp, c_vp, c_vp, ctypes.c_double, c_vp]),
     "mrbf_ps_step": (ctypes.c_int32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(PsOptions), c_vp, c_vp, c_vp,
                                       ctypes.POINTER(PsInfo)]),
+    "mrbf_ps_step_problem": (ctypes.c_int32, [c_vp, ctypes.POINTER(PsProblem), c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(PsOptions),
+                                              c_vp, c_vp, c_vp, ctypes.POINTER(PsInfo)]),
+    "mrbf_dispatch_ps": (ctypes.c_int32, [ctypes.c_int32] * 6),
+    "mrbf_dispatch_backtrack": (ctypes.c_int32, [ctypes.c_int32] * 3),
+    "mrbf_dispatch_affine": (ctypes.c_int32, [ctypes.c_int64, ctypes.c_int32]),
+    "mrbf_dispatch_round4": (ctypes.c_int32, [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64]),
+    "mrbf_dispatch_fit": (ctypes.c_int32, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
+    "mrbf_dispatch_after": (ctypes.c_int32, [ctypes.c_int32, ctypes.c_int32]),
 }
 
 _LIB = None

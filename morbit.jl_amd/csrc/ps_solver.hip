@@ -1,17 +1,25 @@
 // Pascoletti-Serafini descent step with the whole subproblem solver on the device -- replaces the NLopt runs of
 // compute_local_ideal_point / _ps_optimization inside get_criticality(::PascolettiSerafiniConfig, ...)
-// (/root/reference/src/descent.jl:369-412, :434-510, :512-581) for objectives that share one grouped RBF model.
+// (/root/reference/src/descent.jl:369-412, :434-510, :512-581).
 //
-// The reference hands one-point closures to NLopt's GN_ISRES: every candidate costs k sweeps over all n centres.  Here the
-// subproblems are solved by an ISRES-style (mu, lambda) evolution strategy (Runarsson & Yao; population 20 (dim + 1), mu =
-// lambda / 7, as NLopt's defaults) whose state lives in device memory:
-//   * the k single-objective runs of the local ideal point and the Pascoletti-Serafini run each own a population block;
-//     all blocks of a generation are evaluated by ONE batched surrogate sweep (eval_model, values only);
-//   * one workgroup per run then does everything else of the generation: objective / constraint violation, best-so-far,
-//     stochastic ranking (odd-even transposition in LDS with the random comparison rule -- the parallel form of the bubble
-//     sweeps), survivor selection, differential variation, log-normal self-adaptive mutation with re-draws inside the box,
-//     from a counter-based generator (Philox 4x32-10, keyed by seed / run / generation: no state, any launch order);
+// The reference hands one-point closures to NLopt's GN_ISRES: every candidate costs one sweep over all n centres PER OUTPUT.
+// Here the subproblems are solved by an ISRES-style (mu, lambda) evolution strategy (Runarsson & Yao; population 20 (dim + 1),
+// mu = lambda / 7, as NLopt's defaults) whose state lives in device memory:
+//   * the k single-objective runs of the local ideal point and the Pascoletti-Serafini run each own a population block; all
+//     blocks of a generation are evaluated by ONE batched surrogate sweep per grouped model (eval_model, values only);
+//   * per generation three more launches do everything else, for all runs at once:
+//       ps_score_kernel  one wave per individual: objective and constraint violation -- the PS constraints of descent.jl:443,
+//                        the modelled (in)equality constraints (:448-466) and the MOP's linear constraints
+//                        (AbstractMOPInterface.jl:487-495) -- into per-run arrays;
+//       ps_rank_kernel   one 1024-thread workgroup per run: best so far, stop tests, stochastic ranking with the records in LDS
+//                        (odd-even transposition with the random comparison rule -- the parallel form of the bubble sweeps --
+//                        or, when no individual violates a constraint, a bitonic network that ends in the same order);
+//       ps_breed_kernel  one wave per offspring: differential variation, log-normal self-adaptive mutation with re-draws inside
+//                        the box, from a counter-based generator (Philox 4x32-10, keyed by seed / run / generation / individual /
+//                        component: no state, any launch order);
 //   * the host enqueues generations back to back and reads the runs' status words every few generations only.
+// Populations up to MAXLAM individuals (d <= 356): the C4 / C5 dimensions of BASELINE.json (d = 128, 256; examples/example_zdt.jl:39)
+// run here, not in a host loop.
 // Parity with the reference is the contract of get_criticality (problem solved, budgets, start values, critical / failure
 // short cuts, returned tuple), not NLopt's random trajectory; the returned point is always feasible for the subproblem.
 #include "radial.hpp"
@@ -23,33 +31,48 @@ int eval_model(mrbf_ctx *ctx, const mrbf_model *M, int64_t m, const double *Xdev
 
 namespace ps {
 
-constexpr int LDSPOP = 6144;  // doubles of population / step sizes staged in LDS by the generation kernel
-constexpr int MAXLAM = 2048;  // population limit of the device path (dim <= 100); larger problems use the host loop of the mirrors
+constexpr int MAXLAM = 7168;   // population limit: the ranking keeps one run's records in one workgroup's LDS
+constexpr int MAXRUNS = 9;     // k <= 8 ideal-point runs side by side, or the PS run
+constexpr int MAXMODELS = 8;   // grouped models of one container
+constexpr int MAXOBJ = 8;
+constexpr int MAXCON = 32;     // modelled (nonlinear) constraint rows
+constexpr int RANK_THREADS = 1024;
 
 struct Run {  // one (mu, lambda) run; all pointers into device arenas
     int nvar;       // 1 + d for the PS run (chi = [t; x]), d for an ideal-point run
     int lam, mu;
-    int kind;       // 0: minimise output `obj` over the box; 1: Pascoletti-Serafini run
+    int kind;       // 0: minimise objective `obj` over the box; 1: Pascoletti-Serafini run
     int obj;
     int off;        // first row of this run's block in the evaluation batch
     int max_evals;
     double *X[2];   // lam x nvar, ping-pong
     double *S[2];   // lam x nvar step sizes
     double *best;   // nvar + 2: best_x, best_f, best_phi
-    int *stat;      // [0] evals so far, [1] done, [2] generations run
+    double *f, *phi;  // lam: objective / violation of the current generation
+    int *order;     // lam: ranked individuals (best first); the first mu are the parents
+    int *stat;      // [0] evals so far, [1] done, [2] generations run, [3] generation + 1 whose offspring are to be bred
 };
 
 struct Args {
-    Run runs[9];
-    int nruns, d, k;
+    Run runs[MAXRUNS];
+    int nruns, d, nobj, rows;
     const double *lb, *ub;   // d
-    const double *mx, *r;    // k (PS run)
-    const double *F;         // evaluation batch results, rows x k
+    const double *mx, *r;    // nobj (PS run)
+    // evaluation batch results: one rows x kf[j] block per grouped model
+    const double *F[MAXMODELS];
+    int kf[MAXMODELS];
+    int nmodels;
+    short obj_model[MAXOBJ], obj_col[MAXOBJ];   // where objective l lives
+    int ncon;                                   // modelled constraints: (model, column, 1 = equality)
+    short con_model[MAXCON], con_col[MAXCON], con_eq[MAXCON];
+    int nlin_eq, nlin_ineq;                     // A x = b, A x <= b in scaled variables (row-major rows x d)
+    const double *A_eq, *b_eq, *A_ineq, *b_ineq;
+    double eq_tol;
     double *Xeval;           // evaluation batch, rows x d
     unsigned long long seed;
     double xtol_rel;
     int gen;
-    int dbg;  // timing experiments (MRBF_PS_DBG): 1 no ranking, 2 no breeding, 4 no best / stop bookkeeping
+    int dbg;  // timing experiments (MRBF_PS_DBG): 1 no ranking, 2 no breeding, 4 transposition phases also when a sort would do
 };
 
 // ---- Philox 4x32-10 ---------------------------------------------------------------------------------------------
@@ -81,17 +104,23 @@ __device__ __forceinline__ void rng4(const Args &a, int run, int gen, int ind, i
 
 __device__ __forceinline__ double lo_of(const Args &a, const Run &R, int j) { return R.kind == 1 ? (j == 0 ? -1.0 : a.lb[j - 1]) : a.lb[j]; }
 __device__ __forceinline__ double hi_of(const Args &a, const Run &R, int j) { return R.kind == 1 ? (j == 0 ? 0.0 : a.ub[j - 1]) : a.ub[j]; }
+__device__ __forceinline__ int run_of_row(const Args &a, int row) {  // runs are laid out in row order
+    int run = 0;
+    while (run + 1 < a.nruns && row >= a.runs[run + 1].off) ++run;
+    return run;
+}
 
 // generation 0: uniform population in the box, individual 0 = the start point (PS: [t0; x_n]), PS individual 1 = [0; x_n]
-// (always feasible: m(x_n) - m(x_n) - 0 r = 0, so the run can never end without a feasible point); step sizes (ub - lb) / sqrt(n)
+// (feasible for the PS constraints: m(x_n) - m(x_n) - 0 r = 0); step sizes (ub - lb) / sqrt(n)
 __global__ __launch_bounds__(256) void ps_init_kernel(Args a, const double *xn, double t0) {
-    const Run &R = a.runs[blockIdx.x];
+    const Run &R = a.runs[blockIdx.y];
     const int n = R.nvar;
-    for (int e = threadIdx.x; e < R.lam * n; e += 256) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < R.lam * n) {
         const int i = e / n, j = e % n;
         const double lo = lo_of(a, R, j), hi = hi_of(a, R, j);
         double u0, u1, z0, z1;
-        rng4(a, blockIdx.x, 0, i, j, 15, u0, u1, z0, z1);
+        rng4(a, blockIdx.y, 0, i, j, 15, u0, u1, z0, z1);
         double v = lo + u0 * (hi - lo);
         if (i == 0 || (i == 1 && R.kind == 1)) {
             v = (R.kind == 1) ? (j == 0 ? (i == 0 ? t0 : 0.0) : xn[j - 1]) : xn[j];
@@ -102,97 +131,143 @@ __global__ __launch_bounds__(256) void ps_init_kernel(Args a, const double *xn, 
         const int skip = R.kind == 1 ? 1 : 0;  // the evaluation batch holds the x part of every individual of every run
         if (j >= skip) a.Xeval[(size_t)(R.off + i) * a.d + (j - skip)] = v;
     }
-    if (threadIdx.x == 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
         R.best[n] = INFINITY;
         R.best[n + 1] = INFINITY;
         R.stat[0] = 0;
         R.stat[1] = 0;
         R.stat[2] = 0;
+        R.stat[3] = 0;
     }
 }
 
-__global__ __launch_bounds__(256) void ps_step_kernel(Args a) {
-    __shared__ double sf[MAXLAM], sphi[MAXLAM];
-    __shared__ int sidx[MAXLAM];
-    __shared__ int s_swapped, s_stop, s_best;
-    __shared__ int s_cand[256];
-    const int run = blockIdx.x, tid = threadIdx.x;
+__device__ __forceinline__ double wave_sum(double v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// ---- objective and constraint violation of every individual of every run: one wave per row of the evaluation batch
+__global__ __launch_bounds__(256) void ps_score_kernel(Args a) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.rows) return;
+    const int run = run_of_row(a, row);
     const Run &R = a.runs[run];
     if (R.stat[1]) return;  // finished earlier
-    const int n = R.nvar, lam = R.lam, mu = R.mu, k = a.k, gen = a.gen;
-    const double *X = R.X[gen & 1], *S = R.S[gen & 1];
-    double *Xn = R.X[(gen + 1) & 1], *Sn = R.S[(gen + 1) & 1];
+    const int i = row - R.off;
+    const int m = min(R.lam, R.max_evals - R.stat[0]);  // individuals of this generation inside the budget
+    double f = INFINITY, phi = INFINITY;
+    if (i < m) {
+        if (R.kind == 0) {
+            f = a.F[a.obj_model[R.obj]][(size_t)row * a.kf[a.obj_model[R.obj]] + a.obj_col[R.obj]];
+            phi = 0.0;
+        } else {
+            const double t = R.X[a.gen & 1][(size_t)i * R.nvar];
+            f = t;
+            phi = 0.0;
+            for (int l = 0; l < a.nobj; ++l) {
+                const double g = a.F[a.obj_model[l]][(size_t)row * a.kf[a.obj_model[l]] + a.obj_col[l]] - a.mx[l] - t * a.r[l];
+                phi += g > 0.0 ? g * g : 0.0;  // m_l(x) - m_l(x_n) - t r_l <= 0  (descent.jl:443)
+            }
+        }
+        for (int c = 0; c < a.ncon; ++c) {  // modelled constraints (descent.jl:448-466): h(x) = 0, g(x) <= 0
+            const double v = a.F[a.con_model[c]][(size_t)row * a.kf[a.con_model[c]] + a.con_col[c]];
+            if (a.con_eq[c])
+                phi += fabs(v) > a.eq_tol ? v * v : (v == v ? 0.0 : INFINITY);
+            else
+                phi += v > 0.0 ? v * v : (v == v ? 0.0 : INFINITY);
+        }
+        const double *x = a.Xeval + (size_t)row * a.d;
+        for (int c = 0; c < a.nlin_eq + a.nlin_ineq; ++c) {  // linear constraints of the MOP in scaled variables
+            const bool eq = c < a.nlin_eq;
+            const double *Ar = eq ? a.A_eq + (size_t)c * a.d : a.A_ineq + (size_t)(c - a.nlin_eq) * a.d;
+            double s = 0.0;
+            for (int j = lane; j < a.d; j += 64) s = fma(Ar[j], x[j], s);
+            s = wave_sum(s) - (eq ? a.b_eq[c] : a.b_ineq[c - a.nlin_eq]);
+            if (eq)
+                phi += fabs(s) > a.eq_tol ? s * s : (s == s ? 0.0 : INFINITY);
+            else
+                phi += s > 0.0 ? s * s : (s == s ? 0.0 : INFINITY);
+        }
+        if (!(f == f) || !(phi == phi) || fabs(f) == INFINITY || fabs(phi) == INFINITY) {
+            f = INFINITY;
+            phi = INFINITY;
+        }
+    }
+    if (lane == 0) {
+        R.f[i] = f;
+        R.phi[i] = phi;
+    }
+}
+
+// record order of the best-so-far bookkeeping: feasible beats infeasible, then the objective (feasible) or the violation
+// (infeasible), ties by index
+struct Cand {
+    double key;  // f when feasible, phi otherwise
+    int feas;    // 1 feasible, 0 infeasible, -1 none
+    int idx;
+};
+__device__ __forceinline__ bool cand_better(const Cand &x, const Cand &y) {
+    if (y.feas < 0) return x.feas >= 0;
+    if (x.feas < 0) return false;
+    if (x.feas != y.feas) return x.feas > y.feas;
+    if (x.key != y.key) return x.key < y.key;
+    return x.idx < y.idx;
+}
+
+// ---- one workgroup per run: best so far, stop tests, ranking
+__global__ __launch_bounds__(RANK_THREADS) void ps_rank_kernel(Args a) {
+    extern __shared__ double smem[];
+    __shared__ double s_red[2 * (RANK_THREADS / 64)];
+    __shared__ int s_ired[2 * (RANK_THREADS / 64)];
+    __shared__ int s_swapped, s_stop, s_best, s_infeas;
+    const int run = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const Run &R = a.runs[run];
+    if (R.stat[1]) return;
+    const int n = R.nvar, lam = R.lam, mu = R.mu, gen = a.gen;
+    const double *X = R.X[gen & 1];
     const int evals0 = R.stat[0];
-    // a single workgroup is latency-bound: every dependent global load costs ~1-2 us, so the population, the step sizes and the
-    // box are staged in LDS once (coalesced) whenever they fit
-    __shared__ double ldsX[LDSPOP], ldsS[LDSPOP], ldsLo[256], ldsHi[256];
-    const bool staged = lam * n <= LDSPOP && n <= 256;
-    if (staged) {
-        for (int e = tid; e < lam * n; e += 256) {
-            ldsX[e] = X[e];
-            ldsS[e] = S[e];
-        }
-        for (int c = tid; c < n; c += 256) {
-            ldsLo[c] = lo_of(a, R, c);
-            ldsHi[c] = hi_of(a, R, c);
-        }
-        X = ldsX;
-        S = ldsS;
-    }
-    auto lo_at = [&](int c) { return staged ? ldsLo[c] : lo_of(a, R, c); };
-    auto hi_at = [&](int c) { return staged ? ldsHi[c] : hi_of(a, R, c); };
-    const int m = min(lam, R.max_evals - evals0);  // individuals of this generation inside the budget
-    // ---- objective and constraint violation
-    for (int i = tid; i < lam; i += 256) {
-        double f = INFINITY, phi = INFINITY;
-        if (i < m) {
-            const double *Fi = a.F + (size_t)(R.off + i) * k;
-            if (R.kind == 0) {
-                f = Fi[R.obj];
-                phi = 0.0;
-            } else {
-                const double t = X[(size_t)i * n];
-                f = t;
-                phi = 0.0;
-                for (int l = 0; l < k; ++l) {
-                    const double g = Fi[l] - a.mx[l] - t * a.r[l];  // m_l(x) - m_l(x_n) - t r_l <= 0  (descent.jl:443)
-                    phi += g > 0.0 ? g * g : 0.0;
-                }
-            }
-            if (!(f == f) || !(phi == phi) || fabs(f) == INFINITY || fabs(phi) == INFINITY) {
-                f = INFINITY;
-                phi = INFINITY;
-            }
-        }
-        sf[i] = f;
-        sphi[i] = phi;
-        sidx[i] = i;
-    }
+    const int m = min(lam, R.max_evals - evals0);
+    if (tid == 0) s_infeas = 0;
     __syncthreads();
-    // ---- best so far: feasible beats infeasible, then the objective (strided scan per thread, 256 finalists by thread 0)
+    // ---- this generation's best individual and whether any individual inside the budget violates a constraint
     {
-        auto better = [&](int i, int j) {  // is individual i better than j
-            if (j < 0) return true;
-            const bool fi = sphi[i] == 0.0, fj = sphi[j] == 0.0;
-            return (fi && !fj) || (fi && fj && sf[i] < sf[j]) || (!fi && !fj && sphi[i] < sphi[j]);
-        };
-        int mine = -1;
-        for (int i = tid; i < m; i += 256)
-            if (better(i, mine)) mine = i;
-        s_cand[tid] = mine;
+        Cand mine{0.0, -1, 0x7fffffff};
+        bool infeas = false;
+        for (int i = tid; i < m; i += RANK_THREADS) {
+            const double fi = R.f[i], pi = R.phi[i];
+            if (pi > 0.0 && pi < INFINITY) infeas = true;
+            if (pi == INFINITY) continue;
+            const Cand c{pi == 0.0 ? fi : pi, pi == 0.0 ? 1 : 0, i};
+            if (cand_better(c, mine)) mine = c;
+        }
+        if (infeas) s_infeas = 1;
+        for (int off = 32; off > 0; off >>= 1) {
+            Cand o;
+            o.key = __shfl_xor(mine.key, off);
+            o.feas = __shfl_xor(mine.feas, off);
+            o.idx = __shfl_xor(mine.idx, off);
+            if (cand_better(o, mine)) mine = o;
+        }
+        if (lane == 0) {
+            s_red[wave] = mine.key;
+            s_ired[2 * wave] = mine.feas;
+            s_ired[2 * wave + 1] = mine.idx;
+        }
         __syncthreads();
         if (tid == 0) {
-            int j = -1;
-            for (int t = 0; t < 256; ++t)
-                if (s_cand[t] >= 0 && (j < 0 || better(s_cand[t], j) || (!better(j, s_cand[t]) && s_cand[t] < j))) j = s_cand[t];
+            Cand b{0.0, -1, 0x7fffffff};
+            for (int w = 0; w < RANK_THREADS / 64; ++w) {
+                const Cand c{s_red[w], s_ired[2 * w], s_ired[2 * w + 1]};
+                if (cand_better(c, b)) b = c;
+            }
             s_best = -1;
-            if (j >= 0) {
+            if (b.feas >= 0) {
                 const double bf = R.best[n], bphi = R.best[n + 1];
-                const bool fj = sphi[j] == 0.0;
-                if ((fj && (bphi > 0.0 || sf[j] < bf)) || (!fj && sphi[j] < bphi)) {
-                    s_best = j;
-                    R.best[n] = sf[j];
-                    R.best[n + 1] = sphi[j];
+                if ((b.feas == 1 && (bphi > 0.0 || b.key < bf)) || (b.feas == 0 && b.key < bphi)) {
+                    s_best = b.idx;
+                    R.best[n] = b.feas == 1 ? b.key : R.f[b.idx];
+                    R.best[n + 1] = b.feas == 1 ? 0.0 : b.key;
                 }
             }
             R.stat[0] = evals0 + max(m, 0);
@@ -201,222 +276,399 @@ __global__ __launch_bounds__(256) void ps_step_kernel(Args a) {
         }
         __syncthreads();
         if (s_best >= 0)
-            for (int c = tid; c < n; c += 256) R.best[c] = X[(size_t)s_best * n + c];
+            for (int c = tid; c < n; c += RANK_THREADS) R.best[c] = X[(size_t)s_best * n + c];
     }
     if (s_stop) {
         if (tid == 0) R.stat[1] = 1;
         return;
     }
-    // ---- stochastic ranking: lam phases of odd-even transposition; a pair is compared by f when both are feasible or with
-    //      probability 0.45, else by the constraint violation (Runarsson & Yao)
-    // (the records themselves are swapped -- one LDS round trip per phase instead of an index indirection; one Philox call feeds
-    //  four phases of a pair; one barrier per phase; the no-swap exit is tested every 16 phases)
-    // If no individual inside the budget violates a constraint (always so for the ideal-point runs, usually so late in a PS run)
-    // every comparison of the pairwise rule is decided by (violation, objective) whatever is drawn, and lam phases of the stable
-    // transposition sort end in THE sorted order (ties by index): a bitonic network over the padded array reaches the same
-    // order in log2(N) (log2(N) + 1) / 2 phases (45 instead of 260 at lam = 260).
-    __shared__ int s_infeas;
-    if (tid == 0) s_infeas = 0;
-    __syncthreads();
-    for (int i = tid; i < lam; i += 256)
-        if (sphi[i] > 0.0 && sphi[i] < INFINITY) s_infeas = 1;
-    __syncthreads();
+    // ---- ranking.  If no individual inside the budget violates a constraint (always so for unconstrained ideal-point runs,
+    // usually so late in a PS run) every comparison of the pairwise rule is decided by (violation, objective) whatever is drawn,
+    // and lam phases of the stable transposition sort end in THE sorted order (ties by index): a bitonic network over the padded
+    // array reaches the same order in log2(N) (log2(N) + 1) / 2 phases (91 instead of 5160 at lam = 5160).
     const bool plain_sort = s_infeas == 0 && !(a.dbg & 4);
-    if (plain_sort && !(a.dbg & 1)) {
+    int *sidx;
+    if (a.dbg & 1) {
+        sidx = (int *)smem;
+        for (int i = tid; i < lam; i += RANK_THREADS) sidx[i] = i;
+        __syncthreads();
+    } else if (plain_sort) {
         int N = 1;
         while (N < lam) N <<= 1;
-        for (int i = lam + tid; i < N; i += 256) {
-            sf[i] = INFINITY;
-            sphi[i] = INFINITY;
-            sidx[i] = 0x7fffffff;
+        double *sf = smem;      // N keys: violation is 0 or inf here, and inf comes with f = inf
+        sidx = (int *)(sf + N);
+        for (int i = tid; i < N; i += RANK_THREADS) {
+            sf[i] = i < lam ? R.f[i] : INFINITY;
+            sidx[i] = i < lam ? i : 0x7fffffff;
         }
         __syncthreads();
         for (int kk = 2; kk <= N; kk <<= 1)
             for (int j = kk >> 1; j > 0; j >>= 1) {
-                for (int t = tid; t < N / 2; t += 256) {
+                for (int t = tid; t < N / 2; t += RANK_THREADS) {
                     const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;  // the t-th pair of this stage
-                    const double fa = sf[i], fb = sf[l], pa = sphi[i], pb = sphi[l];
+                    const double fa = sf[i], fb = sf[l];
                     const int ia = sidx[i], ib = sidx[l];
-                    const bool greater = pa > pb || (pa == pb && (fa > fb || (fa == fb && ia > ib)));
+                    const bool greater = fa > fb || (fa == fb && ia > ib);
                     const bool up = (i & kk) == 0;
                     if (greater == up) {
                         sf[i] = fb;
                         sf[l] = fa;
-                        sphi[i] = pb;
-                        sphi[l] = pa;
                         sidx[i] = ib;
                         sidx[l] = ia;
                     }
                 }
                 __syncthreads();
             }
-    }
-    if (tid == 0) s_swapped = 1;
-    __syncthreads();
-    for (int ph0 = 0; ph0 < (((a.dbg & 1) || plain_sort) ? 0 : lam); ph0 += 4) {
-        if ((ph0 & 15) == 0) {
-            const int sw = s_swapped;
-            __syncthreads();
-            if (!sw) break;  // sixteen phases without a swap: sorted under the drawn rules
-            if (tid == 0) s_swapped = 0;
-            __syncthreads();
+    } else {
+        // lam phases of odd-even transposition; a pair is compared by f when both are feasible or with probability 0.45, else by
+        // the constraint violation (Runarsson & Yao).  The records themselves are swapped; one Philox call feeds four phases of a
+        // pair; one barrier per phase; the no-swap exit is tested every 16 phases.
+        double *sf = smem, *sphi = sf + lam;
+        sidx = (int *)(sphi + lam);
+        for (int i = tid; i < lam; i += RANK_THREADS) {
+            sf[i] = R.f[i];
+            sphi[i] = R.phi[i];
+            sidx[i] = i;
         }
-        unsigned c4[4] = {0u, 0u, 0u, 0u};
-        bool drawn = false;
+        if (tid == 0) s_swapped = 1;
+        __syncthreads();
+        constexpr int PSLOTS = (MAXLAM / 2 + RANK_THREADS - 1) / RANK_THREADS;  // pairs per thread and phase
+        for (int ph0 = 0; ph0 < lam; ph0 += 4) {
+            if ((ph0 & 15) == 0) {
+                const int sw = s_swapped;
+                __syncthreads();
+                if (!sw) break;  // sixteen phases without a swap: sorted under the drawn rules
+                if (tid == 0) s_swapped = 0;
+                __syncthreads();
+            }
+            unsigned c4[PSLOTS][4];
+            bool drawn[PSLOTS];
 #pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-            const int ph = ph0 + q4;
-            if (ph < lam) {
-                for (int p = tid; 2 * p + (ph & 1) + 1 < lam; p += 256) {
-                    const int j = 2 * p + (ph & 1);
-                    const double fa = sf[j], fb = sf[j + 1], pa = sphi[j], pb = sphi[j + 1];
-                    bool by_f = pa == 0.0 && pb == 0.0;
-                    if (!by_f) {
-                        if (!drawn || p >= 256) {  // (p >= 256 only for lam > 512: one call per pair and phase there)
-                            c4[0] = (unsigned)p;
-                            c4[1] = (unsigned)(p < 256 ? ph0 : ph);
-                            c4[2] = (unsigned)(gen * 16 + 1);
-                            c4[3] = (unsigned)run;
-                            philox(c4, (unsigned)a.seed, (unsigned)(a.seed >> 32));
-                            drawn = p < 256;
+            for (int s = 0; s < PSLOTS; ++s) drawn[s] = false;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int ph = ph0 + q4;
+                if (ph < lam) {
+#pragma unroll
+                    for (int s = 0; s < PSLOTS; ++s) {
+                        const int p = tid + s * RANK_THREADS;
+                        const int j = 2 * p + (ph & 1);
+                        if (j + 1 < lam) {
+                            const double fa = sf[j], fb = sf[j + 1], pa = sphi[j], pb = sphi[j + 1];
+                            bool by_f = pa == 0.0 && pb == 0.0;
+                            if (!by_f) {
+                                if (!drawn[s]) {
+                                    c4[s][0] = (unsigned)p;
+                                    c4[s][1] = (unsigned)ph0;
+                                    c4[s][2] = (unsigned)(gen * 16 + 1);
+                                    c4[s][3] = (unsigned)run;
+                                    philox(c4[s], (unsigned)a.seed, (unsigned)(a.seed >> 32));
+                                    drawn[s] = true;
+                                }
+                                by_f = ((double)c4[s][q4] + 0.5) * (1.0 / 4294967296.0) < 0.45;
+                            }
+                            const bool worse = by_f ? (fa > fb) : (pa > pb);
+                            if (worse) {
+                                const int ia = sidx[j], ib = sidx[j + 1];
+                                sf[j] = fb;
+                                sf[j + 1] = fa;
+                                sphi[j] = pb;
+                                sphi[j + 1] = pa;
+                                sidx[j] = ib;
+                                sidx[j + 1] = ia;
+                                s_swapped = 1;
+                            }
                         }
-                        by_f = ((double)c4[p < 256 ? q4 : 0] + 0.5) * (1.0 / 4294967296.0) < 0.45;
-                    }
-                    const bool worse = by_f ? (fa > fb) : (pa > pb);
-                    if (worse) {
-                        const int ia = sidx[j], ib = sidx[j + 1];
-                        sf[j] = fb;
-                        sf[j + 1] = fa;
-                        sphi[j] = pb;
-                        sphi[j + 1] = pa;
-                        sidx[j] = ib;
-                        sidx[j + 1] = ia;
-                        s_swapped = 1;
                     }
                 }
+                __syncthreads();
             }
-            __syncthreads();
         }
+        __syncthreads();
     }
-    __syncthreads();
-    // ---- stop like NLopt's xtol_rel, on the survivors' spread (one thread per variable)
-    if (tid == 0) s_swapped = 0;  // reused: number of variables whose spread is still above the tolerance
-    __syncthreads();
-    for (int c = tid; c < n; c += 256) {
+    // the parents, in rank order
+    for (int i = tid; i < mu; i += RANK_THREADS) R.order[i] = sidx[i];
+    // ---- stop like NLopt's xtol_rel, on the survivors' spread: variable by variable, leaving at the first one that still spreads
+    bool converged = true;
+    for (int c = 0; c < n; ++c) {
         double lo = INFINITY, hi = -INFINITY;
-        for (int s2 = 0; s2 < mu; ++s2) {
+        for (int s2 = tid; s2 < mu; s2 += RANK_THREADS) {
             const double v = X[(size_t)sidx[s2] * n + c];
             lo = fmin(lo, v);
             hi = fmax(hi, v);
         }
-        if (hi - lo > a.xtol_rel * fmax(fabs(X[(size_t)sidx[0] * n + c]), 1e-300)) atomicAdd(&s_swapped, 1);
+        for (int off = 32; off > 0; off >>= 1) {
+            lo = fmin(lo, __shfl_xor(lo, off));
+            hi = fmax(hi, __shfl_xor(hi, off));
+        }
+        __syncthreads();  // s_red of the previous variable has been read
+        if (lane == 0) {
+            s_red[2 * wave] = lo;
+            s_red[2 * wave + 1] = hi;
+        }
+        __syncthreads();
+        for (int w = 0; w < RANK_THREADS / 64; ++w) {
+            lo = fmin(lo, s_red[2 * w]);
+            hi = fmax(hi, s_red[2 * w + 1]);
+        }
+        if (hi - lo > a.xtol_rel * fmax(fabs(X[(size_t)sidx[0] * n + c]), 1e-300)) {
+            converged = false;
+            break;  // uniform: every thread holds the same lo / hi
+        }
     }
-    __syncthreads();
-    if (s_swapped == 0) {
-        if (tid == 0) R.stat[1] = 1;
-        return;
+    if (tid == 0) {
+        if (converged)
+            R.stat[1] = 1;
+        else
+            R.stat[3] = gen + 1;  // breed the next generation
     }
-    // ---- next generation
+}
+
+// ---- next generation: one wave per offspring, lanes over the components
+__global__ __launch_bounds__(256) void ps_breed_kernel(Args a) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.rows) return;
+    const int run = run_of_row(a, row);
+    const Run &R = a.runs[run];
+    const int gen = a.gen;
+    if (R.stat[3] != gen + 1 || (a.dbg & 2)) return;
+    const int n = R.nvar, mu = R.mu, o = row - R.off;
+    const double *X = R.X[gen & 1], *S = R.S[gen & 1];
+    double *Xn = R.X[(gen + 1) & 1], *Sn = R.S[(gen + 1) & 1];
     const double tau = 1.0 / sqrt(2.0 * sqrt((double)n)), taup = 1.0 / sqrt(2.0 * (double)n), alpha = 0.2, gamma = 0.85;
     const int nd = mu - 1;
-    for (int o = tid; o < ((a.dbg & 2) ? 0 : lam); o += 256) {
-        const int par = sidx[o % mu];
-        const double *xp = X + (size_t)par * n, *sp = S + (size_t)par * n;
-        double *xo = Xn + (size_t)o * n, *so = Sn + (size_t)o * n;
-        const int skip = R.kind == 1 ? 1 : 0;
-        double *xe = a.Xeval + (size_t)(R.off + o) * a.d;  // next generation's row of the evaluation batch (x part)
-        if (o < nd) {
-            // differential variation towards the best individual; kept only if it stays inside the box
-            const double *xb = X + (size_t)sidx[0] * n, *xq = X + (size_t)sidx[o + 1] * n;
-            bool inside = true;
-            for (int c = 0; c < n; ++c) {
-                const double v = xp[c] + gamma * (xb[c] - xq[c]);
-                inside = inside && v >= lo_at(c) && v <= hi_at(c);
+    const int par = R.order[o % mu];
+    const double *xp = X + (size_t)par * n, *sp = S + (size_t)par * n;
+    double *xo = Xn + (size_t)o * n, *so = Sn + (size_t)o * n;
+    const int skip = R.kind == 1 ? 1 : 0;
+    double *xe = a.Xeval + (size_t)row * a.d;  // next generation's row of the evaluation batch (x part)
+    if (o < nd) {
+        // differential variation towards the best individual; kept only if it stays inside the box
+        const double *xb = X + (size_t)R.order[0] * n, *xq = X + (size_t)R.order[o + 1] * n;
+        bool inside = true;
+        for (int c = lane; c < n; c += 64) {
+            const double v = xp[c] + gamma * (xb[c] - xq[c]);
+            inside = inside && v >= lo_of(a, R, c) && v <= hi_of(a, R, c);
+        }
+        inside = __all(inside);
+        for (int c = lane; c < n; c += 64) {
+            const double v = inside ? xp[c] + gamma * (xb[c] - xq[c]) : xp[c];
+            xo[c] = v;
+            so[c] = sp[c];
+            if (c >= skip) xe[c - skip] = v;
+        }
+    } else {
+        double u0, u1, zg, z1;
+        rng4(a, run, gen, o, n, 2, u0, u1, zg, z1);  // the individual's global factor (the same draw in every lane)
+        for (int c = lane; c < n; c += 64) {
+            const double lo = lo_of(a, R, c), hi = hi_of(a, R, c);
+            double z0, zz;
+            rng4(a, run, gen, o, c, 3, u0, u1, z0, zz);
+            double s = sp[c] * (double)__expf((float)(taup * zg + tau * z0));
+            s = fmin(s, (hi - lo) / sqrt((double)n));
+            double v = xp[c] + s * zz;
+            for (int tr = 0; tr < 10 && (v < lo || v > hi); ++tr) {  // re-draw components that leave the box
+                double w0, w1;
+                rng4(a, run, gen, o, c, 4 + tr, u0, u1, w0, w1);
+                v = xp[c] + s * w0;
             }
-            for (int c = 0; c < n; ++c) {
-                const double v = inside ? xp[c] + gamma * (xb[c] - xq[c]) : xp[c];
-                xo[c] = v;
-                so[c] = sp[c];
-                if (c >= skip) xe[c - skip] = v;
-            }
-        } else {
-            double u0, u1, zg, z1;
-            rng4(a, run, gen, o, n, 2, u0, u1, zg, z1);  // the individual's global factor
-            for (int c = 0; c < n; ++c) {
-                const double lo = lo_at(c), hi = hi_at(c);
-                double z0, zz;
-                rng4(a, run, gen, o, c, 3, u0, u1, z0, zz);
-                double s = sp[c] * (double)__expf((float)(taup * zg + tau * z0));
-                s = fmin(s, (hi - lo) / sqrt((double)n));
-                double v = xp[c] + s * zz;
-                for (int tr = 0; tr < 10 && (v < lo || v > hi); ++tr) {  // re-draw components that leave the box
-                    double w0, w1;
-                    rng4(a, run, gen, o, c, 4 + tr, u0, u1, w0, w1);
-                    v = xp[c] + s * w0;
-                }
-                if (v < lo || v > hi) v = xp[c];
-                xo[c] = v;
-                if (c >= skip) xe[c - skip] = v;
-                so[c] = sp[c] + alpha * (s - sp[c]);  // exponential smoothing
-            }
+            if (v < lo || v > hi) v = xp[c];
+            xo[c] = v;
+            if (c >= skip) xe[c - skip] = v;
+            so[c] = sp[c] + alpha * (s - sp[c]);  // exponential smoothing
         }
     }
 }
 
+// host view of the problem (function table, constraints) shared by the driver and the polish
+struct Problem {
+    int nmodels = 0, nobj = 0, nftot = 0, d = 0;
+    const mrbf_model *models[MAXMODELS] = {};
+    int foff[MAXMODELS] = {};  // first column of model j in the concatenated function vector
+    int obj_model[MAXOBJ] = {}, obj_col[MAXOBJ] = {};
+    int ncon = 0, con_model[MAXCON] = {}, con_col[MAXCON] = {}, con_eq[MAXCON] = {};
+    int nlin_eq = 0, nlin_ineq = 0;
+    std::vector<double> A_eq, b_eq, A_ineq, b_ineq;  // host copies (polish, final feasibility)
+    const double *dA_eq = nullptr, *db_eq = nullptr, *dA_ineq = nullptr, *db_ineq = nullptr;
+    double eq_tol = 1e-8;
+    double objective(const std::vector<double> &allF, int l) const { return allF[foff[obj_model[l]] + obj_col[l]]; }
+    // sum of squared violations of the modelled and linear constraints at x (allF = all model outputs at x)
+    double violation(const std::vector<double> &allF, const double *x) const {
+        double phi = 0.0;
+        for (int c = 0; c < ncon; ++c) {
+            const double v = allF[foff[con_model[c]] + con_col[c]];
+            if (con_eq[c] ? std::fabs(v) > eq_tol : v > 0.0) phi += v * v;
+            if (!(v == v)) phi = INFINITY;
+        }
+        for (int c = 0; c < nlin_eq + nlin_ineq; ++c) {
+            const bool eq = c < nlin_eq;
+            const double *Ar = eq ? &A_eq[(size_t)c * d] : &A_ineq[(size_t)(c - nlin_eq) * d];
+            double s = 0.0;
+            for (int j = 0; j < d; ++j) s = std::fma(Ar[j], x[j], s);
+            s -= eq ? b_eq[c] : b_ineq[c - nlin_eq];
+            if (eq ? std::fabs(s) > eq_tol : s > 0.0) phi += s * s;
+        }
+        return phi;
+    }
+};
+
 }  // namespace ps
 
-// host-side gradient polish of the PS solution (the reference hands a local NLopt algorithm, descent.jl:560-569): projected steps on
-// chi = [t; x] that keep every iterate feasible; each trial costs one batched value (+ Jacobian) call
-static int ps_polish(mrbf_ctx *ctx, const mrbf_model *M, const std::vector<double> &lb, const std::vector<double> &ub, const std::vector<double> &mx,
+// all model outputs at m points (row-major m x nftot) and, optionally (m == 1), the objectives' Jacobian rows
+static int ps_eval_points(mrbf_ctx *ctx, const ps::Problem &P, const double *x_host, int m, std::vector<double> &allF, std::vector<double> *Jobj) {
+    const int d = P.d;
+    double *dX;
+    size_t cnt = (size_t)m * d + (size_t)m * P.nftot;
+    for (int j = 0; j < P.nmodels; ++j) cnt += (size_t)P.models[j]->k * d;
+    MRBF_TRY(get_buf(ctx, S_PS_POLISH, cnt, &dX));
+    double *dV = dX + (size_t)m * d, *dJ = dV + (size_t)m * P.nftot;
+    MRBF_HIP(ctx, hipMemcpyAsync(dX, x_host, (size_t)m * d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    std::vector<double *> jp(P.nmodels, nullptr), vp(P.nmodels, nullptr);
+    for (int j = 0; j < P.nmodels; ++j) {
+        bool need = false;
+        for (int l = 0; Jobj && m == 1 && l < P.nobj; ++l) need = need || P.obj_model[l] == j;
+        jp[j] = need ? dJ : nullptr;
+        vp[j] = dV + (size_t)m * P.foff[j];  // model j's m x k_j block
+        MRBF_TRY(eval_model(ctx, P.models[j], m, dX, vp[j], jp[j], nullptr));
+        dJ += (size_t)P.models[j]->k * d;
+    }
+    std::vector<double> blocks((size_t)m * P.nftot);
+    MRBF_HIP(ctx, hipMemcpyAsync(blocks.data(), dV, blocks.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<std::vector<double>> Jm(P.nmodels);
+    for (int j = 0; j < P.nmodels; ++j)
+        if (jp[j]) {
+            Jm[j].resize((size_t)P.models[j]->k * d);
+            MRBF_HIP(ctx, hipMemcpyAsync(Jm[j].data(), jp[j], Jm[j].size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        }
+    MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    allF.resize((size_t)m * P.nftot);
+    for (int j = 0; j < P.nmodels; ++j) {
+        const int kj = P.models[j]->k;
+        for (int p = 0; p < m; ++p)
+            for (int c = 0; c < kj; ++c) allF[(size_t)p * P.nftot + P.foff[j] + c] = blocks[(size_t)m * P.foff[j] + (size_t)p * kj + c];
+    }
+    if (Jobj && m == 1) {
+        Jobj->resize((size_t)P.nobj * d);
+        for (int l = 0; l < P.nobj; ++l) {
+            const int j = P.obj_model[l], kj = P.models[j]->k;
+            for (int t = 0; t < d; ++t) (*Jobj)[(size_t)l * d + t] = Jm[j][(size_t)t * kj + P.obj_col[l]];  // per point k x d column-major
+        }
+    }
+    return 0;
+}
+static int ps_eval_point(mrbf_ctx *ctx, const ps::Problem &P, const double *x_host, std::vector<double> &allF, std::vector<double> *Jobj) {
+    return ps_eval_points(ctx, P, x_host, 1, allF, Jobj);
+}
+
+// weights of the minimum-norm point of the convex hull of k vectors with Gram matrix M (k x k): Gilbert / Frank-Wolfe steps
+static void min_norm_weights(int k, const std::vector<double> &M, std::vector<double> &lam) {
+    lam.assign(k, 1.0 / k);
+    std::vector<double> Ml(k);
+    for (int it = 0; it < 500; ++it) {
+        double gg = 0.0;
+        for (int a = 0; a < k; ++a) {
+            Ml[a] = 0.0;
+            for (int b = 0; b < k; ++b) Ml[a] += M[(size_t)a * k + b] * lam[b];
+            gg += lam[a] * Ml[a];
+        }
+        int best = 0;
+        for (int a = 1; a < k; ++a)
+            if (Ml[a] < Ml[best]) best = a;
+        if (gg - Ml[best] <= 1e-14 * std::max(gg, 1e-300)) break;
+        const double den = gg - 2.0 * Ml[best] + M[(size_t)best * k + best];
+        const double gamma = den > 0.0 ? std::min(1.0, std::max(0.0, (gg - Ml[best]) / den)) : 1.0;
+        for (int a = 0; a < k; ++a) lam[a] *= (1.0 - gamma);
+        lam[best] += gamma;
+    }
+}
+
+// Gradient polish of the PS solution (the reference hands a local NLopt algorithm, descent.jl:560-569; the paper benchmark uses
+// :LD_MMA with 100 (d + 1) evaluations, examples/large_scale_benchmarks.jl:217-219).  Here: multi-objective steepest descent on
+// max_l (m_l(x) - m_l(x_n)) / r_l -- the direction is minus the minimum-norm convex combination of the (nearly) active scaled
+// gradients, projected at active bounds -- with all step sizes of a line search evaluated as ONE batch; every accepted iterate is
+// feasible (PS constraints, modelled and linear constraints, box).  Each iteration costs 1 + NSTEP evaluations.
+static int ps_polish(mrbf_ctx *ctx, const ps::Problem &P, const std::vector<double> &lb, const std::vector<double> &ub, const std::vector<double> &mx,
                      const std::vector<double> &r, int max_evals, double &tau, std::vector<double> &x, int *evals_out) {
-    const int d = M->d, k = M->k;
-    double *dX, *dV, *dJ;
-    MRBF_TRY(get_buf(ctx, S_PS_POLISH, (size_t)d + k + (size_t)k * d, &dX));
-    dV = dX + d;
-    dJ = dV + k;
-    std::vector<double> F(k), J((size_t)k * d), Ft(k), xt(d), dir(d);
+    const int d = P.d, k = P.nobj;
+    constexpr int NSTEP = 12;
+    std::vector<double> allF, J, F(k), dir(d), XT((size_t)NSTEP * d), M, lam;
     int evals = 0;
-    auto eval = [&](const std::vector<double> &xx, std::vector<double> &out, bool jac) -> int {
-        MRBF_HIP(ctx, hipMemcpyAsync(dX, xx.data(), d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-        MRBF_TRY(eval_model(ctx, M, 1, dX, dV, jac ? dJ : nullptr, nullptr));
-        MRBF_HIP(ctx, hipMemcpyAsync(out.data(), dV, k * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        if (jac) MRBF_HIP(ctx, hipMemcpyAsync(J.data(), dJ, (size_t)k * d * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    while (evals + 1 + NSTEP <= max_evals) {
+        MRBF_TRY(ps_eval_point(ctx, P, x.data(), allF, &J));
         ++evals;
-        return 0;
-    };
-    while (evals < max_evals) {
-        MRBF_TRY(eval(x, F, true));
-        int act = 0;
-        for (int l = 1; l < k; ++l)
-            if ((F[l] - mx[l]) / r[l] > (F[act] - mx[act]) / r[act]) act = l;
-        double nrm = 0.0;
+        double tmax = -INFINITY;
+        for (int l = 0; l < k; ++l) {
+            F[l] = (P.objective(allF, l) - mx[l]) / r[l];
+            tmax = std::max(tmax, F[l]);
+        }
+        std::vector<int> act;
+        for (int l = 0; l < k; ++l)
+            if (F[l] >= tmax - 0.05) act.push_back(l);
+        const int ka = (int)act.size();
+        // scaled gradients of the active objectives; components that every one of them pushes through an active bound are dropped
+        std::vector<double> G((size_t)ka * d);
         for (int t = 0; t < d; ++t) {
-            dir[t] = -J[(size_t)t * k + act] / r[act];  // per point k x d column-major block
-            nrm += dir[t] * dir[t];
-        }
-        if (nrm == 0.0) break;
-        double step = 1.0;
-        bool improved = false;
-        for (int it = 0; it < 20 && evals < max_evals; ++it) {
-            for (int t = 0; t < d; ++t) xt[t] = std::min(std::max(x[t] + step * dir[t], lb[t]), ub[t]);
-            MRBF_TRY(eval(xt, Ft, false));
-            double tt = -1.0;
-            for (int l = 0; l < k; ++l) tt = std::max(tt, (Ft[l] - mx[l]) / r[l]);
-            tt = std::min(std::max(tt, -1.0), 0.0);
-            bool feas = true;
-            for (int l = 0; l < k; ++l) feas = feas && (Ft[l] - mx[l] - tt * r[l] <= 1e-14);
-            if (feas && tt < tau - 1e-12) {
-                x = xt;
-                tau = tt;
-                improved = true;
-                break;
+            bool out_lo = x[t] <= lb[t], out_hi = x[t] >= ub[t];
+            for (int a = 0; a < ka; ++a) {
+                const double g = J[(size_t)act[a] * d + t] / r[act[a]];
+                G[(size_t)a * d + t] = g;
+                out_lo = out_lo && g > 0.0;  // descent direction -g < 0 leaves through the lower bound
+                out_hi = out_hi && g < 0.0;
             }
-            step *= 0.5;
+            if (out_lo || out_hi)
+                for (int a = 0; a < ka; ++a) G[(size_t)a * d + t] = 0.0;
         }
-        if (!improved) break;
+        M.assign((size_t)ka * ka, 0.0);
+        for (int a = 0; a < ka; ++a)
+            for (int b = 0; b <= a; ++b) {
+                double sdot = 0.0;
+                for (int t = 0; t < d; ++t) sdot += G[(size_t)a * d + t] * G[(size_t)b * d + t];
+                M[(size_t)a * ka + b] = M[(size_t)b * ka + a] = sdot;
+            }
+        min_norm_weights(ka, M, lam);
+        double dmax = 0.0, width = 0.0;
+        for (int t = 0; t < d; ++t) {
+            double v = 0.0;
+            for (int a = 0; a < ka; ++a) v -= lam[a] * G[(size_t)a * d + t];
+            dir[t] = v;
+            dmax = std::max(dmax, std::fabs(v));
+            width = std::max(width, ub[t] - lb[t]);
+        }
+        if (!(dmax > 0.0) || !(width > 0.0)) break;  // Pareto-critical for the active objectives (or a degenerate box)
+        double step = width / dmax;                  // the first trial moves the fastest component across the whole box
+        for (int j = 0; j < NSTEP; ++j, step *= 0.5)
+            for (int t = 0; t < d; ++t) XT[(size_t)j * d + t] = std::min(std::max(x[t] + step * dir[t], lb[t]), ub[t]);
+        MRBF_TRY(ps_eval_points(ctx, P, XT.data(), NSTEP, allF, nullptr));
+        evals += NSTEP;
+        int bestj = -1;
+        double bestt = tau - 1e-12;
+        std::vector<double> row(P.nftot);
+        for (int j = 0; j < NSTEP; ++j) {
+            for (int c = 0; c < P.nftot; ++c) row[c] = allF[(size_t)j * P.nftot + c];
+            double tt = -1.0;
+            for (int l = 0; l < k; ++l) tt = std::max(tt, (P.objective(row, l) - mx[l]) / r[l]);
+            if (!(tt == tt)) continue;
+            tt = std::min(std::max(tt, -1.0), 0.0);
+            bool feas = P.violation(row, &XT[(size_t)j * d]) == 0.0;
+            for (int l = 0; l < k; ++l) feas = feas && (P.objective(row, l) - mx[l] - tt * r[l] <= 1e-14);
+            if (feas && tt < bestt) {
+                bestt = tt;
+                bestj = j;
+            }
+        }
+        if (bestj < 0) break;
+        for (int t = 0; t < d; ++t) x[t] = XT[(size_t)bestj * d + t];
+        tau = bestt;
+        if (tau <= -1.0) break;
     }
     *evals_out = evals;
+    return 0;
+}
+
+static int fetch_host(mrbf_ctx *ctx, const double *src, size_t cnt, std::vector<double> &dst) {
+    dst.resize(cnt);
+    if (cnt) MRBF_HIP(ctx, hipMemcpy(dst.data(), src, cnt * sizeof(double), hipMemcpyDefault));
     return 0;
 }
 
@@ -424,11 +676,11 @@ static int ps_polish(mrbf_ctx *ctx, const mrbf_model *M, const std::vector<doubl
 
 using namespace mrbf;
 
-extern "C" int32_t mrbf_ps_step(mrbf_ctx *ctx, const mrbf_model *model, const double *x_n, const double *lb_eff, const double *ub_eff,
-                                const double *fx_n, const double *r_or_null, const mrbf_ps_options *opts, double *x_trial, double *mx_trial,
-                                double *r_out, mrbf_ps_info *info) {
+extern "C" int32_t mrbf_ps_step_problem(mrbf_ctx *ctx, const mrbf_ps_problem *prob, const double *x_n, const double *lb_eff, const double *ub_eff,
+                                        const double *fx_n, const double *r_or_null, const mrbf_ps_options *opts, double *x_trial,
+                                        double *mx_trial, double *r_out, mrbf_ps_info *info) {
     if (!ctx) return -1;
-    if (!model) return fail(ctx, -2, "model is NULL");
+    if (!prob) return fail(ctx, -2, "problem is NULL");
     if (!x_n) return fail(ctx, -3, "x_n is NULL");
     if (!lb_eff) return fail(ctx, -4, "lb_eff is NULL");
     if (!ub_eff) return fail(ctx, -5, "ub_eff is NULL");
@@ -440,38 +692,102 @@ extern "C" int32_t mrbf_ps_step(mrbf_ctx *ctx, const mrbf_model *model, const do
     if (!info) return fail(ctx, -12, "info is NULL");
     (void)hipSetDevice(ctx->device);
     using namespace ps;
-    const int d = model->d, k = model->k;
     std::memset(info, 0, sizeof(*info));
-    if (20 * (d + 2) > MAXLAM || k > 8) return fail(ctx, -2, "mrbf_ps_step: d = %d (limit %d) or k = %d (limit 8) too large for the device path", d, MAXLAM / 20 - 2, k);
+    // ---- the function table
+    if (prob->n_models < 1 || prob->n_models > MAXMODELS || !prob->models || !prob->roles)
+        return fail(ctx, -2, "mrbf_ps_step: 1..%d grouped models with a roles table are required", MAXMODELS);
+    Problem P;
+    P.nmodels = prob->n_models;
+    P.nobj = prob->n_objectives;
+    if (P.nobj < 1 || P.nobj > MAXOBJ) return fail(ctx, -2, "mrbf_ps_step: %d objectives (device path: 1..%d)", P.nobj, MAXOBJ);
+    std::vector<int> seen(P.nobj, 0);
+    for (int j = 0, e = 0; j < P.nmodels; ++j) {
+        const mrbf_model *M = prob->models[j];
+        if (!M) return fail(ctx, -2, "mrbf_ps_step: model %d is NULL", j);
+        if (j == 0) P.d = M->d;
+        if (M->d != P.d) return fail(ctx, -2, "mrbf_ps_step: model %d has %d variables, model 0 has %d", j, M->d, P.d);
+        P.models[j] = M;
+        P.foff[j] = P.nftot;
+        P.nftot += M->k;
+        for (int c = 0; c < M->k; ++c, ++e) {
+            const int role = prob->roles[e];
+            if (role >= 0) {
+                if (role >= P.nobj || seen[role]) return fail(ctx, -2, "mrbf_ps_step: roles[%d] = %d is not a (new) objective position", e, role);
+                seen[role] = 1;
+                P.obj_model[role] = j;
+                P.obj_col[role] = c;
+            } else if (role == MRBF_ROLE_EQ || role == MRBF_ROLE_INEQ) {
+                if (P.ncon >= MAXCON) return fail(ctx, -2, "mrbf_ps_step: more than %d modelled constraints", MAXCON);
+                P.con_model[P.ncon] = j;
+                P.con_col[P.ncon] = c;
+                P.con_eq[P.ncon] = role == MRBF_ROLE_EQ;
+                ++P.ncon;
+            } else if (role != MRBF_ROLE_NONE) {
+                return fail(ctx, -2, "mrbf_ps_step: roles[%d] = %d is not a role", e, role);
+            }
+        }
+    }
+    for (int l = 0; l < P.nobj; ++l)
+        if (!seen[l]) return fail(ctx, -2, "mrbf_ps_step: objective %d is not an output of any model", l);
+    const int d = P.d, k = P.nobj;
+    if (mrbf_dispatch_ps(d, k, P.nmodels, P.ncon, prob->n_lin_eq + prob->n_lin_ineq, 0) != MRBF_DISPATCH_DEVICE)
+        return fail(ctx, -2, "mrbf_ps_step: d = %d / k = %d / %d constraints outside the device path (ask mrbf_dispatch_ps first)", d, k, P.ncon);
+    P.nlin_eq = prob->n_lin_eq;
+    P.nlin_ineq = prob->n_lin_ineq;
+    if (P.nlin_eq < 0 || P.nlin_ineq < 0) return fail(ctx, -2, "mrbf_ps_step: negative constraint count");
+    if ((P.nlin_eq && (!prob->A_eq || !prob->b_eq)) || (P.nlin_ineq && (!prob->A_ineq || !prob->b_ineq)))
+        return fail(ctx, -2, "mrbf_ps_step: linear constraint matrices are NULL");
+    P.eq_tol = prob->eq_tol >= 0.0 ? prob->eq_tol : 1e-8;
+    // box, start point, direction: host copies first (the pointers may be host or device memory)
+    std::vector<double> hlb, hub, hxn, hfx, r(k), mx(k), allF;
+    MRBF_TRY(fetch_host(ctx, lb_eff, d, hlb));
+    MRBF_TRY(fetch_host(ctx, ub_eff, d, hub));
+    MRBF_TRY(fetch_host(ctx, x_n, d, hxn));
+    if (fx_n) MRBF_TRY(fetch_host(ctx, fx_n, k, hfx));
+    if (r_or_null) MRBF_TRY(fetch_host(ctx, r_or_null, k, r));
     for (int t = 0; t < d; ++t)
-        if (!(lb_eff[t] <= ub_eff[t])) return fail(ctx, -4, "lb_eff[%d] > ub_eff[%d]", t, t);
+        if (!(hlb[t] <= hub[t])) return fail(ctx, -4, "lb_eff[%d] > ub_eff[%d]", t, t);
+    MRBF_TRY(fetch_host(ctx, prob->A_eq, (size_t)P.nlin_eq * d, P.A_eq));
+    MRBF_TRY(fetch_host(ctx, prob->b_eq, (size_t)P.nlin_eq, P.b_eq));
+    MRBF_TRY(fetch_host(ctx, prob->A_ineq, (size_t)P.nlin_ineq * d, P.A_ineq));
+    MRBF_TRY(fetch_host(ctx, prob->b_ineq, (size_t)P.nlin_ineq, P.b_ineq));
+
     hipEvent_t e0 = ctx->ev[0], e1 = ctx->ev[1];
     MRBF_HIP(ctx, hipEventRecord(e0, ctx->stream));
     const bool need_ideal = r_or_null == nullptr;
     const int lam_ip = 20 * (d + 1), lam_ps = 20 * (d + 2);
-    const int rows = (need_ideal ? k * lam_ip : 0) + lam_ps;
-    // device arena: box, x_n, mx, r, evaluation batch, results, per-run state
-    const size_t per_ip = (size_t)4 * lam_ip * d + d + 2, per_ps = (size_t)4 * lam_ps * (d + 1) + d + 3;
-    const size_t cnt = (size_t)3 * d + 2 * k + (size_t)rows * d + (size_t)rows * k + k * per_ip + per_ps + 64;
+    const int rows = std::max(need_ideal ? k * lam_ip : 0, lam_ps);
+    // device arena: box, x_n, mx, r, linear constraints, evaluation batch, results, per-run state
+    const size_t nlin = (size_t)P.nlin_eq + P.nlin_ineq;
+    const size_t per_ip = (size_t)4 * lam_ip * d + d + 2 + (size_t)3 * lam_ip, per_ps = (size_t)4 * lam_ps * (d + 1) + d + 3 + (size_t)3 * lam_ps;
+    const size_t cnt = (size_t)3 * d + 2 * k + nlin * (d + 1) + (size_t)rows * d + (size_t)rows * P.nftot + std::max(k * per_ip, per_ps) + 64;
     double *base;
     int *stat;
     MRBF_TRY(get_buf(ctx, S_PS_STATE, cnt, &base));
-    MRBF_TRY(get_buf(ctx, S_PS_STAT, (size_t)4 * 9, &stat));
-    double *dlb = base, *dub = dlb + d, *dxn = dub + d, *dmx = dxn + d, *dr = dmx + k, *Xeval = dr + k, *F = Xeval + (size_t)rows * d;
-    double *pool = F + (size_t)rows * k;
-    MRBF_HIP(ctx, hipMemcpyAsync(dlb, lb_eff, d * sizeof(double), hipMemcpyDefault, ctx->stream));
-    MRBF_HIP(ctx, hipMemcpyAsync(dub, ub_eff, d * sizeof(double), hipMemcpyDefault, ctx->stream));
-    MRBF_HIP(ctx, hipMemcpyAsync(dxn, x_n, d * sizeof(double), hipMemcpyDefault, ctx->stream));
-    // mx = m(x_n)
-    MRBF_TRY(eval_model(ctx, model, 1, dxn, dmx, nullptr, nullptr));
-    std::vector<double> mx(k), r(k), hlb(d), hub(d), hxn(d), hfx(k);
-    if (fx_n) MRBF_HIP(ctx, hipMemcpyAsync(hfx.data(), fx_n, k * sizeof(double), hipMemcpyDefault, ctx->stream));
-    if (r_or_null) MRBF_HIP(ctx, hipMemcpyAsync(r.data(), r_or_null, k * sizeof(double), hipMemcpyDefault, ctx->stream));
-    MRBF_HIP(ctx, hipMemcpyAsync(mx.data(), dmx, k * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    MRBF_HIP(ctx, hipMemcpyAsync(hlb.data(), dlb, d * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    MRBF_HIP(ctx, hipMemcpyAsync(hub.data(), dub, d * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    MRBF_HIP(ctx, hipMemcpyAsync(hxn.data(), dxn, d * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    MRBF_TRY(get_buf(ctx, S_PS_STAT, (size_t)4 * MAXRUNS, &stat));
+    double *dlb = base, *dub = dlb + d, *dxn = dub + d, *dmx = dxn + d, *dr = dmx + k, *dlin = dr + k;
+    double *Xeval = dlin + nlin * (d + 1), *F = Xeval + (size_t)rows * d;
+    double *pool = F + (size_t)rows * P.nftot;
+    MRBF_HIP(ctx, hipMemcpyAsync(dlb, hlb.data(), d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    MRBF_HIP(ctx, hipMemcpyAsync(dub, hub.data(), d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    MRBF_HIP(ctx, hipMemcpyAsync(dxn, hxn.data(), d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    {
+        double *p = dlin;
+        auto up = [&](const std::vector<double> &v, const double **dev) -> int {
+            *dev = p;
+            if (!v.empty()) MRBF_HIP(ctx, hipMemcpyAsync(p, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+            p += v.size();
+            return 0;
+        };
+        MRBF_TRY(up(P.A_eq, &P.dA_eq));
+        MRBF_TRY(up(P.b_eq, &P.db_eq));
+        MRBF_TRY(up(P.A_ineq, &P.dA_ineq));
+        MRBF_TRY(up(P.b_ineq, &P.db_ineq));
+    }
+    // mx = m(x_n)  (descent.jl:543)
+    MRBF_TRY(ps_eval_point(ctx, P, hxn.data(), allF, nullptr));
+    for (int l = 0; l < k; ++l) mx[l] = P.objective(allF, l);
+    MRBF_HIP(ctx, hipMemcpyAsync(dmx, mx.data(), k * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     const int max_ip = opts->max_ideal_evals < 0 ? 500 * (d + 1) : opts->max_ideal_evals;   // descent.jl:527
     const int max_ps = opts->max_ps_evals < 0 ? 500 * (d + 1) : opts->max_ps_evals;          // descent.jl:416
     const double xtol = opts->xtol_rel > 0.0 ? opts->xtol_rel : 1e-3;                        // descent.jl:379, :485
@@ -492,17 +808,36 @@ extern "C" int32_t mrbf_ps_step(mrbf_ctx *ctx, const mrbf_model *model, const do
         }
         R.best = p;
         p += nvar + 2;
+        R.f = p;
+        p += lam;
+        R.phi = p;
+        p += lam;
+        R.order = (int *)p;
+        p += lam;
         R.stat = st;
     };
     auto run_batch = [&](Args &a, const double *start, double t0, int max_gens) -> int {
-        hipLaunchKernelGGL(ps_init_kernel, dim3((unsigned)a.nruns), dim3(256), 0, ctx->stream, a, start, t0);
-        int rows_now = 0;
-        for (int q2 = 0; q2 < a.nruns; ++q2) rows_now = std::max(rows_now, a.runs[q2].off + a.runs[q2].lam);
+        int maxlam = 0, maxel = 0;
+        a.rows = 0;
+        for (int q2 = 0; q2 < a.nruns; ++q2) {
+            a.rows = std::max(a.rows, a.runs[q2].off + a.runs[q2].lam);
+            maxlam = std::max(maxlam, a.runs[q2].lam);
+            maxel = std::max(maxel, a.runs[q2].lam * a.runs[q2].nvar);
+        }
+        int N = 1;
+        while (N < maxlam) N <<= 1;
+        const size_t shm = std::max((size_t)20 * maxlam, (size_t)12 * N);
+        MRBF_HIP(ctx, hipFuncSetAttribute((const void *)ps_rank_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        hipLaunchKernelGGL(ps_init_kernel, dim3((unsigned)((maxel + 255) / 256), (unsigned)a.nruns), dim3(256), 0, ctx->stream, a, start, t0);
         std::vector<int> hstat((size_t)4 * a.nruns);
+        const unsigned wave_blocks = (unsigned)((a.rows + 3) / 4);
         for (int g = 0; g < max_gens; ++g) {
             a.gen = g;
-            MRBF_TRY(eval_model(ctx, model, rows_now, a.Xeval, const_cast<double *>(a.F), nullptr, nullptr));
-            hipLaunchKernelGGL(ps_step_kernel, dim3((unsigned)a.nruns), dim3(256), 0, ctx->stream, a);
+            for (int j = 0; j < P.nmodels; ++j)
+                MRBF_TRY(eval_model(ctx, P.models[j], a.rows, a.Xeval, const_cast<double *>(a.F[j]), nullptr, nullptr));
+            hipLaunchKernelGGL(ps_score_kernel, dim3(wave_blocks), dim3(256), 0, ctx->stream, a);
+            hipLaunchKernelGGL(ps_rank_kernel, dim3((unsigned)a.nruns), dim3(RANK_THREADS), shm, ctx->stream, a);
+            hipLaunchKernelGGL(ps_breed_kernel, dim3(wave_blocks), dim3(256), 0, ctx->stream, a);
             if ((g & 7) == 7 || g + 1 == max_gens) {  // status words every 8 generations: stop when every run is done
                 MRBF_HIP(ctx, hipMemcpyAsync(hstat.data(), a.runs[0].stat, hstat.size() * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
                 MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -517,12 +852,37 @@ extern "C" int32_t mrbf_ps_step(mrbf_ctx *ctx, const mrbf_model *model, const do
 
     Args a{};
     a.d = d;
-    a.k = k;
+    a.nobj = k;
     a.lb = dlb;
     a.ub = dub;
     a.mx = dmx;
     a.r = dr;
-    a.F = F;
+    a.nmodels = P.nmodels;
+    {
+        double *fp = F;
+        for (int j = 0; j < P.nmodels; ++j) {
+            a.F[j] = fp;
+            a.kf[j] = P.models[j]->k;
+            fp += (size_t)rows * P.models[j]->k;
+        }
+    }
+    for (int l = 0; l < k; ++l) {
+        a.obj_model[l] = (short)P.obj_model[l];
+        a.obj_col[l] = (short)P.obj_col[l];
+    }
+    a.ncon = P.ncon;
+    for (int c = 0; c < P.ncon; ++c) {
+        a.con_model[c] = (short)P.con_model[c];
+        a.con_col[c] = (short)P.con_col[c];
+        a.con_eq[c] = (short)P.con_eq[c];
+    }
+    a.nlin_eq = P.nlin_eq;
+    a.nlin_ineq = P.nlin_ineq;
+    a.A_eq = P.dA_eq;
+    a.b_eq = P.db_eq;
+    a.A_ineq = P.dA_ineq;
+    a.b_ineq = P.db_ineq;
+    a.eq_tol = P.eq_tol;
     a.Xeval = Xeval;
     a.seed = opts->seed;
     a.dbg = getenv("MRBF_PS_DBG") ? atoi(getenv("MRBF_PS_DBG")) : 0;
@@ -533,14 +893,16 @@ extern "C" int32_t mrbf_ps_step(mrbf_ctx *ctx, const mrbf_model *model, const do
         a.nruns = k;
         for (int l = 0; l < k; ++l) make_run(a.runs[l], 0, l, lam_ip, d, l * lam_ip, max_ip, p, stat + 4 * l);
         MRBF_TRY(run_batch(a, dxn, 0.0, (max_ip + lam_ip - 1) / lam_ip + 1));
-        std::vector<double> bf(k);
+        std::vector<double> bf(2 * k);
         std::vector<int> hs((size_t)4 * k);
         for (int l = 0; l < k; ++l)
-            MRBF_HIP(ctx, hipMemcpyAsync(&bf[l], a.runs[l].best + d, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            MRBF_HIP(ctx, hipMemcpyAsync(&bf[2 * l], a.runs[l].best + d, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         MRBF_HIP(ctx, hipMemcpyAsync(hs.data(), stat, hs.size() * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
         for (int l = 0; l < k; ++l) {
-            r[l] = hfx[l] - bf[l];  // r = f(x_n) - ideal point (descent.jl:536-538)
+            // r = f(x_n) - ideal point (descent.jl:536-538); a run that never met a feasible point contributes its start value
+            const double ideal = (bf[2 * l + 1] == 0.0 && std::isfinite(bf[2 * l])) ? bf[2 * l] : mx[l];
+            r[l] = hfx[l] - ideal;
             info->evals_ideal += hs[(size_t)4 * l];
             info->generations += hs[(size_t)4 * l + 2];
         }
@@ -572,7 +934,7 @@ extern "C" int32_t mrbf_ps_step(mrbf_ctx *ctx, const mrbf_model *model, const do
             for (int t = 0; t < d; ++t) xt[t] = best[1 + t];
             if (opts->max_polish_evals > 0) {
                 int pe = 0;
-                MRBF_TRY(ps_polish(ctx, model, hlb, hub, mx, r, opts->max_polish_evals, tau, xt, &pe));
+                MRBF_TRY(ps_polish(ctx, P, hlb, hub, mx, r, opts->max_polish_evals, tau, xt, &pe));
                 info->evals_polish = pe;
             }
             info->tau = tau;
@@ -581,9 +943,8 @@ extern "C" int32_t mrbf_ps_step(mrbf_ctx *ctx, const mrbf_model *model, const do
     }
     // mx_trial = m(x_trial)
     if (info->status == MRBF_PS_OK) {
-        MRBF_HIP(ctx, hipMemcpyAsync(dxn, xt.data(), d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-        MRBF_TRY(eval_model(ctx, model, 1, dxn, dmx, nullptr, nullptr));
-        MRBF_HIP(ctx, hipMemcpyAsync(mx.data(), dmx, k * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        MRBF_TRY(ps_eval_point(ctx, P, xt.data(), allF, nullptr));
+        for (int l = 0; l < k; ++l) mx[l] = P.objective(allF, l);
     }
     MRBF_HIP(ctx, hipEventRecord(e1, ctx->stream));
     MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -596,4 +957,24 @@ extern "C" int32_t mrbf_ps_step(mrbf_ctx *ctx, const mrbf_model *model, const do
     MRBF_TRY(put(mx_trial, mx.data(), k));
     if (r_out) MRBF_TRY(put(r_out, r.data(), k));
     return MRBF_OK;
+}
+
+// one grouped model whose outputs are the objectives in order, no constraints: the common case (and the round-2 entry point)
+extern "C" int32_t mrbf_ps_step(mrbf_ctx *ctx, const mrbf_model *model, const double *x_n, const double *lb_eff, const double *ub_eff,
+                                const double *fx_n, const double *r_or_null, const mrbf_ps_options *opts, double *x_trial, double *mx_trial,
+                                double *r_out, mrbf_ps_info *info) {
+    if (!ctx) return -1;
+    if (!model) return fail(ctx, -2, "model is NULL");
+    if (model->k > ps::MAXOBJ) return fail(ctx, -2, "mrbf_ps_step: k = %d objectives (device path: <= %d)", model->k, ps::MAXOBJ);
+    int32_t roles[ps::MAXOBJ];
+    for (int l = 0; l < model->k; ++l) roles[l] = l;
+    const mrbf_model *models[1] = {model};
+    mrbf_ps_problem prob;
+    std::memset(&prob, 0, sizeof(prob));
+    prob.n_models = 1;
+    prob.n_objectives = model->k;
+    prob.models = models;
+    prob.roles = roles;
+    prob.eq_tol = -1.0;
+    return mrbf_ps_step_problem(ctx, &prob, x_n, lb_eff, ub_eff, fx_n, r_or_null, opts, x_trial, mx_trial, r_out, info);
 }

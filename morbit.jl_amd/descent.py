@@ -39,20 +39,13 @@ def _armijo_condition(strict, Mx, Mx_plus, step_size, omega, const_rhs):
 
 
 def _single_model(sc):
-    """the inner RbfModel when every objective refers to the same grouped model in output order, else None"""
-    objs = sc.lists["objective"]
-    if not objs:
-        return None
-    if any(isinstance(s, sg.CompositeSurrogate) for s in objs):
-        return None  # the outer functions are evaluated on the host: general batched route
-    inner = objs[0].model if isinstance(objs[0], sg.RefSurrogate) else objs[0]
-    idx = []
-    for s in objs:
-        m = s.model if isinstance(s, sg.RefSurrogate) else s
-        if m is not inner:
-            return None
-        idx += s.output_indices if isinstance(s, sg.RefSurrogate) else list(range(m.num_outputs))
-    return inner if idx == list(range(inner.num_outputs)) else None
+    """the inner RbfModel when the decision table (mrbf_dispatch_backtrack, the same call HipRbf.jl makes) sends `_backtrack` to
+    mrbf_backtrack: every objective a RefSurrogate row of ONE grouped device model, outputs in order; else None"""
+    plan = sg.container_plan(sc, objectives_only=True)
+    lib = _lib.load()
+    if lib.mrbf_dispatch_backtrack(len(plan["models"]), plan["n_foreign"], int(plan["in_order"])) == _lib.DISPATCH_DEVICE:
+        return plan["models"][0]
+    return None
 
 
 def _backtrack(x, direction, step_size, omega, sc, cfg, scal=None):

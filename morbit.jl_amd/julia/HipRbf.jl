@@ -10,7 +10,9 @@
 #     candidate scan of the affine filter           AffinelyIndependentPoints.jl:71-106 -> mrbf_affine_scores
 #     eval_container_*_at_scaled_site[s]            SurrogateContainer.jl:234-269     -> one mrbf_eval per grouped model
 #     _backtrack                                    descent.jl:150-185                -> mrbf_backtrack
-#     get_criticality(::PascolettiSerafiniConfig)   descent.jl:512-581                -> mrbf_ps_step
+#     get_criticality(::PascolettiSerafiniConfig)   descent.jl:512-581                -> mrbf_ps_step_problem
+# Which of Morbit's calls go to the device and which to Morbit's own methods is decided by the mrbf_dispatch_* functions of the
+# library (include/mrbf.h, "decision table"), the same ones the Python mirror calls; no method here raises because of a size limit.
 # Every ccall below has a 1:1 ctypes twin in morbit.jl_amd/_lib.py, which is what tests/ execute; struct layouts are pinned by
 # tests/test_abi.py.  Conventions: a context is owned by one Julia task at a time (one per thread, created under a lock);
 # models keep their context alive and are released through it; buffers passed to ccall are GC.@preserve'd.
@@ -30,6 +32,14 @@ end
 struct MrbfPsInfo           # mirrors mrbf_ps_info, 32 bytes
     status::Int32; generations::Int32; evals_ideal::Int32; evals_ps::Int32; evals_polish::Int32; ms_total::Float32
     tau::Float64
+end
+
+struct MrbfPsProblem        # mirrors mrbf_ps_problem, 72 bytes
+    n_models::Int32; n_objectives::Int32
+    models::Ptr{Ptr{Cvoid}}; roles::Ptr{Int32}
+    n_lin_eq::Int32; n_lin_ineq::Int32
+    A_eq::Ptr{Float64}; b_eq::Ptr{Float64}; A_ineq::Ptr{Float64}; b_ineq::Ptr{Float64}
+    eq_tol::Float64
 end
 
 const MRBF_KERNEL_ID = Dict(k => Int32(i - 1) for (i, k) in enumerate(RbfKernels))  # order of RbfModel.jl:48-54
@@ -165,10 +175,39 @@ fully_linear(m::HipRbfModel)::Bool = m.fully_linear
 num_outputs(m::HipRbfModel) = m.num_outputs
 set_fully_linear!(m::HipRbfModel, val) = (m.fully_linear = val; nothing)
 
-# ---- two-phase construction: phase I (which sites) stays Morbit's control flow, its arithmetic goes to the device -------------
-prepare_init_model(cfg::HipRbfConfig, args...; kwargs...) = prepare_init_model(_as_rbf_config(cfg), args...; kwargs...)
-prepare_update_model(mod::Union{Nothing,HipRbfModel}, meta::RbfMeta, cfg::HipRbfConfig, args...; kwargs...) =
-    prepare_update_model(nothing, meta, _as_rbf_config(cfg), args...; kwargs...)
+# ---- the decision table (include/mrbf.h, "decision table"): pure host functions of libmrbf that the Python mirror calls as well,
+#      so both bindings route every call the same way; 1 = device entry point, 0 = Morbit's own method
+_dispatch_ps(d, k, n_models, n_nl, n_lin, n_foreign) =
+    ccall((:mrbf_dispatch_ps, libmrbf), Int32, (Int32, Int32, Int32, Int32, Int32, Int32), d, k, n_models, n_nl, n_lin, n_foreign) == 1
+_dispatch_backtrack(n_models, n_foreign, in_order::Bool) =
+    ccall((:mrbf_dispatch_backtrack, libmrbf), Int32, (Int32, Int32, Int32), n_models, n_foreign, in_order) == 1
+_dispatch_affine(n_candidates, d) = ccall((:mrbf_dispatch_affine, libmrbf), Int32, (Int64, Int32), n_candidates, d) == 1
+_dispatch_round4(n0, d, deg, n_candidates) =
+    ccall((:mrbf_dispatch_round4, libmrbf), Int32, (Int64, Int32, Int32, Int64), n0, d, deg, n_candidates) == 1
+_dispatch_fit(n_training, n0, q, n_accepted, same_sites::Bool) =
+    ccall((:mrbf_dispatch_fit, libmrbf), Int32, (Int64, Int64, Int32, Int32, Int32), n_training, n0, q, n_accepted, same_sites) == 1
+"Does return code `rc` of device entry point `entry` (1 round4, 2 fit_from_round4, 3 ps_step) mean: take the reference method?"
+_fallback_rc(entry, rc) = ccall((:mrbf_dispatch_after, libmrbf), Int32, (Int32, Int32), entry, rc) == 1
+
+# ---- two-phase construction: phase I (which sites) stays Morbit's control flow (RbfModel.jl:506-655 is generic in `cfg`); the
+#      pieces of it that are arithmetic are re-routed by dispatch on the config / element type:
+#        _rbf_round4(..., cfg::HipRbfConfig)                       -> mrbf_round4, factors kept for the fit
+#        iterate(::AffinelyIndependentPointFilter{Float64}, n)    -> mrbf_affine_scores for large candidate sets
+_get_signature(cfg::HipRbfConfig) = (cfg.θ_pivot, cfg.θ_enlarge_1, cfg.θ_enlarge_2, cfg.optimized_sampling)   # RbfModel.jl:114
+
+function prepare_init_model(cfg::HipRbfConfig, func_indices, mop, scal, id, sdb, ac; ensure_fully_linear = true, kwargs...)
+    F = eltype(get_x_scaled(id))                                                 # RbfModel.jl:506-513
+    meta = RbfMeta{F,typeof(func_indices)}(; signature = _get_signature(cfg), func_indices)
+    return prepare_update_model(nothing, meta, cfg, func_indices, mop, scal, id, sdb, ac; ensure_fully_linear, kwargs...)
+end
+# Morbit's generic method (first argument Union{Nothing,RbfModel}, `cfg` untyped); run with `nothing` as the model it never looks at.
+# Two methods so that neither is ambiguous with the generic one for a `nothing` model.
+const _GENERIC_PREPARE_SIG = Tuple{Union{Nothing,RbfModel},RbfMeta,Any,Any,Any,Any,Any,Any,Any}
+prepare_update_model(mod::Nothing, meta::RbfMeta, cfg::HipRbfConfig, func_indices, mop, scal, iter_data, sdb, ac; kwargs...) =
+    invoke(prepare_update_model, _GENERIC_PREPARE_SIG, nothing, meta, cfg, func_indices, mop, scal, iter_data, sdb, ac; kwargs...)
+prepare_update_model(mod::HipRbfModel, meta::RbfMeta, cfg::HipRbfConfig, func_indices, mop, scal, iter_data, sdb, ac; kwargs...) =
+    invoke(prepare_update_model, _GENERIC_PREPARE_SIG, nothing, meta, cfg, func_indices, mop, scal, iter_data, sdb, ac; kwargs...)
+# the improvement step only reads config fields (RbfModel.jl:699-732)
 prepare_improve_model(mod::Union{Nothing,HipRbfModel}, meta::RbfMeta, cfg::HipRbfConfig, args...; kwargs...) =
     prepare_improve_model(nothing, meta, _as_rbf_config(cfg), args...; kwargs...)
 
@@ -177,17 +216,102 @@ init_model(meta::RbfMeta, cfg::HipRbfConfig, func_indices, mop, scal, iter_data,
 improve_model(mod, meta::RbfMeta, cfg::HipRbfConfig, args...; kwargs...) = update_model(mod, meta, cfg, args...; kwargs...)
 
 # sites / values in the ABI layouts: centres n x d row-major == the d x n column-major Matrix, values n x k row-major == k x n.
-# (`reinterpret(reshape, Float64, ::Vector{SVector{d,Float64}})` would be a copy-free view of the same bytes; Morbit's sites may be
-#  Float32 or plain Vectors, so the binding materialises one Float64 matrix per call: n d doubles, negligible next to the fit.)
-_as_matrix(v) = Matrix{Float64}(reduce(hcat, v))
+# A Vector{SVector{d,Float64}} / Vector{MVector{k,Float64}} already IS those bytes: reinterpret it (no copy); anything else
+# (Float32 sites, plain Vectors) is materialised once.
+_as_matrix(v::Vector{StaticArrays.SVector{N,Float64}}) where {N} = reshape(reinterpret(Float64, v), N, length(v))   # zero-copy view
+_as_matrix(v) = Matrix{Float64}(reduce(hcat, v))      # MVectors (heap objects), Float32 sites, plain Vectors: one d x n copy
+_dense(A::Matrix{Float64}) = A
+_dense(A::Base.ReshapedArray{Float64,2,<:Base.ReinterpretArray{Float64}}) = A   # dense, stride 1: ccall takes its pointer as it is
+_dense(A) = Matrix{Float64}(A)
 
+# ---- round 4 (RbfModel.jl:352-499) inside Morbit's own prepare_update_model: same arguments, same return value (database indices
+#      of the accepted sites in acceptance order); the whole selection is ONE device call and its factor is kept for update_model
+const _ROUND4_KEPT = IdDict{Any,Any}()          # sub-database => (state, training indices in factor order)
+const _ROUND4_LOCK = ReentrantLock()
+function _rbf_round4(db, lb_2, ub_2, x::AbstractVector{F}, Δ, indices_found_so_far, cfg::HipRbfConfig) where {F}
+    lock(_ROUND4_LOCK) do
+        delete!(_ROUND4_KEPT, db)               # whatever was kept belongs to an older training set
+    end
+    n_vars = length(x)
+    max_points = cfg.max_model_points <= 0 ? Int(((n_vars + 1) * (n_vars + 2)) / 2) : cfg.max_model_points   # :356
+    N = length(indices_found_so_far)
+    candidate_indices_4 = results_in_box_indices(db, lb_2, ub_2, indices_found_so_far)
+    (N < max_points && (!isempty(candidate_indices_4) || cfg.use_max_points)) || return Int[]                  # :367
+    # with use_max_points the reference draws random box points one by one once the database candidates are used up (:405-416, at
+    # most 10 max_points + 1); here they are drawn up front so that they ride in the same device call
+    fresh = cfg.use_max_points ? [_rand_box_point(lb_2, ub_2, F) for _ = 1:(10 * max_points + 1)] : Vector{Vector{F}}()
+    cand_sites = [get_site.(db, candidate_indices_4); fresh]
+    if _dispatch_round4(N, n_vars, cfg.polynomial_degree, length(cand_sites))
+        rc, accepted, state = rbf_round4_device(cfg, Δ, get_site.(db, indices_found_so_far), cand_sites; keep_state = true, rc_only = true)
+        if rc == 0
+            round4_indices = Int[]
+            for pos in accepted
+                id = pos <= length(candidate_indices_4) ? candidate_indices_4[pos] : new_result!(db, cand_sites[pos], F[])   # :455-457
+                push!(round4_indices, id)
+            end
+            if state !== nothing
+                lock(_ROUND4_LOCK) do
+                    _ROUND4_KEPT[db] = (state, [collect(Int, indices_found_so_far); round4_indices])
+                end
+            end
+            return round4_indices
+        end
+        _fallback_rc(1, rc) || _check(mrbf_context(), rc)       # a start set without the tail / rank deficient: Morbit's own loop
+    end
+    return _rbf_round4(db, lb_2, ub_2, x, Δ, indices_found_so_far, _as_rbf_config(cfg))
+end
+
+# ---- rounds 1-2: the candidate scan of the affine filter (AffinelyIndependentPoints.jl:71-106) for Float64 filters with many
+#      candidates; picks, order and the Y / Z bookkeeping are the reference's
+const _AFFINE_SEEDS = IdDict{Any,Matrix{Float64}}()      # filter => d x mc matrix of shifted seeds, picked columns zeroed
+function Base.iterate(filter::AffinelyIndependentPointFilter{Float64,VF,SV}, num_found::Int) where {VF,SV}
+    num_found == filter.n && (delete!(_AFFINE_SEEDS, filter); return nothing)
+    isempty(filter.candidate_indices) && (delete!(_AFFINE_SEEDS, filter); return nothing)
+    generic() = invoke(Base.iterate, Tuple{AffinelyIndependentPointFilter,Int}, filter, num_found)
+    _dispatch_affine(length(filter.candidate_indices), length(filter.x_0)) || return generic()
+    S = get!(_AFFINE_SEEDS, filter) do
+        M = _dense(_as_matrix(filter.shifted_seeds))
+        for j in setdiff(eachindex(filter.shifted_seeds), filter.candidate_indices)
+            M[:, j] .= 0                                   # chosen sites score 0 (the reference removes them from the list)
+        end
+        M
+    end
+    best_index, best_val = affine_scores(S, filter.Z, filter.p)
+    if best_index >= 1 && best_val > filter.pivot_val
+        i = best_index
+        filter.Y = hcat(filter.Y, filter.shifted_seeds[i])
+        filter.Z = _orthogonal_complement_matrix(filter.Y, filter.p)
+        setdiff!(filter.candidate_indices, i)
+        S[:, i] .= 0
+        return (filter.return_indices ? i : filter.seeds[i]), num_found + 1
+    end
+    delete!(_AFFINE_SEEDS, filter)
+    return nothing
+end
+
+# ---- phase II: the fit.  With a kept round-4 factor that describes exactly this training set: two triangular solves
+#      (mrbf_fit_from_round4, the reference's TODO at RbfModel.jl:657-660); otherwise Gram + factorisation + solve (mrbf_fit)
 function update_model(mod::Union{Nothing,HipRbfModel}, meta::RbfMeta, cfg::HipRbfConfig,
                       func_indices, mop, scal, iter_data, sdb, ac; kwargs...)
     db = get_sub_db(sdb, func_indices)
     Δ = get_delta(iter_data)
-    training_results = get_result.(db, _collect_indices(meta))                 # RbfModel.jl:754-757
-    C = _as_matrix(get_site.(training_results))
-    Y = _as_matrix(get_value.(training_results))
+    training_indices = _collect_indices(meta)                                  # RbfModel.jl:754-757
+    training_results = get_result.(db, training_indices)
+    sites = get_site.(training_results); values = get_value.(training_results)
+    kept = lock(_ROUND4_LOCK) do
+        pop!(_ROUND4_KEPT, db, nothing)
+    end
+    if kept !== nothing
+        state, ids = kept
+        n0, nacc, q = _round4_dims(state, cfg, length(first(sites)))
+        if _dispatch_fit(length(training_indices), n0, q, nacc, ids == training_indices)
+            rc, model = fit_from_round4(state, values, length(first(sites)), meta.fully_linear; rc_only = true)
+            rc == 0 && return model, meta
+            _fallback_rc(2, rc) || _check(state.ctx, rc)
+        end
+    end
+    C = _dense(_as_matrix(sites))
+    Y = _dense(_as_matrix(values))
     d, n = size(C)
     k = size(Y, 1)
     kid, a, b = _mrbf_kernel_params(Δ, cfg)
@@ -236,11 +360,16 @@ eval_models_at_sites(mod::HipRbfModel, scal, X::AbstractMatrix) = _mrbf_eval(mod
 get_jacobians_at_sites(mod::HipRbfModel, scal, X::AbstractMatrix) = _mrbf_eval(mod, Matrix{Float64}(X); values = false, jac = true)[2]
 
 # ---- container twins: eval_container_{objectives,nl_eq_constraints,nl_ineq_constraints}[_jacobian]_at_scaled_sites ------------
-# (SurrogateContainer.jl:234-269 does one inner-model call per objective index; here every distinct grouped HipRbfModel is swept
+# (SurrogateContainer.jl:234-269 does one inner-model call per function index; here every distinct grouped HipRbfModel is swept
 #  ONCE for all sites, RefSurrogates select rows, CompositeSurrogates apply their outer function / chain rule per site,
 #  AbstractSurrogateInterface.jl:136-154, :175-229.)  Sites are the columns of X_scaled (d x m).
 _inner(s::RefSurrogate) = s.model_ref[]
 _inner(s::CompositeSurrogate) = s.model_ref[]
+_inner(s) = s
+# the container keeps dictionaries function index => surrogate (SurrogateContainer.jl:111-113); order = key order, as in :248-267
+_container_surrogates(sc::SurrogateContainer, ::Val{:objectives}) = [get_surrogates(sc, ind) for ind in get_objective_indices(sc)]
+_container_surrogates(sc::SurrogateContainer, ::Val{:nl_eq_constraints}) = [get_surrogates(sc, ind) for ind in get_nl_eq_constraint_indices(sc)]
+_container_surrogates(sc::SurrogateContainer, ::Val{:nl_ineq_constraints}) = [get_surrogates(sc, ind) for ind in get_nl_ineq_constraint_indices(sc)]
 function _sweep_groups(surrogates, scal, X::Matrix{Float64}; jac::Bool)
     cache = IdDict{Any,Any}()
     for s in surrogates
@@ -258,7 +387,7 @@ function _container_values_at_sites(surrogates, scal, X_scaled::AbstractMatrix)
     rows = map(surrogates) do s
         sweep = cache[_inner(s)]
         if sweep === nothing                                                  # some other surrogate family: site by site
-            reduce(hcat, [eval_models(s, scal, X[:, p]) for p = 1:m])
+            reduce(hcat, [_eval_models_vec(s, scal, X[:, p]) for p = 1:m])
         elseif s isa RefSurrogate
             sweep[1][s.output_indices, :]
         else                                                                  # CompositeSurrogate: φ([T(x); g(x)]) per site
@@ -287,57 +416,86 @@ function _container_jacobians_at_sites(surrogates, scal, X_scaled::AbstractMatri
     end
     return reduce(vcat, blocks)                                               # Σk x d x m
 end
-for (fld, plural) in ((:objectives, :objectives), (:nl_eq_constraints, :nl_eq_constraints), (:nl_ineq_constraints, :nl_ineq_constraints))
+for plural in (:objectives, :nl_eq_constraints, :nl_ineq_constraints)
     vals = Symbol("eval_container_", plural, "_at_scaled_sites")
     jacs = Symbol("eval_container_", plural, "_jacobian_at_scaled_sites")
     @eval begin
-        $vals(sc::SurrogateContainer, scal, X::AbstractMatrix) = _container_values_at_sites(getfield(sc, $(QuoteNode(fld))), scal, X)
-        $jacs(sc::SurrogateContainer, scal, X::AbstractMatrix) = _container_jacobians_at_sites(getfield(sc, $(QuoteNode(fld))), scal, X)
+        $vals(sc::SurrogateContainer, scal, X::AbstractMatrix) = _container_values_at_sites(_container_surrogates(sc, Val($(QuoteNode(plural)))), scal, X)
+        $jacs(sc::SurrogateContainer, scal, X::AbstractMatrix) = _container_jacobians_at_sites(_container_surrogates(sc, Val($(QuoteNode(plural)))), scal, X)
     end
 end
 
-# the objectives' single grouped model when every objective is a RefSurrogate of it, outputs in order (then the C entry points that
-# take one model apply); nothing otherwise
-function _single_objective_model(sc::SurrogateContainer)
-    objs = sc.objectives
-    (isempty(objs) || !all(o -> o isa RefSurrogate, objs)) && return nothing
-    m = _inner(first(objs))
-    (m isa HipRbfModel && all(o -> _inner(o) === m, objs)) || return nothing
-    return reduce(vcat, [o.output_indices for o in objs]) == collect(1:num_outputs(m)) ? m : nothing
+# What the device entry points need to know about a container: its distinct grouped HipRbfModels, the role of every output row
+# (objective position l >= 0, MRBF_ROLE_EQ = -2, MRBF_ROLE_INEQ = -3, MRBF_ROLE_NONE = -1) and how many surrogates are "foreign"
+# (CompositeSurrogates, other model families, or a model row used twice): with a foreign one the reference methods run.
+function _container_plan(sc::SurrogateContainer; objectives_only::Bool = false)
+    models = HipRbfModel[]; roles = Vector{Vector{Int32}}()
+    k = 0; n_con = 0; n_foreign = 0
+    function slot(m)
+        i = findfirst(x -> x === m, models)
+        i === nothing || return i
+        push!(models, m); push!(roles, fill(Int32(-1), num_outputs(m)))
+        return length(models)
+    end
+    for (kind, role) in ((Val(:objectives), 0), (Val(:nl_eq_constraints), -2), (Val(:nl_ineq_constraints), -3))
+        objectives_only && role != 0 && continue                              # _backtrack only evaluates the objectives (descent.jl:161-179)
+        for s in _container_surrogates(sc, kind)
+            if s isa RefSurrogate && _inner(s) isa HipRbfModel
+                i = slot(_inner(s))
+                for oi in s.output_indices
+                    roles[i][oi] == -1 || (n_foreign += 1)                    # one row in two roles: not expressible
+                    roles[i][oi] = role == 0 ? Int32(k) : Int32(role)
+                    role == 0 ? (k += 1) : (n_con += 1)
+                end
+            else
+                n_foreign += 1
+                role == 0 ? (k += num_outputs(s)) : (n_con += num_outputs(s))
+            end
+        end
+    end
+    in_order = length(models) == 1 && n_con == 0 && roles[1] == Int32.(0:num_outputs(models[1])-1)
+    return (; models, roles = isempty(roles) ? Int32[] : reduce(vcat, roles), k, n_con, n_foreign, in_order)
 end
 
 # ---- descent consumers ------------------------------------------------------------------------------------------------------------
 "All Armijo step sizes of `_backtrack` (descent.jl:150-185) in one batch; returns (x₊, mx₊, step) like the reference."
-function _backtrack(x::AbstractVector, dir::AbstractVector, step_size, ω, sc::SurrogateContainer, cfg, scal; model::HipRbfModel = _single_objective_model(sc))
-    x = Vector{Float64}(x); dir = Vector{Float64}(dir)
-    d, k = model.n_vars, model.num_outputs
-    x₊, mx₊, step, loops = similar(x), Vector{Float64}(undef, k), similar(x), Ref{Int32}(0)
-    GC.@preserve x dir x₊ mx₊ step begin
+function _backtrack(x::AbstractVector{F}, dir, step_size, ω, sc::SurrogateContainer, cfg, scal) where {F<:AbstractFloat}
+    plan = _container_plan(sc; objectives_only = true)
+    if !_dispatch_backtrack(length(plan.models), plan.n_foreign, plan.in_order)
+        return invoke(_backtrack, Tuple{AbstractVector{F},Any,Any,Any,Any,Any,Any}, x, dir, step_size, ω, sc, cfg, scal)
+    end
+    model = plan.models[1]
+    x64 = Vector{Float64}(x); dir64 = Vector{Float64}(dir)
+    k = model.num_outputs
+    x₊, mx₊, step, loops = similar(x64), Vector{Float64}(undef, k), similar(x64), Ref{Int32}(0)
+    GC.@preserve x64 dir64 x₊ mx₊ step begin
         rc = ccall((:mrbf_backtrack, libmrbf), Int32,
                    (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Float64, Float64, Int32, Float64, Float64, Float64, Int32,
                     Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Int32}),
-                   model.ctx.handle, model.handle, x, dir, step_size, ω, cfg.strict_backtracking, cfg.armijo_const_rhs,
-                   cfg.armijo_const_shrink, cfg.min_stepsize >= 0 ? cfg.min_stepsize : eps(Float64), cfg.max_loops,
+                   model.ctx.handle, model.handle, x64, dir64, step_size, ω, cfg.strict_backtracking, cfg.armijo_const_rhs,
+                   cfg.armijo_const_shrink, cfg.min_stepsize >= 0 ? cfg.min_stepsize : eps(F), cfg.max_loops,
                    x₊, mx₊, step, loops)
     end
     _check(model.ctx, rc)
-    return x₊, mx₊, step
+    return F.(x₊), F.(mx₊), F.(step)
 end
 
 """
-Pascoletti-Serafini descent step (descent.jl:512-581) with the subproblem solver on the device (`mrbf_ps_step`): applies when the
-objectives are the outputs of one grouped `HipRbfModel` and the problem carries no modelled or MOP constraints; otherwise call
-Morbit's own method (NLopt with the one-point handles of `get_objectives_optim_handles`).  Same returns as the reference.
+Pascoletti-Serafini descent step (descent.jl:512-581) with the subproblem solver on the device (`mrbf_ps_step_problem`): objectives
+and modelled constraints may be spread over several grouped `HipRbfModel`s, the MOP may carry linear constraints.  Whenever the
+decision table says so (a `CompositeSurrogate` or another model family in the container, sizes outside the device path) or the
+device call asks for it, Morbit's own method runs on the same arguments -- this method never raises because of a size limit.
+Same returns as the reference.
 """
 function get_criticality(desc_cfg::PascolettiSerafiniConfig, mop, scal, x_it, x_it_n, data_base, sc::SurrogateContainer, algo_config;
-                         model::Union{Nothing,HipRbfModel} = _single_objective_model(sc), seed::UInt64 = rand(UInt64))
-    constrained = !isempty(sc.nl_eq_constraints) || !isempty(sc.nl_ineq_constraints) ||
-                  !isempty(get_eq_constraints_optim_handles(mop, scal)) || !isempty(get_ineq_constraints_optim_handles(mop, scal))
-    if model === nothing || constrained
-        return invoke(get_criticality, Tuple{PascolettiSerafiniConfig,Any,Any,Any,Any,Any,Any,Any}, desc_cfg, mop, scal, x_it, x_it_n, data_base, sc, algo_config)
-    end
+                         seed::UInt64 = rand(UInt64))
+    reference() = invoke(get_criticality, Tuple{PascolettiSerafiniConfig,Any,Any,Any,Any,Any,Any,Any}, desc_cfg, mop, scal, x_it, x_it_n, data_base, sc, algo_config)
+    plan = _container_plan(sc)
     x = Vector{Float64}(get_x_scaled(x_it)); x_n = Vector{Float64}(get_x_scaled(x_it_n)); fx_n = Vector{Float64}(get_fx(x_it_n))
-    d, k = length(x_n), model.num_outputs
+    d, k = length(x_n), plan.k
+    A_eq, b_eq = transformed_linear_eq_constraints(scal, mop)                  # AbstractMOPInterface.jl:463-481: A x_scaled (=, <=) b
+    A_in, b_in = transformed_linear_ineq_constraints(scal, mop)
+    _dispatch_ps(d, k, length(plan.models), plan.n_con, length(b_eq) + length(b_in), plan.n_foreign) || return reference()
     lb_eff, ub_eff = local_bounds(scal, x, get_delta(x_it))
     lb = Vector{Float64}(lb_eff); ub = Vector{Float64}(ub_eff)
     r = _get_global_dir(desc_cfg, fx_n)                                        # descent.jl:360-368
@@ -346,14 +504,22 @@ function get_criticality(desc_cfg::PascolettiSerafiniConfig, mop, scal, x_it, x_
     opts = Ref(MrbfPsOptions(desc_cfg.max_ideal_point_problem_evals, g_evals, l_evals, 0, seed, -0.5, 1e-3))
     info = Ref{MrbfPsInfo}()
     x_trial, mx_trial = Vector{Float64}(undef, d), Vector{Float64}(undef, k)
-    GC.@preserve x_n lb ub fx_n rbuf x_trial mx_trial begin
-        rc = ccall((:mrbf_ps_step, libmrbf), Int32,
-                   (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{MrbfPsOptions},
-                    Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{MrbfPsInfo}),
-                   model.ctx.handle, model.handle, x_n, lb, ub, fx_n, rbuf === nothing ? C_NULL : pointer(rbuf), opts,
-                   x_trial, mx_trial, C_NULL, info)
+    handles = Ptr{Cvoid}[m.handle for m in plan.models]
+    roles = plan.roles
+    Aeq = Matrix{Float64}(transpose(Matrix(A_eq))); beq = Vector{Float64}(b_eq)   # row-major rows x d == the d x rows column-major matrix
+    Ain = Matrix{Float64}(transpose(Matrix(A_in))); bin = Vector{Float64}(b_in)
+    ctx = plan.models[1].ctx
+    rc = GC.@preserve handles roles Aeq beq Ain bin x_n lb ub fx_n rbuf x_trial mx_trial begin
+        prob = Ref(MrbfPsProblem(length(handles), k, pointer(handles), pointer(roles), length(beq), length(bin),
+                                 isempty(beq) ? C_NULL : pointer(Aeq), isempty(beq) ? C_NULL : pointer(beq),
+                                 isempty(bin) ? C_NULL : pointer(Ain), isempty(bin) ? C_NULL : pointer(bin), -1.0))
+        ccall((:mrbf_ps_step_problem, libmrbf), Int32,
+              (Ptr{Cvoid}, Ref{MrbfPsProblem}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{MrbfPsOptions},
+               Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{MrbfPsInfo}),
+              ctx.handle, prob, x_n, lb, ub, fx_n, rbuf === nothing ? C_NULL : pointer(rbuf), opts, x_trial, mx_trial, C_NULL, info)
     end
-    _check(model.ctx, rc)
+    rc != 0 && _fallback_rc(3, rc) && return reference()
+    _check(ctx, rc)
     Xet = eltype(get_x_scaled(x_it_n))
     info[].status == 1 && return 0, copy(get_x_scaled(x_it_n)), mx_trial, 0    # critical: some r_l <= 0 (descent.jl:546-549)
     info[].status == 2 && return 0, copy(get_x_scaled(x_it)), mx_trial, 0      # failure (descent.jl:571-572)
@@ -365,13 +531,28 @@ mutable struct HipRound4State
     ctx::MrbfContext
     handle::Ptr{Cvoid}
 end
+function _free_round4!(s::HipRound4State)
+    if s.handle != C_NULL && s.ctx.handle != C_NULL
+        ccall((:mrbf_free_round4, libmrbf), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), s.ctx.handle, s.handle)
+    end
+    s.handle = C_NULL
+    return nothing
+end
+"(n0, accepted sites, q) of a kept round-4 factor"
+function _round4_dims(state::HipRound4State, cfg, n_vars)
+    n0 = Ref{Int64}(0); nc = Ref{Int64}(0); nacc = Ref{Int32}(0)
+    ccall((:mrbf_round4_sites, libmrbf), Int32, (Ptr{Cvoid}, Ref{Int64}, Ref{Int64}, Ref{Int32}), state.handle, n0, nc, nacc)
+    q = cfg.polynomial_degree < 0 ? 0 : (cfg.polynomial_degree == 0 ? 1 : n_vars + 1)
+    return n0[], Int(nacc[]), q
+end
 """
 `_rbf_round4` (RbfModel.jl:352-499) as one device call.  `start_sites` / `cand_sites`: vectors of sites (the sites found so far; the
 box candidates in database order, followed -- with `use_max_points` -- by the random box points the caller drew).  Returns the
-positions of the accepted candidates in acceptance order and, with `keep_state`, the factors for `fit_from_round4`.
+positions of the accepted candidates in acceptance order and, with `keep_state`, the factors for `fit_from_round4` (`nothing` when
+there was nothing to select: the library then keeps no state).  With `rc_only` the return code comes first and nothing is raised.
 """
-function rbf_round4_device(cfg::HipRbfConfig, Δ, start_sites, cand_sites; keep_state::Bool = false)
-    C0 = _as_matrix(start_sites); Xc = isempty(cand_sites) ? Matrix{Float64}(undef, size(C0, 1), 0) : _as_matrix(cand_sites)
+function rbf_round4_device(cfg::HipRbfConfig, Δ, start_sites, cand_sites; keep_state::Bool = false, rc_only::Bool = false)
+    C0 = _dense(_as_matrix(start_sites)); Xc = isempty(cand_sites) ? Matrix{Float64}(undef, size(C0, 1), 0) : _dense(_as_matrix(cand_sites))
     d, n0 = size(C0); mc = size(Xc, 2)
     kid, a, b = _mrbf_kernel_params(Δ, cfg)
     ctx = mrbf_context()
@@ -383,28 +564,38 @@ function rbf_round4_device(cfg::HipRbfConfig, Δ, start_sites, cand_sites; keep_
                    ctx.handle, n0, d, C0, mc, Xc, kid, a, b, cfg.polynomial_degree, cfg.max_model_points, cfg.θ_pivot_cholesky,
                    acc, nacc, keep_state ? Base.unsafe_convert(Ptr{Ptr{Cvoid}}, st) : C_NULL)
     end
-    _check(ctx, rc)
+    if rc != 0
+        rc_only && return rc, Int[], nothing
+        _check(ctx, rc)
+    end
     accepted = Int.(acc[1:nacc[]]) .+ 1                                         # 1-based positions into cand_sites
-    keep_state || return accepted
-    state = HipRound4State(ctx, st[])
-    finalizer(s -> (s.handle != C_NULL && s.ctx.handle != C_NULL &&
-                    ccall((:mrbf_free_round4, libmrbf), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), s.ctx.handle, s.handle); s.handle = C_NULL), state)
-    return accepted, state
+    state = nothing
+    if keep_state && st[] != C_NULL                                             # NULL: nothing to select, no state (mrbf.h)
+        state = HipRound4State(ctx, st[])
+        finalizer(_free_round4!, state)
+    end
+    rc_only && return rc, accepted, state
+    return keep_state ? (accepted, state) : accepted
 end
 "The model on (start sites, accepted sites) from the factor round 4 kept (RbfModel.jl:657-660): `values` in that order, k x n."
-function fit_from_round4(state::HipRound4State, values, n_vars::Int, fully_linear::Bool)
-    Y = _as_matrix(values); k = size(Y, 1)
+function fit_from_round4(state::HipRound4State, values, n_vars::Int, fully_linear::Bool; rc_only::Bool = false)
+    Y = _dense(_as_matrix(values)); k = size(Y, 1)
     h = Ref{Ptr{Cvoid}}(C_NULL); info = Ref{MrbfFitInfo}()
     GC.@preserve Y begin
         rc = ccall((:mrbf_fit_from_round4, libmrbf), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Ptr{Float64}, Ref{Ptr{Cvoid}}, Ptr{Float64}, Ptr{Float64}, Ref{MrbfFitInfo}),
                    state.ctx.handle, state.handle, k, Y, h, C_NULL, C_NULL, info)
     end
-    _check(state.ctx, rc)
-    return HipRbfModel(state.ctx, h[], n_vars, k, fully_linear, info[])
+    if rc != 0
+        rc_only && return rc, nothing
+        _check(state.ctx, rc)
+    end
+    model = HipRbfModel(state.ctx, h[], n_vars, k, fully_linear, info[])
+    return rc_only ? (rc, model) : model
 end
 "Scores `‖Z (Zᵀ(ξ - x₀))‖_p` of all filter candidates and the first maximiser (AffinelyIndependentPoints.jl:71-106)."
-function affine_scores(shifted_seeds, Z::AbstractMatrix, p = Inf)
-    S = _as_matrix(shifted_seeds); d, mc = size(S); Zm = Matrix{Float64}(Z)
+affine_scores(shifted_seeds::AbstractVector, Z::AbstractMatrix, p = Inf) = affine_scores(_dense(_as_matrix(shifted_seeds)), Z, p)
+function affine_scores(S::AbstractMatrix{Float64}, Z::AbstractMatrix, p = Inf)     # S: d x mc, one shifted seed per column
+    d, mc = size(S); Zm = Matrix{Float64}(Z)
     ctx = mrbf_context(); best = Ref{Int64}(-1); val = Ref{Float64}(-Inf)
     GC.@preserve S Zm begin
         rc = ccall((:mrbf_affine_scores, libmrbf), Int32, (Ptr{Cvoid}, Int64, Int32, Int32, Ptr{Float64}, Ptr{Float64}, Int32, Ptr{Float64}, Ref{Int64}, Ref{Float64}),

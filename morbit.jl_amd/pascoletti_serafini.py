@@ -222,47 +222,71 @@ def _ps_optimization(t0, x, lb, ub, eval_objectives: Callable, mx, r, max_evals,
     return run.best_f, run.best_x[1:].copy(), ("MAXEVAL_REACHED" if run.evals >= max_evals else "XTOL_REACHED")
 
 
-def _polish(tau, x_min, lb, ub, eval_objectives, eval_jacobians, mx, r, max_evals):
-    """Gradient polish of the PS solution (the reference hands a local NLopt algorithm, descent.jl:560-569): projected steps on
-    chi = [t; x] that keep every iterate feasible; each trial costs one batched value + Jacobian call."""
+def _min_norm_weights(M):
+    """weights of the minimum-norm point of the convex hull of vectors with Gram matrix M (Gilbert / Frank-Wolfe steps)"""
+    k = M.shape[0]
+    lam = np.full(k, 1.0 / k)
+    for _ in range(500):
+        Ml = M @ lam
+        gg = float(lam @ Ml)
+        b = int(np.argmin(Ml))
+        if gg - Ml[b] <= 1e-14 * max(gg, 1e-300):
+            break
+        den = gg - 2.0 * Ml[b] + M[b, b]
+        gamma = min(1.0, max(0.0, (gg - Ml[b]) / den)) if den > 0.0 else 1.0
+        lam *= (1.0 - gamma)
+        lam[b] += gamma
+    return lam
+
+
+def _polish(tau, x_min, lb, ub, eval_objectives, eval_jacobians, mx, r, max_evals, eval_constraints=None, n_step=12):
+    """Gradient polish of the PS solution (the reference hands a local NLopt algorithm, descent.jl:560-569): multi-objective steepest
+    descent on max_l (m_l(x) - m_l(x_n)) / r_l -- minus the minimum-norm convex combination of the nearly active scaled gradients,
+    projected at active bounds -- with all step sizes of a line search in ONE batched call; every accepted iterate is feasible.
+    The same algorithm as `ps_polish` in csrc/ps_solver.hip."""
     t, x = float(tau), np.array(x_min, dtype=np.float64)
+    lb, ub = np.asarray(lb, dtype=np.float64), np.asarray(ub, dtype=np.float64)
     evals = 0
-    while evals < max_evals:
-        F = eval_objectives(x[None, :])[0]
+    while evals + 1 + n_step <= max_evals:
+        F = (eval_objectives(x[None, :])[0] - mx) / r
         J = eval_jacobians(x[None, :])[0]                      # k x d
         evals += 1
-        # direction that decreases the largest scaled objective excess: steepest descent of max_l (m_l - mx_l)/r_l
-        act = int(np.argmax((F - mx) / r))
-        d = -J[act] / r[act]
-        if np.linalg.norm(d) == 0.0:
+        act = np.flatnonzero(F >= F.max() - 0.05)
+        G = J[act] / r[act, None]
+        blocked = ((x <= lb) & np.all(G > 0.0, axis=0)) | ((x >= ub) & np.all(G < 0.0, axis=0))
+        G = np.where(blocked[None, :], 0.0, G)
+        lam = _min_norm_weights(G @ G.T)
+        d = -(lam @ G)
+        dmax, width = np.abs(d).max(), (ub - lb).max()
+        if not dmax > 0.0 or not width > 0.0:
             break
-        step, improved = 1.0, False
-        for _ in range(20):
-            xt = np.clip(x + step * d, lb, ub)
-            Ft = eval_objectives(xt[None, :])[0]
-            evals += 1
-            tt = float(np.clip(np.max((Ft - mx) / r), -1.0, 0.0))
-            if np.all(Ft - mx - tt * r <= 1e-14) and tt < t - 1e-12:
-                x, t, improved = xt, tt, True
-                break
-            step *= 0.5
-            if evals >= max_evals:
-                break
-        if not improved:
+        steps = (width / dmax) * 0.5 ** np.arange(n_step)
+        XT = np.clip(x[None, :] + steps[:, None] * d[None, :], lb, ub)
+        FT = eval_objectives(XT)
+        evals += n_step
+        tt = np.clip(np.max((FT - mx[None, :]) / r[None, :], axis=1), -1.0, 0.0)
+        feas = np.all(FT - mx[None, :] - tt[:, None] * r[None, :] <= 1e-14, axis=1) & np.isfinite(tt)
+        if eval_constraints is not None:
+            feas &= np.all(eval_constraints(XT) <= 0.0, axis=1)
+        ok = feas & (tt < t - 1e-12)
+        if not ok.any():
+            break
+        j = int(np.argmin(np.where(ok, tt, np.inf)))
+        x, t = XT[j], float(tt[j])
+        if t <= -1.0:
             break
     return t, x, "SUCCESS"
 
 
-def get_criticality_device(desc_cfg, model, x, x_n, fx_n, lb_eff, ub_eff, seed=0, stats=None):
-    """descent.jl:512-581 with the whole subproblem solver on the device (`mrbf_ps_step`): for objectives that are the outputs
-    of ONE grouped RbfModel `model` and no modelled constraints.  Same returns as `get_criticality`."""
+def _ps_step_problem(desc_cfg, models, roles, k, x, x_n, fx_n, lb_eff, ub_eff, lin=None, seed=0, stats=None):
+    """one mrbf_ps_step_problem call; returns (rc, result) -- rc != 0: no result"""
     import ctypes
 
     from . import _lib
 
-    ctx = model.ctx
+    ctx = models[0].ctx
     x, x_n = np.ascontiguousarray(x, dtype=np.float64), np.ascontiguousarray(x_n, dtype=np.float64)
-    d, k = x_n.size, model.num_outputs
+    d = x_n.size
     lb, ub = np.ascontiguousarray(lb_eff, dtype=np.float64), np.ascontiguousarray(ub_eff, dtype=np.float64)
     fx = np.ascontiguousarray(fx_n, dtype=np.float64)
     r = _get_global_dir(desc_cfg, fx)
@@ -270,18 +294,89 @@ def get_criticality_device(desc_cfg, model, x, x_n, fx_n, lb_eff, ub_eff, seed=0
     g_evals, l_evals = _ps_max_evals(desc_cfg, d)
     opts = _lib.PsOptions(max_ideal_evals=int(desc_cfg.max_ideal_point_problem_evals), max_ps_evals=int(g_evals),
                           max_polish_evals=int(l_evals), reserved=0, seed=int(seed) & (2 ** 64 - 1), t0=-0.5, xtol_rel=1e-3)
+    A_eq, b_eq, A_in, b_in = [None if a is None else np.ascontiguousarray(a, dtype=np.float64) for a in (lin or (None,) * 4)]
+    handles = (ctypes.c_void_p * len(models))(*[m.model.value if hasattr(m.model, "value") else m.model for m in models])
+    roles_c = (ctypes.c_int32 * max(len(roles), 1))(*roles)
+    prob = _lib.PsProblem(n_models=len(models), n_objectives=k, models=handles, roles=roles_c,
+                          n_lin_eq=0 if b_eq is None else b_eq.size, n_lin_ineq=0 if b_in is None else b_in.size,
+                          A_eq=None if A_eq is None else A_eq.ctypes.data, b_eq=None if b_eq is None else b_eq.ctypes.data,
+                          A_ineq=None if A_in is None else A_in.ctypes.data, b_ineq=None if b_in is None else b_in.ctypes.data, eq_tol=-1.0)
     info = _lib.PsInfo()
     xt, mt, r_out = np.empty(d), np.empty(k), np.empty(k)
-    ctx.check(ctx.lib.mrbf_ps_step(ctx.h, model.model, _lib.as_ptr(x_n), _lib.as_ptr(lb), _lib.as_ptr(ub), _lib.as_ptr(fx), _lib.as_ptr(r),
-                                   ctypes.byref(opts), _lib.as_ptr(xt), _lib.as_ptr(mt), _lib.as_ptr(r_out), ctypes.byref(info)))
+    rc = ctx.lib.mrbf_ps_step_problem(ctx.h, ctypes.byref(prob), _lib.as_ptr(x_n), _lib.as_ptr(lb), _lib.as_ptr(ub), _lib.as_ptr(fx),
+                                      _lib.as_ptr(r), ctypes.byref(opts), _lib.as_ptr(xt), _lib.as_ptr(mt), _lib.as_ptr(r_out), ctypes.byref(info))
+    if rc != 0:
+        return rc, None
     if stats is not None:
         stats.update(info.asdict())
         stats["r"] = r_out.copy()
+        stats["path"] = "device"
     if info.status == _lib.PS_CRITICAL:
-        return 0, x_n.copy(), mt, 0          # descent.jl:546-549
+        return 0, (0, x_n.copy(), mt, 0)          # descent.jl:546-549
     if info.status == _lib.PS_FAILURE:
-        return 0, x.copy(), mt, 0            # descent.jl:571-572
-    return abs(float(info.tau)), (xt, mt, float(np.linalg.norm(x - xt, ord=np.inf)))
+        return 0, (0, x.copy(), mt, 0)            # descent.jl:571-572
+    return 0, (abs(float(info.tau)), (xt, mt, float(np.linalg.norm(x - xt, ord=np.inf))))
+
+
+def get_criticality_device(desc_cfg, model, x, x_n, fx_n, lb_eff, ub_eff, seed=0, stats=None):
+    """descent.jl:512-581 with the whole subproblem solver on the device for objectives that are the outputs of ONE grouped
+    RbfModel `model` and no constraints.  Same returns as `get_criticality`; raises when the device call refuses (use
+    `get_criticality_container` for the routing Morbit's `get_criticality` method gets in HipRbf.jl)."""
+    rc, out = _ps_step_problem(desc_cfg, [model], list(range(model.num_outputs)), model.num_outputs, x, x_n, fx_n, lb_eff, ub_eff,
+                               seed=seed, stats=stats)
+    model.ctx.check(rc)
+    return out
+
+
+def get_criticality_container(desc_cfg, sc, scal, x, x_n, fx_n, lb_eff, ub_eff, lin=None, seed=0, rng=None, stats=None):
+    """`get_criticality(::PascolettiSerafiniConfig, mop, scal, x_it, x_it_n, db, sc, ac)` (descent.jl:512-581) as HipRbf.jl routes it:
+    the decision table of the library (mrbf_dispatch_ps / mrbf_dispatch_after) picks the device solver (objectives and modelled
+    constraints over several grouped models, linear constraints `lin = (A_eq, b_eq, A_ineq, b_ineq)` in scaled variables) or the
+    reference method -- here the host-loop mirror on batched container sweeps.  Never raises because of a size limit."""
+    from . import _lib
+    from . import surrogates as sg
+
+    lib = _lib.load()
+    plan = sg.container_plan(sc)
+    d = int(np.asarray(x_n).size)
+    lin = lin or (None, None, None, None)
+    n_lin = sum(0 if b is None else int(np.asarray(b).size) for b in (lin[1], lin[3]))
+    if lib.mrbf_dispatch_ps(d, plan["k"], len(plan["models"]), plan["n_con"], n_lin, plan["n_foreign"]) == _lib.DISPATCH_DEVICE:
+        rc, out = _ps_step_problem(desc_cfg, plan["models"], plan["roles"], plan["k"], x, x_n, fx_n, lb_eff, ub_eff, lin=lin, seed=seed, stats=stats)
+        if rc == 0:
+            return out
+        if not lib.mrbf_dispatch_after(_lib.ENTRY_PS_STEP, rc):
+            plan["models"][0].ctx.check(rc)
+    # the reference method: one-point handles in Morbit, the population-batched host loop here
+    if stats is not None:
+        stats["path"] = "reference"
+
+    def ev(X):
+        return sg.eval_container_objectives_at_scaled_sites(sc, scal, X)
+
+    def jac(X):
+        return sg.eval_container_objectives_jacobian_at_scaled_sites(sc, scal, X)
+
+    eq_tol = 1e-8
+    has_con = plan["n_con"] > 0 or n_lin > 0
+
+    def con(X):
+        X = np.atleast_2d(X)
+        cols = []
+        if sc.lists["nl_eq_constraint"]:
+            h = sg.eval_container_nl_eq_constraints_at_scaled_sites(sc, scal, X)
+            cols.append(np.where(np.abs(h) > eq_tol, np.abs(h), 0.0))
+        if sc.lists["nl_ineq_constraint"]:
+            cols.append(sg.eval_container_nl_ineq_constraints_at_scaled_sites(sc, scal, X))
+        if lin[1] is not None and np.asarray(lin[1]).size:
+            h = X @ np.asarray(lin[0], dtype=np.float64).T - np.asarray(lin[1], dtype=np.float64)[None, :]
+            cols.append(np.where(np.abs(h) > eq_tol, np.abs(h), 0.0))
+        if lin[3] is not None and np.asarray(lin[3]).size:
+            cols.append(X @ np.asarray(lin[2], dtype=np.float64).T - np.asarray(lin[3], dtype=np.float64)[None, :])
+        return np.hstack(cols)
+
+    return get_criticality(desc_cfg, x, x_n, fx_n, lb_eff, ub_eff, ev, eval_jacobians=jac, eval_constraints=con if has_con else None,
+                           rng=rng if rng is not None else np.random.default_rng(seed), stats=stats)
 
 
 def get_criticality(desc_cfg, x, x_n, fx_n, lb_eff, ub_eff, eval_objectives: Callable, eval_jacobians: Optional[Callable] = None,
@@ -305,7 +400,7 @@ def get_criticality(desc_cfg, x, x_n, fx_n, lb_eff, ub_eff, eval_objectives: Cal
     tau, x_min, ret = _ps_optimization(-0.5, x_n, lb_eff, ub_eff, eval_objectives, mx, r, g_evals, rng, eval_constraints, stats)
     fail = ret == "FAILURE" or not np.isfinite(tau) or np.any(np.isnan(x_min))
     if l_evals > 0 and not fail and eval_jacobians is not None:
-        t2, x2, ret2 = _polish(tau, x_min, np.asarray(lb_eff), np.asarray(ub_eff), eval_objectives, eval_jacobians, mx, r, l_evals)
+        t2, x2, ret2 = _polish(tau, x_min, np.asarray(lb_eff), np.asarray(ub_eff), eval_objectives, eval_jacobians, mx, r, l_evals, eval_constraints)
         if ret2 != "FAILURE" and np.isfinite(t2) and not np.any(np.isnan(x2)):
             tau, x_min = t2, x2
     if fail:

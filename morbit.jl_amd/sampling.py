@@ -28,7 +28,7 @@ def _orthogonal_complement_matrix(Y, p=np.inf):
 class AffinelyIndependentPointFilter:
     """Greedy filter: repeatedly the candidate maximising ||Z Z'(xi - x0)||_p, accepted while it exceeds pivot_val."""
 
-    def __init__(self, x_0, seeds, n=None, Y=None, Z=None, p=np.inf, pivot_val=1e-3, ctx=None, device_threshold=4096):
+    def __init__(self, x_0, seeds, n=None, Y=None, Z=None, p=np.inf, pivot_val=1e-3, ctx=None):
         self.x_0 = np.asarray(x_0, dtype=np.float64)
         self.shifted = [np.asarray(s, dtype=np.float64) - self.x_0 for s in seeds]
         d = self.x_0.size
@@ -38,8 +38,9 @@ class AffinelyIndependentPointFilter:
         self.Z = np.eye(d) if Z is None else np.array(Z, dtype=np.float64)
         self.p, self.pivot_val = p, pivot_val
         # databases with many sites in the box: the candidate scan (two tall products + a reduction per pick) runs on the device
-        # (mrbf_affine_scores); below the threshold the host's BLAS is faster than a launch
-        self.ctx, self.device_threshold = ctx, device_threshold
+        # (mrbf_affine_scores) when the decision table says so (mrbf_dispatch_affine, as in HipRbf.jl's iterate method); a given
+        # `ctx` forces the device scan (tests)
+        self.ctx = ctx
 
     def _scores_device(self, S):
         ctx = self.ctx or _lib.default_context()
@@ -59,7 +60,8 @@ class AffinelyIndependentPointFilter:
         self.Z = _orthogonal_complement_matrix(self.Y, self.p)
         out.append(i)
         S = np.array(self.shifted) if self.shifted else np.empty((0, self.x_0.size))
-        on_device = self.ctx is not None or len(cand) >= self.device_threshold
+        on_device = self.ctx is not None or \
+            _lib.load().mrbf_dispatch_affine(len(cand), self.x_0.size) == _lib.DISPATCH_DEVICE
         if on_device:
             Sd = np.ascontiguousarray(S, dtype=np.float64)
             Sd[i] = 0.0   # chosen sites score 0 (the reference removes them from the candidate list)
@@ -169,9 +171,10 @@ class Round4State:
             pass
 
 
-def rbf_round4_device(cfg, start_sites, cand_sites, delta=1.0, ctx=None, keep_state=False):
+def rbf_round4_device(cfg, start_sites, cand_sites, delta=1.0, ctx=None, keep_state=False, rc_only=False):
     """_rbf_round4's selection (RbfModel.jl:352-499) as ONE device call: positions (into cand_sites) of the accepted sites in
-    acceptance order [, Round4State].  Raises MrbfError(-2 / ESINGULAR) when the start set does not carry the polynomial tail."""
+    acceptance order [, Round4State].  Raises MrbfError(-2 / ESINGULAR) when the start set does not carry the polynomial tail;
+    with `rc_only` returns (rc, accepted, state) and raises nothing (what the routed `_rbf_round4` uses)."""
     ctx = ctx or _lib.default_context()
     C0, Xc = _lib.host_f64(start_sites), _lib.host_f64(cand_sites)
     n0, d = C0.shape
@@ -180,18 +183,24 @@ def rbf_round4_device(cfg, start_sites, cand_sites, delta=1.0, ctx=None, keep_st
     acc = np.zeros(max(mc, 1), dtype=np.int32)
     nacc = ctypes.c_int32()
     h = _lib.c_vp()
-    ctx.check(ctx.lib.mrbf_round4(ctx.h, n0, d, _lib.as_ptr(C0), mc, _lib.as_ptr(Xc) if mc else None, kid, a, b, cfg.polynomial_degree,
-                                  int(cfg.max_model_points), float(cfg.θ_pivot_cholesky), _lib.as_ptr(acc), ctypes.byref(nacc),
-                                  ctypes.byref(h) if keep_state else None))
+    rc = ctx.lib.mrbf_round4(ctx.h, n0, d, _lib.as_ptr(C0), mc, _lib.as_ptr(Xc) if mc else None, kid, a, b, cfg.polynomial_degree,
+                             int(cfg.max_model_points), float(cfg.θ_pivot_cholesky), _lib.as_ptr(acc), ctypes.byref(nacc),
+                             ctypes.byref(h) if keep_state else None)
+    if rc != 0:
+        if rc_only:
+            return rc, [], None
+        ctx.check(rc)
     accepted = [int(v) for v in acc[: nacc.value]]
-    if keep_state:
-        return accepted, Round4State(ctx, h if h.value else None, cfg, delta, C0, Xc.reshape(mc, d), accepted)
-    return accepted
+    state = Round4State(ctx, h if h.value else None, cfg, delta, C0, Xc.reshape(mc, d), accepted) if keep_state else None
+    if rc_only:
+        return rc, accepted, state
+    return (accepted, state) if keep_state else accepted
 
 
-def fit_from_round4(state, training_values, fully_linear=False):
+def fit_from_round4(state, training_values, fully_linear=False, rc_only=False):
     """update_model (RbfModel.jl:743-767) for the training set (start sites + sites accepted by round 4) from the factor round 4
-    left on the device -- the reference's TODO at RbfModel.jl:657-660.  `training_values`: (n0 + n_accepted) x k in that order."""
+    left on the device -- the reference's TODO at RbfModel.jl:657-660.  `training_values`: (n0 + n_accepted) x k in that order.
+    With `rc_only` returns (rc, model or None) and raises nothing."""
     ctx = state.ctx
     S = state.training_sites
     n, d = S.shape
@@ -201,12 +210,69 @@ def fit_from_round4(state, training_values, fully_linear=False):
     W, L = np.empty((n, k)), np.empty((max(q, 1), k))
     h, info = _lib.c_vp(), _lib.FitInfo()
     if state.handle is None:  # nothing was selected / no state kept: the ordinary fit
-        return rm.update_model(state.cfg, S, Y, state.delta, fully_linear, ctx=ctx)
-    ctx.check(ctx.lib.mrbf_fit_from_round4(ctx.h, state.handle, k, _lib.as_ptr(Y), ctypes.byref(h), _lib.as_ptr(W), _lib.as_ptr(L), ctypes.byref(info)))
-    return rm.RbfModel(ctx, h, n, d, k, q, fully_linear, W, L[:q], info.asdict())
+        mod = rm.update_model(state.cfg, S, Y, state.delta, fully_linear, ctx=ctx)
+        return (0, mod) if rc_only else mod
+    rc = ctx.lib.mrbf_fit_from_round4(ctx.h, state.handle, k, _lib.as_ptr(Y), ctypes.byref(h), _lib.as_ptr(W), _lib.as_ptr(L), ctypes.byref(info))
+    if rc != 0:
+        if rc_only:
+            return rc, None
+        ctx.check(rc)
+    mod = rm.RbfModel(ctx, h, n, d, k, q, fully_linear, W, L[:q], info.asdict())
+    return (0, mod) if rc_only else mod
 
 
-def _rbf_round4(sites, lb_2, ub_2, x, delta, indices_found_so_far, cfg, ctx=None, kernel_block=None, rng=None, new_sites=None):
+class Round4Keeper:
+    """HipRbf.jl's `_ROUND4_KEPT`: the factor round 4 left behind, per (sub-)database, together with the training indices it
+    describes (start indices, then accepted indices, in factor order); `update_model_from_selection` consumes it."""
+
+    def __init__(self):
+        self.kept = {}
+
+    def put(self, db_key, state, training_indices):
+        self.drop(db_key)
+        self.kept[db_key] = (state, list(training_indices))
+
+    def pop(self, db_key):
+        return self.kept.pop(db_key, None)
+
+    def drop(self, db_key):
+        old = self.kept.pop(db_key, None)
+        if old is not None and old[0] is not None:
+            old[0].free()
+
+
+def update_model_from_selection(cfg, sites, values, training_indices, delta=1.0, fully_linear=False, keeper=None, db_key=None, ctx=None,
+                                stats=None):
+    """`update_model(mod, meta, cfg::HipRbfConfig, ...)` of HipRbf.jl (RbfModel.jl:743-767): the model on the training set
+    `_collect_indices(meta)` -- from the kept round-4 factor when the decision table (mrbf_dispatch_fit / mrbf_dispatch_after) says
+    it describes exactly this training set, else Gram + factorisation + solve (`mrbf_fit`).  `sites` / `values`: the database."""
+    lib = _lib.load()
+    idx = list(training_indices)
+    S, Y = np.asarray(sites, dtype=np.float64)[idx], np.asarray(values, dtype=np.float64)[idx]
+    kept = keeper.pop(db_key) if keeper is not None else None
+    if kept is not None:
+        state, ids = kept
+        d = S.shape[1]
+        q = 0 if cfg.polynomial_degree < 0 else (1 if cfg.polynomial_degree == 0 else d + 1)
+        n0, nacc = (state.start_sites.shape[0], len(state.accepted)) if state is not None and state.handle is not None else (0, 0)
+        if lib.mrbf_dispatch_fit(len(idx), n0, q, nacc, int(ids == idx)) == _lib.FIT_FROM_ROUND4:
+            rc, mod = fit_from_round4(state, Y, fully_linear, rc_only=True)
+            if rc == 0:
+                if stats is not None:
+                    stats["fit"] = "from_round4"
+                state.free()
+                return mod
+            if not lib.mrbf_dispatch_after(_lib.ENTRY_FIT_FROM_ROUND4, rc):
+                state.ctx.check(rc)
+        if state is not None:
+            state.free()
+    if stats is not None:
+        stats["fit"] = "full"
+    return rm.update_model(cfg, S, Y, delta, fully_linear, ctx=ctx)
+
+
+def _rbf_round4(sites, lb_2, ub_2, x, delta, indices_found_so_far, cfg, ctx=None, kernel_block=None, rng=None, new_sites=None,
+                keeper=None, db_key=None, stats=None):
     """Wild's second selection round (RbfModel.jl:352-499): database indices of additional training sites that keep the
     Cholesky factors of Z'Phi Z bounded.  `sites` is the database as an (N_db, d) array; candidates are the box members
     not yet chosen, in database order.  With `cfg.use_max_points` random box points are tried once the database candidates
@@ -234,23 +300,29 @@ def _rbf_round4(sites, lb_2, ub_2, x, delta, indices_found_so_far, cfg, ctx=None
     C0 = sites[list(indices_found_so_far)]
     Xc = np.vstack([sites[cand], fresh]) if len(cand) else fresh
     ids = list(cand) + [-1] * fresh.shape[0]
-    if kernel_block is None:
-        # the whole selection as one device call (round4.hip); the incremental host bookkeeping below only remains for start sets
-        # that do not carry the polynomial tail (n0 < q or rank deficient), which the device path refuses
-        try:
-            accepted = rbf_round4_device(cfg, C0, Xc, delta, ctx=ctx)
-        except _lib.MrbfError as e:
-            if e.code not in (-2, _lib.MRBF_ESINGULAR):
-                raise
-            accepted = None
-        if accepted is not None:
+    if keeper is not None:
+        keeper.drop(db_key)          # whatever was kept belongs to an older training set
+    if kernel_block is None and _lib.load().mrbf_dispatch_round4(N, d, deg, Xc.shape[0]) == _lib.DISPATCH_DEVICE:
+        # the whole selection as one device call (round4.hip), routed like `_rbf_round4(..., cfg::HipRbfConfig)` in HipRbf.jl; the
+        # incremental host bookkeeping below is Morbit's own method: start sets that cannot carry the polynomial tail (n0 < q, decided
+        # up front) or turn out rank deficient (the device call says so: mrbf_dispatch_after)
+        rc, accepted, state = rbf_round4_device(cfg, C0, Xc, delta, ctx=ctx, keep_state=keeper is not None, rc_only=True)
+        if rc == 0:
             for pos in accepted:
                 id_ = ids[pos]
                 if id_ < 0:
                     new_sites.append(Xc[pos].copy())
                     id_ = sites.shape[0] + len(new_sites) - 1
                 round4.append(id_)
+            if keeper is not None and state is not None:
+                keeper.put(db_key, state, list(indices_found_so_far) + round4)
+            if stats is not None:
+                stats["round4"] = "device"
             return round4
+        if not _lib.load().mrbf_dispatch_after(_lib.ENTRY_ROUND4, rc):
+            (ctx or _lib.default_context()).check(rc)
+    if stats is not None:
+        stats["round4"] = "reference"
     if kernel_block is None:
         # two device calls replace one kernels(xi) call per candidate plus RBF.get_matrices
         Phi, Pi, _ = rm.get_matrices(cfg, C0, delta, ctx=ctx)

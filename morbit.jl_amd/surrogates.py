@@ -186,6 +186,49 @@ class SurrogateContainer:
         return [_get_optim_handle(s, scal, l) for s in self.lists[kind] for l in range(s.num_outputs)]
 
 
+def container_plan(sc, objectives_only=False):
+    """What the device entry points need to know about a container (HipRbf.jl `_container_plan`): its distinct grouped device
+    models, the role of every output row of each (objective position l >= 0, ROLE_EQ, ROLE_INEQ, ROLE_NONE), the number of objective
+    rows k, of modelled constraint rows and of "foreign" surrogates (CompositeSurrogates, anything that is not a device RbfModel,
+    a model row used twice) -- with a foreign one the decision table sends the call to the reference method."""
+    from . import _lib
+    models, roles = [], []
+    k = n_con = n_foreign = 0
+
+    def slot(m):
+        for i, mm in enumerate(models):
+            if mm is m:
+                return i
+        models.append(m)
+        roles.append([_lib.ROLE_NONE] * m.num_outputs)
+        return len(models) - 1
+
+    for kind, role in (("objective", 0), ("nl_eq_constraint", _lib.ROLE_EQ), ("nl_ineq_constraint", _lib.ROLE_INEQ)):
+        if objectives_only and role != 0:     # _backtrack only evaluates the objectives (descent.jl:161-179)
+            continue
+        for s in sc.lists[kind]:
+            inner = s.model if isinstance(s, (RefSurrogate, CompositeSurrogate)) else s
+            if isinstance(s, CompositeSurrogate) or not isinstance(inner, rm.RbfModel):
+                n_foreign += 1
+                if role == 0:
+                    k += s.num_outputs
+                else:
+                    n_con += s.num_outputs
+                continue
+            i = slot(inner)
+            for oi in (s.output_indices if isinstance(s, RefSurrogate) else range(inner.num_outputs)):
+                if roles[i][oi] != _lib.ROLE_NONE:
+                    n_foreign += 1                      # one row in two roles: not expressible
+                roles[i][oi] = k if role == 0 else role
+                if role == 0:
+                    k += 1
+                else:
+                    n_con += 1
+    in_order = len(models) == 1 and n_con == 0 and roles[0] == list(range(models[0].num_outputs))
+    return {"models": models, "roles": [r for rr in roles for r in rr], "k": k, "n_con": n_con, "n_foreign": n_foreign,
+            "in_order": in_order}
+
+
 def _make(kind, plural):
     def at_site(sc, scal, x_scaled):
         return sc._eval_at_site(kind, scal, x_scaled)

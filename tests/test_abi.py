@@ -50,6 +50,7 @@ def test_struct_layouts_match_header():
     assert _lib.Result.fit.offset == 8
     assert ctypes.sizeof(_lib.PsOptions) == 40 and ctypes.sizeof(_lib.PsInfo) == 32 and _lib.PsInfo.tau.offset == 24
     assert ctypes.sizeof(_lib.Result) == 8 + 72 + 8 + 16
+    assert ctypes.sizeof(_lib.PsProblem) == 72 and _lib.PsProblem.eq_tol.offset == 64 and _lib.PsProblem.n_lin_eq.offset == 24
 
 
 def test_version_and_no_cpu_fallback(lib):

@@ -149,7 +149,7 @@ def test_ps_step_on_device_container():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("d,n,given_dir", [(4, 200, False), (12, 512, False), (6, 300, True)])
+@pytest.mark.parametrize("d,n,given_dir", [(4, 200, False), (12, 512, False), (6, 300, True), (20, 600, False)])
 def test_ps_step_with_the_solver_on_the_device(d, n, given_dir):
     """mrbf_ps_step: population state, ranking and breeding on the device.  Asserted: the contract of get_criticality
     (descent.jl:512-581) -- budgets, feasibility of the returned point for the subproblem, omega = |tau|, trial point inside
@@ -172,6 +172,9 @@ def test_ps_step_with_the_solver_on_the_device(d, n, given_dir):
     assert np.allclose(mt, ev(xt[None, :])[0], rtol=0, atol=1e-12)
     # feasible for the subproblem: m_l(x_trial) - m_l(x_n) - tau r_l <= 0 (descent.jl:443), so every objective improves by >= omega r_l
     assert np.all(mt - fx + omega * r <= 1e-9 * max(1.0, np.abs(fx).max()))
+    # info.tau is what the returned point achieves (recomputed on the host from a fresh sweep): an individual recorded as the
+    # feasible best must BE feasible
+    assert np.max((ev(xt[None, :])[0] - fx) / r) <= stats["tau"] + 1e-9
     # budgets (descent.jl:416, :527): never more evaluations than allowed; one batched sweep per generation
     assert stats["evals_ps"] <= 500 * (d + 1)
     if given_dir:
@@ -200,6 +203,130 @@ def test_ps_step_with_the_solver_on_the_device(d, n, given_dir):
     print("PS step d=%d: %.2f ms on the device, %d evaluations in %d generations, omega %.4f (host mirror %.4f)"
           % (d, stats["ms_total"], stats["evals_ideal"] + stats["evals_ps"], stats["generations"], omega_d, omega_h))
     mod.free()
+
+
+def _check_ps_contract(ev_obj, ev_con, x, lb, ub, fx, omega, xt, mt, stats, lin=None, strict=True):
+    """the contract of get_criticality for a returned (omega, x_trial, mx_trial), recomputed on the host from batched sweeps"""
+    r = stats["r"]
+    assert stats["status"] == 0 and omega == abs(stats["tau"]) and 0 <= omega <= 1.0 and (omega > 0 or not strict)
+    assert np.all(xt >= lb) and np.all(xt <= ub)
+    assert np.allclose(mt, ev_obj(xt[None, :])[0], rtol=0, atol=1e-10 * max(1.0, np.abs(mt).max()))
+    # tau is what the trial point achieves: max_l (m_l(x_trial) - m_l(x_n)) / r_l <= tau  (feasible for descent.jl:443), recomputed
+    mx = ev_obj(x[None, :])[0]
+    tau_host = np.max((ev_obj(xt[None, :])[0] - mx) / r)
+    assert tau_host <= stats["tau"] + 1e-9, (tau_host, stats["tau"])
+    if ev_con is not None:
+        g = ev_con(xt[None, :])[0]
+        assert np.all(g <= 1e-8), g
+    if lin is not None and lin[3] is not None:
+        assert np.all(lin[2] @ xt - lin[3] <= 1e-8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d", [24, 64, 128])
+def test_ps_step_on_device_at_baseline_dimensions(d):
+    """The device solver at the dimensions of BASELINE.json: d = 64 on a C3-shaped model (the C3 centres, n = 8192, multiquadric),
+    d = 128 on one C4 start (ZDT1, n = 2d + 1 = 257 -- the reference's own `:ps` example, examples/example_zdt.jl:39) and a d between
+    the small tests and those.  (a) the paper benchmark's configuration (examples/large_scale_benchmarks.jl:215-219: direction from a
+    reference point, 50 (d + 1) global + 100 (d + 1) polish evaluations): contract asserts, tau recomputed on the host, same seed ->
+    same step; (b) Morbit's defaults (local ideal point + 500 (d + 1) evaluations, no polish): contract + wall time."""
+    from morbit.jl_amd import workloads
+
+    if d == 64:
+        C = workloads.problem("C3")[0]
+        assert C.shape == (8192, 64)
+        Y = np.stack([np.sum((C - 0.3) ** 2, axis=1), np.sum((C - 0.7) ** 2, axis=1)], axis=1) / d
+        cfg = pkg.RbfConfig(kernel="multiquadric")
+    elif d == 128:
+        C, Y, _ = workloads.problem("C4", 0)
+        assert C.shape == (257, 128)
+        cfg = pkg.RbfConfig(kernel="cubic")
+    else:
+        rng = np.random.default_rng(d)
+        C = rng.random((700, d))
+        Y = np.stack([np.sum((C - 0.3) ** 2, axis=1), np.sum((C - 0.7) ** 2, axis=1)], axis=1) / d
+        cfg = pkg.RbfConfig(kernel="cubic")
+    mod = pkg.update_model(cfg, C, Y)
+    ev = lambda X: pkg.eval_models_at_sites(mod, None, X)
+    if d == 128:
+        x = C[0].copy()                    # the start point itself (first training site)
+    else:
+        x = np.full(d, 0.5)
+        x[1], x[3] = 0.8, 0.25
+    lb, ub = np.maximum(x - 0.1, 0.0), np.minimum(x + 0.1, 1.0)
+    fx = ev(x[None, :])[0]
+    bench = ps.PascolettiSerafiniConfig(reference_point=[-1.0, -1.0], max_ps_problem_evals=50 * (d + 1), max_ps_polish_evals=100 * (d + 1),
+                                        ps_polish_algo="LD_MMA")
+    stats = {}
+    omega, (xt, mt, sl) = ps.get_criticality_device(bench, mod, x, x, fx, lb, ub, seed=21, stats=stats)
+    _check_ps_contract(ev, None, x, lb, ub, fx, omega, xt, mt, stats)
+    assert stats["evals_ideal"] == 0 and stats["evals_ps"] <= 50 * (d + 1) and 0 < stats["evals_polish"] <= 100 * (d + 1)
+    assert np.allclose(stats["r"], fx + 1.0) and abs(sl - np.abs(x - xt).max()) < 1e-15 and np.all(mt < fx)
+    stats2 = {}
+    omega2, (xt2, _, _) = ps.get_criticality_device(bench, mod, x, x, fx, lb, ub, seed=21, stats=stats2)
+    assert omega2 == omega and np.array_equal(xt2, xt)
+    stats3 = {}
+    omega3, rest = ps.get_criticality_device(ps.PascolettiSerafiniConfig(), mod, x, x, fx, lb, ub, seed=22, stats=stats3)[:2]
+    if stats3["status"] == 0:
+        _check_ps_contract(ev, None, x, lb, ub, fx, omega3, rest[0], rest[1], stats3, strict=False)
+    assert stats3["evals_ps"] <= 500 * (d + 1) and stats3["evals_ideal"] <= 2 * 500 * (d + 1)
+    print("PS step d=%d n=%d: benchmark budgets %.1f ms (%d + %d polish evaluations, %d generations, omega %.5f); Morbit defaults %.1f ms "
+          "(%d evaluations, %d generations, omega %.5f)" % (d, C.shape[0], stats["ms_total"], stats["evals_ps"], stats["evals_polish"],
+                                                            stats["generations"], omega, stats3["ms_total"], stats3["evals_ideal"] + stats3["evals_ps"],
+                                                            stats3["generations"], omega3))
+    mod.free()
+
+
+@pytest.mark.gpu
+def test_ps_step_container_with_two_models_and_constraints():
+    """mrbf_ps_step_problem through the routed `get_criticality_container`: objectives from two grouped models, a modelled inequality
+    constraint (a row of the first model), a modelled equality constraint and a linear inequality of the MOP; compared with the
+    reference method (host loop) on the same container."""
+    rng = np.random.default_rng(12)
+    d, n = 6, 400
+    C = rng.random((n, d))
+    Ya = np.stack([np.sum((C - 0.3) ** 2, axis=1), C[:, 0] - 0.52, C[:, 2] - C[:, 4]], axis=1)     # objective 0 | g(x) <= 0 | h(x) = 0
+    Yb = np.sum((C - 0.7) ** 2, axis=1, keepdims=True)                                               # objective 1
+    ma = pkg.update_model(pkg.RbfConfig(kernel="cubic"), C, Ya)
+    mb = pkg.update_model(pkg.RbfConfig(kernel="multiquadric"), C, Yb)
+    R = pkg.surrogates.RefSurrogate
+    sc = pkg.surrogates.SurrogateContainer(objectives=[R(ma, [0]), R(mb, [0])], nl_ineq_constraints=[R(ma, [1])], nl_eq_constraints=[R(ma, [2])])
+    x = np.array([0.5, 0.85, 0.4, 0.2, 0.4, 0.5])
+    lb, ub = x - 0.12, x + 0.12
+    A, b = np.array([[0.0, 1.0, 0.0, 1.0, 0.0, 0.0]]), np.array([1.0])        # x1 + x3 <= 1
+    lin = (None, None, A, b)
+    ev = lambda X: pkg.surrogates.eval_container_objectives_at_scaled_sites(sc, None, X)
+    fx = ev(x[None, :])[0]
+    cfgps = ps.PascolettiSerafiniConfig()
+    stats = {}
+    omega, (xt, mt, sl) = ps.get_criticality_container(cfgps, sc, None, x, x, fx, lb, ub, lin=lin, seed=5, stats=stats)
+    assert stats["path"] == "device"
+    g = lambda X: pkg.surrogates.eval_container_nl_ineq_constraints_at_scaled_sites(sc, None, X)
+    h = pkg.surrogates.eval_container_nl_eq_constraints_at_scaled_sites(sc, None, xt[None, :])[0]
+    _check_ps_contract(ev, g, x, lb, ub, fx, omega, xt, mt, stats, lin=lin)
+    assert np.all(np.abs(h) <= 1e-8 + 1e-12), h                                 # equality within the tolerance the problem states
+    assert np.all(mt < fx)
+    stats2 = {}
+    omega2, (xt2, _, _) = ps.get_criticality_container(cfgps, sc, None, x, x, fx, lb, ub, lin=lin, seed=5, stats=stats2)
+    assert omega2 == omega and np.array_equal(xt2, xt)
+    # the reference method on the same container and direction
+    cfg_r = ps.PascolettiSerafiniConfig(reference_direction=list(stats["r"]))
+    plan_models = pkg.surrogates.container_plan(sc)["models"]
+    assert plan_models == [ma, mb]
+    import morbit.jl_amd.pascoletti_serafini as psm
+    real = psm._ps_step_problem
+    psm._ps_step_problem = lambda *a, **k: (-2, None)                         # the device refuses -> reference method
+    try:
+        st_h = {}
+        omega_h, _ = ps.get_criticality_container(cfg_r, sc, None, x, x, fx, lb, ub, lin=lin, seed=3, stats=st_h)[:2]
+    finally:
+        psm._ps_step_problem = real
+    assert st_h["path"] == "reference"
+    omega_d, _ = ps.get_criticality_container(cfg_r, sc, None, x, x, fx, lb, ub, lin=lin, seed=7)[:2]
+    assert omega_d >= 0.8 * omega_h, (omega_d, omega_h)
+    print("PS step, 2 models + 3 constraints, d=%d: %.2f ms on the device, omega %.4f (reference method %.4f)" % (d, stats["ms_total"], omega_d, omega_h))
+    ma.free()
+    mb.free()
 
 
 @pytest.mark.gpu
