@@ -278,7 +278,7 @@ def _polish(tau, x_min, lb, ub, eval_objectives, eval_jacobians, mx, r, max_eval
     return t, x, "SUCCESS"
 
 
-def _ps_step_problem(desc_cfg, models, roles, k, x, x_n, fx_n, lb_eff, ub_eff, lin=None, seed=0, stats=None):
+def _ps_step_problem(desc_cfg, models, roles, k, x, x_n, fx_n, lb_eff, ub_eff, lin=None, seed=0, stats=None, eq_tol=-1.0):
     """one mrbf_ps_step_problem call; returns (rc, result) -- rc != 0: no result"""
     import ctypes
 
@@ -300,7 +300,7 @@ def _ps_step_problem(desc_cfg, models, roles, k, x, x_n, fx_n, lb_eff, ub_eff, l
     prob = _lib.PsProblem(n_models=len(models), n_objectives=k, models=handles, roles=roles_c,
                           n_lin_eq=0 if b_eq is None else b_eq.size, n_lin_ineq=0 if b_in is None else b_in.size,
                           A_eq=None if A_eq is None else A_eq.ctypes.data, b_eq=None if b_eq is None else b_eq.ctypes.data,
-                          A_ineq=None if A_in is None else A_in.ctypes.data, b_ineq=None if b_in is None else b_in.ctypes.data, eq_tol=-1.0)
+                          A_ineq=None if A_in is None else A_in.ctypes.data, b_ineq=None if b_in is None else b_in.ctypes.data, eq_tol=float(eq_tol))
     info = _lib.PsInfo()
     xt, mt, r_out = np.empty(d), np.empty(k), np.empty(k)
     rc = ctx.lib.mrbf_ps_step_problem(ctx.h, ctypes.byref(prob), _lib.as_ptr(x_n), _lib.as_ptr(lb), _lib.as_ptr(ub), _lib.as_ptr(fx),
@@ -328,11 +328,12 @@ def get_criticality_device(desc_cfg, model, x, x_n, fx_n, lb_eff, ub_eff, seed=0
     return out
 
 
-def get_criticality_container(desc_cfg, sc, scal, x, x_n, fx_n, lb_eff, ub_eff, lin=None, seed=0, rng=None, stats=None):
+def get_criticality_container(desc_cfg, sc, scal, x, x_n, fx_n, lb_eff, ub_eff, lin=None, seed=0, rng=None, stats=None, eq_tol=1e-8):
     """`get_criticality(::PascolettiSerafiniConfig, mop, scal, x_it, x_it_n, db, sc, ac)` (descent.jl:512-581) as HipRbf.jl routes it:
     the decision table of the library (mrbf_dispatch_ps / mrbf_dispatch_after) picks the device solver (objectives and modelled
     constraints over several grouped models, linear constraints `lin = (A_eq, b_eq, A_ineq, b_ineq)` in scaled variables) or the
-    reference method -- here the host-loop mirror on batched container sweeps.  Never raises because of a size limit."""
+    reference method -- here the host-loop mirror on batched container sweeps.  Never raises because of a size limit.
+    `eq_tol`: an equality constraint counts as satisfied when |h| <= eq_tol (mrbf_ps_problem.eq_tol)."""
     from . import _lib
     from . import surrogates as sg
 
@@ -342,7 +343,7 @@ def get_criticality_container(desc_cfg, sc, scal, x, x_n, fx_n, lb_eff, ub_eff, 
     lin = lin or (None, None, None, None)
     n_lin = sum(0 if b is None else int(np.asarray(b).size) for b in (lin[1], lin[3]))
     if lib.mrbf_dispatch_ps(d, plan["k"], len(plan["models"]), plan["n_con"], n_lin, plan["n_foreign"]) == _lib.DISPATCH_DEVICE:
-        rc, out = _ps_step_problem(desc_cfg, plan["models"], plan["roles"], plan["k"], x, x_n, fx_n, lb_eff, ub_eff, lin=lin, seed=seed, stats=stats)
+        rc, out = _ps_step_problem(desc_cfg, plan["models"], plan["roles"], plan["k"], x, x_n, fx_n, lb_eff, ub_eff, lin=lin, seed=seed, stats=stats, eq_tol=eq_tol)
         if rc == 0:
             return out
         if not lib.mrbf_dispatch_after(_lib.ENTRY_PS_STEP, rc):
@@ -357,7 +358,6 @@ def get_criticality_container(desc_cfg, sc, scal, x, x_n, fx_n, lb_eff, ub_eff, 
     def jac(X):
         return sg.eval_container_objectives_jacobian_at_scaled_sites(sc, scal, X)
 
-    eq_tol = 1e-8
     has_con = plan["n_con"] > 0 or n_lin > 0
 
     def con(X):

@@ -135,7 +135,7 @@ def test_ps_routing_device_vs_reference(models, monkeypatch):
     lb, ub = x - 0.15, x + 0.15
     calls = []
 
-    def fake_device(desc_cfg, mods, roles, k, *a, lin=None, seed=0, stats=None):
+    def fake_device(desc_cfg, mods, roles, k, *a, lin=None, seed=0, stats=None, eq_tol=-1.0):
         calls.append((list(mods), list(roles), k, lin))
         return fake_device.rc, ((0.25, (x.copy(), np.zeros(k), 0.0)) if fake_device.rc == 0 else None)
 

