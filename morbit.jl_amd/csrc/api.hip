@@ -51,6 +51,84 @@ static void pool_release(mrbf_ctx *c) {
         mrbf_shutdown(c);
 }
 
+namespace mrbf {
+// the per-problem launch chain for the problems listed in `which` (anything the batched small-problem path of batch.hip does not
+// take: large n, d > 128, LU / minimum-norm paths): worker threads x contexts, problem p on GPU p % n_dev
+int batch_run_chain(int n_dev, const int *devs, const std::vector<int64_t> &which, const mrbf_problem *problems, mrbf_result *results) {
+    if (which.empty()) return MRBF_OK;
+    // small problems are launch-latency bound: several host threads (each with its own context and streams) per GPU keep
+    // more kernels in flight; large problems fill the chip on their own
+    int64_t nmax = 0;
+    for (int64_t p : which) nmax = std::max<int64_t>(nmax, problems[p].n);
+    int per_dev = (nmax <= 2048) ? 4 : 1;
+    if (const char *e = getenv("MRBF_BATCH_WORKERS")) per_dev = std::max(1, atoi(e));
+    per_dev = (int)std::max<int64_t>(1, std::min<int64_t>(per_dev, ((int64_t)which.size() + n_dev - 1) / n_dev));
+    std::vector<std::vector<int64_t>> per_gpu(n_dev);
+    for (int64_t p : which) per_gpu[p % n_dev].push_back(p);
+    const int n_workers = n_dev * per_dev;
+    std::vector<int> rcs(n_workers, 0);
+    auto worker = [&](int w) {
+        const int g = w % n_dev, lane = w / n_dev;
+        const std::vector<int64_t> &mine = per_gpu[g];
+        int rc = 0;
+        mrbf_ctx *ctx = pool_acquire(devs[g], &rc);
+        if (rc != 0) {
+            rcs[w] = rc;
+            for (size_t j = lane; j < mine.size(); j += per_dev) {
+                std::memset(&results[mine[j]], 0, sizeof(mrbf_result));
+                results[mine[j]].status = rc;
+                results[mine[j]].device = devs[g];
+            }
+            return;
+        }
+        for (size_t j = lane; j < mine.size(); j += per_dev) {  // round-robin shard (problem p -> GPU p % n_dev), no exchange
+            const int64_t p = mine[j];
+            const mrbf_problem &pr = problems[p];
+            mrbf_result &res = results[p];
+            std::memset(&res, 0, sizeof(res));
+            res.device = devs[g];
+            mrbf_model *M = nullptr;
+            std::vector<double> wtmp, vtmp;
+            double *wout = pr.weights_out, *vout = pr.vals_out;
+            if (!wout || is_device_ptr(wout)) {
+                wtmp.resize((size_t)pr.n * pr.k);
+                wout = wtmp.data();
+            }
+            res.status = mrbf_fit(ctx, pr.n, pr.d, pr.k, pr.centres, pr.values, pr.kernel_id, pr.a, pr.b, pr.poly_deg, &M,
+                                  wout, pr.poly_out, &res.fit);
+            if (res.status == 0 && wout != pr.weights_out && pr.weights_out)
+                (void)hipMemcpy(pr.weights_out, wout, wtmp.size() * sizeof(double), hipMemcpyDefault);
+            if (res.status == 0 && pr.m > 0) {
+                if (!vout || is_device_ptr(vout)) {
+                    vtmp.resize((size_t)pr.m * pr.k);
+                    vout = vtmp.data();
+                }
+                mrbf_eval_info ei;
+                res.status = mrbf_eval(ctx, M, pr.m, pr.X, vout, pr.jac_out, &ei);
+                res.ms_eval = ei.ms_total;
+                if (res.status == 0) {
+                    for (size_t i = 0; i < (size_t)pr.m * pr.k; ++i) res.checksum_vals += vout[i];  // (host sums on this path)
+                    if (vout != pr.vals_out && pr.vals_out) (void)hipMemcpy(pr.vals_out, vout, vtmp.size() * sizeof(double), hipMemcpyDefault);
+                }
+            }
+            if (res.status == 0 || M)
+                for (size_t i = 0; M && i < (size_t)pr.n * pr.k; ++i) res.checksum_w += wout[i];
+            if (M) mrbf_free_model(ctx, M);
+        }
+        pool_release(ctx);
+    };
+    std::vector<std::thread> th;
+    for (int w = 0; w < n_workers; ++w) th.emplace_back(worker, w);
+    for (auto &t : th) t.join();
+    for (int w = 0; w < n_workers; ++w)
+        if (rcs[w] != 0) return rcs[w];
+    return MRBF_OK;
+}
+
+mrbf_ctx *batch_pool_acquire(int device, int *rc) { return pool_acquire(device, rc); }
+void batch_pool_release(mrbf_ctx *c) { pool_release(c); }
+}  // namespace mrbf
+
 extern "C" {
 
 int32_t mrbf_gram(mrbf_ctx *ctx, int64_t n, int32_t d, const double *centres, int32_t kernel_id, double a, double b,
@@ -300,79 +378,6 @@ int32_t mrbf_free_model(mrbf_ctx *ctx, mrbf_model *model) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     destroy_model(ctx, model);
-    return MRBF_OK;
-}
-
-int32_t mrbf_batch_run(int32_t n_dev, const int32_t *device_ids, int64_t n_problems, const mrbf_problem *problems,
-                       mrbf_result *results) {
-    if (n_dev < 1) return -1;
-    if (n_problems < 0) return -3;
-    if (n_problems > 0 && (!problems || !results)) return -4;
-    int visible = 0;
-    if (hipGetDeviceCount(&visible) != hipSuccess || visible <= 0) return MRBF_ENODEVICE;
-    std::vector<int> devs(n_dev);
-    for (int g = 0; g < n_dev; ++g) {
-        devs[g] = device_ids ? device_ids[g] : g;
-        if (devs[g] < 0 || devs[g] >= visible) return -2;
-    }
-    // small problems are launch-latency bound: several host threads (each with its own context and streams) per GPU keep
-    // more kernels in flight; large problems fill the chip on their own
-    int64_t nmax = 0;
-    for (int64_t p = 0; p < n_problems; ++p) nmax = std::max<int64_t>(nmax, problems[p].n);
-    int per_dev = (nmax <= 2048) ? 4 : 1;
-    if (const char *e = getenv("MRBF_BATCH_WORKERS")) per_dev = std::max(1, atoi(e));
-    per_dev = (int)std::max<int64_t>(1, std::min<int64_t>(per_dev, (n_problems + n_dev - 1) / n_dev));
-    const int n_workers = n_dev * per_dev;
-    std::vector<int> rcs(n_workers, 0);
-    auto worker = [&](int w) {
-        const int g = w % n_dev;
-        int rc = 0;
-        mrbf_ctx *ctx = pool_acquire(devs[g], &rc);
-        if (rc != 0) {
-            rcs[w] = rc;
-            for (int64_t p = w; p < n_problems; p += n_workers) {
-                std::memset(&results[p], 0, sizeof(mrbf_result));
-                results[p].status = rc;
-                results[p].device = devs[g];
-            }
-            return;
-        }
-        for (int64_t p = w; p < n_problems; p += n_workers) {  // round-robin shard (problem p -> GPU p % n_dev), no exchange
-            const mrbf_problem &pr = problems[p];
-            mrbf_result &res = results[p];
-            std::memset(&res, 0, sizeof(res));
-            res.device = devs[g];
-            mrbf_model *M = nullptr;
-            std::vector<double> wtmp, vtmp;
-            double *wout = pr.weights_out, *vout = pr.vals_out;
-            if (!wout) {
-                wtmp.resize((size_t)pr.n * pr.k);
-                wout = wtmp.data();
-            }
-            res.status = mrbf_fit(ctx, pr.n, pr.d, pr.k, pr.centres, pr.values, pr.kernel_id, pr.a, pr.b, pr.poly_deg, &M,
-                                  wout, pr.poly_out, &res.fit);
-            if (res.status == 0 && pr.m > 0) {
-                if (!vout) {
-                    vtmp.resize((size_t)pr.m * pr.k);
-                    vout = vtmp.data();
-                }
-                mrbf_eval_info ei;
-                res.status = mrbf_eval(ctx, M, pr.m, pr.X, vout, pr.jac_out, &ei);
-                res.ms_eval = ei.ms_total;
-                if (res.status == 0)
-                    for (size_t i = 0; i < (size_t)pr.m * pr.k; ++i) res.checksum_vals += vout[i];
-            }
-            if (res.status == 0 || M)
-                for (size_t i = 0; M && i < (size_t)pr.n * pr.k; ++i) res.checksum_w += wout[i];
-            if (M) mrbf_free_model(ctx, M);
-        }
-        pool_release(ctx);
-    };
-    std::vector<std::thread> th;
-    for (int w = 0; w < n_workers; ++w) th.emplace_back(worker, w);
-    for (auto &t : th) t.join();
-    for (int w = 0; w < n_workers; ++w)
-        if (rcs[w] != 0) return rcs[w];
     return MRBF_OK;
 }
 

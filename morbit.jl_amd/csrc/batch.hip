@@ -1,0 +1,407 @@
+// mrbf_batch_run: the many-problem mode -- replaces the reference's Threads.@threads loop over independent problems
+// (/root/reference/examples/large_scale_benchmarks.jl:253; Halton starts :102-109, n = 2d + 1 sites per start :157, 50 (d + 1)
+// surrogate evaluations per subproblem :217).
+//
+// Problems are dealt round-robin over the GPUs (problem p -> GPU p % n_dev, one host thread + context per GPU, no exchange).  On each
+// GPU the small problems (n <= 512, d <= 128, Cholesky paths -- the regime Morbit runs in) go through a handful of launches whose grids
+// span ALL of them:
+//     1   small_fit_kernel            one workgroup per problem: the whole fit (small.hip)
+//     1   center_pad_batch_kernel     queries of all problems (and, for the residual, their sites) centred + padded
+//   2 k'  eval_fused / eval_combine   the fused MFMA evaluation with the problem index in the grid (k' = output passes)
+//     1   batch_check_kernel          residual through the evaluation, max |Pi' w|, order-fixed checksums, per problem
+// instead of ~65 device operations per problem.  A batch and single calls (mrbf_fit + mrbf_eval) run the same kernels with the same
+// split of the centre range, so their results agree bit for bit (tests/test_gpu_configs.py::test_c4_many_start_batch).  Problems of
+// any other shape, and problems whose factorisation raised a flag, take the per-problem chain (api.hip: batch_run_chain).
+#include <algorithm>
+#include <thread>
+
+#include "common.hpp"
+#include "small.hpp"
+
+namespace mrbf {
+
+int batch_run_chain(int n_dev, const int *devs, const std::vector<int64_t> &which, const mrbf_problem *problems, mrbf_result *results);
+mrbf_ctx *batch_pool_acquire(int device, int *rc);
+void batch_pool_release(mrbf_ctx *c);
+void fill_small_prob(const mrbf_model *M, const double *Y, double *ws, int *flags, double *scal, smallfit::Prob *P);
+int small_fit_verdict(const mrbf_model *M, const int *hflags, const double *hscal, mrbf_fit_info *info);
+
+struct CheckDesc {
+    const double *V, *Y;       // surrogate values at the sites / data, n x k
+    const double *C, *Wc, *W;  // sites n x d, weights npad x k column-major, n x k row-major
+    const double *vals;        // m x k values at the queries (may be NULL)
+    int64_t n, npad, m;
+    int d, k, q;
+    double *out;               // [0] sum (V - Y)^2, [1] sum Y^2, [2] max |Pi' w|, [3] sum W, [4] sum vals
+};
+
+// one workgroup per problem, every reduction in a fixed order
+__global__ __launch_bounds__(256) void batch_check_kernel(const CheckDesc *__restrict__ many) {
+    const CheckDesc &E = many[blockIdx.x];
+    __shared__ double r0[256], r1[256];
+    const int tid = threadIdx.x;
+    auto tree = [&](double a, double b, bool use_max) {
+        r0[tid] = a;
+        r1[tid] = b;
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) {
+            if (tid < w) {
+                r0[tid] = use_max ? fmax(r0[tid], r0[tid + w]) : r0[tid] + r0[tid + w];
+                r1[tid] += r1[tid + w];
+            }
+            __syncthreads();
+        }
+    };
+    double s0 = 0.0, s1 = 0.0;
+    for (int64_t i = tid; i < E.n * E.k; i += 256) {
+        const double df = E.V[i] - E.Y[i];
+        s0 = fma(df, df, s0);
+        s1 = fma(E.Y[i], E.Y[i], s1);
+    }
+    tree(s0, s1, false);
+    if (tid == 0) {
+        E.out[0] = r0[0];
+        E.out[1] = r1[0];
+    }
+    __syncthreads();
+    // max |Pi' w|: entry (t, l) = sum_i pi_t(c_i) w_il, pi_0 = 1, pi_t = coordinate t - 1
+    double mx = 0.0;
+    for (int e = tid; e < E.q * E.k; e += 256) {
+        const int t = e % E.q, l = e / E.q;
+        double acc = 0.0;
+        for (int64_t i = 0; i < E.n; ++i) acc = fma(t == 0 ? 1.0 : E.C[i * E.d + (t - 1)], E.Wc[i + (int64_t)l * E.npad], acc);
+        mx = fmax(mx, fabs(acc));
+    }
+    double sw = 0.0;
+    for (int64_t i = tid; i < E.n * E.k; i += 256) sw += E.W[i];
+    tree(mx, sw, true);
+    if (tid == 0) {
+        E.out[2] = r0[0];
+        E.out[3] = r1[0];
+    }
+    __syncthreads();
+    double sv = 0.0;
+    if (E.vals)
+        for (int64_t i = tid; i < E.m * E.k; i += 256) sv += E.vals[i];
+    tree(0.0, sv, false);
+    if (tid == 0) E.out[4] = r1[0];
+}
+
+static inline size_t al16(size_t c) { return (c + 15) & ~size_t(15); }
+
+// all small problems of one GPU; `redo` receives the problems that have to take the per-problem chain after all (flags)
+static int run_small_batch(mrbf_ctx *ctx, const std::vector<int64_t> &idx, const mrbf_problem *problems, mrbf_result *results,
+                           std::vector<int64_t> *redo) {
+    const int P = (int)idx.size();
+    if (P == 0) return 0;
+    (void)hipSetDevice(ctx->device);
+    struct Lay {
+        size_t C, Y, X, Xc, sq, mean, W, Wc, lam, ws, Xq0, xsq0, vp0, gp0, V0, Xq1, xsq1, vp1, gp1, vals, jac, out;
+        int nsplit0, nsplit1, D, q, KO;
+        int64_t npad, mpad0, mpad1;
+    };
+    std::vector<Lay> lay(P);
+    size_t total = 0;
+    auto take = [&](size_t cnt) {
+        const size_t at = total;
+        total += al16(std::max<size_t>(cnt, 1));
+        return at;
+    };
+    const bool check = ctx->residual != 0;
+    const size_t out0 = take((size_t)8 * P);  // the per-problem result words, contiguous: one copy back for the whole batch
+    for (int i = 0; i < P; ++i) {
+        const mrbf_problem &pr = problems[idx[i]];
+        Lay &L = lay[i];
+        const int d = pr.d, k = pr.k;
+        L.q = poly_dim(d, pr.poly_deg);
+        L.npad = round_up(pr.n, 128);
+        L.D = d <= 64 ? 64 : 128;
+        L.KO = (k >= 2 && L.D == 64) ? 2 : 1;
+        const int q16 = (int)round_up(std::max(L.q, 1), 16);
+        L.C = is_device_ptr(pr.centres) ? (size_t)-1 : take((size_t)pr.n * d);
+        L.Y = is_device_ptr(pr.values) ? (size_t)-1 : take((size_t)pr.n * k);
+        L.X = (pr.m == 0 || is_device_ptr(pr.X)) ? (size_t)-1 : take((size_t)pr.m * d);
+        L.Xc = take((size_t)L.npad * L.D);
+        L.sq = take((size_t)L.npad);
+        L.mean = take((size_t)L.D);
+        L.W = (pr.weights_out && is_device_ptr(pr.weights_out)) ? (size_t)-1 : take((size_t)pr.n * k);  // device output: written in place
+        L.Wc = take((size_t)L.npad * k);
+        L.lam = (pr.poly_out && L.q > 0 && is_device_ptr(pr.poly_out)) ? (size_t)-1 : take((size_t)std::max(L.q, 1) * k);
+        L.ws = take(smallfit::carve((int)L.npad, q16).total);
+        // evaluation 0: the fit's residual at the sites; evaluation 1: the caller's queries
+        L.mpad0 = check ? round_up(pr.n, 64) : 0;
+        L.nsplit0 = check ? eval_nsplit(ctx, pr.n, L.npad) : 1;
+        L.Xq0 = take((size_t)L.mpad0 * L.D);
+        L.xsq0 = take((size_t)L.mpad0);
+        L.vp0 = take((size_t)L.nsplit0 * L.mpad0 * L.KO * 2);
+        L.gp0 = take((size_t)0);
+        L.V0 = take((size_t)pr.n * k);
+        L.mpad1 = round_up(pr.m, 64);
+        L.nsplit1 = pr.m > 0 ? eval_nsplit(ctx, pr.m, L.npad) : 1;
+        L.Xq1 = take((size_t)L.mpad1 * L.D);
+        L.xsq1 = take((size_t)L.mpad1);
+        L.vp1 = take((size_t)L.nsplit1 * L.mpad1 * L.KO * 2);
+        L.gp1 = take(pr.jac_out ? (size_t)L.nsplit1 * L.mpad1 * L.KO * L.D : 0);
+        L.vals = (pr.m == 0 || (pr.vals_out && is_device_ptr(pr.vals_out))) ? (size_t)-1 : take((size_t)pr.m * k);
+        L.jac = (pr.m == 0 || !pr.jac_out || is_device_ptr(pr.jac_out)) ? (size_t)-1 : take((size_t)pr.m * k * d);
+        L.out = out0 + (size_t)8 * i;
+    }
+    double *base;
+    int *flags;
+    MRBF_TRY(get_buf(ctx, S_SMALL_WS, total, &base));
+    MRBF_TRY(get_buf(ctx, S_SMALL_FLAGS, (size_t)4 * P, &flags));
+    // descriptors: [Prob x P | EvalDesc x 2P | CheckDesc x P] in one device buffer
+    const size_t desc_bytes = (size_t)P * (sizeof(smallfit::Prob) + 2 * sizeof(EvalDesc) + sizeof(CheckDesc)) + 256;
+    char *ddesc;
+    MRBF_TRY(get_buf(ctx, S_SMALL_DESC, desc_bytes, (void **)&ddesc));
+    std::vector<smallfit::Prob> probs(P);
+    std::vector<EvalDesc> evs((size_t)2 * P);
+    std::vector<CheckDesc> chk(P);
+    std::vector<mrbf_model> models(P);
+    hipStream_t st = ctx->stream;
+    auto dev_in = [&](const double *user, size_t off, size_t cnt, const double **out) -> int {
+        if (off == (size_t)-1) {
+            *out = user;
+            return 0;
+        }
+        MRBF_HIP(ctx, hipMemcpyAsync(base + off, user, cnt * sizeof(double), hipMemcpyHostToDevice, st));
+        *out = base + off;
+        return 0;
+    };
+    for (int i = 0; i < P; ++i) {
+        const mrbf_problem &pr = problems[idx[i]];
+        const Lay &L = lay[i];
+        const double *C, *Y, *X = nullptr;
+        MRBF_TRY(dev_in(pr.centres, L.C, (size_t)pr.n * pr.d, &C));
+        MRBF_TRY(dev_in(pr.values, L.Y, (size_t)pr.n * pr.k, &Y));
+        if (pr.m > 0) MRBF_TRY(dev_in(pr.X, L.X, (size_t)pr.m * pr.d, &X));
+        mrbf_model &M = models[i];
+        M.n = pr.n;
+        M.npad = L.npad;
+        M.d = pr.d;
+        M.dpad = L.D;
+        M.k = pr.k;
+        M.q = L.q;
+        M.deg = pr.poly_deg;
+        M.kp = make_kp(pr.kernel_id, pr.a, pr.b);
+        M.C = const_cast<double *>(C);
+        M.Xc = base + L.Xc;
+        M.sq = base + L.sq;
+        M.mean = base + L.mean;
+        M.W = L.W == (size_t)-1 ? pr.weights_out : base + L.W;
+        M.Wc = base + L.Wc;
+        M.lam = L.lam == (size_t)-1 ? pr.poly_out : base + L.lam;
+        fill_small_prob(&M, Y, base + L.ws, flags + 4 * i, base + L.out + 5, &probs[i]);
+        for (int e = 0; e < 2; ++e) {
+            EvalDesc &E = evs[(size_t)e * P + i];  // [residual evaluations of all problems | query evaluations of all problems]
+            const int64_t m = e == 0 ? (check ? pr.n : 0) : pr.m;
+            E.X = e == 0 ? C : X;
+            E.mean = M.mean;
+            E.Xq = base + (e == 0 ? L.Xq0 : L.Xq1);
+            E.xsq = base + (e == 0 ? L.xsq0 : L.xsq1);
+            E.Cc = M.Xc;
+            E.csq = M.sq;
+            E.Wc = M.Wc;
+            E.lam = M.lam;
+            E.npad = L.npad;
+            E.mpad = e == 0 ? L.mpad0 : L.mpad1;
+            E.m = m;
+            E.d = pr.d;
+            E.k = pr.k;
+            E.q = L.q;
+            E.nsplit = e == 0 ? L.nsplit0 : L.nsplit1;
+            const int ntiles = (int)(L.npad / 64);
+            E.tiles_per_split = (ntiles + E.nsplit - 1) / E.nsplit;
+            E.kp = M.kp;
+            E.vpart = base + (e == 0 ? L.vp0 : L.vp1);
+            E.sapart = E.vpart + (size_t)E.nsplit * E.mpad * L.KO;
+            E.gpart = base + (e == 0 ? L.gp0 : L.gp1);
+            E.vals = e == 0 ? base + L.V0 : (L.vals == (size_t)-1 ? pr.vals_out : base + L.vals);
+            E.jac = e == 0 ? nullptr : (pr.jac_out ? (L.jac == (size_t)-1 ? pr.jac_out : base + L.jac) : nullptr);
+        }
+        CheckDesc &K = chk[i];
+        K.V = base + L.V0;
+        K.Y = Y;
+        K.C = C;
+        K.Wc = M.Wc;
+        K.W = M.W;
+        K.vals = pr.m > 0 ? evs[(size_t)P + i].vals : nullptr;
+        K.n = check ? pr.n : 0;
+        K.npad = L.npad;
+        K.m = pr.m;
+        K.d = pr.d;
+        K.k = pr.k;
+        K.q = check ? L.q : 0;
+        K.out = base + L.out;
+    }
+    smallfit::Prob *dprobs = (smallfit::Prob *)ddesc;
+    EvalDesc *devs_ = (EvalDesc *)(ddesc + al16((size_t)P * sizeof(smallfit::Prob)));
+    CheckDesc *dchk = (CheckDesc *)((char *)devs_ + al16((size_t)2 * P * sizeof(EvalDesc)));
+    MRBF_HIP(ctx, hipMemcpyAsync(dprobs, probs.data(), (size_t)P * sizeof(smallfit::Prob), hipMemcpyHostToDevice, st));
+    MRBF_HIP(ctx, hipMemcpyAsync(devs_, evs.data(), (size_t)2 * P * sizeof(EvalDesc), hipMemcpyHostToDevice, st));
+    MRBF_HIP(ctx, hipMemcpyAsync(dchk, chk.data(), (size_t)P * sizeof(CheckDesc), hipMemcpyHostToDevice, st));
+    MRBF_HIP(ctx, hipEventRecord(ctx->ev[0], st));
+    MRBF_TRY(launch_small_fit(ctx, probs.data(), P, dprobs));
+    MRBF_HIP(ctx, hipEventRecord(ctx->ev[1], st));
+    // evaluation launches per group of equal (kernel, fast flag, padded dimension, outputs, Jacobians wanted): usually one group
+    {
+        std::vector<char> done((size_t)2 * P, 0);
+        for (size_t a = 0; a < evs.size(); ++a) {
+            if (done[a]) continue;
+            const mrbf_problem &pa = problems[idx[a % P]];
+            const KP kpa = evs[a].kp;
+            const bool ja = evs[a].jac != nullptr;
+            std::vector<EvalDesc> grp;
+            std::vector<size_t> members;
+            for (size_t b = a; b < evs.size(); ++b) {
+                const mrbf_problem &pb = problems[idx[b % P]];
+                if (!done[b] && evs[b].kp.kid == kpa.kid && evs[b].kp.fast == kpa.fast && lay[b % P].D == lay[a % P].D && pb.k == pa.k &&
+                    (evs[b].jac != nullptr) == ja) {
+                    done[b] = 1;
+                    if (evs[b].m > 0) members.push_back(b);
+                }
+            }
+            if (members.empty()) continue;
+            // contiguous runs of the device array are launched as they lie; scattered members are compacted into a second array
+            bool contiguous = true;
+            for (size_t j = 1; j < members.size(); ++j) contiguous = contiguous && members[j] == members[j - 1] + 1;
+            const EvalDesc *dev = devs_ + members[0];
+            const EvalDesc *host = &evs[members[0]];
+            if (!contiguous) {
+                for (size_t b : members) grp.push_back(evs[b]);
+                EvalDesc *dgrp;
+                MRBF_TRY(get_buf(ctx, S_STAGE_D, grp.size() * sizeof(EvalDesc) / sizeof(double) + 16, (double **)&dgrp));
+                MRBF_HIP(ctx, hipMemcpyAsync(dgrp, grp.data(), grp.size() * sizeof(EvalDesc), hipMemcpyHostToDevice, st));
+                MRBF_HIP(ctx, hipStreamSynchronize(st));  // grp is reused by the next group
+                dev = dgrp;
+                host = grp.data();
+            }
+            MRBF_TRY(eval_fused_batch(ctx, kpa, lay[a % P].D, pa.k, ja, host, dev, (int)members.size()));
+            if (!contiguous) MRBF_HIP(ctx, hipStreamSynchronize(st));
+        }
+    }
+    hipLaunchKernelGGL(batch_check_kernel, dim3((unsigned)P), dim3(256), 0, st, dchk);
+    MRBF_HIP(ctx, hipGetLastError());
+    MRBF_HIP(ctx, hipEventRecord(ctx->ev[2], st));
+    // results
+    std::vector<int> hflags((size_t)4 * P);
+    std::vector<double> hout((size_t)8 * P);
+    MRBF_HIP(ctx, hipMemcpyAsync(hflags.data(), flags, hflags.size() * sizeof(int), hipMemcpyDeviceToHost, st));
+    MRBF_HIP(ctx, hipMemcpyAsync(hout.data(), base + out0, hout.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    for (int i = 0; i < P; ++i) {
+        const mrbf_problem &pr = problems[idx[i]];
+        const Lay &L = lay[i];
+        if (pr.weights_out && L.W != (size_t)-1)
+            MRBF_HIP(ctx, hipMemcpyAsync(pr.weights_out, base + L.W, (size_t)pr.n * pr.k * sizeof(double), hipMemcpyDeviceToHost, st));
+        if (pr.poly_out && L.q > 0 && L.lam != (size_t)-1)
+            MRBF_HIP(ctx, hipMemcpyAsync(pr.poly_out, base + L.lam, (size_t)L.q * pr.k * sizeof(double), hipMemcpyDeviceToHost, st));
+        if (pr.m > 0 && pr.vals_out && L.vals != (size_t)-1)
+            MRBF_HIP(ctx, hipMemcpyAsync(pr.vals_out, base + L.vals, (size_t)pr.m * pr.k * sizeof(double), hipMemcpyDeviceToHost, st));
+        if (pr.m > 0 && pr.jac_out && L.jac != (size_t)-1)
+            MRBF_HIP(ctx, hipMemcpyAsync(pr.jac_out, base + L.jac, (size_t)pr.m * pr.k * pr.d * sizeof(double), hipMemcpyDeviceToHost, st));
+    }
+    MRBF_HIP(ctx, hipStreamSynchronize(st));
+    float ms_fit = 0.f, ms_eval = 0.f;
+    MRBF_HIP(ctx, hipEventElapsedTime(&ms_fit, ctx->ev[0], ctx->ev[1]));
+    MRBF_HIP(ctx, hipEventElapsedTime(&ms_eval, ctx->ev[1], ctx->ev[2]));
+    for (int i = 0; i < P; ++i) {
+        const mrbf_problem &pr = problems[idx[i]];
+        mrbf_result &res = results[idx[i]];
+        std::memset(&res, 0, sizeof(res));
+        res.device = ctx->device;
+        res.fit.n = (int32_t)pr.n;
+        res.fit.q = lay[i].q;
+        res.fit.rel_residual = NAN;
+        res.fit.max_pitw = NAN;
+        const double *o = &hout[(size_t)8 * i];
+        if (small_fit_verdict(&models[i], &hflags[(size_t)4 * i], o + 5, &res.fit)) {
+            redo->push_back(idx[i]);  // not positive definite / rank-deficient tail: the per-problem chain takes the LU path
+            continue;
+        }
+        if (check) {
+            res.fit.rel_residual = std::sqrt(o[0]) / std::max(std::sqrt(o[1]), 1e-300);
+            res.fit.max_pitw = lay[i].q > 0 ? o[2] : 0.0;
+        }
+        // one launch fits the whole batch and a few more evaluate it: the times are those of the batch, shared by its members
+        res.fit.ms_factor = ms_fit;
+        res.fit.ms_total = ms_fit;
+        res.ms_eval = ms_eval;
+        res.checksum_w = o[3];
+        res.checksum_vals = o[4];
+    }
+    return 0;
+}
+
+}  // namespace mrbf
+
+using namespace mrbf;
+
+extern "C" int32_t mrbf_batch_run(int32_t n_dev, const int32_t *device_ids, int64_t n_problems, const mrbf_problem *problems,
+                                  mrbf_result *results) {
+    if (n_dev < 1) return -1;
+    if (n_problems < 0) return -3;
+    if (n_problems > 0 && (!problems || !results)) return -4;
+    int visible = 0;
+    if (hipGetDeviceCount(&visible) != hipSuccess || visible <= 0) return MRBF_ENODEVICE;
+    std::vector<int> devs(n_dev);
+    for (int g = 0; g < n_dev; ++g) {
+        devs[g] = device_ids ? device_ids[g] : g;
+        if (devs[g] < 0 || devs[g] >= visible) return -2;
+    }
+    // which problems the batched small-problem path takes (decided as fit_model decides the path of a single call)
+    std::vector<std::vector<int64_t>> small(n_dev);
+    std::vector<int64_t> chain;
+    std::vector<int> rcs(n_dev, 0);
+    std::vector<std::vector<int64_t>> redo(n_dev);
+    auto worker = [&](int g) {
+        if (small[g].empty()) return;
+        int rc = 0;
+        mrbf_ctx *ctx = batch_pool_acquire(devs[g], &rc);
+        if (rc != 0) {
+            rcs[g] = rc;
+            for (int64_t p : small[g]) {
+                std::memset(&results[p], 0, sizeof(mrbf_result));
+                results[p].status = rc;
+                results[p].device = devs[g];
+            }
+            return;
+        }
+        rcs[g] = run_small_batch(ctx, small[g], problems, results, &redo[g]);
+        if (rcs[g] != 0)
+            for (int64_t p : small[g]) {
+                std::memset(&results[p], 0, sizeof(mrbf_result));
+                results[p].status = rcs[g];
+                results[p].device = devs[g];
+            }
+        batch_pool_release(ctx);
+    };
+    {
+        // (the context only supplies the options small_fit_applies looks at; a pooled context of the first device)
+        int rc = 0;
+        mrbf_ctx *probe = batch_pool_acquire(devs[0], &rc);
+        if (rc != 0) return rc;
+        for (int64_t p = 0; p < n_problems; ++p) {
+            const mrbf_problem &pr = problems[p];
+            const int q = poly_dim(pr.d, pr.poly_deg);
+            int path = MRBF_PATH_LU;
+            if (pr.kernel_id >= 0 && pr.kernel_id <= 4 && pr.n > q && pr.poly_deg >= -1 && pr.poly_deg <= 1 &&
+                cpd_order(pr.kernel_id, pr.a, pr.b) <= pr.poly_deg + 1)
+                path = q > 0 ? MRBF_PATH_PROJ_CHOL : MRBF_PATH_CHOL;
+            const bool ok = pr.centres && pr.values && (pr.m == 0 || pr.X) && pr.m >= 0 && probe->force_path == 0 && probe->eval_impl != 1 &&
+                            small_fit_applies(probe, pr.n, pr.d, pr.k, q, path);
+            if (ok)
+                small[p % n_dev].push_back(p);
+            else
+                chain.push_back(p);
+        }
+        batch_pool_release(probe);
+    }
+    std::vector<std::thread> th;
+    for (int g = 0; g < n_dev; ++g) th.emplace_back(worker, g);
+    for (auto &t : th) t.join();
+    for (int g = 0; g < n_dev; ++g) {
+        if (rcs[g] != 0) return rcs[g];
+        chain.insert(chain.end(), redo[g].begin(), redo[g].end());
+    }
+    return batch_run_chain(n_dev, devs.data(), chain, problems, results);
+}

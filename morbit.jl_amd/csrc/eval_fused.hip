@@ -11,6 +11,7 @@
 // The centre range is split over gridDim.y so that small query batches still fill the chip; a combine kernel sums the
 // splits in a fixed order, adds the polynomial tail and writes  J_l = (sum_c a_lc) xc - G_l + grad p_l.
 #include "radial.hpp"
+#include "small.hpp"
 
 namespace mrbf {
 
@@ -24,8 +25,24 @@ template <int KID, bool FAST, int KOUT, int DT, bool JAC>
 __global__ __launch_bounds__(256, (DT <= 4) ? 2 : 1) void eval_fused_kernel(
     const double *__restrict__ Xq, const double *__restrict__ xsq, const double *__restrict__ Cc, const double *__restrict__ csq,
     const double *__restrict__ Wc, int64_t npad, int l0, KP kp, int64_t mpad, int tiles_per_split, double *__restrict__ vpart,
-    double *__restrict__ sapart, double *__restrict__ gpart) {
+    double *__restrict__ sapart, double *__restrict__ gpart, const EvalDesc *__restrict__ many) {
     constexpr int D = DT * 16, LDC = D + 2;
+    if (many) {  // batched launch: blockIdx.z = problem; the grid is sized for the largest problem of the batch
+        const EvalDesc &E = many[blockIdx.z];
+        if ((int64_t)blockIdx.x * EQ >= E.mpad || (int)blockIdx.y >= E.nsplit) return;
+        Xq = E.Xq;
+        xsq = E.xsq;
+        Cc = E.Cc;
+        csq = E.csq;
+        Wc = E.Wc;
+        npad = E.npad;
+        kp = E.kp;
+        mpad = E.mpad;
+        tiles_per_split = E.tiles_per_split;
+        vpart = E.vpart;
+        sapart = E.sapart;
+        gpart = E.gpart;
+    }
     __shared__ __attribute__((aligned(16))) double Cs[EC * LDC];
     __shared__ double Ws[KOUT * EC];
     __shared__ double Sq[EC];
@@ -163,7 +180,24 @@ __global__ __launch_bounds__(128) void eval_combine_kernel(const double *__restr
                                                            const double *__restrict__ gpart, int nsplit, int64_t mpad, int64_t m, int D, int d,
                                                            int k, int l0, const double *__restrict__ Xq, const double *__restrict__ Xorig,
                                                            const double *__restrict__ lam, int q, double *__restrict__ vals,
-                                                           double *__restrict__ jac) {
+                                                           double *__restrict__ jac, const EvalDesc *__restrict__ many) {
+    if (many) {  // batched launch: blockIdx.y = problem
+        const EvalDesc &E = many[blockIdx.y];
+        vpart = E.vpart;
+        sapart = E.sapart;
+        gpart = E.gpart;
+        nsplit = E.nsplit;
+        mpad = E.mpad;
+        m = E.m;
+        d = E.d;
+        k = E.k;
+        Xq = E.Xq;
+        Xorig = E.X;
+        lam = E.lam;
+        q = E.q;
+        vals = E.vals;
+        jac = E.jac;
+    }
     const int64_t p = blockIdx.x;
     if (p >= m) return;
     __shared__ double sa[KOUT], sv[KOUT];
@@ -217,10 +251,10 @@ static int launch_fused2(mrbf_ctx *ctx, bool want_jac, dim3 grid, const double *
                         int64_t mpad, int tps, double *vpart, double *sapart, double *gpart) {
     if (want_jac)
         hipLaunchKernelGGL((eval_fused_kernel<KID, FAST, KOUT, DT, true>), grid, dim3(256), 0, ctx->stream, Xq, xsq, M->Xc, M->sq, M->Wc, M->npad,
-                           l0, M->kp, mpad, tps, vpart, sapart, gpart);
+                           l0, M->kp, mpad, tps, vpart, sapart, gpart, (const EvalDesc *)nullptr);
     else
         hipLaunchKernelGGL((eval_fused_kernel<KID, FAST, KOUT, DT, false>), grid, dim3(256), 0, ctx->stream, Xq, xsq, M->Xc, M->sq, M->Wc, M->npad,
-                           l0, M->kp, mpad, tps, vpart, sapart, gpart);
+                           l0, M->kp, mpad, tps, vpart, sapart, gpart, (const EvalDesc *)nullptr);
     return 0;
 }
 
@@ -232,18 +266,18 @@ static int launch_fused(mrbf_ctx *ctx, bool want_jac, dim3 grid, const double *X
     return launch_fused2<KID, false, KOUT, DT>(ctx, want_jac, grid, Xq, xsq, M, l0, mpad, tps, vpart, sapart, gpart);
 }
 
-int eval_fused(mrbf_ctx *ctx, const mrbf_model *M, int64_t m, const double *X, double *vals, double *jac, mrbf_eval_info *info) {
-    const int d = M->d, k = M->k, q = M->q;
-    const int D = (M->dpad <= 64) ? 64 : 128;
-    if (M->dpad > 128) return fail(ctx, MRBF_EHIP, "eval_fused supports d <= 128");
-    if (D != M->dpad) return fail(ctx, MRBF_EHIP, "eval_fused needs dpad in {64, 128} (got %d)", M->dpad);
+int eval_nsplit(const mrbf_ctx *ctx, int64_t m, int64_t npad) {
     const int64_t mpad = round_up(m, EQ);
-    const int ntiles = (int)(M->npad / EC);
+    const int ntiles = (int)(npad / EC);
     // Split the centre range so that the grid fills the resident workgroup slots (2 per CU) in whole rounds: the cost of a
     // split count is (rounds of workgroups) x (tiles per workgroup) plus the combine pass, which reads one partial per split.
     // (C3: 157 query tiles -> 3 splits of 43 tiles = 471 workgroups in one round, instead of 4 x 32 tiles in two rounds.)
     const int slots = 2 * ctx->ncu;
     const int64_t qtiles = mpad / EQ;
+    // few centre tiles (n <= 512): never split -- a workgroup's prologue and epilogue (query fragments in, 64 x D partial Jacobian
+    // tile out, per split) cost more than the handful of tiles it would shed, the partials triple the traffic of the combine pass,
+    // and such models are evaluated in batches that fill the chip anyway (mrbf_batch_run, the PS solver's generations)
+    if (ntiles <= 8) return 1;
     int nsplit = 1;
     double best_cost = 1e300;
     for (int s = 1; s <= std::min(ntiles, 32); ++s) {
@@ -259,6 +293,84 @@ int eval_fused(mrbf_ctx *ctx, const mrbf_model *M, int64_t m, const double *X, d
     static const int force_split = getenv("MRBF_EVAL_NSPLIT") ? atoi(getenv("MRBF_EVAL_NSPLIT")) : 0;
     if (force_split > 0 && force_split <= ntiles && (int64_t)(force_split - 1) * ((ntiles + force_split - 1) / force_split) < ntiles)
         nsplit = force_split;
+    return nsplit;
+}
+
+// ---- batched evaluation: the same kernels, blockIdx.z / .y = problem --------------------------------------------------------
+// queries: Xq[row][t] = X[row][t] - mean[t] (zero in the padding), xsq[row] = |Xq[row]|^2 -- center_pad_kernel's arithmetic (prep.hip)
+__global__ void center_pad_batch_kernel(const EvalDesc *__restrict__ many, int D) {
+    const EvalDesc &E = many[blockIdx.y];
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= E.mpad) return;
+    double s = 0.0;
+    for (int t = lane; t < D; t += 64) {
+        double v = 0.0;
+        if (row < E.m && t < E.d) v = E.X[row * E.d + t] - E.mean[t];
+        E.Xq[row * D + t] = v;
+        s = fma(v, v, s);
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) E.xsq[row] = s;
+}
+
+template <int KID, bool FAST, int KOUT, int DT>
+static void launch_fused_batch2(mrbf_ctx *ctx, bool want_jac, dim3 grid, int l0, const KP &kp, const EvalDesc *dev) {
+    if (want_jac)
+        hipLaunchKernelGGL((eval_fused_kernel<KID, FAST, KOUT, DT, true>), grid, dim3(256), 0, ctx->stream, nullptr, nullptr, nullptr, nullptr, nullptr,
+                           (int64_t)0, l0, kp, (int64_t)0, 0, nullptr, nullptr, nullptr, dev);
+    else
+        hipLaunchKernelGGL((eval_fused_kernel<KID, FAST, KOUT, DT, false>), grid, dim3(256), 0, ctx->stream, nullptr, nullptr, nullptr, nullptr, nullptr,
+                           (int64_t)0, l0, kp, (int64_t)0, 0, nullptr, nullptr, nullptr, dev);
+}
+template <int KID, int KOUT, int DT>
+static void launch_fused_batch(mrbf_ctx *ctx, bool want_jac, dim3 grid, int l0, const KP &kp, const EvalDesc *dev) {
+    if (kp.fast && (KID == MRBF_MULTIQUADRIC || KID == MRBF_INV_MULTIQUADRIC || KID == MRBF_CUBIC))
+        launch_fused_batch2<KID, true, KOUT, DT>(ctx, want_jac, grid, l0, kp, dev);
+    else
+        launch_fused_batch2<KID, false, KOUT, DT>(ctx, want_jac, grid, l0, kp, dev);
+}
+
+int eval_fused_batch(mrbf_ctx *ctx, const KP &kp, int D, int k, bool want_jac, const EvalDesc *host_descs, const EvalDesc *dev_descs, int count) {
+    if (count <= 0) return 0;
+    if (D != 64 && D != 128) return fail(ctx, MRBF_EHIP, "eval_fused_batch needs dpad in {64, 128}");
+    int64_t max_mpad = 0, max_m = 0;
+    int max_split = 1;
+    for (int p = 0; p < count; ++p) {
+        max_mpad = std::max(max_mpad, host_descs[p].mpad);
+        max_m = std::max(max_m, host_descs[p].m);
+        max_split = std::max(max_split, host_descs[p].nsplit);
+    }
+    hipLaunchKernelGGL(center_pad_batch_kernel, dim3((unsigned)((max_mpad + 3) / 4), (unsigned)count), dim3(256), 0, ctx->stream, dev_descs, D);
+    const int KO = (k >= 2 && D == 64) ? 2 : 1;  // as eval_fused
+    dim3 grid((unsigned)(max_mpad / EQ), (unsigned)max_split, (unsigned)count);
+    dim3 cgrid((unsigned)max_m, (unsigned)count);
+    for (int l0 = 0; l0 < k; l0 += KO) {
+        const int ko = std::min(KO, k - l0);
+#define MRBF_EFB(KOV, DTV) MRBF_DISPATCH_KID(kp.kid, (launch_fused_batch<KID, KOV, DTV>(ctx, want_jac, grid, l0, kp, dev_descs)))
+        if (ko == 2) {
+            MRBF_EFB(2, 4);
+            hipLaunchKernelGGL(eval_combine_kernel<2>, cgrid, dim3(128), 0, ctx->stream, nullptr, nullptr, nullptr, 0, (int64_t)0, (int64_t)0, D, 0, 0, l0,
+                               nullptr, nullptr, nullptr, 0, nullptr, nullptr, dev_descs);
+        } else {
+            if (D == 64) { MRBF_EFB(1, 4); } else { MRBF_EFB(1, 8); }
+            hipLaunchKernelGGL(eval_combine_kernel<1>, cgrid, dim3(128), 0, ctx->stream, nullptr, nullptr, nullptr, 0, (int64_t)0, (int64_t)0, D, 0, 0, l0,
+                               nullptr, nullptr, nullptr, 0, nullptr, nullptr, dev_descs);
+        }
+#undef MRBF_EFB
+    }
+    MRBF_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+int eval_fused(mrbf_ctx *ctx, const mrbf_model *M, int64_t m, const double *X, double *vals, double *jac, mrbf_eval_info *info) {
+    const int d = M->d, k = M->k, q = M->q;
+    const int D = (M->dpad <= 64) ? 64 : 128;
+    if (M->dpad > 128) return fail(ctx, MRBF_EHIP, "eval_fused supports d <= 128");
+    if (D != M->dpad) return fail(ctx, MRBF_EHIP, "eval_fused needs dpad in {64, 128} (got %d)", M->dpad);
+    const int64_t mpad = round_up(m, EQ);
+    const int ntiles = (int)(M->npad / EC);
+    const int nsplit = eval_nsplit(ctx, m, M->npad);
     const int tps = (ntiles + nsplit - 1) / nsplit;
     double *Xq, *xsq, *vpart, *sapart, *gpart = nullptr;
     MRBF_TRY(get_buf(ctx, S_EVAL_XC, (size_t)mpad * D, &Xq));
@@ -278,11 +390,11 @@ int eval_fused(mrbf_ctx *ctx, const mrbf_model *M, int64_t m, const double *X, d
         if (ko == 2) {
             MRBF_EF(2, 4);
             hipLaunchKernelGGL(eval_combine_kernel<2>, dim3((unsigned)m), dim3(128), 0, ctx->stream, vpart, sapart, gpart, nsplit, mpad, m, D,
-                               d, k, l0, Xq, X, M->lam, q, vals, jac);
+                               d, k, l0, Xq, X, M->lam, q, vals, jac, (const EvalDesc *)nullptr);
         } else {
             if (D == 64) { MRBF_EF(1, 4); } else { MRBF_EF(1, 8); }
             hipLaunchKernelGGL(eval_combine_kernel<1>, dim3((unsigned)m), dim3(128), 0, ctx->stream, vpart, sapart, gpart, nsplit, mpad, m, D,
-                               d, k, l0, Xq, X, M->lam, q, vals, jac);
+                               d, k, l0, Xq, X, M->lam, q, vals, jac, (const EvalDesc *)nullptr);
         }
 #undef MRBF_EF
     }

@@ -1,0 +1,379 @@
+// Small problems (n <= 512 sites, d <= 128): the whole fit -- centring, Gram matrix, polynomial-tail basis, projection, Cholesky
+// factorisation, the two triangular solves, tail coefficients -- in ONE launch, one workgroup per problem.
+//
+// This is the regime Morbit actually runs in (n <= (d+1)(d+2)/2 sites per model, /root/reference/src/models/RbfModel.jl:356) and the
+// one its benchmark driver parallelises over (Threads.@threads over independent problems,
+// /root/reference/examples/large_scale_benchmarks.jl:253; n = 2d + 1 sites per start, :157).  The per-problem launch chain of
+// solve.hip (~60 launches, memsets and copies) is pure launch latency at these sizes: 0.87 ms for 5.7 MFLOP of factorisation at
+// n = 257.  Here a batch of problems is one grid; a single mrbf_fit of such a size is a grid of one workgroup, so a batch and single
+// calls run the same code on the same data and agree bit for bit.
+//
+// The arithmetic is that of solve.hip's Cholesky paths (mrbf_fit_info.path 1 and 2): K = P Phi P + mu Q1 Q1' on the lower triangle of
+// Phi, Q1 from the Cholesky-QR of the centred coordinates, 128 x 128 diagonal blocks factored by the register-resident MFMA core of
+// chol_diag_core.hpp, everything else by one generic workgroup GEMM on the fp64 matrix cores with its operands read from global
+// memory (the working set of a problem, ~4 MB, lives in L2 / Infinity Cache).  A problem whose factorisation meets a non-positive
+// pivot, a rank-deficient tail basis or a non-positive shift sets a flag and the caller takes the ordinary path (LU) for it.
+#include "chol_diag_core.hpp"
+#include "radial.hpp"
+#include "small.hpp"
+
+namespace mrbf {
+namespace smallfit {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double phi_rt(double s, const KP &p) {
+    switch (p.kid) {
+        case MRBF_CUBIC: return p.fast ? rbf_phi_t<MRBF_CUBIC, true>(s, p) : rbf_phi_t<MRBF_CUBIC, false>(s, p);
+        case MRBF_INV_MULTIQUADRIC: return p.fast ? rbf_phi_t<MRBF_INV_MULTIQUADRIC, true>(s, p) : rbf_phi_t<MRBF_INV_MULTIQUADRIC, false>(s, p);
+        case MRBF_MULTIQUADRIC: return p.fast ? rbf_phi_t<MRBF_MULTIQUADRIC, true>(s, p) : rbf_phi_t<MRBF_MULTIQUADRIC, false>(s, p);
+        case MRBF_THIN_PLATE_SPLINE: return rbf_phi_t<MRBF_THIN_PLATE_SPLINE, false>(s, p);
+        default: return rbf_phi_t<MRBF_GAUSSIAN, false>(s, p);
+    }
+}
+
+// C(i, j) (op)= sum_k A'(i, k) B'(k, j) for one workgroup of 4 waves; A' = TA ? A^T : A, B' = TB ? B^T : B (A, B column-major with
+// leading dimensions lda, ldb); M, N multiples of 16, K a multiple of 4.  Every wave takes 32 x 32 macro tiles (2 x 2 MFMA tiles)
+// round-robin and hands each finished element to epi(i, j, value).  LOWER: only 16 x 16 tiles on or below the diagonal.
+// f64 MFMA lane maps (tests/test_gpu_parity.py::test_f64_mfma_lane_maps): A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15],
+// D[row = (l >> 4) + 4 r][col = l & 15].
+template <bool TA, bool TB, bool LOWER, class Epi>
+__device__ __forceinline__ void wg_gemm(int M, int N, int K, const double *__restrict__ A, int lda, const double *__restrict__ B, int ldb, Epi epi) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int mt = M >> 4, nt = N >> 4, MT = (mt + 1) >> 1, NT2 = (nt + 1) >> 1;
+    for (int idx = wave; idx < MT * NT2; idx += 4) {
+        const int I = idx % MT, J = idx / MT;
+        if (LOWER && 2 * I + 1 < 2 * J) continue;
+        const int i0 = 32 * I, j0 = 32 * J;
+        const bool va1 = 2 * I + 1 < mt, vb1 = 2 * J + 1 < nt;
+        v4d acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+        const double *pa = TA ? A + l4 + (int64_t)(i0 + l15) * lda : A + (i0 + l15) + (int64_t)l4 * lda;
+        const double *pb = TB ? B + (j0 + l15) + (int64_t)l4 * ldb : B + l4 + (int64_t)(j0 + l15) * ldb;
+        const int64_t sa = TA ? 4 : 4 * (int64_t)lda, sb = TB ? 4 * (int64_t)ldb : 4;
+        const int64_t oa = TA ? 16 * (int64_t)lda : 16, ob = TB ? 16 : 16 * (int64_t)ldb;
+        // the operands come straight from global memory (L2 / Infinity Cache): UK k-steps of loads are issued as one burst and the
+        // next burst is in flight under this burst's MFMAs, otherwise every k-step would pay a full memory round trip
+        constexpr int UK = 4;
+        double fa0[2][UK], fa1[2][UK], fb0[2][UK], fb1[2][UK];
+        auto burst = [&](int buf, int k) {
+#pragma unroll
+            for (int u = 0; u < UK; ++u) {
+                const bool in = k + 4 * u < K;
+                fa0[buf][u] = in ? pa[u * sa] : 0.0;
+                fa1[buf][u] = (in && va1) ? pa[u * sa + oa] : 0.0;
+                fb0[buf][u] = in ? pb[u * sb] : 0.0;
+                fb1[buf][u] = (in && vb1) ? pb[u * sb + ob] : 0.0;
+            }
+            pa += UK * sa;
+            pb += UK * sb;
+        };
+        burst(0, 0);
+        for (int k = 0; k < K; k += 8 * UK) {
+            if (k + 4 * UK < K) burst(1, k + 4 * UK);
+#pragma unroll
+            for (int u = 0; u < UK; ++u) {
+                acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa0[0][u], fb0[0][u], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa0[0][u], fb1[0][u], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa1[0][u], fb0[0][u], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa1[0][u], fb1[0][u], acc[1][1], 0, 0, 0);
+            }
+            if (k + 4 * UK >= K) break;
+            if (k + 8 * UK < K) burst(0, k + 8 * UK);
+#pragma unroll
+            for (int u = 0; u < UK; ++u) {
+                acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa0[1][u], fb0[1][u], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa0[1][u], fb1[1][u], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa1[1][u], fb0[1][u], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa1[1][u], fb1[1][u], acc[1][1], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                if ((a == 1 && !va1) || (b == 1 && !vb1)) continue;
+                if (LOWER && 2 * I + a < 2 * J + b) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) epi(i0 + 16 * a + l4 + 4 * r, j0 + 16 * b + l15, acc[a][b][r]);
+            }
+    }
+}
+
+__device__ __forceinline__ double wg_sum(double v, double *red /* 4 doubles of LDS */) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// the 128 x 128 diagonal-block core as ONE out-of-line function: inlined at both call sites it pushed the whole kernel into scratch
+__device__ __noinline__ int diag_block(double *__restrict__ A, int ld, double *__restrict__ Linv, diagcore::DiagV4Shared &sh) {
+    diagcore::v4d acc[diagcore::NSLOT];
+    return diagcore::diag_v4_core<false, false, false>(A, (int64_t)ld, Linv, sh, acc, nullptr, nullptr, 0);
+}
+
+// blocked Cholesky of the np x np matrix at A (lower, column-major, ld; np a multiple of 128) with the 128 x 128 MFMA core for the
+// diagonal blocks; rows beyond `rows16` are known to be zero below the diagonal blocks (identity padding) and skipped in the panel
+// and trailing products.  Linv: np x 128, block c at Linv + c * 128 * 128 holds inv(L_cc).  Returns 0 or 1-based index of a bad pivot.
+__device__ int wg_potrf(double *__restrict__ A, int ld, int np, int rows16, double *__restrict__ Linv, double *__restrict__ Pt,
+                        diagcore::DiagV4Shared &sh, int *s_bad) {
+    const int nb = np / 128;
+    for (int c = 0; c < nb; ++c) {
+        double *Acc = A + (int64_t)c * 128 * (ld + 1);
+        double *Lc = Linv + (int64_t)c * 128 * 128;
+        {
+            const int bad = diag_block(Acc, ld, Lc, sh);
+            __syncthreads();
+            if (threadIdx.x == 0) *s_bad = bad ? 128 * c + bad : 0;
+            __syncthreads();
+            if (*s_bad) return *s_bad;
+        }
+        const int r0 = 128 * (c + 1);
+        const int mrows = rows16 - r0;  // real rows below this block
+        if (mrows <= 0) continue;
+        // panel: L(r, c) = A(r, c) inv(L_cc)'  -> Pt (mrows x 128), then back into A
+        const double *Arc = A + r0 + (int64_t)c * 128 * ld;
+        wg_gemm<false, true, false>(mrows, 128, 128, Arc, ld, Lc, 128, [&](int i, int j, double v) { Pt[i + (int64_t)j * np] = v; });
+        __syncthreads();
+        for (int e = threadIdx.x; e < mrows * 128; e += 256) {
+            const int i = e % mrows, j = e / mrows;
+            A[(r0 + i) + (int64_t)(c * 128 + j) * ld] = Pt[i + (int64_t)j * np];
+        }
+        // trailing update: A(r, s) -= L(r, c) L(s, c)'  for r >= s > c (lower tiles)
+        double *Att = A + (int64_t)r0 * (ld + 1);
+        wg_gemm<false, true, true>(mrows, mrows, 128, Pt, np, Pt, np, [&](int i, int j, double v) { Att[i + (int64_t)j * ld] -= v; });
+        __syncthreads();
+    }
+    return 0;
+}
+
+__global__ __launch_bounds__(256, 1) void small_fit_kernel(Prob one, const Prob *__restrict__ many) {
+    __shared__ __attribute__((aligned(16))) diagcore::DiagV4Shared sh;
+    __shared__ double red[4];
+    __shared__ double s_mean[128];
+    __shared__ int s_bad;
+    const Prob P = many ? many[blockIdx.x] : one;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = P.n, d = P.d, k = P.k, q = P.q, n16 = P.n16, np = P.npad, dpad = P.dpad, q16 = P.q16;
+    const Carve cv = carve(np, q16);
+    double *ws = P.ws;
+    double *Phi = ws + cv.Phi, *Q1 = ws + cv.Q1, *Wm = ws + cv.Wm, *V = ws + cv.V, *G = ws + cv.G, *Gx = ws + cv.Gx, *LinvX = ws + cv.LinvX,
+           *Linv = ws + cv.Linv, *Pt = ws + cv.Pt, *Yc = ws + cv.Ycol, *Bm = ws + cv.B, *Fy = ws + cv.Fy, *Xs = ws + cv.Xs, *T1 = ws + cv.T1,
+           *T2 = ws + cv.T2, *Z = ws + cv.Z;
+    const int ldz = cv.ldz;
+    if (tid < 4) P.flags[tid] = 0;
+
+    // ---- centroid, centred + zero-padded coordinates, squared norms (the model's own arrays: the evaluation uses them later)
+    if (tid < 128) {
+        double s = 0.0;
+        if (tid < d)
+            for (int i = 0; i < n; ++i) s += P.C[(int64_t)i * d + tid];
+        s_mean[tid] = tid < d ? s / (double)n : 0.0;
+    }
+    __syncthreads();
+    for (int t = tid; t < dpad; t += 256) P.mean[t] = t < 128 ? s_mean[t] : 0.0;
+    for (int row = wave; row < np; row += 4) {
+        double s = 0.0;
+        for (int t = lane; t < dpad; t += 64) {
+            double v = 0.0;
+            if (row < n && t < d) v = P.C[(int64_t)row * d + t] - s_mean[t];
+            P.Xc[(int64_t)row * dpad + t] = v;
+            s = fma(v, v, s);
+        }
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        if (lane == 0) P.sq[row] = s;
+    }
+    // right-hand sides, column-major and zero padded: Yc (np x 16)
+    for (int e = tid; e < np * 16; e += 256) {
+        const int i = e % np, l = e / np;
+        Yc[e] = (i < n && l < k) ? P.Y[(int64_t)i * k + l] : 0.0;
+    }
+    __syncthreads();
+
+    // ---- Phi = phi(|x_i - x_j|): GEMM form on the centred coordinates, radial function in the epilogue; rows / columns >= n: identity
+    {
+        const double *XcT = P.Xc;  // dpad x np column-major
+        const KP kp = P.kp;
+        const double *sq = P.sq;
+        wg_gemm<true, false, false>(n16, n16, dpad, XcT, dpad, XcT, dpad, [&](int i, int j, double sdot) {
+            double v;
+            if (i < n && j < n) {
+                double s = fma(-2.0, sdot, sq[i] + sq[j]);
+                s = s > 0.0 ? s : 0.0;
+                if (i == j) s = 0.0;
+                v = phi_rt(s, kp);
+            } else {
+                v = (i == j) ? 1.0 : 0.0;
+            }
+            Phi[(int64_t)i * np + j] = v;
+        });
+        // identity in the padding beyond n16 (rows / columns n16 .. np - 1 of the lower triangle are all the factorisation reads there)
+        for (int e = tid; e < (np - n16) * np; e += 256) {
+            const int c = n16 + e / np, r = e % np;
+            Phi[r + (int64_t)c * np] = (r == c) ? 1.0 : 0.0;
+            Phi[c + (int64_t)r * np] = (r == c) ? 1.0 : 0.0;
+        }
+    }
+    __syncthreads();
+
+    const double rsn = 1.0 / sqrt((double)n);
+    if (q > 0) {
+        // ---- Q1 = [1/sqrt(n) | Xc Lx^-T]: orthonormal basis of the polynomial tail from the Cholesky-QR of the centred coordinates
+        for (int e = tid; e < np * q16; e += 256) {
+            const int i = e % np, t = e / np;
+            Q1[e] = (t == 0 && i < n) ? rsn : 0.0;
+        }
+        if (q > 1) {
+            const int d16 = (d + 15) & ~15;
+            // Gx = Xc' Xc (d x d), identity padded to 128 x 128
+            for (int e = tid; e < 128 * 128; e += 256) Gx[e] = (e % 128 == e / 128 && e % 128 >= d) ? 1.0 : 0.0;
+            __syncthreads();
+            wg_gemm<false, true, true>(d16, d16, n16, P.Xc, dpad, P.Xc, dpad, [&](int a, int b, double v) {
+                if (a < d && b < d) Gx[a + b * 128] = v;
+            });
+            __syncthreads();
+            {
+                const int bad = diag_block(Gx, 128, LinvX, sh);
+                __syncthreads();
+                if (tid == 0 && bad) P.flags[1] = bad;
+            }
+            __syncthreads();
+            // Qx(i, a) = sum_b Xc(i, b) inv(Lx)(a, b)
+            double *Qx = Q1 + np;
+            wg_gemm<true, true, false>(n16, d16, d16, P.Xc, dpad, LinvX, 128, [&](int i, int a, double v) {
+                if (i < n && a < d) Qx[i + (int64_t)a * np] = v;
+            });
+        }
+        __syncthreads();
+        // ---- W1 = Phi Q1;  G = Q1' W1;  W = W1 - 1/2 Q1 G;  mu = (n phi0 - trace G) / (n - q);  V = W - mu/2 Q1
+        wg_gemm<false, false, false>(n16, q16, n16, Phi, np, Q1, np, [&](int i, int t, double v) { Wm[i + (int64_t)t * np] = v; });
+        for (int e = tid; e < (np - n16) * q16; e += 256) Wm[n16 + e % (np - n16) + (int64_t)(e / (np - n16)) * np] = 0.0;
+        __syncthreads();
+        wg_gemm<true, false, false>(q16, q16, n16, Q1, np, Wm, np, [&](int a, int b, double v) { G[a + b * q16] = v; });
+        __syncthreads();
+        double tr = 0.0;
+        for (int t = tid; t < q; t += 256) tr += G[t + t * q16];
+        tr = wg_sum(tr, red);
+        const double mu_raw = ((double)n * P.kp.phi0 - tr) / (double)max(n - q, 1);
+        const bool mu_ok = mu_raw > 0.0 && mu_raw < 1e300;
+        const double mu = mu_ok ? mu_raw : 1.0;
+        if (tid == 0) {
+            P.scal[0] = tr;
+            P.scal[1] = mu;
+            if (!mu_ok) P.flags[2] = 1;
+        }
+        wg_gemm<false, false, false>(n16, q16, q16, Q1, np, G, q16, [&](int i, int t, double v) { Wm[i + (int64_t)t * np] -= 0.5 * v; });
+        __syncthreads();
+        for (int e = tid; e < np * q16; e += 256) V[e] = fma(-0.5 * mu, Q1[e], Wm[e]);
+        __syncthreads();
+        // ---- K = Phi - Q1 V' - V Q1' on the lower triangle (column-major: K(i, j), i >= j, at Phi[i + j * np])
+        wg_gemm<false, true, true>(n16, n16, q16, Q1, np, V, np, [&](int i, int j, double v) { Phi[i + (int64_t)j * np] -= v; });
+        __syncthreads();
+        wg_gemm<false, true, true>(n16, n16, q16, V, np, Q1, np, [&](int i, int j, double v) { Phi[i + (int64_t)j * np] -= v; });
+        // ---- B = P Y = Y - Q1 (Q1' Y);  T1 keeps Q1' Y for the tail coefficients
+        wg_gemm<true, false, false>(q16, 16, n16, Q1, np, Yc, np, [&](int a, int l, double v) { T1[a + l * ldz] = v; });
+        __syncthreads();
+        for (int e = tid; e < np * 16; e += 256) Bm[e] = Yc[e];
+        __syncthreads();
+        wg_gemm<false, false, false>(n16, 16, q16, Q1, np, T1, ldz, [&](int i, int l, double v) { Bm[i + l * np] -= v; });
+    } else {
+        for (int e = tid; e < np * 16; e += 256) Bm[e] = Yc[e];
+        if (tid == 0) {
+            P.scal[0] = 0.0;
+            P.scal[1] = 0.0;
+        }
+    }
+    __syncthreads();
+
+    // ---- factorisation K = L L'
+    {
+        const int bad = wg_potrf(Phi, np, np, n16, Linv, Pt, sh, &s_bad);
+        if (bad) {
+            if (tid == 0) P.flags[0] = bad;
+            return;
+        }
+    }
+    __syncthreads();
+    const int nb = np / 128;
+    // ---- forward substitution L y = B (block rows; inv(L_cc) from the factorisation), then backward L' x = y
+    for (int c = 0; c < nb; ++c) {
+        if (c > 0) {
+            wg_gemm<false, false, false>(128, 16, 128 * c, Phi + 128 * c, np, Fy, np, [&](int i, int l, double v) { Bm[128 * c + i + l * np] -= v; });
+            __syncthreads();
+        }
+        wg_gemm<false, false, false>(128, 16, 128, Linv + (int64_t)c * 128 * 128, 128, Bm + 128 * c, np,
+                                     [&](int i, int l, double v) { Fy[128 * c + i + l * np] = v; });
+        __syncthreads();
+    }
+    for (int c = nb - 1; c >= 0; --c) {
+        const int rest = np - 128 * (c + 1);
+        if (rest > 0) {
+            wg_gemm<true, false, false>(128, 16, rest, Phi + 128 * (c + 1) + (int64_t)128 * c * np, np, Xs + 128 * (c + 1), np,
+                                        [&](int i, int l, double v) { Fy[128 * c + i + l * np] -= v; });
+            __syncthreads();
+        }
+        wg_gemm<true, false, false>(128, 16, 128, Linv + (int64_t)c * 128 * 128, 128, Fy + 128 * c, np,
+                                    [&](int i, int l, double v) { Xs[128 * c + i + l * np] = v; });
+        __syncthreads();
+    }
+    // ---- tail: re-project w (rounding hygiene), z = Q1' Y - W' w, lam = R^-1 z with R = [[sqrt n, sqrt n mean'], [0, Lx']]
+    if (q > 0) {
+        wg_gemm<true, false, false>(q16, 16, n16, Q1, np, Xs, np, [&](int a, int l, double v) { T2[a + l * ldz] = v; });
+        __syncthreads();
+        wg_gemm<false, false, false>(n16, 16, q16, Q1, np, T2, ldz, [&](int i, int l, double v) { Xs[i + l * np] -= v; });
+        __syncthreads();
+        wg_gemm<true, false, false>(q16, 16, n16, Wm, np, Xs, np, [&](int a, int l, double v) { Z[a + l * ldz] = T1[a + l * ldz] - v; });
+        for (int e = tid; e < 16 * 16; e += 256) Z[q16 + e % 16 + (e / 16) * ldz] = 0.0;  // the rows the next product may read beyond q16
+        __syncthreads();
+        if (q > 1) {
+            const int d16 = (d + 15) & ~15;
+            // lam_tail = Lx^-T z[1:]  =  inv(Lx)' z[1:]
+            wg_gemm<true, false, false>(d16, 16, d16, LinvX, 128, Z + 1, ldz, [&](int a, int l, double v) { T2[1 + a + l * ldz] = v; });
+            __syncthreads();
+        }
+        // lam[0] = z0 / sqrt(n) - mean . lam[1:]
+        for (int l = wave; l < k; l += 4) {
+            double acc = 0.0;
+            for (int t = 1 + lane; t < q; t += 64) acc = fma(s_mean[t - 1], T2[t + l * ldz], acc);
+            for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+            if (lane == 0) P.lam[l] = Z[l * ldz] * rsn - acc;
+        }
+        for (int e = tid; e < (q - 1) * k; e += 256) {
+            const int t = 1 + e / k, l = e % k;
+            P.lam[(int64_t)t * k + l] = T2[t + l * ldz];
+        }
+    }
+    // ---- the model's weights: W (n x k row-major), Wc (npad x k column-major, zero padded)
+    for (int e = tid; e < np * k; e += 256) {
+        const int i = e % np, l = e / np;
+        const double v = i < n ? Xs[i + l * np] : 0.0;
+        P.Wc[e] = v;
+        if (i < n) P.W[(int64_t)i * k + l] = v;
+    }
+}
+
+}  // namespace smallfit
+
+bool small_fit_applies(const mrbf_ctx *ctx, int64_t n, int d, int k, int q, int path) {
+    static const int off = getenv("MRBF_SMALL_FIT") ? atoi(getenv("MRBF_SMALL_FIT")) == 0 : 0;
+    if (off || ctx->chol_impl == 1 || ctx->gram_mode == 1) return false;
+    return n >= 1 && n <= 512 && d >= 1 && d <= 128 && k >= 1 && k <= 16 && n > q && (path == MRBF_PATH_CHOL || path == MRBF_PATH_PROJ_CHOL);
+}
+
+int launch_small_fit(mrbf_ctx *ctx, const smallfit::Prob *host_probs, int count, const smallfit::Prob *dev_probs) {
+    if (count <= 0) return 0;
+    if (count == 1 && !dev_probs)
+        hipLaunchKernelGGL(smallfit::small_fit_kernel, dim3(1), dim3(256), 0, ctx->stream, host_probs[0], (const smallfit::Prob *)nullptr);
+    else
+        hipLaunchKernelGGL(smallfit::small_fit_kernel, dim3((unsigned)count), dim3(256), 0, ctx->stream, host_probs[0], dev_probs);
+    MRBF_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+}  // namespace mrbf

@@ -1,0 +1,78 @@
+// Problem descriptor and scratch layout of the one-launch small-problem fit (small.hip) and of the batched evaluation
+// (eval_fused.hip): shared by the kernels and by the host code that carves the arena (solve.hip, api.hip).
+#pragma once
+#include "common.hpp"
+
+namespace mrbf {
+namespace smallfit {
+
+struct Prob {
+    int n, d, k, q, deg;
+    int n16, npad, dpad, q16;  // n16 = round_up(n, 16), npad = round_up(n, 128), dpad in {64, 128}, q16 = round_up(max(q, 1), 16)
+    KP kp;
+    const double *C, *Y;                     // sites n x d, values n x k (row-major, device)
+    double *Xc, *sq, *mean, *W, *Wc, *lam;   // the model's arrays (mrbf_model)
+    double *ws;                              // scratch, carve(npad, q16).total doubles
+    int *flags;                              // [0] bad pivot of K (1-based), [1] bad pivot of the tail's Cholesky-QR, [2] shift not positive
+    double *scal;                            // [0] trace(Q1' Phi Q1), [1] mu
+};
+
+struct Carve {
+    size_t Phi, Q1, Wm, V, G, Gx, LinvX, Linv, Pt, Ycol, B, Fy, Xs, T1, T2, Z, total;
+    int ldz;
+};
+__host__ __device__ inline Carve carve(int npad, int q16) {
+    Carve c;
+    size_t o = 0;
+    auto take = [&](size_t cnt) {
+        const size_t at = o;
+        o += (cnt + 15) & ~size_t(15);
+        return at;
+    };
+    c.ldz = q16 + 16;
+    c.Phi = take((size_t)npad * npad);
+    c.Q1 = take((size_t)npad * q16);
+    c.Wm = take((size_t)npad * q16);
+    c.V = take((size_t)npad * q16);
+    c.G = take((size_t)q16 * q16);
+    c.Gx = take((size_t)128 * 128);
+    c.LinvX = take((size_t)128 * 128);
+    c.Linv = take((size_t)npad * 128);
+    c.Pt = take((size_t)npad * 128);
+    c.Ycol = take((size_t)npad * 16);
+    c.B = take((size_t)npad * 16);
+    c.Fy = take((size_t)npad * 16);
+    c.Xs = take((size_t)npad * 16);
+    c.T1 = take((size_t)c.ldz * 16);
+    c.T2 = take((size_t)c.ldz * 16);
+    c.Z = take((size_t)c.ldz * 16 + 16);
+    c.total = o;
+    return c;
+}
+
+}  // namespace smallfit
+
+// one problem of a batched evaluation (eval_fused.hip): the kernels of mrbf_eval with the problem index in the grid
+struct EvalDesc {
+    const double *X;      // m x d query points (row-major)
+    const double *mean;   // the model's centroid
+    double *Xq, *xsq;     // mpad x D centred + zero-padded queries, squared norms (scratch)
+    const double *Cc, *csq, *Wc, *lam;  // the model: centred centres (npad x D), their norms, weights (npad x k col-major), tail
+    int64_t npad, mpad, m;
+    int d, k, q, tiles_per_split, nsplit;
+    KP kp;
+    double *vpart, *sapart, *gpart;     // per-split partials (scratch)
+    double *vals, *jac;                 // m x k, m x (k x d column-major); jac may be NULL for the whole batch only
+};
+// the centre-range split a single mrbf_eval of m points on a model with npad padded centres uses (the batch takes the same one, so
+// that a batch and single calls add up their partial sums in the same order)
+int eval_nsplit(const mrbf_ctx *ctx, int64_t m, int64_t npad);
+// all descriptors: same kernel id / fast flag / padded dimension D (64 or 128) / k; dev_descs = the same array in device memory
+int eval_fused_batch(mrbf_ctx *ctx, const KP &kp, int D, int k, bool want_jac, const EvalDesc *host_descs, const EvalDesc *dev_descs, int count);
+
+// does the one-launch path take a problem of this shape on this context?  (path: MRBF_PATH_* chosen by fit_model)
+bool small_fit_applies(const mrbf_ctx *ctx, int64_t n, int d, int k, int q, int path);
+// count == 1 and dev_probs == nullptr: the descriptor travels as a kernel argument; else one workgroup per descriptor of dev_probs
+int launch_small_fit(mrbf_ctx *ctx, const smallfit::Prob *host_probs, int count, const smallfit::Prob *dev_probs);
+
+}  // namespace mrbf

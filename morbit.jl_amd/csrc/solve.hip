@@ -12,6 +12,7 @@
 //   LU         anything else (tail of too low a degree for the kernel's order, failed Cholesky):
 //              getrf/getrs on the full saddle matrix.
 #include "common.hpp"
+#include "small.hpp"
 
 namespace mrbf {
 
@@ -669,6 +670,69 @@ static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info
     return 0;
 }
 
+// ---- small problems: the whole Cholesky-path fit as one launch (small.hip) ---------------------------------------------------
+void fill_small_prob(const mrbf_model *M, const double *Y, double *ws, int *flags, double *scal, smallfit::Prob *P) {
+    P->n = (int)M->n;
+    P->d = M->d;
+    P->k = M->k;
+    P->q = M->q;
+    P->deg = M->deg;
+    P->n16 = (int)round_up(M->n, 16);
+    P->npad = (int)M->npad;
+    P->dpad = M->dpad;
+    P->q16 = (int)round_up(std::max(M->q, 1), 16);
+    P->kp = M->kp;
+    P->C = M->C;
+    P->Y = Y;
+    P->Xc = M->Xc;
+    P->sq = M->sq;
+    P->mean = M->mean;
+    P->W = M->W;
+    P->Wc = M->Wc;
+    P->lam = M->lam;
+    P->ws = ws;
+    P->flags = flags;
+    P->scal = scal;
+}
+// what the flags of a small-problem fit mean for mrbf_fit_info (shared with the batched entry point): returns 1 when the problem
+// has to be re-done on the LU path
+int small_fit_verdict(const mrbf_model *M, const int *hflags, const double *hscal, mrbf_fit_info *info) {
+    info->path = M->q > 0 ? MRBF_PATH_PROJ_CHOL : MRBF_PATH_CHOL;
+    info->mu = M->q > 0 ? hscal[1] : 0.0;
+    info->factor_info = hflags[0];
+    if (hflags[1] != 0) {  // affinely dependent sites: Pi is rank deficient
+        info->factor_info = -2;
+        return 1;
+    }
+    if (hflags[2] != 0) {  // trace <= 0: Z' Phi Z cannot be positive definite
+        info->factor_info = -1;
+        return 1;
+    }
+    return hflags[0] != 0 ? 1 : 0;
+}
+static int fit_small(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info *info, int *not_pd) {
+    *not_pd = 0;
+    smallfit::Prob P;
+    const smallfit::Carve cv = smallfit::carve((int)M->npad, (int)round_up(std::max(M->q, 1), 16));
+    double *ws, *scal;
+    int *flags;
+    MRBF_TRY(get_buf(ctx, S_SMALL_WS, cv.total, &ws));
+    MRBF_TRY(get_buf(ctx, S_SMALL_FLAGS, (size_t)4, &flags));
+    MRBF_TRY(get_buf(ctx, S_MISC, (size_t)8, &scal));
+    fill_small_prob(M, Y, ws, flags, scal, &P);
+    MRBF_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    MRBF_TRY(launch_small_fit(ctx, &P, 1, nullptr));
+    MRBF_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    int hflags[4] = {0, 0, 0, 0};
+    double hscal[2] = {0.0, 0.0};
+    MRBF_HIP(ctx, hipMemcpyAsync(hflags, flags, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    MRBF_HIP(ctx, hipMemcpyAsync(hscal, scal, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    MRBF_HIP(ctx, hipEventElapsedTime(&info->ms_factor, ctx->ev[0], ctx->ev[1]));  // one launch: assembly, projection, factorisation, solve
+    *not_pd = small_fit_verdict(M, hflags, hscal, info);
+    return 0;
+}
+
 // residual ||s(C) - Y|| / ||Y|| through the evaluation kernels (an independent code path), and max |Pi' w|
 int fit_check(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info *info) {
     const int64_t n = M->n;
@@ -715,6 +779,16 @@ int fit_model(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info *info
     if (path == MRBF_PATH_PROJ_CHOL && M->q == 0) path = MRBF_PATH_CHOL;
     if (path == MRBF_PATH_MINNORM) {
         MRBF_TRY(fit_minnorm(ctx, M, Y, info));
+    } else if (path != MRBF_PATH_LU && small_fit_applies(ctx, M->n, M->d, M->k, M->q, path)) {
+        int not_pd = 0;
+        MRBF_TRY(fit_small(ctx, M, Y, info, &not_pd));
+        if (not_pd) {
+            info->fallbacks |= MRBF_FB_LU;
+            if (ctx->force_path != 0)
+                return fail(ctx, MRBF_ENOTPD, "Cholesky path forced but the matrix is not positive definite (info = %d)",
+                            info->factor_info);
+            path = MRBF_PATH_LU;
+        }
     } else if (path != MRBF_PATH_LU) {
         int not_pd = 0, gave_up = 0;
         MRBF_TRY(fit_chol(ctx, M, Y, info, &not_pd, &gave_up));
