@@ -36,7 +36,9 @@ struct CheckDesc {
 };
 
 // one workgroup per problem, every reduction in a fixed order
-__global__ __launch_bounds__(256) void batch_check_kernel(const CheckDesc *__restrict__ many) {
+// part 0: what depends on the fit and on the evaluation at the sites only (runs beside the evaluation of the queries); part 1: the
+// checksum of the values at the queries
+__global__ __launch_bounds__(256) void batch_check_kernel(const CheckDesc *__restrict__ many, int part) {
     const CheckDesc &E = many[blockIdx.x];
     __shared__ double r0[256], r1[256];
     const int tid = threadIdx.x;
@@ -52,6 +54,14 @@ __global__ __launch_bounds__(256) void batch_check_kernel(const CheckDesc *__res
             __syncthreads();
         }
     };
+    if (part == 1) {
+        double sv = 0.0;
+        if (E.vals)
+            for (int64_t i = tid; i < E.m * E.k; i += 256) sv += E.vals[i];
+        tree(0.0, sv, false);
+        if (tid == 0) E.out[4] = r1[0];
+        return;
+    }
     double s0 = 0.0, s1 = 0.0;
     for (int64_t i = tid; i < E.n * E.k; i += 256) {
         const double df = E.V[i] - E.Y[i];
@@ -79,12 +89,6 @@ __global__ __launch_bounds__(256) void batch_check_kernel(const CheckDesc *__res
         E.out[2] = r0[0];
         E.out[3] = r1[0];
     }
-    __syncthreads();
-    double sv = 0.0;
-    if (E.vals)
-        for (int64_t i = tid; i < E.m * E.k; i += 256) sv += E.vals[i];
-    tree(0.0, sv, false);
-    if (tid == 0) E.out[4] = r1[0];
 }
 
 static inline size_t al16(size_t c) { return (c + 15) & ~size_t(15); }
@@ -116,7 +120,7 @@ static int run_small_batch(mrbf_ctx *ctx, const std::vector<int64_t> &idx, const
         L.q = poly_dim(d, pr.poly_deg);
         L.npad = round_up(pr.n, 128);
         L.D = d <= 64 ? 64 : 128;
-        L.KO = (k >= 2 && L.D == 64) ? 2 : 1;
+        L.KO = outputs_per_pass(k, L.D);
         const int q16 = (int)round_up(std::max(L.q, 1), 16);
         L.C = is_device_ptr(pr.centres) ? (size_t)-1 : take((size_t)pr.n * d);
         L.Y = is_device_ptr(pr.values) ? (size_t)-1 : take((size_t)pr.n * k);
@@ -133,15 +137,15 @@ static int run_small_batch(mrbf_ctx *ctx, const std::vector<int64_t> &idx, const
         L.nsplit0 = check ? eval_nsplit(ctx, pr.n, L.npad) : 1;
         L.Xq0 = take((size_t)L.mpad0 * L.D);
         L.xsq0 = take((size_t)L.mpad0);
-        L.vp0 = take((size_t)L.nsplit0 * L.mpad0 * L.KO * 2);
+        L.vp0 = take(L.nsplit0 > 1 ? (size_t)L.nsplit0 * L.mpad0 * L.KO * 2 : 0);
         L.gp0 = take((size_t)0);
         L.V0 = take((size_t)pr.n * k);
         L.mpad1 = round_up(pr.m, 64);
         L.nsplit1 = pr.m > 0 ? eval_nsplit(ctx, pr.m, L.npad) : 1;
         L.Xq1 = take((size_t)L.mpad1 * L.D);
         L.xsq1 = take((size_t)L.mpad1);
-        L.vp1 = take((size_t)L.nsplit1 * L.mpad1 * L.KO * 2);
-        L.gp1 = take(pr.jac_out ? (size_t)L.nsplit1 * L.mpad1 * L.KO * L.D : 0);
+        L.vp1 = take(L.nsplit1 > 1 ? (size_t)L.nsplit1 * L.mpad1 * L.KO * 2 : 0);
+        L.gp1 = take((pr.jac_out && L.nsplit1 > 1) ? (size_t)L.nsplit1 * L.mpad1 * L.KO * L.D : 0);
         L.vals = (pr.m == 0 || (pr.vals_out && is_device_ptr(pr.vals_out))) ? (size_t)-1 : take((size_t)pr.m * k);
         L.jac = (pr.m == 0 || !pr.jac_out || is_device_ptr(pr.jac_out)) ? (size_t)-1 : take((size_t)pr.m * k * d);
         L.out = out0 + (size_t)8 * i;
@@ -243,17 +247,30 @@ static int run_small_batch(mrbf_ctx *ctx, const std::vector<int64_t> &idx, const
     MRBF_HIP(ctx, hipEventRecord(ctx->ev[0], st));
     MRBF_TRY(launch_small_fit(ctx, probs.data(), P, dprobs));
     MRBF_HIP(ctx, hipEventRecord(ctx->ev[1], st));
-    // evaluation launches per group of equal (kernel, fast flag, padded dimension, outputs, Jacobians wanted): usually one group
+    // evaluation launches per group of equal (kernel, fast flag, padded dimension, outputs, Jacobians wanted): usually two groups,
+    // the residual evaluations at the sites (no Jacobians; on the side stream, beside the evaluation of the queries, together with
+    // part 0 of the check kernel) and the evaluations of the queries
+    hipStream_t side = (ctx->panel_stream && ctx->panel_stream != st) ? ctx->panel_stream : st;
+    if (side != st) {
+        MRBF_HIP(ctx, hipEventRecord(ctx->evx[0], st));
+        MRBF_HIP(ctx, hipStreamWaitEvent(side, ctx->evx[0], 0));
+    }
     {
+        struct RestoreStream {
+            mrbf_ctx *c;
+            hipStream_t s;
+            ~RestoreStream() { c->stream = s; }
+        } restore{ctx, st};
         std::vector<char> done((size_t)2 * P, 0);
         for (size_t a = 0; a < evs.size(); ++a) {
             if (done[a]) continue;
             const mrbf_problem &pa = problems[idx[a % P]];
             const KP kpa = evs[a].kp;
             const bool ja = evs[a].jac != nullptr;
+            const bool is_check = a < (size_t)P;
             std::vector<EvalDesc> grp;
             std::vector<size_t> members;
-            for (size_t b = a; b < evs.size(); ++b) {
+            for (size_t b = a; b < (is_check ? (size_t)P : evs.size()); ++b) {
                 const mrbf_problem &pb = problems[idx[b % P]];
                 if (!done[b] && evs[b].kp.kid == kpa.kid && evs[b].kp.fast == kpa.fast && lay[b % P].D == lay[a % P].D && pb.k == pa.k &&
                     (evs[b].jac != nullptr) == ja) {
@@ -262,6 +279,7 @@ static int run_small_batch(mrbf_ctx *ctx, const std::vector<int64_t> &idx, const
                 }
             }
             if (members.empty()) continue;
+            ctx->stream = is_check ? side : st;
             // contiguous runs of the device array are launched as they lie; scattered members are compacted into a second array
             bool contiguous = true;
             for (size_t j = 1; j < members.size(); ++j) contiguous = contiguous && members[j] == members[j - 1] + 1;
@@ -270,17 +288,22 @@ static int run_small_batch(mrbf_ctx *ctx, const std::vector<int64_t> &idx, const
             if (!contiguous) {
                 for (size_t b : members) grp.push_back(evs[b]);
                 EvalDesc *dgrp;
-                MRBF_TRY(get_buf(ctx, S_STAGE_D, grp.size() * sizeof(EvalDesc) / sizeof(double) + 16, (double **)&dgrp));
-                MRBF_HIP(ctx, hipMemcpyAsync(dgrp, grp.data(), grp.size() * sizeof(EvalDesc), hipMemcpyHostToDevice, st));
-                MRBF_HIP(ctx, hipStreamSynchronize(st));  // grp is reused by the next group
+                MRBF_TRY(get_buf(ctx, is_check ? S_STAGE_C : S_STAGE_D, grp.size() * sizeof(EvalDesc) / sizeof(double) + 16, (double **)&dgrp));
+                MRBF_HIP(ctx, hipMemcpyAsync(dgrp, grp.data(), grp.size() * sizeof(EvalDesc), hipMemcpyHostToDevice, ctx->stream));
+                MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));  // grp is reused by the next group
                 dev = dgrp;
                 host = grp.data();
             }
             MRBF_TRY(eval_fused_batch(ctx, kpa, lay[a % P].D, pa.k, ja, host, dev, (int)members.size()));
-            if (!contiguous) MRBF_HIP(ctx, hipStreamSynchronize(st));
+            if (!contiguous) MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
         }
     }
-    hipLaunchKernelGGL(batch_check_kernel, dim3((unsigned)P), dim3(256), 0, st, dchk);
+    hipLaunchKernelGGL(batch_check_kernel, dim3((unsigned)P), dim3(256), 0, side, dchk, 0);
+    if (side != st) {
+        MRBF_HIP(ctx, hipEventRecord(ctx->evx[1], side));
+        MRBF_HIP(ctx, hipStreamWaitEvent(st, ctx->evx[1], 0));
+    }
+    hipLaunchKernelGGL(batch_check_kernel, dim3((unsigned)P), dim3(256), 0, st, dchk, 1);
     MRBF_HIP(ctx, hipGetLastError());
     MRBF_HIP(ctx, hipEventRecord(ctx->ev[2], st));
     // results

@@ -1,15 +1,18 @@
 // Fused batched surrogate evaluation on the fp64 matrix cores (dpad <= 128).
 //
 // For a block of 64 query points and a run of 64-centre tiles, per tile:
-//   1. S'[c][q] = <cc_c, xc_q>                     MFMA, A operand = centre tile from LDS, B operand = query fragments
-//                                                  kept in registers for the whole kernel
+//   1. S'[c][q] = <cc_c, xc_q>                     MFMA, A operand = centre tile from LDS, B operand = query fragments (kept in
+//                                                  registers for the whole kernel, or in LDS when two outputs share a pass at D = 128)
 //   2. s = |xc_q|^2 + |cc_c|^2 - 2 S', phi(s), psi(s);  per output l:  v_l[q] += w_lc phi,  a_lc = w_lc psi
 //   3. G_l'[t][q] += cc_c[t] a_lc                  MFMA: the a_l tile sits in the C/D register layout with the summed
 //                                                  index c on its ROW axis, which is exactly the B-operand layout of the
 //                                                  next MFMA, so phase 2's output feeds phase 3 with no data movement
 // (the structure of a flash-attention forward pass: centres play K and V, the radial function plays softmax).
-// The centre range is split over gridDim.y so that small query batches still fill the chip; a combine kernel sums the
-// splits in a fixed order, adds the polynomial tail and writes  J_l = (sum_c a_lc) xc - G_l + grad p_l.
+// Large models: the centre range is split over gridDim.y so that small query batches still fill the chip; a combine kernel sums
+// the splits in a fixed order, adds the polynomial tail and writes  J_l = (sum_c a_lc) xc - G_l + grad p_l.
+// Small models (<= 8 centre tiles, never split): the kernel's own epilogue does that (FINAL) -- no partials, no combine pass.
+// Every launch takes its operands from an EvalDesc: one by value for a single mrbf_eval, an array (blockIdx.z = problem) for the
+// batched entry points (mrbf_batch_run); the arithmetic per problem is the same, so a batch and single calls agree bit for bit.
 #include "radial.hpp"
 #include "small.hpp"
 
@@ -21,31 +24,24 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 constexpr int EQ = 64;  // queries per workgroup
 constexpr int EC = 64;  // centres per tile
 
-template <int KID, bool FAST, int KOUT, int DT, bool JAC>
-__global__ __launch_bounds__(256, (DT <= 4) ? 2 : 1) void eval_fused_kernel(
-    const double *__restrict__ Xq, const double *__restrict__ xsq, const double *__restrict__ Cc, const double *__restrict__ csq,
-    const double *__restrict__ Wc, int64_t npad, int l0, KP kp, int64_t mpad, int tiles_per_split, double *__restrict__ vpart,
-    double *__restrict__ sapart, double *__restrict__ gpart, const EvalDesc *__restrict__ many) {
+// QLDS: the query fragments live in LDS instead of registers (frees D / 2 VGPRs per lane: two outputs per pass fit at D = 128 without
+// accumulators in AGPRs, where the f64 MFMA runs at half rate -- tools/microbench.py)
+template <int KID, bool FAST, int KOUT, int DT, bool JAC, bool FINAL, bool QLDS>
+__global__ __launch_bounds__(256, (DT <= 4) ? 2 : 1) void eval_fused_kernel(EvalDesc one, const EvalDesc *__restrict__ many, int l0) {
     constexpr int D = DT * 16, LDC = D + 2;
-    if (many) {  // batched launch: blockIdx.z = problem; the grid is sized for the largest problem of the batch
-        const EvalDesc &E = many[blockIdx.z];
-        if ((int64_t)blockIdx.x * EQ >= E.mpad || (int)blockIdx.y >= E.nsplit) return;
-        Xq = E.Xq;
-        xsq = E.xsq;
-        Cc = E.Cc;
-        csq = E.csq;
-        Wc = E.Wc;
-        npad = E.npad;
-        kp = E.kp;
-        mpad = E.mpad;
-        tiles_per_split = E.tiles_per_split;
-        vpart = E.vpart;
-        sapart = E.sapart;
-        gpart = E.gpart;
-    }
-    __shared__ __attribute__((aligned(16))) double Cs[EC * LDC];
-    __shared__ double Ws[KOUT * EC];
-    __shared__ double Sq[EC];
+    __shared__ __attribute__((aligned(16))) double Cs[EC * LDC];              // centre tile
+    __shared__ double Ws[KOUT * EC];                                          // weights of the tile
+    __shared__ double Sq[EC];                                                 // squared norms of the tile's centres
+    __shared__ __attribute__((aligned(16))) double Xs[QLDS ? EQ * LDC : 2];   // QLDS: the query block
+    const EvalDesc &E = many ? many[blockIdx.z] : one;
+    if (many && ((int64_t)blockIdx.x * EQ >= E.mpad || (int)blockIdx.y >= E.nsplit)) return;
+    const double *__restrict__ Xq = E.Xq;
+    const double *__restrict__ Cc = E.Cc;
+    const double *__restrict__ csq = E.csq;
+    const double *__restrict__ Wc = E.Wc;
+    const int64_t npad = E.npad, mpad = E.mpad;
+    const int tiles_per_split = E.tiles_per_split;
+    const KP kp = E.kp;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
     const int64_t q0 = (int64_t)blockIdx.x * EQ;
@@ -53,10 +49,17 @@ __global__ __launch_bounds__(256, (DT <= 4) ? 2 : 1) void eval_fused_kernel(
     const int64_t qrow = q0 + wave * 16 + l15;
 
     // query fragments: B operand of phase 1, k-slice s -> Xq[qrow][4s + l4]
-    double xb[D / 4];
+    double xb[QLDS ? 1 : D / 4];
+    if constexpr (QLDS) {
+        for (int e = tid; e < EQ * D / 2; e += 256) {
+            const int row = (2 * e) / D, col = (2 * e) % D;
+            *(v2d *)&Xs[row * LDC + col] = *(const v2d *)&Xq[(q0 + row) * D + col];
+        }
+    } else {
 #pragma unroll
-    for (int s = 0; s < D / 4; ++s) xb[s] = Xq[qrow * D + 4 * s + l4];
-    const double xs = xsq[qrow];
+        for (int s = 0; s < D / 4; ++s) xb[s] = Xq[qrow * D + 4 * s + l4];
+    }
+    const double xs = E.xsq[qrow];
 
     v4d JT[KOUT][DT];
     double vsum[KOUT], sasum[KOUT];
@@ -102,8 +105,14 @@ __global__ __launch_bounds__(256, (DT <= 4) ? 2 : 1) void eval_fused_kernel(
             // ---- phase 1
             v4d S = {0.0, 0.0, 0.0, 0.0};
             const double *crow = &Cs[(16 * ct + l15) * LDC + l4];
+            if constexpr (QLDS) {
+                const double *xrow = &Xs[(wave * 16 + l15) * LDC + l4];
 #pragma unroll
-            for (int s = 0; s < D / 4; ++s) S = __builtin_amdgcn_mfma_f64_16x16x4f64(crow[4 * s], xb[s], S, 0, 0, 0);
+                for (int s = 0; s < D / 4; ++s) S = __builtin_amdgcn_mfma_f64_16x16x4f64(crow[4 * s], xrow[4 * s], S, 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int s = 0; s < D / 4; ++s) S = __builtin_amdgcn_mfma_f64_16x16x4f64(crow[4 * s], xb[s], S, 0, 0, 0);
+            }
             // ---- phase 2: C/D layout: register r <-> centre c = 16 ct + l4 + 4 r, lane & 15 <-> query
             v4d Aw[KOUT];
 #pragma unroll
@@ -144,29 +153,84 @@ __global__ __launch_bounds__(256, (DT <= 4) ? 2 : 1) void eval_fused_kernel(
         sasum[l] += __shfl_xor(sasum[l], 16);
         sasum[l] += __shfl_xor(sasum[l], 32);
     }
-    if (l4 == 0) {
+    if constexpr (!FINAL) {
+        double *__restrict__ vpart = E.vpart, *__restrict__ sapart = E.sapart, *__restrict__ gpart = E.gpart;
+        if (l4 == 0) {
 #pragma unroll
-        for (int l = 0; l < KOUT; ++l) {
-            vpart[((int64_t)split * mpad + qrow) * KOUT + l] = vsum[l];
-            sapart[((int64_t)split * mpad + qrow) * KOUT + l] = sasum[l];
-        }
-    }
-    if (JAC) {
-        // G tiles -> gpart[split][q][l][t] through an LDS transpose (per wave 16 q x D), coalesced rows of D doubles
-        __syncthreads();
-        double *T = Cs + wave * 16 * LDC;
-#pragma unroll
-        for (int l = 0; l < KOUT; ++l) {
-#pragma unroll
-            for (int tt = 0; tt < DT; ++tt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) T[l15 * LDC + 16 * tt + l4 + 4 * r] = JT[l][tt][r];
-            __syncthreads();
-            for (int e = lane; e < 16 * D; e += 64) {
-                const int qq = e / D, t = e % D;
-                gpart[(((int64_t)split * mpad + q0 + wave * 16 + qq) * KOUT + l) * D + t] = T[qq * LDC + t];
+            for (int l = 0; l < KOUT; ++l) {
+                vpart[((int64_t)split * mpad + qrow) * KOUT + l] = vsum[l];
+                sapart[((int64_t)split * mpad + qrow) * KOUT + l] = sasum[l];
             }
+        }
+        if (JAC) {
+            // G tiles -> gpart[split][q][l][t] through an LDS transpose (per wave 16 q x D), coalesced rows of D doubles
             __syncthreads();
+            double *T = Cs + wave * 16 * LDC;
+#pragma unroll
+            for (int l = 0; l < KOUT; ++l) {
+#pragma unroll
+                for (int tt = 0; tt < DT; ++tt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) T[l15 * LDC + 16 * tt + l4 + 4 * r] = JT[l][tt][r];
+                __syncthreads();
+                for (int e = lane; e < 16 * D; e += 64) {
+                    const int qq = e / D, t = e % D;
+                    gpart[(((int64_t)split * mpad + q0 + wave * 16 + qq) * KOUT + l) * D + t] = T[qq * LDC + t];
+                }
+                __syncthreads();
+            }
+        }
+    } else {
+        // ---- the whole centre range was this workgroup's: final values and Jacobians straight from the accumulators
+        //      vals[p][l] = sum_c w phi + p_l(x);   jac[p][t*k + l] = (sum_c a_lc) xc[p][t] - G_l[t] + lam[t+1][l]
+        const int d = E.d, k = E.k, q = E.q;
+        const int64_t m = E.m;
+        const double *__restrict__ lam = E.lam;
+        const double *__restrict__ Xorig = E.X;
+        double *__restrict__ vals = E.vals;
+        double *__restrict__ jac = E.jac;
+#pragma unroll
+        for (int l = 0; l < KOUT; ++l) {
+            // polynomial tail of the value: lanes (query l15, part l4) take the coordinates t = l4, l4 + 4, ...; fixed-order reduction
+            double v = vsum[l];
+            if (vals && l0 + l < k) {
+                double acc = 0.0;
+                if (q > 1 && qrow < m)
+                    for (int t = l4; t < d; t += 4) acc = fma(lam[(int64_t)(t + 1) * k + l0 + l], Xorig[qrow * d + t], acc);
+                acc += __shfl_xor(acc, 16);
+                acc += __shfl_xor(acc, 32);
+                if (q > 0) v += lam[l0 + l];
+                if (q > 1) v += acc;
+                if (l4 == 0 && qrow < m) vals[qrow * k + l0 + l] = v;
+            }
+        }
+        if (JAC && jac) {
+            __syncthreads();  // every wave is done with the last centre tile
+            double *T = Cs + wave * 16 * LDC;
+            double *SA = Ws;  // KOUT x 64 (= 4 waves x 16 queries): the weights of the last tile are not needed any more
+#pragma unroll
+            for (int l = 0; l < KOUT; ++l)
+                if (l4 == 0) SA[l * EQ + wave * 16 + l15] = sasum[l];
+#pragma unroll
+            for (int l = 0; l < KOUT; ++l) {
+#pragma unroll
+                for (int tt = 0; tt < DT; ++tt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) T[l15 * LDC + 16 * tt + l4 + 4 * r] = JT[l][tt][r];
+                __syncthreads();
+                if (l0 + l < k) {
+                    for (int e = lane; e < 16 * D; e += 64) {
+                        const int qq = e / D, t = e % D;
+                        const int64_t row = q0 + wave * 16 + qq;
+                        if (row < m && t < d) {
+                            double v = fma(SA[l * EQ + wave * 16 + qq], Xq[row * D + t], -T[qq * LDC + t]);
+                            if (q > 1) v += lam[(int64_t)(t + 1) * k + l0 + l];
+                            jac[row * (int64_t)k * d + (int64_t)t * k + l0 + l] = v;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
         }
     }
 }
@@ -176,30 +240,14 @@ __global__ __launch_bounds__(256, (DT <= 4) ? 2 : 1) void eval_fused_kernel(
 // is spread over the threads that also produce the Jacobian entries and summed in a fixed order through LDS (it used to be a serial
 // d-term loop of one thread per output, the critical path of the whole workgroup: 54 us for 10^4 points at d = 64, 92 us at d = 128).
 template <int KOUT>
-__global__ __launch_bounds__(128) void eval_combine_kernel(const double *__restrict__ vpart, const double *__restrict__ sapart,
-                                                           const double *__restrict__ gpart, int nsplit, int64_t mpad, int64_t m, int D, int d,
-                                                           int k, int l0, const double *__restrict__ Xq, const double *__restrict__ Xorig,
-                                                           const double *__restrict__ lam, int q, double *__restrict__ vals,
-                                                           double *__restrict__ jac, const EvalDesc *__restrict__ many) {
-    if (many) {  // batched launch: blockIdx.y = problem
-        const EvalDesc &E = many[blockIdx.y];
-        vpart = E.vpart;
-        sapart = E.sapart;
-        gpart = E.gpart;
-        nsplit = E.nsplit;
-        mpad = E.mpad;
-        m = E.m;
-        d = E.d;
-        k = E.k;
-        Xq = E.Xq;
-        Xorig = E.X;
-        lam = E.lam;
-        q = E.q;
-        vals = E.vals;
-        jac = E.jac;
-    }
-    const int64_t p = blockIdx.x;
+__global__ __launch_bounds__(128) void eval_combine_kernel(EvalDesc one, const EvalDesc *__restrict__ many, int l0, int D) {
+    const EvalDesc &E = many ? many[blockIdx.y] : one;
+    const int64_t p = blockIdx.x, m = E.m, mpad = E.mpad;
     if (p >= m) return;
+    const double *__restrict__ vpart = E.vpart, *__restrict__ sapart = E.sapart, *__restrict__ gpart = E.gpart;
+    const double *__restrict__ Xq = E.Xq, *__restrict__ Xorig = E.X, *__restrict__ lam = E.lam;
+    double *__restrict__ vals = E.vals, *__restrict__ jac = E.jac;
+    const int nsplit = E.nsplit, d = E.d, k = E.k, q = E.q;
     __shared__ double sa[KOUT], sv[KOUT];
     __shared__ double pdot[KOUT][128];
     const int tid = threadIdx.x;
@@ -246,24 +294,21 @@ __global__ __launch_bounds__(128) void eval_combine_kernel(const double *__restr
     }
 }
 
-template <int KID, bool FAST, int KOUT, int DT>
-static int launch_fused2(mrbf_ctx *ctx, bool want_jac, dim3 grid, const double *Xq, const double *xsq, const mrbf_model *M, int l0,
-                        int64_t mpad, int tps, double *vpart, double *sapart, double *gpart) {
-    if (want_jac)
-        hipLaunchKernelGGL((eval_fused_kernel<KID, FAST, KOUT, DT, true>), grid, dim3(256), 0, ctx->stream, Xq, xsq, M->Xc, M->sq, M->Wc, M->npad,
-                           l0, M->kp, mpad, tps, vpart, sapart, gpart, (const EvalDesc *)nullptr);
-    else
-        hipLaunchKernelGGL((eval_fused_kernel<KID, FAST, KOUT, DT, false>), grid, dim3(256), 0, ctx->stream, Xq, xsq, M->Xc, M->sq, M->Wc, M->npad,
-                           l0, M->kp, mpad, tps, vpart, sapart, gpart, (const EvalDesc *)nullptr);
-    return 0;
-}
-
-template <int KID, int KOUT, int DT>
-static int launch_fused(mrbf_ctx *ctx, bool want_jac, dim3 grid, const double *Xq, const double *xsq, const mrbf_model *M, int l0,
-                        int64_t mpad, int tps, double *vpart, double *sapart, double *gpart) {
-    if (M->kp.fast && (KID == MRBF_MULTIQUADRIC || KID == MRBF_INV_MULTIQUADRIC || KID == MRBF_CUBIC))
-        return launch_fused2<KID, true, KOUT, DT>(ctx, want_jac, grid, Xq, xsq, M, l0, mpad, tps, vpart, sapart, gpart);
-    return launch_fused2<KID, false, KOUT, DT>(ctx, want_jac, grid, Xq, xsq, M, l0, mpad, tps, vpart, sapart, gpart);
+// queries: Xq[row][t] = X[row][t] - mean[t] (zero in the padding), xsq[row] = |Xq[row]|^2 -- center_pad_kernel's arithmetic (prep.hip)
+__global__ void center_pad_batch_kernel(const EvalDesc *__restrict__ many, int D) {
+    const EvalDesc &E = many[blockIdx.y];
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= E.mpad) return;
+    double s = 0.0;
+    for (int t = lane; t < D; t += 64) {
+        double v = 0.0;
+        if (row < E.m && t < E.d) v = E.X[row * E.d + t] - E.mean[t];
+        E.Xq[row * D + t] = v;
+        s = fma(v, v, s);
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) E.xsq[row] = s;
 }
 
 int eval_nsplit(const mrbf_ctx *ctx, int64_t m, int64_t npad) {
@@ -274,9 +319,9 @@ int eval_nsplit(const mrbf_ctx *ctx, int64_t m, int64_t npad) {
     // (C3: 157 query tiles -> 3 splits of 43 tiles = 471 workgroups in one round, instead of 4 x 32 tiles in two rounds.)
     const int slots = 2 * ctx->ncu;
     const int64_t qtiles = mpad / EQ;
-    // few centre tiles (n <= 512): never split -- a workgroup's prologue and epilogue (query fragments in, 64 x D partial Jacobian
-    // tile out, per split) cost more than the handful of tiles it would shed, the partials triple the traffic of the combine pass,
-    // and such models are evaluated in batches that fill the chip anyway (mrbf_batch_run, the PS solver's generations)
+    // few centre tiles (n <= 512): never split -- a workgroup's prologue and epilogue (query fragments in, 64 x D Jacobian tile
+    // out) cost more than the handful of tiles it would shed, the unsplit kernel finishes values and Jacobians itself (no partials,
+    // no combine pass), and such models are evaluated in batches that fill the chip anyway (mrbf_batch_run, the PS solver)
     if (ntiles <= 8) return 1;
     int nsplit = 1;
     double best_cost = 1e300;
@@ -296,39 +341,60 @@ int eval_nsplit(const mrbf_ctx *ctx, int64_t m, int64_t npad) {
     return nsplit;
 }
 
-// ---- batched evaluation: the same kernels, blockIdx.z / .y = problem --------------------------------------------------------
-// queries: Xq[row][t] = X[row][t] - mean[t] (zero in the padding), xsq[row] = |Xq[row]|^2 -- center_pad_kernel's arithmetic (prep.hip)
-__global__ void center_pad_batch_kernel(const EvalDesc *__restrict__ many, int D) {
-    const EvalDesc &E = many[blockIdx.y];
-    const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (row >= E.mpad) return;
-    double s = 0.0;
-    for (int t = lane; t < D; t += 64) {
-        double v = 0.0;
-        if (row < E.m && t < E.d) v = E.X[row * E.d + t] - E.mean[t];
-        E.Xq[row * D + t] = v;
-        s = fma(v, v, s);
-    }
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    if (lane == 0) E.xsq[row] = s;
+// outputs per pass: two when the model has several (at D = 128 with the query block in LDS)
+int outputs_per_pass(int k, int D) {
+    static const int ko128 = getenv("MRBF_EVAL_KO128") ? atoi(getenv("MRBF_EVAL_KO128")) : 2;
+    return k >= 2 ? (D == 128 ? ko128 : 2) : 1;
 }
 
-template <int KID, bool FAST, int KOUT, int DT>
-static void launch_fused_batch2(mrbf_ctx *ctx, bool want_jac, dim3 grid, int l0, const KP &kp, const EvalDesc *dev) {
-    if (want_jac)
-        hipLaunchKernelGGL((eval_fused_kernel<KID, FAST, KOUT, DT, true>), grid, dim3(256), 0, ctx->stream, nullptr, nullptr, nullptr, nullptr, nullptr,
-                           (int64_t)0, l0, kp, (int64_t)0, 0, nullptr, nullptr, nullptr, dev);
+template <int KID, bool FAST, int KOUT, int DT, bool QLDS>
+static int launch_fused3(mrbf_ctx *ctx, bool want_jac, bool final_, dim3 grid, const EvalDesc &one, const EvalDesc *many, int l0) {
+#define MRBF_EFL(JACV, FINV) \
+    hipLaunchKernelGGL((eval_fused_kernel<KID, FAST, KOUT, DT, JACV, FINV, QLDS>), grid, dim3(256), 0, ctx->stream, one, many, l0)
+    if (want_jac && final_)
+        MRBF_EFL(true, true);
+    else if (want_jac)
+        MRBF_EFL(true, false);
+    else if (final_)
+        MRBF_EFL(false, true);
     else
-        hipLaunchKernelGGL((eval_fused_kernel<KID, FAST, KOUT, DT, false>), grid, dim3(256), 0, ctx->stream, nullptr, nullptr, nullptr, nullptr, nullptr,
-                           (int64_t)0, l0, kp, (int64_t)0, 0, nullptr, nullptr, nullptr, dev);
+        MRBF_EFL(false, false);
+#undef MRBF_EFL
+    return 0;
 }
-template <int KID, int KOUT, int DT>
-static void launch_fused_batch(mrbf_ctx *ctx, bool want_jac, dim3 grid, int l0, const KP &kp, const EvalDesc *dev) {
+template <int KID, int KOUT, int DT, bool QLDS>
+static int launch_fused(mrbf_ctx *ctx, bool want_jac, bool final_, dim3 grid, const KP &kp, const EvalDesc &one, const EvalDesc *many, int l0) {
     if (kp.fast && (KID == MRBF_MULTIQUADRIC || KID == MRBF_INV_MULTIQUADRIC || KID == MRBF_CUBIC))
-        launch_fused_batch2<KID, true, KOUT, DT>(ctx, want_jac, grid, l0, kp, dev);
-    else
-        launch_fused_batch2<KID, false, KOUT, DT>(ctx, want_jac, grid, l0, kp, dev);
+        return launch_fused3<KID, true, KOUT, DT, QLDS>(ctx, want_jac, final_, grid, one, many, l0);
+    return launch_fused3<KID, false, KOUT, DT, QLDS>(ctx, want_jac, final_, grid, one, many, l0);
+}
+
+// the passes over the outputs of one evaluation (single: many == nullptr, `one` by value; batch: blockIdx.z / .y = problem)
+static int run_passes(mrbf_ctx *ctx, const KP &kp, int D, int k, bool want_jac, bool final_, dim3 grid, dim3 cgrid, const EvalDesc &one,
+                      const EvalDesc *many) {
+    const int KO = outputs_per_pass(k, D);
+    for (int l0 = 0; l0 < k; l0 += KO) {
+        const int ko = std::min(KO, k - l0);
+#define MRBF_EF(KOV, DTV, QL) MRBF_DISPATCH_KID(kp.kid, MRBF_TRY((launch_fused<KID, KOV, DTV, QL>(ctx, want_jac, final_, grid, kp, one, many, l0))))
+        if (ko == 2) {
+            if (D == 64) {
+                MRBF_EF(2, 4, false);
+            } else {
+                MRBF_EF(2, 8, true);
+            }
+            if (!final_) hipLaunchKernelGGL(eval_combine_kernel<2>, cgrid, dim3(128), 0, ctx->stream, one, many, l0, D);
+        } else {
+            if (D == 64) {
+                MRBF_EF(1, 4, false);
+            } else {
+                MRBF_EF(1, 8, false);
+            }
+            if (!final_) hipLaunchKernelGGL(eval_combine_kernel<1>, cgrid, dim3(128), 0, ctx->stream, one, many, l0, D);
+        }
+#undef MRBF_EF
+    }
+    MRBF_HIP(ctx, hipGetLastError());
+    return 0;
 }
 
 int eval_fused_batch(mrbf_ctx *ctx, const KP &kp, int D, int k, bool want_jac, const EvalDesc *host_descs, const EvalDesc *dev_descs, int count) {
@@ -342,25 +408,9 @@ int eval_fused_batch(mrbf_ctx *ctx, const KP &kp, int D, int k, bool want_jac, c
         max_split = std::max(max_split, host_descs[p].nsplit);
     }
     hipLaunchKernelGGL(center_pad_batch_kernel, dim3((unsigned)((max_mpad + 3) / 4), (unsigned)count), dim3(256), 0, ctx->stream, dev_descs, D);
-    const int KO = (k >= 2 && D == 64) ? 2 : 1;  // as eval_fused
     dim3 grid((unsigned)(max_mpad / EQ), (unsigned)max_split, (unsigned)count);
     dim3 cgrid((unsigned)max_m, (unsigned)count);
-    for (int l0 = 0; l0 < k; l0 += KO) {
-        const int ko = std::min(KO, k - l0);
-#define MRBF_EFB(KOV, DTV) MRBF_DISPATCH_KID(kp.kid, (launch_fused_batch<KID, KOV, DTV>(ctx, want_jac, grid, l0, kp, dev_descs)))
-        if (ko == 2) {
-            MRBF_EFB(2, 4);
-            hipLaunchKernelGGL(eval_combine_kernel<2>, cgrid, dim3(128), 0, ctx->stream, nullptr, nullptr, nullptr, 0, (int64_t)0, (int64_t)0, D, 0, 0, l0,
-                               nullptr, nullptr, nullptr, 0, nullptr, nullptr, dev_descs);
-        } else {
-            if (D == 64) { MRBF_EFB(1, 4); } else { MRBF_EFB(1, 8); }
-            hipLaunchKernelGGL(eval_combine_kernel<1>, cgrid, dim3(128), 0, ctx->stream, nullptr, nullptr, nullptr, 0, (int64_t)0, (int64_t)0, D, 0, 0, l0,
-                               nullptr, nullptr, nullptr, 0, nullptr, nullptr, dev_descs);
-        }
-#undef MRBF_EFB
-    }
-    MRBF_HIP(ctx, hipGetLastError());
-    return 0;
+    return run_passes(ctx, kp, D, k, want_jac, max_split == 1, grid, cgrid, host_descs[0], dev_descs);
 }
 
 int eval_fused(mrbf_ctx *ctx, const mrbf_model *M, int64_t m, const double *X, double *vals, double *jac, mrbf_eval_info *info) {
@@ -371,34 +421,38 @@ int eval_fused(mrbf_ctx *ctx, const mrbf_model *M, int64_t m, const double *X, d
     const int64_t mpad = round_up(m, EQ);
     const int ntiles = (int)(M->npad / EC);
     const int nsplit = eval_nsplit(ctx, m, M->npad);
-    const int tps = (ntiles + nsplit - 1) / nsplit;
-    double *Xq, *xsq, *vpart, *sapart, *gpart = nullptr;
-    MRBF_TRY(get_buf(ctx, S_EVAL_XC, (size_t)mpad * D, &Xq));
-    MRBF_TRY(get_buf(ctx, S_EVAL_XSQ, (size_t)mpad, &xsq));
-    const int KO = (k >= 2 && D == 64) ? 2 : 1;  // outputs per pass; at D = 128 two outputs would push the accumulators into
-                                                 // AGPRs, where the f64 MFMA runs at half rate (tools/microbench.py)
-    MRBF_TRY(get_buf(ctx, S_EVAL_SA, (size_t)nsplit * mpad * KO * 2, &vpart));
-    sapart = vpart + (size_t)nsplit * mpad * KO;
-    if (jac) MRBF_TRY(get_buf(ctx, S_EVAL_J, (size_t)nsplit * mpad * KO * D, &gpart));
+    const int KO = outputs_per_pass(k, D);
+    EvalDesc E;
+    std::memset(&E, 0, sizeof(E));
+    E.X = X;
+    E.mean = M->mean;
+    MRBF_TRY(get_buf(ctx, S_EVAL_XC, (size_t)mpad * D, &E.Xq));
+    MRBF_TRY(get_buf(ctx, S_EVAL_XSQ, (size_t)mpad, &E.xsq));
+    E.Cc = M->Xc;
+    E.csq = M->sq;
+    E.Wc = M->Wc;
+    E.lam = M->lam;
+    E.npad = M->npad;
+    E.mpad = mpad;
+    E.m = m;
+    E.d = d;
+    E.k = k;
+    E.q = q;
+    E.nsplit = nsplit;
+    E.tiles_per_split = (ntiles + nsplit - 1) / nsplit;
+    E.kp = M->kp;
+    if (nsplit > 1) {
+        MRBF_TRY(get_buf(ctx, S_EVAL_SA, (size_t)nsplit * mpad * KO * 2, &E.vpart));
+        E.sapart = E.vpart + (size_t)nsplit * mpad * KO;
+        if (jac) MRBF_TRY(get_buf(ctx, S_EVAL_J, (size_t)nsplit * mpad * KO * D, &E.gpart));
+    }
+    E.vals = vals;
+    E.jac = jac;
     const bool timing = ctx->timing && info;
     if (timing) MRBF_HIP(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
-    MRBF_TRY(launch_center_pad(ctx, X, m, d, M->mean, nullptr, Xq, mpad, D, xsq));
+    MRBF_TRY(launch_center_pad(ctx, X, m, d, M->mean, nullptr, E.Xq, mpad, D, E.xsq));
     dim3 grid((unsigned)(mpad / EQ), (unsigned)nsplit);
-    for (int l0 = 0; l0 < k; l0 += KO) {
-        const int ko = std::min(KO, k - l0);
-#define MRBF_EF(KOV, DTV) MRBF_DISPATCH_KID(M->kp.kid, (launch_fused<KID, KOV, DTV>(ctx, jac != nullptr, grid, Xq, xsq, M, l0, mpad, tps, vpart, sapart, gpart)))
-        if (ko == 2) {
-            MRBF_EF(2, 4);
-            hipLaunchKernelGGL(eval_combine_kernel<2>, dim3((unsigned)m), dim3(128), 0, ctx->stream, vpart, sapart, gpart, nsplit, mpad, m, D,
-                               d, k, l0, Xq, X, M->lam, q, vals, jac, (const EvalDesc *)nullptr);
-        } else {
-            if (D == 64) { MRBF_EF(1, 4); } else { MRBF_EF(1, 8); }
-            hipLaunchKernelGGL(eval_combine_kernel<1>, dim3((unsigned)m), dim3(128), 0, ctx->stream, vpart, sapart, gpart, nsplit, mpad, m, D,
-                               d, k, l0, Xq, X, M->lam, q, vals, jac, (const EvalDesc *)nullptr);
-        }
-#undef MRBF_EF
-    }
-    MRBF_HIP(ctx, hipGetLastError());
+    MRBF_TRY(run_passes(ctx, M->kp, D, k, jac != nullptr, nsplit == 1, grid, dim3((unsigned)m), E, nullptr));
     if (timing) {
         MRBF_HIP(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
         MRBF_HIP(ctx, hipEventSynchronize(ctx->ev[7]));

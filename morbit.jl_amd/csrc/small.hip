@@ -168,6 +168,13 @@ __global__ __launch_bounds__(256, 1) void small_fit_kernel(Prob one, const Prob 
            *T2 = ws + cv.T2, *Z = ws + cv.Z;
     const int ldz = cv.ldz;
     if (tid < 4) P.flags[tid] = 0;
+    int nstamp = 0;
+#define MRBF_STAMP()                                                              \
+    do {                                                                          \
+        if (P.stamps && tid == 0) P.stamps[nstamp] = (long long)wall_clock64();   \
+        ++nstamp;                                                                 \
+    } while (0)
+    MRBF_STAMP();
 
     // ---- centroid, centred + zero-padded coordinates, squared norms (the model's own arrays: the evaluation uses them later)
     if (tid < 128) {
@@ -196,6 +203,7 @@ __global__ __launch_bounds__(256, 1) void small_fit_kernel(Prob one, const Prob 
     }
     __syncthreads();
 
+    MRBF_STAMP();  // 1: centred
     // ---- Phi = phi(|x_i - x_j|): GEMM form on the centred coordinates, radial function in the epilogue; rows / columns >= n: identity
     {
         const double *XcT = P.Xc;  // dpad x np column-major
@@ -222,6 +230,7 @@ __global__ __launch_bounds__(256, 1) void small_fit_kernel(Prob one, const Prob 
     }
     __syncthreads();
 
+    MRBF_STAMP();  // 2: Gram
     const double rsn = 1.0 / sqrt((double)n);
     if (q > 0) {
         // ---- Q1 = [1/sqrt(n) | Xc Lx^-T]: orthonormal basis of the polynomial tail from the Cholesky-QR of the centred coordinates
@@ -251,6 +260,7 @@ __global__ __launch_bounds__(256, 1) void small_fit_kernel(Prob one, const Prob 
             });
         }
         __syncthreads();
+        MRBF_STAMP();  // 3: Q1
         // ---- W1 = Phi Q1;  G = Q1' W1;  W = W1 - 1/2 Q1 G;  mu = (n phi0 - trace G) / (n - q);  V = W - mu/2 Q1
         wg_gemm<false, false, false>(n16, q16, n16, Phi, np, Q1, np, [&](int i, int t, double v) { Wm[i + (int64_t)t * np] = v; });
         for (int e = tid; e < (np - n16) * q16; e += 256) Wm[n16 + e % (np - n16) + (int64_t)(e / (np - n16)) * np] = 0.0;
@@ -272,10 +282,12 @@ __global__ __launch_bounds__(256, 1) void small_fit_kernel(Prob one, const Prob 
         __syncthreads();
         for (int e = tid; e < np * q16; e += 256) V[e] = fma(-0.5 * mu, Q1[e], Wm[e]);
         __syncthreads();
+        MRBF_STAMP();  // 4: W, G, mu, V
         // ---- K = Phi - Q1 V' - V Q1' on the lower triangle (column-major: K(i, j), i >= j, at Phi[i + j * np])
         wg_gemm<false, true, true>(n16, n16, q16, Q1, np, V, np, [&](int i, int j, double v) { Phi[i + (int64_t)j * np] -= v; });
         __syncthreads();
         wg_gemm<false, true, true>(n16, n16, q16, V, np, Q1, np, [&](int i, int j, double v) { Phi[i + (int64_t)j * np] -= v; });
+        MRBF_STAMP();  // 5: K update (issued)
         // ---- B = P Y = Y - Q1 (Q1' Y);  T1 keeps Q1' Y for the tail coefficients
         wg_gemm<true, false, false>(q16, 16, n16, Q1, np, Yc, np, [&](int a, int l, double v) { T1[a + l * ldz] = v; });
         __syncthreads();
@@ -291,6 +303,7 @@ __global__ __launch_bounds__(256, 1) void small_fit_kernel(Prob one, const Prob 
     }
     __syncthreads();
 
+    MRBF_STAMP();  // 6: rhs
     // ---- factorisation K = L L'
     {
         const int bad = wg_potrf(Phi, np, np, n16, Linv, Pt, sh, &s_bad);
@@ -300,6 +313,7 @@ __global__ __launch_bounds__(256, 1) void small_fit_kernel(Prob one, const Prob 
         }
     }
     __syncthreads();
+    MRBF_STAMP();  // 7: potrf
     const int nb = np / 128;
     // ---- forward substitution L y = B (block rows; inv(L_cc) from the factorisation), then backward L' x = y
     for (int c = 0; c < nb; ++c) {
@@ -322,6 +336,7 @@ __global__ __launch_bounds__(256, 1) void small_fit_kernel(Prob one, const Prob 
                                     [&](int i, int l, double v) { Xs[128 * c + i + l * np] = v; });
         __syncthreads();
     }
+    MRBF_STAMP();  // 8: solves
     // ---- tail: re-project w (rounding hygiene), z = Q1' Y - W' w, lam = R^-1 z with R = [[sqrt n, sqrt n mean'], [0, Lx']]
     if (q > 0) {
         wg_gemm<true, false, false>(q16, 16, n16, Q1, np, Xs, np, [&](int a, int l, double v) { T2[a + l * ldz] = v; });
@@ -349,6 +364,7 @@ __global__ __launch_bounds__(256, 1) void small_fit_kernel(Prob one, const Prob 
             P.lam[(int64_t)t * k + l] = T2[t + l * ldz];
         }
     }
+    MRBF_STAMP();  // 9: tail
     // ---- the model's weights: W (n x k row-major), Wc (npad x k column-major, zero padded)
     for (int e = tid; e < np * k; e += 256) {
         const int i = e % np, l = e / np;

@@ -15,6 +15,7 @@ struct Prob {
     double *ws;                              // scratch, carve(npad, q16).total doubles
     int *flags;                              // [0] bad pivot of K (1-based), [1] bad pivot of the tail's Cholesky-QR, [2] shift not positive
     double *scal;                            // [0] trace(Q1' Phi Q1), [1] mu
+    long long *stamps;                       // debug (MRBF_SMALL_STAMPS): wall_clock64 at the phase boundaries, or NULL
 };
 
 struct Carve {
@@ -67,6 +68,7 @@ struct EvalDesc {
 // the centre-range split a single mrbf_eval of m points on a model with npad padded centres uses (the batch takes the same one, so
 // that a batch and single calls add up their partial sums in the same order)
 int eval_nsplit(const mrbf_ctx *ctx, int64_t m, int64_t npad);
+int outputs_per_pass(int k, int D);  // outputs of a model the fused evaluation handles per pass
 // all descriptors: same kernel id / fast flag / padded dimension D (64 or 128) / k; dev_descs = the same array in device memory
 int eval_fused_batch(mrbf_ctx *ctx, const KP &kp, int D, int k, bool want_jac, const EvalDesc *host_descs, const EvalDesc *dev_descs, int count);
 

@@ -693,6 +693,7 @@ void fill_small_prob(const mrbf_model *M, const double *Y, double *ws, int *flag
     P->ws = ws;
     P->flags = flags;
     P->scal = scal;
+    P->stamps = nullptr;
 }
 // what the flags of a small-problem fit mean for mrbf_fit_info (shared with the batched entry point): returns 1 when the problem
 // has to be re-done on the LU path
@@ -720,6 +721,12 @@ static int fit_small(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_inf
     MRBF_TRY(get_buf(ctx, S_SMALL_FLAGS, (size_t)4, &flags));
     MRBF_TRY(get_buf(ctx, S_MISC, (size_t)8, &scal));
     fill_small_prob(M, Y, ws, flags, scal, &P);
+    static const int want_stamps = getenv("MRBF_SMALL_STAMPS") ? atoi(getenv("MRBF_SMALL_STAMPS")) : 0;
+    long long *dstamps = nullptr;
+    if (want_stamps) {
+        MRBF_TRY(get_buf(ctx, S_SMALL_DESC, (size_t)16, &dstamps));
+        P.stamps = dstamps;
+    }
     MRBF_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     MRBF_TRY(launch_small_fit(ctx, &P, 1, nullptr));
     MRBF_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
@@ -729,6 +736,14 @@ static int fit_small(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_inf
     MRBF_HIP(ctx, hipMemcpyAsync(hscal, scal, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     MRBF_HIP(ctx, hipEventElapsedTime(&info->ms_factor, ctx->ev[0], ctx->ev[1]));  // one launch: assembly, projection, factorisation, solve
+    if (want_stamps) {
+        long long hs[16];
+        MRBF_HIP(ctx, hipMemcpy(hs, dstamps, sizeof(hs), hipMemcpyDeviceToHost));
+        static const char *names[] = {"centre", "gram", "Q1", "W,G,mu,V", "K update", "rhs", "potrf", "solves", "tail"};
+        fprintf(stderr, "small fit n=%lld d=%d q=%d: %.3f ms |", (long long)M->n, M->d, M->q, info->ms_factor);
+        for (int i = 0; i < 9; ++i) fprintf(stderr, " %s %.1f us |", names[i], (hs[i + 1] - hs[i]) * 0.01);
+        fprintf(stderr, "\n");
+    }
     *not_pd = small_fit_verdict(M, hflags, hscal, info);
     return 0;
 }
