@@ -45,6 +45,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--config", default="C3", choices=["C2", "C3", "C4", "C5"])
+    ap.add_argument("--no-batch", action="store_true", help="C4: per-problem mrbf_fit / mrbf_eval calls from worker threads instead of mrbf_batch_run")
     ap.add_argument("--problems", type=int, default=None, help="problems per step of the many-start configs (default: C4 64, C5 8 per rank)")
     ap.add_argument("--workers", type=int, default=0, help="host threads (contexts) per rank for the many-start configs (default: 4 for n <= 2048, else 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -249,16 +250,64 @@ def main():
                     self.fallbacks += 1
                 return [float(p), 0.0, float(finfo.path), float(finfo.rel_residual), 0.0, 0.0, finfo.ms_total, einfo.ms_total if m > 0 else 0.0]
 
-        workers = [Worker() for _ in range(nworkers)]
+        class BatchWorker:
+            """C4: all of this rank's problems through ONE mrbf_batch_run per step (one-launch small-problem fit + batched fused
+            evaluation, csrc/batch.hip); inputs and outputs are torch tensors resident in HBM, handed over as device pointers"""
+
+            def __init__(self):
+                self.ctx = pkg.Context(local_rank)          # keeps the device selected; the library pools its own batch contexts
+                self.lib = self.ctx.lib
+                self.finfo = _lib.FitInfo()
+                self.phases = {p: 0.0 for p in PH}
+                self.fallbacks = 0
+                self.factor_ms = []
+                P_ = len(mine)
+                self.arr = (_lib.Problem * max(P_, 1))()
+                self.res = (_lib.Result * max(P_, 1))()
+                self.keep = []
+                dp = lambda t: ctypes.cast(t.data_ptr(), _lib.c_dp)
+                for j, p in enumerate(mine):
+                    dC, dY, dX = dev[p]
+                    dV = torch.empty((max(m, 1), k), dtype=torch.float64, device="cuda")
+                    dJ = torch.empty((max(m, 1), d, k), dtype=torch.float64, device="cuda")
+                    dW = torch.empty((n, k), dtype=torch.float64, device="cuda")
+                    self.keep.append((dV, dJ, dW))
+                    self.arr[j] = _lib.Problem(n, m, d, k, kid, cfg["deg"], a, b, dp(dC), dp(dY), dp(dX), dp(dW), None, dp(dV), dp(dJ))
+
+            def step(self):
+                rc = self.lib.mrbf_batch_run(1, (ctypes.c_int32 * 1)(local_rank), len(mine), self.arr, self.res)
+                assert rc == 0, "mrbf_batch_run failed: %d" % rc
+                recs = []
+                for j, p in enumerate(mine):
+                    r = self.res[j]
+                    assert r.status == 0, (p, r.status)
+                    recs.append([float(p), 0.0, float(r.fit.path), float(r.fit.rel_residual), r.checksum_w, r.checksum_vals, r.fit.ms_total, r.ms_eval])
+                    if r.fit.fallbacks & ~_lib.FB_LU:
+                        self.fallbacks += 1
+                if mine:   # the batch's times are shared by its members: count them once per step, spread over the problems below
+                    self.phases["factor"] += self.res[0].fit.ms_factor
+                    self.phases["eval"] += self.res[0].ms_eval
+                    self.factor_ms.append(float(self.res[0].fit.ms_factor))
+                    self.finfo = self.res[0].fit
+                return recs
+
+        batched = many and n <= 512 and d <= 128 and not args.no_batch
+        workers = [BatchWorker()] if batched else [Worker() for _ in range(nworkers)]
         # one checked cycle per rank (residual through the eval kernels), then the timed loop without the extra check
         w0 = workers[0]
-        w0.ctx.set_option(_lib.OPT_RESIDUAL, 1)
-        if mine:
-            w0.cycle(mine[0])
-            check.update(path=w0.finfo.path, rel_residual=w0.finfo.rel_residual, max_pitw=w0.finfo.max_pitw)
-            assert w0.finfo.rel_residual < 1e-9, "fit residual too large: %r" % (check,)
-        for w in workers:
-            w.ctx.set_option(_lib.OPT_RESIDUAL, 0)
+        if batched:
+            if mine:   # (the batched path always carries its residual check: it runs beside the evaluation of the queries)
+                w0.step()
+                check.update(path=w0.finfo.path, rel_residual=w0.finfo.rel_residual, max_pitw=w0.finfo.max_pitw, batched=True)
+                assert w0.finfo.rel_residual < 1e-9, "fit residual too large: %r" % (check,)
+        else:
+            w0.ctx.set_option(_lib.OPT_RESIDUAL, 1)
+            if mine:
+                w0.cycle(mine[0])
+                check.update(path=w0.finfo.path, rel_residual=w0.finfo.rel_residual, max_pitw=w0.finfo.max_pitw)
+                assert w0.finfo.rel_residual < 1e-9, "fit residual too large: %r" % (check,)
+            for w in workers:
+                w.ctx.set_option(_lib.OPT_RESIDUAL, 0)
 
     pool = None
     if len(workers) > 1:
@@ -266,6 +315,10 @@ def main():
         pool = ThreadPoolExecutor(len(workers))
 
     def step():
+        if not dry and batched:
+            recs = workers[0].step()
+            local = np.asarray(recs, dtype=np.float64).reshape(-1, manystart.RECORD_LEN)
+            return manystart.gather_records(local, P, device=device)
         if pool is None:
             recs = [workers[0].cycle(p) for p in mine]
         else:  # worker w takes this rank's problems w, w + nworkers, ... (ctypes releases the GIL inside the library)
@@ -318,6 +371,7 @@ def main():
             "higher_is_better": True, "scaling": "strong" if many else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": cfg["desc"], "n": n, "d": d, "k": k, "m": m, "kernel": cfg["kernel"],
                        "polynomial_degree": cfg["deg"], "problems_per_step": P, "contexts_per_gpu": len(workers),
+                       "batched": bool(not dry and batched),
                        "parallelism": "problem-sharded x%d (problem p on rank p %% %d%s)" % (world, world, ", one all_gather of records per step" if many else "")},
             "rank_seconds": rank_times, "rank_imbalance": max(rank_times) / max(min(rank_times), 1e-12),
         }
@@ -329,18 +383,28 @@ def main():
             assert table.shape[0] == P and np.array_equal(table[:, 0], np.arange(P)), "record gather lost problems"
         if not dry:
             kernels = {
-                "gram": dict(bound="hbm", achieved=alg["gram_bytes"] / (phases["gram"] * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", ms=phases["gram"]),
-                "factor": dict(bound="mfma", achieved=alg["factor_flops"] / (phases["factor"] * 1e-3) / 1e12, peak=FP64_MFMA_PEAK_TF,
+                "gram": dict(bound="mfma" if d >= 96 else "hbm",
+                             achieved=(alg["gram_flops"] / max(phases["gram"], 1e-9) / 1e9) if d >= 96 else alg["gram_bytes"] / max(phases["gram"], 1e-9) / 1e6,
+                             peak=FP64_MFMA_PEAK_TF if d >= 96 else HBM_PEAK_GBS, unit="TFLOP/s" if d >= 96 else "GB/s", ms=phases["gram"]),
+                "factor": dict(bound="mfma", achieved=alg["factor_flops"] / max(phases["factor"] * 1e-3, 1e-12) / 1e12, peak=FP64_MFMA_PEAK_TF,
                                unit="TFLOP/s", ms=phases["factor"]),
                 "project": dict(bound="hbm", achieved=alg["project_bytes"] / max(phases["project"], 1e-9) / 1e6, peak=HBM_PEAK_GBS, unit="GB/s",
                                 ms=phases["project"], flops_tf=alg["project_flops"] / max(phases["project"], 1e-9) / 1e9),
             }
             if m > 0:
-                kernels["eval"] = dict(bound="mfma", achieved=alg["eval_flops"] / (phases["eval"] * 1e-3) / 1e12, peak=FP64_MFMA_PEAK_TF,
+                kernels["eval"] = dict(bound="mfma", achieved=alg["eval_flops"] / max(phases["eval"] * 1e-3, 1e-12) / 1e12, peak=FP64_MFMA_PEAK_TF,
                                        unit="TFLOP/s", ms=phases["eval"])
+            if batched:
+                # one launch does the whole fit of every problem of the batch (small_fit_kernel): one entry, priced with all of its flops
+                fit_flops = alg["gram_flops"] + alg["project_flops"] + alg["factor_flops"] + alg["solve_flops"]
+                kernels = {"fit": dict(bound="mfma", achieved=fit_flops / max(phases["factor"] * 1e-3, 1e-12) / 1e12, peak=FP64_MFMA_PEAK_TF,
+                                       unit="TFLOP/s", ms=phases["factor"], note="small_fit_kernel, whole batch in one launch; ms = batch time / problems"),
+                           "eval": kernels["eval"]}
             for kd in kernels.values():
                 kd["frac"] = kd["achieved"] / kd["peak"]
-            dom = max(("gram", "factor", "eval") if m > 0 else ("gram", "factor"), key=lambda p: phases[p])
+            dom = max([p for p in ("gram", "factor", "eval") if (p in kernels or p == "factor") and (m > 0 or p != "eval")], key=lambda p: phases[p])
+            if batched and dom == "factor":
+                dom = "fit"
             roof = dict(kernels[dom])
             roof["kernel"] = dom
             roof["traffic"] = None

@@ -221,8 +221,9 @@ typedef struct {
     int32_t device;   /* GPU that ran it */
     mrbf_fit_info fit;
     float ms_eval;
-    double checksum_w;    /* sum of weights (order-fixed reduction on the device) */
-    double checksum_vals; /* sum of values */
+    double checksum_w;    /* sum of weights: order-fixed reduction on the device for the problems of the batched small-problem path
+                             (batch.hip), a host loop over the output buffer for problems on the per-problem chain */
+    double checksum_vals; /* sum of values, likewise */
 } mrbf_result;
 
 int32_t mrbf_batch_run(int32_t n_dev, const int32_t *device_ids, int64_t n_problems, const mrbf_problem *problems,

@@ -413,7 +413,8 @@ struct DiagV6Shared {
     double Dt[2 * TILE];   // leaf hand-over: [col][32 rows], rows 16..31 the identity
     double Lb[2 * TILE];   // factored leaves (double-buffered: the storing wave reads one while the next is written)
     double DH[2 * TILE];   // diagonal tiles on their way to the leaf wave (double-buffered)
-    int bad;
+    int bad[2];            // failure word of leaf b in slot b & 1: the leaf wave may write leaf b + 1's word before a slower wave has
+                           // read leaf b's behind M_b -- with one word that wave would leave the loop one barrier early
 };
 
 __device__ __forceinline__ void diag_v6_load(const double *__restrict__ A, int64_t lda, v4d (&acc)[NSLOT6]) {
@@ -448,7 +449,7 @@ __device__ __forceinline__ int diag_v6_core(double *__restrict__ A, int64_t lda,
     // other waves may still be folding the caller's last panel into their tiles; they meet at M_0.  (The caller's LDS use ended
     // behind a barrier.)
     if (wave == 0) {
-        if (tid == 0) sh.bad = 0;
+        if (tid == 0) sh.bad[0] = sh.bad[1] = 0;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int e = lane_ + 64 * u;
@@ -488,7 +489,7 @@ __device__ __forceinline__ int diag_v6_core(double *__restrict__ A, int64_t lda,
             leaf_step<13>(a, bad, 16 * b);
             leaf_step<14>(a, bad, 16 * b);
             leaf_step<15>(a, bad, 16 * b);
-            if (bad && lane == 0) sh.bad = bad;
+            if (bad && lane == 0) sh.bad[bb] = bad;
             if (lane < 16) {
 #pragma unroll
                 for (int c = 0; c < 16; ++c) sh.Lb[bb * TILE + c * 16 + lane] = a[c];
@@ -501,7 +502,7 @@ __device__ __forceinline__ int diag_v6_core(double *__restrict__ A, int64_t lda,
         // every wave: its write-through stores of the previous panel (L tiles, leaf, inverse) are out before the panel is published
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // M_b
-        if (sh.bad) break;
+        if (sh.bad[bb]) break;
         if (b > 0 && tid == 64)
             __hip_atomic_store((__attribute__((address_space(1))) unsigned *)prog, (unsigned)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (wave == 0) {
@@ -597,7 +598,7 @@ __device__ __forceinline__ int diag_v6_core(double *__restrict__ A, int64_t lda,
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int lane = lane_, l15 = lane & 15, l4 = lane >> 4;
-    const int bad_all = sh.bad;
+    const int bad_all = sh.bad[0] ? (sh.bad[1] && sh.bad[1] < sh.bad[0] ? sh.bad[1] : sh.bad[0]) : sh.bad[1];
     if (bad_all) return bad_all;
     if (tid == 64) {
         __hip_atomic_store((__attribute__((address_space(1))) unsigned *)prog, (unsigned)NT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -639,6 +639,13 @@ static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info
         }
         info->factor_info = hinfo;
         if (q > 0) info->mu = hscal[1];
+        if (hflags[1] < 0) {
+            // the tail's Cholesky-QR ran through the persistent factorisation (d > 128) and THAT gave up on a dependency: not a rank
+            // deficiency -- same remedy as for the main factorisation (host-driven launches), not the LU of the saddle system
+            *gave_up = 1;
+            info->giveup_code = -hflags[1];
+            return 0;
+        }
         if (hflags[1] != 0) {  // affinely dependent sites: Pi is rank deficient
             *not_pd = 1;
             info->factor_info = -2;

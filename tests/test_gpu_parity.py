@@ -396,6 +396,62 @@ def test_full_size_properties_c2_c3(ctx):
     REPORT["full_size"] = out
 
 
+def test_c3_bench_workload_eval_against_oracle(ctx):
+    """The workload bench.py times (workloads.problem("C3"): n = 8192, d = 64, k = 2, multiquadric + degree-1 tail, m = 10 000 query
+    points -- the launch shape with the centre range split over gridDim.y and the combine kernel): the fit's interpolation residual,
+    and values / Jacobians of a strided subset of the 10 000-point launch against the oracle's evaluation of the SAME weights (this
+    isolates the evaluation at the shape that is timed; the weights themselves are checked through the residual and Pi'w)."""
+    from morbit.jl_amd import workloads as wl
+
+    C, Y, X = wl.problem("C3")
+    assert C.shape == (8192, 64) and X.shape == (10000, 64) and Y.shape[1] == 2
+    cfg = pkg.RbfConfig(kernel="multiquadric", polynomial_degree=1)
+    kid, a, b = pkg.rbf_model._get_kernel_params(1.0, cfg)
+    mod = pkg.update_model(cfg, C, Y, ctx=ctx)
+    assert mod.info["path"] == _lib.PATH_PROJ_CHOL and mod.info["fallbacks"] == 0
+    assert mod.info["rel_residual"] < 1e-10 and mod.info["max_pitw"] < 1e-8 * max(1.0, np.abs(mod.weights).max()), mod.info
+    V, J = mod.eval_sites(X, want_values=True, want_jac=True)          # the bench's launch: all 10 000 points, values + Jacobians
+    sub = np.arange(0, 10000, 39)[:256]
+    ref = orc.OracleModel(C, mod.weights, mod.poly, kid, a, b, 1)       # the oracle's formulas on the GPU's coefficients
+    ev = np.abs(V[sub] - ref.values(X[sub])).max() / max(1.0, np.abs(V).max())
+    ej = np.abs(J[sub] - ref.jacs(X[sub])).max() / max(1.0, np.abs(J).max())
+    assert ev < 1e-8 and ej < 1e-8, (ev, ej)
+    # the same points alone (another launch shape: one query tile, other split) give the same numbers to rounding
+    V2, J2 = mod.eval_sites(X[sub], want_values=True, want_jac=True)
+    assert np.abs(V2 - V[sub]).max() < 1e-12 * max(1.0, np.abs(V).max()) and np.abs(J2 - J[sub]).max() < 1e-11 * max(1.0, np.abs(J).max())
+    REPORT["c3_bench_workload"] = dict(values=ev, jac=ej, rel_residual=mod.info["rel_residual"])
+    mod.free()
+
+
+def test_c2_full_size_without_tail(ctx):
+    """the C2 variant without a polynomial tail (degree -1): the pure Cholesky path (path 1) at n = 2048, d = 32
+    through the one-launch factorisation, against the oracle's dense solve."""
+    from morbit.jl_amd import workloads as wl
+
+    C, Y, _ = wl.problem("C2")
+    assert C.shape == (2048, 32)
+    cfg = pkg.RbfConfig(kernel="gaussian", polynomial_degree=-1)
+    kid, a, b = pkg.rbf_model._get_kernel_params(1.0, cfg)
+    mod = pkg.update_model(cfg, C, Y, ctx=ctx)
+    assert mod.info["path"] == _lib.PATH_CHOL and mod.info["fallbacks"] == 0 and mod.info["q"] == 0
+    assert mod.info["rel_residual"] < 1e-9, mod.info
+    ref = orc.fit(C, Y, kid, a, b, -1)
+    Phi, Pi = orc.gram(C, kid, a, b, -1)
+    case = dict(Phi=Phi, Pi=Pi, Y=Y)
+    be, be_o = _backward_error(case, mod.weights, mod.poly), _backward_error(case, ref.w, ref.lam)
+    cond = float(np.linalg.cond(Phi))
+    assert be <= 50 * EPS, be
+    ew = np.abs(mod.weights - ref.w).max() / np.abs(ref.w).max()
+    assert ew < W_TOL or ew <= 4 * cond * (be + be_o), (ew, cond, be, be_o)
+    X = np.random.Generator(np.random.PCG64(6)).random((200, 32))
+    V, J = mod.eval_sites(X, want_values=True, want_jac=True)
+    assert np.abs(V - ref.values(X)).max() < 1e-8 * max(1.0, np.abs(V).max(), cond * EPS * 1e8)
+    refg = orc.OracleModel(C, mod.weights, mod.poly, kid, a, b, -1)
+    assert np.abs(V - refg.values(X)).max() < 1e-8 * max(1.0, np.abs(V).max()) and np.abs(J - refg.jacs(X)).max() < 1e-8 * max(1.0, np.abs(J).max())
+    REPORT["c2_deg-1_full_size"] = dict(cond=cond, backward_error=be, weights=ew, rel_residual=mod.info["rel_residual"])
+    mod.free()
+
+
 def test_batch_run_matches_single_calls(ctx):
     probs, keep = [], []
     P = 5
