@@ -229,6 +229,8 @@ def main():
                 self.phases = {p: 0.0 for p in PH}
                 self.fallbacks = 0
                 self.factor_ms = []   # per cycle: spread of the dominant kernel (a stalled persistent launch must show up here)
+                self.factor_dev_ms = []   # the same launches by the kernel's own clock (excludes host-side gaps between the events)
+                self.slow_launches = 0
 
             def cycle(self, p):
                 ctx, lib, finfo, einfo = self.ctx, self.ctx.lib, self.finfo, self.einfo
@@ -244,6 +246,8 @@ def main():
                 ph["project"] += finfo.ms_project
                 ph["factor"] += finfo.ms_factor
                 self.factor_ms.append(float(finfo.ms_factor))
+                self.factor_dev_ms.append(float(finfo.ms_factor_device))
+                self.slow_launches = int(finfo.slow_launches)
                 ph["solve"] += finfo.ms_solve
                 ph["eval"] += einfo.ms_total if m > 0 else 0.0
                 if finfo.fallbacks & ~_lib.FB_LU:
@@ -337,6 +341,8 @@ def main():
         w.fallbacks = 0
         if hasattr(w, "factor_ms"):
             w.factor_ms.clear()
+        if hasattr(w, "factor_dev_ms"):
+            w.factor_dev_ms.clear()
     barrier()
     t0 = time.perf_counter()
     table = None
@@ -362,6 +368,12 @@ def main():
     if fm:
         med = fm[len(fm) // 2]
         check["factor_ms"] = dict(min=fm[0], median=med, max=fm[-1], slow_launches=sum(1 for v in fm if v > 1.5 * med))
+    fd = sorted(v for w in workers for v in getattr(w, "factor_dev_ms", []) if v > 0)
+    if fd:
+        # the persistent factorisation's own clock (first workgroup in -> last workgroup out): a launch that is slow here stalled on the
+        # device; one that is slow in factor_ms only had a host-side gap inside the hipEvent bracket
+        check["factor_device_ms"] = dict(min=fd[0], median=fd[len(fd) // 2], max=fd[-1],
+                                         slow_launches_ctx=sum(getattr(w, "slow_launches", 0) for w in workers))
 
     if rank == 0:
         alg = wl.algorithmic(args.config)

@@ -83,6 +83,11 @@ enum {
     MRBF_OPT_CHOL_WINDOW = 8,  /* panels aggregated per trailing update: 0 = size-dependent schedule (default), else 1, 2 or 4 */
     MRBF_OPT_SPIN_MS = 9,      /* wall-clock limit (ms) a persistent kernel waits on one dependency without progress before it gives up
                                   and the call falls back to the host-driven GPU path (default 1000) */
+    MRBF_OPT_LAST_DEVICE_MS = 11, /* read only: time the last persistent factorisation spent on the device, by its own clock (first
+                                  workgroup in -> last workgroup out); unlike the hipEvent phases it excludes whatever the host did
+                                  between the events */
+    MRBF_OPT_SLOW_LAUNCHES = 12,  /* read only: persistent factorisations of this context that took more than twice the shortest seen
+                                  at their shape (cumulative) */
     MRBF_OPT_DEBUG_FAULT = 10  /* test hook: bit 0 = one workgroup of the persistent factorisation skips a publish, bit 1 = one workgroup of
                                   the persistent backward substitution does (the next fit must fall back and still return the right weights) */
 };
@@ -104,6 +109,9 @@ typedef struct {
     float ms_gram, ms_project, ms_factor, ms_solve, ms_check, ms_total; /* hipEvent times on the ctx stream */
     int32_t fallbacks;    /* MRBF_FB_* bits */
     int32_t giveup_code;  /* diagnostic code of the last give-up (0 if none) */
+    float ms_factor_device; /* persistent factorisation: its time by the launch's own clock (0 on other paths); ms_factor - this =
+                               host-side gaps inside the hipEvent bracket (descheduled launcher thread, job-table rebuild) */
+    int32_t slow_launches;  /* MRBF_OPT_SLOW_LAUNCHES of the context after this fit */
 } mrbf_fit_info;
 
 typedef struct {

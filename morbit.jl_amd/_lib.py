@@ -16,7 +16,7 @@ c_vp = ctypes.c_void_p
 MRBF_OK, MRBF_ENOTPD, MRBF_ESINGULAR, MRBF_EHIP, MRBF_EBLAS, MRBF_ENOMEM, MRBF_ENODEVICE, MRBF_ENCCL = range(8)
 PATH_CHOL, PATH_PROJ_CHOL, PATH_LU, PATH_MINNORM, PATH_ROUND4 = 1, 2, 3, 4, 5
 OPT_GRAM_MODE, OPT_RESIDUAL, OPT_FORCE_PATH, OPT_CHOL_IMPL, OPT_EVAL_IMPL, OPT_TIMING, OPT_DIAG_IMPL, OPT_CHOL_WINDOW = 1, 2, 3, 4, 5, 6, 7, 8
-OPT_SPIN_MS, OPT_DEBUG_FAULT = 9, 10
+OPT_SPIN_MS, OPT_DEBUG_FAULT, OPT_LAST_DEVICE_MS, OPT_SLOW_LAUNCHES = 9, 10, 11, 12
 FB_CHOL_HOST_DRIVEN, FB_BACKSOLVE_BLOCKED, FB_LU = 1, 2, 4
 
 
@@ -25,7 +25,8 @@ class FitInfo(ctypes.Structure):
                 ("rel_residual", ctypes.c_double), ("max_pitw", ctypes.c_double), ("mu", ctypes.c_double),
                 ("ms_gram", ctypes.c_float), ("ms_project", ctypes.c_float), ("ms_factor", ctypes.c_float),
                 ("ms_solve", ctypes.c_float), ("ms_check", ctypes.c_float), ("ms_total", ctypes.c_float),
-                ("fallbacks", ctypes.c_int32), ("giveup_code", ctypes.c_int32)]
+                ("fallbacks", ctypes.c_int32), ("giveup_code", ctypes.c_int32), ("ms_factor_device", ctypes.c_float),
+                ("slow_launches", ctypes.c_int32)]
 
     def asdict(self):
         return {f: getattr(self, f) for f, _ in self._fields_}

@@ -2,6 +2,8 @@
 //   impl 1: rocSOLVER dpotrf
 //   impl 2: built-in blocked right-looking Cholesky, host-driven launches (chol_blocked.hip)
 //   impl 3: the same factorisation as one persistent launch (chol_mega.hip)
+#include <chrono>
+
 #include "common.hpp"
 
 namespace mrbf {
@@ -35,6 +37,7 @@ int potrf_lower(mrbf_ctx *ctx, int impl, int64_t n, double *A, int64_t lda, int 
     }
     MRBF_HIP(ctx, hipMemcpyAsync(info_host, dinfo, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    MRBF_TRY(mega_collect_stat(ctx));
     return 0;
 }
 
@@ -56,10 +59,19 @@ extern "C" int32_t mrbf_debug_potrf(mrbf_ctx *ctx, int64_t n, double *A, int32_t
     MRBF_HIP(ctx, hipMemcpy2DAsync(dA, (size_t)npad * sizeof(double), A, (size_t)n * sizeof(double), (size_t)n * sizeof(double),
                                    (size_t)n, in, ctx->stream));
     int hinfo = 0;
+    static const double host_trace_ms = getenv("MRBF_MEGA_HOSTTRACE") ? atof(getenv("MRBF_MEGA_HOSTTRACE")) : 0.0;
+    auto now_ms = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double h0 = now_ms();
     MRBF_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-    MRBF_TRY(potrf_lower(ctx, impl, n, dA, npad, &hinfo));
+    const double h1 = now_ms();
+    MRBF_TRY(potrf_lower(ctx, impl, n, dA, npad, &hinfo));  // (ends with a stream synchronisation)
+    const double h2 = now_ms();
     MRBF_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     MRBF_HIP(ctx, hipEventSynchronize(ctx->ev[1]));
+    const double h3 = now_ms();
+    if (host_trace_ms > 0.0 && h3 - h0 > host_trace_ms)
+        fprintf(stderr, "mrbf_debug_potrf host trace (n %lld): record ev0 %.3f ms | potrf_lower incl. sync %.3f | record ev1 + sync %.3f\n", (long long)n,
+                h1 - h0, h2 - h1, h3 - h2);
     if (ms) MRBF_HIP(ctx, hipEventElapsedTime(ms, ctx->ev[0], ctx->ev[1]));
     if (info) *info = hinfo;
     MRBF_HIP(ctx, hipMemcpy2DAsync(A, (size_t)n * sizeof(double), dA, (size_t)npad * sizeof(double), (size_t)n * sizeof(double),

@@ -39,6 +39,8 @@
 // the workgroup meets at a barrier, ONE lane publishes the flag / counter with an agent-scope atomic; the consumer
 // polls that word with relaxed agent-scope loads, then ONE agent-scope acquire + s_waitcnt vmcnt(0) + barrier, then
 // plain loads.
+#include <chrono>
+
 #include "chol_diag_core.hpp"
 #include "common.hpp"
 
@@ -57,7 +59,7 @@ struct Job {
     short kind, i, c, w;
 };
 // control words (each on its own 128-byte line)
-enum { CTL_QP = 0, CTL_ABORT = 32, CTL_TIMEOUT = 64, CTL_PCOLS = 96, CTL_QC = 128, CTL_WORDS = 160 };
+enum { CTL_QP = 0, CTL_ABORT = 32, CTL_TIMEOUT = 64, CTL_PCOLS = 96, CTL_QC = 128, CTL_TS = 144 /* two 64-bit words: ~(first start), last end (wall_clock64) */, CTL_WORDS = 160 };
 constexpr int QSTRIDE = 32;  // one bulk-queue head per 128-byte line
 // Window w covers the panels [wstart(w), wstart(w+1)): the first window is shorter (`first` panels) so that bulk work
 // exists early in the launch, all others hold `win` panels.
@@ -773,7 +775,7 @@ __device__ __forceinline__ int pick_bulk(const Args &a, Shared &sh) {
     return -1;
 }
 
-__global__ __launch_bounds__(256, 2) void potrf_mega_kernel(const Args a) {
+__device__ __forceinline__ void mega_body(const Args &a) {
     __shared__ __attribute__((aligned(16))) Shared sh;
     const bool chain = (int)blockIdx.x < a.nchain;
     const bool dedicated = !chain && (int)blockIdx.x < a.nchain + a.ndedicated;
@@ -910,8 +912,22 @@ __global__ __launch_bounds__(256, 2) void potrf_mega_kernel(const Args a) {
     }
 }
 
-__global__ void mega_status_kernel(const unsigned *ctl, int *info) {
+// The launch's own clock: every workgroup stamps wall_clock64 (100 MHz) when it starts and when it leaves; first start and last end
+// are kept by 64-bit atomic max (the start inverted, so that the zeroed control block is the neutral element).  The difference is
+// the time the grid spent on the device, whatever the host did between the hipEvents that bracket the phase (a host thread that is
+// descheduled between recording the first event and launching the kernel shows up in the events, not here).
+__global__ __launch_bounds__(256, 2) void potrf_mega_kernel(const Args a) {
+    if (threadIdx.x == 0)
+        __hip_atomic_fetch_max((unsigned long long *)(a.ctl + CTL_TS), ~(unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    mega_body(a);
+    if (threadIdx.x == 0)
+        __hip_atomic_fetch_max((unsigned long long *)(a.ctl + CTL_TS + 2), (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ void mega_status_kernel(const unsigned *ctl, int *info, unsigned long long *stat) {
     if (ctl[CTL_TIMEOUT] != 0 && *info == 0) *info = -(int)ctl[CTL_TIMEOUT];
+    const unsigned long long *ts = (const unsigned long long *)(ctl + CTL_TS);
+    if (stat) stat[0] = (ts[0] != 0 && ts[1] != 0) ? ts[1] - ~ts[0] : 0ull;  // device time of the launch, 10-ns ticks
 }
 
 }  // namespace mega
@@ -926,6 +942,14 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
                     (long long)ncols, (long long)mrows, (long long)lda);
     const int NT = (int)(ncols / NB), MT = (int)(mrows / NB);
     if (MT > 32000) return fail(ctx, MRBF_EHIP, "potrf_mega: too many block rows");
+    // MRBF_MEGA_HOSTTRACE=<ms>: host-side time of every runtime call of this launcher, printed when the call as a whole took longer
+    static const double host_trace_ms = getenv("MRBF_MEGA_HOSTTRACE") ? atof(getenv("MRBF_MEGA_HOSTTRACE")) : 0.0;
+    double hstamp[8];
+    int nh = 0;
+    auto hnow = [&]() {
+        if (host_trace_ms > 0.0 && nh < 8) hstamp[nh++] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    };
+    hnow();
     Args a{};
     a.A = A;
     a.lda = lda;
@@ -952,8 +976,14 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
     const int win = std::max(1, ctx->mega_win > 0 ? ctx->mega_win : (NT >= 88 ? 8 : (NT >= 56 ? 6 : WIN_DEFAULT)));
     const int first = std::min(win, std::max(1, ctx->mega_first_window));
     const int srows = ctx->mega_srows > 0 ? ctx->mega_srows : srows_auto;  // streamed tiles below each diagonal block
-    if (ctx->mega_nt != NT || ctx->mega_mt != MT || ctx->mega_tab_slack != slack + 100 * ctx->mega_half_cols + 10000 * slack_chain + 1000000 * first + 10000000 * win + 100000000 * srows) {
-        ctx->mega_tab_slack = slack + 100 * ctx->mega_half_cols + 10000 * slack_chain + 1000000 * first + 10000000 * win + 100000000 * srows;
+    // job tables: one set per (NT, MT, schedule parameters), kept in a small per-context LRU -- Morbit's training sets grow and shrink
+    // by a few sites between iterations, so n keeps crossing 128-boundaries back and forth; rebuilding the tables on every change
+    // cost three copies and a stream synchronisation inside the factorisation phase
+    const long tab_key = slack + 100 * ctx->mega_half_cols + 10000 * slack_chain + 1000000 * first + 10000000 * win + 100000000 * (long)srows;
+    MegaTables *tab = nullptr;
+    for (auto &t : ctx->mega_tables)
+        if (t.nt == NT && t.mt == MT && t.key == tab_key) tab = &t;
+    if (!tab) {
         std::vector<Job> pj, bj;
         std::vector<Job> cj;
         for (int c = 0; c < NT; ++c) {
@@ -984,25 +1014,46 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
                 }
         }
         wqs.push_back((int)bj.size());
-        int *dwq;
-        MRBF_TRY(get_buf(ctx, S_MEGA_WQ, wqs.size(), &dwq));
-        MRBF_HIP(ctx, hipMemcpyAsync(dwq, wqs.data(), wqs.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-        ctx->mega_nwin = (int)wqs.size() - 1;
-        Job *dj;
-        MRBF_TRY(get_buf(ctx, S_MEGA_JOBS, pj.size() + bj.size() + cj.size() + 1, &dj));
-        if (!pj.empty()) MRBF_HIP(ctx, hipMemcpyAsync(dj, pj.data(), pj.size() * sizeof(Job), hipMemcpyHostToDevice, ctx->stream));
-        MRBF_HIP(ctx, hipMemcpyAsync(dj + pj.size() + bj.size(), cj.data(), cj.size() * sizeof(Job), hipMemcpyHostToDevice, ctx->stream));
-        ctx->mega_nchainjobs = (int)cj.size();
-        if (!bj.empty())
-            MRBF_HIP(ctx, hipMemcpyAsync(dj + pj.size(), bj.data(), bj.size() * sizeof(Job), hipMemcpyHostToDevice, ctx->stream));
-        MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the host vectors die here
-        ctx->mega_nt = NT;
-        ctx->mega_mt = MT;
-        ctx->mega_npanel = (int)pj.size();
-        ctx->mega_nbulk = (int)bj.size();
+        if (ctx->mega_tables.size() >= 8) {  // evict the least recently used set (nothing on the stream may still read it)
+            MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            size_t lru = 0;
+            for (size_t t = 1; t < ctx->mega_tables.size(); ++t)
+                if (ctx->mega_tables[t].stamp < ctx->mega_tables[lru].stamp) lru = t;
+            (void)hipFree(ctx->mega_tables[lru].block);
+            ctx->mega_tables.erase(ctx->mega_tables.begin() + lru);
+        }
+        MegaTables t{};
+        t.nt = NT;
+        t.mt = MT;
+        t.key = tab_key;
+        t.npanel = (int)pj.size();
+        t.nbulk = (int)bj.size();
+        t.nchainjobs = (int)cj.size();
+        t.nwin = (int)wqs.size() - 1;
+        const size_t job_bytes = (pj.size() + bj.size() + cj.size() + 1) * sizeof(Job), wq_bytes = wqs.size() * sizeof(int);
+        const size_t wq_off = (job_bytes + 255) & ~size_t(255);
+        MRBF_HIP(ctx, hipMalloc(&t.block, wq_off + wq_bytes));
+        // one host image, one copy (a synchronous hipMemcpy from pageable memory: the image may die right after it)
+        std::vector<char> img(wq_off + wq_bytes, 0);
+        Job *hj = (Job *)img.data();
+        std::copy(pj.begin(), pj.end(), hj);
+        std::copy(bj.begin(), bj.end(), hj + pj.size());
+        std::copy(cj.begin(), cj.end(), hj + pj.size() + bj.size());
+        std::memcpy(img.data() + wq_off, wqs.data(), wq_bytes);
+        MRBF_HIP(ctx, hipMemcpy(t.block, img.data(), img.size(), hipMemcpyHostToDevice));
+        t.jobs = t.block;
+        t.wq = (char *)t.block + wq_off;
+        ctx->mega_tables.push_back(t);
+        tab = &ctx->mega_tables.back();
     }
-    Job *dj;
-    MRBF_TRY(get_buf(ctx, S_MEGA_JOBS, (size_t)ctx->mega_npanel + ctx->mega_nbulk + ctx->mega_nchainjobs + 1, &dj));
+    tab->stamp = ++ctx->mega_table_clock;
+    ctx->mega_nt = NT;
+    ctx->mega_mt = MT;
+    ctx->mega_npanel = tab->npanel;
+    ctx->mega_nbulk = tab->nbulk;
+    ctx->mega_nchainjobs = tab->nchainjobs;
+    ctx->mega_nwin = tab->nwin;
+    Job *dj = (Job *)tab->jobs;
     a.cjobs = dj + ctx->mega_npanel + ctx->mega_nbulk;
     a.nchainjobs = ctx->mega_nchainjobs;
     a.pjobs = dj;
@@ -1010,15 +1061,16 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
     a.bjobs = dj + ctx->mega_npanel;
     a.nbulk = ctx->mega_nbulk;
     a.nwin = ctx->mega_nwin;
-    int *dwq;
-    MRBF_TRY(get_buf(ctx, S_MEGA_WQ, (size_t)a.nwin + 1, &dwq));
-    a.wq_start = dwq;
+    a.wq_start = (int *)tab->wq;
     // flags: one block, zeroed before every launch
     const size_t nfl = ((size_t)CTL_WORDS + (size_t)QSTRIDE * (a.nwin + 1) + (size_t)QSTRIDE * 512 + (size_t)QSTRIDE * (1 + srows) * NT + 2 * (size_t)MT * NT + 3) / 4 * 4;
     unsigned *fl;
     MRBF_TRY(get_buf(ctx, S_MEGA_FLAGS, nfl, &fl));
+    hnow();  // 1: buffers / job tables
     MRBF_HIP(ctx, hipMemsetAsync(fl, 0, nfl * sizeof(unsigned), ctx->stream));
+    hnow();  // 2: first memset enqueued
     MRBF_HIP(ctx, hipMemsetAsync(dinfo, 0, sizeof(int), ctx->stream));
+    hnow();  // 3: second memset enqueued
     a.ctl = fl;
     a.wq_head = fl + CTL_WORDS;
     a.quiet = a.wq_head + (size_t)QSTRIDE * (a.nwin + 1);
@@ -1057,6 +1109,7 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
         MRBF_HIP(ctx, hipMemsetAsync(a.jlog, 0, ((size_t)8 * a.jlog_cap + 16) * sizeof(unsigned long long), ctx->stream));
     }
     hipLaunchKernelGGL(potrf_mega_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, a);
+    hnow();  // 4: persistent kernel enqueued
     if (jlog_path) {
         std::vector<unsigned long long> h((size_t)8 * a.jlog_cap + 16);
         MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1116,7 +1169,16 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
         }
     }
     // a launch that gave up reports through dinfo as well
-    hipLaunchKernelGGL(mega_status_kernel, dim3(1), dim3(1), 0, ctx->stream, (const unsigned *)fl, dinfo);
+    unsigned long long *dstat;
+    MRBF_TRY(get_buf(ctx, S_MEGA_STAT, (size_t)2, &dstat));
+    hipLaunchKernelGGL(mega_status_kernel, dim3(1), dim3(1), 0, ctx->stream, (const unsigned *)fl, dinfo, dstat);
+    ctx->mega_stat_dev = dstat;
+    ctx->mega_stat_shape = (long)NT * 100000 + MT;
+    ctx->mega_stat_pending = 1;
+    hnow();  // 5: status kernel enqueued
+    if (host_trace_ms > 0.0 && nh == 6 && hstamp[5] - hstamp[0] > host_trace_ms)
+        fprintf(stderr, "potrf_mega_tall host trace (NT %d): buffers/tables %.3f ms | memset flags %.3f | memset info %.3f | kernel launch %.3f | status launch %.3f\n", NT,
+                hstamp[1] - hstamp[0], hstamp[2] - hstamp[1], hstamp[3] - hstamp[2], hstamp[4] - hstamp[3], hstamp[5] - hstamp[4]);
     if (getenv("MRBF_MEGA_DEBUG")) {
         unsigned h[CTL_WORDS];
         MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));

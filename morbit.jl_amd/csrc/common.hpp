@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -34,13 +35,24 @@ enum Slot {
     S_XC = 0, S_SQ, S_MEAN, S_PHI, S_PI, S_Q1, S_W1, S_G, S_R, S_TAU, S_RHS, S_T1, S_T2, S_IPIV, S_INFO,
     S_STAGE_A, S_STAGE_B, S_STAGE_C, S_STAGE_D, S_EVAL_E, S_EVAL_A, S_EVAL_J, S_EVAL_SA, S_EVAL_XC, S_EVAL_XSQ,
     S_OUT_A, S_OUT_B, S_CHOL_WS, S_MISC, S_MEGA_JOBS, S_MEGA_FLAGS, S_MEGA_WQ, S_MEGA_IT, S_BSOLVE_FLAGS, S_MEGA_TRACE, S_MEGA_JLOG,
-    S_T1W, S_PS_STATE, S_PS_STAT, S_PS_POLISH, S_BSOLVE_X, S_V0, S_QR_INV, S_DIAG_SCR, S_SMALL_WS, S_SMALL_DESC, S_SMALL_FLAGS, S_NSLOTS
+    S_T1W, S_PS_STATE, S_PS_STAT, S_PS_POLISH, S_BSOLVE_X, S_V0, S_QR_INV, S_DIAG_SCR, S_SMALL_WS, S_SMALL_DESC, S_SMALL_FLAGS, S_MEGA_STAT, S_NSLOTS
 };
 struct Buf {
     void *p = nullptr;
     size_t bytes = 0;
 };
 
+}  // namespace mrbf
+
+namespace mrbf {
+// job tables of the persistent factorisation for one shape (chol_mega.hip), device resident
+struct MegaTables {
+    int nt, mt;
+    long key;
+    void *block, *jobs, *wq;
+    int npanel, nbulk, nchainjobs, nwin;
+    unsigned long long stamp;
+};
 }  // namespace mrbf
 
 struct mrbf_ctx {
@@ -67,6 +79,16 @@ struct mrbf_ctx {
     // bounded spins of the persistent kernels: wall-clock limit without progress (ms); debug_fault makes ONE workgroup of the named
     // kernel skip a publish so that the give-up paths can be tested deterministically (bit 0: factorisation, bit 1: backward substitution)
     int spin_ms = 1000, debug_fault = 0;
+    // the persistent factorisation's own clock (chol_mega.hip): device time of the last launch, the shortest seen per shape, and the
+    // number of launches of this context that took more than twice that (a stalled persistent launch must be visible to callers)
+    unsigned long long *mega_stat_dev = nullptr;
+    long mega_stat_shape = 0;
+    int mega_stat_pending = 0;
+    float last_device_ms = 0.f;
+    int slow_launches = 0;
+    std::map<long, float> mega_best_ms;
+    std::vector<mrbf::MegaTables> mega_tables;  // LRU of job tables, one set per shape
+    unsigned long long mega_table_clock = 0;
 };
 
 struct mrbf_model {
@@ -142,5 +164,7 @@ int build_model_shell(mrbf_ctx *ctx, int64_t n, int d, int k, const double *Cdev
                       mrbf_model **out);
 void destroy_model(mrbf_ctx *ctx, mrbf_model *M);
 int fit_check(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info *info);
+// chol_mega.hip's launch clock: call after the stream has been synchronised behind a persistent factorisation
+int mega_collect_stat(mrbf_ctx *ctx);
 
 }  // namespace mrbf

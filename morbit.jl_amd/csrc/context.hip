@@ -123,6 +123,26 @@ int finish_out(mrbf_ctx *ctx, double *user, const double *dev, size_t count) {
     return 0;
 }
 
+int mega_collect_stat(mrbf_ctx *ctx) {
+    if (!ctx->mega_stat_pending || !ctx->mega_stat_dev) return 0;
+    ctx->mega_stat_pending = 0;
+    unsigned long long ticks = 0;
+    MRBF_HIP(ctx, hipMemcpy(&ticks, ctx->mega_stat_dev, sizeof(ticks), hipMemcpyDeviceToHost));
+    const float ms = (float)((double)ticks * 1e-5);  // wall_clock64 runs at 100 MHz
+    ctx->last_device_ms = ms;
+    if (ms > 0.f) {
+        auto it = ctx->mega_best_ms.find(ctx->mega_stat_shape);
+        if (it == ctx->mega_best_ms.end()) {
+            if (ctx->mega_best_ms.size() > 256) ctx->mega_best_ms.clear();
+            ctx->mega_best_ms[ctx->mega_stat_shape] = ms;
+        } else {
+            if (ms > 2.f * it->second) ++ctx->slow_launches;
+            if (ms < it->second) it->second = ms;
+        }
+    }
+    return 0;
+}
+
 }  // namespace mrbf
 
 using namespace mrbf;
@@ -220,6 +240,8 @@ int32_t mrbf_shutdown(mrbf_ctx *ctx) {
         if (b.p) (void)hipFree(b.p);
     for (auto &b : ctx->model_pool)
         if (b.p) (void)hipFree(b.p);
+    for (auto &t : ctx->mega_tables)
+        if (t.block) (void)hipFree(t.block);
     for (auto &ev : ctx->ev)
         if (ev) (void)hipEventDestroy(ev);
     for (auto &ev : ctx->evx)
@@ -271,6 +293,8 @@ int32_t mrbf_get_option(const mrbf_ctx *ctx, int32_t key, double *value) {
         case MRBF_OPT_CHOL_WINDOW: *value = ctx->chol_window; break;
         case MRBF_OPT_SPIN_MS: *value = ctx->spin_ms; break;
         case MRBF_OPT_DEBUG_FAULT: *value = ctx->debug_fault; break;
+        case MRBF_OPT_LAST_DEVICE_MS: *value = ctx->last_device_ms; break;
+        case MRBF_OPT_SLOW_LAUNCHES: *value = ctx->slow_launches; break;
         default: return -2;
     }
     return MRBF_OK;

@@ -629,6 +629,8 @@ static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info
         MRBF_HIP(ctx, hipMemcpyAsync(hflags, dinfo, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         if (q > 0) MRBF_HIP(ctx, hipMemcpyAsync(hscal, scal, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        MRBF_TRY(mega_collect_stat(ctx));
+        info->ms_factor_device = ctx->last_device_ms;
         hinfo = hflags[0];
         if (hinfo < 0) {
             // the persistent factorisation gave up on a dependency (bounded wait): the matrix is half factored, the caller
@@ -835,6 +837,7 @@ int fit_model(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info *info
     if (path == MRBF_PATH_LU) MRBF_TRY(fit_lu(ctx, M, Y, info));
     if (ctx->residual) MRBF_TRY(fit_check(ctx, M, Y, info));
     info->ms_total = info->ms_gram + info->ms_project + info->ms_factor + info->ms_solve;
+    info->slow_launches = ctx->slow_launches;
     return 0;
 }
 

@@ -19,11 +19,12 @@
 
 const libmrbf = get(ENV, "MRBF_LIB", "libmrbf.so")
 
-struct MrbfFitInfo          # mirrors mrbf_fit_info (include/mrbf.h), 72 bytes
+struct MrbfFitInfo          # mirrors mrbf_fit_info (include/mrbf.h), 80 bytes
     path::Int32; factor_info::Int32; n::Int32; q::Int32
     rel_residual::Float64; max_pitw::Float64; mu::Float64
     ms_gram::Float32; ms_project::Float32; ms_factor::Float32; ms_solve::Float32; ms_check::Float32; ms_total::Float32
     fallbacks::Int32; giveup_code::Int32
+    ms_factor_device::Float32; slow_launches::Int32
 end
 struct MrbfPsOptions        # mirrors mrbf_ps_options, 40 bytes
     max_ideal_evals::Int32; max_ps_evals::Int32; max_polish_evals::Int32; reserved::Int32

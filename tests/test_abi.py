@@ -44,12 +44,12 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 def test_struct_layouts_match_header():
     from morbit.jl_amd import _lib
 
-    assert ctypes.sizeof(_lib.FitInfo) == 4 * 4 + 3 * 8 + 6 * 4 + 2 * 4 == 72
+    assert ctypes.sizeof(_lib.FitInfo) == 4 * 4 + 3 * 8 + 6 * 4 + 2 * 4 + 2 * 4 == 80
     assert ctypes.sizeof(_lib.EvalInfo) == 16
     assert ctypes.sizeof(_lib.Problem) == 2 * 8 + 4 * 4 + 2 * 8 + 7 * 8 == 104
     assert _lib.Result.fit.offset == 8
     assert ctypes.sizeof(_lib.PsOptions) == 40 and ctypes.sizeof(_lib.PsInfo) == 32 and _lib.PsInfo.tau.offset == 24
-    assert ctypes.sizeof(_lib.Result) == 8 + 72 + 8 + 16
+    assert ctypes.sizeof(_lib.Result) == 8 + 80 + 8 + 16
     assert ctypes.sizeof(_lib.PsProblem) == 72 and _lib.PsProblem.eq_tol.offset == 64 and _lib.PsProblem.n_lin_eq.offset == 24
 
 
