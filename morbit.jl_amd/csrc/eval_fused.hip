@@ -189,19 +189,33 @@ __global__ __launch_bounds__(256, (DT <= 4) ? 2 : 1) void eval_fused_kernel(Eval
         const double *__restrict__ Xorig = E.X;
         double *__restrict__ vals = E.vals;
         double *__restrict__ jac = E.jac;
+        // polynomial tail of the value, p_l(x) = lam_0l + sum_t lam_tl (xc_t + mean_t): the centred coordinates are at hand (query
+        // fragments), the tail coefficients of this pass and the centroid go through LDS once per workgroup; lane (query l15, part l4)
+        // takes the coordinates 4 s + l4, the four parts are added in a fixed order
+        if (vals) {
+            __syncthreads();  // the last centre tile is done: its LDS area holds the coefficients now
+            double *Lm = Cs;  // KOUT x D tail coefficients, then D centroid entries
+            for (int e = tid; e < (KOUT + 1) * D; e += 256) {
+                const int l = e / D, t = e % D;
+                Lm[e] = (t < d && q > 1) ? (l < KOUT ? (l0 + l < k ? lam[(int64_t)(t + 1) * k + l0 + l] : 0.0) : E.mean[t]) : 0.0;
+            }
+            __syncthreads();
 #pragma unroll
-        for (int l = 0; l < KOUT; ++l) {
-            // polynomial tail of the value: lanes (query l15, part l4) take the coordinates t = l4, l4 + 4, ...; fixed-order reduction
-            double v = vsum[l];
-            if (vals && l0 + l < k) {
-                double acc = 0.0;
-                if (q > 1 && qrow < m)
-                    for (int t = l4; t < d; t += 4) acc = fma(lam[(int64_t)(t + 1) * k + l0 + l], Xorig[qrow * d + t], acc);
+            for (int l = 0; l < KOUT; ++l) {
+                double acc = 0.0, cst = 0.0;
+#pragma unroll
+                for (int s = 0; s < D / 4; ++s) {
+                    const double xq = QLDS ? Xs[(wave * 16 + l15) * LDC + 4 * s + l4] : xb[QLDS ? 0 : s];
+                    acc = fma(Lm[l * D + 4 * s + l4], xq, acc);
+                }
+                for (int t = lane; t < D; t += 64) cst = fma(Lm[l * D + t], Lm[KOUT * D + t], cst);
+                for (int off = 32; off > 0; off >>= 1) cst += __shfl_xor(cst, off);
                 acc += __shfl_xor(acc, 16);
                 acc += __shfl_xor(acc, 32);
-                if (q > 0) v += lam[l0 + l];
-                if (q > 1) v += acc;
-                if (l4 == 0 && qrow < m) vals[qrow * k + l0 + l] = v;
+                double v = vsum[l];
+                if (q > 0 && l0 + l < k) v += lam[l0 + l];
+                if (q > 1) v += acc + cst;
+                if (l4 == 0 && qrow < m && l0 + l < k) vals[qrow * k + l0 + l] = v;
             }
         }
         if (JAC && jac) {
@@ -231,6 +245,217 @@ __global__ __launch_bounds__(256, (DT <= 4) ? 2 : 1) void eval_fused_kernel(Eval
                 }
                 __syncthreads();
             }
+        }
+    }
+}
+
+// ---- D = 128: the same evaluation with the 128 coordinates cut in two halves over two groups of four waves (512 threads) -----
+// With D = 128 one wave cannot hold the Jacobian accumulators of two outputs (2 x 8 tiles = 128 VGPRs) next to its query fragments and
+// the staged centre tile: the compiler moved them to AGPRs, where the f64 MFMA issues at half rate, and one wave per SIMD left
+// nothing to overlap the radial function and the LDS traffic with.  Here group g (waves 4g .. 4g + 3) owns coordinates 64 g .. 64 g + 63:
+//   phase 1  each group sums its half of <cc_c, xc_q> (16 MFMAs per 16 x 16 tile), the halves meet through LDS (one barrier per
+//            16-centre step, slots double-buffered by the step's parity) and are added in the fixed order  S = S_0 + S_1;
+//   phase 2  both groups apply the radial function to the same S (the VALU work is duplicated; it runs under the partner's MFMAs);
+//   phase 3  each group accumulates its 64 Jacobian columns (2 outputs x 4 tiles = 64 VGPRs: no AGPRs, two waves per SIMD).
+// No matrix-core work is duplicated: 16 + 32 MFMAs per group and step against 32 + 64 for one wave.
+template <int KID, bool FAST, int KOUT, bool JAC, bool FINAL>
+__global__ __launch_bounds__(512, 2) void eval_fused128_kernel(EvalDesc one, const EvalDesc *__restrict__ many, int l0) {
+    constexpr int D = 128, H = 64, LDC = D + 2, LDT = H + 1;
+    __shared__ __attribute__((aligned(16))) double Cs[EC * LDC];  // centre tile; the epilogue's transpose area (8 waves x 16 x LDT)
+    __shared__ double Ws[KOUT * EC];
+    __shared__ double Sq[EC];
+    __shared__ double Sx[2 * 8 * 256];                            // partial S tiles of the eight waves, two parities
+    const EvalDesc &E = many ? many[blockIdx.z] : one;
+    if (many && ((int64_t)blockIdx.x * EQ >= E.mpad || (int)blockIdx.y >= E.nsplit)) return;
+    const double *__restrict__ Xq = E.Xq;
+    const double *__restrict__ Cc = E.Cc;
+    const double *__restrict__ csq = E.csq;
+    const double *__restrict__ Wc = E.Wc;
+    const int64_t npad = E.npad, mpad = E.mpad;
+    const int tiles_per_split = E.tiles_per_split;
+    const KP kp = E.kp;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = wave >> 2, qw = wave & 3;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int64_t q0 = (int64_t)blockIdx.x * EQ;
+    const int split = blockIdx.y;
+    const int64_t qrow = q0 + qw * 16 + l15;
+    double xb[H / 4];  // this group's half of the query fragments: k-slice s -> Xq[qrow][64 grp + 4 s + l4]
+#pragma unroll
+    for (int s = 0; s < H / 4; ++s) xb[s] = Xq[qrow * D + H * grp + 4 * s + l4];
+    const double xs = E.xsq[qrow];
+    v4d JT[KOUT][4];
+    double vsum[KOUT], sasum[KOUT];
+#pragma unroll
+    for (int l = 0; l < KOUT; ++l) {
+        vsum[l] = 0.0;
+        sasum[l] = 0.0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) JT[l][t] = (v4d){0.0, 0.0, 0.0, 0.0};
+    }
+    const int64_t c_begin = (int64_t)split * tiles_per_split * EC;
+    const int ntiles_all = (int)(npad / EC);
+    const int my_tiles = min(tiles_per_split, ntiles_all - split * tiles_per_split);
+    constexpr int NLD = 8;  // 64 * 128 / 2 v2d over 512 threads
+    v2d stg[NLD];
+    auto load_tile = [&](int64_t c0) {
+        const v2d *src = reinterpret_cast<const v2d *>(Cc + c0 * D);
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) stg[u] = src[tid + 512 * u];
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int e = (tid + 512 * u) * 2;
+            const int row = e / D, col = e % D;
+            *(v2d *)&Cs[row * LDC + col] = stg[u];
+        }
+    };
+    load_tile(c_begin);
+    for (int tile = 0; tile < my_tiles; ++tile) {
+        const int64_t c0 = c_begin + (int64_t)tile * EC;
+        __syncthreads();
+        store_tile();
+        if (tid < EC) Sq[tid] = csq[c0 + tid];
+        for (int e = tid; e < KOUT * EC; e += 512) Ws[e] = Wc[(int64_t)(l0 + e / EC) * npad + c0 + (e % EC)];
+        __syncthreads();
+        if (tile + 1 < my_tiles) load_tile(c0 + EC);
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            // ---- phase 1: this group's half of S', exchanged with the partner wave (same queries, other half)
+            v4d Sp = {0.0, 0.0, 0.0, 0.0};
+            const double *crow = &Cs[(16 * ct + l15) * LDC + H * grp + l4];
+#pragma unroll
+            for (int s = 0; s < H / 4; ++s) Sp = __builtin_amdgcn_mfma_f64_16x16x4f64(crow[4 * s], xb[s], Sp, 0, 0, 0);
+            double *mine = &Sx[((ct & 1) * 8 + wave) * 256];
+            const double *theirs = &Sx[((ct & 1) * 8 + (wave ^ 4)) * 256];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mine[r * 64 + lane] = Sp[r];
+            __syncthreads();
+            v4d S;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double o = theirs[r * 64 + lane];
+                S[r] = grp == 0 ? Sp[r] + o : o + Sp[r];  // S_0 + S_1 in both groups
+            }
+            // ---- phase 2
+            v4d Aw[KOUT];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = 16 * ct + l4 + 4 * r;
+                double s2 = fma(-2.0, S[r], xs + Sq[c]);
+                s2 = s2 > 0.0 ? s2 : 0.0;
+                double phi, psi;
+                rbf_phi_psi_t<KID, FAST>(s2, kp, phi, psi);
+#pragma unroll
+                for (int l = 0; l < KOUT; ++l) {
+                    const double w = Ws[l * EC + c];
+                    vsum[l] = fma(w, phi, vsum[l]);
+                    const double a = w * psi;
+                    sasum[l] += a;
+                    Aw[l][r] = a;
+                }
+            }
+            // ---- phase 3: this group's 64 Jacobian columns
+            if (JAC) {
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const double cop = Cs[(16 * ct + 4 * s + l4) * LDC + H * grp + 16 * tt + l15];
+#pragma unroll
+                        for (int l = 0; l < KOUT; ++l) JT[l][tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(cop, Aw[l][s], JT[l][tt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int l = 0; l < KOUT; ++l) {
+        vsum[l] += __shfl_xor(vsum[l], 16);
+        vsum[l] += __shfl_xor(vsum[l], 32);
+        sasum[l] += __shfl_xor(sasum[l], 16);
+        sasum[l] += __shfl_xor(sasum[l], 32);
+    }
+    const int d = E.d, k = E.k, q = E.q;
+    const int64_t m = E.m;
+    const double *__restrict__ lam = E.lam;
+    const double *__restrict__ Xorig = E.X;
+    double *__restrict__ vals = E.vals;
+    double *__restrict__ jac = E.jac;
+    if constexpr (!FINAL) {
+        if (l4 == 0 && grp == 0) {
+#pragma unroll
+            for (int l = 0; l < KOUT; ++l) {
+                E.vpart[((int64_t)split * mpad + qrow) * KOUT + l] = vsum[l];
+                E.sapart[((int64_t)split * mpad + qrow) * KOUT + l] = sasum[l];
+            }
+        }
+    } else if (vals) {
+        // polynomial tail of the value, p_l(x) = lam_0l + sum_t lam_tl (xc_t + mean_t), from the query fragments (see eval_fused_kernel):
+        // each group sums its 64 coordinates, group 1 hands its part to group 0 through LDS
+        __syncthreads();
+        double *Lm = Sx;                    // KOUT x 128 tail coefficients, then 128 centroid entries (the exchange slots are free now)
+        double *Pp = Sx + (KOUT + 1) * D;   // KOUT x 64 partial sums of group 1
+        for (int e = tid; e < (KOUT + 1) * D; e += 512) {
+            const int l = e / D, t = e % D;
+            Lm[e] = (t < d && q > 1) ? (l < KOUT ? (l0 + l < k ? lam[(int64_t)(t + 1) * k + l0 + l] : 0.0) : E.mean[t]) : 0.0;
+        }
+        __syncthreads();
+        double accs[KOUT], csts[KOUT];
+#pragma unroll
+        for (int l = 0; l < KOUT; ++l) {
+            double acc = 0.0, cst = 0.0;
+#pragma unroll
+            for (int s = 0; s < H / 4; ++s) acc = fma(Lm[l * D + H * grp + 4 * s + l4], xb[s], acc);
+            for (int t = lane; t < D; t += 64) cst = fma(Lm[l * D + t], Lm[KOUT * D + t], cst);
+            for (int off = 32; off > 0; off >>= 1) cst += __shfl_xor(cst, off);
+            acc += __shfl_xor(acc, 16);
+            acc += __shfl_xor(acc, 32);
+            accs[l] = acc;
+            csts[l] = cst;
+            if (grp == 1 && l4 == 0) Pp[l * EQ + qw * 16 + l15] = acc;
+        }
+        __syncthreads();
+        if (grp == 0 && l4 == 0 && qrow < m) {
+#pragma unroll
+            for (int l = 0; l < KOUT; ++l) {
+                if (l0 + l >= k) continue;
+                double v = vsum[l];
+                if (q > 0) v += lam[l0 + l];
+                if (q > 1) v += (accs[l] + Pp[l * EQ + qw * 16 + l15]) + csts[l];
+                vals[qrow * k + l0 + l] = v;
+            }
+        }
+    }
+    if (JAC && (!FINAL || jac)) {
+        __syncthreads();  // every wave is done with the last centre tile
+        double *T = Cs + wave * 16 * LDT;
+        double *SA = Ws;  // KOUT x 64
+        if (FINAL && grp == 0 && l4 == 0) {
+#pragma unroll
+            for (int l = 0; l < KOUT; ++l) SA[l * EQ + qw * 16 + l15] = sasum[l];
+        }
+#pragma unroll
+        for (int l = 0; l < KOUT; ++l) {
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) T[l15 * LDT + 16 * tt + l4 + 4 * r] = JT[l][tt][r];
+            __syncthreads();
+            for (int e = lane; e < 16 * H; e += 64) {
+                const int qq = e / H, t = e % H, col = H * grp + t;
+                const int64_t row = q0 + qw * 16 + qq;
+                if constexpr (!FINAL) {
+                    E.gpart[(((int64_t)split * mpad + row) * KOUT + l) * D + col] = T[qq * LDT + t];
+                } else {
+                    if (l0 + l < k && row < m && col < d) {
+                        double v = fma(SA[l * EQ + qw * 16 + qq], Xq[row * D + col], -T[qq * LDT + t]);
+                        if (q > 1) v += lam[(int64_t)(col + 1) * k + l0 + l];
+                        jac[row * (int64_t)k * d + (int64_t)col * k + l0 + l] = v;
+                    }
+                }
+            }
+            __syncthreads();
         }
     }
 }
@@ -362,6 +587,27 @@ static int launch_fused3(mrbf_ctx *ctx, bool want_jac, bool final_, dim3 grid, c
 #undef MRBF_EFL
     return 0;
 }
+template <int KID, bool FAST, int KOUT>
+static int launch_fused128b(mrbf_ctx *ctx, bool want_jac, bool final_, dim3 grid, const EvalDesc &one, const EvalDesc *many, int l0) {
+#define MRBF_EFL(JACV, FINV) hipLaunchKernelGGL((eval_fused128_kernel<KID, FAST, KOUT, JACV, FINV>), grid, dim3(512), 0, ctx->stream, one, many, l0)
+    if (want_jac && final_)
+        MRBF_EFL(true, true);
+    else if (want_jac)
+        MRBF_EFL(true, false);
+    else if (final_)
+        MRBF_EFL(false, true);
+    else
+        MRBF_EFL(false, false);
+#undef MRBF_EFL
+    return 0;
+}
+template <int KID, int KOUT>
+static int launch_fused128(mrbf_ctx *ctx, bool want_jac, bool final_, dim3 grid, const KP &kp, const EvalDesc &one, const EvalDesc *many, int l0) {
+    if (kp.fast && (KID == MRBF_MULTIQUADRIC || KID == MRBF_INV_MULTIQUADRIC || KID == MRBF_CUBIC))
+        return launch_fused128b<KID, true, KOUT>(ctx, want_jac, final_, grid, one, many, l0);
+    return launch_fused128b<KID, false, KOUT>(ctx, want_jac, final_, grid, one, many, l0);
+}
+
 template <int KID, int KOUT, int DT, bool QLDS>
 static int launch_fused(mrbf_ctx *ctx, bool want_jac, bool final_, dim3 grid, const KP &kp, const EvalDesc &one, const EvalDesc *many, int l0) {
     if (kp.fast && (KID == MRBF_MULTIQUADRIC || KID == MRBF_INV_MULTIQUADRIC || KID == MRBF_CUBIC))
@@ -376,9 +622,13 @@ static int run_passes(mrbf_ctx *ctx, const KP &kp, int D, int k, bool want_jac, 
     for (int l0 = 0; l0 < k; l0 += KO) {
         const int ko = std::min(KO, k - l0);
 #define MRBF_EF(KOV, DTV, QL) MRBF_DISPATCH_KID(kp.kid, MRBF_TRY((launch_fused<KID, KOV, DTV, QL>(ctx, want_jac, final_, grid, kp, one, many, l0))))
+        static const int split128 = getenv("MRBF_EVAL_SPLIT128") ? atoi(getenv("MRBF_EVAL_SPLIT128")) : 1;
+#define MRBF_EF128(KOV) MRBF_DISPATCH_KID(kp.kid, MRBF_TRY((launch_fused128<KID, KOV>(ctx, want_jac, final_, grid, kp, one, many, l0))))
         if (ko == 2) {
             if (D == 64) {
                 MRBF_EF(2, 4, false);
+            } else if (split128) {
+                MRBF_EF128(2);
             } else {
                 MRBF_EF(2, 8, true);
             }
@@ -386,12 +636,15 @@ static int run_passes(mrbf_ctx *ctx, const KP &kp, int D, int k, bool want_jac, 
         } else {
             if (D == 64) {
                 MRBF_EF(1, 4, false);
+            } else if (split128) {
+                MRBF_EF128(1);
             } else {
                 MRBF_EF(1, 8, false);
             }
             if (!final_) hipLaunchKernelGGL(eval_combine_kernel<1>, cgrid, dim3(128), 0, ctx->stream, one, many, l0, D);
         }
 #undef MRBF_EF
+#undef MRBF_EF128
     }
     MRBF_HIP(ctx, hipGetLastError());
     return 0;

@@ -111,10 +111,9 @@ __device__ __forceinline__ double rbf_phi_t(double s, const KP &p) {
         fast_sqrt_rsqrt(fma(p.a2, s, 1.0), sq, rs);
         return rs;
     } else if constexpr (KID == MRBF_CUBIC && FAST) {
-        if (s <= 0.0) return 0.0;
-        double sq, rs;
-        fast_sqrt_rsqrt(s, sq, rs);
-        return p.sgn * s * sq;
+        double sq, rs;  // branch-free: the root of a stand-in for s <= 0, the result selected afterwards
+        fast_sqrt_rsqrt(s > 0.0 ? s : 1.0, sq, rs);
+        return s > 0.0 ? p.sgn * s * sq : 0.0;
     } else {
         return rbf_phi<KID>(s, p);
     }
@@ -134,15 +133,10 @@ __device__ __forceinline__ void rbf_phi_psi_t(double s, const KP &p, double &phi
         phi = rs;
         psi = -p.a2 * rs * rs * rs;
     } else if constexpr (KID == MRBF_CUBIC && FAST) {
-        if (s <= 0.0) {
-            phi = 0.0;
-            psi = 0.0;
-        } else {
-            double sq, rs;
-            fast_sqrt_rsqrt(s, sq, rs);
-            phi = p.sgn * s * sq;
-            psi = p.sgn * 3.0 * sq;
-        }
+        double sq, rs;  // branch-free (see rbf_phi_t)
+        fast_sqrt_rsqrt(s > 0.0 ? s : 1.0, sq, rs);
+        phi = s > 0.0 ? p.sgn * s * sq : 0.0;
+        psi = s > 0.0 ? p.sgn * 3.0 * sq : 0.0;
     } else {
         rbf_phi_psi<KID>(s, p, phi, psi);
     }
