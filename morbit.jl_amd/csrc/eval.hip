@@ -173,7 +173,7 @@ int eval_model(mrbf_ctx *ctx, const mrbf_model *M, int64_t m, const double *Xdev
     if (info) std::memset(info, 0, sizeof(*info));
     if (m <= 0) return 0;
     if (M->n == 0) return fail(ctx, -2, "model has no centres");
-    if (ctx->eval_impl != 1 && (M->dpad == 64 || M->dpad == 128)) return eval_fused(ctx, M, m, Xdev, vals_dev, jac_dev, info);
+    if (ctx->eval_impl != 1 && (M->dpad == 64 || M->dpad == 128 || M->dpad == 256)) return eval_fused(ctx, M, m, Xdev, vals_dev, jac_dev, info);
     return eval_gemm_pipeline(ctx, M, m, Xdev, vals_dev, jac_dev, info);
 }
 

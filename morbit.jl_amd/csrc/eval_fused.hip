@@ -249,22 +249,26 @@ __global__ __launch_bounds__(256, (DT <= 4) ? 2 : 1) void eval_fused_kernel(Eval
     }
 }
 
-// ---- D = 128: the same evaluation with the 128 coordinates cut in two halves over two groups of four waves (512 threads) -----
+// ---- D = 128 / 256: the same evaluation with the coordinates cut in two halves over two groups of four waves (512 threads) -----
 // With D = 128 one wave cannot hold the Jacobian accumulators of two outputs (2 x 8 tiles = 128 VGPRs) next to its query fragments and
 // the staged centre tile: the compiler moved them to AGPRs, where the f64 MFMA issues at half rate, and one wave per SIMD left
-// nothing to overlap the radial function and the LDS traffic with.  Here group g (waves 4g .. 4g + 3) owns coordinates 64 g .. 64 g + 63:
-//   phase 1  each group sums its half of <cc_c, xc_q> (16 MFMAs per 16 x 16 tile), the halves meet through LDS (one barrier per
+// nothing to overlap the radial function and the LDS traffic with.  Here group g (waves 4g .. 4g + 3) owns coordinates H g .. H g + H - 1
+// (H = D / 2):
+//   phase 1  each group sums its half of <cc_c, xc_q> (H / 4 MFMAs per 16 x 16 tile), the halves meet through LDS (one barrier per
 //            16-centre step, slots double-buffered by the step's parity) and are added in the fixed order  S = S_0 + S_1;
 //   phase 2  both groups apply the radial function to the same S (the VALU work is duplicated; it runs under the partner's MFMAs);
-//   phase 3  each group accumulates its 64 Jacobian columns (2 outputs x 4 tiles = 64 VGPRs: no AGPRs, two waves per SIMD).
-// No matrix-core work is duplicated: 16 + 32 MFMAs per group and step against 32 + 64 for one wave.
-template <int KID, bool FAST, int KOUT, bool JAC, bool FINAL>
-__global__ __launch_bounds__(512, 2) void eval_fused128_kernel(EvalDesc one, const EvalDesc *__restrict__ many, int l0) {
-    constexpr int D = 128, H = 64, LDC = D + 2, LDT = H + 1;
-    __shared__ __attribute__((aligned(16))) double Cs[EC * LDC];  // centre tile; the epilogue's transpose area (8 waves x 16 x LDT)
-    __shared__ double Ws[KOUT * EC];
-    __shared__ double Sq[EC];
-    __shared__ double Sx[2 * 8 * 256];                            // partial S tiles of the eight waves, two parities
+//   phase 3  each group accumulates its H Jacobian columns (KOUT x H / 16 tiles: 64 VGPRs, no AGPRs, two waves per SIMD).
+// No matrix-core work is duplicated.  H = 64 (D = 128): two outputs per pass, 64-centre tiles.  H = 128 (D = 256, the C5 models): one
+// output per pass, 32-centre tiles (LDS), replaces the rocBLAS pipeline of eval.hip for 128 < d <= 256.
+template <int KID, bool FAST, int KOUT, int H, int ECT, bool JAC, bool FINAL>
+__global__ __launch_bounds__(512, 2) void eval_fused_split_kernel(EvalDesc one, const EvalDesc *__restrict__ many, int l0) {
+    constexpr int D = 2 * H, LDC = D + 2, LDT = 65, NCT = ECT / 16, HT = H / 16;
+    static_assert(8 * 16 * LDT <= ECT * LDC + 2 * 8 * 256, "epilogue transpose area");
+    __shared__ __attribute__((aligned(16))) double smem[ECT * LDC + 2 * 8 * 256];
+    double *Cs = smem;              // centre tile; the epilogue's transpose area (8 waves x 16 x LDT, reaching into Sx)
+    double *Sx = smem + ECT * LDC;  // partial S tiles of the eight waves, two parities; the epilogue's coefficient area
+    __shared__ double Ws[KOUT * ECT];
+    __shared__ double Sq[ECT];
     const EvalDesc &E = many ? many[blockIdx.z] : one;
     if (many && ((int64_t)blockIdx.x * EQ >= E.mpad || (int)blockIdx.y >= E.nsplit)) return;
     const double *__restrict__ Xq = E.Xq;
@@ -272,30 +276,30 @@ __global__ __launch_bounds__(512, 2) void eval_fused128_kernel(EvalDesc one, con
     const double *__restrict__ csq = E.csq;
     const double *__restrict__ Wc = E.Wc;
     const int64_t npad = E.npad, mpad = E.mpad;
-    const int tiles_per_split = E.tiles_per_split;
     const KP kp = E.kp;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = wave >> 2, qw = wave & 3;
     const int l15 = lane & 15, l4 = lane >> 4;
     const int64_t q0 = (int64_t)blockIdx.x * EQ;
     const int split = blockIdx.y;
     const int64_t qrow = q0 + qw * 16 + l15;
-    double xb[H / 4];  // this group's half of the query fragments: k-slice s -> Xq[qrow][64 grp + 4 s + l4]
+    double xb[H / 4];  // this group's half of the query fragments: k-slice s -> Xq[qrow][H grp + 4 s + l4]
 #pragma unroll
     for (int s = 0; s < H / 4; ++s) xb[s] = Xq[qrow * D + H * grp + 4 * s + l4];
     const double xs = E.xsq[qrow];
-    v4d JT[KOUT][4];
+    v4d JT[KOUT][HT];
     double vsum[KOUT], sasum[KOUT];
 #pragma unroll
     for (int l = 0; l < KOUT; ++l) {
         vsum[l] = 0.0;
         sasum[l] = 0.0;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) JT[l][t] = (v4d){0.0, 0.0, 0.0, 0.0};
+        for (int t = 0; t < HT; ++t) JT[l][t] = (v4d){0.0, 0.0, 0.0, 0.0};
     }
-    const int64_t c_begin = (int64_t)split * tiles_per_split * EC;
+    // the descriptor counts centre tiles of EC = 64; this kernel walks them in pieces of ECT
+    const int64_t c_begin = (int64_t)split * E.tiles_per_split * EC;
     const int ntiles_all = (int)(npad / EC);
-    const int my_tiles = min(tiles_per_split, ntiles_all - split * tiles_per_split);
-    constexpr int NLD = 8;  // 64 * 128 / 2 v2d over 512 threads
+    const int my_tiles = min(E.tiles_per_split, ntiles_all - split * E.tiles_per_split) * (EC / ECT);
+    constexpr int NLD = ECT * D / 2 / 512;
     v2d stg[NLD];
     auto load_tile = [&](int64_t c0) {
         const v2d *src = reinterpret_cast<const v2d *>(Cc + c0 * D);
@@ -312,22 +316,23 @@ __global__ __launch_bounds__(512, 2) void eval_fused128_kernel(EvalDesc one, con
     };
     load_tile(c_begin);
     for (int tile = 0; tile < my_tiles; ++tile) {
-        const int64_t c0 = c_begin + (int64_t)tile * EC;
+        const int64_t c0 = c_begin + (int64_t)tile * ECT;
         __syncthreads();
         store_tile();
-        if (tid < EC) Sq[tid] = csq[c0 + tid];
-        for (int e = tid; e < KOUT * EC; e += 512) Ws[e] = Wc[(int64_t)(l0 + e / EC) * npad + c0 + (e % EC)];
+        if (tid < ECT) Sq[tid] = csq[c0 + tid];
+        for (int e = tid; e < KOUT * ECT; e += 512) Ws[e] = Wc[(int64_t)(l0 + e / ECT) * npad + c0 + (e % ECT)];
         __syncthreads();
-        if (tile + 1 < my_tiles) load_tile(c0 + EC);
+        if (tile + 1 < my_tiles) load_tile(c0 + ECT);
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
+        for (int ct = 0; ct < NCT; ++ct) {
             // ---- phase 1: this group's half of S', exchanged with the partner wave (same queries, other half)
             v4d Sp = {0.0, 0.0, 0.0, 0.0};
             const double *crow = &Cs[(16 * ct + l15) * LDC + H * grp + l4];
 #pragma unroll
             for (int s = 0; s < H / 4; ++s) Sp = __builtin_amdgcn_mfma_f64_16x16x4f64(crow[4 * s], xb[s], Sp, 0, 0, 0);
-            double *mine = &Sx[((ct & 1) * 8 + wave) * 256];
-            const double *theirs = &Sx[((ct & 1) * 8 + (wave ^ 4)) * 256];
+            const int par = (tile * NCT + ct) & 1;
+            double *mine = &Sx[(par * 8 + wave) * 256];
+            const double *theirs = &Sx[(par * 8 + (wave ^ 4)) * 256];
 #pragma unroll
             for (int r = 0; r < 4; ++r) mine[r * 64 + lane] = Sp[r];
             __syncthreads();
@@ -348,17 +353,17 @@ __global__ __launch_bounds__(512, 2) void eval_fused128_kernel(EvalDesc one, con
                 rbf_phi_psi_t<KID, FAST>(s2, kp, phi, psi);
 #pragma unroll
                 for (int l = 0; l < KOUT; ++l) {
-                    const double w = Ws[l * EC + c];
+                    const double w = Ws[l * ECT + c];
                     vsum[l] = fma(w, phi, vsum[l]);
                     const double a = w * psi;
                     sasum[l] += a;
                     Aw[l][r] = a;
                 }
             }
-            // ---- phase 3: this group's 64 Jacobian columns
+            // ---- phase 3: this group's H Jacobian columns
             if (JAC) {
 #pragma unroll
-                for (int tt = 0; tt < 4; ++tt) {
+                for (int tt = 0; tt < HT; ++tt) {
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
                         const double cop = Cs[(16 * ct + 4 * s + l4) * LDC + H * grp + 16 * tt + l15];
@@ -379,7 +384,6 @@ __global__ __launch_bounds__(512, 2) void eval_fused128_kernel(EvalDesc one, con
     const int d = E.d, k = E.k, q = E.q;
     const int64_t m = E.m;
     const double *__restrict__ lam = E.lam;
-    const double *__restrict__ Xorig = E.X;
     double *__restrict__ vals = E.vals;
     double *__restrict__ jac = E.jac;
     if constexpr (!FINAL) {
@@ -392,9 +396,9 @@ __global__ __launch_bounds__(512, 2) void eval_fused128_kernel(EvalDesc one, con
         }
     } else if (vals) {
         // polynomial tail of the value, p_l(x) = lam_0l + sum_t lam_tl (xc_t + mean_t), from the query fragments (see eval_fused_kernel):
-        // each group sums its 64 coordinates, group 1 hands its part to group 0 through LDS
+        // each group sums its H coordinates, group 1 hands its part to group 0 through LDS
         __syncthreads();
-        double *Lm = Sx;                    // KOUT x 128 tail coefficients, then 128 centroid entries (the exchange slots are free now)
+        double *Lm = Sx;                    // KOUT x D tail coefficients, then D centroid entries (the exchange slots are free now)
         double *Pp = Sx + (KOUT + 1) * D;   // KOUT x 64 partial sums of group 1
         for (int e = tid; e < (KOUT + 1) * D; e += 512) {
             const int l = e / D, t = e % D;
@@ -428,9 +432,11 @@ __global__ __launch_bounds__(512, 2) void eval_fused128_kernel(EvalDesc one, con
         }
     }
     if (JAC && (!FINAL || jac)) {
-        __syncthreads();  // every wave is done with the last centre tile
-        double *T = Cs + wave * 16 * LDT;
-        double *SA = Ws;  // KOUT x 64
+        __syncthreads();  // every wave is done with the last centre tile (and with the coefficient area)
+        double *T = smem + wave * 16 * LDT;
+        double *SA = Ws;  // KOUT x 64 is at most KOUT x ECT only for ECT = 64: the sums go to Sq's neighbour otherwise
+        __shared__ double SAs[KOUT * EQ];
+        SA = SAs;
         if (FINAL && grp == 0 && l4 == 0) {
 #pragma unroll
             for (int l = 0; l < KOUT; ++l) SA[l * EQ + qw * 16 + l15] = sasum[l];
@@ -438,24 +444,27 @@ __global__ __launch_bounds__(512, 2) void eval_fused128_kernel(EvalDesc one, con
 #pragma unroll
         for (int l = 0; l < KOUT; ++l) {
 #pragma unroll
-            for (int tt = 0; tt < 4; ++tt)
+            for (int hc = 0; hc < H / 64; ++hc) {  // 64 Jacobian columns at a time through the transpose area
 #pragma unroll
-                for (int r = 0; r < 4; ++r) T[l15 * LDT + 16 * tt + l4 + 4 * r] = JT[l][tt][r];
-            __syncthreads();
-            for (int e = lane; e < 16 * H; e += 64) {
-                const int qq = e / H, t = e % H, col = H * grp + t;
-                const int64_t row = q0 + qw * 16 + qq;
-                if constexpr (!FINAL) {
-                    E.gpart[(((int64_t)split * mpad + row) * KOUT + l) * D + col] = T[qq * LDT + t];
-                } else {
-                    if (l0 + l < k && row < m && col < d) {
-                        double v = fma(SA[l * EQ + qw * 16 + qq], Xq[row * D + col], -T[qq * LDT + t]);
-                        if (q > 1) v += lam[(int64_t)(col + 1) * k + l0 + l];
-                        jac[row * (int64_t)k * d + (int64_t)col * k + l0 + l] = v;
+                for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) T[l15 * LDT + 16 * tt + l4 + 4 * r] = JT[l][4 * hc + tt][r];
+                __syncthreads();
+                for (int e = lane; e < 16 * 64; e += 64) {
+                    const int qq = e / 64, t = e % 64, col = H * grp + 64 * hc + t;
+                    const int64_t row = q0 + qw * 16 + qq;
+                    if constexpr (!FINAL) {
+                        E.gpart[(((int64_t)split * mpad + row) * KOUT + l) * D + col] = T[qq * LDT + t];
+                    } else {
+                        if (l0 + l < k && row < m && col < d) {
+                            double v = fma(SA[l * EQ + qw * 16 + qq], Xq[row * D + col], -T[qq * LDT + t]);
+                            if (q > 1) v += lam[(int64_t)(col + 1) * k + l0 + l];
+                            jac[row * (int64_t)k * d + (int64_t)col * k + l0 + l] = v;
+                        }
                     }
                 }
+                __syncthreads();
             }
-            __syncthreads();
         }
     }
 }
@@ -569,6 +578,7 @@ int eval_nsplit(const mrbf_ctx *ctx, int64_t m, int64_t npad) {
 // outputs per pass: two when the model has several (at D = 128 with the query block in LDS)
 int outputs_per_pass(int k, int D) {
     static const int ko128 = getenv("MRBF_EVAL_KO128") ? atoi(getenv("MRBF_EVAL_KO128")) : 2;
+    if (D == 256) return 1;  // the Jacobian tiles of one output fill the accumulator budget
     return k >= 2 ? (D == 128 ? ko128 : 2) : 1;
 }
 
@@ -587,9 +597,10 @@ static int launch_fused3(mrbf_ctx *ctx, bool want_jac, bool final_, dim3 grid, c
 #undef MRBF_EFL
     return 0;
 }
-template <int KID, bool FAST, int KOUT>
-static int launch_fused128b(mrbf_ctx *ctx, bool want_jac, bool final_, dim3 grid, const EvalDesc &one, const EvalDesc *many, int l0) {
-#define MRBF_EFL(JACV, FINV) hipLaunchKernelGGL((eval_fused128_kernel<KID, FAST, KOUT, JACV, FINV>), grid, dim3(512), 0, ctx->stream, one, many, l0)
+template <int KID, bool FAST, int KOUT, int H, int ECT>
+static int launch_split_b(mrbf_ctx *ctx, bool want_jac, bool final_, dim3 grid, const EvalDesc &one, const EvalDesc *many, int l0) {
+#define MRBF_EFL(JACV, FINV) \
+    hipLaunchKernelGGL((eval_fused_split_kernel<KID, FAST, KOUT, H, ECT, JACV, FINV>), grid, dim3(512), 0, ctx->stream, one, many, l0)
     if (want_jac && final_)
         MRBF_EFL(true, true);
     else if (want_jac)
@@ -601,11 +612,11 @@ static int launch_fused128b(mrbf_ctx *ctx, bool want_jac, bool final_, dim3 grid
 #undef MRBF_EFL
     return 0;
 }
-template <int KID, int KOUT>
-static int launch_fused128(mrbf_ctx *ctx, bool want_jac, bool final_, dim3 grid, const KP &kp, const EvalDesc &one, const EvalDesc *many, int l0) {
+template <int KID, int KOUT, int H, int ECT>
+static int launch_split(mrbf_ctx *ctx, bool want_jac, bool final_, dim3 grid, const KP &kp, const EvalDesc &one, const EvalDesc *many, int l0) {
     if (kp.fast && (KID == MRBF_MULTIQUADRIC || KID == MRBF_INV_MULTIQUADRIC || KID == MRBF_CUBIC))
-        return launch_fused128b<KID, true, KOUT>(ctx, want_jac, final_, grid, one, many, l0);
-    return launch_fused128b<KID, false, KOUT>(ctx, want_jac, final_, grid, one, many, l0);
+        return launch_split_b<KID, true, KOUT, H, ECT>(ctx, want_jac, final_, grid, one, many, l0);
+    return launch_split_b<KID, false, KOUT, H, ECT>(ctx, want_jac, final_, grid, one, many, l0);
 }
 
 template <int KID, int KOUT, int DT, bool QLDS>
@@ -623,8 +634,12 @@ static int run_passes(mrbf_ctx *ctx, const KP &kp, int D, int k, bool want_jac, 
         const int ko = std::min(KO, k - l0);
 #define MRBF_EF(KOV, DTV, QL) MRBF_DISPATCH_KID(kp.kid, MRBF_TRY((launch_fused<KID, KOV, DTV, QL>(ctx, want_jac, final_, grid, kp, one, many, l0))))
         static const int split128 = getenv("MRBF_EVAL_SPLIT128") ? atoi(getenv("MRBF_EVAL_SPLIT128")) : 1;
-#define MRBF_EF128(KOV) MRBF_DISPATCH_KID(kp.kid, MRBF_TRY((launch_fused128<KID, KOV>(ctx, want_jac, final_, grid, kp, one, many, l0))))
-        if (ko == 2) {
+#define MRBF_EF128(KOV) MRBF_DISPATCH_KID(kp.kid, MRBF_TRY((launch_split<KID, KOV, 64, 64>(ctx, want_jac, final_, grid, kp, one, many, l0))))
+#define MRBF_EF256() MRBF_DISPATCH_KID(kp.kid, MRBF_TRY((launch_split<KID, 1, 128, 32>(ctx, want_jac, final_, grid, kp, one, many, l0))))
+        if (D == 256) {
+            MRBF_EF256();
+            if (!final_) hipLaunchKernelGGL(eval_combine_kernel<1>, cgrid, dim3(128), 0, ctx->stream, one, many, l0, D);
+        } else if (ko == 2) {
             if (D == 64) {
                 MRBF_EF(2, 4, false);
             } else if (split128) {
@@ -645,6 +660,7 @@ static int run_passes(mrbf_ctx *ctx, const KP &kp, int D, int k, bool want_jac, 
         }
 #undef MRBF_EF
 #undef MRBF_EF128
+#undef MRBF_EF256
     }
     MRBF_HIP(ctx, hipGetLastError());
     return 0;
@@ -652,7 +668,7 @@ static int run_passes(mrbf_ctx *ctx, const KP &kp, int D, int k, bool want_jac, 
 
 int eval_fused_batch(mrbf_ctx *ctx, const KP &kp, int D, int k, bool want_jac, const EvalDesc *host_descs, const EvalDesc *dev_descs, int count) {
     if (count <= 0) return 0;
-    if (D != 64 && D != 128) return fail(ctx, MRBF_EHIP, "eval_fused_batch needs dpad in {64, 128}");
+    if (D != 64 && D != 128 && D != 256) return fail(ctx, MRBF_EHIP, "eval_fused_batch needs dpad in {64, 128, 256}");
     int64_t max_mpad = 0, max_m = 0;
     int max_split = 1;
     for (int p = 0; p < count; ++p) {
@@ -668,9 +684,9 @@ int eval_fused_batch(mrbf_ctx *ctx, const KP &kp, int D, int k, bool want_jac, c
 
 int eval_fused(mrbf_ctx *ctx, const mrbf_model *M, int64_t m, const double *X, double *vals, double *jac, mrbf_eval_info *info) {
     const int d = M->d, k = M->k, q = M->q;
-    const int D = (M->dpad <= 64) ? 64 : 128;
-    if (M->dpad > 128) return fail(ctx, MRBF_EHIP, "eval_fused supports d <= 128");
-    if (D != M->dpad) return fail(ctx, MRBF_EHIP, "eval_fused needs dpad in {64, 128} (got %d)", M->dpad);
+    const int D = (M->dpad <= 64) ? 64 : (M->dpad <= 128 ? 128 : 256);
+    if (M->dpad > 256) return fail(ctx, MRBF_EHIP, "eval_fused supports d <= 256");
+    if (D != M->dpad) return fail(ctx, MRBF_EHIP, "eval_fused needs dpad in {64, 128, 256} (got %d)", M->dpad);
     const int64_t mpad = round_up(m, EQ);
     const int ntiles = (int)(M->npad / EC);
     const int nsplit = eval_nsplit(ctx, m, M->npad);

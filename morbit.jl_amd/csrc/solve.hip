@@ -148,8 +148,8 @@ int build_model_shell(mrbf_ctx *ctx, int64_t n, int d, int k, const double *Cdev
     M->deg = deg;
     M->q = poly_dim(d, deg);
     M->npad = round_up(n, 128);
-    // the fused evaluation kernel is instantiated for row strides 64 and 128; wider problems keep the minimal padding
-    M->dpad = (d <= 64) ? 64 : (d <= 128 ? 128 : (int)round_up(d, 16));
+    // the fused evaluation kernels are instantiated for row strides 64, 128 and 256; wider problems keep the minimal padding
+    M->dpad = (d <= 64) ? 64 : (d <= 128 ? 128 : (d <= 256 ? 256 : (int)round_up(d, 16)));
     M->kp = make_kp(kid, a, b);
     // one block, carved at 256-byte granularity
     const size_t cnt[7] = {(size_t)n * d, (size_t)M->npad * M->dpad, (size_t)M->npad, (size_t)M->dpad, (size_t)n * k,
