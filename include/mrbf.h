@@ -318,7 +318,8 @@ int32_t mrbf_ps_step_problem(mrbf_ctx *ctx, const mrbf_ps_problem *problem, cons
  *                            and there are candidates.
  *   mrbf_dispatch_fit        update_model (RbfModel.jl:743-767): MRBF_FIT_FROM_ROUND4 iff a kept round-4 state describes exactly
  *                            the training set (state_n0 + state_n_accepted == n_training, same sites in the same order:
- *                            same_sites != 0) with a unisolvent start set (state_n0 == q) and at least one accepted site.
+ *                            same_sites != 0) with a unisolvent start set (state_n0 == q), at least one accepted site and at most
+ *                            1024 training sites (beyond that the ordinary fit is as fast and more accurate).
  *   mrbf_dispatch_after      the return code rc of a device entry point (MRBF_ENTRY_*) that means "take the reference method
  *                            for this call" (start set without the tail or rank deficient, limits of the device path) rather
  *                            than an error: 1 = fall back, 0 = rc is what it says. */

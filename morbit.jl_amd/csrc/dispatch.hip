@@ -8,6 +8,7 @@ namespace {
 constexpr int PS_MAXLAM = 7168, PS_MAXOBJ = 8, PS_MAXMODELS = 8, PS_MAXCON = 32, PS_MAXLIN = 256;
 // below this many candidate coordinates one host BLAS call beats a launch + two copies (tools/affine_bench.py)
 constexpr int64_t AFFINE_MIN_WORK = 4096 * 8;
+constexpr int64_t FIT_REUSE_MAX_N = 1024;
 }  // namespace
 
 extern "C" {
@@ -40,6 +41,10 @@ int32_t mrbf_dispatch_round4(int64_t n0, int32_t d, int32_t poly_deg, int64_t n_
 int32_t mrbf_dispatch_fit(int64_t n_training, int64_t state_n0, int32_t state_q, int32_t state_n_accepted, int32_t same_sites) {
     if (state_n0 < 1 || state_n_accepted < 1 || !same_sites) return MRBF_FIT_FULL;
     if (state_n0 != state_q) return MRBF_FIT_FULL;  // the kept factor only covers the directions added by round 4
+    // beyond ~1000 sites the ordinary fit (persistent Cholesky) is as fast as the two triangular solves with the kept factor (d = 64,
+    // n = 2145: 1.6 ms both, tools/round4_bench.py) and more accurate (the kappa matrix is formed with cancellation: residual 2e-11
+    // against 1e-15): reuse pays below that
+    if (n_training > FIT_REUSE_MAX_N) return MRBF_FIT_FULL;
     return state_n0 + state_n_accepted == n_training ? MRBF_FIT_FROM_ROUND4 : MRBF_FIT_FULL;
 }
 

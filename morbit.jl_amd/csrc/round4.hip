@@ -13,8 +13,12 @@
 //     tau^2(xi | accepted) = s_K(xi) / s_H(xi),
 // the ratio of the running Cholesky pivots of K = kappa(candidates, candidates) and of H when xi joins the accepted set.  That
 // makes round 4 a left-looking Cholesky factorisation of K in candidate order that SKIPS the columns whose pivot ratio fails the
-// test: one GEMM chain builds K for all candidates at once, one kernel walks the candidates (s_H from a q x q matrix updated
-// by Sherman-Morrison), and the factor of the accepted block is exactly what the fit needs:
+// test: one GEMM chain builds K for all candidates at once; the candidates are then walked in blocks of 128 -- per block one
+// triangular solve with the accepted factor (all rows of the block at once, rocBLAS), one Schur-complement GEMM, and one workgroup
+// that takes the sequential decisions inside the block with the 128 x 128 complement in LDS (s_H from a q x q matrix updated by
+// Sherman-Morrison) -- so the O(n_acc^3) arithmetic runs on the whole device and only ~2 us per candidate are sequential (d = 64,
+// 10^4 candidates, 2080 accepted: 5.1 s for the one-workgroup walk of round 2, see profiles/).  The factor of the accepted block
+// is exactly what the fit needs:
 //     K_acc v = Y_acc - Lam_acc Y_0,   w_0 = -Lam_acc' v,   Pi0 lambda = Y_0 - Phi00 w_0 - Phi0a v        (start set unisolvent: N0 = q)
 // so the fit costs two triangular solves instead of an n^3 / 3 factorisation.  Checked against an independent from-scratch
 // restatement (oracle/sampling_oracle.py) in tests/test_sampling.py.
@@ -39,7 +43,7 @@ struct mrbf_round4_state {
     double *Phi00 = nullptr, *P0c = nullptr;       // n0 x n0; phi(X0, candidates) n0 x mc column-major
     double *Pi0 = nullptr;                         // n0 x q column-major
     double *LamT = nullptr;                        // n0 x mc column-major: column j = lam(xi_j)
-    double *K = nullptr, *LK = nullptr, *diagK = nullptr;  // mc x mc kappa matrix; mc x maxacc factor columns; running pivots
+    double *K = nullptr, *LK = nullptr, *diagK = nullptr;  // mc x mc kappa matrix; factor of the ACCEPTED block (maxacc x maxacc lower, ld maxacc); unused
     double *Prow = nullptr, *Ginv = nullptr;       // mc x q row-major polynomial rows; q x q
     int *acc = nullptr;                            // accepted candidate positions, acceptance order; acc[maxacc] = count
 };
@@ -71,78 +75,125 @@ __global__ void kappa_kernel(const double *__restrict__ Phicc, const double *__r
     if (i == j) diagK[i] = v;
 }
 
-// The walk over the candidates: ONE workgroup (the recurrence is sequential in the accepted sites; per accepted site the new
-// factor column is an mc x nacc matrix-vector product, coalesced over the rows).
+// ---- blocked walk: per block of SB candidates --------------------------------------------------------------------------------
+constexpr int SB = 128;
+// Kab[a + j * ld] = K[acc[a]][i0 + j]  (rows = accepted sites so far, columns = the block's candidates)
+__global__ void gather_kab_kernel(const double *__restrict__ K, int64_t mc, const int *__restrict__ acc, int nacc, int64_t i0, int b,
+                                  double *__restrict__ Kab, int ld) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)nacc * b) return;
+    const int a = (int)(idx % nacc), j = (int)(idx / nacc);
+    Kab[a + (int64_t)j * ld] = K[(i0 + j) + (int64_t)acc[a] * mc];  // K symmetric: read along a column of K
+}
+// S[r + c * SB] = K[i0 + r][i0 + c]
+__global__ void block_copy_kernel(const double *__restrict__ K, int64_t mc, int64_t i0, int b, double *__restrict__ S) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= SB * SB) return;
+    const int r = idx % SB, c = idx / SB;
+    S[idx] = (r < b && c < b) ? K[(i0 + r) + (i0 + c) * mc] : 0.0;
+}
+// the sequential decisions inside one block: S = Schur complement of the block w.r.t. the accepted sites (SB x SB, global -> LDS);
+// cnt[0] = accepted so far (in / out), cnt[1] = accepted in this block (out); Lblk column a = in-block factor column of the a-th site
+// accepted here (rows = in-block candidate index), blkidx[a] = its in-block index
 constexpr int SEL_THREADS = 1024;
-__global__ __launch_bounds__(SEL_THREADS) void select_kernel(int64_t mc, int n0, int q, int max_points, double thr, const double *__restrict__ K,
-                                                             double *__restrict__ LK, double *__restrict__ diagK,
-                                                             const double *__restrict__ Prow, double *__restrict__ Ginv, int *__restrict__ acc,
-                                                             int maxacc) {
-    extern __shared__ double smem[];  // Li[maxacc] | g[q] | pi[q] | red[SEL_THREADS / 64]
-    double *Li = smem, *g = Li + maxacc, *pi = g + (q > 0 ? q : 1), *red = pi + (q > 0 ? q : 1);
+__global__ __launch_bounds__(SEL_THREADS) void select_block_kernel(const double *__restrict__ Sg, int b, int64_t i0, int n0, int q, int max_points,
+                                                                   int maxacc, double thr, const double *__restrict__ Prow, double *__restrict__ Ginv,
+                                                                   int *__restrict__ acc, int *__restrict__ cnt, double *__restrict__ Lblk,
+                                                                   int *__restrict__ blkidx) {
+    extern __shared__ double smem[];  // S[SB * SB] | cs[SB] | g[q] | pi[q] | red[SEL_THREADS / 64]
+    double *S = smem, *cs = S + SB * SB, *g = cs + SB, *pi = g + (q > 0 ? q : 1), *red = pi + (q > 0 ? q : 1);
     __shared__ int s_acc;
     __shared__ double s_pk, s_ph;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int nacc = 0;
-    for (int64_t i = 0; i < mc; ++i) {
+    for (int e = tid; e < SB * SB; e += SEL_THREADS) S[e] = Sg[e];
+    int nacc = cnt[0], nblk = 0;
+    __syncthreads();
+    for (int j = 0; j < b; ++j) {
         if (n0 + nacc >= max_points || nacc >= maxacc) break;
         __syncthreads();  // the previous candidate's decision words have been read by everybody
         // s_H = 1 + pi' Ginv pi
-        double ph = 1.0;
         if (q > 0) {
-            for (int t = tid; t < q; t += SEL_THREADS) pi[t] = Prow[i * q + t];
+            for (int t = tid; t < q; t += SEL_THREADS) pi[t] = Prow[(i0 + j) * q + t];
             __syncthreads();
             double part = 0.0;
             for (int t = tid; t < q; t += SEL_THREADS) {
-                double s = 0.0;
-                for (int u = 0; u < q; ++u) s = fma(Ginv[t + (int64_t)u * q], pi[u], s);  // Ginv symmetric: column access is coalesced
-                g[t] = s;
-                part = fma(pi[t], s, part);
+                double sdot = 0.0;
+                for (int u = 0; u < q; ++u) sdot = fma(Ginv[t + (int64_t)u * q], pi[u], sdot);  // Ginv symmetric: column access is coalesced
+                g[t] = sdot;
+                part = fma(pi[t], sdot, part);
             }
             for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
             if (lane == 0) red[wave] = part;
             __syncthreads();
             if (tid == 0) {
-                double s = 0.0;
-                for (int w = 0; w < SEL_THREADS / 64; ++w) s += red[w];
-                s_ph = 1.0 + s;
+                double sdot = 0.0;
+                for (int w = 0; w < SEL_THREADS / 64; ++w) sdot += red[w];
+                s_ph = 1.0 + sdot;
             }
         }
         if (tid == 0) {
-            const double pk = diagK[i];
+            const double pk = S[j + j * SB];
             if (q == 0) s_ph = 1.0;
             s_pk = pk;
             const double tau2 = pk / s_ph;
             s_acc = (pk > 0.0 && tau2 > thr && tau2 < 1e300) ? 1 : 0;  // tau^2 > (theta^2)^2, RbfModel.jl:370, :452 (NaN fails)
         }
         __syncthreads();
-        ph = s_ph;
         if (!s_acc) continue;
-        const double pk = s_pk, rs = 1.0 / sqrt(pk);
-        for (int a2 = tid; a2 < nacc; a2 += SEL_THREADS) Li[a2] = LK[i + (int64_t)a2 * mc];
+        const double pk = s_pk, ph = s_ph, rs = 1.0 / sqrt(pk);
+        for (int r = tid; r < SB; r += SEL_THREADS) {
+            const double c = (r > j && r < b) ? S[r + j * SB] * rs : (r == j ? pk * rs : 0.0);
+            cs[r] = c;
+            Lblk[r + nblk * SB] = c;
+        }
         __syncthreads();
-        double *col = LK + (int64_t)nacc * mc;
-        for (int64_t r = tid; r < mc; r += SEL_THREADS) {
-            double v = 0.0;
-            if (r > i) {
-                double s = 0.0;
-                for (int a2 = 0; a2 < nacc; ++a2) s = fma(LK[r + (int64_t)a2 * mc], Li[a2], s);
-                v = (K[r + i * mc] - s) * rs;
-                diagK[r] -= v * v;
-            } else if (r == i) {
-                v = pk * rs;
-            }
-            col[r] = v;
+        for (int e = tid; e < SB * SB; e += SEL_THREADS) {  // rank-1 update of the trailing complement (lower part)
+            const int r = e % SB, c = e / SB;
+            if (c > j && r >= c && r < b) S[e] = fma(-cs[r], cs[c], S[e]);
         }
         // Ginv <- Ginv - g g' / s_H   (Sherman-Morrison for G + pi pi')
         if (q > 0)
             for (int e = tid; e < q * q; e += SEL_THREADS) Ginv[e] -= g[e % q] * g[e / q] / ph;
-        if (tid == 0) acc[nacc] = (int)i;
+        if (tid == 0) {
+            acc[nacc] = (int)(i0 + j);
+            blkidx[nblk] = j;
+        }
         ++nacc;
+        ++nblk;
         __threadfence();
-        __syncthreads();
     }
-    if (tid == 0) acc[maxacc] = nacc;
+    __syncthreads();
+    if (tid == 0) {
+        cnt[0] = nacc;
+        cnt[1] = nblk;
+        acc[maxacc] = nacc;
+    }
+}
+// rows nacc0 .. nacc0 + nblk - 1 of the accepted factor: [ R(:, j_a)' | in-block factor entries | 0 ]
+__global__ void append_rows_kernel(const double *__restrict__ R, int ldr, int nacc0, const double *__restrict__ Lblk, const int *__restrict__ blkidx,
+                                   const int *__restrict__ cnt, double *__restrict__ L, int ldl) {
+    const int nblk = cnt[1];
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int width = nacc0 + SB;
+    if (idx >= (int64_t)SB * width) return;
+    const int a = (int)(idx / width), c = (int)(idx % width);
+    if (a >= nblk) return;
+    const int jb = blkidx[a];
+    double v = 0.0;
+    if (c < nacc0)
+        v = R[c + (int64_t)jb * ldr];
+    else if (c - nacc0 <= a)
+        v = Lblk[jb + (c - nacc0) * SB];
+    else if (c - nacc0 >= nblk)
+        return;
+    L[(nacc0 + a) + (int64_t)c * ldl] = v;
+}
+// dense j x j copy of the accepted factor
+__global__ void copy_factor_kernel(const double *__restrict__ L, int ldl, int j, double *__restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= j * j) return;
+    const int p = idx % j, a2 = idx / j;
+    out[idx] = (p >= a2) ? L[p + (int64_t)a2 * ldl] : 0.0;
 }
 
 // gathers for the fit: LaT (n0 x j) = columns acc of LamT; P0a (n0 x j) = columns acc of P0c; Lacc (j x j lower) = rows acc of LK
@@ -237,7 +288,7 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
     auto *st = new mrbf_round4_state();
     st->n0 = n0; st->mc = mc; st->d = d; st->q = q; st->deg = poly_deg; st->kid = kernel_id; st->a = a; st->b = b; st->maxacc = maxacc;
     const size_t cnt[11] = {(size_t)n0 * d, (size_t)mc * d, (size_t)n0 * n0, (size_t)n0 * mc, (size_t)n0 * std::max(q, 1), (size_t)n0 * mc,
-                            (size_t)mc * mc, (size_t)mc * maxacc, (size_t)mc, (size_t)mc * std::max(q, 1), (size_t)std::max(q, 1) * std::max(q, 1)};
+                            (size_t)mc * mc, (size_t)maxacc * maxacc, (size_t)mc, (size_t)mc * std::max(q, 1), (size_t)std::max(q, 1) * std::max(q, 1)};
     size_t off[12];
     off[0] = 0;
     for (int i = 0; i < 11; ++i) off[i + 1] = off[i] + ((cnt[i] * sizeof(double) + 255) & ~size_t(255));
@@ -301,11 +352,37 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
         }
         hipLaunchKernelGGL(kappa_kernel, dim3(nb(mc * mc)), dim3(256), 0, s, Phicc, E, Qm, mc, st->K, st->diagK, q > 0 ? 1 : 0);
         const double thr = (theta_pivot_cholesky * theta_pivot_cholesky) * (theta_pivot_cholesky * theta_pivot_cholesky);
-        const size_t shm = ((size_t)maxacc + 2 * (size_t)std::max(q, 1) + SEL_THREADS / 64) * sizeof(double);
-        if (shm > 150 * 1024) return fail(ctx, -11, "round 4: max_points - n0 = %d too large for the selection kernel", maxacc);
-        MRBF_HIP(ctx, hipFuncSetAttribute((const void *)select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-        hipLaunchKernelGGL(select_kernel, dim3(1), dim3(SEL_THREADS), shm, s, mc, (int)n0, q, (int)max_points, thr, st->K, st->LK, st->diagK, st->Prow,
-                           st->Ginv, st->acc, maxacc);
+        const size_t shm = ((size_t)SB * SB + SB + 2 * (size_t)std::max(q, 1) + SEL_THREADS / 64) * sizeof(double);
+        MRBF_HIP(ctx, hipFuncSetAttribute((const void *)select_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        double *Rb, *Sb, *Lblk;
+        int *cnt, *blkidx;
+        MRBF_TRY(get_buf(ctx, S_Q1, (size_t)maxacc * SB, &Rb));          // R = L_acc^-1 K[acc, block]
+        MRBF_TRY(get_buf(ctx, S_RHS, (size_t)2 * SB * SB, &Sb));          // Schur complement of the block | in-block factor columns
+        Lblk = Sb + (size_t)SB * SB;
+        MRBF_TRY(get_buf(ctx, S_IPIV, (size_t)SB + 8, &cnt));
+        blkidx = cnt + 8;
+        MRBF_HIP(ctx, hipMemsetAsync(cnt, 0, 8 * sizeof(int), s));
+        MRBF_HIP(ctx, hipMemsetAsync(st->LK, 0, (size_t)maxacc * maxacc * sizeof(double), s));
+        int nacc = 0;
+        for (int64_t i0 = 0; i0 < mc && (int64_t)n0 + nacc < max_points && nacc < maxacc; i0 += SB) {
+            const int bsz = (int)std::min<int64_t>(SB, mc - i0);
+            hipLaunchKernelGGL(block_copy_kernel, dim3(nb(SB * SB)), dim3(256), 0, s, st->K, mc, i0, bsz, Sb);
+            if (nacc > 0) {
+                hipLaunchKernelGGL(gather_kab_kernel, dim3(nb((int64_t)nacc * bsz)), dim3(256), 0, s, st->K, mc, st->acc, nacc, i0, bsz, Rb, maxacc);
+                MRBF_BLAS(ctx, rocblas_dtrsm(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, nacc, bsz,
+                                             &one, st->LK, maxacc, Rb, maxacc));
+                const double mone = -1.0;
+                MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, bsz, bsz, nacc, &mone, Rb, maxacc, Rb, maxacc,
+                                             &one, Sb, SB));
+            }
+            hipLaunchKernelGGL(select_block_kernel, dim3(1), dim3(SEL_THREADS), shm, s, Sb, bsz, i0, (int)n0, q, (int)max_points, maxacc, thr, st->Prow,
+                               st->Ginv, st->acc, cnt, Lblk, blkidx);
+            hipLaunchKernelGGL(append_rows_kernel, dim3(nb((int64_t)SB * (nacc + SB))), dim3(256), 0, s, Rb, maxacc, nacc, Lblk, blkidx, cnt, st->LK, maxacc);
+            int hc[2] = {0, 0};
+            MRBF_HIP(ctx, hipMemcpyAsync(hc, cnt, sizeof(hc), hipMemcpyDeviceToHost, s));
+            MRBF_HIP(ctx, hipStreamSynchronize(s));  // the next block's shapes depend on the number accepted so far
+            nacc = hc[0];
+        }
         MRBF_HIP(ctx, hipGetLastError());
         std::vector<int> hacc((size_t)maxacc + 1);
         MRBF_HIP(ctx, hipMemcpyAsync(hacc.data(), st->acc, hacc.size() * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -379,7 +456,7 @@ extern "C" int32_t mrbf_fit_from_round4(mrbf_ctx *ctx, const mrbf_round4_state *
         if (j > 0) {
             hipLaunchKernelGGL(gather_cols_kernel, dim3(nb((int64_t)n0 * j)), dim3(256), 0, s, st->LamT, (int64_t)n0, st->acc, j, LaT);
             hipLaunchKernelGGL(gather_cols_kernel, dim3(nb((int64_t)n0 * j)), dim3(256), 0, s, st->P0c, (int64_t)n0, st->acc, j, P0a);
-            hipLaunchKernelGGL(gather_factor_kernel, dim3(nb((int64_t)j * j)), dim3(256), 0, s, st->LK, mc, st->acc, j, Lacc);
+            hipLaunchKernelGGL(copy_factor_kernel, dim3(nb((int64_t)j * j)), dim3(256), 0, s, st->LK, st->maxacc, j, Lacc);
             // Ya <- Ya - Lam_acc Y0 ;  v = K_acc^-1 (..) by the two triangular solves with the round-4 factor
             MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, j, k, n0, &mone, LaT, n0, Y0, n0, &one, Ya, j));
             MRBF_BLAS(ctx, rocblas_dtrsm(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, j, k, &one,

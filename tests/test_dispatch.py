@@ -43,7 +43,8 @@ def test_decision_table(lib):
     assert lib.mrbf_dispatch_round4(1, 3, -1, 50) == D and lib.mrbf_dispatch_round4(1, 3, 0, 50) == D and lib.mrbf_dispatch_round4(4, 3, 1, 0) == R
     # fit: factor reuse iff the kept state is exactly the training set and the start set is unisolvent
     F, K = _lib.FIT_FULL, _lib.FIT_FROM_ROUND4
-    assert lib.mrbf_dispatch_fit(10, 4, 4, 6, 1) == K
+    assert lib.mrbf_dispatch_fit(10, 4, 4, 6, 1) == K and lib.mrbf_dispatch_fit(1024, 65, 65, 959, 1) == K
+    assert lib.mrbf_dispatch_fit(2145, 65, 65, 2080, 1) == F      # large training sets: the ordinary fit is as fast and more accurate
     assert lib.mrbf_dispatch_fit(10, 4, 4, 6, 0) == F and lib.mrbf_dispatch_fit(11, 4, 4, 6, 1) == F
     assert lib.mrbf_dispatch_fit(10, 5, 4, 5, 1) == F and lib.mrbf_dispatch_fit(4, 4, 4, 0, 1) == F and lib.mrbf_dispatch_fit(10, 0, 4, 0, 1) == F
     # return codes that mean "take the reference method", not an error
