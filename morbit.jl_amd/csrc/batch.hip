@@ -112,7 +112,9 @@ static int run_small_batch(mrbf_ctx *ctx, const std::vector<int64_t> &idx, const
         return at;
     };
     const bool check = ctx->residual != 0;
-    const size_t out0 = take((size_t)8 * P);  // the per-problem result words, contiguous: one copy back for the whole batch
+    // the per-problem result words (8 doubles each), contiguous, and the flag words (4 ints each) right behind them: one copy back
+    // for the whole batch
+    const size_t out0 = take((size_t)10 * P);
     for (int i = 0; i < P; ++i) {
         const mrbf_problem &pr = problems[idx[i]];
         Lay &L = lay[i];
@@ -151,13 +153,14 @@ static int run_small_batch(mrbf_ctx *ctx, const std::vector<int64_t> &idx, const
         L.out = out0 + (size_t)8 * i;
     }
     double *base;
-    int *flags;
+    int *flags = nullptr;
     MRBF_TRY(get_buf(ctx, S_SMALL_WS, total, &base));
-    MRBF_TRY(get_buf(ctx, S_SMALL_FLAGS, (size_t)4 * P, &flags));
+    flags = reinterpret_cast<int *>(base + out0 + (size_t)8 * P);
     // descriptors: [Prob x P | EvalDesc x 2P | CheckDesc x P] in one device buffer
     const size_t desc_bytes = (size_t)P * (sizeof(smallfit::Prob) + 2 * sizeof(EvalDesc) + sizeof(CheckDesc)) + 256;
     char *ddesc;
     MRBF_TRY(get_buf(ctx, S_SMALL_DESC, desc_bytes, (void **)&ddesc));
+    std::vector<char> hdesc;
     std::vector<smallfit::Prob> probs(P);
     std::vector<EvalDesc> evs((size_t)2 * P);
     std::vector<CheckDesc> chk(P);
@@ -241,9 +244,14 @@ static int run_small_batch(mrbf_ctx *ctx, const std::vector<int64_t> &idx, const
     smallfit::Prob *dprobs = (smallfit::Prob *)ddesc;
     EvalDesc *devs_ = (EvalDesc *)(ddesc + al16((size_t)P * sizeof(smallfit::Prob)));
     CheckDesc *dchk = (CheckDesc *)((char *)devs_ + al16((size_t)2 * P * sizeof(EvalDesc)));
-    MRBF_HIP(ctx, hipMemcpyAsync(dprobs, probs.data(), (size_t)P * sizeof(smallfit::Prob), hipMemcpyHostToDevice, st));
-    MRBF_HIP(ctx, hipMemcpyAsync(devs_, evs.data(), (size_t)2 * P * sizeof(EvalDesc), hipMemcpyHostToDevice, st));
-    MRBF_HIP(ctx, hipMemcpyAsync(dchk, chk.data(), (size_t)P * sizeof(CheckDesc), hipMemcpyHostToDevice, st));
+    {
+        // one upload for the three descriptor arrays (the staging vector lives until the stream is synchronised below)
+        hdesc.assign(desc_bytes, 0);
+        memcpy(hdesc.data(), probs.data(), (size_t)P * sizeof(smallfit::Prob));
+        memcpy(hdesc.data() + ((char *)devs_ - ddesc), evs.data(), (size_t)2 * P * sizeof(EvalDesc));
+        memcpy(hdesc.data() + ((char *)dchk - ddesc), chk.data(), (size_t)P * sizeof(CheckDesc));
+        MRBF_HIP(ctx, hipMemcpyAsync(ddesc, hdesc.data(), desc_bytes, hipMemcpyHostToDevice, st));
+    }
     MRBF_HIP(ctx, hipEventRecord(ctx->ev[0], st));
     MRBF_TRY(launch_small_fit(ctx, probs.data(), P, dprobs));
     MRBF_HIP(ctx, hipEventRecord(ctx->ev[1], st));
@@ -307,10 +315,9 @@ static int run_small_batch(mrbf_ctx *ctx, const std::vector<int64_t> &idx, const
     MRBF_HIP(ctx, hipGetLastError());
     MRBF_HIP(ctx, hipEventRecord(ctx->ev[2], st));
     // results
-    std::vector<int> hflags((size_t)4 * P);
-    std::vector<double> hout((size_t)8 * P);
-    MRBF_HIP(ctx, hipMemcpyAsync(hflags.data(), flags, hflags.size() * sizeof(int), hipMemcpyDeviceToHost, st));
+    std::vector<double> hout((size_t)10 * P);
     MRBF_HIP(ctx, hipMemcpyAsync(hout.data(), base + out0, hout.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    const int *hflags = reinterpret_cast<const int *>(hout.data() + (size_t)8 * P);
     for (int i = 0; i < P; ++i) {
         const mrbf_problem &pr = problems[idx[i]];
         const Lay &L = lay[i];
