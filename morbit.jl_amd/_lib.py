@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmrbf.so")
+LIB_PATH = os.environ.get("MRBF_LIB") or os.path.join(_HERE, "libmrbf.so")  # MRBF_LIB: same override as HipRbf.jl (A/B runs of two builds)
 
 c_dp = ctypes.POINTER(ctypes.c_double)
 c_fp = ctypes.POINTER(ctypes.c_float)
