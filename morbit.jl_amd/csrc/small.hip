@@ -34,11 +34,12 @@ __device__ __forceinline__ double phi_rt(double s, const KP &p) {
 
 // C(i, j) (op)= sum_k A'(i, k) B'(k, j) for one workgroup of 4 waves; A' = TA ? A^T : A, B' = TB ? B^T : B (A, B column-major with
 // leading dimensions lda, ldb); M, N multiples of 16, K a multiple of 4.  Every wave takes 32 x 32 macro tiles (2 x 2 MFMA tiles)
-// round-robin and hands each finished element to epi(i, j, value).  LOWER: only 16 x 16 tiles on or below the diagonal.
+// round-robin; the epilogue is pre(i, j) -> what it reads, then post(i, j, value, what pre returned).  LOWER: only 16 x 16 tiles on or below the diagonal.
 // f64 MFMA lane maps (tests/test_gpu_parity.py::test_f64_mfma_lane_maps): A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15],
 // D[row = (l >> 4) + 4 r][col = l & 15].
-template <bool TA, bool TB, bool LOWER, class Epi>
-__device__ __forceinline__ void wg_gemm(int M, int N, int K, const double *__restrict__ A, int lda, const double *__restrict__ B, int ldb, Epi epi) {
+template <bool TA, bool TB, bool LOWER, class Pre, class Post>
+__device__ __forceinline__ void wg_gemm(int M, int N, int K, const double *__restrict__ A, int lda, const double *__restrict__ B, int ldb, Pre pre,
+                                        Post post) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l15 = lane & 15, l4 = lane >> 4;
     const int mt = M >> 4, nt = N >> 4, MT = (mt + 1) >> 1, NT2 = (nt + 1) >> 1;
@@ -52,22 +53,25 @@ __device__ __forceinline__ void wg_gemm(int M, int N, int K, const double *__res
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int b = 0; b < 2; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
-        const double *pa = TA ? A + l4 + (int64_t)(i0 + l15) * lda : A + (i0 + l15) + (int64_t)l4 * lda;
-        const double *pb = TB ? B + (j0 + l15) + (int64_t)l4 * ldb : B + l4 + (int64_t)(j0 + l15) * ldb;
+        // (explicit global address space: global_load, not flat_load; no guards on the loads -- K is a multiple of 16 at every call
+        //  site and a missing second tile re-reads the first one: as `cond ? load : 0` every operand load sat in its own exec-mask
+        //  branch)
+        typedef const __attribute__((address_space(1))) double gcd;
+        gcd *pa = (gcd *)(TA ? A + l4 + (int64_t)(i0 + l15) * lda : A + (i0 + l15) + (int64_t)l4 * lda);
+        gcd *pb = (gcd *)(TB ? B + (j0 + l15) + (int64_t)l4 * ldb : B + l4 + (int64_t)(j0 + l15) * ldb);
         const int64_t sa = TA ? 4 : 4 * (int64_t)lda, sb = TB ? 4 * (int64_t)ldb : 4;
-        const int64_t oa = TA ? 16 * (int64_t)lda : 16, ob = TB ? 16 : 16 * (int64_t)ldb;
+        const int64_t oa = va1 ? (TA ? 16 * (int64_t)lda : 16) : 0, ob = vb1 ? (TB ? 16 : 16 * (int64_t)ldb) : 0;
         // the operands come straight from global memory (L2 / Infinity Cache): UK k-steps of loads are issued as one burst and the
         // next burst is in flight under this burst's MFMAs, otherwise every k-step would pay a full memory round trip
         constexpr int UK = 4;
         double fa0[2][UK], fa1[2][UK], fb0[2][UK], fb1[2][UK];
-        auto burst = [&](int buf, int k) {
+        auto burst = [&](int buf, int) {
 #pragma unroll
             for (int u = 0; u < UK; ++u) {
-                const bool in = k + 4 * u < K;
-                fa0[buf][u] = in ? pa[u * sa] : 0.0;
-                fa1[buf][u] = (in && va1) ? pa[u * sa + oa] : 0.0;
-                fb0[buf][u] = in ? pb[u * sb] : 0.0;
-                fb1[buf][u] = (in && vb1) ? pb[u * sb + ob] : 0.0;
+                fa0[buf][u] = pa[u * sa];
+                fa1[buf][u] = pa[u * sa + oa];
+                fb0[buf][u] = pb[u * sb];
+                fb1[buf][u] = pb[u * sb + ob];
             }
             pa += UK * sa;
             pb += UK * sb;
@@ -77,21 +81,35 @@ __device__ __forceinline__ void wg_gemm(int M, int N, int K, const double *__res
             if (k + 4 * UK < K) burst(1, k + 4 * UK);
 #pragma unroll
             for (int u = 0; u < UK; ++u) {
-                acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa0[0][u], fb0[0][u], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa0[0][u], fb1[0][u], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa1[0][u], fb0[0][u], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa1[0][u], fb1[0][u], acc[1][1], 0, 0, 0);
+                acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb0[0][u], fa0[0][u], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb1[0][u], fa0[0][u], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb0[0][u], fa1[0][u], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb1[0][u], fa1[0][u], acc[1][1], 0, 0, 0);
             }
             if (k + 4 * UK >= K) break;
             if (k + 8 * UK < K) burst(0, k + 8 * UK);
 #pragma unroll
             for (int u = 0; u < UK; ++u) {
-                acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa0[1][u], fb0[1][u], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa0[1][u], fb1[1][u], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa1[1][u], fb0[1][u], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa1[1][u], fb1[1][u], acc[1][1], 0, 0, 0);
+                acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb0[1][u], fa0[1][u], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb1[1][u], fa0[1][u], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb0[1][u], fa1[1][u], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb1[1][u], fa1[1][u], acc[1][1], 0, 0, 0);
             }
         }
+        // Epilogue in two passes: everything the epilogue READS for this macro tile first (pre: one burst of loads), then the stores
+        // (post).  With a per-element read-modify-write the compiler must keep every load behind the previous element's store
+        // (they may alias), and a 32 x 32 tile paid sixteen dependent memory round trips per lane: the Gram matrix of a 257-site
+        // problem took 260 us whatever the dimension.  The products are formed transposed (B fragment as the MFMA's A operand), so
+        // that the lane index runs along i, the contiguous index of every column-major output.
+        double old[2][2][4];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const bool on = !((a == 1 && !va1) || (b == 1 && !vb1)) && !(LOWER && 2 * I + a < 2 * J + b);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) old[a][b][r] = on ? pre(i0 + 16 * a + l15, j0 + 16 * b + l4 + 4 * r) : 0.0;
+            }
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -99,10 +117,14 @@ __device__ __forceinline__ void wg_gemm(int M, int N, int K, const double *__res
                 if ((a == 1 && !va1) || (b == 1 && !vb1)) continue;
                 if (LOWER && 2 * I + a < 2 * J + b) continue;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) epi(i0 + 16 * a + l4 + 4 * r, j0 + 16 * b + l15, acc[a][b][r]);
+                for (int r = 0; r < 4; ++r) post(i0 + 16 * a + l15, j0 + 16 * b + l4 + 4 * r, acc[a][b][r], old[a][b][r]);
             }
     }
 }
+
+struct NoPre {
+    __device__ __forceinline__ double operator()(int, int) const { return 0.0; }
+};
 
 __device__ __forceinline__ double wg_sum(double v, double *red /* 4 doubles of LDS */) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
@@ -139,7 +161,7 @@ __device__ int wg_potrf(double *__restrict__ A, int ld, int np, int rows16, doub
         if (mrows <= 0) continue;
         // panel: L(r, c) = A(r, c) inv(L_cc)'  -> Pt (mrows x 128), then back into A
         const double *Arc = A + r0 + (int64_t)c * 128 * ld;
-        wg_gemm<false, true, false>(mrows, 128, 128, Arc, ld, Lc, 128, [&](int i, int j, double v) { Pt[i + (int64_t)j * np] = v; });
+        wg_gemm<false, true, false>(mrows, 128, 128, Arc, ld, Lc, 128, NoPre(), [&](int i, int j, double v, double) { Pt[i + (int64_t)j * np] = v; });
         __syncthreads();
         for (int e = threadIdx.x; e < mrows * 128; e += 256) {
             const int i = e % mrows, j = e / mrows;
@@ -147,7 +169,8 @@ __device__ int wg_potrf(double *__restrict__ A, int ld, int np, int rows16, doub
         }
         // trailing update: A(r, s) -= L(r, c) L(s, c)'  for r >= s > c (lower tiles)
         double *Att = A + (int64_t)r0 * (ld + 1);
-        wg_gemm<false, true, true>(mrows, mrows, 128, Pt, np, Pt, np, [&](int i, int j, double v) { Att[i + (int64_t)j * ld] -= v; });
+        wg_gemm<false, true, true>(mrows, mrows, 128, Pt, np, Pt, np, [&](int i, int j) { return Att[i + (int64_t)j * ld]; },
+                                   [&](int i, int j, double v, double o) { Att[i + (int64_t)j * ld] = o - v; });
         __syncthreads();
     }
     return 0;
@@ -209,18 +232,20 @@ __global__ __launch_bounds__(256, 1) void small_fit_kernel(Prob one, const Prob 
         const double *XcT = P.Xc;  // dpad x np column-major
         const KP kp = P.kp;
         const double *sq = P.sq;
-        wg_gemm<true, false, false>(n16, n16, dpad, XcT, dpad, XcT, dpad, [&](int i, int j, double sdot) {
-            double v;
-            if (i < n && j < n) {
-                double s = fma(-2.0, sdot, sq[i] + sq[j]);
-                s = s > 0.0 ? s : 0.0;
-                if (i == j) s = 0.0;
-                v = phi_rt(s, kp);
-            } else {
-                v = (i == j) ? 1.0 : 0.0;
-            }
-            Phi[(int64_t)i * np + j] = v;
-        });
+        wg_gemm<true, false, false>(
+            n16, n16, dpad, XcT, dpad, XcT, dpad, [&](int i, int j) { return (i < n && j < n) ? sq[i] + sq[j] : 0.0; },
+            [&](int i, int j, double sdot, double sqsum) {
+                double v;
+                if (i < n && j < n) {
+                    double s = fma(-2.0, sdot, sqsum);
+                    s = s > 0.0 ? s : 0.0;
+                    if (i == j) s = 0.0;
+                    v = phi_rt(s, kp);
+                } else {
+                    v = (i == j) ? 1.0 : 0.0;
+                }
+                Phi[(int64_t)j * np + i] = v;
+            });
         // identity in the padding beyond n16 (rows / columns n16 .. np - 1 of the lower triangle are all the factorisation reads there)
         for (int e = tid; e < (np - n16) * np; e += 256) {
             const int c = n16 + e / np, r = e % np;
@@ -243,7 +268,7 @@ __global__ __launch_bounds__(256, 1) void small_fit_kernel(Prob one, const Prob 
             // Gx = Xc' Xc (d x d), identity padded to 128 x 128
             for (int e = tid; e < 128 * 128; e += 256) Gx[e] = (e % 128 == e / 128 && e % 128 >= d) ? 1.0 : 0.0;
             __syncthreads();
-            wg_gemm<false, true, true>(d16, d16, n16, P.Xc, dpad, P.Xc, dpad, [&](int a, int b, double v) {
+            wg_gemm<false, true, true>(d16, d16, n16, P.Xc, dpad, P.Xc, dpad, NoPre(), [&](int a, int b, double v, double) {
                 if (a < d && b < d) Gx[a + b * 128] = v;
             });
             __syncthreads();
@@ -255,17 +280,17 @@ __global__ __launch_bounds__(256, 1) void small_fit_kernel(Prob one, const Prob 
             __syncthreads();
             // Qx(i, a) = sum_b Xc(i, b) inv(Lx)(a, b)
             double *Qx = Q1 + np;
-            wg_gemm<true, true, false>(n16, d16, d16, P.Xc, dpad, LinvX, 128, [&](int i, int a, double v) {
+            wg_gemm<true, true, false>(n16, d16, d16, P.Xc, dpad, LinvX, 128, NoPre(), [&](int i, int a, double v, double) {
                 if (i < n && a < d) Qx[i + (int64_t)a * np] = v;
             });
         }
         __syncthreads();
         MRBF_STAMP();  // 3: Q1
         // ---- W1 = Phi Q1;  G = Q1' W1;  W = W1 - 1/2 Q1 G;  mu = (n phi0 - trace G) / (n - q);  V = W - mu/2 Q1
-        wg_gemm<false, false, false>(n16, q16, n16, Phi, np, Q1, np, [&](int i, int t, double v) { Wm[i + (int64_t)t * np] = v; });
+        wg_gemm<false, false, false>(n16, q16, n16, Phi, np, Q1, np, NoPre(), [&](int i, int t, double v, double) { Wm[i + (int64_t)t * np] = v; });
         for (int e = tid; e < (np - n16) * q16; e += 256) Wm[n16 + e % (np - n16) + (int64_t)(e / (np - n16)) * np] = 0.0;
         __syncthreads();
-        wg_gemm<true, false, false>(q16, q16, n16, Q1, np, Wm, np, [&](int a, int b, double v) { G[a + b * q16] = v; });
+        wg_gemm<true, false, false>(q16, q16, n16, Q1, np, Wm, np, NoPre(), [&](int a, int b, double v, double) { G[a + b * q16] = v; });
         __syncthreads();
         double tr = 0.0;
         for (int t = tid; t < q; t += 256) tr += G[t + t * q16];
@@ -278,22 +303,26 @@ __global__ __launch_bounds__(256, 1) void small_fit_kernel(Prob one, const Prob 
             P.scal[1] = mu;
             if (!mu_ok) P.flags[2] = 1;
         }
-        wg_gemm<false, false, false>(n16, q16, q16, Q1, np, G, q16, [&](int i, int t, double v) { Wm[i + (int64_t)t * np] -= 0.5 * v; });
+        wg_gemm<false, false, false>(n16, q16, q16, Q1, np, G, q16, [&](int i, int t) { return Wm[i + (int64_t)t * np]; },
+                                     [&](int i, int t, double v, double o) { Wm[i + (int64_t)t * np] = o - 0.5 * v; });
         __syncthreads();
         for (int e = tid; e < np * q16; e += 256) V[e] = fma(-0.5 * mu, Q1[e], Wm[e]);
         __syncthreads();
         MRBF_STAMP();  // 4: W, G, mu, V
         // ---- K = Phi - Q1 V' - V Q1' on the lower triangle (column-major: K(i, j), i >= j, at Phi[i + j * np])
-        wg_gemm<false, true, true>(n16, n16, q16, Q1, np, V, np, [&](int i, int j, double v) { Phi[i + (int64_t)j * np] -= v; });
+        wg_gemm<false, true, true>(n16, n16, q16, Q1, np, V, np, [&](int i, int j) { return Phi[i + (int64_t)j * np]; },
+                                   [&](int i, int j, double v, double o) { Phi[i + (int64_t)j * np] = o - v; });
         __syncthreads();
-        wg_gemm<false, true, true>(n16, n16, q16, V, np, Q1, np, [&](int i, int j, double v) { Phi[i + (int64_t)j * np] -= v; });
+        wg_gemm<false, true, true>(n16, n16, q16, V, np, Q1, np, [&](int i, int j) { return Phi[i + (int64_t)j * np]; },
+                                   [&](int i, int j, double v, double o) { Phi[i + (int64_t)j * np] = o - v; });
         MRBF_STAMP();  // 5: K update (issued)
         // ---- B = P Y = Y - Q1 (Q1' Y);  T1 keeps Q1' Y for the tail coefficients
-        wg_gemm<true, false, false>(q16, 16, n16, Q1, np, Yc, np, [&](int a, int l, double v) { T1[a + l * ldz] = v; });
+        wg_gemm<true, false, false>(q16, 16, n16, Q1, np, Yc, np, NoPre(), [&](int a, int l, double v, double) { T1[a + l * ldz] = v; });
         __syncthreads();
         for (int e = tid; e < np * 16; e += 256) Bm[e] = Yc[e];
         __syncthreads();
-        wg_gemm<false, false, false>(n16, 16, q16, Q1, np, T1, ldz, [&](int i, int l, double v) { Bm[i + l * np] -= v; });
+        wg_gemm<false, false, false>(n16, 16, q16, Q1, np, T1, ldz, [&](int i, int l) { return Bm[i + l * np]; },
+                                     [&](int i, int l, double v, double o) { Bm[i + l * np] = o - v; });
     } else {
         for (int e = tid; e < np * 16; e += 256) Bm[e] = Yc[e];
         if (tid == 0) {
@@ -318,38 +347,42 @@ __global__ __launch_bounds__(256, 1) void small_fit_kernel(Prob one, const Prob 
     // ---- forward substitution L y = B (block rows; inv(L_cc) from the factorisation), then backward L' x = y
     for (int c = 0; c < nb; ++c) {
         if (c > 0) {
-            wg_gemm<false, false, false>(128, 16, 128 * c, Phi + 128 * c, np, Fy, np, [&](int i, int l, double v) { Bm[128 * c + i + l * np] -= v; });
+            wg_gemm<false, false, false>(128, 16, 128 * c, Phi + 128 * c, np, Fy, np, [&](int i, int l) { return Bm[128 * c + i + l * np]; },
+                                         [&](int i, int l, double v, double o) { Bm[128 * c + i + l * np] = o - v; });
             __syncthreads();
         }
-        wg_gemm<false, false, false>(128, 16, 128, Linv + (int64_t)c * 128 * 128, 128, Bm + 128 * c, np,
-                                     [&](int i, int l, double v) { Fy[128 * c + i + l * np] = v; });
+        wg_gemm<false, false, false>(128, 16, 128, Linv + (int64_t)c * 128 * 128, 128, Bm + 128 * c, np, NoPre(),
+                                     [&](int i, int l, double v, double) { Fy[128 * c + i + l * np] = v; });
         __syncthreads();
     }
     for (int c = nb - 1; c >= 0; --c) {
         const int rest = np - 128 * (c + 1);
         if (rest > 0) {
             wg_gemm<true, false, false>(128, 16, rest, Phi + 128 * (c + 1) + (int64_t)128 * c * np, np, Xs + 128 * (c + 1), np,
-                                        [&](int i, int l, double v) { Fy[128 * c + i + l * np] -= v; });
+                                        [&](int i, int l) { return Fy[128 * c + i + l * np]; },
+                                        [&](int i, int l, double v, double o) { Fy[128 * c + i + l * np] = o - v; });
             __syncthreads();
         }
-        wg_gemm<true, false, false>(128, 16, 128, Linv + (int64_t)c * 128 * 128, 128, Fy + 128 * c, np,
-                                    [&](int i, int l, double v) { Xs[128 * c + i + l * np] = v; });
+        wg_gemm<true, false, false>(128, 16, 128, Linv + (int64_t)c * 128 * 128, 128, Fy + 128 * c, np, NoPre(),
+                                    [&](int i, int l, double v, double) { Xs[128 * c + i + l * np] = v; });
         __syncthreads();
     }
     MRBF_STAMP();  // 8: solves
     // ---- tail: re-project w (rounding hygiene), z = Q1' Y - W' w, lam = R^-1 z with R = [[sqrt n, sqrt n mean'], [0, Lx']]
     if (q > 0) {
-        wg_gemm<true, false, false>(q16, 16, n16, Q1, np, Xs, np, [&](int a, int l, double v) { T2[a + l * ldz] = v; });
+        wg_gemm<true, false, false>(q16, 16, n16, Q1, np, Xs, np, NoPre(), [&](int a, int l, double v, double) { T2[a + l * ldz] = v; });
         __syncthreads();
-        wg_gemm<false, false, false>(n16, 16, q16, Q1, np, T2, ldz, [&](int i, int l, double v) { Xs[i + l * np] -= v; });
+        wg_gemm<false, false, false>(n16, 16, q16, Q1, np, T2, ldz, [&](int i, int l) { return Xs[i + l * np]; },
+                                     [&](int i, int l, double v, double o) { Xs[i + l * np] = o - v; });
         __syncthreads();
-        wg_gemm<true, false, false>(q16, 16, n16, Wm, np, Xs, np, [&](int a, int l, double v) { Z[a + l * ldz] = T1[a + l * ldz] - v; });
+        wg_gemm<true, false, false>(q16, 16, n16, Wm, np, Xs, np, [&](int a, int l) { return T1[a + l * ldz]; },
+                                    [&](int a, int l, double v, double o) { Z[a + l * ldz] = o - v; });
         for (int e = tid; e < 16 * 16; e += 256) Z[q16 + e % 16 + (e / 16) * ldz] = 0.0;  // the rows the next product may read beyond q16
         __syncthreads();
         if (q > 1) {
             const int d16 = (d + 15) & ~15;
             // lam_tail = Lx^-T z[1:]  =  inv(Lx)' z[1:]
-            wg_gemm<true, false, false>(d16, 16, d16, LinvX, 128, Z + 1, ldz, [&](int a, int l, double v) { T2[1 + a + l * ldz] = v; });
+            wg_gemm<true, false, false>(d16, 16, d16, LinvX, 128, Z + 1, ldz, NoPre(), [&](int a, int l, double v, double) { T2[1 + a + l * ldz] = v; });
             __syncthreads();
         }
         // lam[0] = z0 / sqrt(n) - mean . lam[1:]

@@ -1,15 +1,17 @@
+"""Phase times of the one-launch small fit (MRBF_SMALL_STAMPS=1 prints them per call): C4 start, then shapes that separate the
+cost of the operands (d) from the cost per output element (n)."""
 import sys, os
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MRBF_SMALL_STAMPS", "1")
 import numpy as np
 import morbit.jl_amd as pkg
 from morbit.jl_amd import workloads as wl
-C, Y, X = wl.problem("C4", 0)
 cfg = pkg.RbfConfig(kernel="cubic")
+C, Y, X = wl.problem("C4", 0)
 for _ in range(3):
-    mod = pkg.update_model(cfg, C, Y)
-    mod.free()
+    pkg.update_model(cfg, C, Y).free()
 rng = np.random.default_rng(0)
-for n, d in ((100, 10), (512, 64), (60, 5)):
+for n, d in ((257, 16), (257, 64), (129, 128), (512, 64), (100, 10)):
     C = rng.random((n, d)); Y = (C**2).sum(1, keepdims=True)
     for _ in range(2):
-        mod = pkg.update_model(cfg, C, Y); mod.free()
+        pkg.update_model(cfg, C, Y).free()
