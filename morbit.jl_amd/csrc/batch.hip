@@ -136,14 +136,14 @@ static int run_small_batch(mrbf_ctx *ctx, const std::vector<int64_t> &idx, const
         L.ws = take(smallfit::carve((int)L.npad, q16).total);
         // evaluation 0: the fit's residual at the sites; evaluation 1: the caller's queries
         L.mpad0 = check ? round_up(pr.n, 64) : 0;
-        L.nsplit0 = check ? eval_nsplit(ctx, pr.n, L.npad) : 1;
+        L.nsplit0 = check ? eval_nsplit(ctx, pr.n, (int)((pr.n + 63) / 64)) : 1;
         L.Xq0 = take((size_t)L.mpad0 * L.D);
         L.xsq0 = take((size_t)L.mpad0);
         L.vp0 = take(L.nsplit0 > 1 ? (size_t)L.nsplit0 * L.mpad0 * L.KO * 2 : 0);
         L.gp0 = take((size_t)0);
         L.V0 = take((size_t)pr.n * k);
         L.mpad1 = round_up(pr.m, 64);
-        L.nsplit1 = pr.m > 0 ? eval_nsplit(ctx, pr.m, L.npad) : 1;
+        L.nsplit1 = pr.m > 0 ? eval_nsplit(ctx, pr.m, (int)((pr.n + 63) / 64)) : 1;
         L.Xq1 = take((size_t)L.mpad1 * L.D);
         L.xsq1 = take((size_t)L.mpad1);
         L.vp1 = take(L.nsplit1 > 1 ? (size_t)L.nsplit1 * L.mpad1 * L.KO * 2 : 0);
@@ -217,7 +217,8 @@ static int run_small_batch(mrbf_ctx *ctx, const std::vector<int64_t> &idx, const
             E.k = pr.k;
             E.q = L.q;
             E.nsplit = e == 0 ? L.nsplit0 : L.nsplit1;
-            const int ntiles = (int)(L.npad / 64);
+            const int ntiles = (int)((pr.n + 63) / 64);
+            E.ntiles = ntiles;
             E.tiles_per_split = (ntiles + E.nsplit - 1) / E.nsplit;
             E.kp = M.kp;
             E.vpart = base + (e == 0 ? L.vp0 : L.vp1);

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256, (DT <= 4) ? 2 : 1) void eval_fused_kernel(Eval
     // centre-tile staging: 64 rows x D doubles, row-major in global (contiguous 64*D*8 bytes); DT v2d per thread
     const int64_t c_begin = (int64_t)split * tiles_per_split * EC;
     // the centre range is cut into gridDim.y nearly equal pieces (the last one may be shorter)
-    const int ntiles_all = (int)(npad / EC);
+    const int ntiles_all = E.ntiles;
     const int my_tiles = min(tiles_per_split, ntiles_all - split * tiles_per_split);
     constexpr int NLD = 2 * DT;  // 64 * D / 2 v2d over 256 threads
     v2d stg[NLD];
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(512, 2) void eval_fused_split_kernel(EvalDesc one, 
     }
     // the descriptor counts centre tiles of EC = 64; this kernel walks them in pieces of ECT
     const int64_t c_begin = (int64_t)split * E.tiles_per_split * EC;
-    const int ntiles_all = (int)(npad / EC);
+    const int ntiles_all = E.ntiles;
     const int my_tiles = min(E.tiles_per_split, ntiles_all - split * E.tiles_per_split) * (EC / ECT);
     constexpr int NLD = ECT * D / 2 / 512;
     v2d stg[NLD];
@@ -545,9 +545,8 @@ __global__ void center_pad_batch_kernel(const EvalDesc *__restrict__ many, int D
     if (lane == 0) E.xsq[row] = s;
 }
 
-int eval_nsplit(const mrbf_ctx *ctx, int64_t m, int64_t npad) {
+int eval_nsplit(const mrbf_ctx *ctx, int64_t m, int ntiles) {
     const int64_t mpad = round_up(m, EQ);
-    const int ntiles = (int)(npad / EC);
     // Split the centre range so that the grid fills the resident workgroup slots (2 per CU) in whole rounds: the cost of a
     // split count is (rounds of workgroups) x (tiles per workgroup) plus the combine pass, which reads one partial per split.
     // (C3: 157 query tiles -> 3 splits of 43 tiles = 471 workgroups in one round, instead of 4 x 32 tiles in two rounds.)
@@ -688,8 +687,9 @@ int eval_fused(mrbf_ctx *ctx, const mrbf_model *M, int64_t m, const double *X, d
     if (M->dpad > 256) return fail(ctx, MRBF_EHIP, "eval_fused supports d <= 256");
     if (D != M->dpad) return fail(ctx, MRBF_EHIP, "eval_fused needs dpad in {64, 128, 256} (got %d)", M->dpad);
     const int64_t mpad = round_up(m, EQ);
-    const int ntiles = (int)(M->npad / EC);
-    const int nsplit = eval_nsplit(ctx, m, M->npad);
+    // (n = 2d + 1 = 257 sites are five tiles, not the six of the 128-padded storage: a sixth of a C4 evaluation)
+    const int ntiles = (int)((M->n + EC - 1) / EC);
+    const int nsplit = eval_nsplit(ctx, m, ntiles);
     const int KO = outputs_per_pass(k, D);
     EvalDesc E;
     std::memset(&E, 0, sizeof(E));
@@ -708,6 +708,7 @@ int eval_fused(mrbf_ctx *ctx, const mrbf_model *M, int64_t m, const double *X, d
     E.k = k;
     E.q = q;
     E.nsplit = nsplit;
+    E.ntiles = ntiles;
     E.tiles_per_split = (ntiles + nsplit - 1) / nsplit;
     E.kp = M->kp;
     if (nsplit > 1) {

@@ -61,13 +61,14 @@ struct EvalDesc {
     const double *Cc, *csq, *Wc, *lam;  // the model: centred centres (npad x D), their norms, weights (npad x k col-major), tail
     int64_t npad, mpad, m;
     int d, k, q, tiles_per_split, nsplit;
+    int ntiles;           // 64-centre tiles that hold real centres, ceil(n / 64) <= npad / 64: the padding tiles beyond are never walked
     KP kp;
     double *vpart, *sapart, *gpart;     // per-split partials (scratch)
     double *vals, *jac;                 // m x k, m x (k x d column-major); jac may be NULL for the whole batch only
 };
-// the centre-range split a single mrbf_eval of m points on a model with npad padded centres uses (the batch takes the same one, so
+// the centre-range split a single mrbf_eval of m points on a model with ntiles tiles of 64 centres uses (the batch takes the same one, so
 // that a batch and single calls add up their partial sums in the same order)
-int eval_nsplit(const mrbf_ctx *ctx, int64_t m, int64_t npad);
+int eval_nsplit(const mrbf_ctx *ctx, int64_t m, int ntiles);  // ntiles = ceil(n / 64)
 int outputs_per_pass(int k, int D);  // outputs of a model the fused evaluation handles per pass
 // all descriptors: same kernel id / fast flag / padded dimension D (64 or 128) / k; dev_descs = the same array in device memory
 int eval_fused_batch(mrbf_ctx *ctx, const KP &kp, int D, int k, bool want_jac, const EvalDesc *host_descs, const EvalDesc *dev_descs, int count);
