@@ -61,11 +61,12 @@ __device__ __forceinline__ void wg_gemm(int M, int N, int K, const double *__res
         gcd *pb = (gcd *)(TB ? B + (j0 + l15) + (int64_t)l4 * ldb : B + l4 + (int64_t)(j0 + l15) * ldb);
         const int64_t sa = TA ? 4 : 4 * (int64_t)lda, sb = TB ? 4 * (int64_t)ldb : 4;
         const int64_t oa = va1 ? (TA ? 16 * (int64_t)lda : 16) : 0, ob = vb1 ? (TB ? 16 : 16 * (int64_t)ldb) : 0;
-        // the operands come straight from global memory (L2 / Infinity Cache): UK k-steps of loads are issued as one burst and the
-        // next burst is in flight under this burst's MFMAs, otherwise every k-step would pay a full memory round trip
-        constexpr int UK = 4;
-        double fa0[2][UK], fa1[2][UK], fb0[2][UK], fb1[2][UK];
-        auto burst = [&](int buf, int) {
+        // The operands come straight from global memory, in bursts of UK k-steps kept in a ring of NR: a memory round trip costs ~1.5 us
+        // here (a problem's working set does not stay in the L2 once a batch shares it), the MFMAs of a burst 0.1 us -- the number of
+        // bursts in flight sets the pace (two: 6 us per macro tile at K = 128; four: one round trip per 64 columns of K).
+        constexpr int UK = 4, NR = 4;
+        double fa0[NR][UK], fa1[NR][UK], fb0[NR][UK], fb1[NR][UK];
+        auto burst = [&](int buf) {
 #pragma unroll
             for (int u = 0; u < UK; ++u) {
                 fa0[buf][u] = pa[u * sa];
@@ -76,24 +77,22 @@ __device__ __forceinline__ void wg_gemm(int M, int N, int K, const double *__res
             pa += UK * sa;
             pb += UK * sb;
         };
-        burst(0, 0);
-        for (int k = 0; k < K; k += 8 * UK) {
-            if (k + 4 * UK < K) burst(1, k + 4 * UK);
 #pragma unroll
-            for (int u = 0; u < UK; ++u) {
-                acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb0[0][u], fa0[0][u], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb1[0][u], fa0[0][u], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb0[0][u], fa1[0][u], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb1[0][u], fa1[0][u], acc[1][1], 0, 0, 0);
-            }
-            if (k + 4 * UK >= K) break;
-            if (k + 8 * UK < K) burst(0, k + 8 * UK);
+        for (int r = 0; r < NR; ++r)
+            if (4 * UK * r < K) burst(r);
+        for (int k0 = 0; k0 < K; k0 += 4 * UK * NR) {
 #pragma unroll
-            for (int u = 0; u < UK; ++u) {
-                acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb0[1][u], fa0[1][u], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb1[1][u], fa0[1][u], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb0[1][u], fa1[1][u], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb1[1][u], fa1[1][u], acc[1][1], 0, 0, 0);
+            for (int r = 0; r < NR; ++r) {
+                if (k0 + 4 * UK * r < K) {
+#pragma unroll
+                    for (int u = 0; u < UK; ++u) {
+                        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb0[r][u], fa0[r][u], acc[0][0], 0, 0, 0);
+                        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb1[r][u], fa0[r][u], acc[0][1], 0, 0, 0);
+                        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb0[r][u], fa1[r][u], acc[1][0], 0, 0, 0);
+                        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb1[r][u], fa1[r][u], acc[1][1], 0, 0, 0);
+                    }
+                    if (k0 + 4 * UK * (r + NR) < K) burst(r);
+                }
             }
         }
         // Epilogue in two passes: everything the epilogue READS for this macro tile first (pre: one burst of loads), then the stores
@@ -106,9 +105,11 @@ __device__ __forceinline__ void wg_gemm(int M, int N, int K, const double *__res
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
-                const bool on = !((a == 1 && !va1) || (b == 1 && !vb1)) && !(LOWER && 2 * I + a < 2 * J + b);
+                // (no branch around the reads: a missing second tile reads the first one's operands again, a tile above the diagonal
+                //  is read like any other and not written -- inside a branch every read waited for memory on its own)
+                const int ia = i0 + ((a == 1 && va1) ? 16 : 0), jb = j0 + ((b == 1 && vb1) ? 16 : 0);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) old[a][b][r] = on ? pre(i0 + 16 * a + l15, j0 + 16 * b + l4 + 4 * r) : 0.0;
+                for (int r = 0; r < 4; ++r) old[a][b][r] = pre(ia + l15, jb + l4 + 4 * r);
             }
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -121,6 +122,12 @@ __device__ __forceinline__ void wg_gemm(int M, int N, int K, const double *__res
             }
     }
 }
+
+// epilogue accesses through explicit global-address-space pointers: the workspace pointers come out of a struct, so the compiler
+// would emit flat_ instructions (both counters, the LDS aperture check) for every element
+typedef __attribute__((address_space(1))) double gdbl;
+__device__ __forceinline__ void gst(double *p, double v) { *(gdbl *)p = v; }
+__device__ __forceinline__ double gld(const double *p) { return *(const gdbl *)p; }
 
 struct NoPre {
     __device__ __forceinline__ double operator()(int, int) const { return 0.0; }
@@ -161,7 +168,7 @@ __device__ int wg_potrf(double *__restrict__ A, int ld, int np, int rows16, doub
         if (mrows <= 0) continue;
         // panel: L(r, c) = A(r, c) inv(L_cc)'  -> Pt (mrows x 128), then back into A
         const double *Arc = A + r0 + (int64_t)c * 128 * ld;
-        wg_gemm<false, true, false>(mrows, 128, 128, Arc, ld, Lc, 128, NoPre(), [&](int i, int j, double v, double) { Pt[i + (int64_t)j * np] = v; });
+        wg_gemm<false, true, false>(mrows, 128, 128, Arc, ld, Lc, 128, NoPre(), [&](int i, int j, double v, double) { gst(&Pt[i + (int64_t)j * np], v); });
         __syncthreads();
         for (int e = threadIdx.x; e < mrows * 128; e += 256) {
             const int i = e % mrows, j = e / mrows;
@@ -169,14 +176,14 @@ __device__ int wg_potrf(double *__restrict__ A, int ld, int np, int rows16, doub
         }
         // trailing update: A(r, s) -= L(r, c) L(s, c)'  for r >= s > c (lower tiles)
         double *Att = A + (int64_t)r0 * (ld + 1);
-        wg_gemm<false, true, true>(mrows, mrows, 128, Pt, np, Pt, np, [&](int i, int j) { return Att[i + (int64_t)j * ld]; },
-                                   [&](int i, int j, double v, double o) { Att[i + (int64_t)j * ld] = o - v; });
+        wg_gemm<false, true, true>(mrows, mrows, 128, Pt, np, Pt, np, [&](int i, int j) { return gld(&Att[i + (int64_t)j * ld]); },
+                                   [&](int i, int j, double v, double o) { gst(&Att[i + (int64_t)j * ld], o - v); });
         __syncthreads();
     }
     return 0;
 }
 
-__global__ __launch_bounds__(256, 1) void small_fit_kernel(Prob one, const Prob *__restrict__ many) {
+__global__ __launch_bounds__(256, 2) void small_fit_kernel(Prob one, const Prob *__restrict__ many) {
     __shared__ __attribute__((aligned(16))) diagcore::DiagV4Shared sh;
     __shared__ double red[4];
     __shared__ double s_mean[128];
@@ -233,7 +240,8 @@ __global__ __launch_bounds__(256, 1) void small_fit_kernel(Prob one, const Prob 
         const KP kp = P.kp;
         const double *sq = P.sq;
         wg_gemm<true, false, false>(
-            n16, n16, dpad, XcT, dpad, XcT, dpad, [&](int i, int j) { return (i < n && j < n) ? sq[i] + sq[j] : 0.0; },
+            n16, n16, dpad, XcT, dpad, XcT, dpad, // (no branch around the loads: inside one, the sum waits for its two loads, sixteen dependent round trips per macro tile)
+            [&](int i, int j) { return gld(&sq[i < n ? i : n - 1]) + gld(&sq[j < n ? j : n - 1]); },
             [&](int i, int j, double sdot, double sqsum) {
                 double v;
                 if (i < n && j < n) {
@@ -244,7 +252,7 @@ __global__ __launch_bounds__(256, 1) void small_fit_kernel(Prob one, const Prob 
                 } else {
                     v = (i == j) ? 1.0 : 0.0;
                 }
-                Phi[(int64_t)j * np + i] = v;
+                gst(&Phi[(int64_t)j * np + i], v);
             });
         // identity in the padding beyond n16 (rows / columns n16 .. np - 1 of the lower triangle are all the factorisation reads there)
         for (int e = tid; e < (np - n16) * np; e += 256) {
@@ -269,7 +277,7 @@ __global__ __launch_bounds__(256, 1) void small_fit_kernel(Prob one, const Prob 
             for (int e = tid; e < 128 * 128; e += 256) Gx[e] = (e % 128 == e / 128 && e % 128 >= d) ? 1.0 : 0.0;
             __syncthreads();
             wg_gemm<false, true, true>(d16, d16, n16, P.Xc, dpad, P.Xc, dpad, NoPre(), [&](int a, int b, double v, double) {
-                if (a < d && b < d) Gx[a + b * 128] = v;
+                if (a < d && b < d) gst(&Gx[a + b * 128], v);
             });
             __syncthreads();
             {
@@ -281,16 +289,16 @@ __global__ __launch_bounds__(256, 1) void small_fit_kernel(Prob one, const Prob 
             // Qx(i, a) = sum_b Xc(i, b) inv(Lx)(a, b)
             double *Qx = Q1 + np;
             wg_gemm<true, true, false>(n16, d16, d16, P.Xc, dpad, LinvX, 128, NoPre(), [&](int i, int a, double v, double) {
-                if (i < n && a < d) Qx[i + (int64_t)a * np] = v;
+                if (i < n && a < d) gst(&Qx[i + (int64_t)a * np], v);
             });
         }
         __syncthreads();
         MRBF_STAMP();  // 3: Q1
         // ---- W1 = Phi Q1;  G = Q1' W1;  W = W1 - 1/2 Q1 G;  mu = (n phi0 - trace G) / (n - q);  V = W - mu/2 Q1
-        wg_gemm<false, false, false>(n16, q16, n16, Phi, np, Q1, np, NoPre(), [&](int i, int t, double v, double) { Wm[i + (int64_t)t * np] = v; });
+        wg_gemm<false, false, false>(n16, q16, n16, Phi, np, Q1, np, NoPre(), [&](int i, int t, double v, double) { gst(&Wm[i + (int64_t)t * np], v); });
         for (int e = tid; e < (np - n16) * q16; e += 256) Wm[n16 + e % (np - n16) + (int64_t)(e / (np - n16)) * np] = 0.0;
         __syncthreads();
-        wg_gemm<true, false, false>(q16, q16, n16, Q1, np, Wm, np, NoPre(), [&](int a, int b, double v, double) { G[a + b * q16] = v; });
+        wg_gemm<true, false, false>(q16, q16, n16, Q1, np, Wm, np, NoPre(), [&](int a, int b, double v, double) { gst(&G[a + b * q16], v); });
         __syncthreads();
         double tr = 0.0;
         for (int t = tid; t < q; t += 256) tr += G[t + t * q16];
@@ -303,26 +311,26 @@ __global__ __launch_bounds__(256, 1) void small_fit_kernel(Prob one, const Prob 
             P.scal[1] = mu;
             if (!mu_ok) P.flags[2] = 1;
         }
-        wg_gemm<false, false, false>(n16, q16, q16, Q1, np, G, q16, [&](int i, int t) { return Wm[i + (int64_t)t * np]; },
-                                     [&](int i, int t, double v, double o) { Wm[i + (int64_t)t * np] = o - 0.5 * v; });
+        wg_gemm<false, false, false>(n16, q16, q16, Q1, np, G, q16, [&](int i, int t) { return gld(&Wm[i + (int64_t)t * np]); },
+                                     [&](int i, int t, double v, double o) { gst(&Wm[i + (int64_t)t * np], o - 0.5 * v); });
         __syncthreads();
         for (int e = tid; e < np * q16; e += 256) V[e] = fma(-0.5 * mu, Q1[e], Wm[e]);
         __syncthreads();
         MRBF_STAMP();  // 4: W, G, mu, V
         // ---- K = Phi - Q1 V' - V Q1' on the lower triangle (column-major: K(i, j), i >= j, at Phi[i + j * np])
-        wg_gemm<false, true, true>(n16, n16, q16, Q1, np, V, np, [&](int i, int j) { return Phi[i + (int64_t)j * np]; },
-                                   [&](int i, int j, double v, double o) { Phi[i + (int64_t)j * np] = o - v; });
+        wg_gemm<false, true, true>(n16, n16, q16, Q1, np, V, np, [&](int i, int j) { return gld(&Phi[i + (int64_t)j * np]); },
+                                   [&](int i, int j, double v, double o) { gst(&Phi[i + (int64_t)j * np], o - v); });
         __syncthreads();
-        wg_gemm<false, true, true>(n16, n16, q16, V, np, Q1, np, [&](int i, int j) { return Phi[i + (int64_t)j * np]; },
-                                   [&](int i, int j, double v, double o) { Phi[i + (int64_t)j * np] = o - v; });
+        wg_gemm<false, true, true>(n16, n16, q16, V, np, Q1, np, [&](int i, int j) { return gld(&Phi[i + (int64_t)j * np]); },
+                                   [&](int i, int j, double v, double o) { gst(&Phi[i + (int64_t)j * np], o - v); });
         MRBF_STAMP();  // 5: K update (issued)
         // ---- B = P Y = Y - Q1 (Q1' Y);  T1 keeps Q1' Y for the tail coefficients
-        wg_gemm<true, false, false>(q16, 16, n16, Q1, np, Yc, np, NoPre(), [&](int a, int l, double v, double) { T1[a + l * ldz] = v; });
+        wg_gemm<true, false, false>(q16, 16, n16, Q1, np, Yc, np, NoPre(), [&](int a, int l, double v, double) { gst(&T1[a + l * ldz], v); });
         __syncthreads();
         for (int e = tid; e < np * 16; e += 256) Bm[e] = Yc[e];
         __syncthreads();
-        wg_gemm<false, false, false>(n16, 16, q16, Q1, np, T1, ldz, [&](int i, int l) { return Bm[i + l * np]; },
-                                     [&](int i, int l, double v, double o) { Bm[i + l * np] = o - v; });
+        wg_gemm<false, false, false>(n16, 16, q16, Q1, np, T1, ldz, [&](int i, int l) { return gld(&Bm[i + l * np]); },
+                                     [&](int i, int l, double v, double o) { gst(&Bm[i + l * np], o - v); });
     } else {
         for (int e = tid; e < np * 16; e += 256) Bm[e] = Yc[e];
         if (tid == 0) {
@@ -347,42 +355,42 @@ __global__ __launch_bounds__(256, 1) void small_fit_kernel(Prob one, const Prob 
     // ---- forward substitution L y = B (block rows; inv(L_cc) from the factorisation), then backward L' x = y
     for (int c = 0; c < nb; ++c) {
         if (c > 0) {
-            wg_gemm<false, false, false>(128, 16, 128 * c, Phi + 128 * c, np, Fy, np, [&](int i, int l) { return Bm[128 * c + i + l * np]; },
-                                         [&](int i, int l, double v, double o) { Bm[128 * c + i + l * np] = o - v; });
+            wg_gemm<false, false, false>(128, 16, 128 * c, Phi + 128 * c, np, Fy, np, [&](int i, int l) { return gld(&Bm[128 * c + i + l * np]); },
+                                         [&](int i, int l, double v, double o) { gst(&Bm[128 * c + i + l * np], o - v); });
             __syncthreads();
         }
         wg_gemm<false, false, false>(128, 16, 128, Linv + (int64_t)c * 128 * 128, 128, Bm + 128 * c, np, NoPre(),
-                                     [&](int i, int l, double v, double) { Fy[128 * c + i + l * np] = v; });
+                                     [&](int i, int l, double v, double) { gst(&Fy[128 * c + i + l * np], v); });
         __syncthreads();
     }
     for (int c = nb - 1; c >= 0; --c) {
         const int rest = np - 128 * (c + 1);
         if (rest > 0) {
             wg_gemm<true, false, false>(128, 16, rest, Phi + 128 * (c + 1) + (int64_t)128 * c * np, np, Xs + 128 * (c + 1), np,
-                                        [&](int i, int l) { return Fy[128 * c + i + l * np]; },
-                                        [&](int i, int l, double v, double o) { Fy[128 * c + i + l * np] = o - v; });
+                                        [&](int i, int l) { return gld(&Fy[128 * c + i + l * np]); },
+                                        [&](int i, int l, double v, double o) { gst(&Fy[128 * c + i + l * np], o - v); });
             __syncthreads();
         }
         wg_gemm<true, false, false>(128, 16, 128, Linv + (int64_t)c * 128 * 128, 128, Fy + 128 * c, np, NoPre(),
-                                    [&](int i, int l, double v, double) { Xs[128 * c + i + l * np] = v; });
+                                    [&](int i, int l, double v, double) { gst(&Xs[128 * c + i + l * np], v); });
         __syncthreads();
     }
     MRBF_STAMP();  // 8: solves
     // ---- tail: re-project w (rounding hygiene), z = Q1' Y - W' w, lam = R^-1 z with R = [[sqrt n, sqrt n mean'], [0, Lx']]
     if (q > 0) {
-        wg_gemm<true, false, false>(q16, 16, n16, Q1, np, Xs, np, NoPre(), [&](int a, int l, double v, double) { T2[a + l * ldz] = v; });
+        wg_gemm<true, false, false>(q16, 16, n16, Q1, np, Xs, np, NoPre(), [&](int a, int l, double v, double) { gst(&T2[a + l * ldz], v); });
         __syncthreads();
-        wg_gemm<false, false, false>(n16, 16, q16, Q1, np, T2, ldz, [&](int i, int l) { return Xs[i + l * np]; },
-                                     [&](int i, int l, double v, double o) { Xs[i + l * np] = o - v; });
+        wg_gemm<false, false, false>(n16, 16, q16, Q1, np, T2, ldz, [&](int i, int l) { return gld(&Xs[i + l * np]); },
+                                     [&](int i, int l, double v, double o) { gst(&Xs[i + l * np], o - v); });
         __syncthreads();
-        wg_gemm<true, false, false>(q16, 16, n16, Wm, np, Xs, np, [&](int a, int l) { return T1[a + l * ldz]; },
-                                    [&](int a, int l, double v, double o) { Z[a + l * ldz] = o - v; });
+        wg_gemm<true, false, false>(q16, 16, n16, Wm, np, Xs, np, [&](int a, int l) { return gld(&T1[a + l * ldz]); },
+                                    [&](int a, int l, double v, double o) { gst(&Z[a + l * ldz], o - v); });
         for (int e = tid; e < 16 * 16; e += 256) Z[q16 + e % 16 + (e / 16) * ldz] = 0.0;  // the rows the next product may read beyond q16
         __syncthreads();
         if (q > 1) {
             const int d16 = (d + 15) & ~15;
             // lam_tail = Lx^-T z[1:]  =  inv(Lx)' z[1:]
-            wg_gemm<true, false, false>(d16, 16, d16, LinvX, 128, Z + 1, ldz, NoPre(), [&](int a, int l, double v, double) { T2[1 + a + l * ldz] = v; });
+            wg_gemm<true, false, false>(d16, 16, d16, LinvX, 128, Z + 1, ldz, NoPre(), [&](int a, int l, double v, double) { gst(&T2[1 + a + l * ldz], v); });
             __syncthreads();
         }
         // lam[0] = z0 / sqrt(n) - mean . lam[1:]
