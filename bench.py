@@ -281,13 +281,18 @@ def main():
             def step(self):
                 rc = self.lib.mrbf_batch_run(1, (ctypes.c_int32 * 1)(local_rank), len(mine), self.arr, self.res)
                 assert rc == 0, "mrbf_batch_run failed: %d" % rc
-                recs = []
-                for j, p in enumerate(mine):
-                    r = self.res[j]
-                    assert r.status == 0, (p, r.status)
-                    recs.append([float(p), 0.0, float(r.fit.path), float(r.fit.rel_residual), r.checksum_w, r.checksum_vals, r.fit.ms_total, r.ms_eval])
-                    if r.fit.fallbacks & ~_lib.FB_LU:
-                        self.fallbacks += 1
+                # the result records as columns of one byte view over the ctypes array (a Python loop over 64 structs costs ~0.4 ms a step)
+                raw = np.frombuffer(self.res, dtype=np.uint8).reshape(-1, ctypes.sizeof(_lib.Result))[:len(mine)]
+                col = lambda off, dt: raw[:, off:off + np.dtype(dt).itemsize].copy().view(dt)[:, 0]
+                R, F = _lib.Result, _lib.FitInfo
+                status = col(R.status.offset, np.int32)
+                assert not status.any(), [(p, int(st)) for p, st in zip(mine, status) if st]
+                fo = R.fit.offset
+                recs = np.stack([np.asarray(mine, dtype=np.float64), np.zeros(len(mine)), col(fo + F.path.offset, np.int32).astype(np.float64),
+                                 col(fo + F.rel_residual.offset, np.float64), col(R.checksum_w.offset, np.float64),
+                                 col(R.checksum_vals.offset, np.float64), col(fo + F.ms_total.offset, np.float32).astype(np.float64),
+                                 col(R.ms_eval.offset, np.float32).astype(np.float64)], axis=1) if mine else np.zeros((0, 8))
+                self.fallbacks += int(np.count_nonzero(col(fo + F.fallbacks.offset, np.int32) & ~_lib.FB_LU)) if mine else 0
                 if mine:   # the batch's times are shared by its members: count them once per step, spread over the problems below
                     self.phases["factor"] += self.res[0].fit.ms_factor
                     self.phases["eval"] += self.res[0].ms_eval
