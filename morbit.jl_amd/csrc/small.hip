@@ -57,25 +57,52 @@ __device__ __forceinline__ void wg_gemm(int M, int N, int K, const double *__res
         //  site and a missing second tile re-reads the first one: as `cond ? load : 0` every operand load sat in its own exec-mask
         //  branch)
         typedef const __attribute__((address_space(1))) double gcd;
-        gcd *pa = (gcd *)(TA ? A + l4 + (int64_t)(i0 + l15) * lda : A + (i0 + l15) + (int64_t)l4 * lda);
-        gcd *pb = (gcd *)(TB ? B + (j0 + l15) + (int64_t)l4 * ldb : B + l4 + (int64_t)(j0 + l15) * ldb);
-        const int64_t sa = TA ? 4 : 4 * (int64_t)lda, sb = TB ? 4 * (int64_t)ldb : 4;
+        // Within a group of 16 columns of K, MFMA step s takes k = 4 l4 + s from lane group l4 (any assignment works as long as both
+        // operands use the same one): an operand that is contiguous in k then gives every lane 32 contiguous bytes per burst and the
+        // four lane groups one whole 128-byte line per row.  (With k = 4 s + l4 every 8-byte load took its own 32 bytes out of a line
+        // that three later loads fetched again from the L2: 128 KB of line traffic per burst and CU, ~1.1 us, the pace of every
+        // product here.)
+        typedef const __attribute__((address_space(1))) v4d gcv4 __attribute__((aligned(8)));
+        gcd *pa = (gcd *)(TA ? A + 4 * l4 + (int64_t)(i0 + l15) * lda : A + (i0 + l15) + (int64_t)(4 * l4) * lda);
+        gcd *pb = (gcd *)(TB ? B + (j0 + l15) + (int64_t)(4 * l4) * ldb : B + 4 * l4 + (int64_t)(j0 + l15) * ldb);
         const int64_t oa = va1 ? (TA ? 16 * (int64_t)lda : 16) : 0, ob = vb1 ? (TB ? 16 : 16 * (int64_t)ldb) : 0;
-        // The operands come straight from global memory, in bursts of UK k-steps kept in a ring of NR: a memory round trip costs ~1.5 us
-        // here (a problem's working set does not stay in the L2 once a batch shares it), the MFMAs of a burst 0.1 us -- the number of
-        // bursts in flight sets the pace (two: 6 us per macro tile at K = 128; four: one round trip per 64 columns of K).
+        // Bursts of UK = 4 k-steps (one group of 16 columns) kept in a ring of NR: a memory round trip costs ~1.5 us here (a problem's
+        // working set does not stay in the L2 once a batch shares it), the MFMAs of a burst 0.1 us.
         constexpr int UK = 4, NR = 4;
         double fa0[NR][UK], fa1[NR][UK], fb0[NR][UK], fb1[NR][UK];
         auto burst = [&](int buf) {
+            if constexpr (TA) {
+                const v4d x0 = *(gcv4 *)pa, x1 = *(gcv4 *)(pa + oa);
 #pragma unroll
-            for (int u = 0; u < UK; ++u) {
-                fa0[buf][u] = pa[u * sa];
-                fa1[buf][u] = pa[u * sa + oa];
-                fb0[buf][u] = pb[u * sb];
-                fb1[buf][u] = pb[u * sb + ob];
+                for (int u = 0; u < UK; ++u) {
+                    fa0[buf][u] = x0[u];
+                    fa1[buf][u] = x1[u];
+                }
+                pa += 16;
+            } else {
+#pragma unroll
+                for (int u = 0; u < UK; ++u) {
+                    fa0[buf][u] = pa[(int64_t)u * lda];
+                    fa1[buf][u] = pa[(int64_t)u * lda + oa];
+                }
+                pa += 16 * (int64_t)lda;
             }
-            pa += UK * sa;
-            pb += UK * sb;
+            if constexpr (!TB) {
+                const v4d y0 = *(gcv4 *)pb, y1 = *(gcv4 *)(pb + ob);
+#pragma unroll
+                for (int u = 0; u < UK; ++u) {
+                    fb0[buf][u] = y0[u];
+                    fb1[buf][u] = y1[u];
+                }
+                pb += 16;
+            } else {
+#pragma unroll
+                for (int u = 0; u < UK; ++u) {
+                    fb0[buf][u] = pb[(int64_t)u * ldb];
+                    fb1[buf][u] = pb[(int64_t)u * ldb + ob];
+                }
+                pb += 16 * (int64_t)ldb;
+            }
         };
 #pragma unroll
         for (int r = 0; r < NR; ++r)
@@ -207,24 +234,63 @@ __global__ __launch_bounds__(256, 2) void small_fit_kernel(Prob one, const Prob 
     MRBF_STAMP();
 
     // ---- centroid, centred + zero-padded coordinates, squared norms (the model's own arrays: the evaluation uses them later)
-    if (tid < 128) {
-        double s = 0.0;
-        if (tid < d)
-            for (int i = 0; i < n; ++i) s += P.C[(int64_t)i * d + tid];
-        s_mean[tid] = tid < d ? s / (double)n : 0.0;
+    {
+        // column sums: wave w takes the rows w, w + 4, ..., eight rows (independent loads) per step, lanes over the columns; the four
+        // partial sums meet in LDS in a fixed order.  (One thread per column walking all n rows paid a memory round trip per row:
+        // 80 us of a 257-site fit.)
+        const gdbl *Cg = (const gdbl *)P.C;
+        double s0 = 0.0, s1 = 0.0;
+        const int t0 = lane, t1 = lane + 64;
+        for (int i0 = wave; i0 < n; i0 += 32) {
+            double a0[8], a1[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + 4 * u;
+                a0[u] = (i < n && t0 < d) ? Cg[(int64_t)i * d + t0] : 0.0;
+                a1[u] = (i < n && t1 < d) ? Cg[(int64_t)i * d + t1] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                s0 += a0[u];
+                s1 += a1[u];
+            }
+        }
+        double *part = sh.LT;  // 4 x 128 doubles of the (idle) diagonal-core LDS
+        part[wave * 128 + t0] = s0;
+        part[wave * 128 + t1] = s1;
+        __syncthreads();
+        if (tid < 128) s_mean[tid] = tid < d ? ((part[tid] + part[128 + tid]) + (part[256 + tid] + part[384 + tid])) / (double)n : 0.0;
     }
     __syncthreads();
     for (int t = tid; t < dpad; t += 256) P.mean[t] = t < 128 ? s_mean[t] : 0.0;
-    for (int row = wave; row < np; row += 4) {
-        double s = 0.0;
-        for (int t = lane; t < dpad; t += 64) {
-            double v = 0.0;
-            if (row < n && t < d) v = P.C[(int64_t)row * d + t] - s_mean[t];
-            P.Xc[(int64_t)row * dpad + t] = v;
-            s = fma(v, v, s);
+    {
+        const gdbl *Cg = (const gdbl *)P.C;
+        gdbl *Xg = (gdbl *)P.Xc;
+        for (int row0 = wave; row0 < np; row0 += 16) {  // four rows per wave and step
+            double sacc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int row = row0 + 4 * u;
+                double sr = 0.0;
+                if (row < np) {
+                    for (int t = lane; t < dpad; t += 64) {
+                        double v = 0.0;
+                        if (row < n && t < d) v = Cg[(int64_t)row * d + t] - s_mean[t];
+                        Xg[(int64_t)row * dpad + t] = v;
+                        sr = fma(v, v, sr);
+                    }
+                }
+                sacc[u] = sr;
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) sacc[u] += __shfl_xor(sacc[u], off);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (lane == 0 && row0 + 4 * u < np) P.sq[row0 + 4 * u] = sacc[u];
         }
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-        if (lane == 0) P.sq[row] = s;
     }
     // right-hand sides, column-major and zero padded: Yc (np x 16)
     for (int e = tid; e < np * 16; e += 256) {
@@ -243,23 +309,57 @@ __global__ __launch_bounds__(256, 2) void small_fit_kernel(Prob one, const Prob 
             n16, n16, dpad, XcT, dpad, XcT, dpad, // (no branch around the loads: inside one, the sum waits for its two loads, sixteen dependent round trips per macro tile)
             [&](int i, int j) { return gld(&sq[i < n ? i : n - 1]) + gld(&sq[j < n ? j : n - 1]); },
             [&](int i, int j, double sdot, double sqsum) {
+                // squared distances here; the radial function follows as a pass of its own with the kernel family chosen OUTSIDE the
+                // loop: inlined into this epilogue the five-way switch stood sixteen times in every macro tile's code (100 KB of
+                // instructions per tile, more than the instruction cache holds)
                 double v;
                 if (i < n && j < n) {
-                    double s = fma(-2.0, sdot, sqsum);
-                    s = s > 0.0 ? s : 0.0;
-                    if (i == j) s = 0.0;
-                    v = phi_rt(s, kp);
+                    v = fma(-2.0, sdot, sqsum);
+                    v = v > 0.0 ? v : 0.0;
+                    if (i == j) v = 0.0;
                 } else {
                     v = (i == j) ? 1.0 : 0.0;
                 }
                 gst(&Phi[(int64_t)j * np + i], v);
             });
-        // identity in the padding beyond n16 (rows / columns n16 .. np - 1 of the lower triangle are all the factorisation reads there)
-        for (int e = tid; e < (np - n16) * np; e += 256) {
-            const int c = n16 + e / np, r = e % np;
-            Phi[r + (int64_t)c * np] = (r == c) ? 1.0 : 0.0;
-            Phi[c + (int64_t)r * np] = (r == c) ? 1.0 : 0.0;
+        __syncthreads();
+        if (P.stamps && tid == 0) P.stamps[11] = (long long)wall_clock64();  // product done
+        {
+            // eight columns at a time per wave: all loads of a batch before its first store (one element at a time, every iteration
+            // paid a memory round trip: 110 us for 257 x 257 entries)
+            auto radial = [&](auto f) {
+                for (int j0 = 8 * wave; j0 < n; j0 += 32)
+                    for (int i = lane; i < n; i += 64) {
+                        double t[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) t[u] = gld(&Phi[(int64_t)(j0 + u < n ? j0 + u : n - 1) * np + i]);
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            if (j0 + u < n) gst(&Phi[(int64_t)(j0 + u) * np + i], f(t[u]));
+                    }
+            };
+            switch (kp.kid) {
+                case MRBF_CUBIC:
+                    if (kp.fast) radial([&](double t) { return rbf_phi_t<MRBF_CUBIC, true>(t, kp); });
+                    else radial([&](double t) { return rbf_phi_t<MRBF_CUBIC, false>(t, kp); });
+                    break;
+                case MRBF_INV_MULTIQUADRIC:
+                    if (kp.fast) radial([&](double t) { return rbf_phi_t<MRBF_INV_MULTIQUADRIC, true>(t, kp); });
+                    else radial([&](double t) { return rbf_phi_t<MRBF_INV_MULTIQUADRIC, false>(t, kp); });
+                    break;
+                case MRBF_MULTIQUADRIC:
+                    if (kp.fast) radial([&](double t) { return rbf_phi_t<MRBF_MULTIQUADRIC, true>(t, kp); });
+                    else radial([&](double t) { return rbf_phi_t<MRBF_MULTIQUADRIC, false>(t, kp); });
+                    break;
+                case MRBF_THIN_PLATE_SPLINE: radial([&](double t) { return rbf_phi_t<MRBF_THIN_PLATE_SPLINE, false>(t, kp); }); break;
+                default: radial([&](double t) { return rbf_phi_t<MRBF_GAUSSIAN, false>(t, kp); }); break;
+            }
         }
+        if (P.stamps && tid == 0) P.stamps[12] = (long long)wall_clock64();  // radial function done (this wave)
+        // identity in the padding beyond n16 (rows / columns n16 .. np - 1 of the lower triangle are all the factorisation reads there)
+        // (rows n16 .. np - 1 of every column, contiguous per column; the block above the diagonal is never read)
+        for (int c = wave; c < np; c += 4)
+            for (int r = n16 + lane; r < np; r += 64) gst(&Phi[r + (int64_t)c * np], (r == c) ? 1.0 : 0.0);
     }
     __syncthreads();
 

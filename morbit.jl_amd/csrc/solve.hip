@@ -751,7 +751,8 @@ static int fit_small(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_inf
         static const char *names[] = {"centre", "gram", "Q1", "W,G,mu,V", "K update", "rhs", "potrf", "solves", "tail"};
         fprintf(stderr, "small fit n=%lld d=%d q=%d: %.3f ms |", (long long)M->n, M->d, M->q, info->ms_factor);
         for (int i = 0; i < 9; ++i) fprintf(stderr, " %s %.1f us |", names[i], (hs[i + 1] - hs[i]) * 0.01);
-        fprintf(stderr, "\n");
+        fprintf(stderr, " [gram: product %.1f us, radial function %.1f us, padding %.1f us]\n", (hs[11] - hs[1]) * 0.01, (hs[12] - hs[11]) * 0.01,
+                (hs[2] - hs[12]) * 0.01);
     }
     *not_pd = small_fit_verdict(M, hflags, hscal, info);
     return 0;
