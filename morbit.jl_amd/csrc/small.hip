@@ -32,6 +32,25 @@ __device__ __forceinline__ double phi_rt(double s, const KP &p) {
     }
 }
 
+// epilogue accesses through explicit global-address-space pointers: the workspace pointers come out of a struct, so the compiler
+// would emit flat_ instructions (both counters, the LDS aperture check) for every element
+typedef __attribute__((address_space(1))) double gdbl;
+__device__ __forceinline__ void gst(double *p, double v) { *(gdbl *)p = v; }
+__device__ __forceinline__ double gld(const double *p) { return *(const gdbl *)p; }
+
+// elementwise pass over [0, count): f(e, loaded...) with the loads of eight elements per thread issued before the first store
+template <class Load, class Store>
+__device__ __forceinline__ void batched_pass(int count, Load load, Store store) {
+    for (int e0 = threadIdx.x; e0 < count; e0 += 8 * 256) {
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = load(e0 + 256 * u < count ? e0 + 256 * u : e0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (e0 + 256 * u < count) store(e0 + 256 * u, t[u]);
+    }
+}
+
 // C(i, j) (op)= sum_k A'(i, k) B'(k, j) for one workgroup of 4 waves; A' = TA ? A^T : A, B' = TB ? B^T : B (A, B column-major with
 // leading dimensions lda, ldb); M, N multiples of 16, K a multiple of 4.  Every wave takes 32 x 32 macro tiles (2 x 2 MFMA tiles)
 // round-robin; the epilogue is pre(i, j) -> what it reads, then post(i, j, value, what pre returned).  LOWER: only 16 x 16 tiles on or below the diagonal.
@@ -150,12 +169,6 @@ __device__ __forceinline__ void wg_gemm(int M, int N, int K, const double *__res
     }
 }
 
-// epilogue accesses through explicit global-address-space pointers: the workspace pointers come out of a struct, so the compiler
-// would emit flat_ instructions (both counters, the LDS aperture check) for every element
-typedef __attribute__((address_space(1))) double gdbl;
-__device__ __forceinline__ void gst(double *p, double v) { *(gdbl *)p = v; }
-__device__ __forceinline__ double gld(const double *p) { return *(const gdbl *)p; }
-
 struct NoPre {
     __device__ __forceinline__ double operator()(int, int) const { return 0.0; }
 };
@@ -197,10 +210,8 @@ __device__ int wg_potrf(double *__restrict__ A, int ld, int np, int rows16, doub
         const double *Arc = A + r0 + (int64_t)c * 128 * ld;
         wg_gemm<false, true, false>(mrows, 128, 128, Arc, ld, Lc, 128, NoPre(), [&](int i, int j, double v, double) { gst(&Pt[i + (int64_t)j * np], v); });
         __syncthreads();
-        for (int e = threadIdx.x; e < mrows * 128; e += 256) {
-            const int i = e % mrows, j = e / mrows;
-            A[(r0 + i) + (int64_t)(c * 128 + j) * ld] = Pt[i + (int64_t)j * np];
-        }
+        batched_pass(mrows * 128, [&](int e) { return gld(&Pt[e % mrows + (int64_t)(e / mrows) * np]); },
+                     [&](int e, double v) { gst(&A[(r0 + e % mrows) + (int64_t)(c * 128 + e / mrows) * ld], v); });
         // trailing update: A(r, s) -= L(r, c) L(s, c)'  for r >= s > c (lower tiles)
         double *Att = A + (int64_t)r0 * (ld + 1);
         wg_gemm<false, true, true>(mrows, mrows, 128, Pt, np, Pt, np, [&](int i, int j) { return gld(&Att[i + (int64_t)j * ld]); },
@@ -414,7 +425,10 @@ __global__ __launch_bounds__(256, 2) void small_fit_kernel(Prob one, const Prob 
         wg_gemm<false, false, false>(n16, q16, q16, Q1, np, G, q16, [&](int i, int t) { return gld(&Wm[i + (int64_t)t * np]); },
                                      [&](int i, int t, double v, double o) { gst(&Wm[i + (int64_t)t * np], o - 0.5 * v); });
         __syncthreads();
-        for (int e = tid; e < np * q16; e += 256) V[e] = fma(-0.5 * mu, Q1[e], Wm[e]);
+        {
+            const double hmu = -0.5 * mu;
+            batched_pass(np * q16, [&](int e) { return fma(hmu, gld(&Q1[e]), gld(&Wm[e])); }, [&](int e, double v) { gst(&V[e], v); });
+        }
         __syncthreads();
         MRBF_STAMP();  // 4: W, G, mu, V
         // ---- K = Phi - Q1 V' - V Q1' on the lower triangle (column-major: K(i, j), i >= j, at Phi[i + j * np])
@@ -427,12 +441,12 @@ __global__ __launch_bounds__(256, 2) void small_fit_kernel(Prob one, const Prob 
         // ---- B = P Y = Y - Q1 (Q1' Y);  T1 keeps Q1' Y for the tail coefficients
         wg_gemm<true, false, false>(q16, 16, n16, Q1, np, Yc, np, NoPre(), [&](int a, int l, double v, double) { gst(&T1[a + l * ldz], v); });
         __syncthreads();
-        for (int e = tid; e < np * 16; e += 256) Bm[e] = Yc[e];
+        batched_pass(np * 16, [&](int e) { return gld(&Yc[e]); }, [&](int e, double v) { gst(&Bm[e], v); });
         __syncthreads();
         wg_gemm<false, false, false>(n16, 16, q16, Q1, np, T1, ldz, [&](int i, int l) { return gld(&Bm[i + l * np]); },
                                      [&](int i, int l, double v, double o) { gst(&Bm[i + l * np], o - v); });
     } else {
-        for (int e = tid; e < np * 16; e += 256) Bm[e] = Yc[e];
+        batched_pass(np * 16, [&](int e) { return gld(&Yc[e]); }, [&](int e, double v) { gst(&Bm[e], v); });
         if (tid == 0) {
             P.scal[0] = 0.0;
             P.scal[1] = 0.0;
