@@ -219,6 +219,7 @@ static int run_small_batch(mrbf_ctx *ctx, const std::vector<int64_t> &idx, const
             E.nsplit = e == 0 ? L.nsplit0 : L.nsplit1;
             const int ntiles = (int)((pr.n + 63) / 64);
             E.ntiles = ntiles;
+            E.nsub = (int)((pr.n + 15) / 16);
             E.tiles_per_split = (ntiles + E.nsplit - 1) / E.nsplit;
             E.kp = M.kp;
             E.vpart = base + (e == 0 ? L.vp0 : L.vp1);

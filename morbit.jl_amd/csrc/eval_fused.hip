@@ -102,6 +102,7 @@ __global__ __launch_bounds__(256, (DT <= 4) ? 2 : 1) void eval_fused_kernel(Eval
         if (tile + 1 < my_tiles) load_tile(c0 + EC);
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
+            if ((int)(c0 >> 4) + ct >= E.nsub) break;  // only padding from here on (zero weights: nothing to add)
             // ---- phase 1
             v4d S = {0.0, 0.0, 0.0, 0.0};
             const double *crow = &Cs[(16 * ct + l15) * LDC + l4];
@@ -325,6 +326,7 @@ __global__ __launch_bounds__(512, 2) void eval_fused_split_kernel(EvalDesc one, 
         if (tile + 1 < my_tiles) load_tile(c0 + ECT);
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) {
+            if ((int)(c0 >> 4) + ct >= E.nsub) break;  // only padding from here on (uniform: every wave leaves before the barrier)
             // ---- phase 1: this group's half of S', exchanged with the partner wave (same queries, other half)
             v4d Sp = {0.0, 0.0, 0.0, 0.0};
             const double *crow = &Cs[(16 * ct + l15) * LDC + H * grp + l4];
@@ -709,6 +711,7 @@ int eval_fused(mrbf_ctx *ctx, const mrbf_model *M, int64_t m, const double *X, d
     E.q = q;
     E.nsplit = nsplit;
     E.ntiles = ntiles;
+    E.nsub = (int)((M->n + 15) / 16);
     E.tiles_per_split = (ntiles + nsplit - 1) / nsplit;
     E.kp = M->kp;
     if (nsplit > 1) {

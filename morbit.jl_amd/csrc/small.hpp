@@ -62,6 +62,7 @@ struct EvalDesc {
     int64_t npad, mpad, m;
     int d, k, q, tiles_per_split, nsplit;
     int ntiles;           // 64-centre tiles that hold real centres, ceil(n / 64) <= npad / 64: the padding tiles beyond are never walked
+    int nsub;             // ... and 16-centre steps, ceil(n / 16): the last tile stops there (n = 2d + 1 = 257: 17 steps, not 20)
     KP kp;
     double *vpart, *sapart, *gpart;     // per-split partials (scratch)
     double *vals, *jac;                 // m x k, m x (k x d column-major); jac may be NULL for the whole batch only
