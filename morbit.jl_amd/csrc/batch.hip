@@ -23,7 +23,7 @@ namespace mrbf {
 int batch_run_chain(int n_dev, const int *devs, const std::vector<int64_t> &which, const mrbf_problem *problems, mrbf_result *results);
 mrbf_ctx *batch_pool_acquire(int device, int *rc);
 void batch_pool_release(mrbf_ctx *c);
-void fill_small_prob(const mrbf_model *M, const double *Y, double *ws, int *flags, double *scal, smallfit::Prob *P);
+void fill_small_prob(const mrbf_ctx *ctx, const mrbf_model *M, const double *Y, double *ws, int *flags, double *scal, int *cl, smallfit::Prob *P);
 int small_fit_verdict(const mrbf_model *M, const int *hflags, const double *hscal, mrbf_fit_info *info);
 
 struct CheckDesc {
@@ -156,10 +156,15 @@ static int run_small_batch(mrbf_ctx *ctx, const std::vector<int64_t> &idx, const
     int *flags = nullptr;
     MRBF_TRY(get_buf(ctx, S_SMALL_WS, total, &base));
     flags = reinterpret_cast<int *>(base + out0 + (size_t)8 * P);
-    // descriptors: [Prob x P | EvalDesc x 2P | CheckDesc x P] in one device buffer
-    const size_t desc_bytes = (size_t)P * (sizeof(smallfit::Prob) + 2 * sizeof(EvalDesc) + sizeof(CheckDesc)) + 256;
+    // descriptors: [Prob x P | EvalDesc x 2P | CheckDesc x P | 8 cluster words x P (zero)] in one device buffer
+    const size_t desc_bytes = (size_t)P * (sizeof(smallfit::Prob) + 2 * sizeof(EvalDesc) + sizeof(CheckDesc) + 8 * sizeof(int)) + 256;
     char *ddesc;
     MRBF_TRY(get_buf(ctx, S_SMALL_DESC, desc_bytes, (void **)&ddesc));
+    // (the device addresses of the three arrays and of the cluster words are known before the host copies are filled)
+    smallfit::Prob *dprobs = (smallfit::Prob *)ddesc;
+    EvalDesc *devs_ = (EvalDesc *)(ddesc + al16((size_t)P * sizeof(smallfit::Prob)));
+    CheckDesc *dchk = (CheckDesc *)((char *)devs_ + al16((size_t)2 * P * sizeof(EvalDesc)));
+    int *dcl = (int *)((char *)dchk + al16((size_t)P * sizeof(CheckDesc)));
     std::vector<char> hdesc;
     std::vector<smallfit::Prob> probs(P);
     std::vector<EvalDesc> evs((size_t)2 * P);
@@ -198,7 +203,7 @@ static int run_small_batch(mrbf_ctx *ctx, const std::vector<int64_t> &idx, const
         M.W = L.W == (size_t)-1 ? pr.weights_out : base + L.W;
         M.Wc = base + L.Wc;
         M.lam = L.lam == (size_t)-1 ? pr.poly_out : base + L.lam;
-        fill_small_prob(&M, Y, base + L.ws, flags + 4 * i, base + L.out + 5, &probs[i]);
+        fill_small_prob(ctx, &M, Y, base + L.ws, flags + 4 * i, base + L.out + 5, dcl + 8 * i, &probs[i]);
         for (int e = 0; e < 2; ++e) {
             EvalDesc &E = evs[(size_t)e * P + i];  // [residual evaluations of all problems | query evaluations of all problems]
             const int64_t m = e == 0 ? (check ? pr.n : 0) : pr.m;
@@ -243,11 +248,8 @@ static int run_small_batch(mrbf_ctx *ctx, const std::vector<int64_t> &idx, const
         K.q = check ? L.q : 0;
         K.out = base + L.out;
     }
-    smallfit::Prob *dprobs = (smallfit::Prob *)ddesc;
-    EvalDesc *devs_ = (EvalDesc *)(ddesc + al16((size_t)P * sizeof(smallfit::Prob)));
-    CheckDesc *dchk = (CheckDesc *)((char *)devs_ + al16((size_t)2 * P * sizeof(EvalDesc)));
     {
-        // one upload for the three descriptor arrays (the staging vector lives until the stream is synchronised below)
+        // one upload for the three descriptor arrays and the zeroed cluster words (the staging vector lives until the stream is synchronised below)
         hdesc.assign(desc_bytes, 0);
         memcpy(hdesc.data(), probs.data(), (size_t)P * sizeof(smallfit::Prob));
         memcpy(hdesc.data() + ((char *)devs_ - ddesc), evs.data(), (size_t)2 * P * sizeof(EvalDesc));
@@ -255,7 +257,8 @@ static int run_small_batch(mrbf_ctx *ctx, const std::vector<int64_t> &idx, const
         MRBF_HIP(ctx, hipMemcpyAsync(ddesc, hdesc.data(), desc_bytes, hipMemcpyHostToDevice, st));
     }
     MRBF_HIP(ctx, hipEventRecord(ctx->ev[0], st));
-    MRBF_TRY(launch_small_fit(ctx, probs.data(), P, dprobs));
+    const int nc = small_fit_cluster(ctx);
+    MRBF_TRY(launch_small_fit(ctx, probs.data(), P, dprobs, nc));
     MRBF_HIP(ctx, hipEventRecord(ctx->ev[1], st));
     // evaluation launches per group of equal (kernel, fast flag, padded dimension, outputs, Jacobians wanted): usually two groups,
     // the residual evaluations at the sites (no Jacobians; on the side stream, beside the evaluation of the queries, together with
@@ -333,6 +336,14 @@ static int run_small_batch(mrbf_ctx *ctx, const std::vector<int64_t> &idx, const
             MRBF_HIP(ctx, hipMemcpyAsync(pr.jac_out, base + L.jac, (size_t)pr.m * pr.k * pr.d * sizeof(double), hipMemcpyDeviceToHost, st));
     }
     MRBF_HIP(ctx, hipStreamSynchronize(st));
+    if (nc > 1) {
+        bool cluster_failed = false;
+        for (int i = 0; i < P; ++i) cluster_failed = cluster_failed || hflags[(size_t)4 * i + 3] != 0;
+        if (cluster_failed) {  // placement or residency did not allow workgroup clusters here: one workgroup per problem from now on
+            ctx->small_nc = 1;
+            return run_small_batch(ctx, idx, problems, results, redo);
+        }
+    }
     float ms_fit = 0.f, ms_eval = 0.f;
     MRBF_HIP(ctx, hipEventElapsedTime(&ms_fit, ctx->ev[0], ctx->ev[1]));
     MRBF_HIP(ctx, hipEventElapsedTime(&ms_eval, ctx->ev[1], ctx->ev[2]));

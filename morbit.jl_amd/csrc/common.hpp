@@ -35,7 +35,7 @@ enum Slot {
     S_XC = 0, S_SQ, S_MEAN, S_PHI, S_PI, S_Q1, S_W1, S_G, S_R, S_TAU, S_RHS, S_T1, S_T2, S_IPIV, S_INFO,
     S_STAGE_A, S_STAGE_B, S_STAGE_C, S_STAGE_D, S_EVAL_E, S_EVAL_A, S_EVAL_J, S_EVAL_SA, S_EVAL_XC, S_EVAL_XSQ,
     S_OUT_A, S_OUT_B, S_CHOL_WS, S_MISC, S_MEGA_JOBS, S_MEGA_FLAGS, S_MEGA_WQ, S_MEGA_IT, S_BSOLVE_FLAGS, S_MEGA_TRACE, S_MEGA_JLOG,
-    S_T1W, S_PS_STATE, S_PS_STAT, S_PS_POLISH, S_BSOLVE_X, S_V0, S_QR_INV, S_DIAG_SCR, S_SMALL_WS, S_SMALL_DESC, S_SMALL_FLAGS, S_MEGA_STAT, S_BSOLVE_M, S_NSLOTS
+    S_T1W, S_PS_STATE, S_PS_STAT, S_PS_POLISH, S_BSOLVE_X, S_V0, S_QR_INV, S_DIAG_SCR, S_SMALL_WS, S_SMALL_DESC, S_SMALL_FLAGS, S_MEGA_STAT, S_BSOLVE_M, S_SMALL_CL, S_NSLOTS
 };
 struct Buf {
     void *p = nullptr;
@@ -86,6 +86,7 @@ struct mrbf_ctx {
     int mega_stat_pending = 0;
     float last_device_ms = 0.f;
     int slow_launches = 0;
+    int small_nc = 4;  // workgroups per problem of the one-launch small fit (1 after a cluster failure on this context)
     std::map<long, float> mega_best_ms;
     std::vector<mrbf::MegaTables> mega_tables;  // LRU of job tables, one set per shape
     unsigned long long mega_table_clock = 0;

@@ -40,8 +40,8 @@ __device__ __forceinline__ double gld(const double *p) { return *(const gdbl *)p
 
 // elementwise pass over [0, count): f(e, loaded...) with the loads of eight elements per thread issued before the first store
 template <class Load, class Store>
-__device__ __forceinline__ void batched_pass(int count, Load load, Store store) {
-    for (int e0 = threadIdx.x; e0 < count; e0 += 8 * 256) {
+__device__ __forceinline__ void batched_pass(int count, Load load, Store store, int member = 0, int nc = 1) {
+    for (int e0 = threadIdx.x + 8 * 256 * member; e0 < count; e0 += 8 * 256 * nc) {
         double t[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) t[u] = load(e0 + 256 * u < count ? e0 + 256 * u : e0);
@@ -58,11 +58,11 @@ __device__ __forceinline__ void batched_pass(int count, Load load, Store store) 
 // D[row = (l >> 4) + 4 r][col = l & 15].
 template <bool TA, bool TB, bool LOWER, class Pre, class Post>
 __device__ __forceinline__ void wg_gemm(int M, int N, int K, const double *__restrict__ A, int lda, const double *__restrict__ B, int ldb, Pre pre,
-                                        Post post) {
+                                        Post post, int member = 0, int nc = 1) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l15 = lane & 15, l4 = lane >> 4;
     const int mt = M >> 4, nt = N >> 4, MT = (mt + 1) >> 1, NT2 = (nt + 1) >> 1;
-    for (int idx = wave; idx < MT * NT2; idx += 4) {
+    for (int idx = wave + 4 * member; idx < MT * NT2; idx += 4 * nc) {  // macro tiles dealt over the waves of the cluster's workgroups
         const int I = idx % MT, J = idx / MT;
         if (LOWER && 2 * I + 1 < 2 * J) continue;
         const int i0 = 32 * I, j0 = 32 * J;
@@ -187,47 +187,121 @@ __device__ __noinline__ int diag_block(double *__restrict__ A, int ld, double *_
     return diagcore::diag_v4_core<false, false, false>(A, (int64_t)ld, Linv, sh, acc, nullptr, nullptr, 0);
 }
 
+// A problem is worked on by nc (1 or 4) workgroups: every product and every elementwise pass deals its tiles / elements over them,
+// the sequential pieces (the 128 x 128 diagonal blocks, the triangular solves, the tail) are member 0's, and the members meet at a
+// barrier after every phase.  With one workgroup per problem a batch of 64 kept 64 of the 256 CUs busy for the whole fit.
+// The members of a cluster are the blocks x + 8 (4 g + m), m = 0..3: blocks are dealt round-robin over the 8 XCDs (observed, not
+// promised), so a cluster shares ONE L2 -- stores become visible to the siblings once they have left the CU (s_waitcnt vmcnt(0)),
+// and a barrier only has to drop the reader's L1 (buffer_inv sc1).  Every member publishes the XCD it runs on; if they differ the
+// cluster gives up before it has relied on anything (flag 3), and the host repeats the launch with one workgroup per problem.
+// Progress at any residency: blocks are dispatched in index order, so the lowest-numbered unfinished group of 32 blocks is
+// always resident as a whole.  The spin is bounded by wall-clock time all the same.
+struct Cluster {
+    int member, nc, phase;
+    int *words;  // [0] arrivals, [1] failure / bad-pivot word, [2..5] XCD of the members (device memory, zero at launch)
+    unsigned long long ticks;
+    int *s_ok;   // LDS word
+};
+__device__ __forceinline__ int cl_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void cl_store(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// false: the cluster has failed (a sibling did not arrive in time, or reported a failure)
+__device__ __forceinline__ bool cl_barrier(Cluster &cl) {
+    if (cl.nc == 1) {
+        __syncthreads();
+        return true;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have left the CU
+    __syncthreads();
+    ++cl.phase;
+    if (threadIdx.x == 0) {
+        const int target = cl.nc * cl.phase;
+        __hip_atomic_fetch_add(cl.words, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool ok = true;
+        unsigned spins = 0;
+        unsigned long long t0 = 0;
+        while (cl_load(cl.words) < target) {
+            if ((++spins & 15u) == 0u) {
+                if (cl_load(cl.words + 1) < 0) {
+                    ok = false;
+                    break;
+                }
+                const unsigned long long now = wall_clock64();
+                if (t0 == 0) t0 = now;
+                if (now - t0 > cl.ticks) {
+                    cl_store(cl.words + 1, -9);
+                    ok = false;
+                    break;
+                }
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (ok && cl_load(cl.words + 1) < 0) ok = false;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // buffer_inv sc1: what the siblings wrote is read from the L2, not from this CU's L1
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        *cl.s_ok = ok ? 1 : 0;
+    }
+    __syncthreads();
+    return *cl.s_ok != 0;
+}
+
 // blocked Cholesky of the np x np matrix at A (lower, column-major, ld; np a multiple of 128) with the 128 x 128 MFMA core for the
-// diagonal blocks; rows beyond `rows16` are known to be zero below the diagonal blocks (identity padding) and skipped in the panel
-// and trailing products.  Linv: np x 128, block c at Linv + c * 128 * 128 holds inv(L_cc).  Returns 0 or 1-based index of a bad pivot.
+// diagonal blocks (member 0); rows beyond `rows16` are known to be zero below the diagonal blocks (identity padding) and skipped in
+// the panel and trailing products.  Linv: np x 128, block c at Linv + c * 128 * 128 holds inv(L_cc).  Returns 0, the 1-based index
+// of a bad pivot, or -1 when the cluster failed.
 __device__ int wg_potrf(double *__restrict__ A, int ld, int np, int rows16, double *__restrict__ Linv, double *__restrict__ Pt,
-                        diagcore::DiagV4Shared &sh, int *s_bad) {
+                        diagcore::DiagV4Shared &sh, Cluster &cl) {
     const int nb = np / 128;
     for (int c = 0; c < nb; ++c) {
         double *Acc = A + (int64_t)c * 128 * (ld + 1);
         double *Lc = Linv + (int64_t)c * 128 * 128;
-        {
+        if (cl.member == 0) {
             const int bad = diag_block(Acc, ld, Lc, sh);
             __syncthreads();
-            if (threadIdx.x == 0) *s_bad = bad ? 128 * c + bad : 0;
-            __syncthreads();
-            if (*s_bad) return *s_bad;
+            if (threadIdx.x == 0 && bad) cl_store(cl.words + 1, 128 * c + bad);  // positive: a bad pivot, every member leaves
+        }
+        if (!cl_barrier(cl)) return -1;
+        {
+            const int bad = cl_load(cl.words + 1);
+            if (bad > 0) return bad;
         }
         const int r0 = 128 * (c + 1);
         const int mrows = rows16 - r0;  // real rows below this block
         if (mrows <= 0) continue;
         // panel: L(r, c) = A(r, c) inv(L_cc)'  -> Pt (mrows x 128), then back into A
         const double *Arc = A + r0 + (int64_t)c * 128 * ld;
-        wg_gemm<false, true, false>(mrows, 128, 128, Arc, ld, Lc, 128, NoPre(), [&](int i, int j, double v, double) { gst(&Pt[i + (int64_t)j * np], v); });
-        __syncthreads();
+        wg_gemm<false, true, false>(mrows, 128, 128, Arc, ld, Lc, 128, NoPre(), [&](int i, int j, double v, double) { gst(&Pt[i + (int64_t)j * np], v); },
+                                    cl.member, cl.nc);
+        if (!cl_barrier(cl)) return -1;
         batched_pass(mrows * 128, [&](int e) { return gld(&Pt[e % mrows + (int64_t)(e / mrows) * np]); },
-                     [&](int e, double v) { gst(&A[(r0 + e % mrows) + (int64_t)(c * 128 + e / mrows) * ld], v); });
+                     [&](int e, double v) { gst(&A[(r0 + e % mrows) + (int64_t)(c * 128 + e / mrows) * ld], v); }, cl.member, cl.nc);
         // trailing update: A(r, s) -= L(r, c) L(s, c)'  for r >= s > c (lower tiles)
         double *Att = A + (int64_t)r0 * (ld + 1);
         wg_gemm<false, true, true>(mrows, mrows, 128, Pt, np, Pt, np, [&](int i, int j) { return gld(&Att[i + (int64_t)j * ld]); },
-                                   [&](int i, int j, double v, double o) { gst(&Att[i + (int64_t)j * ld], o - v); });
-        __syncthreads();
+                                   [&](int i, int j, double v, double o) { gst(&Att[i + (int64_t)j * ld], o - v); }, cl.member, cl.nc);
+        if (!cl_barrier(cl)) return -1;
     }
     return 0;
 }
 
-__global__ __launch_bounds__(256, 2) void small_fit_kernel(Prob one, const Prob *__restrict__ many) {
+__global__ __launch_bounds__(256, 2) void small_fit_kernel(Prob one, const Prob *__restrict__ many, int count, int nc) {
     __shared__ __attribute__((aligned(16))) diagcore::DiagV4Shared sh;
     __shared__ double red[4];
     __shared__ double s_mean[128];
-    __shared__ int s_bad;
-    const Prob P = many ? many[blockIdx.x] : one;
+    __shared__ int s_ok;
+    // nc = 4: block x + 8 (4 g + m) is member m of the cluster of problem x + 8 g (see Cluster)
+    const int bx = (int)blockIdx.x;
+    const int prob = nc == 1 ? bx : (bx & 7) + 8 * (bx >> 5);
+    if (prob >= count) return;
+    const Prob P = many ? many[prob] : one;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    Cluster cl;
+    cl.member = nc == 1 ? 0 : (bx >> 3) & 3;
+    cl.nc = nc;
+    cl.phase = 0;
+    cl.words = P.cl;
+    cl.ticks = P.spin_ticks;
+    cl.s_ok = &s_ok;
+    const int member = cl.member;
     const int n = P.n, d = P.d, k = P.k, q = P.q, n16 = P.n16, np = P.npad, dpad = P.dpad, q16 = P.q16;
     const Carve cv = carve(np, q16);
     double *ws = P.ws;
@@ -235,14 +309,27 @@ __global__ __launch_bounds__(256, 2) void small_fit_kernel(Prob one, const Prob 
            *Linv = ws + cv.Linv, *Pt = ws + cv.Pt, *Yc = ws + cv.Ycol, *Bm = ws + cv.B, *Fy = ws + cv.Fy, *Xs = ws + cv.Xs, *T1 = ws + cv.T1,
            *T2 = ws + cv.T2, *Z = ws + cv.Z;
     const int ldz = cv.ldz;
-    if (tid < 4) P.flags[tid] = 0;
+    if (member == 0 && tid < 4) P.flags[tid] = 0;
     int nstamp = 0;
-#define MRBF_STAMP()                                                              \
-    do {                                                                          \
-        if (P.stamps && tid == 0) P.stamps[nstamp] = (long long)wall_clock64();   \
-        ++nstamp;                                                                 \
+#define MRBF_STAMP()                                                                           \
+    do {                                                                                       \
+        if (P.stamps && tid == 0 && member == 0) P.stamps[nstamp] = (long long)wall_clock64(); \
+        ++nstamp;                                                                              \
+    } while (0)
+#define MRBF_CLB()                  \
+    do {                            \
+        if (!cl_barrier(cl)) {      \
+            if (tid == 0) P.flags[3] = 1; /* the cluster failed: the host repeats the launch with one workgroup per problem */ \
+            return;                 \
+        }                           \
     } while (0)
     MRBF_STAMP();
+    if (nc > 1) {
+        // the XCD this member runs on; after the first barrier every member compares the four
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        if (tid == 0) cl_store(cl.words + 2 + member, (int)(xcc & 0xf) + 1);
+    }
 
     // ---- centroid, centred + zero-padded coordinates, squared norms (the model's own arrays: the evaluation uses them later)
     {
@@ -273,11 +360,12 @@ __global__ __launch_bounds__(256, 2) void small_fit_kernel(Prob one, const Prob 
         if (tid < 128) s_mean[tid] = tid < d ? ((part[tid] + part[128 + tid]) + (part[256 + tid] + part[384 + tid])) / (double)n : 0.0;
     }
     __syncthreads();
-    for (int t = tid; t < dpad; t += 256) P.mean[t] = t < 128 ? s_mean[t] : 0.0;
+    if (member == 0)
+        for (int t = tid; t < dpad; t += 256) P.mean[t] = t < 128 ? s_mean[t] : 0.0;
     {
         const gdbl *Cg = (const gdbl *)P.C;
         gdbl *Xg = (gdbl *)P.Xc;
-        for (int row0 = wave; row0 < np; row0 += 16) {  // four rows per wave and step
+        for (int row0 = wave + 16 * member; row0 < np; row0 += 16 * nc) {  // four rows per wave and step
             double sacc[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -304,11 +392,19 @@ __global__ __launch_bounds__(256, 2) void small_fit_kernel(Prob one, const Prob 
         }
     }
     // right-hand sides, column-major and zero padded: Yc (np x 16)
-    for (int e = tid; e < np * 16; e += 256) {
+    for (int e = tid + 256 * member; e < np * 16; e += 256 * nc) {
         const int i = e % np, l = e / np;
         Yc[e] = (i < n && l < k) ? P.Y[(int64_t)i * k + l] : 0.0;
     }
-    __syncthreads();
+    MRBF_CLB();
+    if (nc > 1) {
+        const int x0 = cl_load(cl.words + 2);
+        const bool same = x0 != 0 && cl_load(cl.words + 3) == x0 && cl_load(cl.words + 4) == x0 && cl_load(cl.words + 5) == x0;
+        if (!same) {  // not one L2: nothing has been relied on yet (every member sees the same four words and leaves)
+            if (tid == 0 && member == 0) P.flags[3] = 2;
+            return;
+        }
+    }
 
     MRBF_STAMP();  // 1: centred
     // ---- Phi = phi(|x_i - x_j|): GEMM form on the centred coordinates, radial function in the epilogue; rows / columns >= n: identity
@@ -332,14 +428,14 @@ __global__ __launch_bounds__(256, 2) void small_fit_kernel(Prob one, const Prob 
                     v = (i == j) ? 1.0 : 0.0;
                 }
                 gst(&Phi[(int64_t)j * np + i], v);
-            });
-        __syncthreads();
-        if (P.stamps && tid == 0) P.stamps[11] = (long long)wall_clock64();  // product done
+            }, member, nc);
+        MRBF_CLB();
+        if (P.stamps && tid == 0 && member == 0) P.stamps[11] = (long long)wall_clock64();  // product done
         {
             // eight columns at a time per wave: all loads of a batch before its first store (one element at a time, every iteration
             // paid a memory round trip: 110 us for 257 x 257 entries)
             auto radial = [&](auto f) {
-                for (int j0 = 8 * wave; j0 < n; j0 += 32)
+                for (int j0 = 8 * wave + 32 * member; j0 < n; j0 += 32 * nc)
                     for (int i = lane; i < n; i += 64) {
                         double t[8];
 #pragma unroll
@@ -366,102 +462,103 @@ __global__ __launch_bounds__(256, 2) void small_fit_kernel(Prob one, const Prob 
                 default: radial([&](double t) { return rbf_phi_t<MRBF_GAUSSIAN, false>(t, kp); }); break;
             }
         }
-        if (P.stamps && tid == 0) P.stamps[12] = (long long)wall_clock64();  // radial function done (this wave)
+        if (P.stamps && tid == 0 && member == 0) P.stamps[12] = (long long)wall_clock64();  // radial function done (this wave)
         // identity in the padding beyond n16 (rows / columns n16 .. np - 1 of the lower triangle are all the factorisation reads there)
         // (rows n16 .. np - 1 of every column, contiguous per column; the block above the diagonal is never read)
-        for (int c = wave; c < np; c += 4)
+        for (int c = wave + 4 * member; c < np; c += 4 * nc)
             for (int r = n16 + lane; r < np; r += 64) gst(&Phi[r + (int64_t)c * np], (r == c) ? 1.0 : 0.0);
     }
-    __syncthreads();
+    MRBF_CLB();
 
     MRBF_STAMP();  // 2: Gram
     const double rsn = 1.0 / sqrt((double)n);
     if (q > 0) {
         // ---- Q1 = [1/sqrt(n) | Xc Lx^-T]: orthonormal basis of the polynomial tail from the Cholesky-QR of the centred coordinates
-        for (int e = tid; e < np * q16; e += 256) {
+        for (int e = tid + 256 * member; e < np * q16; e += 256 * nc) {
             const int i = e % np, t = e / np;
             Q1[e] = (t == 0 && i < n) ? rsn : 0.0;
         }
         if (q > 1) {
             const int d16 = (d + 15) & ~15;
             // Gx = Xc' Xc (d x d), identity padded to 128 x 128
-            for (int e = tid; e < 128 * 128; e += 256) Gx[e] = (e % 128 == e / 128 && e % 128 >= d) ? 1.0 : 0.0;
-            __syncthreads();
+            for (int e = tid + 256 * member; e < 128 * 128; e += 256 * nc) Gx[e] = (e % 128 == e / 128 && e % 128 >= d) ? 1.0 : 0.0;
+            MRBF_CLB();
             wg_gemm<false, true, true>(d16, d16, n16, P.Xc, dpad, P.Xc, dpad, NoPre(), [&](int a, int b, double v, double) {
                 if (a < d && b < d) gst(&Gx[a + b * 128], v);
-            });
-            __syncthreads();
-            {
+            }, member, nc);
+            MRBF_CLB();
+            if (member == 0) {
                 const int bad = diag_block(Gx, 128, LinvX, sh);
                 __syncthreads();
                 if (tid == 0 && bad) P.flags[1] = bad;
             }
-            __syncthreads();
+            MRBF_CLB();
             // Qx(i, a) = sum_b Xc(i, b) inv(Lx)(a, b)
             double *Qx = Q1 + np;
             wg_gemm<true, true, false>(n16, d16, d16, P.Xc, dpad, LinvX, 128, NoPre(), [&](int i, int a, double v, double) {
                 if (i < n && a < d) gst(&Qx[i + (int64_t)a * np], v);
-            });
+            }, member, nc);
         }
-        __syncthreads();
+        MRBF_CLB();
         MRBF_STAMP();  // 3: Q1
         // ---- W1 = Phi Q1;  G = Q1' W1;  W = W1 - 1/2 Q1 G;  mu = (n phi0 - trace G) / (n - q);  V = W - mu/2 Q1
-        wg_gemm<false, false, false>(n16, q16, n16, Phi, np, Q1, np, NoPre(), [&](int i, int t, double v, double) { gst(&Wm[i + (int64_t)t * np], v); });
-        for (int e = tid; e < (np - n16) * q16; e += 256) Wm[n16 + e % (np - n16) + (int64_t)(e / (np - n16)) * np] = 0.0;
-        __syncthreads();
-        wg_gemm<true, false, false>(q16, q16, n16, Q1, np, Wm, np, NoPre(), [&](int a, int b, double v, double) { gst(&G[a + b * q16], v); });
-        __syncthreads();
+        wg_gemm<false, false, false>(n16, q16, n16, Phi, np, Q1, np, NoPre(), [&](int i, int t, double v, double) { gst(&Wm[i + (int64_t)t * np], v); },
+                                     member, nc);
+        for (int e = tid + 256 * member; e < (np - n16) * q16; e += 256 * nc) Wm[n16 + e % (np - n16) + (int64_t)(e / (np - n16)) * np] = 0.0;
+        MRBF_CLB();
+        wg_gemm<true, false, false>(q16, q16, n16, Q1, np, Wm, np, NoPre(), [&](int a, int b, double v, double) { gst(&G[a + b * q16], v); }, member, nc);
+        MRBF_CLB();
         double tr = 0.0;
-        for (int t = tid; t < q; t += 256) tr += G[t + t * q16];
+        for (int t = tid; t < q; t += 256) tr += gld(&G[t + t * q16]);  // (every member for itself)
         tr = wg_sum(tr, red);
         const double mu_raw = ((double)n * P.kp.phi0 - tr) / (double)max(n - q, 1);
         const bool mu_ok = mu_raw > 0.0 && mu_raw < 1e300;
         const double mu = mu_ok ? mu_raw : 1.0;
-        if (tid == 0) {
+        if (tid == 0 && member == 0) {
             P.scal[0] = tr;
             P.scal[1] = mu;
             if (!mu_ok) P.flags[2] = 1;
         }
         wg_gemm<false, false, false>(n16, q16, q16, Q1, np, G, q16, [&](int i, int t) { return gld(&Wm[i + (int64_t)t * np]); },
-                                     [&](int i, int t, double v, double o) { gst(&Wm[i + (int64_t)t * np], o - 0.5 * v); });
-        __syncthreads();
+                                     [&](int i, int t, double v, double o) { gst(&Wm[i + (int64_t)t * np], o - 0.5 * v); }, member, nc);
+        MRBF_CLB();
         {
             const double hmu = -0.5 * mu;
-            batched_pass(np * q16, [&](int e) { return fma(hmu, gld(&Q1[e]), gld(&Wm[e])); }, [&](int e, double v) { gst(&V[e], v); });
+            batched_pass(np * q16, [&](int e) { return fma(hmu, gld(&Q1[e]), gld(&Wm[e])); }, [&](int e, double v) { gst(&V[e], v); }, member, nc);
         }
-        __syncthreads();
+        MRBF_CLB();
         MRBF_STAMP();  // 4: W, G, mu, V
         // ---- K = Phi - Q1 V' - V Q1' on the lower triangle (column-major: K(i, j), i >= j, at Phi[i + j * np])
         wg_gemm<false, true, true>(n16, n16, q16, Q1, np, V, np, [&](int i, int j) { return gld(&Phi[i + (int64_t)j * np]); },
-                                   [&](int i, int j, double v, double o) { gst(&Phi[i + (int64_t)j * np], o - v); });
-        __syncthreads();
+                                   [&](int i, int j, double v, double o) { gst(&Phi[i + (int64_t)j * np], o - v); }, member, nc);
+        __syncthreads();  // (the second product meets every tile in the wave that held it in the first)
         wg_gemm<false, true, true>(n16, n16, q16, V, np, Q1, np, [&](int i, int j) { return gld(&Phi[i + (int64_t)j * np]); },
-                                   [&](int i, int j, double v, double o) { gst(&Phi[i + (int64_t)j * np], o - v); });
+                                   [&](int i, int j, double v, double o) { gst(&Phi[i + (int64_t)j * np], o - v); }, member, nc);
         MRBF_STAMP();  // 5: K update (issued)
         // ---- B = P Y = Y - Q1 (Q1' Y);  T1 keeps Q1' Y for the tail coefficients
-        wg_gemm<true, false, false>(q16, 16, n16, Q1, np, Yc, np, NoPre(), [&](int a, int l, double v, double) { gst(&T1[a + l * ldz], v); });
-        __syncthreads();
-        batched_pass(np * 16, [&](int e) { return gld(&Yc[e]); }, [&](int e, double v) { gst(&Bm[e], v); });
-        __syncthreads();
+        wg_gemm<true, false, false>(q16, 16, n16, Q1, np, Yc, np, NoPre(), [&](int a, int l, double v, double) { gst(&T1[a + l * ldz], v); }, member, nc);
+        batched_pass(np * 16, [&](int e) { return gld(&Yc[e]); }, [&](int e, double v) { gst(&Bm[e], v); }, member, nc);
+        MRBF_CLB();
         wg_gemm<false, false, false>(n16, 16, q16, Q1, np, T1, ldz, [&](int i, int l) { return gld(&Bm[i + l * np]); },
-                                     [&](int i, int l, double v, double o) { gst(&Bm[i + l * np], o - v); });
+                                     [&](int i, int l, double v, double o) { gst(&Bm[i + l * np], o - v); }, member, nc);
     } else {
-        batched_pass(np * 16, [&](int e) { return gld(&Yc[e]); }, [&](int e, double v) { gst(&Bm[e], v); });
-        if (tid == 0) {
+        batched_pass(np * 16, [&](int e) { return gld(&Yc[e]); }, [&](int e, double v) { gst(&Bm[e], v); }, member, nc);
+        if (tid == 0 && member == 0) {
             P.scal[0] = 0.0;
             P.scal[1] = 0.0;
         }
     }
-    __syncthreads();
+    MRBF_CLB();
 
     MRBF_STAMP();  // 6: rhs
     // ---- factorisation K = L L'
     {
-        const int bad = wg_potrf(Phi, np, np, n16, Linv, Pt, sh, &s_bad);
+        const int bad = wg_potrf(Phi, np, np, n16, Linv, Pt, sh, cl);
         if (bad) {
-            if (tid == 0) P.flags[0] = bad;
+            if (tid == 0 && (member == 0 || bad < 0)) P.flags[bad > 0 ? 0 : 3] = bad > 0 ? bad : 1;
             return;
         }
+        if (member != 0) return;  // the triangular solves and the tail are member 0's (one macro tile per wave: nothing to deal out)
     }
     __syncthreads();
     MRBF_STAMP();  // 7: potrf
@@ -537,12 +634,16 @@ bool small_fit_applies(const mrbf_ctx *ctx, int64_t n, int d, int k, int q, int 
     return n >= 1 && n <= 512 && d >= 1 && d <= 128 && k >= 1 && k <= 16 && n > q && (path == MRBF_PATH_CHOL || path == MRBF_PATH_PROJ_CHOL);
 }
 
-int launch_small_fit(mrbf_ctx *ctx, const smallfit::Prob *host_probs, int count, const smallfit::Prob *dev_probs) {
+int small_fit_cluster(const mrbf_ctx *ctx) {
+    static const int env = getenv("MRBF_SMALL_NC") ? atoi(getenv("MRBF_SMALL_NC")) : 0;
+    return (env == 1 || ctx->small_nc == 1) ? 1 : 4;
+}
+
+int launch_small_fit(mrbf_ctx *ctx, const smallfit::Prob *host_probs, int count, const smallfit::Prob *dev_probs, int nc) {
     if (count <= 0) return 0;
-    if (count == 1 && !dev_probs)
-        hipLaunchKernelGGL(smallfit::small_fit_kernel, dim3(1), dim3(256), 0, ctx->stream, host_probs[0], (const smallfit::Prob *)nullptr);
-    else
-        hipLaunchKernelGGL(smallfit::small_fit_kernel, dim3((unsigned)count), dim3(256), 0, ctx->stream, host_probs[0], dev_probs);
+    const unsigned grid = nc == 1 ? (unsigned)count : 32u * (unsigned)((count + 7) / 8);
+    hipLaunchKernelGGL(smallfit::small_fit_kernel, dim3(grid), dim3(256), 0, ctx->stream, host_probs[0],
+                       (count == 1 && !dev_probs) ? (const smallfit::Prob *)nullptr : dev_probs, count, nc);
     MRBF_HIP(ctx, hipGetLastError());
     return 0;
 }

@@ -13,9 +13,12 @@ struct Prob {
     const double *C, *Y;                     // sites n x d, values n x k (row-major, device)
     double *Xc, *sq, *mean, *W, *Wc, *lam;   // the model's arrays (mrbf_model)
     double *ws;                              // scratch, carve(npad, q16).total doubles
-    int *flags;                              // [0] bad pivot of K (1-based), [1] bad pivot of the tail's Cholesky-QR, [2] shift not positive
+    int *flags;                              // [0] bad pivot of K (1-based), [1] bad pivot of the tail's Cholesky-QR, [2] shift not positive,
+                                             // [3] the cluster failed (1: a barrier timed out, 2: its members are not on one XCD): repeat with nc = 1
     double *scal;                            // [0] trace(Q1' Phi Q1), [1] mu
     long long *stamps;                       // debug (MRBF_SMALL_STAMPS): wall_clock64 at the phase boundaries, or NULL
+    int *cl;                                 // 8 words of the problem's workgroup cluster (zero at launch): arrivals, failure word, XCDs
+    unsigned long long spin_ticks;           // bound of a cluster barrier's spin (wall_clock64 ticks)
 };
 
 struct Carve {
@@ -77,6 +80,7 @@ int eval_fused_batch(mrbf_ctx *ctx, const KP &kp, int D, int k, bool want_jac, c
 // does the one-launch path take a problem of this shape on this context?  (path: MRBF_PATH_* chosen by fit_model)
 bool small_fit_applies(const mrbf_ctx *ctx, int64_t n, int d, int k, int q, int path);
 // count == 1 and dev_probs == nullptr: the descriptor travels as a kernel argument; else one workgroup per descriptor of dev_probs
-int launch_small_fit(mrbf_ctx *ctx, const smallfit::Prob *host_probs, int count, const smallfit::Prob *dev_probs);
+int launch_small_fit(mrbf_ctx *ctx, const smallfit::Prob *host_probs, int count, const smallfit::Prob *dev_probs, int nc);
+int small_fit_cluster(const mrbf_ctx *ctx);  // workgroups per problem this context uses (4, or 1 after a cluster failure / MRBF_SMALL_NC=1)
 
 }  // namespace mrbf

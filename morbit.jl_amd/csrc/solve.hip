@@ -680,7 +680,7 @@ static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info
 }
 
 // ---- small problems: the whole Cholesky-path fit as one launch (small.hip) ---------------------------------------------------
-void fill_small_prob(const mrbf_model *M, const double *Y, double *ws, int *flags, double *scal, smallfit::Prob *P) {
+void fill_small_prob(const mrbf_ctx *ctx, const mrbf_model *M, const double *Y, double *ws, int *flags, double *scal, int *cl, smallfit::Prob *P) {
     P->n = (int)M->n;
     P->d = M->d;
     P->k = M->k;
@@ -703,6 +703,8 @@ void fill_small_prob(const mrbf_model *M, const double *Y, double *ws, int *flag
     P->flags = flags;
     P->scal = scal;
     P->stamps = nullptr;
+    P->cl = cl;
+    P->spin_ticks = (unsigned long long)std::max(1, ctx->spin_ms) * 100000ull;  // wall_clock64: 100 MHz
 }
 // what the flags of a small-problem fit mean for mrbf_fit_info (shared with the batched entry point): returns 1 when the problem
 // has to be re-done on the LU path
@@ -729,27 +731,36 @@ static int fit_small(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_inf
     MRBF_TRY(get_buf(ctx, S_SMALL_WS, cv.total, &ws));
     MRBF_TRY(get_buf(ctx, S_SMALL_FLAGS, (size_t)4, &flags));
     MRBF_TRY(get_buf(ctx, S_MISC, (size_t)8, &scal));
-    fill_small_prob(M, Y, ws, flags, scal, &P);
+    int *cl;
+    MRBF_TRY(get_buf(ctx, S_SMALL_CL, (size_t)8, &cl));
+    fill_small_prob(ctx, M, Y, ws, flags, scal, cl, &P);
     static const int want_stamps = getenv("MRBF_SMALL_STAMPS") ? atoi(getenv("MRBF_SMALL_STAMPS")) : 0;
     long long *dstamps = nullptr;
     if (want_stamps) {
         MRBF_TRY(get_buf(ctx, S_SMALL_DESC, (size_t)16, &dstamps));
         P.stamps = dstamps;
     }
-    MRBF_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-    MRBF_TRY(launch_small_fit(ctx, &P, 1, nullptr));
-    MRBF_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     int hflags[4] = {0, 0, 0, 0};
     double hscal[2] = {0.0, 0.0};
-    MRBF_HIP(ctx, hipMemcpyAsync(hflags, flags, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    MRBF_HIP(ctx, hipMemcpyAsync(hscal, scal, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const int nc = small_fit_cluster(ctx);
+        MRBF_HIP(ctx, hipMemsetAsync(cl, 0, 8 * sizeof(int), ctx->stream));
+        MRBF_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+        MRBF_TRY(launch_small_fit(ctx, &P, 1, nullptr, nc));
+        MRBF_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+        MRBF_HIP(ctx, hipMemcpyAsync(hflags, flags, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        MRBF_HIP(ctx, hipMemcpyAsync(hscal, scal, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (hflags[3] == 0 || nc == 1) break;
+        ctx->small_nc = 1;  // the cluster could not be relied on here (placement or residency): one workgroup per problem from now on
+    }
     MRBF_HIP(ctx, hipEventElapsedTime(&info->ms_factor, ctx->ev[0], ctx->ev[1]));  // one launch: assembly, projection, factorisation, solve
     if (want_stamps) {
         long long hs[16];
         MRBF_HIP(ctx, hipMemcpy(hs, dstamps, sizeof(hs), hipMemcpyDeviceToHost));
         static const char *names[] = {"centre", "gram", "Q1", "W,G,mu,V", "K update", "rhs", "potrf", "solves", "tail"};
-        fprintf(stderr, "small fit n=%lld d=%d q=%d: %.3f ms |", (long long)M->n, M->d, M->q, info->ms_factor);
+        fprintf(stderr, "small fit n=%lld d=%d q=%d (%d workgroup%s): %.3f ms |", (long long)M->n, M->d, M->q, small_fit_cluster(ctx),
+                small_fit_cluster(ctx) == 1 ? "" : "s", info->ms_factor);
         for (int i = 0; i < 9; ++i) fprintf(stderr, " %s %.1f us |", names[i], (hs[i + 1] - hs[i]) * 0.01);
         fprintf(stderr, " [gram: product %.1f us, radial function %.1f us, padding %.1f us]\n", (hs[11] - hs[1]) * 0.01, (hs[12] - hs[11]) * 0.01,
                 (hs[2] - hs[12]) * 0.01);
