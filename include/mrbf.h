@@ -89,7 +89,8 @@ enum {
     MRBF_OPT_SLOW_LAUNCHES = 12,  /* read only: persistent factorisations of this context that took more than twice the shortest seen
                                   at their shape (cumulative) */
     MRBF_OPT_DEBUG_FAULT = 10  /* test hook: bit 0 = one workgroup of the persistent factorisation skips a publish, bit 1 = one workgroup of
-                                  the persistent backward substitution does (the next fit must fall back and still return the right weights) */
+                                  the persistent backward substitution does (the next fit must fall back and still return the right weights), bit 2 = one
+                                  member of a small fit's workgroup cluster leaves early (the fit is repeated with one workgroup per problem) */
 };
 
 /* bits of mrbf_fit_info.fallbacks: a GPU path that was abandoned for another GPU path inside the same call (rc stays 0) */

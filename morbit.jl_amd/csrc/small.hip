@@ -406,6 +406,8 @@ __global__ __launch_bounds__(256, 2) void small_fit_kernel(Prob one, const Prob 
         }
     }
 
+    if (P.fault && nc > 1 && member == 1) return;  // test hook: the siblings' next barrier times out, the host repeats with nc = 1
+
     MRBF_STAMP();  // 1: centred
     // ---- Phi = phi(|x_i - x_j|): GEMM form on the centred coordinates, radial function in the epilogue; rows / columns >= n: identity
     {

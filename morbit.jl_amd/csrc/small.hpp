@@ -19,6 +19,7 @@ struct Prob {
     long long *stamps;                       // debug (MRBF_SMALL_STAMPS): wall_clock64 at the phase boundaries, or NULL
     int *cl;                                 // 8 words of the problem's workgroup cluster (zero at launch): arrivals, failure word, XCDs
     unsigned long long spin_ticks;           // bound of a cluster barrier's spin (wall_clock64 ticks)
+    int fault;                               // test hook (MRBF_OPT_DEBUG_FAULT bit 4): member 1 leaves before the third barrier
 };
 
 struct Carve {

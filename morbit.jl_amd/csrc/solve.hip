@@ -705,6 +705,7 @@ void fill_small_prob(const mrbf_ctx *ctx, const mrbf_model *M, const double *Y, 
     P->stamps = nullptr;
     P->cl = cl;
     P->spin_ticks = (unsigned long long)std::max(1, ctx->spin_ms) * 100000ull;  // wall_clock64: 100 MHz
+    P->fault = (ctx->debug_fault & 4) ? 1 : 0;
 }
 // what the flags of a small-problem fit mean for mrbf_fit_info (shared with the batched entry point): returns 1 when the problem
 // has to be re-done on the LU path

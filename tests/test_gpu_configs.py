@@ -230,3 +230,30 @@ def test_giveup_paths_fall_back_on_the_gpu(ctx):
     assert again.info["fallbacks"] == 0 and np.array_equal(again.weights, clean.weights)
     again.free()
     clean.free()
+
+
+def test_small_fit_cluster_failure_repeats_with_one_workgroup():
+    """n <= 512: the fit runs on a cluster of four workgroups per problem (small.hip); when a member does not arrive at a barrier
+    (MRBF_OPT_DEBUG_FAULT bit 2) the siblings give up after MRBF_OPT_SPIN_MS, the same call repeats the launch with one workgroup per
+    problem, and the result is bit for bit the clustered one (every tile is computed by the same code whoever takes it)"""
+    rng = np.random.Generator(np.random.PCG64(78))
+    C = rng.random((300, 20))
+    Y = np.stack([np.sin(C.sum(axis=1)), (C ** 2).sum(axis=1)], axis=1)
+    cfg = pkg.RbfConfig(kernel="cubic", polynomial_degree=1)
+    good = pkg.Context(0)
+    clean = pkg.update_model(cfg, C, Y, ctx=good)
+    assert clean.info["path"] == _lib.PATH_PROJ_CHOL and clean.info["rel_residual"] < 1e-12
+    ctx2 = pkg.Context(0)   # its own context: the repeat switches the context to one workgroup per problem for good
+    ctx2.set_option(_lib.OPT_SPIN_MS, 20)
+    ctx2.set_option(_lib.OPT_DEBUG_FAULT, 4)
+    t0 = time.perf_counter()
+    m = pkg.update_model(cfg, C, Y, ctx=ctx2)
+    dt = time.perf_counter() - t0
+    assert dt < 2.0, dt
+    assert m.info["path"] == _lib.PATH_PROJ_CHOL and m.info["rel_residual"] < 1e-12, m.info
+    assert np.array_equal(m.weights, clean.weights)
+    ctx2.set_option(_lib.OPT_DEBUG_FAULT, 0)
+    m2 = pkg.update_model(cfg, C, Y, ctx=ctx2)   # one workgroup per problem from now on, same numbers
+    assert np.array_equal(m2.weights, clean.weights)
+    for x in (m, m2, clean):
+        x.free()
