@@ -26,7 +26,7 @@ namespace mrbf {
 
 namespace bsolve {
 
-constexpr int NB = 128, NTHR = 512, RPT = 32;  // rows per lane
+constexpr int NB = 128, NTHR = 512;
 typedef double v2d __attribute__((ext_vector_type(2)));
 typedef double v4d __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) unsigned gu32;

@@ -187,7 +187,6 @@ __global__ __launch_bounds__(256, (DT <= 4) ? 2 : 1) void eval_fused_kernel(Eval
         const int d = E.d, k = E.k, q = E.q;
         const int64_t m = E.m;
         const double *__restrict__ lam = E.lam;
-        const double *__restrict__ Xorig = E.X;
         double *__restrict__ vals = E.vals;
         double *__restrict__ jac = E.jac;
         // polynomial tail of the value, p_l(x) = lam_0l + sum_t lam_tl (xc_t + mean_t): the centred coordinates are at hand (query

@@ -418,7 +418,7 @@ extern "C" int32_t mrbf_fit_from_round4(mrbf_ctx *ctx, const mrbf_round4_state *
                              "part of the round-4 factor; use mrbf_fit", (long long)st->n0, st->q);
     (void)hipSetDevice(ctx->device);
     const int n0 = (int)st->n0, j = st->nacc, q = st->q, d = st->d;
-    const int64_t n = n0 + j, mc = st->mc;
+    const int64_t n = n0 + j;
     mrbf_fit_info local;
     if (!info) info = &local;
     std::memset(info, 0, sizeof(*info));

@@ -283,7 +283,7 @@ __device__ int wg_potrf(double *__restrict__ A, int ld, int np, int rows16, doub
     return 0;
 }
 
-__global__ __launch_bounds__(256, 2) void small_fit_kernel(Prob one, const Prob *__restrict__ many, int count, int nc) {
+__global__ __launch_bounds__(256, 1) void small_fit_kernel(Prob one, const Prob *__restrict__ many, int count, int nc) {
     __shared__ __attribute__((aligned(16))) diagcore::DiagV4Shared sh;
     __shared__ double red[4];
     __shared__ double s_mean[128];

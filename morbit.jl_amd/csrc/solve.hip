@@ -481,7 +481,7 @@ __global__ __launch_bounds__(256) void trsm_lt_small_kernel(const double *__rest
 static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info *info, int *not_pd, int *gave_up) {
     const int64_t n = M->n, npad = M->npad;
     const int k = M->k, q = M->q, d = M->d;
-    const double one = 1.0, zero = 0.0, mone = -1.0, mhalf = -0.5;
+    const double one = 1.0, mhalf = -0.5;
     *not_pd = 0;
     *gave_up = 0;
     const bool builtin = ctx->chol_impl != 1;
@@ -783,7 +783,6 @@ int fit_check(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info *info
     double h[3] = {0, 0, 0};
     if (q > 0) {
         double *Pi, *T;
-        const double one = 1.0, zero = 0.0;
         MRBF_TRY(get_buf(ctx, S_PI, (size_t)n * q, &Pi));
         MRBF_TRY(get_buf(ctx, S_T2, (size_t)q * k, &T));
         MRBF_TRY(launch_poly_matrix(ctx, M->C, n, M->d, q, Pi, n));
