@@ -24,6 +24,17 @@ __device__ __forceinline__ unsigned long long ld(const unsigned long long *p) {
     if constexpr (LV == 1) asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1\n s_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
     if constexpr (LV == 2) asm volatile("global_load_dwordx2 %0, %1, off nt\n s_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
     if constexpr (LV == 3) asm volatile("global_load_dwordx2 %0, %1, off sc0\n s_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    if constexpr (LV == 4 || LV == 5) {
+        // scalar load (lgkmcnt, not vmcnt): the address must be wave-uniform -- lane 0's pointer
+        // (readfirstlane returns int: widen through unsigned, or a set bit 31 sign-extends into the upper half of the address)
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)p);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)p >> 32));
+        const unsigned long long a = ((unsigned long long)hi << 32) | (unsigned long long)lo;
+        unsigned long long sv;
+        if constexpr (LV == 4) asm volatile("s_load_dwordx2 %0, %1, 0x0 glc\n s_waitcnt lgkmcnt(0)" : "=s"(sv) : "s"(a) : "memory");
+        if constexpr (LV == 5) asm volatile("s_dcache_inv\n s_load_dwordx2 %0, %1, 0x0\n s_waitcnt lgkmcnt(0)" : "=s"(sv) : "s"(a) : "memory");
+        v = sv;
+    }
     return v;
 }
 
@@ -95,5 +106,9 @@ int main() {
     run<1, 2>("sc1", "nt", buf, out, xcc, nblocks);
     run<1, 1>("sc1", "sc0sc1", buf, out, xcc, nblocks);
     run<0, 3>("plain", "sc0", buf, out, xcc, nblocks);
+    run<1, 4>("sc1", "s_load glc", buf, out, xcc, nblocks);
+    run<0, 4>("plain", "s_load glc", buf, out, xcc, nblocks);
+    run<1, 5>("sc1", "dcache_inv+s_load", buf, out, xcc, nblocks);
+    run<0, 5>("plain", "dcache_inv+s_load", buf, out, xcc, nblocks);
     return 0;
 }
