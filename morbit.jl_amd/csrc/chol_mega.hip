@@ -99,6 +99,7 @@ struct Args {
     unsigned long long spin_ticks;  // wall_clock64 ticks (10 ns) one wait may last without the awaited word changing
     int fault;                      // test hook: the last block row's first panel job of column 0 never publishes its tile
     int use_quiet;
+    int xchain;      // chain workgroups on one XCD (blocks 0, 8, 16, ...)
     int slack, slack_chain, first, win, wbias, srows;
     unsigned long long *jlog;   // diagnostic launches only: 8 words per job (meta, claim, 5 stage stamps, end), jlog[0] = count
     int jlog_cap;
@@ -777,8 +778,14 @@ __device__ __forceinline__ int pick_bulk(const Args &a, Shared &sh) {
 
 __device__ __forceinline__ void mega_body(const Args &a) {
     __shared__ __attribute__((aligned(16))) Shared sh;
-    const bool chain = (int)blockIdx.x < a.nchain;
-    const bool dedicated = !chain && (int)blockIdx.x < a.nchain + a.ndedicated;
+    // The chain workgroups are the blocks 0, 8, 16, ...: blocks are dealt round-robin over the 8 XCDs (observed, not promised; nothing
+    // depends on it but speed), so the whole chain sits behind ONE L2 and its hand-offs stay on one die (tools/pingpong: 0.47 against
+    // 0.58 us for a write-through word; n = 2048 / 4096 / 8192: -1.2 / -2.8 / -0.5 % against the blocks 0 .. nchain-1).  Copies of
+    // the chain's panels written with plain stores and read from the L2 (0.3 us) were tried on top: only the LAST panel's hand-off of a
+    // block column is on the critical path, -1 us of 36 per column, not kept.  MRBF_MEGA_XCHAIN=0: the old placement.
+    const int bx = (int)blockIdx.x;
+    const bool chain = a.xchain ? ((bx & 7) == 0 && (bx >> 3) < a.nchain) : bx < a.nchain;
+    const bool dedicated = !chain && (a.xchain ? ((bx & 7) != 0 && bx - (bx >> 3) - 1 < a.ndedicated) : bx < a.nchain + a.ndedicated);
     if (chain || dedicated) __builtin_amdgcn_s_setprio(2);
     if (threadIdx.x == 0) {
         sh.wlo = 0;
@@ -1096,6 +1103,10 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
     const int grid = (NT <= 16 && ctx->mega_grid > 256) ? 256 : ctx->mega_grid;
     if (a.nchain < 1) a.nchain = 1;
     if (a.nchain + a.ndedicated >= grid) a.ndedicated = std::max(0, grid / 2 - a.nchain);
+    {
+        static const int xc = getenv("MRBF_MEGA_XCHAIN") ? atoi(getenv("MRBF_MEGA_XCHAIN")) : 1;
+        a.xchain = (xc && 8 * a.nchain <= grid) ? 1 : 0;  // enough blocks = 0 (mod 8) for the chain
+    }
     const char *trace_path = getenv("MRBF_MEGA_TRACE");
     if (trace_path) {
         a.trace_dbg = getenv("MRBF_MEGA_TRACE_WAVE") ? 12 + 16 * (atoi(getenv("MRBF_MEGA_TRACE_WAVE")) & 3) : 4;
