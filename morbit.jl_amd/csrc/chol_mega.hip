@@ -100,6 +100,7 @@ struct Args {
     int fault;                      // test hook: the last block row's first panel job of column 0 never publishes its tile
     int use_quiet;
     int xchain;      // chain workgroups on one XCD (blocks 0, 8, 16, ...)
+    int quiet_tail;  // a chain workgroup's CU partner pauses only while at most this many block columns are left
     int slack, slack_chain, first, win, wbias, srows;
     unsigned long long *jlog;   // diagnostic launches only: 8 words per job (meta, claim, 5 stage stamps, end), jlog[0] = count
     int jlog_cap;
@@ -829,7 +830,7 @@ __device__ __forceinline__ void mega_body(const Args &a) {
             bool panel_left = false;
             if (ldf(a.ctl + CTL_ABORT)) {
                 kind = -2;
-            } else if (!dedicated && a.use_quiet && ldf(myquiet) != 0) {
+            } else if (!dedicated && a.use_quiet && ldf(myquiet) != 0 && a.NT - (int)ldf(a.ctl + CTL_PCOLS) <= a.quiet_tail) {
                 kind = -1;  // the CU's other workgroup runs a chain-critical job: leave it the SIMDs
                 idle_t0 = 0;
             } else {
@@ -1106,6 +1107,10 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
     {
         static const int xc = getenv("MRBF_MEGA_XCHAIN") ? atoi(getenv("MRBF_MEGA_XCHAIN")) : 1;
         a.xchain = (xc && 8 * a.nchain <= grid) ? 1 : 0;  // enough blocks = 0 (mod 8) for the chain
+        // (n = 16384: the CU partners of the 12 chain workgroups join the bulk work until 32 block columns are left: 27.0 -> 26.5 ms;
+        //  at n <= 8192 the chain is never far from critical and pausing the partners throughout is as good or better)
+        static const int qt = getenv("MRBF_MEGA_QUIET_TAIL") ? atoi(getenv("MRBF_MEGA_QUIET_TAIL")) : -1;
+        a.quiet_tail = qt >= 0 ? qt : (NTq > 96 ? 32 : 1 << 20);
     }
     const char *trace_path = getenv("MRBF_MEGA_TRACE");
     if (trace_path) {
