@@ -232,6 +232,35 @@ def test_giveup_paths_fall_back_on_the_gpu(ctx):
     clean.free()
 
 
+def test_giveup_in_the_tail_factorisation_is_not_read_as_rank_deficiency(ctx):
+    """128 < d <= 256: the Cholesky-QR of the tail basis (a 256-column tall factorisation) goes through the persistent kernel too, on
+    the side stream.  When IT gives up (same fault hook: a half tile of the last row is never published) the fit must report a give-up
+    and repeat on the host-driven Cholesky path -- not mistake the negative status for a rank-deficient Pi and fall to the LU of the
+    saddle system"""
+    rng = np.random.Generator(np.random.PCG64(79))
+    C = rng.random((1300, 140))
+    Y = np.stack([np.sin(C.sum(axis=1) / 10), (C ** 2).sum(axis=1) / 140], axis=1)
+    cfg = pkg.RbfConfig(kernel="cubic", polynomial_degree=1)
+    clean = pkg.update_model(cfg, C, Y, ctx=ctx)
+    assert clean.info["fallbacks"] == 0 and clean.info["path"] == _lib.PATH_PROJ_CHOL
+    ctx.set_option(_lib.OPT_SPIN_MS, 20)
+    try:
+        ctx.set_option(_lib.OPT_DEBUG_FAULT, 1)
+        t0 = time.perf_counter()
+        m = pkg.update_model(cfg, C, Y, ctx=ctx)
+        dt = time.perf_counter() - t0
+        assert m.info["path"] == _lib.PATH_PROJ_CHOL, m.info            # still the projected Cholesky, not the LU fallback
+        assert m.info["fallbacks"] & _lib.FB_CHOL_HOST_DRIVEN and not (m.info["fallbacks"] & _lib.FB_LU), m.info
+        assert m.info["giveup_code"] != 0 and m.info["rel_residual"] < 1e-11, m.info
+        assert np.abs(m.weights - clean.weights).max() <= 1e-10 * np.abs(clean.weights).max()
+        assert dt < 3.0, dt
+        m.free()
+    finally:
+        ctx.set_option(_lib.OPT_DEBUG_FAULT, 0)
+        ctx.set_option(_lib.OPT_SPIN_MS, 1000)
+    clean.free()
+
+
 def test_small_fit_cluster_failure_repeats_with_one_workgroup():
     """n <= 512: the fit runs on a cluster of four workgroups per problem (small.hip); when a member does not arrive at a barrier
     (MRBF_OPT_DEBUG_FAULT bit 2) the siblings give up after MRBF_OPT_SPIN_MS, the same call repeats the launch with one workgroup per
