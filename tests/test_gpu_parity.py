@@ -476,6 +476,43 @@ def test_batch_run_matches_single_calls(ctx):
         mod.free()
 
 
+def test_batch_run_mixed_shapes_matches_single_calls(ctx):
+    """one mrbf_batch_run over problems of different kernels, tails, dimensions (padded to 64 and to 128), output counts, with and
+    without Jacobians, one without queries, small ones (one-launch fit, evaluation groups that are NOT contiguous in the descriptor
+    array) mixed with one beyond the small shape (per-problem chain): every result bit for bit the single call's"""
+    specs = [  # kernel, deg, n, d, k, m, want_jac
+        ("cubic", 1, 150, 6, 2, 20, True), ("multiquadric", 1, 257, 100, 2, 70, True), ("cubic", 1, 90, 6, 1, 33, False),
+        ("gaussian", -1, 200, 12, 3, 40, True), ("multiquadric", 1, 300, 100, 2, 64, False), ("cubic", 1, 160, 6, 2, 0, False),
+        ("inv_multiquadric", 0, 120, 70, 2, 25, True), ("cubic", 1, 700, 10, 2, 30, True), ("cubic", 1, 140, 6, 2, 50, True)]
+    P = len(specs)
+    arr = (_lib.Problem * P)()
+    res = (_lib.Result * P)()
+    keep = []
+    dp = lambda a: a.ctypes.data_as(_lib.c_dp) if a is not None else None
+    for p, (kernel, deg, n, d, k, m, wj) in enumerate(specs):
+        C, Y = _synthetic(n, d, k, seed=500 + p)
+        X = np.random.Generator(np.random.PCG64(600 + p)).random((max(m, 1), d))
+        cfg = pkg.RbfConfig(kernel=kernel, polynomial_degree=deg)
+        kid, a, b = pkg.rbf_model._get_kernel_params(1.0, cfg)
+        W = np.empty((n, k))
+        V = np.empty((max(m, 1), k)) if m > 0 else None
+        J = np.empty((max(m, 1), d, k)) if (m > 0 and wj) else None
+        keep.append((cfg, C, Y, X, W, V, J))
+        arr[p] = _lib.Problem(n, m, d, k, kid, deg, a, b, dp(C), dp(Y), dp(X) if m > 0 else None, dp(W), None, dp(V), dp(J))
+    assert ctx.lib.mrbf_batch_run(1, None, P, arr, res) == 0
+    for p, (kernel, deg, n, d, k, m, wj) in enumerate(specs):
+        cfg, C, Y, X, W, V, J = keep[p]
+        assert res[p].status == 0, (p, res[p].status)
+        mod = pkg.update_model(cfg, C, Y, ctx=ctx)
+        assert np.array_equal(mod.weights, W), p
+        if m > 0:
+            Vs, Js = mod.eval_sites(X[:m], want_values=True, want_jac=wj)
+            assert np.array_equal(Vs, V[:m]), p
+            if wj:
+                assert np.array_equal(Js, np.transpose(J[:m], (0, 2, 1))), p
+        mod.free()
+
+
 @pytest.mark.parametrize("n", [128, 256, 300, 1024, 1537, 2200, 2700, 3500])
 def test_builtin_cholesky_matches_lapack(ctx, n):
     rng = np.random.Generator(np.random.PCG64(n))
