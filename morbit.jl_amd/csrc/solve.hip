@@ -501,6 +501,8 @@ static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info
     // latency-bound kernels (Xc'Xc, 128 x 128 Cholesky, panel solve: ~150 us) runs on a side stream UNDER the Gram kernel.
     hipStream_t main_stream = ctx->stream;
     const bool side = q > 0 && ctx->panel_stream && ctx->panel_stream != main_stream && n >= 2048;
+    // d <= 64: the fit's own assembly writes the lower triangle only and accumulates Phi Xc on the way (gram_fused.hip)
+    const bool fused = q > 0 && gram_w_applies(ctx, M) && (q == 1 || round_up(d, 128) == 128);
     if (q > 0) {
         MRBF_TRY(get_buf(ctx, S_Q1, (size_t)npad * q, &Q1));
         MRBF_TRY(get_buf(ctx, S_W1, (size_t)npad * q, &Wm));
@@ -531,15 +533,35 @@ static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info
             MRBF_TRY(potrf_blocked_tall(ctx, dq, lt, Tall, lt, dinfo + 1, LxInv));  // flag read back with the main one
         }
         hipLaunchKernelGGL(build_q1_kernel, dim3(nblk(npad * q)), dim3(256), 0, ctx->stream, Tall, lt, dq, n, npad, q, Q1);
-        MRBF_HIP(ctx, hipMemsetAsync(Wm, 0, (size_t)npad * q * sizeof(double), ctx->stream));
+        if (!fused) MRBF_HIP(ctx, hipMemsetAsync(Wm, 0, (size_t)npad * q * sizeof(double), ctx->stream));
+        // B = P Y = Y - Q1 (Q1' Y) (T1 keeps Q1' Y for lam) and, for the built-in factorisation, the right-hand sides as extra rows
+        // of the matrix: they depend on Q1 and Y only, so they too run under the Gram kernel
+        MRBF_TRY(tsmm_tn(ctx, n, q, k, 1.0, Q1, npad, B, npad, 0.0, T1, q));
+        hipLaunchKernelGGL(sub_qt_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, ctx->stream, B, npad, Q1, npad, T1, n, q, k);
+        if (builtin) hipLaunchKernelGGL(set_rhs_rows_kernel, dim3(nblk(npad * xt)), dim3(256), 0, ctx->stream, Phi, ld, npad, xt, B, k);
         if (side) MRBF_HIP(ctx, hipEventRecord(ctx->evx[1], ctx->stream));
     }
     ctx->stream = main_stream;
     MRBF_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));  // ev0..ev1 bracket the Gram kernel alone
-    MRBF_TRY(launch_gram(ctx, ctx->gram_mode, M->C, M->Xc, M->sq, n, M->npad, M->d, M->dpad, M->kp, Phi, ld));
+    double *Wpart = nullptr, *rspart = nullptr;
+    int nseg = 0;
+    if (fused)
+        MRBF_TRY(launch_gram_w(ctx, M, Phi, ld, &Wpart, &rspart, &nseg));  // lower triangle + partial panels of Phi Xc, row sums
+    else
+        MRBF_TRY(launch_gram(ctx, ctx->gram_mode, M->C, M->Xc, M->sq, n, M->npad, M->d, M->dpad, M->kp, Phi, ld));
     MRBF_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     if (side) MRBF_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->evx[1], 0));
-    if (q > 0) {
+    if (fused) {
+        // W1 = Phi Q1 from the partial panels, G = Q1' W1, mu, V = W1 - Q1 (G / 2 + mu / 2 I), panels: three small launches
+        const int skip = (q > 1 && round_up(2 * (q - 1), 16) < round_up(2 * q, 16)) ? 1 : 0;
+        const int K2 = (int)round_up(2 * (q - skip), 16);
+        double *PA, *PB, *v0 = nullptr;
+        MRBF_TRY(get_buf(ctx, S_STAGE_C, (size_t)npad * K2, &PA));
+        MRBF_TRY(get_buf(ctx, S_STAGE_D, (size_t)npad * K2, &PB));
+        if (skip) MRBF_TRY(get_buf(ctx, S_V0, (size_t)npad, &v0));
+        MRBF_TRY(launch_projection_small(ctx, M, Wpart, rspart, nseg, LxInv, Q1, Wm, G, scal, dinfo, K2, skip, PA, PB, v0));
+        MRBF_TRY(launch_update_lower(ctx, PA, npad, PB, npad, Phi, ld, npad / 128, K2, v0, 1.0 / std::sqrt((double)n), n));
+    } else if (q > 0) {
         // W1 = Phi Q1 (Phi is stored in full) ; G = Q1' W1 ; W = W1 - 1/2 Q1 G
         MRBF_TRY(symm_panel(ctx, n, npad, q, Phi, ld, Q1, npad, Wm, npad, true, 1.0 / std::sqrt((double)n)));  // column 0 of Q1 is 1/sqrt(n)
         MRBF_TRY(tsmm_tn(ctx, n, q, q, 1.0, Q1, npad, Wm, npad, 0.0, G, q));
@@ -559,9 +581,6 @@ static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info
         if (skip) MRBF_TRY(get_buf(ctx, S_V0, (size_t)npad, &v0));
         hipLaunchKernelGGL(build_panels_kernel, dim3(nblk(npad * K2)), dim3(256), 0, ctx->stream, Q1, Wm, scal, n, npad, q, K2, skip, PA, PB, v0);
         MRBF_TRY(launch_update_lower(ctx, PA, npad, PB, npad, Phi, ld, npad / 128, K2, v0, 1.0 / std::sqrt((double)n), n));
-        // B = P Y = Y - Q1 (Q1' Y);  T1 keeps Q1' Y for lam
-        MRBF_TRY(tsmm_tn(ctx, n, q, k, 1.0, Q1, npad, B, npad, 0.0, T1, q));
-        hipLaunchKernelGGL(sub_qt_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, ctx->stream, B, npad, Q1, npad, T1, n, q, k);
     }
     MRBF_HIP(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
     int hinfo = 0;
@@ -569,7 +588,7 @@ static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info
     if (builtin) {
         MRBF_TRY(get_buf(ctx, S_CHOL_WS, (size_t)npad * 128, &linv_all));
         MRBF_TRY(launch_pad_identity(ctx, Phi, n, npad, ld));
-        hipLaunchKernelGGL(set_rhs_rows_kernel, dim3(nblk(npad * xt)), dim3(256), 0, ctx->stream, Phi, ld, npad, xt, B, k);
+        if (q == 0) hipLaunchKernelGGL(set_rhs_rows_kernel, dim3(nblk(npad * xt)), dim3(256), 0, ctx->stream, Phi, ld, npad, xt, B, k);
         MRBF_TRY(potrf_blocked_tall(ctx, npad, npad + xt, Phi, ld, dinfo, linv_all));
         MRBF_HIP(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
     } else {

@@ -307,8 +307,11 @@ function update_model(mod::Union{Nothing,HipRbfModel}, meta::RbfMeta, cfg::HipRb
         n0, nacc, q = _round4_dims(state, cfg, length(first(sites)))
         if _dispatch_fit(length(training_indices), n0, q, nacc, ids == training_indices)
             rc, model = fit_from_round4(state, values, length(first(sites)), meta.fully_linear; rc_only = true)
+            _free_round4!(state)                 # released here, not left to the finalizer (as sampling.py does)
             rc == 0 && return model, meta
             _fallback_rc(2, rc) || _check(state.ctx, rc)
+        else
+            _free_round4!(state)
         end
     end
     C = _dense(_as_matrix(sites))
@@ -441,9 +444,11 @@ function _container_plan(sc::SurrogateContainer; objectives_only::Bool = false)
     for (kind, role) in ((Val(:objectives), 0), (Val(:nl_eq_constraints), -2), (Val(:nl_ineq_constraints), -3))
         objectives_only && role != 0 && continue                              # _backtrack only evaluates the objectives (descent.jl:161-179)
         for s in _container_surrogates(sc, kind)
-            if s isa RefSurrogate && _inner(s) isa HipRbfModel
-                i = slot(_inner(s))
-                for oi in s.output_indices
+            # a bare HipRbfModel in a container list contributes all its rows in order (as surrogates.py container_plan does)
+            inner = s isa RefSurrogate ? _inner(s) : s
+            if !(s isa CompositeSurrogate) && inner isa HipRbfModel
+                i = slot(inner)
+                for oi in (s isa RefSurrogate ? s.output_indices : 1:num_outputs(inner))
                     roles[i][oi] == -1 || (n_foreign += 1)                    # one row in two roles: not expressible
                     roles[i][oi] = role == 0 ? Int32(k) : Int32(role)
                     role == 0 ? (k += 1) : (n_con += 1)

@@ -419,7 +419,37 @@ def test_c3_bench_workload_eval_against_oracle(ctx):
     # the same points alone (another launch shape: one query tile, other split) give the same numbers to rounding
     V2, J2 = mod.eval_sites(X[sub], want_values=True, want_jac=True)
     assert np.abs(V2 - V[sub]).max() < 1e-12 * max(1.0, np.abs(V).max()) and np.abs(J2 - J[sub]).max() < 1e-11 * max(1.0, np.abs(J).max())
-    REPORT["c3_bench_workload"] = dict(values=ev, jac=ej, rel_residual=mod.info["rel_residual"])
+    # the weights of the headline workload against the oracle: per-pair norm(x - c) assembly (threaded C restatement, the same
+    # arithmetic per entry as oracle.gram) + LAPACK LU of the 8257 x 8257 saddle system -- the same asserts as the C5 test
+    import os
+    import time
+
+    import scipy.linalg
+    from oracle import c_oracle
+
+    n = C.shape[0]
+    threads = min(16, os.cpu_count() or 1)
+    t0 = time.perf_counter()
+    Phi, Pi = c_oracle.gram(C, kid, a, b, 1, threads=threads)
+    S = orc.saddle_matrix(Phi, Pi)
+    rhs = np.vstack([Y, np.zeros((Pi.shape[1], Y.shape[1]))])
+    nrm_S = float(np.linalg.norm(S))
+    sol = scipy.linalg.solve(S, rhs, assume_a="gen", overwrite_a=False, check_finite=False)
+    t_oracle = time.perf_counter() - t0
+    xg = np.vstack([mod.weights, mod.poly])
+    be = float(np.linalg.norm(S @ xg - rhs) / (nrm_S * np.linalg.norm(xg) + np.linalg.norm(rhs)))
+    be_o = float(np.linalg.norm(S @ sol - rhs) / (nrm_S * np.linalg.norm(sol) + np.linalg.norm(rhs)))
+    ew = np.abs(mod.weights - sol[:n]).max() / np.abs(sol[:n]).max()
+    ref_o = orc.OracleModel(C, sol[:n].copy(), sol[n:].copy(), kid, a, b, 1)
+    ev_o = np.abs(V[sub] - ref_o.values(X[sub])).max() / max(1.0, np.abs(V).max())
+    ej_o = np.abs(J[sub[:32]] - ref_o.jacs(X[sub[:32]])).max() / max(1.0, np.abs(J).max())
+    print("C3: oracle LU %.1f s on %d threads; weights %.2e backward error %.2e (oracle %.2e) values %.2e jac %.2e"
+          % (t_oracle, threads, ew, be, be_o, ev_o, ej_o))
+    assert be <= 50 * EPS, be
+    assert ev_o < 1e-8 and ej_o < 1e-8, (ev_o, ej_o)
+    assert ew < W_TOL or np.linalg.norm(xg - sol) / np.linalg.norm(sol) <= 4 * float(np.linalg.cond(S, 1)) * (be + be_o), (ew, be, be_o)
+    REPORT["c3_bench_workload"] = dict(values=ev, jac=ej, rel_residual=mod.info["rel_residual"], weights_vs_oracle_lu=ew,
+                                       backward_error=be, values_vs_oracle=ev_o, jac_vs_oracle=ej_o)
     mod.free()
 
 

@@ -83,8 +83,32 @@ def pmc(wdb, fdb, prefix, inv, config):
     print(json.dumps(out, indent=1))
 
 
+def timeline(db, which):
+    """Kernels of fit number `which` (from the Gram kernel of that cycle to the end of its factorisation), offsets in us."""
+    con = sqlite3.connect(db)
+    cols = [c[0] for c in con.execute("select * from kernels limit 1").description]
+    qcol = next((c for c in ("stream_id", "queue_id", "queue") if c in cols), None)
+    rows = con.execute("select name, start, end%s from kernels order by start" % (", " + qcol if qcol else "")).fetchall()
+    starts = [i for i, r in enumerate(rows) if "gram_w_kernel" in r[0] or "gram_mfma" in r[0]]
+    if not starts:
+        print("no gram kernel in trace; columns:", cols)
+        return
+    i0 = starts[min(which, len(starts) - 1)]
+    # go back to the first kernel of the side chain of this fit (after the previous potrf_mega / eval)
+    j = i0
+    while j > 0 and rows[i0][1] - rows[j - 1][1] < 400000 and "potrf_mega" not in rows[j - 1][0] and "eval_" not in rows[j - 1][0]:
+        j -= 1
+    t0 = rows[j][1]
+    for r in rows[j:]:
+        print("%9.1f %8.1f  q=%s  %s" % ((r[1] - t0) / 1e3, (r[2] - r[1]) / 1e3, r[3] if qcol else "-", r[0][:90]))
+        if "potrf_mega_kernel" in r[0]:
+            break
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "stats":
+    if sys.argv[1] == "timeline":
+        timeline(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 3)
+    elif sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3], float(sys.argv[4]) if len(sys.argv) > 4 else 1.0)
     else:
         pmc(sys.argv[2], sys.argv[3], sys.argv[4], float(sys.argv[5]), sys.argv[6] if len(sys.argv) > 6 else "C3")
