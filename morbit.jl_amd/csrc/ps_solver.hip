@@ -72,7 +72,8 @@ struct Args {
     unsigned long long seed;
     double xtol_rel;
     int gen;
-    int dbg;  // timing experiments (MRBF_PS_DBG): 1 no ranking, 2 no breeding, 4 transposition phases also when a sort would do
+    int dbg;  // experiments (MRBF_PS_DBG): 1 no ranking, 2 no breeding, 4 transposition phases also when a sort would do, 8 t stays a free
+              // variable (no repair), 16 uniform start population
 };
 
 // ---- Philox 4x32-10 ---------------------------------------------------------------------------------------------
@@ -122,12 +123,21 @@ __global__ __launch_bounds__(256) void ps_init_kernel(Args a, const double *xn, 
         double u0, u1, z0, z1;
         rng4(a, blockIdx.y, 0, i, j, 15, u0, u1, z0, z1);
         double v = lo + u0 * (hi - lo);
+        double step = (hi - lo) / sqrt((double)n);
         if (i == 0 || (i == 1 && R.kind == 1)) {
             v = (R.kind == 1) ? (j == 0 ? (i == 0 ? t0 : 0.0) : xn[j - 1]) : xn[j];
             v = fmin(fmax(v, lo), hi);
+        } else if ((i & 1) && !(a.dbg & 16)) {
+            // every second individual is a mutation of the start point with a scale from 1/4 of the box down to 2^-11 of it (NLopt's
+            // ISRES starts its whole population at x0 too): at d >= 64 a uniform population holds no point that improves every
+            // objective at once, i.e. no feasible chi with t < 0, and the run ended where it began (omega = 0 at d = 64 .. 256)
+            const double sigma = 0.25 * exp2(-(double)(((i >> 1) - 1) % 10));
+            const double xs = (R.kind == 1) ? (j == 0 ? 0.0 : xn[j - 1]) : xn[j];
+            v = (R.kind == 1 && j == 0) ? 0.0 : fmin(fmax(xs + sigma * z0 * (hi - lo), lo), hi);
+            step *= sigma;
         }
         R.X[0][e] = v;
-        R.S[0][e] = (hi - lo) / sqrt((double)n);
+        R.S[0][e] = step;
         const int skip = R.kind == 1 ? 1 : 0;  // the evaluation batch holds the x part of every individual of every run
         if (j >= skip) a.Xeval[(size_t)(R.off + i) * a.d + (j - skip)] = v;
     }
@@ -162,7 +172,19 @@ __global__ __launch_bounds__(256) void ps_score_kernel(Args a) {
             f = a.F[a.obj_model[R.obj]][(size_t)row * a.kf[a.obj_model[R.obj]] + a.obj_col[R.obj]];
             phi = 0.0;
         } else {
-            const double t = R.X[a.gen & 1][(size_t)i * R.nvar];
+            double t = R.X[a.gen & 1][(size_t)i * R.nvar];
+            if (!(a.dbg & 8)) {
+                // the subproblem is min_x max_l (m_l(x) - m_l(x_n)) / r_l in disguise: the best t an x admits is known once x has been
+                // evaluated, so the individual carries THAT t (pulled a hair towards 0 so that rounding cannot make it infeasible);
+                // an x that worsens some objective keeps t = 0 and is ranked by its violation
+                double ts = -INFINITY;
+                for (int l = 0; l < a.nobj; ++l)
+                    ts = fmax(ts, (a.F[a.obj_model[l]][(size_t)row * a.kf[a.obj_model[l]] + a.obj_col[l]] - a.mx[l]) / a.r[l]);
+                if (ts == ts) {
+                    t = ts <= 0.0 ? fmax(ts * (1.0 - 1e-14), -1.0) : 0.0;
+                    if (lane == 0) R.X[a.gen & 1][(size_t)i * R.nvar] = t;
+                }
+            }
             f = t;
             phi = 0.0;
             for (int l = 0; l < a.nobj; ++l) {
@@ -561,106 +583,147 @@ static int ps_eval_point(mrbf_ctx *ctx, const ps::Problem &P, const double *x_ho
     return ps_eval_points(ctx, P, x_host, 1, allF, Jobj);
 }
 
-// weights of the minimum-norm point of the convex hull of k vectors with Gram matrix M (k x k): Gilbert / Frank-Wolfe steps
-static void min_norm_weights(int k, const std::vector<double> &M, std::vector<double> &lam) {
-    lam.assign(k, 1.0 / k);
+// weights of the proximal minimax step: minimise  sigma / 2 |sum_l lam_l g_l|^2 - sum_l lam_l gap_l  over the simplex (M = G G',
+// gap_l = F_l - max F <= 0), Frank-Wolfe with exact line search.  sigma -> infinity: the minimum-norm point of the hull of ALL
+// gradients (the common descent direction); sigma -> 0: the gradient of the active objective alone.  In between an objective
+// counts as far as a step of that length can make it active -- no fixed "nearly active" tolerance.
+static void prox_weights(int k, const std::vector<double> &M, const std::vector<double> &gap, double sigma, std::vector<double> &lam) {
+    int b0 = 0;
+    for (int a = 1; a < k; ++a)
+        if (gap[a] > gap[b0]) b0 = a;
+    lam.assign(k, 0.0);
+    lam[b0] = 1.0;
     std::vector<double> Ml(k);
-    for (int it = 0; it < 500; ++it) {
-        double gg = 0.0;
+    for (int it = 0; it < 400; ++it) {
+        double lMl = 0.0, lg = 0.0;
         for (int a = 0; a < k; ++a) {
             Ml[a] = 0.0;
             for (int b = 0; b < k; ++b) Ml[a] += M[(size_t)a * k + b] * lam[b];
-            gg += lam[a] * Ml[a];
+            lMl += lam[a] * Ml[a];
+            lg += lam[a] * gap[a];
         }
         int best = 0;
-        for (int a = 1; a < k; ++a)
-            if (Ml[a] < Ml[best]) best = a;
-        if (gg - Ml[best] <= 1e-14 * std::max(gg, 1e-300)) break;
-        const double den = gg - 2.0 * Ml[best] + M[(size_t)best * k + best];
-        const double gamma = den > 0.0 ? std::min(1.0, std::max(0.0, (gg - Ml[best]) / den)) : 1.0;
+        double gbest = sigma * Ml[0] - gap[0];
+        for (int a = 1; a < k; ++a) {
+            const double ga = sigma * Ml[a] - gap[a];
+            if (ga < gbest) {
+                gbest = ga;
+                best = a;
+            }
+        }
+        const double slope = (sigma * lMl - lg) - gbest;  // -(directional derivative towards the vertex) >= 0
+        if (slope <= 1e-14 * std::max(std::fabs(sigma * lMl) + std::fabs(lg), 1e-300)) break;
+        const double curv = sigma * (lMl - 2.0 * Ml[best] + M[(size_t)best * k + best]);
+        const double gamma = curv > 0.0 ? std::min(1.0, slope / curv) : 1.0;
         for (int a = 0; a < k; ++a) lam[a] *= (1.0 - gamma);
         lam[best] += gamma;
     }
 }
 
-// Gradient polish of the PS solution (the reference hands a local NLopt algorithm, descent.jl:560-569; the paper benchmark uses
-// :LD_MMA with 100 (d + 1) evaluations, examples/large_scale_benchmarks.jl:217-219).  Here: multi-objective steepest descent on
-// max_l (m_l(x) - m_l(x_n)) / r_l -- the direction is minus the minimum-norm convex combination of the (nearly) active scaled
-// gradients, projected at active bounds -- with all step sizes of a line search evaluated as ONE batch; every accepted iterate is
-// feasible (PS constraints, modelled and linear constraints, box).  Each iteration costs 1 + NSTEP evaluations.
-static int ps_polish(mrbf_ctx *ctx, const ps::Problem &P, const std::vector<double> &lb, const std::vector<double> &ub, const std::vector<double> &mx,
-                     const std::vector<double> &r, int max_evals, double &tau, std::vector<double> &x, int *evals_out) {
-    const int d = P.d, k = P.nobj;
+// Gradient refinement of a point of the box: a proximal steepest-descent method for
+//     min_x  max_{l in objs} (m_l(x) - off_l) / scale_l     subject to the problem's constraints and the box
+// -- the Pascoletti-Serafini subproblem itself with objs = all objectives, off = m(x_n), scale = r (the value is tau, kept in
+// [-1, 0]), one objective of the local ideal point with objs = {l}, off = 0, scale = 1.  (The reference hands a local NLopt
+// algorithm for the polish, descent.jl:560-569; the paper benchmark uses :LD_MMA with 100 (d + 1) evaluations,
+// examples/large_scale_benchmarks.jl:217-219.)  Per iteration one evaluation with Jacobians, then NSTEP trial points
+// x - sigma_u sum_l lam_l(sigma_u) g_l for NSTEP proximity parameters a factor two apart (each with its own weights, see
+// prox_weights), projected onto the box, evaluated as ONE batch; components that the step would push through an active bound are
+// taken out and the weights recomputed.  The best feasible improving trial point is taken; the range of sigma follows the accepted
+// steps.  It stops when the budget is used up or no step down to 1e-9 of the box improves (stationarity), NOT at the first line
+// search without improvement.  Every accepted iterate is feasible.  Each iteration costs 1 + NSTEP evaluations.
+static int ps_descend(mrbf_ctx *ctx, const ps::Problem &P, const std::vector<double> &lb, const std::vector<double> &ub, const std::vector<int> &objs,
+                      const std::vector<double> &off, const std::vector<double> &scale, bool clamp, int max_evals, double xtol_rel, double &val,
+                      std::vector<double> &x, int *evals_out) {
+    const int d = P.d, k = (int)objs.size();
     constexpr int NSTEP = 12;
-    std::vector<double> allF, J, F(k), dir(d), XT((size_t)NSTEP * d), M, lam;
+    std::vector<double> allF, J, F(k), gap(k), dir(d), XT((size_t)NSTEP * d), M((size_t)k * k), lam, G((size_t)k * d), row(P.nftot);
+    std::vector<char> fixed(d);
     int evals = 0;
-    while (evals + 1 + NSTEP <= max_evals) {
+    double width = 0.0;
+    for (int t = 0; t < d; ++t) width = std::max(width, ub[t] - lb[t]);
+    double frac = 0.25;  // the largest trial step moves the fastest component by this fraction of the box
+    int nsmall = 0;
+    while (evals + 1 + NSTEP <= max_evals && width > 0.0) {
         MRBF_TRY(ps_eval_point(ctx, P, x.data(), allF, &J));
         ++evals;
-        double tmax = -INFINITY;
+        double tmax = -INFINITY, gmax = 0.0;
         for (int l = 0; l < k; ++l) {
-            F[l] = (P.objective(allF, l) - mx[l]) / r[l];
+            F[l] = (P.objective(allF, objs[l]) - off[l]) / scale[l];
             tmax = std::max(tmax, F[l]);
         }
-        std::vector<int> act;
-        for (int l = 0; l < k; ++l)
-            if (F[l] >= tmax - 0.05) act.push_back(l);
-        const int ka = (int)act.size();
-        // scaled gradients of the active objectives; components that every one of them pushes through an active bound are dropped
-        std::vector<double> G((size_t)ka * d);
-        for (int t = 0; t < d; ++t) {
-            bool out_lo = x[t] <= lb[t], out_hi = x[t] >= ub[t];
-            for (int a = 0; a < ka; ++a) {
-                const double g = J[(size_t)act[a] * d + t] / r[act[a]];
-                G[(size_t)a * d + t] = g;
-                out_lo = out_lo && g > 0.0;  // descent direction -g < 0 leaves through the lower bound
-                out_hi = out_hi && g < 0.0;
+        for (int l = 0; l < k; ++l) {
+            gap[l] = F[l] - tmax;
+            for (int t = 0; t < d; ++t) {
+                G[(size_t)l * d + t] = J[(size_t)objs[l] * d + t] / scale[l];
+                gmax = std::max(gmax, std::fabs(G[(size_t)l * d + t]));
             }
-            if (out_lo || out_hi)
-                for (int a = 0; a < ka; ++a) G[(size_t)a * d + t] = 0.0;
         }
-        M.assign((size_t)ka * ka, 0.0);
-        for (int a = 0; a < ka; ++a)
-            for (int b = 0; b <= a; ++b) {
-                double sdot = 0.0;
-                for (int t = 0; t < d; ++t) sdot += G[(size_t)a * d + t] * G[(size_t)b * d + t];
-                M[(size_t)a * ka + b] = M[(size_t)b * ka + a] = sdot;
+        if (!(gmax > 0.0) || !(gmax < INFINITY)) break;
+        const double sigma0 = frac * width / gmax;
+        for (int u = 0; u < NSTEP; ++u) {
+            const double sigma = sigma0 * std::ldexp(1.0, -u);
+            std::fill(fixed.begin(), fixed.end(), 0);
+            for (int pass = 0; pass < 2; ++pass) {
+                for (int a = 0; a < k; ++a)
+                    for (int b = 0; b <= a; ++b) {
+                        double sdot = 0.0;
+                        for (int t = 0; t < d; ++t)
+                            if (!fixed[t]) sdot += G[(size_t)a * d + t] * G[(size_t)b * d + t];
+                        M[(size_t)a * k + b] = M[(size_t)b * k + a] = sdot;
+                    }
+                prox_weights(k, M, gap, sigma, lam);
+                bool changed = false;
+                for (int t = 0; t < d; ++t) {
+                    double v = 0.0;
+                    if (!fixed[t])
+                        for (int a = 0; a < k; ++a) v -= sigma * lam[a] * G[(size_t)a * d + t];
+                    dir[t] = v;
+                    if (!fixed[t] && ((x[t] <= lb[t] && v < 0.0) || (x[t] >= ub[t] && v > 0.0))) {
+                        fixed[t] = 1;
+                        dir[t] = 0.0;
+                        changed = true;
+                    }
+                }
+                if (!changed) break;
             }
-        min_norm_weights(ka, M, lam);
-        double dmax = 0.0, width = 0.0;
-        for (int t = 0; t < d; ++t) {
-            double v = 0.0;
-            for (int a = 0; a < ka; ++a) v -= lam[a] * G[(size_t)a * d + t];
-            dir[t] = v;
-            dmax = std::max(dmax, std::fabs(v));
-            width = std::max(width, ub[t] - lb[t]);
+            for (int t = 0; t < d; ++t) XT[(size_t)u * d + t] = std::min(std::max(x[t] + dir[t], lb[t]), ub[t]);
         }
-        if (!(dmax > 0.0) || !(width > 0.0)) break;  // Pareto-critical for the active objectives (or a degenerate box)
-        double step = width / dmax;                  // the first trial moves the fastest component across the whole box
-        for (int j = 0; j < NSTEP; ++j, step *= 0.5)
-            for (int t = 0; t < d; ++t) XT[(size_t)j * d + t] = std::min(std::max(x[t] + step * dir[t], lb[t]), ub[t]);
         MRBF_TRY(ps_eval_points(ctx, P, XT.data(), NSTEP, allF, nullptr));
         evals += NSTEP;
         int bestj = -1;
-        double bestt = tau - 1e-12;
-        std::vector<double> row(P.nftot);
+        double bestv = val - 1e-13 * std::max(1.0, std::fabs(val));
         for (int j = 0; j < NSTEP; ++j) {
             for (int c = 0; c < P.nftot; ++c) row[c] = allF[(size_t)j * P.nftot + c];
-            double tt = -1.0;
-            for (int l = 0; l < k; ++l) tt = std::max(tt, (P.objective(row, l) - mx[l]) / r[l]);
-            if (!(tt == tt)) continue;
-            tt = std::min(std::max(tt, -1.0), 0.0);
+            double tt = -INFINITY;
+            for (int l = 0; l < k; ++l) tt = std::max(tt, (P.objective(row, objs[l]) - off[l]) / scale[l]);
+            if (!(tt == tt) || !(tt < INFINITY)) continue;
             bool feas = P.violation(row, &XT[(size_t)j * d]) == 0.0;
-            for (int l = 0; l < k; ++l) feas = feas && (P.objective(row, l) - mx[l] - tt * r[l] <= 1e-14);
-            if (feas && tt < bestt) {
-                bestt = tt;
+            if (clamp) {
+                // tau = the t this x admits, a hair towards 0 so that rounding cannot make the PS constraints fail (descent.jl:443)
+                tt = std::min(std::max(tt < 0.0 ? tt * (1.0 - 1e-14) : tt, -1.0), 0.0);
+                for (int l = 0; l < k; ++l) feas = feas && (P.objective(row, objs[l]) - off[l] - tt * scale[l] <= 0.0);
+            }
+            if (feas && tt < bestv) {
+                bestv = tt;
                 bestj = j;
             }
         }
-        if (bestj < 0) break;
-        for (int t = 0; t < d; ++t) x[t] = XT[(size_t)bestj * d + t];
-        tau = bestt;
-        if (tau <= -1.0) break;
+        if (bestj < 0) {
+            frac *= std::ldexp(1.0, -NSTEP);  // nothing down to 2^-11 of the range improved: continue below it
+            if (frac < 1e-9) break;
+            continue;
+        }
+        bool small = true;  // NLopt's xtol_rel test (descent.jl:379, :485), on two accepted steps in a row
+        for (int t = 0; t < d; ++t) {
+            const double xn2 = XT[(size_t)bestj * d + t];
+            small = small && std::fabs(xn2 - x[t]) <= xtol_rel * std::max(std::fabs(xn2), 1e-300);
+            x[t] = xn2;
+        }
+        val = bestv;
+        frac = std::min(1.0, frac * std::ldexp(4.0, -bestj));  // the accepted step sits two levels below the top of the next range
+        if (clamp && val <= -1.0) break;
+        nsmall = small ? nsmall + 1 : 0;
+        if (nsmall >= 2) break;
     }
     *evals_out = evals;
     return 0;
@@ -790,6 +853,13 @@ extern "C" int32_t mrbf_ps_step_problem(mrbf_ctx *ctx, const mrbf_ps_problem *pr
     MRBF_HIP(ctx, hipMemcpyAsync(dmx, mx.data(), k * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     const int max_ip = opts->max_ideal_evals < 0 ? 500 * (d + 1) : opts->max_ideal_evals;   // descent.jl:527
     const int max_ps = opts->max_ps_evals < 0 ? 500 * (d + 1) : opts->max_ps_evals;          // descent.jl:416
+    // The evolution strategy is a global method: in d + 1 >= 25 variables it locates a basin, it does not descend into it (with the
+    // reference's defaults the step at d = 128 stayed at 7 % of what the subproblem allows).  A tenth of every global budget is
+    // therefore kept back for gradient steps from the strategy's best point (ps_descend) -- the evaluations are counted against the
+    // same budget, so the call never evaluates more than the configuration allows.  MRBF_PS_DBG bit 5 (32): the strategy alone.
+    const int dbg_env = getenv("MRBF_PS_DBG") ? atoi(getenv("MRBF_PS_DBG")) : 0;
+    const auto reserve = [&](int budget) { return (dbg_env & 32) || budget < 20 * 13 ? 0 : budget / 10; };
+    const int res_ip = reserve(max_ip), res_ps = opts->max_polish_evals > 0 ? 0 : reserve(max_ps);
     const double xtol = opts->xtol_rel > 0.0 ? opts->xtol_rel : 1e-3;                        // descent.jl:379, :485
 
     auto make_run = [&](Run &R, int kind, int obj, int lam, int nvar, int off, int max_evals, double *&p, int *st) {
@@ -885,26 +955,35 @@ extern "C" int32_t mrbf_ps_step_problem(mrbf_ctx *ctx, const mrbf_ps_problem *pr
     a.eq_tol = P.eq_tol;
     a.Xeval = Xeval;
     a.seed = opts->seed;
-    a.dbg = getenv("MRBF_PS_DBG") ? atoi(getenv("MRBF_PS_DBG")) : 0;
+    a.dbg = dbg_env;
     a.xtol_rel = xtol;
     // ---- local ideal point: the k single-objective minimisations side by side (descent.jl:404-412)
     if (need_ideal) {
         double *p = pool;
         a.nruns = k;
-        for (int l = 0; l < k; ++l) make_run(a.runs[l], 0, l, lam_ip, d, l * lam_ip, max_ip, p, stat + 4 * l);
-        MRBF_TRY(run_batch(a, dxn, 0.0, (max_ip + lam_ip - 1) / lam_ip + 1));
-        std::vector<double> bf(2 * k);
+        for (int l = 0; l < k; ++l) make_run(a.runs[l], 0, l, lam_ip, d, l * lam_ip, max_ip - res_ip, p, stat + 4 * l);
+        MRBF_TRY(run_batch(a, dxn, 0.0, (max_ip - res_ip + lam_ip - 1) / lam_ip + 1));
+        std::vector<double> bx((size_t)k * (d + 2));
         std::vector<int> hs((size_t)4 * k);
         for (int l = 0; l < k; ++l)
-            MRBF_HIP(ctx, hipMemcpyAsync(&bf[2 * l], a.runs[l].best + d, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            MRBF_HIP(ctx, hipMemcpyAsync(&bx[(size_t)l * (d + 2)], a.runs[l].best, (d + 2) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         MRBF_HIP(ctx, hipMemcpyAsync(hs.data(), stat, hs.size() * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
         for (int l = 0; l < k; ++l) {
             // r = f(x_n) - ideal point (descent.jl:536-538); a run that never met a feasible point contributes its start value
-            const double ideal = (bf[2 * l + 1] == 0.0 && std::isfinite(bf[2 * l])) ? bf[2 * l] : mx[l];
-            r[l] = hfx[l] - ideal;
+            const double *b = &bx[(size_t)l * (d + 2)];
+            const bool found = b[d + 1] == 0.0 && std::isfinite(b[d]);
+            double ideal = found ? b[d] : mx[l];
             info->evals_ideal += hs[(size_t)4 * l];
             info->generations += hs[(size_t)4 * l + 2];
+            const int left = max_ip - hs[(size_t)4 * l];
+            if (found && left >= 13 && !(dbg_env & 32)) {  // gradient steps on objective l from the run's best point
+                std::vector<double> xl(b, b + d);
+                int pe = 0;
+                MRBF_TRY(ps_descend(ctx, P, hlb, hub, std::vector<int>{l}, std::vector<double>{0.0}, std::vector<double>{1.0}, false, left, xtol, ideal, xl, &pe));
+                info->evals_ideal += pe;
+            }
+            r[l] = hfx[l] - ideal;
         }
     }
     info->tau = 0.0;
@@ -917,8 +996,8 @@ extern "C" int32_t mrbf_ps_step_problem(mrbf_ctx *ctx, const mrbf_ps_problem *pr
         MRBF_HIP(ctx, hipMemcpyAsync(dr, r.data(), k * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
         double *p = pool;
         a.nruns = 1;
-        make_run(a.runs[0], 1, 0, lam_ps, d + 1, 0, max_ps, p, stat);
-        MRBF_TRY(run_batch(a, dxn, opts->t0, (max_ps + lam_ps - 1) / lam_ps + 1));
+        make_run(a.runs[0], 1, 0, lam_ps, d + 1, 0, max_ps - res_ps, p, stat);
+        MRBF_TRY(run_batch(a, dxn, opts->t0, (max_ps - res_ps + lam_ps - 1) / lam_ps + 1));
         std::vector<double> best((size_t)d + 3);
         int hs[4];
         MRBF_HIP(ctx, hipMemcpyAsync(best.data(), a.runs[0].best, (d + 3) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -932,10 +1011,19 @@ extern "C" int32_t mrbf_ps_step_problem(mrbf_ctx *ctx, const mrbf_ps_problem *pr
         } else {
             double tau = bf;
             for (int t = 0; t < d; ++t) xt[t] = best[1 + t];
-            if (opts->max_polish_evals > 0) {
+            // the polish the configuration asks for (its own budget, descent.jl:423-429); without one, the part of the global budget
+            // that was kept back or left over
+            std::vector<int> objs(k);
+            for (int l = 0; l < k; ++l) objs[l] = l;
+            const bool own = opts->max_polish_evals > 0;
+            const int pbudget = own ? opts->max_polish_evals : ((dbg_env & 32) ? 0 : max_ps - hs[0]);
+            if (pbudget >= 13) {
                 int pe = 0;
-                MRBF_TRY(ps_polish(ctx, P, hlb, hub, mx, r, opts->max_polish_evals, tau, xt, &pe));
-                info->evals_polish = pe;
+                MRBF_TRY(ps_descend(ctx, P, hlb, hub, objs, mx, r, true, pbudget, xtol, tau, xt, &pe));
+                if (own)
+                    info->evals_polish = pe;
+                else
+                    info->evals_ps += pe;
             }
             info->tau = tau;
             info->status = MRBF_PS_OK;
