@@ -258,7 +258,8 @@ def main():
             """C4: all of this rank's problems through ONE mrbf_batch_run per step (one-launch small-problem fit + batched fused
             evaluation, csrc/batch.hip); inputs and outputs are torch tensors resident in HBM, handed over as device pointers"""
 
-            def __init__(self):
+            def __init__(self, subset=None):
+                mine = self.mine = list(subset) if subset is not None else mine_all
                 self.ctx = pkg.Context(local_rank)          # keeps the device selected; the library pools its own batch contexts
                 self.lib = self.ctx.lib
                 self.finfo = _lib.FitInfo()
@@ -279,6 +280,7 @@ def main():
                     self.arr[j] = _lib.Problem(n, m, d, k, kid, cfg["deg"], a, b, dp(dC), dp(dY), dp(dX), dp(dW), None, dp(dV), dp(dJ))
 
             def step(self):
+                mine = self.mine
                 rc = self.lib.mrbf_batch_run(1, (ctypes.c_int32 * 1)(local_rank), len(mine), self.arr, self.res)
                 assert rc == 0, "mrbf_batch_run failed: %d" % rc
                 # the result records as columns of one byte view over the ctypes array (a Python loop over 64 structs costs ~0.4 ms a step)
@@ -300,6 +302,7 @@ def main():
                     self.finfo = self.res[0].fit
                 return recs
 
+        mine_all = mine
         batched = many and n <= 512 and d <= 128 and not args.no_batch
         workers = [BatchWorker()] if batched else [Worker() for _ in range(nworkers)]
         # one checked cycle per rank (residual through the eval kernels), then the timed loop without the extra check
@@ -436,6 +439,20 @@ def main():
                 except Exception:
                     pass
             out.update({"roofline": roof, "kernels": kernels, "phases_ms": phases, "check": check})
+            if batched and world == 1 and P >= 16:
+                # what ONE of eight GPUs would see of this batch (problems p = 0, 8, 16, ...): the same library call on an eighth of the
+                # problems, timed on this GPU -- total / share bounds the strong scaling of the many-start path from one-GPU numbers
+                share = BatchWorker(mine[::8])
+                for _ in range(max(2, warmup)):
+                    share.step()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(steps):
+                    share.step()
+                torch.cuda.synchronize()
+                ms8 = (time.perf_counter() - t1) / steps * 1e3
+                out["one_of_eight_gpus"] = dict(problems=len(share.mine), ms_per_step=ms8, fit_ms=float(share.res[0].fit.ms_factor),
+                                                eval_ms=float(share.res[0].ms_eval), speedup_bound_8gpu=out["ms_per_step"] / ms8)
             if not args.no_cpu_baseline and world == 1 and args.config in ("C2", "C3", "C4"):
                 C, Y, X = host[mine[0]]
                 port, faithful = cpu_baselines(cfg, C, Y, X)

@@ -35,7 +35,9 @@ struct CheckDesc {
     double *out;               // [0] sum (V - Y)^2, [1] sum Y^2, [2] max |Pi' w|, [3] sum W, [4] sum vals
 };
 
-// one workgroup per problem, every reduction in a fixed order
+// one workgroup per problem, every reduction in a fixed order; every loop issues eight independent loads per thread before it
+// uses them (a thread that walks its elements one load at a time pays a memory round trip each: the first version of this kernel
+// took 166 us for 257 sites)
 // part 0: what depends on the fit and on the evaluation at the sites only (runs beside the evaluation of the queries); part 1: the
 // checksum of the values at the queries
 __global__ __launch_bounds__(256) void batch_check_kernel(const CheckDesc *__restrict__ many, int part) {
@@ -54,36 +56,59 @@ __global__ __launch_bounds__(256) void batch_check_kernel(const CheckDesc *__res
             __syncthreads();
         }
     };
+    // sum over i = tid, tid + 256, ... of f(i), eight terms in flight, added in index order
+    auto strided_sum = [&](int64_t cnt, auto f) {
+        double s = 0.0;
+        int64_t i = tid;
+        for (; i + 7 * 256 < cnt; i += 8 * 256) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = f(i + 256 * u);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; i < cnt; i += 256) s += f(i);
+        return s;
+    };
     if (part == 1) {
-        double sv = 0.0;
-        if (E.vals)
-            for (int64_t i = tid; i < E.m * E.k; i += 256) sv += E.vals[i];
+        const double *vals = E.vals;
+        const double sv = vals ? strided_sum(E.m * E.k, [&](int64_t i) { return vals[i]; }) : 0.0;
         tree(0.0, sv, false);
         if (tid == 0) E.out[4] = r1[0];
         return;
     }
-    double s0 = 0.0, s1 = 0.0;
-    for (int64_t i = tid; i < E.n * E.k; i += 256) {
-        const double df = E.V[i] - E.Y[i];
-        s0 = fma(df, df, s0);
-        s1 = fma(E.Y[i], E.Y[i], s1);
-    }
+    const double *V = E.V, *Y = E.Y;
+    const double s0 = strided_sum(E.n * E.k, [&](int64_t i) { const double df = V[i] - Y[i]; return df * df; });
+    const double s1 = strided_sum(E.n * E.k, [&](int64_t i) { return Y[i] * Y[i]; });
     tree(s0, s1, false);
     if (tid == 0) {
         E.out[0] = r0[0];
         E.out[1] = r1[0];
     }
     __syncthreads();
-    // max |Pi' w|: entry (t, l) = sum_i pi_t(c_i) w_il, pi_0 = 1, pi_t = coordinate t - 1
+    // max |Pi' w|: entry (t, l) = sum_i pi_t(c_i) w_il, pi_0 = 1, pi_t = coordinate t - 1; thread e owns entry e (consecutive t:
+    // coalesced rows of C), eight sites per step
     double mx = 0.0;
     for (int e = tid; e < E.q * E.k; e += 256) {
         const int t = e % E.q, l = e / E.q;
+        const double *wl = E.Wc + (int64_t)l * E.npad;
         double acc = 0.0;
-        for (int64_t i = 0; i < E.n; ++i) acc = fma(t == 0 ? 1.0 : E.C[i * E.d + (t - 1)], E.Wc[i + (int64_t)l * E.npad], acc);
+        int64_t i = 0;
+        for (; i + 8 <= E.n; i += 8) {
+            double c[8], w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                c[u] = t == 0 ? 1.0 : E.C[(i + u) * E.d + (t - 1)];
+                w[u] = wl[i + u];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = fma(c[u], w[u], acc);
+        }
+        for (; i < E.n; ++i) acc = fma(t == 0 ? 1.0 : E.C[i * E.d + (t - 1)], wl[i], acc);
         mx = fmax(mx, fabs(acc));
     }
-    double sw = 0.0;
-    for (int64_t i = tid; i < E.n * E.k; i += 256) sw += E.W[i];
+    const double *W = E.W;
+    const double sw = strided_sum(E.n * E.k, [&](int64_t i) { return W[i]; });
     tree(mx, sw, true);
     if (tid == 0) {
         E.out[2] = r0[0];
@@ -95,7 +120,7 @@ static inline size_t al16(size_t c) { return (c + 15) & ~size_t(15); }
 
 // all small problems of one GPU; `redo` receives the problems that have to take the per-problem chain after all (flags)
 static int run_small_batch(mrbf_ctx *ctx, const std::vector<int64_t> &idx, const mrbf_problem *problems, mrbf_result *results,
-                           std::vector<int64_t> *redo) {
+                           std::vector<int64_t> *redo, int force_nc = 0) {
     const int P = (int)idx.size();
     if (P == 0) return 0;
     (void)hipSetDevice(ctx->device);
@@ -156,8 +181,8 @@ static int run_small_batch(mrbf_ctx *ctx, const std::vector<int64_t> &idx, const
     int *flags = nullptr;
     MRBF_TRY(get_buf(ctx, S_SMALL_WS, total, &base));
     flags = reinterpret_cast<int *>(base + out0 + (size_t)8 * P);
-    // descriptors: [Prob x P | EvalDesc x 2P | CheckDesc x P | 8 cluster words x P (zero)] in one device buffer
-    const size_t desc_bytes = (size_t)P * (sizeof(smallfit::Prob) + 2 * sizeof(EvalDesc) + sizeof(CheckDesc) + 8 * sizeof(int)) + 256;
+    // descriptors: [Prob x P | EvalDesc x 2P | CheckDesc x P | CL_WORDS cluster words x P (zero)] in one device buffer
+    const size_t desc_bytes = (size_t)P * (sizeof(smallfit::Prob) + 2 * sizeof(EvalDesc) + sizeof(CheckDesc) + smallfit::CL_WORDS * sizeof(int)) + 256;
     char *ddesc;
     MRBF_TRY(get_buf(ctx, S_SMALL_DESC, desc_bytes, (void **)&ddesc));
     // (the device addresses of the three arrays and of the cluster words are known before the host copies are filled)
@@ -203,7 +228,8 @@ static int run_small_batch(mrbf_ctx *ctx, const std::vector<int64_t> &idx, const
         M.W = L.W == (size_t)-1 ? pr.weights_out : base + L.W;
         M.Wc = base + L.Wc;
         M.lam = L.lam == (size_t)-1 ? pr.poly_out : base + L.lam;
-        fill_small_prob(ctx, &M, Y, base + L.ws, flags + 4 * i, base + L.out + 5, dcl + 8 * i, &probs[i]);
+        fill_small_prob(ctx, &M, Y, base + L.ws, flags + 4 * i, base + L.out + 5, dcl + smallfit::CL_WORDS * i, &probs[i]);
+        probs[i].mean_given = 1;  // small_mean_kernel below: the queries are centred beside the fit, not after it
         for (int e = 0; e < 2; ++e) {
             EvalDesc &E = evs[(size_t)e * P + i];  // [residual evaluations of all problems | query evaluations of all problems]
             const int64_t m = e == 0 ? (check ? pr.n : 0) : pr.m;
@@ -257,16 +283,34 @@ static int run_small_batch(mrbf_ctx *ctx, const std::vector<int64_t> &idx, const
         MRBF_HIP(ctx, hipMemcpyAsync(ddesc, hdesc.data(), desc_bytes, hipMemcpyHostToDevice, st));
     }
     MRBF_HIP(ctx, hipEventRecord(ctx->ev[0], st));
-    const int nc = small_fit_cluster(ctx);
+    const int nc = force_nc > 0 ? force_nc : small_fit_cluster(ctx, P);
+    hipStream_t side = (ctx->panel_stream && ctx->panel_stream != st) ? ctx->panel_stream : st;
+    // the centroids first (the fit kernel's own arithmetic, small.hip: column_means), then -- on the side stream, under the
+    // latency-bound fit launch -- the centring of all evaluation points of the batch (sites for the residual, queries): 423 MB of
+    // queries at C4, 0.11 ms that used to stand between the fit and the evaluation
+    MRBF_TRY(launch_small_means(ctx, dprobs, P));
+    if (side != st) {
+        MRBF_HIP(ctx, hipEventRecord(ctx->evx[0], st));
+        MRBF_HIP(ctx, hipStreamWaitEvent(side, ctx->evx[0], 0));
+    }
+    {
+        int64_t max_mpad = 0;
+        for (const EvalDesc &E : evs) max_mpad = std::max(max_mpad, E.mpad);
+        ctx->stream = side;
+        const int rc = max_mpad > 0 ? center_pad_batch(ctx, devs_, 2 * P, max_mpad) : 0;
+        ctx->stream = st;
+        if (rc != 0) return rc;
+    }
     MRBF_TRY(launch_small_fit(ctx, probs.data(), P, dprobs, nc));
     MRBF_HIP(ctx, hipEventRecord(ctx->ev[1], st));
     // evaluation launches per group of equal (kernel, fast flag, padded dimension, outputs, Jacobians wanted): usually two groups,
     // the residual evaluations at the sites (no Jacobians; on the side stream, beside the evaluation of the queries, together with
     // part 0 of the check kernel) and the evaluations of the queries
-    hipStream_t side = (ctx->panel_stream && ctx->panel_stream != st) ? ctx->panel_stream : st;
     if (side != st) {
         MRBF_HIP(ctx, hipEventRecord(ctx->evx[0], st));
-        MRBF_HIP(ctx, hipStreamWaitEvent(side, ctx->evx[0], 0));
+        MRBF_HIP(ctx, hipStreamWaitEvent(side, ctx->evx[0], 0));   // residual evaluations: after the fit
+        MRBF_HIP(ctx, hipEventRecord(ctx->evx[2], side));
+        MRBF_HIP(ctx, hipStreamWaitEvent(st, ctx->evx[2], 0));     // query evaluations: after the centring
     }
     {
         struct RestoreStream {
@@ -307,7 +351,7 @@ static int run_small_batch(mrbf_ctx *ctx, const std::vector<int64_t> &idx, const
                 dev = dgrp;
                 host = grp.data();
             }
-            MRBF_TRY(eval_fused_batch(ctx, kpa, lay[a % P].D, pa.k, ja, host, dev, (int)members.size()));
+            MRBF_TRY(eval_fused_batch(ctx, kpa, lay[a % P].D, pa.k, ja, host, dev, (int)members.size(), true));
             if (!contiguous) MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
         }
     }
@@ -337,12 +381,21 @@ static int run_small_batch(mrbf_ctx *ctx, const std::vector<int64_t> &idx, const
     }
     MRBF_HIP(ctx, hipStreamSynchronize(st));
     if (nc > 1) {
-        bool cluster_failed = false;
-        for (int i = 0; i < P; ++i) cluster_failed = cluster_failed || hflags[(size_t)4 * i + 3] != 0;
-        if (cluster_failed) {  // placement or residency did not allow workgroup clusters here: one workgroup per problem from now on
-            ctx->small_nc = 1;
-            return run_small_batch(ctx, idx, problems, results, redo);
+        int worst = 0;
+        bool suspect = false;  // tripwire (small.hip, Cluster): a clustered fit that does not interpolate
+        for (int i = 0; i < P; ++i) {
+            worst = std::max(worst, hflags[(size_t)4 * i + 3]);
+            const double *o = &hout[(size_t)8 * i];
+            const bool flagged = hflags[(size_t)4 * i] != 0 || hflags[(size_t)4 * i + 1] != 0 || hflags[(size_t)4 * i + 2] != 0;
+            if (check && !flagged && !(std::sqrt(o[0]) < 1e-6 * std::max(std::sqrt(o[1]), 1e-300))) suspect = true;
         }
+        if (worst != 0 || suspect) {
+            // members on different XCDs (2) or a residual one workgroup has to confirm: clusters off for this context; a barrier
+            // that timed out (1): this batch again with one workgroup per problem, clusters stay unless it keeps happening
+            if (worst == 2 || suspect || ++ctx->small_timeouts >= 3) ctx->small_nc = 1;
+            return run_small_batch(ctx, idx, problems, results, redo, 1);
+        }
+        ctx->small_timeouts = 0;
     }
     float ms_fit = 0.f, ms_eval = 0.f;
     MRBF_HIP(ctx, hipEventElapsedTime(&ms_fit, ctx->ev[0], ctx->ev[1]));

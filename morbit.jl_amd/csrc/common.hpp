@@ -86,7 +86,9 @@ struct mrbf_ctx {
     int mega_stat_pending = 0;
     float last_device_ms = 0.f;
     int slow_launches = 0;
-    int small_nc = 4;  // workgroups per problem of the one-launch small fit (1 after a cluster failure on this context)
+    int small_nc = 4;  // 1 after a cluster failure on this context (XCD placement, or a result that one workgroup does not reproduce)
+    int small_cluster_ok = 0;    // the device is what the clusters' visibility argument assumes: gfx950, 8 XCDs x 32 CUs (context.hip)
+    int small_timeouts = 0;      // barrier time-outs of clustered launches in a row (three: clusters off for this context)
     std::map<long, float> mega_best_ms;
     std::vector<mrbf::MegaTables> mega_tables;  // LRU of job tables, one set per shape
     unsigned long long mega_table_clock = 0;

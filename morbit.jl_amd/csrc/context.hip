@@ -214,8 +214,14 @@ int32_t mrbf_init(int32_t device_id, mrbf_ctx **out) {
         if (const char *e = getenv("MRBF_SPIN_MS")) ctx->spin_ms = std::max(1, atoi(e));
         hipDeviceProp_t prop;
         int ncu = 256;
-        if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) ncu = prop.multiProcessorCount;
+        bool gfx950 = false;
+        if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) {
+            ncu = prop.multiProcessorCount;
+            gfx950 = std::strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+        }
         ctx->ncu = ncu;
+        // workgroup clusters of the small fit (small.hip) rest on 8 XCDs x 32 CUs with round-robin block placement: only there
+        ctx->small_cluster_ok = (gfx950 && ncu == 256) ? 1 : 0;
         const char *env = getenv("MRBF_BULK_RESERVE");
         const int reserve_per_32 = env ? atoi(env) : 0;  // measured: masking costs more than it buys
         std::vector<uint32_t> mask((ncu + 31) / 32, 0u);

@@ -530,8 +530,9 @@ __global__ __launch_bounds__(128) void eval_combine_kernel(EvalDesc one, const E
 }
 
 // queries: Xq[row][t] = X[row][t] - mean[t] (zero in the padding), xsq[row] = |Xq[row]|^2 -- center_pad_kernel's arithmetic (prep.hip)
-__global__ void center_pad_batch_kernel(const EvalDesc *__restrict__ many, int D) {
+__global__ void center_pad_batch_kernel(const EvalDesc *__restrict__ many, int Dfixed) {
     const EvalDesc &E = many[blockIdx.y];
+    const int D = Dfixed > 0 ? Dfixed : (E.d <= 64 ? 64 : 128);  // 0: by the descriptor (a batch of mixed dimensions)
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= E.mpad) return;
@@ -666,7 +667,15 @@ static int run_passes(mrbf_ctx *ctx, const KP &kp, int D, int k, bool want_jac, 
     return 0;
 }
 
-int eval_fused_batch(mrbf_ctx *ctx, const KP &kp, int D, int k, bool want_jac, const EvalDesc *host_descs, const EvalDesc *dev_descs, int count) {
+int center_pad_batch(mrbf_ctx *ctx, const EvalDesc *dev_descs, int count, int64_t max_mpad) {
+    if (count <= 0 || max_mpad <= 0) return 0;
+    hipLaunchKernelGGL(center_pad_batch_kernel, dim3((unsigned)((max_mpad + 3) / 4), (unsigned)count), dim3(256), 0, ctx->stream, dev_descs, 0);
+    MRBF_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+int eval_fused_batch(mrbf_ctx *ctx, const KP &kp, int D, int k, bool want_jac, const EvalDesc *host_descs, const EvalDesc *dev_descs, int count,
+                     bool centred) {
     if (count <= 0) return 0;
     if (D != 64 && D != 128 && D != 256) return fail(ctx, MRBF_EHIP, "eval_fused_batch needs dpad in {64, 128, 256}");
     int64_t max_mpad = 0, max_m = 0;
@@ -676,7 +685,15 @@ int eval_fused_batch(mrbf_ctx *ctx, const KP &kp, int D, int k, bool want_jac, c
         max_m = std::max(max_m, host_descs[p].m);
         max_split = std::max(max_split, host_descs[p].nsplit);
     }
-    hipLaunchKernelGGL(center_pad_batch_kernel, dim3((unsigned)((max_mpad + 3) / 4), (unsigned)count), dim3(256), 0, ctx->stream, dev_descs, D);
+    // one launch per group: either every member finishes inside the kernel (no split of the centre range anywhere) or every member
+    // carries partial buffers -- a group that mixes the two would run the partial-writing kernels on members without buffers
+    // (batch.hip sizes them by the member's own split); unreachable while the batch holds models of <= 8 centre tiles, refused otherwise
+    if (max_split > 1)
+        for (int p = 0; p < count; ++p)
+            if (host_descs[p].nsplit == 1 && host_descs[p].m > 0)
+                return fail(ctx, MRBF_EHIP, "eval_fused_batch: descriptor %d is unsplit in a group that splits the centre range", p);
+    if (!centred)
+        hipLaunchKernelGGL(center_pad_batch_kernel, dim3((unsigned)((max_mpad + 3) / 4), (unsigned)count), dim3(256), 0, ctx->stream, dev_descs, D);
     dim3 grid((unsigned)(max_mpad / EQ), (unsigned)max_split, (unsigned)count);
     dim3 cgrid((unsigned)max_m, (unsigned)count);
     return run_passes(ctx, kp, D, k, want_jac, max_split == 1, grid, cgrid, host_descs[0], dev_descs);

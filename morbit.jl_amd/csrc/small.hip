@@ -187,18 +187,93 @@ __device__ __noinline__ int diag_block(double *__restrict__ A, int ld, double *_
     return diagcore::diag_v4_core<false, false, false>(A, (int64_t)ld, Linv, sh, acc, nullptr, nullptr, 0);
 }
 
-// A problem is worked on by nc (1 or 4) workgroups: every product and every elementwise pass deals its tiles / elements over them,
-// the sequential pieces (the 128 x 128 diagonal blocks, the triangular solves, the tail) are member 0's, and the members meet at a
-// barrier after every phase.  With one workgroup per problem a batch of 64 kept 64 of the 256 CUs busy for the whole fit.
-// The members of a cluster are the blocks x + 8 (4 g + m), m = 0..3: blocks are dealt round-robin over the 8 XCDs (observed, not
-// promised), so a cluster shares ONE L2 -- stores become visible to the siblings once they have left the CU (s_waitcnt vmcnt(0)),
-// and a barrier only has to drop the reader's L1 (buffer_inv sc1).  Every member publishes the XCD it runs on; if they differ the
-// cluster gives up before it has relied on anything (flag 3), and the host repeats the launch with one workgroup per problem.
-// Progress at any residency: blocks are dispatched in index order, so the lowest-numbered unfinished group of 32 blocks is
-// always resident as a whole.  The spin is bounded by wall-clock time all the same.
+// A 128 x 128 diagonal block of which only the leading `real` x `real` part is not the identity (the last block of a padded matrix:
+// n = 2d + 1 = 257 leaves 16 real rows in its third block; the tail basis' Gram matrix of a problem with d <= 32): factor and invert
+// that part in LDS with one wave -- a few microseconds instead of the 40 of the register-resident 128 x 128 core.  Same contract as
+// diag_block (L in the lower triangle of A, inv(L) as a full 128 x 128 block, the 1-based index of a bad pivot or 0).
+__device__ __noinline__ int small_block(double *__restrict__ A, int ld, int real, double *__restrict__ Linv, double *ws /* >= 2 x 32 x 33 doubles of LDS */) {
+    constexpr int LS = 33;
+    double *L = ws, *X = ws + 32 * LS;
+    __shared__ int s_bad;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < 32 * 32; e += 256) {
+        const int i = e & 31, j = e >> 5;
+        L[i * LS + j] = (i < real && j <= i) ? gld(&A[i + (int64_t)j * ld]) : (i == j ? 1.0 : 0.0);
+        X[i * LS + j] = 0.0;
+    }
+    if (tid == 0) s_bad = 0;
+    __syncthreads();
+    if (tid < 64) {
+        const int i = tid;  // lane i owns row i
+        for (int k = 0; k < real; ++k) {
+            const double piv = L[k * LS + k];
+            if (!(piv > 0.0)) {
+                if (i == 0) s_bad = k + 1;
+                break;  // uniform: every lane reads the same pivot
+            }
+            const double lkk = sqrt(piv);
+            double lik = 0.0;
+            if (i > k && i < real) {
+                lik = L[i * LS + k] / lkk;
+                L[i * LS + k] = lik;
+            }
+            if (i == k) L[k * LS + k] = lkk;
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // LDS writes of this wave are visible to its later reads in program order
+            __builtin_amdgcn_wave_barrier();
+            if (i > k && i < real)
+                for (int j = k + 1; j <= i; ++j) L[i * LS + j] = fma(-lik, L[j * LS + k], L[i * LS + j]);
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (s_bad == 0 && i < real) {
+            // column i of inv(L): forward substitution  x_r = (delta_ri - sum_{i <= p < r} L_rp x_p) / L_rr
+            for (int r = i; r < real; ++r) {
+                double acc = r == i ? 1.0 : 0.0;
+                for (int pp = i; pp < r; ++pp) acc = fma(-L[r * LS + pp], X[pp * LS + i], acc);
+                X[r * LS + i] = acc / L[r * LS + r];
+            }
+        }
+    }
+    __syncthreads();
+    const int bad = s_bad;
+    if (bad) return bad;
+    for (int e = tid; e < 128 * 128; e += 256) {
+        const int i = e & 127, j = e >> 7;
+        double v = i == j ? 1.0 : 0.0;
+        if (i < real && j < real) v = j <= i ? X[i * LS + j] : 0.0;
+        gst(&Linv[e], v);
+        if (i < real && j <= i && j < real) gst(&A[i + (int64_t)j * ld], L[i * LS + j]);
+    }
+    __syncthreads();
+    return 0;
+}
+__device__ __forceinline__ int diag_block_auto(double *__restrict__ A, int ld, int real, double *__restrict__ Linv, diagcore::DiagV4Shared &sh) {
+    return (real > 0 && real <= 32) ? small_block(A, ld, real, Linv, sh.LT) : diag_block(A, ld, Linv, sh);
+}
+
+// A problem is worked on by nc (1, 2, 4, 8 or 16) workgroups: every product and every elementwise pass deals its tiles / elements over
+// them, the sequential pieces (the 128 x 128 diagonal blocks, the triangular solves, the tail) are member 0's, and the members meet at
+// a barrier after every phase.  With one workgroup per problem a batch of 64 kept 64 of the 256 CUs busy for the whole fit.
+// The members of a cluster are the blocks x + 8 (nc g + m), m = 0..nc-1: blocks are dealt round-robin over the 8 XCDs (observed, not
+// promised), so a cluster shares ONE L2.
+//
+// Memory model of the barrier -- on purpose NOT an agent-scope release / acquire pair.  An agent-scope release on gfx950 is
+// `buffer_wbl2 sc1` (write back the XCD's whole L2: the problem's ~4 MB working set is dirty there) and an agent-scope acquire drops
+// the L2 as well; 25 barriers per fit would each pay that.  What the code relies on instead, and checks:
+//   * the vector L1 of a CU is write-through: a store has reached the L2 when it is counted out of vmcnt, so `s_waitcnt vmcnt(0)`
+//     + the workgroup barrier before the arrival means every member's stores ARE in the L2 when the arrival is visible;
+//   * all members sit behind the SAME L2 (HW_REG_XCC_ID of every member is published and compared before anything is relied on;
+//     a mismatch ends the launch with flag 2 and the host repeats it with one workgroup per problem, for good);
+//   * the reader only has to drop its own L1: the acquire fence after the poll is `buffer_inv sc1`.
+// The host gates clusters on the device being gfx950 with 256 CUs (context.hip), repeats a launch whose barrier timed out with one
+// workgroup per problem (and returns to clusters afterwards: a time-out says nothing about visibility), and uses the interpolation
+// residual every fit computes anyway as a tripwire: a clustered fit whose residual is not small is repeated with one workgroup,
+// and if that changes the result the context stops using clusters (solve.hip: fit_model, batch.hip).
+// Progress at any residency: blocks are dispatched in index order, so the lowest-numbered unfinished group of 8 nc blocks is always
+// resident as a whole.  The spin is bounded by wall-clock time all the same.
 struct Cluster {
     int member, nc, phase;
-    int *words;  // [0] arrivals, [1] failure / bad-pivot word, [2..5] XCD of the members (device memory, zero at launch)
+    int *words;  // [0] arrivals, [1] failure / bad-pivot word, [2 .. 2 + nc) XCD of the members (device memory, zero at launch)
     unsigned long long ticks;
     int *s_ok;   // LDS word
 };
@@ -255,7 +330,7 @@ __device__ int wg_potrf(double *__restrict__ A, int ld, int np, int rows16, doub
         double *Acc = A + (int64_t)c * 128 * (ld + 1);
         double *Lc = Linv + (int64_t)c * 128 * 128;
         if (cl.member == 0) {
-            const int bad = diag_block(Acc, ld, Lc, sh);
+            const int bad = diag_block_auto(Acc, ld, rows16 - 128 * c, Lc, sh);
             __syncthreads();
             if (threadIdx.x == 0 && bad) cl_store(cl.words + 1, 128 * c + bad);  // positive: a bad pivot, every member leaves
         }
@@ -283,19 +358,58 @@ __device__ int wg_potrf(double *__restrict__ A, int ld, int np, int rows16, doub
     return 0;
 }
 
+// column sums of the n x d sites -> s_mean[0 .. 127] (zero beyond d): wave w takes the rows w, w + 4, ..., eight rows (independent
+// loads) per step, lanes over the columns; the four partial sums meet in LDS in a fixed order.  (One thread per column walking all n
+// rows paid a memory round trip per row: 80 us of a 257-site fit.)  ONE function for the fit kernel and for small_mean_kernel: a
+// batch (centroid computed up front) and a single fit agree bit for bit.
+__device__ __forceinline__ void column_means(const double *C, int n, int d, double *part /* 4 x 128 doubles of LDS */, double *s_mean) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const gdbl *Cg = (const gdbl *)C;
+    double s0 = 0.0, s1 = 0.0;
+    const int t0 = lane, t1 = lane + 64;
+    for (int i0 = wave; i0 < n; i0 += 32) {
+        double a0[8], a1[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + 4 * u;
+            a0[u] = (i < n && t0 < d) ? Cg[(int64_t)i * d + t0] : 0.0;
+            a1[u] = (i < n && t1 < d) ? Cg[(int64_t)i * d + t1] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            s0 += a0[u];
+            s1 += a1[u];
+        }
+    }
+    part[wave * 128 + t0] = s0;
+    part[wave * 128 + t1] = s1;
+    __syncthreads();
+    if (tid < 128) s_mean[tid] = tid < d ? ((part[tid] + part[128 + tid]) + (part[256 + tid] + part[384 + tid])) / (double)n : 0.0;
+}
+
+__global__ __launch_bounds__(256) void small_mean_kernel(const Prob *__restrict__ many, int count) {
+    __shared__ double part[512];
+    __shared__ double s_mean[128];
+    if ((int)blockIdx.x >= count) return;
+    const Prob &P = many[blockIdx.x];
+    column_means(P.C, P.n, P.d, part, s_mean);
+    __syncthreads();
+    for (int t = threadIdx.x; t < P.dpad; t += 256) P.mean[t] = t < 128 ? s_mean[t] : 0.0;
+}
+
 __global__ __launch_bounds__(256, 1) void small_fit_kernel(Prob one, const Prob *__restrict__ many, int count, int nc) {
     __shared__ __attribute__((aligned(16))) diagcore::DiagV4Shared sh;
     __shared__ double red[4];
     __shared__ double s_mean[128];
     __shared__ int s_ok;
-    // nc = 4: block x + 8 (4 g + m) is member m of the cluster of problem x + 8 g (see Cluster)
+    // nc > 1: block x + 8 (nc g + m) is member m of the cluster of problem x + 8 g (see Cluster)
     const int bx = (int)blockIdx.x;
-    const int prob = nc == 1 ? bx : (bx & 7) + 8 * (bx >> 5);
+    const int prob = nc == 1 ? bx : (bx & 7) + 8 * ((bx >> 3) / nc);
     if (prob >= count) return;
     const Prob P = many ? many[prob] : one;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     Cluster cl;
-    cl.member = nc == 1 ? 0 : (bx >> 3) & 3;
+    cl.member = nc == 1 ? 0 : (bx >> 3) % nc;
     cl.nc = nc;
     cl.phase = 0;
     cl.words = P.cl;
@@ -332,35 +446,13 @@ __global__ __launch_bounds__(256, 1) void small_fit_kernel(Prob one, const Prob 
     }
 
     // ---- centroid, centred + zero-padded coordinates, squared norms (the model's own arrays: the evaluation uses them later)
-    {
-        // column sums: wave w takes the rows w, w + 4, ..., eight rows (independent loads) per step, lanes over the columns; the four
-        // partial sums meet in LDS in a fixed order.  (One thread per column walking all n rows paid a memory round trip per row:
-        // 80 us of a 257-site fit.)
-        const gdbl *Cg = (const gdbl *)P.C;
-        double s0 = 0.0, s1 = 0.0;
-        const int t0 = lane, t1 = lane + 64;
-        for (int i0 = wave; i0 < n; i0 += 32) {
-            double a0[8], a1[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = i0 + 4 * u;
-                a0[u] = (i < n && t0 < d) ? Cg[(int64_t)i * d + t0] : 0.0;
-                a1[u] = (i < n && t1 < d) ? Cg[(int64_t)i * d + t1] : 0.0;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                s0 += a0[u];
-                s1 += a1[u];
-            }
-        }
-        double *part = sh.LT;  // 4 x 128 doubles of the (idle) diagonal-core LDS
-        part[wave * 128 + t0] = s0;
-        part[wave * 128 + t1] = s1;
-        __syncthreads();
-        if (tid < 128) s_mean[tid] = tid < d ? ((part[tid] + part[128 + tid]) + (part[256 + tid] + part[384 + tid])) / (double)n : 0.0;
+    if (P.mean_given) {
+        if (tid < 128) s_mean[tid] = tid < d ? gld(&P.mean[tid]) : 0.0;
+    } else {
+        column_means(P.C, n, d, sh.LT, s_mean);
     }
     __syncthreads();
-    if (member == 0)
+    if (member == 0 && !P.mean_given)
         for (int t = tid; t < dpad; t += 256) P.mean[t] = t < 128 ? s_mean[t] : 0.0;
     {
         const gdbl *Cg = (const gdbl *)P.C;
@@ -399,7 +491,8 @@ __global__ __launch_bounds__(256, 1) void small_fit_kernel(Prob one, const Prob 
     MRBF_CLB();
     if (nc > 1) {
         const int x0 = cl_load(cl.words + 2);
-        const bool same = x0 != 0 && cl_load(cl.words + 3) == x0 && cl_load(cl.words + 4) == x0 && cl_load(cl.words + 5) == x0;
+        bool same = x0 != 0;
+        for (int m2 = 1; m2 < nc; ++m2) same = same && cl_load(cl.words + 2 + m2) == x0;
         if (!same) {  // not one L2: nothing has been relied on yet (every member sees the same four words and leaves)
             if (tid == 0 && member == 0) P.flags[3] = 2;
             return;
@@ -490,7 +583,7 @@ __global__ __launch_bounds__(256, 1) void small_fit_kernel(Prob one, const Prob 
             }, member, nc);
             MRBF_CLB();
             if (member == 0) {
-                const int bad = diag_block(Gx, 128, LinvX, sh);
+                const int bad = diag_block_auto(Gx, 128, d, LinvX, sh);
                 __syncthreads();
                 if (tid == 0 && bad) P.flags[1] = bad;
             }
@@ -636,16 +729,30 @@ bool small_fit_applies(const mrbf_ctx *ctx, int64_t n, int d, int k, int q, int 
     return n >= 1 && n <= 512 && d >= 1 && d <= 128 && k >= 1 && k <= 16 && n > q && (path == MRBF_PATH_CHOL || path == MRBF_PATH_PROJ_CHOL);
 }
 
-int small_fit_cluster(const mrbf_ctx *ctx) {
+int small_fit_cluster(const mrbf_ctx *ctx, int count) {
     static const int env = getenv("MRBF_SMALL_NC") ? atoi(getenv("MRBF_SMALL_NC")) : 0;
-    return (env == 1 || ctx->small_nc == 1) ? 1 : 4;
+    if (env == 1 || ctx->small_nc == 1 || !ctx->small_cluster_ok) return 1;
+    const int groups = (std::max(count, 1) + 7) / 8;  // clusters are dealt in groups of eight problems (one per XCD)
+    int nc = 1;
+    while (2 * nc <= smallfit::MAX_CLUSTER && 8 * groups * 2 * nc <= ctx->ncu) nc *= 2;
+    if (env > 1) nc = std::min(env, smallfit::MAX_CLUSTER);
+    int p2 = 1;
+    while (2 * p2 <= nc) p2 *= 2;
+    return p2;
 }
 
 int launch_small_fit(mrbf_ctx *ctx, const smallfit::Prob *host_probs, int count, const smallfit::Prob *dev_probs, int nc) {
     if (count <= 0) return 0;
-    const unsigned grid = nc == 1 ? (unsigned)count : 32u * (unsigned)((count + 7) / 8);
+    const unsigned grid = nc == 1 ? (unsigned)count : 8u * (unsigned)nc * (unsigned)((count + 7) / 8);
     hipLaunchKernelGGL(smallfit::small_fit_kernel, dim3(grid), dim3(256), 0, ctx->stream, host_probs[0],
                        (count == 1 && !dev_probs) ? (const smallfit::Prob *)nullptr : dev_probs, count, nc);
+    MRBF_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+int launch_small_means(mrbf_ctx *ctx, const smallfit::Prob *dev_probs, int count) {
+    if (count <= 0) return 0;
+    hipLaunchKernelGGL(smallfit::small_mean_kernel, dim3((unsigned)count), dim3(256), 0, ctx->stream, dev_probs, count);
     MRBF_HIP(ctx, hipGetLastError());
     return 0;
 }

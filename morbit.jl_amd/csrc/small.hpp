@@ -17,10 +17,15 @@ struct Prob {
                                              // [3] the cluster failed (1: a barrier timed out, 2: its members are not on one XCD): repeat with nc = 1
     double *scal;                            // [0] trace(Q1' Phi Q1), [1] mu
     long long *stamps;                       // debug (MRBF_SMALL_STAMPS): wall_clock64 at the phase boundaries, or NULL
-    int *cl;                                 // 8 words of the problem's workgroup cluster (zero at launch): arrivals, failure word, XCDs
+    int *cl;                                 // CL_WORDS words of the problem's workgroup cluster (zero at launch): arrivals, failure word, XCDs
+    int mean_given;                          // the centroid already lies in `mean` (small_mean_kernel, same arithmetic): the batch path centres its
+                                             // queries beside the fit instead of after it
     unsigned long long spin_ticks;           // bound of a cluster barrier's spin (wall_clock64 ticks)
     int fault;                               // test hook (MRBF_OPT_DEBUG_FAULT bit 4): member 1 leaves before the third barrier
 };
+
+constexpr int CL_WORDS = 24;   // arrivals, failure word, XCD of up to 16 members
+constexpr int MAX_CLUSTER = 16;
 
 struct Carve {
     size_t Phi, Q1, Wm, V, G, Gx, LinvX, Linv, Pt, Ycol, B, Fy, Xs, T1, T2, Z, total;
@@ -76,12 +81,21 @@ struct EvalDesc {
 int eval_nsplit(const mrbf_ctx *ctx, int64_t m, int ntiles);  // ntiles = ceil(n / 64)
 int outputs_per_pass(int k, int D);  // outputs of a model the fused evaluation handles per pass
 // all descriptors: same kernel id / fast flag / padded dimension D (64 or 128) / k; dev_descs = the same array in device memory
-int eval_fused_batch(mrbf_ctx *ctx, const KP &kp, int D, int k, bool want_jac, const EvalDesc *host_descs, const EvalDesc *dev_descs, int count);
+// centred: the descriptors' Xq / xsq are already filled (center_pad_batch on all descriptors of a batch, launched beside the fit)
+int eval_fused_batch(mrbf_ctx *ctx, const KP &kp, int D, int k, bool want_jac, const EvalDesc *host_descs, const EvalDesc *dev_descs, int count,
+                     bool centred = false);
+// Xq = X - mean (zero padded to D = 64 / 128 by the descriptor's d), xsq = |Xq|^2 for `count` descriptors of any mix of dimensions
+int center_pad_batch(mrbf_ctx *ctx, const EvalDesc *dev_descs, int count, int64_t max_mpad);
 
 // does the one-launch path take a problem of this shape on this context?  (path: MRBF_PATH_* chosen by fit_model)
 bool small_fit_applies(const mrbf_ctx *ctx, int64_t n, int d, int k, int q, int path);
 // count == 1 and dev_probs == nullptr: the descriptor travels as a kernel argument; else one workgroup per descriptor of dev_probs
 int launch_small_fit(mrbf_ctx *ctx, const smallfit::Prob *host_probs, int count, const smallfit::Prob *dev_probs, int nc);
-int small_fit_cluster(const mrbf_ctx *ctx);  // workgroups per problem this context uses (4, or 1 after a cluster failure / MRBF_SMALL_NC=1)
+// workgroups per problem for a launch of `count` problems: the power of two <= 256 / (problems rounded up to 8), at most 16 -- a batch of 8
+// (what one of eight GPUs sees of 64 starts) spreads every problem over 16 compute units, a batch of 64 over 4; 1 after a cluster
+// failure on this context, on devices that are not 8 XCDs x 32 CUs of gfx950, or with MRBF_SMALL_NC=1
+int small_fit_cluster(const mrbf_ctx *ctx, int count);
+// the centroids of `count` problems into their `mean` arrays (what small_fit_kernel computes itself unless Prob::mean_given)
+int launch_small_means(mrbf_ctx *ctx, const smallfit::Prob *dev_probs, int count);
 
 }  // namespace mrbf

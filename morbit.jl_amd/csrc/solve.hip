@@ -725,6 +725,7 @@ void fill_small_prob(const mrbf_ctx *ctx, const mrbf_model *M, const double *Y, 
     P->cl = cl;
     P->spin_ticks = (unsigned long long)std::max(1, ctx->spin_ms) * 100000ull;  // wall_clock64: 100 MHz
     P->fault = (ctx->debug_fault & 4) ? 1 : 0;
+    P->mean_given = 0;
 }
 // what the flags of a small-problem fit mean for mrbf_fit_info (shared with the batched entry point): returns 1 when the problem
 // has to be re-done on the LU path
@@ -742,7 +743,7 @@ int small_fit_verdict(const mrbf_model *M, const int *hflags, const double *hsca
     }
     return hflags[0] != 0 ? 1 : 0;
 }
-static int fit_small(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info *info, int *not_pd) {
+static int fit_small(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info *info, int *not_pd, int force_nc, int *nc_used) {
     *not_pd = 0;
     smallfit::Prob P;
     const smallfit::Carve cv = smallfit::carve((int)M->npad, (int)round_up(std::max(M->q, 1), 16));
@@ -752,7 +753,7 @@ static int fit_small(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_inf
     MRBF_TRY(get_buf(ctx, S_SMALL_FLAGS, (size_t)4, &flags));
     MRBF_TRY(get_buf(ctx, S_MISC, (size_t)8, &scal));
     int *cl;
-    MRBF_TRY(get_buf(ctx, S_SMALL_CL, (size_t)8, &cl));
+    MRBF_TRY(get_buf(ctx, S_SMALL_CL, (size_t)smallfit::CL_WORDS, &cl));
     fill_small_prob(ctx, M, Y, ws, flags, scal, cl, &P);
     static const int want_stamps = getenv("MRBF_SMALL_STAMPS") ? atoi(getenv("MRBF_SMALL_STAMPS")) : 0;
     long long *dstamps = nullptr;
@@ -762,25 +763,33 @@ static int fit_small(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_inf
     }
     int hflags[4] = {0, 0, 0, 0};
     double hscal[2] = {0.0, 0.0};
+    int nc = force_nc > 0 ? force_nc : small_fit_cluster(ctx, 1);
     for (int attempt = 0; attempt < 2; ++attempt) {
-        const int nc = small_fit_cluster(ctx);
-        MRBF_HIP(ctx, hipMemsetAsync(cl, 0, 8 * sizeof(int), ctx->stream));
+        MRBF_HIP(ctx, hipMemsetAsync(cl, 0, smallfit::CL_WORDS * sizeof(int), ctx->stream));
         MRBF_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
         MRBF_TRY(launch_small_fit(ctx, &P, 1, nullptr, nc));
         MRBF_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
         MRBF_HIP(ctx, hipMemcpyAsync(hflags, flags, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         MRBF_HIP(ctx, hipMemcpyAsync(hscal, scal, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (hflags[3] == 0 || nc == 1) break;
-        ctx->small_nc = 1;  // the cluster could not be relied on here (placement or residency): one workgroup per problem from now on
+        if (nc == 1) break;
+        if (hflags[3] == 0) {
+            ctx->small_timeouts = 0;
+            break;
+        }
+        // the cluster gave up before it had relied on anything: repeat with one workgroup.  Members on different XCDs: clusters are off
+        // for this context.  A barrier that timed out (a busy device, a test hook) says nothing about visibility: clusters stay on
+        // unless it happens three times in a row.
+        if (hflags[3] == 2 || ++ctx->small_timeouts >= 3) ctx->small_nc = 1;
+        nc = 1;
     }
+    *nc_used = nc;
     MRBF_HIP(ctx, hipEventElapsedTime(&info->ms_factor, ctx->ev[0], ctx->ev[1]));  // one launch: assembly, projection, factorisation, solve
     if (want_stamps) {
         long long hs[16];
         MRBF_HIP(ctx, hipMemcpy(hs, dstamps, sizeof(hs), hipMemcpyDeviceToHost));
         static const char *names[] = {"centre", "gram", "Q1", "W,G,mu,V", "K update", "rhs", "potrf", "solves", "tail"};
-        fprintf(stderr, "small fit n=%lld d=%d q=%d (%d workgroup%s): %.3f ms |", (long long)M->n, M->d, M->q, small_fit_cluster(ctx),
-                small_fit_cluster(ctx) == 1 ? "" : "s", info->ms_factor);
+        fprintf(stderr, "small fit n=%lld d=%d q=%d (%d workgroup%s): %.3f ms |", (long long)M->n, M->d, M->q, nc, nc == 1 ? "" : "s", info->ms_factor);
         for (int i = 0; i < 9; ++i) fprintf(stderr, " %s %.1f us |", names[i], (hs[i + 1] - hs[i]) * 0.01);
         fprintf(stderr, " [gram: product %.1f us, radial function %.1f us, padding %.1f us]\n", (hs[11] - hs[1]) * 0.01, (hs[12] - hs[11]) * 0.01,
                 (hs[2] - hs[12]) * 0.01);
@@ -828,6 +837,7 @@ int fit_model(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info *info
     info->max_pitw = NAN;
     const int order = cpd_order(M->kp.kid, M->kp.a, M->kp.b);
     int path = ctx->force_path;
+    int small_nc_used = 0;
     if (path == 0) path = (order <= M->deg + 1 && M->n > M->q) ? (M->q > 0 ? MRBF_PATH_PROJ_CHOL : MRBF_PATH_CHOL) : MRBF_PATH_LU;
     if (M->n < M->q) path = MRBF_PATH_MINNORM;  // under-determined tail: minimum-norm coefficients
     if (path == MRBF_PATH_CHOL && M->q > 0) path = MRBF_PATH_PROJ_CHOL;
@@ -836,7 +846,7 @@ int fit_model(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info *info
         MRBF_TRY(fit_minnorm(ctx, M, Y, info));
     } else if (path != MRBF_PATH_LU && small_fit_applies(ctx, M->n, M->d, M->k, M->q, path)) {
         int not_pd = 0;
-        MRBF_TRY(fit_small(ctx, M, Y, info, &not_pd));
+        MRBF_TRY(fit_small(ctx, M, Y, info, &not_pd, 0, &small_nc_used));
         if (not_pd) {
             info->fallbacks |= MRBF_FB_LU;
             if (ctx->force_path != 0)
@@ -867,6 +877,25 @@ int fit_model(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info *info
     }
     if (path == MRBF_PATH_LU) MRBF_TRY(fit_lu(ctx, M, Y, info));
     if (ctx->residual) MRBF_TRY(fit_check(ctx, M, Y, info));
+    if (ctx->residual && small_nc_used > 1 && path != MRBF_PATH_LU && !(info->rel_residual < 1e-6)) {
+        // tripwire of the workgroup clusters (small.hip): a clustered fit that does not interpolate is repeated with one workgroup
+        // per problem; only if THAT interpolates better was the cluster at fault (an ill-conditioned problem gives the same bits
+        // again), and the context stops using clusters
+        const double res_cluster = info->rel_residual;
+        std::vector<double> wc((size_t)M->n * M->k);
+        MRBF_HIP(ctx, hipMemcpy(wc.data(), M->W, wc.size() * sizeof(double), hipMemcpyDeviceToHost));
+        int not_pd = 0, nc1 = 1;
+        mrbf_fit_info again = *info;
+        MRBF_TRY(fit_small(ctx, M, Y, &again, &not_pd, 1, &nc1));
+        if (!not_pd) {
+            MRBF_TRY(fit_check(ctx, M, Y, &again));
+            std::vector<double> w1(wc.size());
+            MRBF_HIP(ctx, hipMemcpy(w1.data(), M->W, w1.size() * sizeof(double), hipMemcpyDeviceToHost));
+            if (std::memcmp(w1.data(), wc.data(), w1.size() * sizeof(double)) != 0 && (again.rel_residual < res_cluster || !(res_cluster == res_cluster)))
+                ctx->small_nc = 1;
+            *info = again;
+        }
+    }
     info->ms_total = info->ms_gram + info->ms_project + info->ms_factor + info->ms_solve;
     info->slow_launches = ctx->slow_launches;
     return 0;

@@ -272,7 +272,7 @@ def test_small_fit_cluster_failure_repeats_with_one_workgroup():
     good = pkg.Context(0)
     clean = pkg.update_model(cfg, C, Y, ctx=good)
     assert clean.info["path"] == _lib.PATH_PROJ_CHOL and clean.info["rel_residual"] < 1e-12
-    ctx2 = pkg.Context(0)   # its own context: the repeat switches the context to one workgroup per problem for good
+    ctx2 = pkg.Context(0)   # its own context (a barrier that times out three times in a row switches a context to one workgroup per problem)
     ctx2.set_option(_lib.OPT_SPIN_MS, 20)
     ctx2.set_option(_lib.OPT_DEBUG_FAULT, 4)
     t0 = time.perf_counter()
@@ -282,7 +282,7 @@ def test_small_fit_cluster_failure_repeats_with_one_workgroup():
     assert m.info["path"] == _lib.PATH_PROJ_CHOL and m.info["rel_residual"] < 1e-12, m.info
     assert np.array_equal(m.weights, clean.weights)
     ctx2.set_option(_lib.OPT_DEBUG_FAULT, 0)
-    m2 = pkg.update_model(cfg, C, Y, ctx=ctx2)   # one workgroup per problem from now on, same numbers
+    m2 = pkg.update_model(cfg, C, Y, ctx=ctx2)   # clusters again (a time-out says nothing about visibility), same numbers
     assert np.array_equal(m2.weights, clean.weights)
     for x in (m, m2, clean):
         x.free()

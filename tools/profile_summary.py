@@ -89,7 +89,7 @@ def timeline(db, which):
     cols = [c[0] for c in con.execute("select * from kernels limit 1").description]
     qcol = next((c for c in ("stream_id", "queue_id", "queue") if c in cols), None)
     rows = con.execute("select name, start, end%s from kernels order by start" % (", " + qcol if qcol else "")).fetchall()
-    starts = [i for i, r in enumerate(rows) if "gram_w_kernel" in r[0] or "gram_mfma" in r[0]]
+    starts = [i for i, r in enumerate(rows) if "gram_w_kernel" in r[0] or "gram_mfma" in r[0] or "small_mean_kernel" in r[0]]
     if not starts:
         print("no gram kernel in trace; columns:", cols)
         return
@@ -101,7 +101,7 @@ def timeline(db, which):
     t0 = rows[j][1]
     for r in rows[j:]:
         print("%9.1f %8.1f  q=%s  %s" % ((r[1] - t0) / 1e3, (r[2] - r[1]) / 1e3, r[3] if qcol else "-", r[0][:90]))
-        if "potrf_mega_kernel" in r[0]:
+        if "potrf_mega_kernel" in r[0] or (r[1] - t0) > 6e6:
             break
 
 
