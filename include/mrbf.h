@@ -248,6 +248,11 @@ int32_t mrbf_debug_mfma_peak(mrbf_ctx *ctx, int32_t blocks_per_cu, int32_t threa
 int32_t mrbf_debug_mfma_asm(mrbf_ctx *ctx, int32_t variant, int32_t blocks_per_cu, int32_t iters, float *ms, double *tflops,
                             double *cycles_per_mfma);
 int32_t mrbf_debug_dgemm(mrbf_ctx *ctx, int32_t m, int32_t n, int32_t k, float *ms, double *tflops);
+/* Host only (no GPU needed): the job tables of the persistent factorisation for nt block columns / mt block rows and the given
+ * schedule parameters, checked against their invariants.  out[0..3] = panel jobs, bulk jobs, chain jobs, windows; out[4] = checksum;
+ * out[5] = violated invariants (0 when the tables are consistent).  Returns 0, or -(argument index) for a parameter out of range. */
+int32_t mrbf_debug_mega_tables(int32_t nt, int32_t mt, int32_t slack, int32_t slack_chain, int32_t first, int32_t win, int32_t srows,
+                               int32_t half_cols, int64_t *out6);
 
 /* ---- Pascoletti-Serafini descent step with the subproblem solver on the device ----------------------------------------
  * Replaces, for objectives that share ONE grouped RBF model and carry no modelled constraints, the NLopt runs inside

@@ -177,9 +177,23 @@ static int run_small_batch(mrbf_ctx *ctx, const std::vector<int64_t> &idx, const
         L.jac = (pr.m == 0 || !pr.jac_out || is_device_ptr(pr.jac_out)) ? (size_t)-1 : take((size_t)pr.m * k * d);
         L.out = out0 + (size_t)8 * i;
     }
+    // the arena of one launch group is bounded (MRBF_BATCH_ARENA_MB, default 8192): a batch that needs more -- 10^4 problems would ask
+    // for tens of GB in one piece -- is worked off in halves, and an allocation that fails is retried in halves as well instead of
+    // failing every problem of the device
+    const size_t arena_budget = (size_t)(getenv("MRBF_BATCH_ARENA_MB") ? atoll(getenv("MRBF_BATCH_ARENA_MB")) : 8192) << 20;
+    auto halves = [&]() -> int {
+        const std::vector<int64_t> lo(idx.begin(), idx.begin() + P / 2), hi(idx.begin() + P / 2, idx.end());
+        MRBF_TRY(run_small_batch(ctx, lo, problems, results, redo, force_nc));
+        return run_small_batch(ctx, hi, problems, results, redo, force_nc);
+    };
+    if (P > 1 && total * sizeof(double) > arena_budget) return halves();
     double *base;
     int *flags = nullptr;
-    MRBF_TRY(get_buf(ctx, S_SMALL_WS, total, &base));
+    {
+        const int rc = get_buf(ctx, S_SMALL_WS, total, &base);
+        if (rc == MRBF_ENOMEM && P > 1) return halves();
+        if (rc != 0) return rc;
+    }
     flags = reinterpret_cast<int *>(base + out0 + (size_t)8 * P);
     // descriptors: [Prob x P | EvalDesc x 2P | CheckDesc x P | CL_WORDS cluster words x P (zero)] in one device buffer
     const size_t desc_bytes = (size_t)P * (sizeof(smallfit::Prob) + 2 * sizeof(EvalDesc) + sizeof(CheckDesc) + smallfit::CL_WORDS * sizeof(int)) + 256;

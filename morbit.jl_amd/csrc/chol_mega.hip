@@ -940,6 +940,47 @@ __global__ void mega_status_kernel(const unsigned *ctl, int *info, unsigned long
 
 }  // namespace mega
 
+// The job tables of one shape -- pure host code (no GPU call), also reachable through mrbf_debug_mega_tables so that the CPU container
+// can check their invariants, with sanitizers (csrc/Makefile: `make asan`).
+//   chain queue  P(c), S(c+1..c+srows, c) column by column;  panel queue  T(i, half, c) for the other rows;
+//   bulk queues  one per window w: U(i, c, w) for every tile the window reaches through a bulk job (nbulk_updates), as two 64-row
+//                halves when block column c lies within `slack + half_cols` columns behind the window's end.
+static void build_job_tables(int NT, int MT, int slack, int slack_chain, int first, int win, int srows, int half_cols,
+                             std::vector<mega::Job> &pj, std::vector<mega::Job> &bj, std::vector<mega::Job> &cj, std::vector<int> &wqs) {
+    using namespace mega;
+    pj.clear();
+    bj.clear();
+    cj.clear();
+    wqs.clear();
+    for (int c = 0; c < NT; ++c) {
+        cj.push_back(Job{JOB_P, (short)c, (short)c, (short)0});
+        for (int i = c + 1; i < MT; ++i) {
+            if (i <= c + srows)
+                cj.push_back(Job{JOB_S, (short)i, (short)c, (short)0});
+            else
+                for (int h = 0; h < 2; ++h) pj.push_back(Job{JOB_T, (short)i, (short)c, (short)h});
+        }
+    }
+    int nwin_max = 0;  // windows that reach at least one tile through a bulk job
+    for (int c = 0; c < NT; ++c)
+        for (int i = c; i < MT; ++i) nwin_max = std::max(nwin_max, nbulk_updates(i, c, slack, slack_chain, first, win, srows));
+    for (int w = 0; w < nwin_max; ++w) {
+        wqs.push_back((int)bj.size());
+        for (int c = 0; c < NT; ++c)
+            for (int i = c; i < MT; ++i) {
+                if (nbulk_updates(i, c, slack, slack_chain, first, win, srows) <= w) continue;  // this window reaches the tile inside its panel job
+                const bool half = i != c && c < wstart(w + 1, first, win) + slack + half_cols;
+                if (half) {
+                    bj.push_back(Job{JOB_UH, (short)i, (short)c, (short)w});
+                    bj.push_back(Job{JOB_UH, (short)i, (short)c, (short)(w + 256)});
+                } else {
+                    bj.push_back(Job{JOB_U, (short)i, (short)c, (short)w});
+                }
+            }
+    }
+    wqs.push_back((int)bj.size());
+}
+
 // Same contract as potrf_blocked_tall (chol_blocked.hip): on return the leading ncols x ncols block holds L, the rows
 // below hold A_below * L^-T, linv_all (optional) the inverses of the diagonal blocks; *dinfo = 0, the 1-based index of
 // the first non-positive pivot, or a negative code when the launch gave up on a dependency (never observed; every spin is bounded).
@@ -992,36 +1033,9 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
     for (auto &t : ctx->mega_tables)
         if (t.nt == NT && t.mt == MT && t.key == tab_key) tab = &t;
     if (!tab) {
-        std::vector<Job> pj, bj;
-        std::vector<Job> cj;
-        for (int c = 0; c < NT; ++c) {
-            cj.push_back(Job{JOB_P, (short)c, (short)c, (short)0});
-            for (int i = c + 1; i < MT; ++i) {
-                if (i <= c + srows)
-                    cj.push_back(Job{JOB_S, (short)i, (short)c, (short)0});
-                else
-                    for (int h = 0; h < 2; ++h) pj.push_back(Job{JOB_T, (short)i, (short)c, (short)h});
-            }
-        }
+        std::vector<Job> pj, bj, cj;
         std::vector<int> wqs;
-        int nwin_max = 0;  // windows that reach at least one tile through a bulk job
-        for (int c = 0; c < NT; ++c)
-            for (int i = c; i < MT; ++i) nwin_max = std::max(nwin_max, nbulk_updates(i, c, slack, slack_chain, first, win, srows));
-        for (int w = 0; w < nwin_max; ++w) {
-            wqs.push_back((int)bj.size());
-            for (int c = 0; c < NT; ++c)
-                for (int i = c; i < MT; ++i) {
-                    if (nbulk_updates(i, c, slack, slack_chain, first, win, srows) <= w) continue;  // this window reaches the tile inside its panel job
-                    const bool half = i != c && c < wstart(w + 1, first, win) + slack + ctx->mega_half_cols;
-                    if (half) {
-                        bj.push_back(Job{JOB_UH, (short)i, (short)c, (short)w});
-                        bj.push_back(Job{JOB_UH, (short)i, (short)c, (short)(w + 256)});
-                    } else {
-                        bj.push_back(Job{JOB_U, (short)i, (short)c, (short)w});
-                    }
-                }
-        }
-        wqs.push_back((int)bj.size());
+        build_job_tables(NT, MT, slack, slack_chain, first, win, srows, ctx->mega_half_cols, pj, bj, cj, wqs);
         if (ctx->mega_tables.size() >= 8) {  // evict the least recently used set (nothing on the stream may still read it)
             MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
             size_t lru = 0;
@@ -1215,3 +1229,70 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
 }
 
 }  // namespace mrbf
+
+// Host-only: builds the job tables of a shape and checks their invariants.  out[0..3] = panel / bulk / chain jobs, windows;
+// out[4] = order-dependent checksum of all jobs; out[5] = violated invariants (0 for every valid parameter set):
+//   every tile (i, c), i >= c, is finished by exactly one chain job or by exactly two panel halves; it receives every window
+//   w < nbulk_updates(i, c) exactly once (one full job or both halves) and no other; every window only updates tiles of block columns
+//   behind its own last panel; a window's queue lists its jobs by ascending block column.
+extern "C" int32_t mrbf_debug_mega_tables(int32_t nt, int32_t mt, int32_t slack, int32_t slack_chain, int32_t first, int32_t win, int32_t srows,
+                                          int32_t half_cols, int64_t *out) {
+    using namespace mrbf;
+    using namespace mrbf::mega;
+    if (nt < 1 || mt < nt || mt > 32000) return -1;
+    if (slack < 1 || slack_chain < slack || win < 1 || first < 1 || first > win || srows < 0 || half_cols < 0) return -3;
+    if (!out) return -9;
+    std::vector<Job> pj, bj, cj;
+    std::vector<int> wqs;
+    build_job_tables(nt, mt, slack, slack_chain, first, win, srows, half_cols, pj, bj, cj, wqs);
+    int64_t bad = 0;
+    std::vector<int> fin((size_t)mt * nt, 0);
+    for (const Job &j : cj) {
+        if (j.i < j.c || j.i >= mt || j.c >= nt) {
+            ++bad;
+            continue;
+        }
+        fin[(size_t)j.i * nt + j.c] += 2;
+        if (j.kind == JOB_P ? j.i != j.c : (j.kind != JOB_S || j.i <= j.c || j.i > j.c + srows)) ++bad;
+    }
+    for (const Job &j : pj) {
+        if (j.kind != JOB_T || j.i <= j.c + srows || j.i >= mt || j.c >= nt || (j.w != 0 && j.w != 1)) {
+            ++bad;
+            continue;
+        }
+        fin[(size_t)j.i * nt + j.c] += 1;
+    }
+    for (int c = 0; c < nt; ++c)
+        for (int i = 0; i < mt; ++i) bad += fin[(size_t)i * nt + c] != (i >= c ? 2 : 0);
+    const int nwin = (int)wqs.size() - 1;
+    std::vector<int> upd((size_t)mt * nt, 0);
+    for (int w = 0; w < nwin; ++w) {
+        std::fill(upd.begin(), upd.end(), 0);
+        int last_c = -1;
+        for (int q = wqs[w]; q < wqs[w + 1]; ++q) {
+            const Job &j = bj[q];
+            if (j.i < j.c || j.i >= mt || j.c >= nt || (j.w & 255) != w || (j.kind != JOB_U && j.kind != JOB_UH)) {
+                ++bad;
+                continue;
+            }
+            if (j.c < last_c) ++bad;  // ascending block columns inside a queue
+            last_c = j.c;
+            if (j.c < wstart(w + 1, first, win)) ++bad;  // a window never reaches a block column it still belongs to
+            upd[(size_t)j.i * nt + j.c] += j.kind == JOB_U ? 2 : 1;
+        }
+        for (int c = 0; c < nt; ++c)
+            for (int i = c; i < mt; ++i) bad += upd[(size_t)i * nt + c] != (w < nbulk_updates(i, c, slack, slack_chain, first, win, srows) ? 2 : 0);
+    }
+    for (size_t w = 0; w + 1 < wqs.size(); ++w) bad += wqs[w] > wqs[w + 1];
+    int64_t sum = 0;
+    int64_t pos = 1;
+    for (const std::vector<Job> *v : {&pj, &bj, &cj})
+        for (const Job &j : *v) sum += (pos++) * (int64_t)(1 + j.kind + 7 * j.i + 131 * j.c + 1009 * j.w);
+    out[0] = (int64_t)pj.size();
+    out[1] = (int64_t)bj.size();
+    out[2] = (int64_t)cj.size();
+    out[3] = nwin;
+    out[4] = sum;
+    out[5] = bad;
+    return 0;
+}

@@ -35,6 +35,9 @@ int32_t mrbf_dispatch_affine(int64_t n_candidates, int32_t d) {
 int32_t mrbf_dispatch_round4(int64_t n0, int32_t d, int32_t poly_deg, int64_t n_candidates) {
     const int q = mrbf::poly_dim(d, poly_deg);
     if (n_candidates < 1 || n0 < 1 || n0 > 8192) return MRBF_DISPATCH_REFERENCE;
+    // the limits of mrbf_round4 itself (round4.hip: d <= 1024, at most 30 000 candidates -- four candidate x candidate matrices live on
+    // the device): a database box beyond them takes the reference's loop, it does not raise
+    if (d < 1 || d > 1024 || n_candidates > 30000) return MRBF_DISPATCH_REFERENCE;
     return n0 >= q ? MRBF_DISPATCH_DEVICE : MRBF_DISPATCH_REFERENCE;
 }
 
@@ -50,7 +53,8 @@ int32_t mrbf_dispatch_fit(int64_t n_training, int64_t state_n0, int32_t state_q,
 
 int32_t mrbf_dispatch_after(int32_t entry, int32_t rc) {
     switch (entry) {
-        case MRBF_ENTRY_ROUND4: return rc == -2 || rc == MRBF_ESINGULAR;
+        // (-3 / -5: dimension / candidate count beyond the device path; MRBF_ENOMEM: the candidate matrices did not fit)
+        case MRBF_ENTRY_ROUND4: return rc == -2 || rc == -3 || rc == -5 || rc == MRBF_ESINGULAR || rc == MRBF_ENOMEM;
         case MRBF_ENTRY_FIT_FROM_ROUND4: return rc == -2 || rc == MRBF_ESINGULAR || rc == MRBF_ENOTPD;
         case MRBF_ENTRY_PS_STEP: return rc == -2;
         default: return 0;

@@ -21,7 +21,7 @@ struct Prob {
     int mean_given;                          // the centroid already lies in `mean` (small_mean_kernel, same arithmetic): the batch path centres its
                                              // queries beside the fit instead of after it
     unsigned long long spin_ticks;           // bound of a cluster barrier's spin (wall_clock64 ticks)
-    int fault;                               // test hook (MRBF_OPT_DEBUG_FAULT bit 4): member 1 leaves before the third barrier
+    int fault;                               // test hook (MRBF_OPT_DEBUG_FAULT bit 2 (value 4)): member 1 leaves before the third barrier
 };
 
 constexpr int CL_WORDS = 24;   // arrivals, failure word, XCD of up to 16 members

@@ -50,6 +50,11 @@ def test_decision_table(lib):
     # return codes that mean "take the reference method", not an error
     assert lib.mrbf_dispatch_after(_lib.ENTRY_ROUND4, -2) == 1 and lib.mrbf_dispatch_after(_lib.ENTRY_ROUND4, _lib.MRBF_ESINGULAR) == 1
     assert lib.mrbf_dispatch_after(_lib.ENTRY_ROUND4, _lib.MRBF_EHIP) == 0 and lib.mrbf_dispatch_after(_lib.ENTRY_ROUND4, 0) == 0
+    # the size limits of mrbf_round4 itself never raise in a binding: asked beforehand they say "reference", met afterwards too
+    assert lib.mrbf_dispatch_round4(70, 64, 1, 30000) == D and lib.mrbf_dispatch_round4(70, 64, 1, 30001) == R
+    assert lib.mrbf_dispatch_round4(2000, 1024, 1, 100) == D and lib.mrbf_dispatch_round4(2000, 1025, 1, 100) == R
+    for rc in (-3, -5, _lib.MRBF_ENOMEM):
+        assert lib.mrbf_dispatch_after(_lib.ENTRY_ROUND4, rc) == 1
     assert lib.mrbf_dispatch_after(_lib.ENTRY_FIT_FROM_ROUND4, _lib.MRBF_ENOTPD) == 1
     assert lib.mrbf_dispatch_after(_lib.ENTRY_PS_STEP, -2) == 1 and lib.mrbf_dispatch_after(_lib.ENTRY_PS_STEP, -4) == 0
     assert lib.mrbf_dispatch_after(_lib.ENTRY_BACKTRACK, -2) == 0
@@ -272,3 +277,39 @@ def test_affine_filter_routing(monkeypatch):
     big = [x + 0.1 * rng.standard_normal(d) for _ in range(9000)]
     got = sampling.AffinelyIndependentPointFilter(x, big, pivot_val=1e-3).collect()
     assert len(got) == d and len(calls) == d - 1 and calls[0] == (9000, d)                                           # device scan
+
+
+def test_mega_job_tables_are_consistent():
+    """The job tables of the persistent factorisation (chol_mega.hip: build_job_tables) are pure host code: for the shapes and schedule
+    parameters the library picks by size -- and for degenerate ones -- every tile is finished exactly once, receives exactly the windows
+    nbulk_updates promises, queues are ordered.  (Runs under ASan / UBSan with `make -C morbit.jl_amd/csrc asan`.)"""
+    import ctypes
+
+    from morbit.jl_amd import _lib
+
+    lib = _lib.load()
+    out = (ctypes.c_int64 * 6)()
+    seen = {}
+    # (nt, mt, slack, slack_chain, first, win, srows, half_cols): potrf_mega_tall's choices for n = 256 .. 16384 (+1 row tile of
+    # right-hand sides), and corner cases: one block column, more streamed rows than rows, no slack beyond one
+    cases = [(2, 3, 3, 6, 1, 4, 5, 0), (16, 17, 3, 6, 1, 4, 5, 0), (48, 49, 3, 6, 1, 4, 5, 0), (64, 65, 3, 7, 1, 6, 3, 0), (96, 97, 3, 7, 1, 8, 3, 0),
+             (128, 129, 3, 6, 1, 8, 2, 0), (1, 1, 1, 1, 1, 1, 0, 0), (1, 2, 3, 6, 1, 4, 5, 0), (5, 9, 1, 1, 1, 1, 7, 2), (33, 33, 2, 2, 4, 4, 0, 3),
+             (20, 24, 3, 9, 2, 5, 2, 1)]
+    for c in cases:
+        assert lib.mrbf_debug_mega_tables(*c, out) == 0, c
+        npanel, nbulk, nchain, nwin, checksum, bad = list(out)
+        assert bad == 0, (c, list(out))
+        nt, mt, srows = c[0], c[1], c[6]
+        tiles = sum(mt - cc for cc in range(nt))
+        chain_tiles = sum(1 + min(srows, mt - cc - 1) for cc in range(nt))
+        assert nchain == chain_tiles and npanel == 2 * (tiles - chain_tiles), (c, list(out))
+        seen[c] = checksum
+    # deterministic
+    for c in cases[:3]:
+        assert lib.mrbf_debug_mega_tables(*c, out) == 0 and out[4] == seen[c]
+    # refused parameter sets
+    assert lib.mrbf_debug_mega_tables(0, 1, 3, 6, 1, 4, 5, 0, out) == -1
+    assert lib.mrbf_debug_mega_tables(4, 3, 3, 6, 1, 4, 5, 0, out) == -1
+    assert lib.mrbf_debug_mega_tables(4, 5, 3, 2, 1, 4, 5, 0, out) == -3
+    assert lib.mrbf_debug_mega_tables(4, 5, 3, 6, 5, 4, 5, 0, out) == -3
+    assert lib.mrbf_debug_mega_tables(4, 5, 3, 6, 1, 4, 5, 0, None) == -9

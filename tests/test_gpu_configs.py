@@ -106,6 +106,16 @@ def test_c4_many_start_batch(ctx):
             fd = _fd_jacobian(mod, X[t])
             assert np.abs(fd - J[t]).max() < 1e-6 * max(1.0, np.abs(J[t]).max()), (p, t, np.abs(fd - J[t]).max())
         mod.free()
+    # a batch whose arena would exceed the budget is worked off in halves (here 16 starts under a 64 MB budget: groups of four, i.e.
+    # clusters of eight workgroups instead of four): the same numbers, bit for bit
+    os.environ["MRBF_BATCH_ARENA_MB"] = "64"
+    try:
+        res2, Ws2, Ls2, Vs2, _ = _batch(problems[:16], kid, a, b, 1)
+    finally:
+        del os.environ["MRBF_BATCH_ARENA_MB"]
+    for p in range(16):
+        assert res2[p].status == 0 and res2[p].fit.fallbacks == 0
+        assert np.array_equal(Ws2[p], Ws[p]) and np.array_equal(Ls2[p], Ls[p]) and np.array_equal(Vs2[p], Vs[p])
     # one start against the CPU oracle (LU of the saddle system): north-star tolerances outright (cond ~ 2e3)
     C, Y, X = problems[0]
     ref = orc.fit(C, Y, kid, a, b, 1)
