@@ -169,6 +169,105 @@ __global__ __launch_bounds__(SEL_THREADS) void select_block_kernel(const double 
         acc[maxacc] = nacc;
     }
 }
+// The same decisions for q <= 128 with the inverse Gram matrix of the tail IN REGISTERS.  The kernel above is a chain of global-memory
+// round trips per candidate -- pi from memory, 65 dependent column loads of Ginv for Ginv pi, the Sherman-Morrison update written
+// back through memory behind a __threadfence, six workgroup barriers: 13.7 us per candidate, 30 of the 43 ms of a round 4 with 10^4
+// candidates at d = 64 (profiles/r04_round4_kernel_stats.csv) -- although the arithmetic per candidate is 4 q^2 + SB^2 flops.  Here
+// thread (lane, wave) owns Ginv[t][u] for t = lane + 64 a, u = wave + 16 b (at most 2 x 8 entries), the product Ginv pi is formed as
+// 16 partial sums per row through LDS, every thread takes the accept / reject decision itself from the same sums (same order: same
+// result), the factor column is read off S's column j, pi of the next candidate is fetched one candidate ahead: three barriers and
+// no global round trip per candidate.  Same arithmetic per entry as above except for the order of the q-term sums.
+template <int NA, int NB_>
+__global__ __launch_bounds__(SEL_THREADS) void select_block_reg_kernel(const double *__restrict__ Sg, int b, int64_t i0, int n0, int q,
+                                                                       int max_points, int maxacc, double thr, const double *__restrict__ Prow,
+                                                                       double *__restrict__ Ginv, int *__restrict__ acc, int *__restrict__ cnt,
+                                                                       double *__restrict__ Lblk, int *__restrict__ blkidx) {
+    extern __shared__ double smem[];  // S[SB * SB] | pi[q] | g[q] | part[16 * q] | red[16]
+    double *S = smem, *pi = S + SB * SB, *g = pi + q, *part = g + q, *red = part + 16 * q;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int e = tid; e < SB * SB; e += SEL_THREADS) S[e] = Sg[e];
+    double G[NA][NB_];
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int bb = 0; bb < NB_; ++bb) {
+            const int t = lane + 64 * a, u = wave + 16 * bb;
+            G[a][bb] = (t < q && u < q) ? Ginv[t + (int64_t)u * q] : 0.0;
+        }
+    int nacc = cnt[0], nblk = 0;
+    double pnext = (tid < q && b > 0) ? Prow[i0 * q + tid] : 0.0;
+    __syncthreads();
+    for (int j = 0; j < b; ++j) {
+        if (n0 + nacc >= max_points || nacc >= maxacc) break;
+        if (tid < q) pi[tid] = pnext;
+        if (tid < q && j + 1 < b) pnext = Prow[(i0 + j + 1) * q + tid];  // in flight under this candidate's work
+        __syncthreads();
+        // partial sums of Ginv pi over this wave's columns
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+            const int t = lane + 64 * a;
+            double sp = 0.0;
+#pragma unroll
+            for (int bb = 0; bb < NB_; ++bb) {
+                const int u = wave + 16 * bb;
+                if (u < q) sp = fma(G[a][bb], pi[u], sp);
+            }
+            if (t < q) part[wave * q + t] = sp;
+        }
+        __syncthreads();
+        double pp = 0.0;
+        if (tid < q) {
+            double sg = 0.0;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) sg += part[w * q + tid];
+            g[tid] = sg;
+            pp = pi[tid] * sg;
+        }
+        for (int off = 32; off > 0; off >>= 1) pp += __shfl_xor(pp, off);
+        if (lane == 0) red[wave] = pp;
+        __syncthreads();
+        double ph = 1.0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) ph += red[w];   // every thread: the same sum in the same order
+        const double pk = S[j + j * SB];
+        const double tau2 = pk / ph;
+        const bool accept = pk > 0.0 && tau2 > thr && tau2 < 1e300;  // tau^2 > (theta^2)^2, RbfModel.jl:370, :452 (NaN fails)
+        if (!accept) continue;
+        const double rs = 1.0 / sqrt(pk);
+        for (int r = tid; r < SB; r += SEL_THREADS) Lblk[r + nblk * SB] = (r > j && r < b) ? S[r + j * SB] * rs : (r == j ? pk * rs : 0.0);
+        for (int e = tid; e < SB * SB; e += SEL_THREADS) {  // rank-1 update of the trailing complement (lower part); column j is not touched
+            const int r = e % SB, c = e / SB;
+            if (c > j && r >= c && r < b) S[e] = fma(-(S[r + j * SB] * rs), S[c + j * SB] * rs, S[e]);
+        }
+        // Ginv <- Ginv - g g' / s_H   (Sherman-Morrison for G + pi pi')
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int bb = 0; bb < NB_; ++bb) {
+                const int t = lane + 64 * a, u = wave + 16 * bb;
+                if (t < q && u < q) G[a][bb] -= g[t] * g[u] / ph;
+            }
+        if (tid == 0) {
+            acc[nacc] = (int)(i0 + j);
+            blkidx[nblk] = j;
+        }
+        ++nacc;
+        ++nblk;
+    }
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int bb = 0; bb < NB_; ++bb) {
+            const int t = lane + 64 * a, u = wave + 16 * bb;
+            if (t < q && u < q) Ginv[t + (int64_t)u * q] = G[a][bb];
+        }
+    if (tid == 0) {
+        cnt[0] = nacc;
+        cnt[1] = nblk;
+        acc[maxacc] = nacc;
+    }
+}
+
 // rows nacc0 .. nacc0 + nblk - 1 of the accepted factor: [ R(:, j_a)' | in-block factor entries | 0 ]
 __global__ void append_rows_kernel(const double *__restrict__ R, int ldr, int nacc0, const double *__restrict__ Lblk, const int *__restrict__ blkidx,
                                    const int *__restrict__ cnt, double *__restrict__ L, int ldl) {
@@ -354,6 +453,14 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
         const double thr = (theta_pivot_cholesky * theta_pivot_cholesky) * (theta_pivot_cholesky * theta_pivot_cholesky);
         const size_t shm = ((size_t)SB * SB + SB + 2 * (size_t)std::max(q, 1) + SEL_THREADS / 64) * sizeof(double);
         MRBF_HIP(ctx, hipFuncSetAttribute((const void *)select_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        // the register variant of the decision kernel: q <= 80 (2 x 5 entries of Ginv per thread) or q <= 128 (2 x 8); needs q >= 1
+        static const int sel_env = getenv("MRBF_R4_SELECT") ? atoi(getenv("MRBF_R4_SELECT")) : 1;
+        const int fast_sel = (sel_env && q >= 1 && q <= 80) ? 1 : ((sel_env && q >= 1 && q <= 128) ? 2 : 0);
+        const size_t shm_reg = ((size_t)SB * SB + 2 * (size_t)std::max(q, 1) + 16 * (size_t)std::max(q, 1) + 16) * sizeof(double);
+        if (fast_sel == 1)
+            MRBF_HIP(ctx, hipFuncSetAttribute((const void *)select_block_reg_kernel<2, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_reg));
+        if (fast_sel == 2)
+            MRBF_HIP(ctx, hipFuncSetAttribute((const void *)select_block_reg_kernel<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_reg));
         double *Rb, *Sb, *Lblk;
         int *cnt, *blkidx;
         MRBF_TRY(get_buf(ctx, S_Q1, (size_t)maxacc * SB, &Rb));          // R = L_acc^-1 K[acc, block]
@@ -375,8 +482,15 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
                 MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, bsz, bsz, nacc, &mone, Rb, maxacc, Rb, maxacc,
                                              &one, Sb, SB));
             }
-            hipLaunchKernelGGL(select_block_kernel, dim3(1), dim3(SEL_THREADS), shm, s, Sb, bsz, i0, (int)n0, q, (int)max_points, maxacc, thr, st->Prow,
-                               st->Ginv, st->acc, cnt, Lblk, blkidx);
+            if (fast_sel == 1)
+                hipLaunchKernelGGL((select_block_reg_kernel<2, 5>), dim3(1), dim3(SEL_THREADS), shm_reg, s, Sb, bsz, i0, (int)n0, q, (int)max_points, maxacc,
+                                   thr, st->Prow, st->Ginv, st->acc, cnt, Lblk, blkidx);
+            else if (fast_sel == 2)
+                hipLaunchKernelGGL((select_block_reg_kernel<2, 8>), dim3(1), dim3(SEL_THREADS), shm_reg, s, Sb, bsz, i0, (int)n0, q, (int)max_points, maxacc,
+                                   thr, st->Prow, st->Ginv, st->acc, cnt, Lblk, blkidx);
+            else
+                hipLaunchKernelGGL(select_block_kernel, dim3(1), dim3(SEL_THREADS), shm, s, Sb, bsz, i0, (int)n0, q, (int)max_points, maxacc, thr, st->Prow,
+                                   st->Ginv, st->acc, cnt, Lblk, blkidx);
             hipLaunchKernelGGL(append_rows_kernel, dim3(nb((int64_t)SB * (nacc + SB))), dim3(256), 0, s, Rb, maxacc, nacc, Lblk, blkidx, cnt, st->LK, maxacc);
             int hc[2] = {0, 0};
             MRBF_HIP(ctx, hipMemcpyAsync(hc, cnt, sizeof(hc), hipMemcpyDeviceToHost, s));
