@@ -16,7 +16,7 @@ import sys
 PHASES = [
     ("fit", ("small_fit_kernel",)),
     ("check", ("batch_check_kernel",)),
-    ("gram", ("gram_mfma", "gram_diff_kernel")),
+    ("gram", ("gram_mfma", "gram_diff_kernel", "gram_w_kernel")),
     ("factor", ("potrf_mega_kernel", "mega_status_kernel", "chol_update_kernel<128, 0>", "chol_update_kernel<64", "chol_diag")),
     ("eval", ("eval_fused_kernel", "eval_fused_split_kernel", "eval_combine_kernel", "eval_rows_kernel", "jac_assemble_kernel", "center_pad")),
     ("solve", ("chol_backsolve_kernel", "backsolve_persistent_kernel", "premul_kernel", "get_rhs_rows", "scatter_solution", "finish_lambda", "residual_kernel", "max_abs")),
