@@ -43,6 +43,7 @@
 
 #include "chol_diag_core.hpp"
 #include "common.hpp"
+#include "mega_gemm.hpp"
 
 namespace mrbf {
 
@@ -51,7 +52,6 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 
 namespace mega {
 
-constexpr int NB = 128, BK = 16, LDS_LD = NB + 16;  // (2*LD) % 64 == 32: k and k+1 rows of a chunk hit disjoint banks
 constexpr int WIN_DEFAULT = 4;                      // block columns per window (Args::win)
 
 enum { JOB_U = 0, JOB_T = 1, JOB_P = 2, JOB_S = 3, JOB_UH = 4 };  // UH: 64-row half of a bulk update (w + 256 * half)
@@ -71,6 +71,15 @@ __host__ __device__ inline int nbulk_updates(int i, int c, int slack, int slack_
     return t < first ? 0 : (t - first) / win + 1;
 }
 
+// Edge regime: the first `head` and the last block columns (from `tail_c0` on) are chain-bound whatever the matrix size (the machine
+// is still filling / already emptying), the middle is throughput-bound.  Streamed rows below the diagonal and the diagonal job's
+// stream depth are therefore chosen per block column: the chain-bound values at the edges, the size's own in between.
+struct Edge {
+    int head, tail_c0, srows_edge, pstream_edge;
+};
+__host__ __device__ inline bool edge_col(int c, const Edge &e) { return c < e.head || c >= e.tail_c0; }
+__host__ __device__ inline int srows_at(int c, int srows, const Edge &e) { return edge_col(c, e) ? e.srows_edge : srows; }
+
 struct Args {
     double *A;
     int64_t lda;
@@ -83,8 +92,8 @@ struct Args {
     int npanel;
     const Job *bjobs;
     int nbulk;
-    const int *wq_start;  // [nwin + 1] first job of each window's queue in bjobs
-    unsigned *wq_head;    // [nwin] x QSTRIDE claimed jobs per window
+    const int *wq_start;  // [2 nwin + 1] first job of each queue in bjobs: queues [0, nwin) the windows' jobs on ordinary tiles, [nwin, 2 nwin) on chain tiles
+    unsigned *wq_head;    // [2 nwin] x QSTRIDE claimed jobs per queue
     double *itg;          // NT x 8 x 256: 16 x 16 leaf inverses of every diagonal block (streamed panel solves)
     unsigned *dprog;      // [NT] x QSTRIDE: 16-column panels of diagonal block c that are published
     unsigned *sprog;      // [srows][NT] x QSTRIDE: 16-column panels of tile (c + 1 + k, c) that are published
@@ -102,6 +111,11 @@ struct Args {
     int xchain;      // chain workgroups on one XCD (blocks 0, 8, 16, ...)
     int quiet_tail;  // a chain workgroup's CU partner pauses only while at most this many block columns are left
     int slack, slack_chain, first, win, wbias, srows;
+    Edge edge;
+    int cboost;       // the chain tiles' window jobs compete as if they lay `cboost` block columns further left
+    int head_job1;    // first chain job behind the head regime
+    int nreserve;     // workgroups [nchain, nchain + nreserve) of the chain's placement class: general workers until the chain queue
+    int reserve_job0;  // reaches job `reserve_job0` (the tail), chain workgroups from then on
     unsigned long long *jlog;   // diagnostic launches only: 8 words per job (meta, claim, 5 stage stamps, end), jlog[0] = count
     int jlog_cap;
     int pstream;                // panels the diagonal job takes in step from streamed producers (1 or 2)
@@ -111,20 +125,20 @@ struct Args {
 
 struct Shared {
     union {
-        double gemm[2 * BK * LDS_LD];
+        double gemm[4 * 2 * 8 * LDS_LD];  // gemm_acc's ring of 8-column stages of both operands (three used)
         diagcore::DiagV6Shared diag;
     } u;
     int ok;
     int jkind, jidx;
     unsigned long long *jrec;  // this job's log record (or null)
-    int wlo;  // first window whose queue still holds jobs (monotone, per workgroup)
+    int wlo;   // first window whose queue still holds jobs (monotone, per workgroup)
+    int cwlo;  // the same for the chain tiles' queues
     int mycu;
 };
 
 // every shared word and tile is accessed through explicit global-address-space pointers: global_ instructions, never flat_
 typedef __attribute__((address_space(1))) unsigned gu32;
 typedef __attribute__((address_space(1))) double gf64;
-typedef __attribute__((address_space(1))) v2d gv2d;
 __device__ __forceinline__ unsigned ldf(const unsigned *p) {
     return __hip_atomic_load((const gu32 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -230,81 +244,6 @@ __device__ __forceinline__ unsigned wg_wait_val2(Shared &sh, const Args &a, cons
 __device__ __forceinline__ void wg_drain() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-}
-
-// acc(j-part, i-part) += sum_k Bp(j, k) * Ap(i, k) over K columns (multiple of 16): the LDS-tiled MFMA loop of
-// chol_update_kernel<TM, *> (16-column chunks staged global -> registers -> LDS, next chunk's loads in flight under
-// the current chunk's MFMAs).  Ag / Bg point at row 0 of the TM-row / 128-row operand tiles, column 0 of the range.
-// TM = 128: wave (w >> 1, w & 1) owns a 64 x 64 quadrant; TM = 64: wave w owns all 64 rows of columns 32w .. 32w+31.
-template <int TM>
-__device__ __forceinline__ void gemm_acc(const double *__restrict__ Ag, int64_t lda, const double *__restrict__ Bg, int64_t ldb, int K,
-                                         v4d (&acc)[TM / 32][4], double *smem) {
-    constexpr int NJ = TM / 32;              // 16-wide j tiles per wave
-    constexpr int AL = TM / 32;              // v2d loads per thread per A chunk
-    constexpr int AKS = (TM == 128) ? 4 : 8;  // k stride between a thread's A loads
-    // global -> register prefetch depth in chunks.  The 128-row loop is MFMA-bound with one chunk in flight (and has no
-    // registers to spare); the 64-row loop has half the MFMAs per chunk and was bound by the ~2 us load latency.
-    constexpr int PF = (TM == 128) ? 1 : 2;
-    double *As = smem;
-    double *Bs = smem + BK * LDS_LD;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l15 = lane & 15, l4 = lane >> 4;
-    const int ioff = (TM == 128) ? (wave >> 1) * 64 : 0;
-    const int joff = (TM == 128) ? (wave & 1) * 64 : wave * 32;
-    const int a_i2 = (TM == 128) ? (tid & 63) * 2 : (tid & 31) * 2;
-    const int a_k0 = (TM == 128) ? (tid >> 6) : (tid >> 5);
-    const int b_i2 = (tid & 63) * 2, b_k0 = tid >> 6;
-    const double *Ap = Ag + a_i2 + (int64_t)a_k0 * lda;
-    const double *Bp = Bg + b_i2 + (int64_t)b_k0 * ldb;
-    v2d ra[PF][AL], rb[PF][4];
-    const int nkc = K / BK;
-#pragma unroll
-    for (int f = 0; f < PF; ++f) {
-        if (f < nkc) {
-            const int64_t ko = (int64_t)f * BK;
-#pragma unroll
-            for (int u = 0; u < AL; ++u) ra[f][u] = *(const gv2d *)(Ap + (ko + AKS * u) * lda);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) rb[f][u] = *(const gv2d *)(Bp + (ko + 4 * u) * ldb);
-        }
-    }
-#pragma unroll 1
-    for (int kc0 = 0; kc0 < nkc; kc0 += PF) {
-#pragma unroll
-        for (int f = 0; f < PF; ++f) {
-            const int kc = kc0 + f;
-            if (kc < nkc) {
-                __syncthreads();
-#pragma unroll
-                for (int u = 0; u < AL; ++u) *(v2d *)&As[(a_k0 + AKS * u) * LDS_LD + a_i2] = ra[f][u];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) *(v2d *)&Bs[(b_k0 + 4 * u) * LDS_LD + b_i2] = rb[f][u];
-                __syncthreads();
-                if (kc + PF < nkc) {
-                    const int64_t ko = (int64_t)(kc + PF) * BK;
-#pragma unroll
-                    for (int u = 0; u < AL; ++u) ra[f][u] = *(const gv2d *)(Ap + (ko + AKS * u) * lda);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) rb[f][u] = *(const gv2d *)(Bp + (ko + 4 * u) * ldb);
-                }
-#pragma unroll
-                for (int kk = 0; kk < BK / 4; ++kk) {
-                    double av[4], bv[NJ];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) av[i] = As[(kk * 4 + l4) * LDS_LD + ioff + i * 16 + l15];
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) bv[j] = Bs[(kk * 4 + l4) * LDS_LD + joff + j * 16 + l15];
-                    // D[row = j][col = i]: the lane index (l & 15) runs along i, contiguous in the column-major tile
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            acc[j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[j], av[i], acc[j][i], 0, 0, 0);
-                }
-            }
-        }
-    }
-    __syncthreads();  // the LDS chunk buffers are free again (the caller may overlay them)
 }
 
 template <int NJ>
@@ -419,7 +358,7 @@ __device__ __forceinline__ bool window_part(const Args &a, Shared &sh, int i, in
                                                       unsigned long long *tr) {
     const int64_t lda = uni64(a.lda);
     double *const A = uni_ptr(a.A);
-    const int wc = nbulk_updates(i, c, a.slack, a.slack_chain, a.first, a.win, a.srows), p0 = wstart(wc, a.first, a.win);
+    const int wc = nbulk_updates(i, c, a.slack, a.slack_chain, a.first, a.win, srows_at(c, a.srows, a.edge)), p0 = wstart(wc, a.first, a.win);
     const unsigned *uc = a.ucnt + (size_t)i * a.NT + c;
     if (p0 >= pend) return wg_wait(sh, a, uc, (unsigned)(2 * wc), nullptr, 0, nullptr, 0, 0x200u);
     v4d acc[TM / 32][4];
@@ -495,7 +434,7 @@ __device__ __attribute__((noinline)) bool run_stream(const Args &a, Shared &sh, 
         const double *Lr = A + (int64_t)i * NB + (int64_t)(c - 1) * NB * lda;
         const double *Lc = A + (int64_t)c * NB + (int64_t)(c - 1) * NB * lda;
         const unsigned *fc = a.sprog + (size_t)(c - 1) * QSTRIDE;
-        const bool row_streamed = i - c < a.srows;
+        const bool row_streamed = i - (c - 1) <= srows_at(c - 1, a.srows, a.edge);  // was tile (i, c-1) a streamed one?
         const unsigned *fr = a.sprog + ((size_t)(i - c) * a.NT + (c - 1)) * QSTRIDE;
         if (!row_streamed && !wg_wait(sh, a, a.tdone + (size_t)i * a.NT + (c - 1), 2u, nullptr, 0, nullptr, 0, 0x520u)) return false;
         unsigned got = 0;
@@ -606,7 +545,8 @@ __device__ __attribute__((noinline)) bool run_diag(const Args &a, Shared &sh, co
     // (c, c-2) -- final a few us after P(c-2) -- still went through a 128^3 GEMM, the read-modify-write and eight catch-up folds
     // (46 us) between the end of S(c, c-2) and the start of P(c), which paced the chain at 38 us per column once the diagonal
     // block itself took 27.  (On large matrices the early read-modify-write would wait for bulk updates: one there.)
-    const int pstream = c < a.pstream ? c : a.pstream;
+    const int pstream_c = edge_col(c, a.edge) ? a.edge.pstream_edge : a.pstream;
+    const int pstream = c < pstream_c ? c : pstream_c;
     if (!window_part<128>(a, sh, c, c, c - pstream, 0, tr)) return false;
     MEGA_STAMP(1);
     JLOG(4);
@@ -691,7 +631,9 @@ __device__ __attribute__((noinline)) bool run_panel(const Args &a, Shared &sh, c
     JLOG(5);
     v4d acc[2][4];
     zero_acc(acc);
-    gemm_acc<64>(C, lda, Linv, NB, NB, acc, sh.u.gemm);  // every wave's loads of X are complete behind the loop's last barrier
+    // (the register-staged loop: X was written by this workgroup's plain stores a moment ago, and LDS-DMA loads of it came back
+    //  wrong -- every other operand of gemm_acc is another workgroup's write-through data behind an acquire, or older; r04)
+    gemm_acc_v1<64>(C, lda, Linv, NB, NB, acc, sh.u.gemm);  // every wave's loads of X are complete behind the loop's last barrier
     store_tile<64, false, false, true>(C, lda, acc);
     wg_drain();
     if (a.fault && i == a.MT - 1 && c == 0 && roff == 0) return true;  // test hook: this half tile is never published
@@ -721,15 +663,22 @@ __device__ __forceinline__ void jlog_end(Shared &sh) {
     if (sh.jrec && threadIdx.x == 0) sh.jrec[7] = wall_clock64();
 }
 
-// wave 0: among the heads of the window queues [wlo, wlo + 64) find the ready job with the smallest block column and
-// claim the next job of that queue.  Returns the job index in bjobs, -1 (nothing ready now) or -2 (every queue drained).
+// wave 0: among the heads of the window queues find the ready job with the smallest block column and claim the next job of that
+// queue.  Lanes 0..31 look at the ordinary queues of the windows [wlo, wlo + 32), lanes 32..63 at the chain tiles' queues of the
+// windows [cwlo, cwlo + 32).  Returns the job index in bjobs, -1 (nothing ready now) or -2 (every queue drained).
+// The chain tiles (diagonal tile and the streamed tiles below it) have queues of their own because their window updates are
+// serial per tile (each a K = 128 win GEMM of ~150-200 us, as long as `win` chain steps): taken in column order with everything
+// else they reached a tile only when the bulk front did, its last three or four windows back to back, and the diagonal job waited
+// 30-280 us for the newest one at every window boundary (job log r04).  In their own queues, `cboost` columns ahead of the front,
+// they run soon after their window closes, spread over the time the chain needs to get there.
 __device__ __forceinline__ int pick_bulk(const Args &a, Shared &sh) {
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, cls = lane >> 5, l32 = lane & 31;
     for (int attempt = 0; attempt < 4; ++attempt) {
-        const int wlo = sh.wlo;
-        if (wlo >= a.nwin) return -2;
-        const int wq = wlo + lane;
-        const bool valid = wq < a.nwin;
+        const int wlo = sh.wlo, cwlo = sh.cwlo;
+        if (wlo >= a.nwin && cwlo >= a.nwin) return -2;
+        const int wnd = (cls ? cwlo : wlo) + l32;
+        const bool valid = wnd < a.nwin;
+        const int wq = cls * a.nwin + wnd;
         unsigned h = 0;
         int cnt = 0, base = 0;
         if (valid) {
@@ -738,22 +687,35 @@ __device__ __forceinline__ int pick_bulk(const Args &a, Shared &sh) {
             h = ldf(a.wq_head + (size_t)wq * QSTRIDE);
         }
         const bool has = valid && h < (unsigned)cnt;
-        // advance wlo past drained queues (lane 0's queue)
+        // advance wlo / cwlo past drained queues
         const unsigned long long has_mask = __ballot(has);
-        if (has_mask == 0ull) {
-            if (wlo + 64 >= a.nwin) return -2;
-            if (lane == 0) sh.wlo = wlo + 64;
-            continue;
+        const unsigned m0 = (unsigned)has_mask, m1 = (unsigned)(has_mask >> 32);
+        bool moved = false;
+        if (wlo < a.nwin) {
+            const int adv = m0 ? __ffs((int)m0) - 1 : 32;
+            if (adv > 0) {
+                if (lane == 0) sh.wlo = wlo + adv;
+                moved = m0 == 0u;
+            }
         }
-        const int first = __ffsll((long long)has_mask) - 1;
-        if (first > 0 && lane == 0) sh.wlo = wlo + first;
+        if (cwlo < a.nwin) {
+            const int adv = m1 ? __ffs((int)m1) - 1 : 32;
+            if (adv > 0) {
+                if (lane == 0) sh.cwlo = cwlo + adv;
+                moved = moved || m1 == 0u;
+            }
+        }
+        if (has_mask == 0ull) {
+            if (!moved) return -2;
+            continue;  // a class moved on by 32 windows: look again
+        }
         unsigned key = 0xffffffffu;
         if (has) {
             const Job jb = a.bjobs[base + (int)h];
             const int jw = jb.w & 255, pl = wstart(jw + 1, a.first, a.win) - 1;
             if (ldf(a.tdone + (size_t)jb.i * a.NT + pl) >= 2u && ldf(a.tdone + (size_t)jb.c * a.NT + pl) >= 2u &&
                 ldf(a.ucnt + (size_t)jb.i * a.NT + jb.c) >= (unsigned)(2 * jw))
-                key = ((unsigned)(jb.c + a.wbias * lane) << 16) | (unsigned)lane;  // newer windows trail the older ones by wbias columns
+                key = ((unsigned)(1024 + jb.c + a.wbias * wnd - (cls ? a.cboost : 0)) << 8) | (unsigned)lane;  // newer windows trail the older ones by wbias columns
         }
         unsigned best = key;
 #pragma unroll
@@ -762,7 +724,7 @@ __device__ __forceinline__ int pick_bulk(const Args &a, Shared &sh) {
             best = o < best ? o : best;
         }
         if (best == 0xffffffffu) return -1;
-        const int win_lane = (int)(best & 0xffffu);
+        const int win_lane = (int)(best & 0xffu);
         // claim by fetch-add (a compare-and-swap on the inspected head serialises all idle workgroups on one word).  The
         // job actually received may lie behind the inspected one and not be ready yet: run_bulk waits for it (bounded);
         // its predecessors are ready or claimed jobs of lower queues, which the same priority rule hands out first.
@@ -790,6 +752,7 @@ __device__ __forceinline__ void mega_body(const Args &a) {
     if (chain || dedicated) __builtin_amdgcn_s_setprio(2);
     if (threadIdx.x == 0) {
         sh.wlo = 0;
+        sh.cwlo = 0;
         // (XCC, shader engine, CU) of this workgroup: a 512-workgroup launch puts exactly two workgroups on each of the 256 CUs
         const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
         const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // HW_REG_XCC_ID
@@ -797,22 +760,51 @@ __device__ __forceinline__ void mega_body(const Args &a) {
     }
     __syncthreads();
     unsigned *myquiet = a.quiet + (size_t)sh.mycu * QSTRIDE;
-    if (chain) {
+    // reserve workgroups (same placement class as the chain): general workers in the throughput-bound middle, chain workgroups while the
+    // chain queue is in the edge regime -- before job `head_job1` and from job `reserve_job0` on, where the machine has idle workgroups
+    // anyway and five streamed rows per column need more hands than the middle's three
+    const bool reserve = !chain && a.xchain && (bx & 7) == 0 && (bx >> 3) < a.nchain + a.nreserve;
+    bool in_chain = chain;
+    if (reserve && threadIdx.x == 0) {
+        const unsigned qc = ldf(a.ctl + CTL_QC);
+        sh.jidx = (qc < (unsigned)a.head_job1 || qc >= (unsigned)a.reserve_job0) ? 1 : 0;
+    }
+    if (reserve) {
+        __syncthreads();
+        in_chain = sh.jidx != 0;
+        __syncthreads();
+    }
+    unsigned long long idle_t0 = 0;  // start of the current run of idle scans
+    int nidle = 0;
+    while (true) {
+    if (in_chain) {
         // chain workgroups only run the diagonal / streamed jobs, in order; the CU's other workgroup (if it is a general
-        // one) stays idle for the whole launch, so the latency-bound chain never shares its SIMDs
+        // one) stays idle meanwhile, so the latency-bound chain never shares its SIMDs
         if (a.use_quiet && threadIdx.x == 0) addf(myquiet, 1u);
+        if (reserve) __builtin_amdgcn_s_setprio(2);
+        bool leave = false;
         while (true) {
             if (threadIdx.x == 0) {
                 int idx = -1;
                 if (!ldf(a.ctl + CTL_ABORT)) {
-                    const unsigned got = addf(a.ctl + CTL_QC, 1u);
-                    if (got < (unsigned)a.nchainjobs) idx = (int)got;
+                    if (reserve) {
+                        const unsigned qc = ldf(a.ctl + CTL_QC);
+                        if (qc >= (unsigned)a.head_job1 && qc < (unsigned)a.reserve_job0) idx = -2;  // the middle: back to the general pool
+                    }
+                    if (idx != -2) {
+                        const unsigned got = addf(a.ctl + CTL_QC, 1u);
+                        if (got < (unsigned)a.nchainjobs) idx = (int)got;
+                    }
                 }
                 sh.jidx = idx;
             }
             __syncthreads();
             const int idx = sh.jidx;
             __syncthreads();
+            if (idx == -2) {
+                leave = true;
+                break;
+            }
             if (idx < 0) break;
             const Job jb = a.cjobs[idx];
             jlog_begin(a, sh, jb);
@@ -820,16 +812,21 @@ __device__ __forceinline__ void mega_body(const Args &a) {
             jlog_end(sh);
         }
         if (a.use_quiet && threadIdx.x == 0) addf(myquiet, 0xffffffffu);
-        return;
+        if (!leave) return;
+        __builtin_amdgcn_s_setprio(0);
+        in_chain = false;
+        idle_t0 = 0;
+        nidle = 0;
+        continue;
     }
-    unsigned long long idle_t0 = 0;  // start of the current run of idle scans
-    int nidle = 0;
-    while (true) {
+    {
         if (threadIdx.x < 64) {
-            int kind = -1, idx = 0;  // -1 idle, -2 exit
+            int kind = -1, idx = 0;  // -1 idle, -2 exit, -3 reserve workgroup: the chain queue has reached the tail
             bool panel_left = false;
             if (ldf(a.ctl + CTL_ABORT)) {
                 kind = -2;
+            } else if (reserve && ldf(a.ctl + CTL_QC) >= (unsigned)a.reserve_job0 && ldf(a.ctl + CTL_QC) < (unsigned)a.nchainjobs) {
+                kind = -3;
             } else if (!dedicated && a.use_quiet && ldf(myquiet) != 0 && a.NT - (int)ldf(a.ctl + CTL_PCOLS) <= a.quiet_tail) {
                 kind = -1;  // the CU's other workgroup runs a chain-critical job: leave it the SIMDs
                 idle_t0 = 0;
@@ -846,7 +843,7 @@ __device__ __forceinline__ void mega_body(const Args &a) {
                         const Job hj = a.pjobs[ph];
                         want_panel = hj.c < (int)ldf(a.ctl + CTL_PCOLS) + a.look &&
                                      ldf(a.ucnt + (size_t)hj.i * a.NT + hj.c) >=
-                                         2u * (unsigned)nbulk_updates(hj.i, hj.c, a.slack, a.slack_chain, a.first, a.win, a.srows);
+                                         2u * (unsigned)nbulk_updates(hj.i, hj.c, a.slack, a.slack_chain, a.first, a.win, srows_at(hj.c, a.srows, a.edge));
                     }
                 }
                 if (want_panel) {
@@ -891,6 +888,10 @@ __device__ __forceinline__ void mega_body(const Args &a) {
         const int kind = sh.jkind, idx = sh.jidx;
         __syncthreads();
         if (kind == -2) break;
+        if (kind == -3) {
+            in_chain = true;
+            continue;
+        }
         if (kind == -1) {
             // back off: an idle workgroup's scan costs ~5 wave loads; 400 of them polling flat out slow everyone's memory traffic
             ++nidle;
@@ -918,6 +919,7 @@ __device__ __forceinline__ void mega_body(const Args &a) {
         }
         if (!ok) break;
     }
+    }
 }
 
 // The launch's own clock: every workgroup stamps wall_clock64 (100 MHz) when it starts and when it leaves; first start and last end
@@ -943,10 +945,11 @@ __global__ void mega_status_kernel(const unsigned *ctl, int *info, unsigned long
 // The job tables of one shape -- pure host code (no GPU call), also reachable through mrbf_debug_mega_tables so that the CPU container
 // can check their invariants, with sanitizers (csrc/Makefile: `make asan`).
 //   chain queue  P(c), S(c+1..c+srows, c) column by column;  panel queue  T(i, half, c) for the other rows;
-//   bulk queues  one per window w: U(i, c, w) for every tile the window reaches through a bulk job (nbulk_updates), as two 64-row
-//                halves when block column c lies within `slack + half_cols` columns behind the window's end.
-static void build_job_tables(int NT, int MT, int slack, int slack_chain, int first, int win, int srows, int half_cols,
-                             std::vector<mega::Job> &pj, std::vector<mega::Job> &bj, std::vector<mega::Job> &cj, std::vector<int> &wqs) {
+//   bulk queues  two per window w (ordinary tiles: queue w, chain tiles: queue nwin + w, empty without `chainq`): U(i, c, w) for
+//                every tile the window reaches through a bulk job (nbulk_updates), as two 64-row halves when block column c lies
+//                within `slack + half_cols` columns behind the window's end.
+static void build_job_tables(int NT, int MT, int slack, int slack_chain, int first, int win, int srows, const mega::Edge &edge, int half_cols,
+                             bool chainq, std::vector<mega::Job> &pj, std::vector<mega::Job> &bj, std::vector<mega::Job> &cj, std::vector<int> &wqs) {
     using namespace mega;
     pj.clear();
     bj.clear();
@@ -955,7 +958,7 @@ static void build_job_tables(int NT, int MT, int slack, int slack_chain, int fir
     for (int c = 0; c < NT; ++c) {
         cj.push_back(Job{JOB_P, (short)c, (short)c, (short)0});
         for (int i = c + 1; i < MT; ++i) {
-            if (i <= c + srows)
+            if (i <= c + srows_at(c, srows, edge))
                 cj.push_back(Job{JOB_S, (short)i, (short)c, (short)0});
             else
                 for (int h = 0; h < 2; ++h) pj.push_back(Job{JOB_T, (short)i, (short)c, (short)h});
@@ -963,21 +966,24 @@ static void build_job_tables(int NT, int MT, int slack, int slack_chain, int fir
     }
     int nwin_max = 0;  // windows that reach at least one tile through a bulk job
     for (int c = 0; c < NT; ++c)
-        for (int i = c; i < MT; ++i) nwin_max = std::max(nwin_max, nbulk_updates(i, c, slack, slack_chain, first, win, srows));
-    for (int w = 0; w < nwin_max; ++w) {
-        wqs.push_back((int)bj.size());
-        for (int c = 0; c < NT; ++c)
-            for (int i = c; i < MT; ++i) {
-                if (nbulk_updates(i, c, slack, slack_chain, first, win, srows) <= w) continue;  // this window reaches the tile inside its panel job
-                const bool half = i != c && c < wstart(w + 1, first, win) + slack + half_cols;
-                if (half) {
-                    bj.push_back(Job{JOB_UH, (short)i, (short)c, (short)w});
-                    bj.push_back(Job{JOB_UH, (short)i, (short)c, (short)(w + 256)});
-                } else {
-                    bj.push_back(Job{JOB_U, (short)i, (short)c, (short)w});
+        for (int i = c; i < MT; ++i) nwin_max = std::max(nwin_max, nbulk_updates(i, c, slack, slack_chain, first, win, srows_at(c, srows, edge)));
+    for (int cls = 0; cls < 2; ++cls)
+        for (int w = 0; w < nwin_max; ++w) {
+            wqs.push_back((int)bj.size());
+            for (int c = 0; c < NT; ++c)
+                for (int i = c; i < MT; ++i) {
+                    const int sr = srows_at(c, srows, edge);
+                    if (nbulk_updates(i, c, slack, slack_chain, first, win, sr) <= w) continue;  // this window reaches the tile inside its panel job
+                    if (((i - c <= sr) && chainq) != (cls == 1)) continue;  // chain tiles: queues of their own
+                    const bool half = i != c && c < wstart(w + 1, first, win) + slack + half_cols;
+                    if (half) {
+                        bj.push_back(Job{JOB_UH, (short)i, (short)c, (short)w});
+                        bj.push_back(Job{JOB_UH, (short)i, (short)c, (short)(w + 256)});
+                    } else {
+                        bj.push_back(Job{JOB_U, (short)i, (short)c, (short)w});
+                    }
                 }
-            }
-    }
+        }
     wqs.push_back((int)bj.size());
 }
 
@@ -1025,17 +1031,33 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
     const int win = std::max(1, ctx->mega_win > 0 ? ctx->mega_win : (NT >= 88 ? 8 : (NT >= 56 ? 6 : WIN_DEFAULT)));
     const int first = std::min(win, std::max(1, ctx->mega_first_window));
     const int srows = ctx->mega_srows > 0 ? ctx->mega_srows : srows_auto;  // streamed tiles below each diagonal block
+    // the edge regime (first / last block columns: chain-bound at every size, see mega::Edge); only where the middle differs from it
+    static const int env_head = getenv("MRBF_MEGA_HEAD") ? atoi(getenv("MRBF_MEGA_HEAD")) : -1;
+    static const int env_tail = getenv("MRBF_MEGA_TAIL") ? atoi(getenv("MRBF_MEGA_TAIL")) : -1;
+    static const int env_reserve = getenv("MRBF_MEGA_RESERVE") ? atoi(getenv("MRBF_MEGA_RESERVE")) : -1;
+    Edge edge{};
+    edge.srows_edge = std::max(srows, 5);
+    edge.pstream_edge = 2;
+    {
+        const int head = env_head >= 0 ? env_head : 0, tail = env_tail >= 0 ? env_tail : 0;
+        edge.head = (srows < edge.srows_edge) ? std::min(head, NT) : 0;
+        edge.tail_c0 = (srows < edge.srows_edge) ? std::max(edge.head, NT - tail) : NT;
+    }
+    const int srows_max = std::max(srows, (edge.head > 0 || edge.tail_c0 < NT) ? edge.srows_edge : srows);
     // job tables: one set per (NT, MT, schedule parameters), kept in a small per-context LRU -- Morbit's training sets grow and shrink
     // by a few sites between iterations, so n keeps crossing 128-boundaries back and forth; rebuilding the tables on every change
     // cost three copies and a stream synchronisation inside the factorisation phase
-    const long tab_key = slack + 100 * ctx->mega_half_cols + 10000 * slack_chain + 1000000 * first + 10000000 * win + 100000000 * (long)srows;
+    static const int chainq = getenv("MRBF_MEGA_CHAINQ") ? atoi(getenv("MRBF_MEGA_CHAINQ")) : 0;
+    static const int cboost = getenv("MRBF_MEGA_CBOOST") ? atoi(getenv("MRBF_MEGA_CBOOST")) : 12;
+    const long tab_key = (chainq ? 50 : 0) + slack + 100 * ctx->mega_half_cols + 10000 * slack_chain + 1000000 * first + 10000000 * win + 100000000 * (long)srows +
+                         1000000000L * edge.head + 1000000000000L * edge.tail_c0;
     MegaTables *tab = nullptr;
     for (auto &t : ctx->mega_tables)
         if (t.nt == NT && t.mt == MT && t.key == tab_key) tab = &t;
     if (!tab) {
         std::vector<Job> pj, bj, cj;
         std::vector<int> wqs;
-        build_job_tables(NT, MT, slack, slack_chain, first, win, srows, ctx->mega_half_cols, pj, bj, cj, wqs);
+        build_job_tables(NT, MT, slack, slack_chain, first, win, srows, edge, ctx->mega_half_cols, chainq != 0, pj, bj, cj, wqs);
         if (ctx->mega_tables.size() >= 8) {  // evict the least recently used set (nothing on the stream may still read it)
             MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
             size_t lru = 0;
@@ -1051,7 +1073,7 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
         t.npanel = (int)pj.size();
         t.nbulk = (int)bj.size();
         t.nchainjobs = (int)cj.size();
-        t.nwin = (int)wqs.size() - 1;
+        t.nwin = ((int)wqs.size() - 1) / 2;
         const size_t job_bytes = (pj.size() + bj.size() + cj.size() + 1) * sizeof(Job), wq_bytes = wqs.size() * sizeof(int);
         const size_t wq_off = (job_bytes + 255) & ~size_t(255);
         MRBF_HIP(ctx, hipMalloc(&t.block, wq_off + wq_bytes));
@@ -1085,7 +1107,7 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
     a.nwin = ctx->mega_nwin;
     a.wq_start = (int *)tab->wq;
     // flags: one block, zeroed before every launch
-    const size_t nfl = ((size_t)CTL_WORDS + (size_t)QSTRIDE * (a.nwin + 1) + (size_t)QSTRIDE * 512 + (size_t)QSTRIDE * (1 + srows) * NT + 2 * (size_t)MT * NT + 3) / 4 * 4;
+    const size_t nfl = ((size_t)CTL_WORDS + (size_t)QSTRIDE * (2 * a.nwin + 1) + (size_t)QSTRIDE * 512 + (size_t)QSTRIDE * (1 + srows_max) * NT + 2 * (size_t)MT * NT + 3) / 4 * 4;
     unsigned *fl;
     MRBF_TRY(get_buf(ctx, S_MEGA_FLAGS, nfl, &fl));
     hnow();  // 1: buffers / job tables
@@ -1095,10 +1117,10 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
     hnow();  // 3: second memset enqueued
     a.ctl = fl;
     a.wq_head = fl + CTL_WORDS;
-    a.quiet = a.wq_head + (size_t)QSTRIDE * (a.nwin + 1);
+    a.quiet = a.wq_head + (size_t)QSTRIDE * (2 * a.nwin + 1);
     a.dprog = a.quiet + (size_t)QSTRIDE * 512;
     a.sprog = a.dprog + (size_t)QSTRIDE * NT;
-    a.tdone = a.sprog + (size_t)QSTRIDE * srows * NT;
+    a.tdone = a.sprog + (size_t)QSTRIDE * srows_max * NT;
     a.ucnt = a.tdone + (size_t)MT * NT;
     a.info = dinfo;
     a.nchain = ctx->mega_chain > 0 ? ctx->mega_chain : chain_auto;
@@ -1111,6 +1133,21 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
     a.win = win;
     a.wbias = ctx->mega_wbias;
     a.srows = srows;
+    a.edge = edge;
+    a.cboost = cboost;
+    {
+        // chain jobs in front of the block columns `head` and `tail_c0 - 3` (the reserves are in place when the tail begins)
+        int job = 0;
+        a.head_job1 = 0;
+        a.reserve_job0 = 1 << 30;
+        const int lead_c0 = std::max(edge.head, edge.tail_c0 - 3);
+        for (int c = 0; c <= NT; ++c) {
+            if (c == edge.head) a.head_job1 = job;
+            if (c == lead_c0 && edge.tail_c0 < NT) a.reserve_job0 = job;
+            if (c < NT) job += 1 + std::min(srows_at(c, srows, edge), MT - 1 - c);
+        }
+        a.nreserve = (edge.head > 0 || edge.tail_c0 < NT) ? (env_reserve >= 0 ? env_reserve : 12) : 0;
+    }
     a.pstream = ctx->mega_pstream > 0 ? std::min(ctx->mega_pstream, srows) : (NTq <= 48 && srows >= 2 ? 2 : 1);
     a.spin_ticks = (unsigned long long)std::max(1, ctx->spin_ms) * 100000ull;  // wall_clock64 runs at 100 MHz
     a.fault = (ctx->debug_fault & 1) && MT > 1;
@@ -1244,7 +1281,8 @@ extern "C" int32_t mrbf_debug_mega_tables(int32_t nt, int32_t mt, int32_t slack,
     if (!out) return -9;
     std::vector<Job> pj, bj, cj;
     std::vector<int> wqs;
-    build_job_tables(nt, mt, slack, slack_chain, first, win, srows, half_cols, pj, bj, cj, wqs);
+    const Edge no_edge{0, nt, srows, 1};
+    build_job_tables(nt, mt, slack, slack_chain, first, win, srows, no_edge, half_cols, false, pj, bj, cj, wqs);
     int64_t bad = 0;
     std::vector<int> fin((size_t)mt * nt, 0);
     for (const Job &j : cj) {
@@ -1264,7 +1302,7 @@ extern "C" int32_t mrbf_debug_mega_tables(int32_t nt, int32_t mt, int32_t slack,
     }
     for (int c = 0; c < nt; ++c)
         for (int i = 0; i < mt; ++i) bad += fin[(size_t)i * nt + c] != (i >= c ? 2 : 0);
-    const int nwin = (int)wqs.size() - 1;
+    const int nwin = ((int)wqs.size() - 1) / 2;  // the ordinary queues (the chain tiles' queues are empty here)
     std::vector<int> upd((size_t)mt * nt, 0);
     for (int w = 0; w < nwin; ++w) {
         std::fill(upd.begin(), upd.end(), 0);
