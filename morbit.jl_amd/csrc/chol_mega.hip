@@ -406,6 +406,181 @@ __device__ __forceinline__ bool window_part(const Args &a, Shared &sh, int i, in
 // S(i,c): panel solve of a tile right below the diagonal, in step with the factorisation of the diagonal block.
 // Wave v owns rows 32v .. 32v+31 of the tile as 2 x 8 tiles of 16 x 16 in the MFMA C/D layout (lane l, register r:
 // X[16u + (l & 15)][16q + (l >> 4) + 4r]), which is directly the B operand of the next MFMA.
+//
+// Round 4: the 16-column panels both phases take from their producers come in by LDS-DMA, one panel ahead when the producer is
+// ahead.  A streamed job spends most of its life catching up (job log r04, n = 2048: S(c+1,c) started its fold of panel c-1 when
+// its producers had finished, took 3.3 us per 16-column step -- 1.4 of it the operand loads' trip, issued behind the previous
+// step's MFMAs because 208 of 256 registers hold the tile and the operands -- and reached the diagonal block's last panel 7 us
+// late, which is what P(c+1) then waited for).  Through LDS the next step's operands travel under this step's MFMAs.
+// MRBF_STREAM_V1: the register-staged version of rounds 2 / 3 (same arithmetic, same order: bit-identical results).
+#ifndef MRBF_STREAM_V1
+__device__ __attribute__((noinline)) bool run_stream(const Args &a, Shared &sh, const Job jb) {
+    const int64_t lda = uni64(a.lda);
+    double *const A = uni_ptr(a.A);
+    const int i = __builtin_amdgcn_readfirstlane(jb.i), c = __builtin_amdgcn_readfirstlane(jb.c);  // uniform: addresses and flags in SGPRs
+    // all left-looking panels but the newest (c - 1) through the GEMM loop, in place
+    if (!window_part<128>(a, sh, i, c, c > 0 ? c - 1 : 0, 0, nullptr)) return false;
+    JLOG(4);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l15 = lane & 15, l4 = lane >> 4;
+    double *C = A + (int64_t)i * NB + (int64_t)c * NB * lda;
+    const double *Lcc = A + (int64_t)c * NB + (int64_t)c * NB * lda;
+    const double *itg = uni_ptr(a.itg + (size_t)c * 8 * 256);
+    const unsigned *dprog = uni_ptr(a.dprog + (size_t)c * QSTRIDE);
+    unsigned *sprog = uni_ptr(a.sprog + ((size_t)(i - c - 1) * a.NT + c) * QSTRIDE);
+    // two LDS slots of [128 x 16 panel | 128 x 16 panel]: [k][row] with the GEMM loop's row stride (conflict-free fragment reads)
+    constexpr int PAN = 16 * LDS_LD, SLOT = 2 * PAN;
+    double *const ring = sh.u.gemm;
+    v4d x[2][8];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                x[u][q][r] = *(const gf64 *)&C[(32 * wave + 16 * u + l15) + (int64_t)(16 * q + l4 + 4 * r) * lda];
+    if (c > 0) {
+        // X -= L(i,c-1) L(c,c-1)', 16 columns at a time: L(c,c-1) is the first streamed tile of block column c-1, L(i,c-1) the
+        // (i-c+1)-th one, or -- the last S row -- a T tile that is awaited whole
+        const double *Lr = A + (int64_t)i * NB + (int64_t)(c - 1) * NB * lda;
+        const double *Lc = A + (int64_t)c * NB + (int64_t)(c - 1) * NB * lda;
+        const unsigned *fc = a.sprog + (size_t)(c - 1) * QSTRIDE;
+        const bool row_streamed = i - (c - 1) <= srows_at(c - 1, a.srows, a.edge);  // was tile (i, c-1) a streamed one?
+        const unsigned *fr = a.sprog + ((size_t)(i - c) * a.NT + (c - 1)) * QSTRIDE;
+        if (!row_streamed && !wg_wait(sh, a, a.tdone + (size_t)i * a.NT + (c - 1), 2u, nullptr, 0, nullptr, 0, 0x520u)) return false;
+        auto issue_fold = [&](int b) {  // wave w: columns 4w .. 4w+3 of both panels, eight LDS-DMA instructions
+            double *sl = ring + (b & 1) * SLOT;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int col = 4 * wave + u;
+                glds16(Lr + 2 * lane + (int64_t)(16 * b + col) * lda, sl + col * LDS_LD);
+                glds16(Lc + 2 * lane + (int64_t)(16 * b + col) * lda, sl + PAN + col * LDS_LD);
+            }
+        };
+        int got = 0, issued = 0;
+#pragma unroll 1
+        for (int b = 0; b < 8; ++b) {
+            if (got < b + 1) {
+                const unsigned g = row_streamed ? wg_wait_val2(sh, a, fr, fc, (unsigned)(b + 1), 0x510u) : wg_wait_val(sh, a, fc, (unsigned)(b + 1), 0x512u);
+                if (!g) return false;
+                got = __builtin_amdgcn_readfirstlane((int)g);
+            }
+            // panel b, and panel b + 1 when it is already published: its slot is that of panel b - 1, whose readers passed the barrier
+            // at the end of the previous step
+            const int upto = got < b + 2 ? got : b + 2;
+            for (; issued < upto; ++issued) issue_fold(issued);
+            if (issued > b + 1)
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // every wave's share of panel b has landed
+            const double *sl = ring + (b & 1) * SLOT;
+            double opr[2][4];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) opr[u][s2] = sl[(4 * s2 + l4) * LDS_LD + 32 * wave + 16 * u + l15];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                double opc[4];
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) opc[s2] = sl[PAN + (4 * s2 + l4) * LDS_LD + 16 * q + l15];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int s2 = 0; s2 < 4; ++s2) x[u][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-opc[s2], opr[u][s2], x[u][q], 0, 0, 0);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // the slot may be refilled
+        }
+    }
+    unsigned long long *const strbase = (a.trace && i == c + 1) ? uni_ptr(a.trace + (size_t)a.NT * 16 + 4 * 1024 + (size_t)c * 64) : nullptr;
+    unsigned *const tdone_ic = uni_ptr(a.tdone + (size_t)i * a.NT + c);
+    auto issue_solve = [&](int b) {  // panel b of L_cc (waves: columns 4w .. 4w+3) and its leaf inverse (two 1-KB halves; waves 2, 3 repeat 0, 1)
+        double *sl = ring + (b & 1) * SLOT;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int col = 4 * wave + u;
+            glds16(Lcc + 2 * lane + (int64_t)(16 * b + col) * lda, sl + col * LDS_LD);
+        }
+        glds16(itg + b * 256 + (wave & 1) * 128 + 2 * lane, sl + PAN + (wave & 1) * 128);
+    };
+    int have = 0, sissued = 0;  // panels of the diagonal block known to be published / whose operands are on their way
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        if (have < b + 1) {
+            const unsigned g = wg_wait_val(sh, a, dprog, (unsigned)(b + 1), 0x500u);
+            if (!g) return false;
+            have = __builtin_amdgcn_readfirstlane((int)g);
+        }
+        if (b == 0) JLOG(5);
+        if (b == 7) JLOG(6);
+        // operands of this step and, when the diagonal block is ahead, of the next one (its slot's readers met at the previous step's
+        // drain barrier; a step that was issued a step ago has landed: that barrier sat behind vmcnt(0))
+        {
+            const int upto = have < b + 2 ? have : b + 2;
+            for (; sissued < upto; ++sissued) issue_solve(sissued);
+        }
+        if (sissued > b + 1)
+            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // per-step opaque copies of the lane coordinates: the store / operand addresses derived from them are otherwise computed
+        // once for all eight (unrolled) steps, spilled, and reloaded between the write-through stores behind s_waitcnt vmcnt(0)
+        int l15s = l15, l4s = l4;
+        asm volatile("" : "+v"(l15s), "+v"(l4s));
+        unsigned long long *str = strbase ? strbase + 8 * b : nullptr;
+        if (str && threadIdx.x == 0) str[0] = wall_clock64();  // panel b of the diagonal block seen
+        const double *sl = ring + (b & 1) * SLOT;
+        double ia[4];
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) ia[s2] = sl[PAN + (4 * s2 + l4s) * 16 + l15s];
+        double lq[8][4];
+#pragma unroll
+        for (int q = b + 1; q < 8; ++q)
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) lq[q][s2] = sl[(4 * s2 + l4s) * LDS_LD + 16 * q + l15s];
+        v4d xs[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            v4d t = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) t = __builtin_amdgcn_mfma_f64_16x16x4f64(ia[s2], x[u][b][s2], t, 0, 0, 0);
+            xs[u] = t;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st_sc1(&C[(32 * wave + 16 * u + l15s) + (int64_t)(16 * b + l4s + 4 * r) * lda], t[r]);
+        }
+        // the next step only needs block column b + 1 brought up to date: that one before the panel is published, the others after
+        // (the early steps carry up to 56 MFMAs per wave, 1.6 us, which the consumers of this panel need not wait for)
+        if (b < 7) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) x[u][b + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(-lq[b + 1][s2], xs[u][s2], x[u][b + 1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // publish the finished 16-column panel, also when this job is only catching up with a diagonal block that is already
+        // complete: its consumers (the next diagonal job, the next column's streamed jobs) fold panel by panel at ~3 us each and
+        // would otherwise start all eight after this job's end (seen as 17-23 us instead of 3 us between the end of S(c+1,c) and
+        // the start of P(c+1): trace r02)
+        wg_drain();  // (also: every wave's LDS reads of this step's slot are in -- lq lives in registers from here on)
+        if (threadIdx.x == 0) {
+            stf(sprog, (unsigned)(b + 1));
+            if (b == 7) stf(tdone_ic, 2u);
+            if (str) str[5] = wall_clock64();  // own panel b published
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = b + 2; q < 8; ++q)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) x[u][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-lq[q][s2], xs[u][s2], x[u][q], 0, 0, 0);
+    }
+    return true;
+}
+#else
 __device__ __attribute__((noinline)) bool run_stream(const Args &a, Shared &sh, const Job jb) {
     const int64_t lda = uni64(a.lda);
     double *const A = uni_ptr(a.A);
@@ -525,6 +700,7 @@ __device__ __attribute__((noinline)) bool run_stream(const Args &a, Shared &sh, 
     }
     return true;
 }
+#endif
 
 #define MEGA_STAMP(k)                                                          \
     do {                                                                       \
@@ -556,6 +732,69 @@ __device__ __attribute__((noinline)) bool run_diag(const Args &a, Shared &sh, co
     double *Linv = a.linv + (size_t)c * NB * NB;
     diagcore::v4d acc[diagcore::NSLOT6];
     diagcore::diag_v6_load(C, lda, acc);
+#ifndef MRBF_STREAM_V1
+    // (round 4: the 16-column panels arrive by LDS-DMA, one panel ahead when the producer is ahead -- see run_stream.  Two slots in
+    //  the first 37 KB of the workgroup's LDS: nothing the diagonal core touches before its first barrier lies there, so the leaf
+    //  wave, which leaves the last step without waiting for the others, may start the core while they finish their tiles.)
+    {
+        constexpr int PAN = 16 * LDS_LD;
+        double *const ring = sh.u.gemm;
+#pragma unroll 1
+        for (int pp = c - pstream; pp < c; ++pp) {
+            const double *Lp = A + (int64_t)c * NB + (int64_t)pp * NB * lda;                       // tile (c, pp), produced by S(c, pp),
+            const unsigned *sprog = uni_ptr(a.sprog + ((size_t)(c - pp - 1) * a.NT + pp) * QSTRIDE);  // the (c-pp)-th streamed tile of column pp
+            auto issue_fold = [&](int b) {  // wave w: columns 4w .. 4w+3 of panel b
+                double *sl = ring + (b & 1) * PAN;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int col = 4 * wave + u;
+                    glds16(Lp + 2 * lane + (int64_t)(16 * b + col) * lda, sl + col * LDS_LD);
+                }
+            };
+            int have = 0, issued = 0;  // 16-column panels of tile (c, pp) known to be published / on their way
+#pragma unroll 1
+            for (int b = 0; b < 8; ++b) {
+                if (have < b + 1) {
+                    const unsigned g = wg_wait_val(sh, a, sprog, (unsigned)(b + 1), 0x600u);
+                    if (!g) return false;
+                    have = __builtin_amdgcn_readfirstlane((int)g);
+                }
+                const int upto = have < b + 2 ? have : b + 2;
+                for (; issued < upto; ++issued) issue_fold(issued);
+                if (issued > b + 1)
+                    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();  // every wave's share of panel b has landed
+                const double *sl = ring + (b & 1) * PAN;
+                double op[8][4];
+                // (the leaf wave's three tiles only need the first two row blocks: it is through its fold -- and, after the last panel,
+                //  into its first leaf -- while the others still work on their eleven tiles each)
+#pragma unroll
+                for (int xb = 0; xb < 8; ++xb)
+                    if (xb < 2 || wave != 0) {
+#pragma unroll
+                        for (int s2 = 0; s2 < 4; ++s2) op[xb][s2] = sl[(4 * s2 + l4) * LDS_LD + 16 * xb + l15];
+                    }
+#pragma unroll
+                for (int ti = 0; ti < 8; ++ti)
+#pragma unroll
+                    for (int tj = 0; tj <= ti; ++tj) {
+                        if (diagcore::v6_owner(ti, tj) == wave) {
+#pragma unroll
+                            for (int s2 = 0; s2 < 4; ++s2)
+                                acc[diagcore::v6_slot(ti, tj)] =
+                                    __builtin_amdgcn_mfma_f64_16x16x4f64(-op[tj][s2], op[ti][s2], acc[diagcore::v6_slot(ti, tj)], 0, 0, 0);
+                        }
+                    }
+                if (b < 7 || pp + 1 < c) {  // (not behind the very last panel: nothing refills its slot)
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();  // the slot may be refilled
+                }
+            }
+        }
+    }
+#else
 #pragma unroll 1
     for (int pp = c - pstream; pp < c; ++pp) {
         const double *Lp = A + (int64_t)c * NB + (int64_t)pp * NB * lda;                       // tile (c, pp), produced by S(c, pp),
@@ -591,6 +830,7 @@ __device__ __attribute__((noinline)) bool run_diag(const Args &a, Shared &sh, co
                 }
         }
     }
+#endif
     MEGA_STAMP(2);
     JLOG(5);
     __builtin_amdgcn_s_setprio(3);
