@@ -257,8 +257,9 @@ __device__ __forceinline__ void zero_acc(v4d (&acc)[NJ][4]) {
 // C tile epilogue (TM x 128).  SUB: C = C - acc (else C = acc).  LOWER: entries above the diagonal of the tile stay
 // untouched (diagonal tiles).  SC1: write-through stores.  Batches of 16 loads before the first store of a batch (see
 // chol_update_kernel: element-wise read-modify-write serialises 64 dependent round trips).
+// (roff: row offset of a 64-row half inside its 128 x 128 tile, for LOWER)
 template <int TM, bool SUB, bool LOWER, bool SC1>
-__device__ __forceinline__ void store_tile(double *__restrict__ C, int64_t ldc, const v4d (&acc)[TM / 32][4]) {
+__device__ __forceinline__ void store_tile(double *__restrict__ C, int64_t ldc, const v4d (&acc)[TM / 32][4], int roff = 0) {
     constexpr int NJ = TM / 32;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
@@ -282,7 +283,7 @@ __device__ __forceinline__ void store_tile(double *__restrict__ C, int64_t ldc, 
             for (int i = 0; i < 4; ++i) {
                 const int64_t gi = ioff + i * 16 + l15;
                 const double v = SUB ? cv[r][i] - acc[j][i][r] : acc[j][i][r];
-                if (!LOWER || gi >= gj) {
+                if (!LOWER || gi + roff >= gj) {
                     if (SC1)
                         st_sc1(C + gi + gj * ldc, v);
                     else
@@ -341,8 +342,8 @@ __device__ __attribute__((noinline)) bool run_bulk(const Args &a, Shared &sh, co
     for (int j = 0; j < TM / 32; ++j)
 #pragma unroll
         for (int i2 = 0; i2 < 4; ++i2) acc[j][i2] = -acc[j][i2];
-    if (TM == 128 && i == c)
-        store_tile<TM, false, true, true>(C, lda, acc);
+    if (i == c)
+        store_tile<TM, false, true, true>(C, lda, acc, roff);  // (a half of a diagonal tile: rows roff .. roff + 63 against all 128 columns)
     else
         store_tile<TM, false, false, true>(C, lda, acc);
     wg_drain();
@@ -1189,7 +1190,7 @@ __global__ void mega_status_kernel(const unsigned *ctl, int *info, unsigned long
 //                every tile the window reaches through a bulk job (nbulk_updates), as two 64-row halves when block column c lies
 //                within `slack + half_cols` columns behind the window's end.
 static void build_job_tables(int NT, int MT, int slack, int slack_chain, int first, int win, int srows, const mega::Edge &edge, int half_cols,
-                             bool chainq, std::vector<mega::Job> &pj, std::vector<mega::Job> &bj, std::vector<mega::Job> &cj, std::vector<int> &wqs) {
+                             int tail_half, bool chainq, std::vector<mega::Job> &pj, std::vector<mega::Job> &bj, std::vector<mega::Job> &cj, std::vector<int> &wqs) {
     using namespace mega;
     pj.clear();
     bj.clear();
@@ -1215,7 +1216,7 @@ static void build_job_tables(int NT, int MT, int slack, int slack_chain, int fir
                     const int sr = srows_at(c, srows, edge);
                     if (nbulk_updates(i, c, slack, slack_chain, first, win, sr) <= w) continue;  // this window reaches the tile inside its panel job
                     if (((i - c <= sr) && chainq) != (cls == 1)) continue;  // chain tiles: queues of their own
-                    const bool half = i != c && c < wstart(w + 1, first, win) + slack + half_cols;
+                    const bool half = (i != c && c < wstart(w + 1, first, win) + slack + half_cols) || c >= NT - tail_half;
                     if (half) {
                         bj.push_back(Job{JOB_UH, (short)i, (short)c, (short)w});
                         bj.push_back(Job{JOB_UH, (short)i, (short)c, (short)(w + 256)});
@@ -1279,7 +1280,9 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
     edge.srows_edge = std::max(srows, 5);
     edge.pstream_edge = 2;
     {
-        const int head = env_head >= 0 ? env_head : 0, tail = env_tail >= 0 ? env_tail : 0;
+        // (measured r04, alternating A/B: sixteen tail columns in the edge regime + 64-row bulk jobs in the last twenty block columns
+        //  -- tail_half below --: n = 6144 / 8192 / 12288 / 16384: -2.5 / -5.3 / -2.6 / -1.2 %; the head alone: no change)
+        const int head = env_head >= 0 ? env_head : 0, tail = env_tail >= 0 ? env_tail : 16;
         edge.head = (srows < edge.srows_edge) ? std::min(head, NT) : 0;
         edge.tail_c0 = (srows < edge.srows_edge) ? std::max(edge.head, NT - tail) : NT;
     }
@@ -1289,7 +1292,13 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
     // cost three copies and a stream synchronisation inside the factorisation phase
     static const int chainq = getenv("MRBF_MEGA_CHAINQ") ? atoi(getenv("MRBF_MEGA_CHAINQ")) : 0;
     static const int cboost = getenv("MRBF_MEGA_CBOOST") ? atoi(getenv("MRBF_MEGA_CBOOST")) : 12;
-    const long tab_key = (chainq ? 50 : 0) + slack + 100 * ctx->mega_half_cols + 10000 * slack_chain + 1000000 * first + 10000000 * win + 100000000 * (long)srows +
+    // bulk jobs of the last block columns as 64-row halves (diagonal tiles included): there the machine runs empty and what is left
+    // are per-tile chains of window updates -- each a K = 128 win GEMM of one workgroup, one after the other on the same tile --
+    // that the diagonal chain ends up waiting for (job log r04: P(56) at n = 8192 waited 146 us for the last three windows of its
+    // tile); two workgroups per tile halve every link.  n = 4096: -1.8 %, smaller: no change.
+    static const int env_tail_half = getenv("MRBF_MEGA_TAILHALF") ? atoi(getenv("MRBF_MEGA_TAILHALF")) : -1;
+    const int tail_half = env_tail_half >= 0 ? env_tail_half : (NT >= 32 ? 20 : 0);
+    const long tab_key = (chainq ? 50 : 0) + slack + 100000000000000L * tail_half + 100 * ctx->mega_half_cols + 10000 * slack_chain + 1000000 * first + 10000000 * win + 100000000 * (long)srows +
                          1000000000L * edge.head + 1000000000000L * edge.tail_c0;
     MegaTables *tab = nullptr;
     for (auto &t : ctx->mega_tables)
@@ -1297,7 +1306,7 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
     if (!tab) {
         std::vector<Job> pj, bj, cj;
         std::vector<int> wqs;
-        build_job_tables(NT, MT, slack, slack_chain, first, win, srows, edge, ctx->mega_half_cols, chainq != 0, pj, bj, cj, wqs);
+        build_job_tables(NT, MT, slack, slack_chain, first, win, srows, edge, ctx->mega_half_cols, tail_half, chainq != 0, pj, bj, cj, wqs);
         if (ctx->mega_tables.size() >= 8) {  // evict the least recently used set (nothing on the stream may still read it)
             MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
             size_t lru = 0;
@@ -1522,7 +1531,7 @@ extern "C" int32_t mrbf_debug_mega_tables(int32_t nt, int32_t mt, int32_t slack,
     std::vector<Job> pj, bj, cj;
     std::vector<int> wqs;
     const Edge no_edge{0, nt, srows, 1};
-    build_job_tables(nt, mt, slack, slack_chain, first, win, srows, no_edge, half_cols, false, pj, bj, cj, wqs);
+    build_job_tables(nt, mt, slack, slack_chain, first, win, srows, no_edge, half_cols, 0, false, pj, bj, cj, wqs);
     int64_t bad = 0;
     std::vector<int> fin((size_t)mt * nt, 0);
     for (const Job &j : cj) {
