@@ -1190,7 +1190,7 @@ __global__ void mega_status_kernel(const unsigned *ctl, int *info, unsigned long
 //                every tile the window reaches through a bulk job (nbulk_updates), as two 64-row halves when block column c lies
 //                within `slack + half_cols` columns behind the window's end.
 static void build_job_tables(int NT, int MT, int slack, int slack_chain, int first, int win, int srows, const mega::Edge &edge, int half_cols,
-                             int tail_half, bool chainq, std::vector<mega::Job> &pj, std::vector<mega::Job> &bj, std::vector<mega::Job> &cj, std::vector<int> &wqs) {
+                             int tail_half, int tail_half_w, bool chainq, std::vector<mega::Job> &pj, std::vector<mega::Job> &bj, std::vector<mega::Job> &cj, std::vector<int> &wqs) {
     using namespace mega;
     pj.clear();
     bj.clear();
@@ -1216,7 +1216,8 @@ static void build_job_tables(int NT, int MT, int slack, int slack_chain, int fir
                     const int sr = srows_at(c, srows, edge);
                     if (nbulk_updates(i, c, slack, slack_chain, first, win, sr) <= w) continue;  // this window reaches the tile inside its panel job
                     if (((i - c <= sr) && chainq) != (cls == 1)) continue;  // chain tiles: queues of their own
-                    const bool half = (i != c && c < wstart(w + 1, first, win) + slack + half_cols) || c >= NT - tail_half;
+                    const bool half = (i != c && c < wstart(w + 1, first, win) + slack + half_cols) ||
+                                      (c >= NT - tail_half && w >= nbulk_updates(i, c, slack, slack_chain, first, win, sr) - tail_half_w);
                     if (half) {
                         bj.push_back(Job{JOB_UH, (short)i, (short)c, (short)w});
                         bj.push_back(Job{JOB_UH, (short)i, (short)c, (short)(w + 256)});
@@ -1298,7 +1299,9 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
     // tile); two workgroups per tile halve every link.  n = 4096: -1.8 %, smaller: no change.
     static const int env_tail_half = getenv("MRBF_MEGA_TAILHALF") ? atoi(getenv("MRBF_MEGA_TAILHALF")) : -1;
     const int tail_half = env_tail_half >= 0 ? env_tail_half : (NT >= 32 ? 20 : 0);
-    const long tab_key = (chainq ? 50 : 0) + slack + 100000000000000L * tail_half + 100 * ctx->mega_half_cols + 10000 * slack_chain + 1000000 * first + 10000000 * win + 100000000 * (long)srows +
+    static const int env_tail_half_w = getenv("MRBF_MEGA_TAILHALF_W") ? atoi(getenv("MRBF_MEGA_TAILHALF_W")) : -1;
+    const int tail_half_w = env_tail_half_w >= 0 ? env_tail_half_w : 1000;  // only the last so many window updates of such a tile
+    const long tab_key = (chainq ? 50 : 0) + slack + 100000000000000L * tail_half + 10000000000000000L * std::min(tail_half_w, 99) + 100 * ctx->mega_half_cols + 10000 * slack_chain + 1000000 * first + 10000000 * win + 100000000 * (long)srows +
                          1000000000L * edge.head + 1000000000000L * edge.tail_c0;
     MegaTables *tab = nullptr;
     for (auto &t : ctx->mega_tables)
@@ -1306,7 +1309,7 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
     if (!tab) {
         std::vector<Job> pj, bj, cj;
         std::vector<int> wqs;
-        build_job_tables(NT, MT, slack, slack_chain, first, win, srows, edge, ctx->mega_half_cols, tail_half, chainq != 0, pj, bj, cj, wqs);
+        build_job_tables(NT, MT, slack, slack_chain, first, win, srows, edge, ctx->mega_half_cols, tail_half, tail_half_w, chainq != 0, pj, bj, cj, wqs);
         if (ctx->mega_tables.size() >= 8) {  // evict the least recently used set (nothing on the stream may still read it)
             MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
             size_t lru = 0;
@@ -1531,7 +1534,7 @@ extern "C" int32_t mrbf_debug_mega_tables(int32_t nt, int32_t mt, int32_t slack,
     std::vector<Job> pj, bj, cj;
     std::vector<int> wqs;
     const Edge no_edge{0, nt, srows, 1};
-    build_job_tables(nt, mt, slack, slack_chain, first, win, srows, no_edge, half_cols, 0, false, pj, bj, cj, wqs);
+    build_job_tables(nt, mt, slack, slack_chain, first, win, srows, no_edge, half_cols, 0, 0, false, pj, bj, cj, wqs);
     int64_t bad = 0;
     std::vector<int> fin((size_t)mt * nt, 0);
     for (const Job &j : cj) {

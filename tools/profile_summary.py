@@ -23,11 +23,15 @@ PHASES = [
 ]
 
 
+FUSED = False  # set when the trace holds the fit's fused assembly kernel: the full-matrix kernel's dispatches then are bench.py's
+               # side measurement of mrbf_gram (kernels.gram_full, seven launches per run), not part of the cycle
 MEGA = False  # set when the trace holds the persistent factorisation: the blocked-Cholesky kernels then belong to the projection
               # (rank-2q update of K, Cholesky-QR of the tail basis), not to the factorisation
 
 
 def phase_of(name):
+    if FUSED and ("gram_mfma" in name or "gram_diff_kernel" in name):
+        return "gram_full_side_measurement"
     if MEGA and ("chol_update_kernel" in name or "chol_diag" in name):
         return "project_misc"
     for ph, keys in PHASES:
@@ -54,8 +58,9 @@ def pmc_sum(db, counter):
 
 
 def pmc(wdb, fdb, prefix, inv, config):
-    global MEGA
+    global MEGA, FUSED
     MEGA = any("potrf_mega_kernel" in r[0] for r in pmc_sum(wdb, "WRITE_SIZE"))
+    FUSED = any("gram_w_kernel" in r[0] for r in pmc_sum(wdb, "WRITE_SIZE"))
     out = {}
     detail = {}
     for db, counter, tag, scale in ((wdb, "WRITE_SIZE", "write", 1.0), (fdb, "FETCH_SIZE", "fetch", 2.0)):
