@@ -253,6 +253,11 @@ int32_t mrbf_debug_dgemm(mrbf_ctx *ctx, int32_t m, int32_t n, int32_t k, float *
  * out[5] = violated invariants (0 when the tables are consistent).  Returns 0, or -(argument index) for a parameter out of range. */
 int32_t mrbf_debug_mega_tables(int32_t nt, int32_t mt, int32_t slack, int32_t slack_chain, int32_t first, int32_t win, int32_t srows,
                                int32_t half_cols, int64_t *out6);
+/* The same with the round-4 schedule options: opt5 = { head columns, tail columns of the chain-bound edge regime, block columns at the
+ * end whose bulk jobs are 64-row halves, only a tile's last so many windows as halves (0: all), chain tiles' window jobs in queues of
+ * their own }.  The invariants cover both queue classes and the per-column number of streamed rows. */
+int32_t mrbf_debug_mega_tables2(int32_t nt, int32_t mt, int32_t slack, int32_t slack_chain, int32_t first, int32_t win, int32_t srows,
+                                int32_t half_cols, const int32_t *opt5, int64_t *out6);
 
 /* ---- Pascoletti-Serafini descent step with the subproblem solver on the device ----------------------------------------
  * Replaces, for objectives that share ONE grouped RBF model and carry no modelled constraints, the NLopt runs inside

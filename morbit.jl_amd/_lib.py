@@ -121,6 +121,7 @@ SIGNATURES = {
     "mrbf_debug_mfma_asm": (ctypes.c_int32, [c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_fp, c_dp, c_dp]),
     "mrbf_debug_dgemm": (ctypes.c_int32, [c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_fp, c_dp]),
     "mrbf_debug_mega_tables": (ctypes.c_int32, [ctypes.c_int32] * 8 + [c_vp]),
+    "mrbf_debug_mega_tables2": (ctypes.c_int32, [ctypes.c_int32] * 8 + [c_vp, c_vp]),
     "mrbf_stochastic_rank": (ctypes.c_int32, [ctypes.c_int32, c_vp, c_vp, c_vp, ctypes.c_double, c_vp]),
     "mrbf_ps_step": (ctypes.c_int32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(PsOptions), c_vp, c_vp, c_vp,
                                       ctypes.POINTER(PsInfo)]),

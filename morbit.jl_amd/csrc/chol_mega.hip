@@ -1522,20 +1522,18 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
 // Host-only: builds the job tables of a shape and checks their invariants.  out[0..3] = panel / bulk / chain jobs, windows;
 // out[4] = order-dependent checksum of all jobs; out[5] = violated invariants (0 for every valid parameter set):
 //   every tile (i, c), i >= c, is finished by exactly one chain job or by exactly two panel halves; it receives every window
-//   w < nbulk_updates(i, c) exactly once (one full job or both halves) and no other; every window only updates tiles of block columns
-//   behind its own last panel; a window's queue lists its jobs by ascending block column.
-extern "C" int32_t mrbf_debug_mega_tables(int32_t nt, int32_t mt, int32_t slack, int32_t slack_chain, int32_t first, int32_t win, int32_t srows,
-                                          int32_t half_cols, int64_t *out) {
+//   w < nbulk_updates(i, c) exactly once (one full job or both halves, over the ordinary and the chain tiles' queue of that window
+//   together) and no other; every window only updates tiles of block columns behind its own last panel; a queue lists its jobs by
+//   ascending block column; the chain tiles' queues hold chain tiles only (and all of them when they are in use).
+static int32_t check_mega_tables(int nt, int mt, int slack, int slack_chain, int first, int win, int srows, const mrbf::mega::Edge &edge,
+                                 int half_cols, int tail_half, int tail_half_w, bool chainq, int64_t *out) {
     using namespace mrbf;
     using namespace mrbf::mega;
-    if (nt < 1 || mt < nt || mt > 32000) return -1;
-    if (slack < 1 || slack_chain < slack || win < 1 || first < 1 || first > win || srows < 0 || half_cols < 0) return -3;
-    if (!out) return -9;
     std::vector<Job> pj, bj, cj;
     std::vector<int> wqs;
-    const Edge no_edge{0, nt, srows, 1};
-    build_job_tables(nt, mt, slack, slack_chain, first, win, srows, no_edge, half_cols, 0, 0, false, pj, bj, cj, wqs);
+    build_job_tables(nt, mt, slack, slack_chain, first, win, srows, edge, half_cols, tail_half, tail_half_w, chainq, pj, bj, cj, wqs);
     int64_t bad = 0;
+    auto sr = [&](int c) { return srows_at(c, srows, edge); };
     std::vector<int> fin((size_t)mt * nt, 0);
     for (const Job &j : cj) {
         if (j.i < j.c || j.i >= mt || j.c >= nt) {
@@ -1543,10 +1541,10 @@ extern "C" int32_t mrbf_debug_mega_tables(int32_t nt, int32_t mt, int32_t slack,
             continue;
         }
         fin[(size_t)j.i * nt + j.c] += 2;
-        if (j.kind == JOB_P ? j.i != j.c : (j.kind != JOB_S || j.i <= j.c || j.i > j.c + srows)) ++bad;
+        if (j.kind == JOB_P ? j.i != j.c : (j.kind != JOB_S || j.i <= j.c || j.i > j.c + sr(j.c))) ++bad;
     }
     for (const Job &j : pj) {
-        if (j.kind != JOB_T || j.i <= j.c + srows || j.i >= mt || j.c >= nt || (j.w != 0 && j.w != 1)) {
+        if (j.kind != JOB_T || j.c >= nt || j.i <= j.c + sr(j.c) || j.i >= mt || (j.w != 0 && j.w != 1)) {
             ++bad;
             continue;
         }
@@ -1554,24 +1552,27 @@ extern "C" int32_t mrbf_debug_mega_tables(int32_t nt, int32_t mt, int32_t slack,
     }
     for (int c = 0; c < nt; ++c)
         for (int i = 0; i < mt; ++i) bad += fin[(size_t)i * nt + c] != (i >= c ? 2 : 0);
-    const int nwin = ((int)wqs.size() - 1) / 2;  // the ordinary queues (the chain tiles' queues are empty here)
+    const int nwin = ((int)wqs.size() - 1) / 2;  // queues [0, nwin): ordinary tiles, [nwin, 2 nwin): chain tiles
     std::vector<int> upd((size_t)mt * nt, 0);
     for (int w = 0; w < nwin; ++w) {
         std::fill(upd.begin(), upd.end(), 0);
-        int last_c = -1;
-        for (int q = wqs[w]; q < wqs[w + 1]; ++q) {
-            const Job &j = bj[q];
-            if (j.i < j.c || j.i >= mt || j.c >= nt || (j.w & 255) != w || (j.kind != JOB_U && j.kind != JOB_UH)) {
-                ++bad;
-                continue;
+        for (int cls = 0; cls < 2; ++cls) {
+            int last_c = -1;
+            for (int q = wqs[cls * nwin + w]; q < wqs[cls * nwin + w + 1]; ++q) {
+                const Job &j = bj[q];
+                if (j.i < j.c || j.i >= mt || j.c >= nt || (j.w & 255) != w || (j.kind != JOB_U && j.kind != JOB_UH)) {
+                    ++bad;
+                    continue;
+                }
+                if (j.c < last_c) ++bad;  // ascending block columns inside a queue
+                last_c = j.c;
+                if (j.c < wstart(w + 1, first, win)) ++bad;  // a window never reaches a block column it still belongs to
+                if (((j.i - j.c <= sr(j.c)) && chainq) != (cls == 1)) ++bad;  // chain tiles in their own queues, nothing else there
+                upd[(size_t)j.i * nt + j.c] += j.kind == JOB_U ? 2 : 1;
             }
-            if (j.c < last_c) ++bad;  // ascending block columns inside a queue
-            last_c = j.c;
-            if (j.c < wstart(w + 1, first, win)) ++bad;  // a window never reaches a block column it still belongs to
-            upd[(size_t)j.i * nt + j.c] += j.kind == JOB_U ? 2 : 1;
         }
         for (int c = 0; c < nt; ++c)
-            for (int i = c; i < mt; ++i) bad += upd[(size_t)i * nt + c] != (w < nbulk_updates(i, c, slack, slack_chain, first, win, srows) ? 2 : 0);
+            for (int i = c; i < mt; ++i) bad += upd[(size_t)i * nt + c] != (w < nbulk_updates(i, c, slack, slack_chain, first, win, sr(c)) ? 2 : 0);
     }
     for (size_t w = 0; w + 1 < wqs.size(); ++w) bad += wqs[w] > wqs[w + 1];
     int64_t sum = 0;
@@ -1585,4 +1586,31 @@ extern "C" int32_t mrbf_debug_mega_tables(int32_t nt, int32_t mt, int32_t slack,
     out[4] = sum;
     out[5] = bad;
     return 0;
+}
+
+extern "C" int32_t mrbf_debug_mega_tables(int32_t nt, int32_t mt, int32_t slack, int32_t slack_chain, int32_t first, int32_t win, int32_t srows,
+                                          int32_t half_cols, int64_t *out) {
+    if (nt < 1 || mt < nt || mt > 32000) return -1;
+    if (slack < 1 || slack_chain < slack || win < 1 || first < 1 || first > win || srows < 0 || half_cols < 0) return -3;
+    if (!out) return -9;
+    const mrbf::mega::Edge no_edge{0, nt, srows, 1};
+    return check_mega_tables(nt, mt, slack, slack_chain, first, win, srows, no_edge, half_cols, 0, 0, false, out);
+}
+
+// The same with the round-4 options: opt[0] = head columns, opt[1] = tail columns of the edge regime (five streamed rows there),
+// opt[2] = block columns at the end whose bulk jobs are 64-row halves, opt[3] = only a tile's last so many windows (0: all),
+// opt[4] = chain tiles' window jobs in queues of their own.
+extern "C" int32_t mrbf_debug_mega_tables2(int32_t nt, int32_t mt, int32_t slack, int32_t slack_chain, int32_t first, int32_t win, int32_t srows,
+                                           int32_t half_cols, const int32_t *opt5, int64_t *out) {
+    if (nt < 1 || mt < nt || mt > 32000) return -1;
+    if (slack < 1 || slack_chain < slack || win < 1 || first < 1 || first > win || srows < 0 || half_cols < 0) return -3;
+    if (!opt5) return -9;
+    if (!out) return -10;
+    if (opt5[0] < 0 || opt5[1] < 0 || opt5[2] < 0 || opt5[3] < 0) return -9;
+    mrbf::mega::Edge edge{};
+    edge.srows_edge = std::max(srows, 5);
+    edge.pstream_edge = 2;
+    edge.head = srows < edge.srows_edge ? std::min(opt5[0], nt) : 0;
+    edge.tail_c0 = srows < edge.srows_edge ? std::max(edge.head, nt - opt5[1]) : nt;
+    return check_mega_tables(nt, mt, slack, slack_chain, first, win, srows, edge, half_cols, opt5[2], opt5[3] > 0 ? opt5[3] : 1000, opt5[4] != 0, out);
 }

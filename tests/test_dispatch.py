@@ -313,3 +313,21 @@ def test_mega_job_tables_are_consistent():
     assert lib.mrbf_debug_mega_tables(4, 5, 3, 2, 1, 4, 5, 0, out) == -3
     assert lib.mrbf_debug_mega_tables(4, 5, 3, 6, 5, 4, 5, 0, out) == -3
     assert lib.mrbf_debug_mega_tables(4, 5, 3, 6, 1, 4, 5, 0, None) == -9
+    # round-4 options (per-column streamed rows at the edges, 64-row bulk halves in the last block columns, chain tiles' queues):
+    # the defaults potrf_mega_tall picks for n = 4096 .. 16384, every option alone, all together, and tails longer than the matrix
+    opt_cases = [((32, 33, 3, 6, 1, 4, 5, 0), (0, 16, 20, 0, 0)), ((64, 65, 3, 7, 1, 6, 3, 0), (0, 16, 20, 0, 0)), ((96, 97, 3, 7, 1, 8, 3, 0), (0, 16, 20, 0, 0)),
+                 ((128, 129, 3, 6, 1, 8, 2, 0), (0, 16, 20, 0, 0)), ((64, 65, 3, 7, 1, 6, 3, 0), (8, 0, 0, 0, 0)), ((64, 65, 3, 7, 1, 6, 3, 0), (0, 0, 20, 3, 0)),
+                 ((64, 65, 3, 7, 1, 6, 3, 0), (0, 0, 0, 0, 1)), ((64, 65, 3, 7, 1, 6, 3, 2), (6, 24, 28, 2, 1)), ((10, 12, 2, 4, 1, 3, 2, 0), (40, 40, 40, 1, 1)),
+                 ((5, 5, 1, 1, 1, 1, 0, 0), (2, 2, 5, 0, 1))]
+    for c, o in opt_cases:
+        opt = (ctypes.c_int32 * 5)(*o)
+        assert lib.mrbf_debug_mega_tables2(*c, opt, out) == 0, (c, o)
+        assert out[5] == 0, (c, o, list(out))
+        nt, mt = c[0], c[1]
+        tiles = sum(mt - cc for cc in range(nt))
+        assert out[2] + out[0] // 2 == tiles, (c, o, list(out))  # every tile finished by one chain job or two panel halves
+    opt = (ctypes.c_int32 * 5)(0, 0, 0, 0, 0)
+    for c in cases[:6]:  # without options: the same tables as the plain entry point
+        assert lib.mrbf_debug_mega_tables2(*c, opt, out) == 0 and out[4] == seen[c], c
+    assert lib.mrbf_debug_mega_tables2(4, 5, 3, 6, 1, 4, 5, 0, None, out) == -9
+    assert lib.mrbf_debug_mega_tables2(4, 5, 3, 6, 1, 4, 5, 0, (ctypes.c_int32 * 5)(0, -1, 0, 0, 0), out) == -9

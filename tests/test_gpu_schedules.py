@@ -1,0 +1,43 @@
+"""The schedule switches of the persistent factorisation (chol_mega.hip) are read once per process from the environment: every variant
+that can be selected -- the round-3 schedule, the edge regime at the head, halves only for a tile's last windows, chain tiles' queues,
+odd window / slack settings -- must factor correctly.  One child process per variant (tools/potrf_time.py with its residual check:
+|L L' - A| / |A| on a device-resident s.p.d. matrix), sizes with 16 and 50 block columns (the latter has the three-streamed-row middle,
+so the edge regime, the reserve workgroups and the tail's halves are all in play)."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+VARIANTS = [
+    {},                                                                       # the defaults
+    {"MRBF_MEGA_TAIL": "0", "MRBF_MEGA_TAILHALF": "0"},                       # the round-3 schedule
+    {"MRBF_MEGA_HEAD": "6", "MRBF_MEGA_TAIL": "12", "MRBF_MEGA_RESERVE": "20"},
+    {"MRBF_MEGA_TAILHALF": "30", "MRBF_MEGA_TAILHALF_W": "2"},
+    {"MRBF_MEGA_CHAINQ": "1", "MRBF_MEGA_CBOOST": "8"},
+    {"MRBF_MEGA_CHAINQ": "1", "MRBF_MEGA_HALF_COLS": "3", "MRBF_MEGA_WIN": "3", "MRBF_MEGA_SLACK": "2", "MRBF_MEGA_SLACK_CHAIN": "4"},
+    {"MRBF_MEGA_SROWS": "2", "MRBF_MEGA_PSTREAM": "1", "MRBF_MEGA_CHAIN": "12", "MRBF_MEGA_TAIL": "20"},
+]
+
+
+@pytest.mark.parametrize("env", VARIANTS, ids=lambda e: ",".join("%s=%s" % (k[10:], v) for k, v in e.items()) or "defaults")
+def test_schedule_variant_factors_correctly(env):
+    e = dict(os.environ)
+    e.update(env)
+    e["POTRF_CHECK"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "potrf_time.py"), "2048,6400", "2"], env=e, cwd=ROOT,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("n=")][-1]
+    parts = line.split(" | ")
+    assert len(parts) == 2, line
+    for part in parts:
+        m = re.search(r"info (-?\d+) resid ([0-9.e+-]+)", part)
+        assert m, part
+        assert int(m.group(1)) == 0, part
+        assert float(m.group(2)) < 1e-13, part
