@@ -11,13 +11,16 @@
 
 using namespace mrbf::mega;
 
+// mode 0: A rows distinct per workgroup, B shared by all (B from L2); 1: both shared by the workgroups of a group of 8 (everything from L2);
+// 2: B distinct per group of 8 workgroups too (both operands streamed from beyond L2: what a bulk job of the factorisation sees)
 template <int TM>
-__global__ __launch_bounds__(256, 2) void k_gemm(const double *A, int64_t lda, const double *B, int64_t ldb, int K, double *C, int reps) {
+__global__ __launch_bounds__(256, 2) void k_gemm(const double *A, int64_t lda, const double *B, int64_t ldb, int K, double *C, int reps, int mode = 0, int nbt = 1) {
     __shared__ __attribute__((aligned(16))) double smem[4 * 2 * 8 * LDS_LD];
     v4d acc[TM / 32][4];
     for (int j = 0; j < TM / 32; ++j)
         for (int i = 0; i < 4; ++i) acc[j][i] = (v4d){0.0, 0.0, 0.0, 0.0};
-    const double *Ab = A + (size_t)blockIdx.x * TM;  // tile rows of this workgroup (wraps inside the test matrix)
+    const double *Ab = A + (size_t)(mode == 1 ? blockIdx.x % 8 : blockIdx.x) * TM;  // tile rows of this workgroup
+    if (mode == 2) B += (size_t)((blockIdx.x / 8) % nbt) * 128;
 #ifdef TEST_V1
     for (int r = 0; r < reps; ++r) gemm_acc_v1<TM>(Ab, lda, B, ldb, K, acc, smem);
 #else
@@ -84,6 +87,35 @@ int run(int K, int tiles, int reps) {
     return bad != 0;
 }
 
+template <int TM>
+void run_mode(int K, int tiles, int reps, int mode) {
+    const int nbt = 64;
+    const int64_t rowsA = (int64_t)tiles * TM, lda = rowsA + 2, ldb = (int64_t)nbt * 128 + 4;
+    double *dA, *dB, *dC;
+    hipMalloc(&dA, (size_t)lda * K * 8);
+    hipMalloc(&dB, (size_t)ldb * K * 8);
+    hipMalloc(&dC, (size_t)tiles * TM * 128 * 8);
+    hipMemset(dA, 0, (size_t)lda * K * 8);
+    hipMemset(dB, 0, (size_t)ldb * K * 8);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    float best = 1e9;
+    for (int it = 0; it < 5; ++it) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(k_gemm<TM>, dim3(tiles), dim3(256), 0, 0, dA, lda, dB, ldb, K, dC, reps, mode, nbt);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
+    printf("mode %d TM %3d K %5d tiles %4d: %.1f us per call, %.1f TFLOP/s\n", mode, TM, K, tiles, best * 1e3 / reps, 2.0 * TM * 128 * K * (double)reps * tiles / best / 1e9);
+    hipFree(dA);
+    hipFree(dB);
+    hipFree(dC);
+}
+
 int main(int argc, char **argv) {
     int rc = 0;
     rc |= run<128>(128, 3, 20);
@@ -92,5 +124,7 @@ int main(int argc, char **argv) {
     rc |= run<128>(768, 512, 20);   // two per CU
     rc |= run<64>(768, 512, 20);
     rc |= run<128>(256, 512, 20);
+    for (int mode = 0; mode < 3; ++mode) run_mode<128>(768, 512, 20, mode);
+    for (int mode = 0; mode < 3; ++mode) run_mode<128>(768, 256, 20, mode);
     return rc;
 }
