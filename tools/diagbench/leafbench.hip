@@ -35,6 +35,8 @@ __global__ __launch_bounds__(64) void kold(const double *A, double *out, unsigne
         for (int c = 0; c < 16; ++c) a[c] = a0[c];
         old_step<0>(a); old_step<1>(a); old_step<2>(a); old_step<3>(a); old_step<4>(a); old_step<5>(a); old_step<6>(a); old_step<7>(a);
         old_step<8>(a); old_step<9>(a); old_step<10>(a); old_step<11>(a); old_step<12>(a); old_step<13>(a); old_step<14>(a); old_step<15>(a);
+        if (it == reps - 1)
+            for (int c = 0; c < 16; ++c) out[64 + lane * 16 + c] = a[c];
         for (int c = 0; c < 16; ++c) acc += a[c];
         a0[0] += acc * 1e-300;
     }
@@ -93,6 +95,67 @@ __global__ __launch_bounds__(64) void ksched(const double *A, double *out, unsig
     const unsigned long long t1 = __builtin_readcyclecounter();
     out[lane] = acc;
     if (lane == 0) ts[6] = t1 - t0;
+}
+
+// Round 4: multipliers through LDS -- 197 -> 156 cycles per column HERE (one wave alone on its CU), but slower inside the factorisation
+// (n = 256 / 2048 / 8192: +14 / +4.5 / +1.5 % with this leaf in diag_v6_core / diag_v4_core: the leaf wave's LDS reads queue behind the
+// three update waves' operand traffic on the same LDS), so the product keeps the readlane leaf.  Two things learnt on the way:
+// (i) lanes that talk to each other through LDS need wavefront-scope fences (no instructions) -- without them the compiler treats
+// the scratch words as private to a lane and reuses, on the lanes that do not store, the value they loaded two columns ago (the
+// identity rows, i.e. the inverse, came out 0.5 % wrong); (ii) the compiler evaluates the column updates lazily (each column's chain of
+// fmas right in front of its pivot) whatever the source order, and pinning them eagerly (empty asm on the values + sched_barrier)
+// is slower (174 cycles): the leaf is bound by its instruction count, not by the pivot chain.
+// The leaf is bound by its instruction count (120 (j, K) pairs x [2 v_readlane + s_nop + fma]); only
+// the next column's multiplier is needed at once (one readlane pair: the critical chain), the others are written to LDS once per
+// column (lanes 0..15: ds_write_b64) and read back as broadcast ds_read_b128 (two multipliers per instruction), applied one column
+// step later under the next column's pivot chain.
+template <int K>
+__device__ __forceinline__ void lds_step(double (&a)[16], double (&m)[2][16], double *col, int lane) {
+    const double piv = diagcore::readlane_f64(a[K], K);
+    const double rinv = diagcore::fast_rsqrt_v4(piv);
+    a[K] *= rinv;
+    if (lane < 16) col[(K & 1) * 16 + lane] = a[K];
+    // lanes talk to each other through LDS here: without the fences the compiler may (and does) treat the location as private to the
+    // lane and reuse the value this lane loaded two columns ago on the lanes that do not store
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if constexpr (K < 15) {
+        const double l = diagcore::readlane_f64(a[K], K + 1);
+        a[K + 1] = fma(-a[K], l, a[K + 1]);
+    }
+#pragma unroll
+    for (int j = K + 2; j < 16; ++j) m[K & 1][j] = col[(K & 1) * 16 + j];
+    if constexpr (K >= 1) {
+#pragma unroll
+        for (int j = K + 1; j < 16; ++j) a[j] = fma(-a[K - 1], m[(K - 1) & 1][j], a[j]);
+    }
+    // (without these the compiler sinks every update of a column to the step that needs it: a chain of K dependent fmas in front of
+    //  column K's pivot)
+#pragma unroll
+    for (int j = K + 1; j < 16; ++j) asm volatile("" : "+v"(a[j]));
+    __builtin_amdgcn_sched_barrier(0);
+}
+__global__ __launch_bounds__(64) void klds(const double *A, double *out, unsigned long long *ts, int reps) {
+    __shared__ __attribute__((aligned(16))) double col[32];
+    const int lane = threadIdx.x;
+    double a0[16], acc = 0.0;
+    for (int c = 0; c < 16; ++c) a0[c] = lane < 16 ? (c <= lane ? A[lane + 16 * c] : 0.0) : (c == lane - 16 ? 1.0 : 0.0);
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < reps; ++it) {
+        double a[16], m[2][16];
+        for (int c = 0; c < 16; ++c) a[c] = a0[c];
+        lds_step<0>(a, m, col, lane); lds_step<1>(a, m, col, lane); lds_step<2>(a, m, col, lane); lds_step<3>(a, m, col, lane);
+        lds_step<4>(a, m, col, lane); lds_step<5>(a, m, col, lane); lds_step<6>(a, m, col, lane); lds_step<7>(a, m, col, lane);
+        lds_step<8>(a, m, col, lane); lds_step<9>(a, m, col, lane); lds_step<10>(a, m, col, lane); lds_step<11>(a, m, col, lane);
+        lds_step<12>(a, m, col, lane); lds_step<13>(a, m, col, lane); lds_step<14>(a, m, col, lane); lds_step<15>(a, m, col, lane);
+        if (it == reps - 1)
+            for (int c = 0; c < 16; ++c) out[64 + lane * 16 + c] = a[c];
+        for (int c = 0; c < 16; ++c) acc += a[c];
+        a0[0] += acc * 1e-300;
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    out[lane] = acc;
+    if (lane == 0) ts[7] = t1 - t0;
 }
 
 template <int V, int K>
@@ -181,7 +244,7 @@ int main() {
     double *dA, *dout;
     unsigned long long *dts;
     hipMalloc(&dA, 256 * 8);
-    hipMalloc(&dout, 256 * 8);
+    hipMalloc(&dout, (64 + 64 * 16) * 8);
     hipMalloc(&dts, 64);
     hipMemcpy(dA, A.data(), 256 * 8, hipMemcpyHostToDevice);
     hipMemset(dts, 0, 64);
@@ -193,18 +256,33 @@ int main() {
     hipLaunchKernelGGL(k<4>, dim3(1), dim3(64), 0, 0, dA, dout, dts, reps);
     hipLaunchKernelGGL(kold, dim3(1), dim3(64), 0, 0, dA, dout, dts, reps);
     double ref[64], got[64];
+    static double fref[64 * 16], fgot[64 * 16];
     hipDeviceSynchronize();
     hipMemcpy(ref, dout, 64 * 8, hipMemcpyDeviceToHost);
+    hipMemcpy(fref, dout + 64, 64 * 16 * 8, hipMemcpyDeviceToHost);
     hipLaunchKernelGGL(ksched, dim3(1), dim3(64), 0, 0, dA, dout, dts, reps);
     hipDeviceSynchronize();
     hipMemcpy(got, dout, 64 * 8, hipMemcpyDeviceToHost);
     double dmax = 0;
     for (int l = 0; l < 32; ++l) dmax = fmax(dmax, fabs(ref[l] - got[l]) / fmax(fabs(ref[l]), 1e-300));
     printf("hand-scheduled vs round-1 leaf: max relative difference of the lane sums %.2e\n", dmax);
+    hipLaunchKernelGGL(klds, dim3(1), dim3(64), 0, 0, dA, dout, dts, reps);
+    hipDeviceSynchronize();
+    hipMemcpy(got, dout, 64 * 8, hipMemcpyDeviceToHost);
+    dmax = 0;
+    for (int l = 0; l < 32; ++l) dmax = fmax(dmax, fabs(ref[l] - got[l]) / fmax(fabs(ref[l]), 1e-300));
+    printf("LDS-broadcast vs round-1 leaf: max relative difference of the lane sums %.2e\n", dmax);
+    hipMemcpy(fgot, dout + 64, 64 * 16 * 8, hipMemcpyDeviceToHost);
+    {
+        int shown = 0;
+        for (int l = 0; l < 32; ++l)
+            for (int c = 0; c < 16; ++c)
+                if (fabs(fref[l * 16 + c] - fgot[l * 16 + c]) > 1e-12 && shown++ < 12) printf("  lane %d col %d: %.6e vs %.6e\n", l, c, fref[l * 16 + c], fgot[l * 16 + c]);
+    }
     hipDeviceSynchronize();
     unsigned long long ts[8];
     hipMemcpy(ts, dts, 64, hipMemcpyDeviceToHost);
-    const char *names[7] = {"full step (T and Y mfma)", "no inverse", "readlane -> mul -> mfma", "mul -> mfma 16x16x4", "mul -> mfma 4x4x4", "round-1 leaf (readlane, with inverse)", "round-1 leaf, hand-scheduled"};
-    for (int v = 0; v < 7; ++v) printf("%-28s %.1f cycles per column step\n", names[v], (double)ts[v] / reps / 16);
+    const char *names[8] = {"full step (T and Y mfma)", "no inverse", "readlane -> mul -> mfma", "mul -> mfma 16x16x4", "mul -> mfma 4x4x4", "round-1 leaf (readlane, with inverse)", "round-1 leaf, hand-scheduled", "leaf with LDS-broadcast multipliers (r4)"};
+    for (int v = 0; v < 8; ++v) printf("%-28s %.1f cycles per column step\n", names[v], (double)ts[v] / reps / 16);
     return 0;
 }
