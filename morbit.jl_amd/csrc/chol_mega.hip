@@ -76,9 +76,11 @@ __host__ __device__ inline int nbulk_updates(int i, int c, int slack, int slack_
 // stream depth are therefore chosen per block column: the chain-bound values at the edges, the size's own in between.
 struct Edge {
     int head, tail_c0, srows_edge, pstream_edge;
+    int shalf, sh_head, sh_tail_c0;  // shalf: streamed tiles of the block columns c < sh_head and c >= sh_tail_c0 as two 64-row jobs (see run_stream)
 };
 __host__ __device__ inline bool edge_col(int c, const Edge &e) { return c < e.head || c >= e.tail_c0; }
 __host__ __device__ inline int srows_at(int c, int srows, const Edge &e) { return edge_col(c, e) ? e.srows_edge : srows; }
+__host__ __device__ inline bool shalf_at(int c, int srows, const Edge &e) { return e.shalf && (c < e.sh_head || c >= e.sh_tail_c0) && srows_at(c, srows, e) >= 5; }
 
 struct Args {
     double *A;
@@ -96,7 +98,7 @@ struct Args {
     unsigned *wq_head;    // [2 nwin] x QSTRIDE claimed jobs per queue
     double *itg;          // NT x 8 x 256: 16 x 16 leaf inverses of every diagonal block (streamed panel solves)
     unsigned *dprog;      // [NT] x QSTRIDE: 16-column panels of diagonal block c that are published
-    unsigned *sprog;      // [srows][NT] x QSTRIDE: 16-column panels of tile (c + 1 + k, c) that are published
+    unsigned *sprog;      // [srows][2][NT] x QSTRIDE: 16-column panels of the 64-row halves of tile (c + 1 + k, c) that are published (sprog_at)
     unsigned *quiet;      // [512] x QSTRIDE per-CU count of chain-critical jobs in flight: the CU's other workgroup pauses
     int nwin;
     int *info;
@@ -108,7 +110,7 @@ struct Args {
     unsigned long long spin_ticks;  // wall_clock64 ticks (10 ns) one wait may last without the awaited word changing
     int fault;                      // test hook: the last block row's first panel job of column 0 never publishes its tile
     int use_quiet;
-    int xchain;      // chain workgroups on one XCD (blocks 0, 8, 16, ...)
+    int xchain;      // chain workgroups on so many XCDs (1: blocks 0, 8, 16, ...); 0: blocks 0 .. nchain-1
     int quiet_tail;  // a chain workgroup's CU partner pauses only while at most this many block columns are left
     int slack, slack_chain, first, win, wbias, srows;
     Edge edge;
@@ -239,6 +241,33 @@ __device__ __forceinline__ unsigned wg_wait_val2(Shared &sh, const Args &a, cons
     __syncthreads();
     return v;
 }
+
+// Same for up to four producers (null pointers are skipped): the smallest of the values observed, 0 on abort.
+__device__ __forceinline__ unsigned wg_wait_val4(Shared &sh, const Args &a, const unsigned *f0, const unsigned *f1, const unsigned *f2, const unsigned *f3,
+                                                 unsigned want, unsigned code) {
+    if (threadIdx.x == 0) {
+        const unsigned *f[4] = {f0, f1, f2, f3};
+        unsigned v = 0xffffffffu;
+        bool ok = true;
+        for (int t = 0; t < 4 && ok; ++t)
+            if (f[t]) ok = poll_ge(f[t], want, a, code + t);
+        if (ok)
+            for (int t = 0; t < 4; ++t)
+                if (f[t]) {
+                    const unsigned x = ldf(f[t]);
+                    v = x < v ? x : v;
+                }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        sh.ok = ok ? (int)v : 0;
+    }
+    __syncthreads();
+    const unsigned v = (unsigned)sh.ok;
+    __syncthreads();
+    return v;
+}
+// progress word of half h of the k-th streamed tile below the diagonal of block column c
+__device__ __forceinline__ unsigned *sprog_at(const Args &a, int k, int h, int c) { return a.sprog + (((size_t)k * 2 + h) * a.NT + c) * QSTRIDE; }
 
 // publish: every storing wave has drained its write-through stores, then one lane sets the word
 __device__ __forceinline__ void wg_drain() {
@@ -413,48 +442,56 @@ __device__ __forceinline__ bool window_part(const Args &a, Shared &sh, int i, in
 // its producers had finished, took 3.3 us per 16-column step -- 1.4 of it the operand loads' trip, issued behind the previous
 // step's MFMAs because 208 of 256 registers hold the tile and the operands -- and reached the diagonal block's last panel 7 us
 // late, which is what P(c+1) then waited for).  Through LDS the next step's operands travel under this step's MFMAs.
-// MRBF_STREAM_V1: the register-staged version of rounds 2 / 3 (same arithmetic, same order: bit-identical results).
-#ifndef MRBF_STREAM_V1
+// HALF: the job owns rows [64 h, 64 h + 64) of the tile (jb.w = 1 + h), wave v rows 16v .. 16v+15 of them.  Chain-bound block columns
+// are streamed as halves (shalf_at): a 128-row job carries 37 us of matrix-pipe time per block column (fold 8 x 64, solve 8 x 16..72
+// MFMAs per wave at 34 ns) plus its left-looking GEMM -- more than the 35 us a chain-bound column takes --, so once behind (it
+// starts behind: its last left-looking panel is final only when the previous-but-one column's streamed row has ended) it stays
+// behind, and the diagonal job of the next column waits for it (trace r04, n = 2048: S(c+1,c) reached the last panel of P(c)
+// 7 us late).  Two workgroups per tile halve every part of that.
+template <bool HALF>
 __device__ __attribute__((noinline)) bool run_stream(const Args &a, Shared &sh, const Job jb) {
     const int64_t lda = uni64(a.lda);
     double *const A = uni_ptr(a.A);
     const int i = __builtin_amdgcn_readfirstlane(jb.i), c = __builtin_amdgcn_readfirstlane(jb.c);  // uniform: addresses and flags in SGPRs
+    const int hh = HALF ? __builtin_amdgcn_readfirstlane(jb.w) - 1 : 0, roff = 64 * hh;
+    constexpr int RW = HALF ? 16 : 32, U = HALF ? 1 : 2;  // rows per wave, 16-row tiles per wave
     // all left-looking panels but the newest (c - 1) through the GEMM loop, in place
-    if (!window_part<128>(a, sh, i, c, c > 0 ? c - 1 : 0, 0, nullptr)) return false;
+    if (HALF ? !window_part<64>(a, sh, i, c, c > 0 ? c - 1 : 0, roff, nullptr) : !window_part<128>(a, sh, i, c, c > 0 ? c - 1 : 0, 0, nullptr)) return false;
     JLOG(4);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l15 = lane & 15, l4 = lane >> 4;
-    double *C = A + (int64_t)i * NB + (int64_t)c * NB * lda;
+    double *C = A + (int64_t)i * NB + roff + (int64_t)c * NB * lda;  // row 0 of this job's rows
     const double *Lcc = A + (int64_t)c * NB + (int64_t)c * NB * lda;
     const double *itg = uni_ptr(a.itg + (size_t)c * 8 * 256);
     const unsigned *dprog = uni_ptr(a.dprog + (size_t)c * QSTRIDE);
-    unsigned *sprog = uni_ptr(a.sprog + ((size_t)(i - c - 1) * a.NT + c) * QSTRIDE);
+    unsigned *sprog0 = uni_ptr(sprog_at(a, i - c - 1, HALF ? hh : 0, c)), *sprog1 = uni_ptr(sprog_at(a, i - c - 1, HALF ? hh : 1, c));  // (a 128-row job: both halves' words)
     // two LDS slots of [128 x 16 panel | 128 x 16 panel]: [k][row] with the GEMM loop's row stride (conflict-free fragment reads)
     constexpr int PAN = 16 * LDS_LD, SLOT = 2 * PAN;
     double *const ring = sh.u.gemm;
-    v4d x[2][8];
+    v4d x[U][8];
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < U; ++u)
 #pragma unroll
         for (int q = 0; q < 8; ++q)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                x[u][q][r] = *(const gf64 *)&C[(32 * wave + 16 * u + l15) + (int64_t)(16 * q + l4 + 4 * r) * lda];
+                x[u][q][r] = *(const gf64 *)&C[(RW * wave + 16 * u + l15) + (int64_t)(16 * q + l4 + 4 * r) * lda];
     if (c > 0) {
         // X -= L(i,c-1) L(c,c-1)', 16 columns at a time: L(c,c-1) is the first streamed tile of block column c-1, L(i,c-1) the
         // (i-c+1)-th one, or -- the last S row -- a T tile that is awaited whole
-        const double *Lr = A + (int64_t)i * NB + (int64_t)(c - 1) * NB * lda;
+        const double *Lr = A + (int64_t)i * NB + roff + (int64_t)(c - 1) * NB * lda;  // this job's rows of tile (i, c-1)
         const double *Lc = A + (int64_t)c * NB + (int64_t)(c - 1) * NB * lda;
-        const unsigned *fc = a.sprog + (size_t)(c - 1) * QSTRIDE;
+        const unsigned *fc0 = sprog_at(a, 0, 0, c - 1), *fc1 = sprog_at(a, 0, 1, c - 1);   // tile (c, c-1): all of its rows are the update's columns
         const bool row_streamed = i - (c - 1) <= srows_at(c - 1, a.srows, a.edge);  // was tile (i, c-1) a streamed one?
-        const unsigned *fr = a.sprog + ((size_t)(i - c) * a.NT + (c - 1)) * QSTRIDE;
+        const unsigned *fr0 = row_streamed ? sprog_at(a, i - c, HALF ? hh : 0, c - 1) : nullptr;      // this job's rows of tile (i, c-1)
+        const unsigned *fr1 = (row_streamed && !HALF) ? sprog_at(a, i - c, 1, c - 1) : nullptr;
         if (!row_streamed && !wg_wait(sh, a, a.tdone + (size_t)i * a.NT + (c - 1), 2u, nullptr, 0, nullptr, 0, 0x520u)) return false;
         auto issue_fold = [&](int b) {  // wave w: columns 4w .. 4w+3 of both panels, eight LDS-DMA instructions
             double *sl = ring + (b & 1) * SLOT;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int col = 4 * wave + u;
-                glds16(Lr + 2 * lane + (int64_t)(16 * b + col) * lda, sl + col * LDS_LD);
+                if (!HALF || lane < 32) glds16(Lr + 2 * lane + (int64_t)(16 * b + col) * lda, sl + col * LDS_LD);  // (64 rows: half a wave)
                 glds16(Lc + 2 * lane + (int64_t)(16 * b + col) * lda, sl + PAN + col * LDS_LD);
             }
         };
@@ -462,7 +499,7 @@ __device__ __attribute__((noinline)) bool run_stream(const Args &a, Shared &sh, 
 #pragma unroll 1
         for (int b = 0; b < 8; ++b) {
             if (got < b + 1) {
-                const unsigned g = row_streamed ? wg_wait_val2(sh, a, fr, fc, (unsigned)(b + 1), 0x510u) : wg_wait_val(sh, a, fc, (unsigned)(b + 1), 0x512u);
+                const unsigned g = wg_wait_val4(sh, a, fc0, fc1, fr0, fr1, (unsigned)(b + 1), 0x510u);
                 if (!g) return false;
                 got = __builtin_amdgcn_readfirstlane((int)g);
             }
@@ -476,18 +513,18 @@ __device__ __attribute__((noinline)) bool run_stream(const Args &a, Shared &sh, 
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();  // every wave's share of panel b has landed
             const double *sl = ring + (b & 1) * SLOT;
-            double opr[2][4];
+            double opr[U][4];
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+            for (int u = 0; u < U; ++u)
 #pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2) opr[u][s2] = sl[(4 * s2 + l4) * LDS_LD + 32 * wave + 16 * u + l15];
+                for (int s2 = 0; s2 < 4; ++s2) opr[u][s2] = sl[(4 * s2 + l4) * LDS_LD + RW * wave + 16 * u + l15];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 double opc[4];
 #pragma unroll
                 for (int s2 = 0; s2 < 4; ++s2) opc[s2] = sl[PAN + (4 * s2 + l4) * LDS_LD + 16 * q + l15];
 #pragma unroll
-                for (int u = 0; u < 2; ++u)
+                for (int u = 0; u < U; ++u)
 #pragma unroll
                     for (int s2 = 0; s2 < 4; ++s2) x[u][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-opc[s2], opr[u][s2], x[u][q], 0, 0, 0);
             }
@@ -495,7 +532,7 @@ __device__ __attribute__((noinline)) bool run_stream(const Args &a, Shared &sh, 
             __builtin_amdgcn_s_barrier();  // the slot may be refilled
         }
     }
-    unsigned long long *const strbase = (a.trace && i == c + 1) ? uni_ptr(a.trace + (size_t)a.NT * 16 + 4 * 1024 + (size_t)c * 64) : nullptr;
+    unsigned long long *const strbase = (a.trace && i == c + 1 && hh == 0) ? uni_ptr(a.trace + (size_t)a.NT * 16 + 4 * 1024 + (size_t)c * 64) : nullptr;
     unsigned *const tdone_ic = uni_ptr(a.tdone + (size_t)i * a.NT + c);
     auto issue_solve = [&](int b) {  // panel b of L_cc (waves: columns 4w .. 4w+3) and its leaf inverse (two 1-KB halves; waves 2, 3 repeat 0, 1)
         double *sl = ring + (b & 1) * SLOT;
@@ -542,21 +579,21 @@ __device__ __attribute__((noinline)) bool run_stream(const Args &a, Shared &sh, 
         for (int q = b + 1; q < 8; ++q)
 #pragma unroll
             for (int s2 = 0; s2 < 4; ++s2) lq[q][s2] = sl[(4 * s2 + l4s) * LDS_LD + 16 * q + l15s];
-        v4d xs[2];
+        v4d xs[U];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < U; ++u) {
             v4d t = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int s2 = 0; s2 < 4; ++s2) t = __builtin_amdgcn_mfma_f64_16x16x4f64(ia[s2], x[u][b][s2], t, 0, 0, 0);
             xs[u] = t;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) st_sc1(&C[(32 * wave + 16 * u + l15s) + (int64_t)(16 * b + l4s + 4 * r) * lda], t[r]);
+            for (int r = 0; r < 4; ++r) st_sc1(&C[(RW * wave + 16 * u + l15s) + (int64_t)(16 * b + l4s + 4 * r) * lda], t[r]);
         }
         // the next step only needs block column b + 1 brought up to date: that one before the panel is published, the others after
         // (the early steps carry up to 56 MFMAs per wave, 1.6 us, which the consumers of this panel need not wait for)
         if (b < 7) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+            for (int u = 0; u < U; ++u)
 #pragma unroll
                 for (int s2 = 0; s2 < 4; ++s2) x[u][b + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(-lq[b + 1][s2], xs[u][s2], x[u][b + 1], 0, 0, 0);
         }
@@ -567,141 +604,26 @@ __device__ __attribute__((noinline)) bool run_stream(const Args &a, Shared &sh, 
         // the start of P(c+1): trace r02)
         wg_drain();  // (also: every wave's LDS reads of this step's slot are in -- lq lives in registers from here on)
         if (threadIdx.x == 0) {
-            stf(sprog, (unsigned)(b + 1));
-            if (b == 7) stf(tdone_ic, 2u);
-            if (str) str[5] = wall_clock64();  // own panel b published
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = b + 2; q < 8; ++q)
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2) x[u][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-lq[q][s2], xs[u][s2], x[u][q], 0, 0, 0);
-    }
-    return true;
-}
-#else
-__device__ __attribute__((noinline)) bool run_stream(const Args &a, Shared &sh, const Job jb) {
-    const int64_t lda = uni64(a.lda);
-    double *const A = uni_ptr(a.A);
-    const int i = __builtin_amdgcn_readfirstlane(jb.i), c = __builtin_amdgcn_readfirstlane(jb.c);  // uniform: addresses and flags in SGPRs
-    // all left-looking panels but the newest (c - 1) through the GEMM loop, in place
-    if (!window_part<128>(a, sh, i, c, c > 0 ? c - 1 : 0, 0, nullptr)) return false;
-    JLOG(4);
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int l15 = lane & 15, l4 = lane >> 4;
-    double *C = A + (int64_t)i * NB + (int64_t)c * NB * lda;
-    const double *Lcc = A + (int64_t)c * NB + (int64_t)c * NB * lda;
-    const double *itg = uni_ptr(a.itg + (size_t)c * 8 * 256);
-    const unsigned *dprog = uni_ptr(a.dprog + (size_t)c * QSTRIDE);
-    unsigned *sprog = uni_ptr(a.sprog + ((size_t)(i - c - 1) * a.NT + c) * QSTRIDE);
-    v4d x[2][8];
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                x[u][q][r] = *(const gf64 *)&C[(32 * wave + 16 * u + l15) + (int64_t)(16 * q + l4 + 4 * r) * lda];
-    if (c > 0) {
-        // X -= L(i,c-1) L(c,c-1)', 16 columns at a time: L(c,c-1) is the first streamed tile of block column c-1, L(i,c-1) the
-        // (i-c+1)-th one, or -- the last S row -- a T tile that is awaited whole
-        const double *Lr = A + (int64_t)i * NB + (int64_t)(c - 1) * NB * lda;
-        const double *Lc = A + (int64_t)c * NB + (int64_t)(c - 1) * NB * lda;
-        const unsigned *fc = a.sprog + (size_t)(c - 1) * QSTRIDE;
-        const bool row_streamed = i - (c - 1) <= srows_at(c - 1, a.srows, a.edge);  // was tile (i, c-1) a streamed one?
-        const unsigned *fr = a.sprog + ((size_t)(i - c) * a.NT + (c - 1)) * QSTRIDE;
-        if (!row_streamed && !wg_wait(sh, a, a.tdone + (size_t)i * a.NT + (c - 1), 2u, nullptr, 0, nullptr, 0, 0x520u)) return false;
-        unsigned got = 0;
-#pragma unroll 1
-        for (int b = 0; b < 8; ++b) {
-            if (got < (unsigned)(b + 1)) {
-                got = row_streamed ? wg_wait_val2(sh, a, fr, fc, (unsigned)(b + 1), 0x510u) : wg_wait_val(sh, a, fc, (unsigned)(b + 1), 0x512u);
-                if (!got) return false;
+            stf(sprog0, (unsigned)(b + 1));
+            if (!HALF) stf(sprog1, (unsigned)(b + 1));
+            if (b == 7) {
+                if (HALF)
+                    addf(tdone_ic, 1u);  // the tile is final when both halves are
+                else
+                    stf(tdone_ic, 2u);
             }
-            double opc[8][4], opr[2][4];
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2) opr[u][s2] = *(const gf64 *)&Lr[(32 * wave + 16 * u + l15) + (int64_t)(16 * b + 4 * s2 + l4) * lda];
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-#pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2) opc[q][s2] = *(const gf64 *)&Lc[(16 * q + l15) + (int64_t)(16 * b + 4 * s2 + l4) * lda];
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-#pragma unroll
-                    for (int s2 = 0; s2 < 4; ++s2) x[u][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-opc[q][s2], opr[u][s2], x[u][q], 0, 0, 0);
-        }
-    }
-    unsigned long long *const strbase = (a.trace && i == c + 1) ? uni_ptr(a.trace + (size_t)a.NT * 16 + 4 * 1024 + (size_t)c * 64) : nullptr;
-    unsigned *const tdone_ic = uni_ptr(a.tdone + (size_t)i * a.NT + c);
-    unsigned have = 0;  // panels of the diagonal block known to be published
-#pragma unroll
-    for (int b = 0; b < 8; ++b) {
-        if (have < (unsigned)(b + 1)) {
-            have = wg_wait_val(sh, a, dprog, (unsigned)(b + 1), 0x500u);
-            if (!have) return false;
-        }
-        if (b == 0) JLOG(5);
-        if (b == 7) JLOG(6);
-        // per-step opaque copies of the lane coordinates: the store / operand addresses derived from them are otherwise computed
-        // once for all eight (unrolled) steps, spilled, and reloaded between the write-through stores behind s_waitcnt vmcnt(0)
-        int l15s = l15, l4s = l4;
-        asm volatile("" : "+v"(l15s), "+v"(l4s));
-        unsigned long long *str = strbase ? strbase + 8 * b : nullptr;
-        if (str && threadIdx.x == 0) str[0] = wall_clock64();  // panel b of the diagonal block seen
-        double ia[4];
-#pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2) ia[s2] = *(const gf64 *)&itg[b * 256 + (4 * s2 + l4s) * 16 + l15s];
-        double lq[8][4];
-#pragma unroll
-        for (int q = b + 1; q < 8; ++q)
-#pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2) lq[q][s2] = *(const gf64 *)&Lcc[(16 * q + l15s) + (int64_t)(16 * b + 4 * s2 + l4s) * lda];
-        v4d xs[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            v4d t = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2) t = __builtin_amdgcn_mfma_f64_16x16x4f64(ia[s2], x[u][b][s2], t, 0, 0, 0);
-            xs[u] = t;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) st_sc1(&C[(32 * wave + 16 * u + l15s) + (int64_t)(16 * b + l4s + 4 * r) * lda], t[r]);
-        }
-        // the next step only needs block column b + 1 brought up to date: that one before the panel is published, the others after
-        // (the early steps carry up to 56 MFMAs per wave, 1.6 us, which the consumers of this panel need not wait for)
-        if (b < 7) {
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2) x[u][b + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(-lq[b + 1][s2], xs[u][s2], x[u][b + 1], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // publish the finished 16-column panel, also when this job is only catching up with a diagonal block that is already
-        // complete: its consumers (the next diagonal job, the next column's streamed jobs) fold panel by panel at ~3 us each and
-        // would otherwise start all eight after this job's end (seen as 17-23 us instead of 3 us between the end of S(c+1,c) and
-        // the start of P(c+1): trace r02)
-        wg_drain();
-        if (threadIdx.x == 0) {
-            stf(sprog, (unsigned)(b + 1));
-            if (b == 7) stf(tdone_ic, 2u);
             if (str) str[5] = wall_clock64();  // own panel b published
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = b + 2; q < 8; ++q)
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+            for (int u = 0; u < U; ++u)
 #pragma unroll
                 for (int s2 = 0; s2 < 4; ++s2) x[u][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-lq[q][s2], xs[u][s2], x[u][q], 0, 0, 0);
     }
     return true;
 }
-#endif
 
 #define MEGA_STAMP(k)                                                          \
     do {                                                                       \
@@ -733,7 +655,6 @@ __device__ __attribute__((noinline)) bool run_diag(const Args &a, Shared &sh, co
     double *Linv = a.linv + (size_t)c * NB * NB;
     diagcore::v4d acc[diagcore::NSLOT6];
     diagcore::diag_v6_load(C, lda, acc);
-#ifndef MRBF_STREAM_V1
     // (round 4: the 16-column panels arrive by LDS-DMA, one panel ahead when the producer is ahead -- see run_stream.  Two slots in
     //  the first 37 KB of the workgroup's LDS: nothing the diagonal core touches before its first barrier lies there, so the leaf
     //  wave, which leaves the last step without waiting for the others, may start the core while they finish their tiles.)
@@ -743,7 +664,7 @@ __device__ __attribute__((noinline)) bool run_diag(const Args &a, Shared &sh, co
 #pragma unroll 1
         for (int pp = c - pstream; pp < c; ++pp) {
             const double *Lp = A + (int64_t)c * NB + (int64_t)pp * NB * lda;                       // tile (c, pp), produced by S(c, pp),
-            const unsigned *sprog = uni_ptr(a.sprog + ((size_t)(c - pp - 1) * a.NT + pp) * QSTRIDE);  // the (c-pp)-th streamed tile of column pp
+            const unsigned *sprog0 = uni_ptr(sprog_at(a, c - pp - 1, 0, pp)), *sprog1 = uni_ptr(sprog_at(a, c - pp - 1, 1, pp));  // the (c-pp)-th streamed tile of column pp, both halves
             auto issue_fold = [&](int b) {  // wave w: columns 4w .. 4w+3 of panel b
                 double *sl = ring + (b & 1) * PAN;
 #pragma unroll
@@ -756,7 +677,7 @@ __device__ __attribute__((noinline)) bool run_diag(const Args &a, Shared &sh, co
 #pragma unroll 1
             for (int b = 0; b < 8; ++b) {
                 if (have < b + 1) {
-                    const unsigned g = wg_wait_val(sh, a, sprog, (unsigned)(b + 1), 0x600u);
+                    const unsigned g = wg_wait_val4(sh, a, sprog0, sprog1, nullptr, nullptr, (unsigned)(b + 1), 0x600u);
                     if (!g) return false;
                     have = __builtin_amdgcn_readfirstlane((int)g);
                 }
@@ -795,43 +716,6 @@ __device__ __attribute__((noinline)) bool run_diag(const Args &a, Shared &sh, co
             }
         }
     }
-#else
-#pragma unroll 1
-    for (int pp = c - pstream; pp < c; ++pp) {
-        const double *Lp = A + (int64_t)c * NB + (int64_t)pp * NB * lda;                       // tile (c, pp), produced by S(c, pp),
-        const unsigned *sprog = uni_ptr(a.sprog + ((size_t)(c - pp - 1) * a.NT + pp) * QSTRIDE);  // the (c-pp)-th streamed tile of column pp
-        unsigned have = 0;  // 16-column panels of tile (c, pp) known to be published
-        // (operands straight from global memory into registers, per wave: staging the panel through LDS once per workgroup, with
-        //  the next panel prefetched, was slower -- two more barriers per panel and LDS operand latency in front of every MFMA)
-#pragma unroll 1
-        for (int b = 0; b < 8; ++b) {
-            if (have < (unsigned)(b + 1)) {
-                have = wg_wait_val(sh, a, sprog, (unsigned)(b + 1), 0x600u);
-                if (!have) return false;
-            }
-            double op[8][4];
-            // (the leaf wave's three tiles only need the first two row blocks: it is through its fold -- and, after the last panel,
-            //  into its first leaf -- while the others still work on their eleven tiles each)
-#pragma unroll
-            for (int xb = 0; xb < 8; ++xb)
-                if (xb < 2 || wave != 0) {
-#pragma unroll
-                    for (int s2 = 0; s2 < 4; ++s2) op[xb][s2] = *(const gf64 *)&Lp[(16 * xb + l15) + (int64_t)(16 * b + 4 * s2 + l4) * lda];
-                }
-#pragma unroll
-            for (int ti = 0; ti < 8; ++ti)
-#pragma unroll
-                for (int tj = 0; tj <= ti; ++tj) {
-                    if (diagcore::v6_owner(ti, tj) == wave) {
-#pragma unroll
-                        for (int s2 = 0; s2 < 4; ++s2)
-                            acc[diagcore::v6_slot(ti, tj)] =
-                                __builtin_amdgcn_mfma_f64_16x16x4f64(-op[tj][s2], op[ti][s2], acc[diagcore::v6_slot(ti, tj)], 0, 0, 0);
-                    }
-                }
-        }
-    }
-#endif
     MEGA_STAMP(2);
     JLOG(5);
     __builtin_amdgcn_s_setprio(3);
@@ -988,8 +872,14 @@ __device__ __forceinline__ void mega_body(const Args &a) {
     // the chain's panels written with plain stores and read from the L2 (0.3 us) were tried on top: only the LAST panel's hand-off of a
     // block column is on the critical path, -1 us of 36 per column, not kept.  MRBF_MEGA_XCHAIN=0: the old placement.
     const int bx = (int)blockIdx.x;
-    const bool chain = a.xchain ? ((bx & 7) == 0 && (bx >> 3) < a.nchain) : bx < a.nchain;
-    const bool dedicated = !chain && (a.xchain ? ((bx & 7) != 0 && bx - (bx >> 3) - 1 < a.ndedicated) : bx < a.nchain + a.ndedicated);
+    // xchain = 2 .. 8: the same on so many XCDs -- blocks = 0 .. xchain-1 (mod 8), the first workgroup of each of their CUs (blocks < 256)
+    // first, so that up to 32 xchain chain workgroups have a CU each.  (One XCD holds 32: a 64-workgroup chain on one XCD put two
+    // chain workgroups on every CU of it, and the half-height streamed jobs that need the 64 lost more to that than they gained.)
+    const int nx = a.xchain, cls = nx > 0 && (bx & 7) < nx;
+    const int cidx = !cls ? -1 : (bx < 256 ? (bx >> 3) * nx + (bx & 7) : 32 * nx + ((bx - 256) >> 3) * nx + (bx & 7));  // rank in the chain's placement class
+    const int oidx = nx == 0 ? bx - a.nchain : (cls ? -1 : (bx < 256 ? bx - ((bx >> 3) * nx + nx) : bx - 32 * nx - (((bx - 256) >> 3) * nx + nx)));  // rank outside it
+    const bool chain = nx ? (cls && cidx < a.nchain) : bx < a.nchain;
+    const bool dedicated = !chain && oidx >= 0 && oidx < a.ndedicated;
     if (chain || dedicated) __builtin_amdgcn_s_setprio(2);
     if (threadIdx.x == 0) {
         sh.wlo = 0;
@@ -1004,7 +894,7 @@ __device__ __forceinline__ void mega_body(const Args &a) {
     // reserve workgroups (same placement class as the chain): general workers in the throughput-bound middle, chain workgroups while the
     // chain queue is in the edge regime -- before job `head_job1` and from job `reserve_job0` on, where the machine has idle workgroups
     // anyway and five streamed rows per column need more hands than the middle's three
-    const bool reserve = !chain && a.xchain && (bx & 7) == 0 && (bx >> 3) < a.nchain + a.nreserve;
+    const bool reserve = !chain && cls && cidx < a.nchain + a.nreserve;
     bool in_chain = chain;
     if (reserve && threadIdx.x == 0) {
         const unsigned qc = ldf(a.ctl + CTL_QC);
@@ -1049,7 +939,9 @@ __device__ __forceinline__ void mega_body(const Args &a) {
             if (idx < 0) break;
             const Job jb = a.cjobs[idx];
             jlog_begin(a, sh, jb);
-            if (!(jb.kind == JOB_P ? (a.trace ? run_diag<true>(a, sh, jb) : run_diag<false>(a, sh, jb)) : run_stream(a, sh, jb))) break;
+            if (!(jb.kind == JOB_P ? (a.trace ? run_diag<true>(a, sh, jb) : run_diag<false>(a, sh, jb))
+                                   : (jb.w == 0 ? run_stream<false>(a, sh, jb) : run_stream<true>(a, sh, jb))))
+                break;
             jlog_end(sh);
         }
         if (a.use_quiet && threadIdx.x == 0) addf(myquiet, 0xffffffffu);
@@ -1199,8 +1091,14 @@ static void build_job_tables(int NT, int MT, int slack, int slack_chain, int fir
     for (int c = 0; c < NT; ++c) {
         cj.push_back(Job{JOB_P, (short)c, (short)c, (short)0});
         for (int i = c + 1; i < MT; ++i) {
-            if (i <= c + srows_at(c, srows, edge))
-                cj.push_back(Job{JOB_S, (short)i, (short)c, (short)0});
+            if (i <= c + srows_at(c, srows, edge)) {
+                if (shalf_at(c, srows, edge)) {  // two 64-row jobs (w = 1 + half)
+                    cj.push_back(Job{JOB_S, (short)i, (short)c, (short)1});
+                    cj.push_back(Job{JOB_S, (short)i, (short)c, (short)2});
+                } else {
+                    cj.push_back(Job{JOB_S, (short)i, (short)c, (short)0});
+                }
+            }
             else
                 for (int h = 0; h < 2; ++h) pj.push_back(Job{JOB_T, (short)i, (short)c, (short)h});
         }
@@ -1266,7 +1164,15 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
     // large matrices pays for (n = 8192: three rows, n >= 12288: two).  Environment / option values override.
     const int NTq = (int)(ncols / NB);
     const int srows_auto = NTq <= 48 ? 5 : (NTq <= 96 ? 3 : 2);
-    const int chain_auto = NTq <= 48 ? 32 : (NTq <= 96 ? 20 : 12);
+    // streamed tiles as 64-row halves where the whole factorisation is chain-bound (n <= 4096), with twice the chain workgroups (each
+    // on a CU of its own: four XCDs).  Measured r04 (tools/sweep_shalf.sh): n = 1024 / 2048 / 3072 / 4096: -8.6 / -10 / -9 /
+    // -6 %; n >= 6144: the halves cost more matrix-pipe time than the chain gains (in the last 16 block columns only: -2.6 .. 0 %).
+    static const int env_shalf = getenv("MRBF_MEGA_SHALF") ? atoi(getenv("MRBF_MEGA_SHALF")) : -1;
+    static const int env_shalf_head = getenv("MRBF_MEGA_SHALF_HEAD") ? atoi(getenv("MRBF_MEGA_SHALF_HEAD")) : -1;
+    const int sh_tail = env_shalf >= 0 ? env_shalf : (NTq <= 40 ? 1 << 20 : 0), sh_head = env_shalf_head >= 0 ? env_shalf_head : 0;
+    const bool shalf_all = sh_tail >= NTq;
+    // (n = 4608 / 5120 with 48 chain workgroups on two XCDs: -9 / -8 %, with 64 on four: -7 / -6 %; n = 6144: +4 %, left alone)
+    const int chain_auto = NTq <= 48 ? (shalf_all ? (NTq <= 32 ? 64 : 48) : 32) : (NTq <= 96 ? 20 : 12);
     const int slack_chain_auto = (NTq > 48 && NTq <= 96) ? 7 : 6;
     const int slack = std::max(1, ctx->mega_slack), slack_chain = std::max(slack, ctx->mega_slack_chain > 0 ? ctx->mega_slack_chain : slack_chain_auto);
     // longer windows for large matrices (measured: n = 16384: 33.8 / 31.7 / 30.8 ms with 4 / 6 / 8 panels per window; n = 8192: the same)
@@ -1287,6 +1193,12 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
         edge.head = (srows < edge.srows_edge) ? std::min(head, NT) : 0;
         edge.tail_c0 = (srows < edge.srows_edge) ? std::max(edge.head, NT - tail) : NT;
     }
+    {
+        // streamed tiles as 64-row halves: the last `MRBF_MEGA_SHALF` block columns (and the first MRBF_MEGA_SHALF_HEAD)
+        edge.shalf = (sh_tail > 0 || sh_head > 0) ? 1 : 0;
+        edge.sh_head = std::min(sh_head, NT);
+        edge.sh_tail_c0 = std::max(edge.sh_head, NT - sh_tail);
+    }
     const int srows_max = std::max(srows, (edge.head > 0 || edge.tail_c0 < NT) ? edge.srows_edge : srows);
     // job tables: one set per (NT, MT, schedule parameters), kept in a small per-context LRU -- Morbit's training sets grow and shrink
     // by a few sites between iterations, so n keeps crossing 128-boundaries back and forth; rebuilding the tables on every change
@@ -1303,9 +1215,10 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
     const int tail_half_w = env_tail_half_w >= 0 ? env_tail_half_w : 1000;  // only the last so many window updates of such a tile
     const long tab_key = (chainq ? 50 : 0) + slack + 100000000000000L * tail_half + 10000000000000000L * std::min(tail_half_w, 99) + 100 * ctx->mega_half_cols + 10000 * slack_chain + 1000000 * first + 10000000 * win + 100000000 * (long)srows +
                          1000000000L * edge.head + 1000000000000L * edge.tail_c0;
+    const long tab_key2 = edge.shalf ? 1 + edge.sh_head + 1000L * edge.sh_tail_c0 : 0;
     MegaTables *tab = nullptr;
     for (auto &t : ctx->mega_tables)
-        if (t.nt == NT && t.mt == MT && t.key == tab_key) tab = &t;
+        if (t.nt == NT && t.mt == MT && t.key == tab_key && t.key2 == tab_key2) tab = &t;
     if (!tab) {
         std::vector<Job> pj, bj, cj;
         std::vector<int> wqs;
@@ -1322,6 +1235,7 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
         t.nt = NT;
         t.mt = MT;
         t.key = tab_key;
+        t.key2 = tab_key2;
         t.npanel = (int)pj.size();
         t.nbulk = (int)bj.size();
         t.nchainjobs = (int)cj.size();
@@ -1359,7 +1273,7 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
     a.nwin = ctx->mega_nwin;
     a.wq_start = (int *)tab->wq;
     // flags: one block, zeroed before every launch
-    const size_t nfl = ((size_t)CTL_WORDS + (size_t)QSTRIDE * (2 * a.nwin + 1) + (size_t)QSTRIDE * 512 + (size_t)QSTRIDE * (1 + srows_max) * NT + 2 * (size_t)MT * NT + 3) / 4 * 4;
+    const size_t nfl = ((size_t)CTL_WORDS + (size_t)QSTRIDE * (2 * a.nwin + 1) + (size_t)QSTRIDE * 512 + (size_t)QSTRIDE * (1 + 2 * srows_max) * NT + 2 * (size_t)MT * NT + 3) / 4 * 4;
     unsigned *fl;
     MRBF_TRY(get_buf(ctx, S_MEGA_FLAGS, nfl, &fl));
     hnow();  // 1: buffers / job tables
@@ -1372,7 +1286,7 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
     a.quiet = a.wq_head + (size_t)QSTRIDE * (2 * a.nwin + 1);
     a.dprog = a.quiet + (size_t)QSTRIDE * 512;
     a.sprog = a.dprog + (size_t)QSTRIDE * NT;
-    a.tdone = a.sprog + (size_t)QSTRIDE * srows_max * NT;
+    a.tdone = a.sprog + (size_t)QSTRIDE * 2 * srows_max * NT;
     a.ucnt = a.tdone + (size_t)MT * NT;
     a.info = dinfo;
     a.nchain = ctx->mega_chain > 0 ? ctx->mega_chain : chain_auto;
@@ -1392,13 +1306,15 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
         int job = 0;
         a.head_job1 = 0;
         a.reserve_job0 = 1 << 30;
-        const int lead_c0 = std::max(edge.head, edge.tail_c0 - 3);
+        // (edge columns here: those of the edge regime and those whose streamed tiles are halved -- twice the chain jobs per column)
+        const int e_head = std::max(edge.head, edge.shalf ? edge.sh_head : 0), e_tail_c0 = std::min(edge.tail_c0, edge.shalf ? edge.sh_tail_c0 : NT);
+        const int lead_c0 = std::max(e_head, e_tail_c0 - 3);
         for (int c = 0; c <= NT; ++c) {
-            if (c == edge.head) a.head_job1 = job;
-            if (c == lead_c0 && edge.tail_c0 < NT) a.reserve_job0 = job;
-            if (c < NT) job += 1 + std::min(srows_at(c, srows, edge), MT - 1 - c);
+            if (c == e_head) a.head_job1 = job;
+            if (c == lead_c0 && e_tail_c0 < NT) a.reserve_job0 = job;
+            if (c < NT) job += 1 + (shalf_at(c, srows, edge) ? 2 : 1) * std::min(srows_at(c, srows, edge), MT - 1 - c);
         }
-        a.nreserve = (edge.head > 0 || edge.tail_c0 < NT) ? (env_reserve >= 0 ? env_reserve : 12) : 0;
+        a.nreserve = (e_head > 0 || e_tail_c0 < NT) ? (env_reserve >= 0 ? env_reserve : 12) : 0;
     }
     a.pstream = ctx->mega_pstream > 0 ? std::min(ctx->mega_pstream, srows) : (NTq <= 48 && srows >= 2 ? 2 : 1);
     a.spin_ticks = (unsigned long long)std::max(1, ctx->spin_ms) * 100000ull;  // wall_clock64 runs at 100 MHz
@@ -1408,8 +1324,9 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
     if (a.nchain < 1) a.nchain = 1;
     if (a.nchain + a.ndedicated >= grid) a.ndedicated = std::max(0, grid / 2 - a.nchain);
     {
-        static const int xc = getenv("MRBF_MEGA_XCHAIN") ? atoi(getenv("MRBF_MEGA_XCHAIN")) : 1;
-        a.xchain = (xc && 8 * a.nchain <= grid) ? 1 : 0;  // enough blocks = 0 (mod 8) for the chain
+        static const int env_xc = getenv("MRBF_MEGA_XCHAIN") ? atoi(getenv("MRBF_MEGA_XCHAIN")) : -1;
+        const int xc = env_xc >= 0 ? env_xc : (a.nchain > 48 ? 4 : (a.nchain > 32 ? 2 : 1));
+        a.xchain = (xc > 0 && 8 * a.nchain <= std::min(xc, 8) * grid) ? std::min(xc, 8) : 0;  // enough blocks = 0 .. xc-1 (mod 8) for the chain
         // (n = 16384: the CU partners of the 12 chain workgroups join the bulk work until 32 block columns are left: 27.0 -> 26.5 ms;
         //  at n <= 8192 the chain is never far from critical and pausing the partners throughout is as good or better)
         static const int qt = getenv("MRBF_MEGA_QUIET_TAIL") ? atoi(getenv("MRBF_MEGA_QUIET_TAIL")) : -1;
@@ -1540,8 +1457,10 @@ static int32_t check_mega_tables(int nt, int mt, int slack, int slack_chain, int
             ++bad;
             continue;
         }
-        fin[(size_t)j.i * nt + j.c] += 2;
-        if (j.kind == JOB_P ? j.i != j.c : (j.kind != JOB_S || j.i <= j.c || j.i > j.c + sr(j.c))) ++bad;
+        fin[(size_t)j.i * nt + j.c] += (j.kind == JOB_S && j.w != 0) ? 1 : 2;  // a streamed tile: one 128-row job or two 64-row ones
+        if (j.kind == JOB_P ? j.i != j.c : (j.kind != JOB_S || j.i <= j.c || j.i > j.c + sr(j.c) || j.w < 0 || j.w > 2 ||
+                                            (j.w != 0) != shalf_at(j.c, srows, edge)))
+            ++bad;
     }
     for (const Job &j : pj) {
         if (j.kind != JOB_T || j.c >= nt || j.i <= j.c + sr(j.c) || j.i >= mt || (j.w != 0 && j.w != 1)) {
@@ -1593,7 +1512,7 @@ extern "C" int32_t mrbf_debug_mega_tables(int32_t nt, int32_t mt, int32_t slack,
     if (nt < 1 || mt < nt || mt > 32000) return -1;
     if (slack < 1 || slack_chain < slack || win < 1 || first < 1 || first > win || srows < 0 || half_cols < 0) return -3;
     if (!out) return -9;
-    const mrbf::mega::Edge no_edge{0, nt, srows, 1};
+    const mrbf::mega::Edge no_edge{0, nt, srows, 1, 0};
     return check_mega_tables(nt, mt, slack, slack_chain, first, win, srows, no_edge, half_cols, 0, 0, false, out);
 }
 
@@ -1612,5 +1531,8 @@ extern "C" int32_t mrbf_debug_mega_tables2(int32_t nt, int32_t mt, int32_t slack
     edge.pstream_edge = 2;
     edge.head = srows < edge.srows_edge ? std::min(opt5[0], nt) : 0;
     edge.tail_c0 = srows < edge.srows_edge ? std::max(edge.head, nt - opt5[1]) : nt;
-    return check_mega_tables(nt, mt, slack, slack_chain, first, win, srows, edge, half_cols, opt5[2], opt5[3] > 0 ? opt5[3] : 1000, opt5[4] != 0, out);
+    edge.shalf = (opt5[4] & 2) ? 1 : 0;  // (bit 1 of the last option: streamed tiles of five-row block columns as 64-row halves;
+    edge.sh_head = (opt5[4] >> 2) & 0xff;  //  bits 2..9 / 10..17: only the first / last so many block columns, 0 / 0 = all)
+    edge.sh_tail_c0 = (opt5[4] >> 10) ? std::max(edge.sh_head, nt - ((opt5[4] >> 10) & 0xff)) : (edge.sh_head ? nt : 0);
+    return check_mega_tables(nt, mt, slack, slack_chain, first, win, srows, edge, half_cols, opt5[2], opt5[3] > 0 ? opt5[3] : 1000, (opt5[4] & 1) != 0, out);
 }

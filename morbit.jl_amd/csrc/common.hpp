@@ -48,7 +48,7 @@ namespace mrbf {
 // job tables of the persistent factorisation for one shape (chol_mega.hip), device resident
 struct MegaTables {
     int nt, mt;
-    long key;
+    long key, key2 = 0;
     void *block, *jobs, *wq;
     int npanel, nbulk, nchainjobs, nwin;
     unsigned long long stamp;

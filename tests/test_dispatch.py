@@ -326,6 +326,17 @@ def test_mega_job_tables_are_consistent():
         nt, mt = c[0], c[1]
         tiles = sum(mt - cc for cc in range(nt))
         assert out[2] + out[0] // 2 == tiles, (c, o, list(out))  # every tile finished by one chain job or two panel halves
+    # streamed tiles of five-row block columns as two 64-row jobs (bit 1 of the last option): one extra chain job per such tile
+    half_cases = [((32, 33, 3, 6, 1, 4, 5, 0), (0, 16, 20, 0, 2), range(32)), ((64, 65, 3, 7, 1, 6, 3, 0), (8, 16, 20, 0, 3), list(range(8)) + list(range(48, 64))),
+                  ((64, 65, 3, 7, 1, 6, 3, 0), (0, 0, 0, 0, 2), []), ((5, 5, 1, 1, 1, 1, 5, 0), (0, 0, 0, 0, 2), range(5)), ((16, 20, 3, 6, 1, 4, 5, 1), (0, 0, 8, 0, 3), range(16))]
+    for c, o, cols in half_cases:
+        opt = (ctypes.c_int32 * 5)(*o)
+        assert lib.mrbf_debug_mega_tables2(*c, opt, out) == 0, (c, o)
+        assert out[5] == 0, (c, o, list(out))
+        nt, mt = c[0], c[1]
+        tiles = sum(mt - cc for cc in range(nt))
+        extra = sum(min(5, mt - 1 - cc) for cc in cols)
+        assert out[2] + out[0] // 2 == tiles + extra, (c, o, list(out))
     opt = (ctypes.c_int32 * 5)(0, 0, 0, 0, 0)
     for c in cases[:6]:  # without options: the same tables as the plain entry point
         assert lib.mrbf_debug_mega_tables2(*c, opt, out) == 0 and out[4] == seen[c], c

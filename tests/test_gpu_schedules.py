@@ -22,6 +22,10 @@ VARIANTS = [
     {"MRBF_MEGA_CHAINQ": "1", "MRBF_MEGA_CBOOST": "8"},
     {"MRBF_MEGA_CHAINQ": "1", "MRBF_MEGA_HALF_COLS": "3", "MRBF_MEGA_WIN": "3", "MRBF_MEGA_SLACK": "2", "MRBF_MEGA_SLACK_CHAIN": "4"},
     {"MRBF_MEGA_SROWS": "2", "MRBF_MEGA_PSTREAM": "1", "MRBF_MEGA_CHAIN": "12", "MRBF_MEGA_TAIL": "20"},
+    {"MRBF_MEGA_SHALF": "0"},                                                 # streamed tiles as 128-row jobs everywhere
+    {"MRBF_MEGA_SHALF": "12", "MRBF_MEGA_SHALF_HEAD": "3", "MRBF_MEGA_RESERVE": "40", "MRBF_MEGA_XCHAIN": "2"},  # halves at the edges only
+    {"MRBF_MEGA_SHALF": "99", "MRBF_MEGA_CHAIN": "96", "MRBF_MEGA_XCHAIN": "8"},
+    {"MRBF_MEGA_SHALF": "99", "MRBF_MEGA_CHAIN": "40", "MRBF_MEGA_XCHAIN": "0"},
 ]
 
 
