@@ -7,6 +7,9 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I/opt/rocm/include -I../../morbit.jl_amd/csrc -I../../include -o leafbench leafbench.hip
 #include "chol_diag_core.hpp"
 
+#ifndef DPPV
+#define DPPV 0
+#endif
 #include <cmath>
 #include <cstdio>
 #include <vector>
@@ -158,6 +161,133 @@ __global__ __launch_bounds__(64) void klds(const double *A, double *out, unsigne
     if (lane == 0) ts[7] = t1 - t0;
 }
 
+// Round 4 (second try): multipliers by DPP.  v_fmac_f64 has a DPP form on gfx90a+ whose only control is row_newbcast:J (lane J of each
+// row of 16 lanes to the whole row): with column K of the leaf duplicated into lanes 16..31 (v_permlane16_swap_b32, gfx950) the update
+// of column J for the leaf rows AND the identity rows is ONE instruction, a[J] += (-m[row_newbcast:J]) * a[K], instead of two
+// v_readlane + s_nop + fma; the pivot comes the same way (v_mov_b64_dpp row_newbcast:K).  DPP reads need two wait states after the
+// VALU write of their source: the producers below end with s_nop 1 (inline asm: nothing inserts it for us).
+template <int K, int V = DPPV>
+__device__ __forceinline__ void dpp_step(double (&a)[16], int &bad, int col0) {
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    const unsigned alo = (unsigned)__double2loint(a[K]), ahi = (unsigned)__double2hiint(a[K]);
+    const u2 slo = __builtin_amdgcn_permlane16_swap(alo, alo, false, false);  // [0]: rows 1, 3 <- rows 0, 2 of the second operand
+    const u2 shi = __builtin_amdgcn_permlane16_swap(ahi, ahi, false, false);
+    const double x = __hiloint2double((int)shi[0], (int)slo[0]);  // column K of the leaf rows, in lanes 0..15 and again in lanes 16..31
+    double piv;
+    if constexpr (V == 0)
+        asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(piv) : "v"(x), "n"(K));
+    else
+        piv = diagcore::readlane_f64(a[K], K);  // (not behind the duplication)
+    const double rinv = diagcore::fast_rsqrt_v4(piv);
+    bad = (!(piv > 0.0) && bad == 0) ? col0 + K + 1 : bad;
+    a[K] *= rinv;
+    if constexpr (K < 15) {
+        double m;
+        asm("v_mul_f64 %0, %1, %2\n\ts_nop 1" : "=v"(m) : "v"(x), "v"(rinv));
+#pragma unroll
+        for (int j = K + 1; j < 16; ++j)
+            asm("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a[j]) : "v"(m), "v"(a[K]), "n"(j));
+    }
+}
+__global__ __launch_bounds__(64) void kdpp(const double *A, double *out, unsigned long long *ts, int reps) {
+    const int lane = threadIdx.x;
+    double a0[16], acc = 0.0;
+    for (int c = 0; c < 16; ++c) a0[c] = lane < 16 ? (c <= lane ? A[lane + 16 * c] : 0.0) : (c == lane - 16 ? 1.0 : 0.0);
+    int bad = 0;
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < reps; ++it) {
+        double a[16];
+        for (int c = 0; c < 16; ++c) a[c] = a0[c];
+        dpp_step<0>(a, bad, 0); dpp_step<1>(a, bad, 0); dpp_step<2>(a, bad, 0); dpp_step<3>(a, bad, 0);
+        dpp_step<4>(a, bad, 0); dpp_step<5>(a, bad, 0); dpp_step<6>(a, bad, 0); dpp_step<7>(a, bad, 0);
+        dpp_step<8>(a, bad, 0); dpp_step<9>(a, bad, 0); dpp_step<10>(a, bad, 0); dpp_step<11>(a, bad, 0);
+        dpp_step<12>(a, bad, 0); dpp_step<13>(a, bad, 0); dpp_step<14>(a, bad, 0); dpp_step<15>(a, bad, 0);
+        if (it == reps - 1)
+            for (int c = 0; c < 16; ++c) out[64 + lane * 16 + c] = a[c];
+        for (int c = 0; c < 16; ++c) acc += a[c];
+        a0[0] += acc * 1e-300;
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    out[lane] = acc + bad;
+    if (lane == 0) ts[4] = t1 - t0;  // (slot of the 4x4x4 variant, which is not launched any more)
+}
+
+// DPP leaf, hand-ordered (every instruction an asm volatile, so the order below IS the issue order): a wave issues in order, and
+// the compiler's order above puts the 15 - K updates column K-1 still owes between v_rsq and the Newton step of column K.  Here the owed
+// updates fill the latency gaps of the pivot chain instead (latbench: dependent v_mul/v_fma_f64 9.5 cycles, v_rsq_f64 21, a DPP
+// read 15 after the write; issue 6 per f64 instruction).
+template <int KP, int J>
+__device__ __forceinline__ void fm(double (&a)[16], const double &m) {
+    asm volatile("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(a[J]) : "v"(m), "v"(a[KP]), "n"(J));
+}
+// the IDX-th update column K-1 owes (to column K + 1 + IDX); returns nothing when there is none
+template <int K, int IDX>
+__device__ __forceinline__ void owed(double (&a)[16], const double &mprev) {
+    if constexpr (K >= 1 && K + 1 + IDX <= 15) fm<(K >= 1 ? K - 1 : 0), (K + 1 + IDX <= 15 ? K + 1 + IDX : 15)>(a, mprev);
+}
+template <int K>
+__device__ __forceinline__ void dpp2_step(double (&a)[16], double &mprev, int &bad, int col0, const double c15) {
+    constexpr int nowed = K >= 1 ? 14 - K : 0;  // updates column K-1 owes to the columns K+1 .. 15
+    int plo, phi;
+    asm volatile("v_readlane_b32 %0, %2, %4\n\tv_readlane_b32 %1, %3, %4" : "=s"(plo), "=s"(phi) : "v"(__double2loint(a[K])), "v"(__double2hiint(a[K])), "n"(K));
+    int xlo = __double2loint(a[K]), xhi = __double2hiint(a[K]), ylo = xlo, yhi = xhi;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %2\n\tv_permlane16_swap_b32 %1, %3" : "+v"(xlo), "+v"(xhi), "+v"(ylo), "+v"(yhi));
+    const double x = __hiloint2double(xhi, xlo);  // column K of the leaf rows in lanes 0..15 and again in lanes 16..31
+    const double piv = __hiloint2double(phi, plo);
+    double r, h, r2, m0, ak0, c, m;
+    asm volatile("v_rsq_f64 %0, %1" : "=v"(r) : "s"(piv));
+    asm volatile("v_mul_f64 %0, %1, -0.5" : "=v"(h) : "s"(piv));
+    owed<K, 0>(a, mprev);
+    owed<K, 1>(a, mprev);
+    owed<K, 2>(a, mprev);
+    asm volatile("s_nop 0\n\tv_mul_f64 %0, %1, %1" : "=v"(r2) : "v"(r));
+    asm volatile("v_mul_f64 %0, %1, %2" : "=v"(m0) : "v"(x), "v"(r));
+    asm volatile("v_mul_f64 %0, %1, %2" : "=v"(ak0) : "v"(a[K]), "v"(r));
+    asm volatile("v_fma_f64 %0, %1, %2, %3" : "=v"(c) : "v"(h), "v"(r2), "v"(c15));
+    owed<K, 3>(a, mprev);
+    asm volatile("v_mul_f64 %0, %1, %2" : "=v"(m) : "v"(m0), "v"(c));
+    asm volatile("v_mul_f64 %0, %1, %2" : "=v"(a[K]) : "v"(ak0), "v"(c));
+    if constexpr (nowed >= 6) {
+        owed<K, 4>(a, mprev);
+        owed<K, 5>(a, mprev);
+    } else {
+        asm volatile("s_nop 1");
+    }
+    if constexpr (K < 15) fm<K, (K < 15 ? K + 1 : 15)>(a, m);
+    if constexpr (nowed < 6) {
+        owed<K, 4>(a, mprev);
+        owed<K, 5>(a, mprev);
+    }
+    owed<K, 6>(a, mprev); owed<K, 7>(a, mprev); owed<K, 8>(a, mprev); owed<K, 9>(a, mprev);
+    owed<K, 10>(a, mprev); owed<K, 11>(a, mprev); owed<K, 12>(a, mprev); owed<K, 13>(a, mprev);
+    bad = (!(piv > 0.0) && bad == 0) ? col0 + K + 1 : bad;
+    mprev = m;
+}
+__global__ __launch_bounds__(64) void kdpp2(const double *A, double *out, unsigned long long *ts, int reps) {
+    const int lane = threadIdx.x;
+    double a0[16], acc = 0.0;
+    for (int c = 0; c < 16; ++c) a0[c] = lane < 16 ? (c <= lane ? A[lane + 16 * c] : 0.0) : (c == lane - 16 ? 1.0 : 0.0);
+    int bad = 0;
+    double c15 = 1.5;
+    asm volatile("" : "+v"(c15));
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < reps; ++it) {
+        double a[16], mp = 0.0;
+        for (int c = 0; c < 16; ++c) a[c] = a0[c];
+        dpp2_step<0>(a, mp, bad, 0, c15); dpp2_step<1>(a, mp, bad, 0, c15); dpp2_step<2>(a, mp, bad, 0, c15); dpp2_step<3>(a, mp, bad, 0, c15);
+        dpp2_step<4>(a, mp, bad, 0, c15); dpp2_step<5>(a, mp, bad, 0, c15); dpp2_step<6>(a, mp, bad, 0, c15); dpp2_step<7>(a, mp, bad, 0, c15);
+        dpp2_step<8>(a, mp, bad, 0, c15); dpp2_step<9>(a, mp, bad, 0, c15); dpp2_step<10>(a, mp, bad, 0, c15); dpp2_step<11>(a, mp, bad, 0, c15);
+        dpp2_step<12>(a, mp, bad, 0, c15); dpp2_step<13>(a, mp, bad, 0, c15); dpp2_step<14>(a, mp, bad, 0, c15); dpp2_step<15>(a, mp, bad, 0, c15);
+        if (it == reps - 1)
+            for (int c = 0; c < 16; ++c) out[64 + lane * 16 + c] = a[c];
+        for (int c = 0; c < 16; ++c) acc += a[c];
+        a0[0] += acc * 1e-300;
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    out[lane] = acc + bad;
+    if (lane == 0) ts[3] = t1 - t0;  // (slot of the 16x16x4 chain variant, not launched any more)
+}
+
 template <int V, int K>
 __device__ __forceinline__ void step(v4d &T, v4d &Y, v4d &Lr, v4d &Yf, double &ps, double &pu, int &bad, int l15, int l4) {
     constexpr int g = K & 3, r = K >> 2;
@@ -252,8 +382,6 @@ int main() {
     hipLaunchKernelGGL(k<0>, dim3(1), dim3(64), 0, 0, dA, dout, dts, reps);
     hipLaunchKernelGGL(k<1>, dim3(1), dim3(64), 0, 0, dA, dout, dts, reps);
     hipLaunchKernelGGL(k<2>, dim3(1), dim3(64), 0, 0, dA, dout, dts, reps);
-    hipLaunchKernelGGL(k<3>, dim3(1), dim3(64), 0, 0, dA, dout, dts, reps);
-    hipLaunchKernelGGL(k<4>, dim3(1), dim3(64), 0, 0, dA, dout, dts, reps);
     hipLaunchKernelGGL(kold, dim3(1), dim3(64), 0, 0, dA, dout, dts, reps);
     double ref[64], got[64];
     static double fref[64 * 16], fgot[64 * 16];
@@ -280,9 +408,37 @@ int main() {
                 if (fabs(fref[l * 16 + c] - fgot[l * 16 + c]) > 1e-12 && shown++ < 12) printf("  lane %d col %d: %.6e vs %.6e\n", l, c, fref[l * 16 + c], fgot[l * 16 + c]);
     }
     hipDeviceSynchronize();
+    hipLaunchKernelGGL(kdpp, dim3(1), dim3(64), 0, 0, dA, dout, dts, reps);
+    hipDeviceSynchronize();
+    hipMemcpy(fgot, dout + 64, 64 * 16 * 8, hipMemcpyDeviceToHost);
+    {
+        int shown = 0;
+        double worst = 0;
+        for (int l = 0; l < 32; ++l)
+            for (int c = 0; c < 16; ++c) {
+                if (l < 16 && c > l) continue;  // (above the diagonal of the leaf rows: not part of the result)
+                worst = fmax(worst, fabs(fref[l * 16 + c] - fgot[l * 16 + c]));
+                if (!(fabs(fref[l * 16 + c] - fgot[l * 16 + c]) <= 1e-12) && shown++ < 12) printf("  lane %d col %d: %.6e vs %.6e\n", l, c, fref[l * 16 + c], fgot[l * 16 + c]);
+            }
+        printf("DPP leaf vs round-1 leaf: max absolute difference of L and its inverse %.2e\n", worst);
+    }
+    hipLaunchKernelGGL(kdpp2, dim3(1), dim3(64), 0, 0, dA, dout, dts, reps);
+    hipDeviceSynchronize();
+    hipMemcpy(fgot, dout + 64, 64 * 16 * 8, hipMemcpyDeviceToHost);
+    {
+        int shown = 0;
+        double worst = 0;
+        for (int l = 0; l < 32; ++l)
+            for (int c = 0; c < 16; ++c) {
+                if (l < 16 && c > l) continue;
+                worst = fmax(worst, fabs(fref[l * 16 + c] - fgot[l * 16 + c]));
+                if (!(fabs(fref[l * 16 + c] - fgot[l * 16 + c]) <= 1e-12) && shown++ < 12) printf("  lane %d col %d: %.6e vs %.6e\n", l, c, fref[l * 16 + c], fgot[l * 16 + c]);
+            }
+        printf("hand-ordered DPP leaf vs round-1 leaf: max absolute difference of L and its inverse %.2e\n", worst);
+    }
     unsigned long long ts[8];
     hipMemcpy(ts, dts, 64, hipMemcpyDeviceToHost);
-    const char *names[8] = {"full step (T and Y mfma)", "no inverse", "readlane -> mul -> mfma", "mul -> mfma 16x16x4", "mul -> mfma 4x4x4", "round-1 leaf (readlane, with inverse)", "round-1 leaf, hand-scheduled", "leaf with LDS-broadcast multipliers (r4)"};
+    const char *names[8] = {"full step (T and Y mfma)", "no inverse", "readlane -> mul -> mfma", "DPP leaf, hand-ordered (r4)", "leaf with DPP multipliers (r4)", "round-1 leaf (readlane, with inverse)", "round-1 leaf, hand-scheduled", "leaf with LDS-broadcast multipliers (r4)"};
     for (int v = 0; v < 8; ++v) printf("%-28s %.1f cycles per column step\n", names[v], (double)ts[v] / reps / 16);
     return 0;
 }
