@@ -721,6 +721,228 @@ __global__ __launch_bounds__(256, 1) void small_fit_kernel(Prob one, const Prob 
     }
 }
 
+// ---- tail basis of the launch chain (n > 512, d <= 64, k <= 16): three launches ------------------------------------------------------
+// What solve.hip needs in front of the projection -- Q1 = [1/sqrt n | Xc Lx^-T] (Cholesky-QR of the centred coordinates), inv(Lx),
+// T1 = Q1' Y, B = Y - Q1 T1 and the right-hand sides as extra rows of the matrix -- was a chain of twelve launches (memset, copy of Xc
+// below its Gram matrix, Xc'Xc in two, identity padding, memset, 128-wide diagonal kernel, panel solve, Q1, Q1'Y, B, extra rows:
+// 156 us at n = 2048, longer than the Gram kernel it is meant to hide under; every link a 3-40 us launch).  Here:
+//   tailq_gram_kernel    partial sums over row chunks of  Xc' [Xc | Y | 1]          (np workgroups)
+//   tailq_factor_kernel  fixed-order sum, Lx and inv(Lx) (the diagonal-block routines of the one-launch fit), T1 = [1'Y / sqrt n ;
+//                        inv(Lx) Xc'Y] -- Q1' Y without Q1                                                     (one workgroup)
+//   tailq_q1_kernel      per 64 rows: Qx = Xc inv(Lx)', Q1, B = Y - Q1 T1, the extra rows                      (npad / 64 workgroups)
+struct TailQ {
+    const double *Xc, *Y;
+    int n, npad, d, dpad, q, k;
+    int np, rows;       // partial sums: np <= 32 chunks of `rows` rows (a multiple of 16)
+    double *part;       // [np][TQ_PS]: lower tiles of Xc'Xc as [a + 64 b] | Xc'Y as 4096 + [c + 64 l] | 1'Y as 4096 + 1024 + [l]
+    double *Gx, *LinvX; // 128 x 128, identity padded
+    double *T1;         // q x k, column-major
+    double *Q1, *B;     // npad x q, npad x k
+    double *rows_out;   // the matrix: right-hand sides as rows npad .. npad + xt - 1 (nullptr: none)
+    int64_t ld;
+    int xt;
+    int *flags;
+    double rsn;
+};
+constexpr int TQ_PS = 4096 + 1024 + 16;
+
+__global__ __launch_bounds__(256) void tailq_gram_kernel(TailQ t) {
+    __shared__ double red[4];
+    __shared__ double part4[4][64];
+    const int tid = threadIdx.x, p = blockIdx.x;
+    const int n16 = (t.n + 15) & ~15, d16 = (t.d + 15) & ~15;
+    const int r0 = p * t.rows, r1 = min(r0 + t.rows, n16), K = max(r1 - r0, 0);
+    double *out = t.part + (size_t)p * TQ_PS;
+    const double *X0 = t.Xc + (int64_t)r0 * t.dpad;
+    if (K > 0) {
+        wg_gemm<false, true, true>(d16, d16, K, X0, t.dpad, X0, t.dpad, NoPre(), [&](int a, int b, double v, double) { gst(&out[a + 64 * b], v); });
+    } else {
+        for (int e = tid; e < 4096; e += 256) gst(&out[e], 0.0);
+    }
+    // Xc' Y and 1' Y of the chunk: thread (c, g) takes rows r0 + g, r0 + g + 4, ..; the four groups are added in a fixed order
+    const int c = tid & 63, g = tid >> 6;
+    const int rend = min(r1, t.n);
+    for (int l = 0; l < t.k; ++l) {
+        double s = 0.0, sy = 0.0;
+        for (int i0 = r0 + g; i0 < rend; i0 += 32) {  // eight rows' loads in flight (a load per iteration is a memory round trip each)
+            double xv[8], yv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + 4 * u < rend ? i0 + 4 * u : i0;
+                xv[u] = gld(&X0[(int64_t)(i - r0) * t.dpad + c]);
+                yv[u] = gld(&t.Y[(int64_t)i * t.k + l]);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (i0 + 4 * u < rend) {
+                    s = fma(xv[u], yv[u], s);
+                    sy += yv[u];
+                }
+        }
+        __syncthreads();
+        part4[g][c] = s;
+        if (c == 0) red[g] = sy;
+        __syncthreads();
+        if (g == 0) gst(&out[4096 + c + 64 * l], (part4[0][c] + part4[1][c]) + (part4[2][c] + part4[3][c]));
+        if (tid == 0) gst(&out[4096 + 1024 + l], (red[0] + red[1]) + (red[2] + red[3]));
+    }
+}
+
+// Cholesky factor and its inverse of an m x m s.p.d. matrix, m <= 64, by one workgroup in registers: thread (i, w) = (tid & 63,
+// tid >> 6) holds the entries (i, 4 u + w), u = 0 .. 15, of G and of E (starts as the identity).  Column k of [G ; E] is published
+// unscaled through LDS (double buffered: ONE barrier per column), every thread scales what it reads with the pivot's reciprocal square
+// root itself and applies the column operation col_j -= col_k L(j, k) to its 16 + 16 entries: G becomes L, E becomes L^-T (the leaf's
+// trick of chol_diag_core.hpp at workgroup size).  ~0.25 us per column instead of the 1.5-3 us of small_block's one-wave loops
+// over LDS (fine for the 1 .. 16 real rows it was written for, 105 us at m = 32).
+// Returns the 1-based index of the first non-positive pivot or 0; on return g[u] = L(i, 4u + w) for 4u + w <= i, e[u] = inv(L)(4u + w, i).
+__device__ __forceinline__ int chol64_regs(double (&g)[16], double (&e)[16], int m, double *buf /* 2 x 2 x 64 doubles of LDS */) {
+    const int i = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int bad = 0;
+#pragma unroll
+    for (int k = 0; k < 64; ++k) {
+        if (k >= m) continue;  // uniform (no break: the loop has to unroll, the register arrays are indexed by k)
+        const int uk = k >> 2, wk = k & 3;
+        double *cb = buf + (k & 1) * 128;
+        if (w == wk) {
+            cb[i] = g[uk];
+            cb[64 + i] = e[uk];
+        }
+        __syncthreads();
+        const double piv = cb[k];
+        if (!(piv > 0.0) && bad == 0) bad = k + 1;
+        const double rinv = diagcore::fast_rsqrt_v4(piv);
+        const double ci = cb[i] * rinv, ei = cb[64 + i] * rinv;
+        double cj[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) cj[u] = cb[4 * u + w];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            if (4 * u + 3 <= k) continue;  // (compile time: no column of this group lies beyond k)
+            const int j = 4 * u + w;
+            const double lj = cj[u] * rinv;
+            const bool beyond = j > k;
+            g[u] = (beyond && j <= i) ? fma(-ci, lj, g[u]) : g[u];
+            e[u] = beyond ? fma(-ei, lj, e[u]) : e[u];
+        }
+        if (w == wk) {
+            g[uk] = ci;
+            e[uk] = ei;
+        }
+    }
+    return bad;
+}
+
+__global__ __launch_bounds__(256) void tailq_factor_kernel(TailQ t) {
+    __shared__ double colbuf[2 * 128];
+    __shared__ double Li[64 * 65];  // inv(Lx) [a][b]
+    __shared__ double xty[64 * 16 + 16];
+    const int tid = threadIdx.x, d = t.d, i = tid & 63, w = tid >> 6;
+    // one workgroup on the critical path of the fit's front end, beside the Gram kernel's two workgroups per CU: first in line at the
+    // SIMDs' issue ports (without: 37-55 us for 32 columns, a third of the issue slots)
+    __builtin_amdgcn_s_setprio(3);
+    // fixed-order sums of the partials (np <= 32: sixteen loads of an element in flight at once)
+    double g[16], e[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) g[u] = 0.0;
+    for (int p0 = 0; p0 < t.np; p0 += 4) {  // four partials x sixteen entries in flight per round trip; p ascending for every entry
+        double x[4][16];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int j = 4 * u + w;
+                x[p][u] = (p0 + p < t.np && i < d && j <= i) ? gld(&t.part[(size_t)(p0 + p) * TQ_PS + i + 64 * j]) : 0.0;
+            }
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int u = 0; u < 16; ++u) g[u] += x[p][u];
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int j = 4 * u + w;
+        if (!(i < d && j <= i)) g[u] = i == j ? 1.0 : 0.0;
+        e[u] = i == j ? 1.0 : 0.0;
+    }
+    for (int idx = tid; idx < 64 * t.k + t.k; idx += 256) {
+        const int src = idx < 64 * t.k ? 4096 + idx : 4096 + 1024 + (idx - 64 * t.k);
+        double v = 0.0;
+        for (int p0 = 0; p0 < t.np; p0 += 16) {
+            double x[16];
+#pragma unroll
+            for (int p = 0; p < 16; ++p) x[p] = p0 + p < t.np ? gld(&t.part[(size_t)(p0 + p) * TQ_PS + src]) : 0.0;
+#pragma unroll
+            for (int p = 0; p < 16; ++p) v += x[p];
+        }
+        xty[idx < 64 * t.k ? idx : 64 * 16 + (idx - 64 * t.k)] = v;
+    }
+    const int bad = chol64_regs(g, e, d, colbuf);
+    if (tid == 0) t.flags[1] = bad;  // > 0: affinely dependent sites (Pi is rank deficient)
+    // inv(Lx)(a, b) = E(b, a): to LDS for T1 and, identity padded to 128 x 128, to memory for the later launches
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int j = 4 * u + w;  // this thread holds E(i, j) = inv(Lx)(j, i)
+        Li[j * 65 + i] = (j < d && i <= j) ? e[u] : 0.0;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 128 * 128; idx += 256) {
+        const int a = idx & 127, b = idx >> 7;
+        gst(&t.LinvX[idx], (a < d && b < d) ? Li[a * 65 + b] : (a == b ? 1.0 : 0.0));
+    }
+    // T1 = Q1' Y = [1'Y / sqrt n ; inv(Lx) (Xc' Y)]
+    for (int idx = tid; idx < t.q * t.k; idx += 256) {
+        const int a = idx % t.q, l = idx / t.q;
+        double v;
+        if (a == 0) {
+            v = xty[64 * 16 + l] * t.rsn;
+        } else {
+            v = 0.0;
+            for (int b = 0; b < a; ++b) v = fma(Li[(a - 1) * 65 + b], xty[b + 64 * l], v);
+        }
+        gst(&t.T1[a + (int64_t)l * t.q], v);
+    }
+}
+
+__global__ __launch_bounds__(256) void tailq_q1_kernel(TailQ t) {
+    __shared__ double Qs[64 * 65];  // [a][i]
+    __shared__ double part4[4][64];
+    const int tid = threadIdx.x, d = t.d, d16 = (t.d + 15) & ~15;
+    const int R0 = 64 * blockIdx.x;
+    for (int e = tid; e < 64 * 65; e += 256) Qs[e] = 0.0;
+    __syncthreads();
+    // Qx(i, a) = sum_b Xc(i, b) inv(Lx)(a, b); rows beyond n are zero rows of Xc
+    wg_gemm<true, true, false>(64, d16, d16, t.Xc + (int64_t)R0 * t.dpad, t.dpad, t.LinvX, 128, NoPre(), [&](int i, int a, double v, double) {
+        if (a < d) {
+            const double w = R0 + i < t.n ? v : 0.0;
+            Qs[a * 65 + i] = w;
+            gst(&t.Q1[(R0 + i) + (int64_t)(1 + a) * t.npad], w);
+        }
+    });
+    if (tid < 64) gst(&t.Q1[R0 + tid], R0 + tid < t.n ? t.rsn : 0.0);
+    __syncthreads();
+    // B = Y - Q1 T1 (rows beyond n: zero), also as rows npad + l of the matrix
+    const int i = tid & 63, g = tid >> 6;
+    for (int l = 0; l < t.k; ++l) {
+        double s = 0.0;
+        for (int a = g; a < d; a += 4) s = fma(Qs[a * 65 + i], gld(&t.T1[1 + a + (int64_t)l * t.q]), s);
+        __syncthreads();
+        part4[g][i] = s;
+        __syncthreads();
+        if (g == 0) {
+            double b = 0.0;
+            if (R0 + i < t.n)
+                b = gld(&t.Y[(int64_t)(R0 + i) * t.k + l]) - fma(t.rsn, gld(&t.T1[(int64_t)l * t.q]), (part4[0][i] + part4[1][i]) + (part4[2][i] + part4[3][i]));
+            gst(&t.B[(R0 + i) + (int64_t)l * t.npad], b);
+            if (t.rows_out) gst(&t.rows_out[(t.npad + l) + (int64_t)(R0 + i) * t.ld], b);
+        }
+    }
+    if (t.rows_out)
+        for (int e = tid; e < 64 * t.xt; e += 256) {
+            const int l = e % t.xt, r = e / t.xt;
+            if (l >= t.k) gst(&t.rows_out[(t.npad + l) + (int64_t)(R0 + r) * t.ld], 0.0);
+        }
+}
+
 }  // namespace smallfit
 
 bool small_fit_applies(const mrbf_ctx *ctx, int64_t n, int d, int k, int q, int path) {
@@ -756,5 +978,43 @@ int launch_small_means(mrbf_ctx *ctx, const smallfit::Prob *dev_probs, int count
     MRBF_HIP(ctx, hipGetLastError());
     return 0;
 }
+
+// The tail basis and the projected right-hand sides in three launches (see TailQ above); applies to d <= 64 (dpad 64), k <= 16, q = d + 1.
+bool tail_basis_applies(const mrbf_model *M) {
+    static const int on = getenv("MRBF_TAILQ") ? atoi(getenv("MRBF_TAILQ")) : 1;
+    return on && M->dpad == 64 && M->d >= 1 && M->d <= 64 && M->q == M->d + 1 && M->k >= 1 && M->k <= 16 && M->npad % 64 == 0;
+}
+int launch_tail_basis(mrbf_ctx *ctx, const mrbf_model *M, const double *Y, double *scratch, double *LinvX, double *T1, double *Q1, double *B,
+                      double *rows_out, int64_t ld, int xt, int *flags) {
+    smallfit::TailQ t;
+    t.Xc = M->Xc;
+    t.Y = Y;
+    t.n = (int)M->n;
+    t.npad = (int)M->npad;
+    t.d = M->d;
+    t.dpad = M->dpad;
+    t.q = M->q;
+    t.k = M->k;
+    const int n16 = (t.n + 15) & ~15;
+    t.np = std::min(32, std::max(4, t.n / 128));
+    t.rows = ((n16 + t.np - 1) / t.np + 15) & ~15;
+    t.Gx = scratch;
+    t.part = scratch + 128 * 128;
+    t.LinvX = LinvX;
+    t.T1 = T1;
+    t.Q1 = Q1;
+    t.B = B;
+    t.rows_out = rows_out;
+    t.ld = ld;
+    t.xt = xt;
+    t.flags = flags;
+    t.rsn = 1.0 / std::sqrt((double)M->n);
+    hipLaunchKernelGGL(smallfit::tailq_gram_kernel, dim3((unsigned)t.np), dim3(256), 0, ctx->stream, t);
+    hipLaunchKernelGGL(smallfit::tailq_factor_kernel, dim3(1), dim3(256), 0, ctx->stream, t);
+    hipLaunchKernelGGL(smallfit::tailq_q1_kernel, dim3((unsigned)(M->npad / 64)), dim3(256), 0, ctx->stream, t);
+    MRBF_HIP(ctx, hipGetLastError());
+    return 0;
+}
+size_t tail_basis_scratch_doubles() { return (size_t)128 * 128 + (size_t)32 * smallfit::TQ_PS; }
 
 }  // namespace mrbf

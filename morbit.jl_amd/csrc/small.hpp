@@ -98,4 +98,12 @@ int small_fit_cluster(const mrbf_ctx *ctx, int count);
 // the centroids of `count` problems into their `mean` arrays (what small_fit_kernel computes itself unless Prob::mean_given)
 int launch_small_means(mrbf_ctx *ctx, const smallfit::Prob *dev_probs, int count);
 
+// The tail basis of the launch chain in three launches (small.hip, TailQ): Q1 = [1/sqrt n | Xc Lx^-T], inv(Lx) (128 x 128, identity
+// padded), T1 = Q1' Y, B = Y - Q1 T1 (npad x k, zero rows beyond n) and, if rows_out, the right-hand sides as rows npad .. npad + xt - 1
+// of the matrix; flags[1] = 1-based index of a non-positive pivot of Xc'Xc (affinely dependent sites) or 0.  d <= 64, k <= 16, q = d + 1.
+bool tail_basis_applies(const mrbf_model *M);
+size_t tail_basis_scratch_doubles();
+int launch_tail_basis(mrbf_ctx *ctx, const mrbf_model *M, const double *Y, double *scratch, double *LinvX, double *T1, double *Q1, double *B,
+                      double *rows_out, int64_t ld, int xt, int *flags);
+
 }  // namespace mrbf

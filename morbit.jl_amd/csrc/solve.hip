@@ -493,7 +493,9 @@ static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info
     MRBF_TRY(get_buf(ctx, S_RHS, (size_t)npad * k, &B));
     MRBF_TRY(get_buf(ctx, S_INFO, (size_t)4, &dinfo));  // [0] main factorisation, [1] Cholesky-QR of the tail, [2] shift not positive, [3] backward substitution gave up
     MRBF_HIP(ctx, hipMemsetAsync(dinfo, 0, 4 * sizeof(int), ctx->stream));
-    hipLaunchKernelGGL(rhs_from_values_kernel, dim3(nblk(npad * k)), dim3(256), 0, ctx->stream, Y, n, k, B, npad);
+    // d <= 64: the tail basis, T1 = Q1' Y, B = P Y and the extra rows in three launches (small.hip, TailQ) instead of twelve
+    const bool tailq = q > 1 && tail_basis_applies(M) && M->k == k;
+    if (!tailq) hipLaunchKernelGGL(rhs_from_values_kernel, dim3(nblk(npad * k)), dim3(256), 0, ctx->stream, Y, n, k, B, npad);
     double *Q1 = nullptr, *Wm = nullptr, *G = nullptr, *T1 = nullptr, *scal = nullptr, *Tall = nullptr, *LxInv = nullptr;
     int64_t lt = 0, dq = 0;
     info->mu = 0.0;
@@ -519,7 +521,12 @@ static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info
             hipStream_t s;
             ~RestoreStream() { c->stream = s; }
         } restore{ctx, main_stream};
-        if (q > 1) {
+        if (tailq) {
+            double *scratch;
+            MRBF_TRY(get_buf(ctx, S_PI, tail_basis_scratch_doubles(), &scratch));
+            MRBF_TRY(get_buf(ctx, S_QR_INV, (size_t)128 * 128, &LxInv));
+            MRBF_TRY(launch_tail_basis(ctx, M, Y, scratch, LxInv, T1, Q1, B, builtin ? Phi : nullptr, ld, xt, dinfo));
+        } else if (q > 1) {
             // Cholesky-QR of the centred coordinates: [Xc'Xc ; Xc] -> [Lx ; Xc Lx^-T] by the tall blocked Cholesky
             dq = round_up(d, 128);
             lt = dq + npad;
@@ -532,13 +539,15 @@ static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info
             if (dq == 128) MRBF_TRY(get_buf(ctx, S_QR_INV, (size_t)128 * 128, &LxInv));
             MRBF_TRY(potrf_blocked_tall(ctx, dq, lt, Tall, lt, dinfo + 1, LxInv));  // flag read back with the main one
         }
-        hipLaunchKernelGGL(build_q1_kernel, dim3(nblk(npad * q)), dim3(256), 0, ctx->stream, Tall, lt, dq, n, npad, q, Q1);
+        if (!tailq) hipLaunchKernelGGL(build_q1_kernel, dim3(nblk(npad * q)), dim3(256), 0, ctx->stream, Tall, lt, dq, n, npad, q, Q1);
         if (!fused) MRBF_HIP(ctx, hipMemsetAsync(Wm, 0, (size_t)npad * q * sizeof(double), ctx->stream));
         // B = P Y = Y - Q1 (Q1' Y) (T1 keeps Q1' Y for lam) and, for the built-in factorisation, the right-hand sides as extra rows
         // of the matrix: they depend on Q1 and Y only, so they too run under the Gram kernel
-        MRBF_TRY(tsmm_tn(ctx, n, q, k, 1.0, Q1, npad, B, npad, 0.0, T1, q));
-        hipLaunchKernelGGL(sub_qt_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, ctx->stream, B, npad, Q1, npad, T1, n, q, k);
-        if (builtin) hipLaunchKernelGGL(set_rhs_rows_kernel, dim3(nblk(npad * xt)), dim3(256), 0, ctx->stream, Phi, ld, npad, xt, B, k);
+        if (!tailq) {
+            MRBF_TRY(tsmm_tn(ctx, n, q, k, 1.0, Q1, npad, B, npad, 0.0, T1, q));
+            hipLaunchKernelGGL(sub_qt_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, ctx->stream, B, npad, Q1, npad, T1, n, q, k);
+            if (builtin) hipLaunchKernelGGL(set_rhs_rows_kernel, dim3(nblk(npad * xt)), dim3(256), 0, ctx->stream, Phi, ld, npad, xt, B, k);
+        }
         if (side) MRBF_HIP(ctx, hipEventRecord(ctx->evx[1], ctx->stream));
     }
     ctx->stream = main_stream;
