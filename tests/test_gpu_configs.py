@@ -271,6 +271,30 @@ def test_giveup_in_the_tail_factorisation_is_not_read_as_rank_deficiency(ctx):
     clean.free()
 
 
+def test_affinely_dependent_sites_through_the_three_launch_front_end(ctx):
+    """n > 512, d <= 64: the tail basis comes from small.hip's TailQ launches.  Sites in a hyperplane (one coordinate a linear function of
+    two others) make Xc'Xc singular up to rounding: either the one-workgroup Cholesky there meets a non-positive pivot (flags[1]) and
+    the fit takes the LU of the saddle system, or the pivot comes out as a positive rounding residue and the projected path goes on
+    with a basis that spans the same space -- in both cases the model must interpolate, with one coordinate exactly duplicated as well"""
+    rng = np.random.Generator(np.random.PCG64(80))
+    C = rng.random((700, 9))
+    C[:, 4] = 0.5 * C[:, 0] - 0.25 * C[:, 2] + 0.3
+    Y = np.sin(C.sum(axis=1))[:, None]
+    for dup in (False, True):
+        if dup:
+            C[:, 4] = C[:, 0]
+        m = pkg.update_model(pkg.RbfConfig(kernel="gaussian", polynomial_degree=1), C, Y, ctx=ctx)
+        assert m.info["path"] in (_lib.PATH_PROJ_CHOL, _lib.PATH_LU), m.info
+        V, _ = m.eval_sites(C[:100])
+        assert np.abs(V - Y[:100]).max() < 1e-6, (dup, m.info, np.abs(V - Y[:100]).max())
+        m.free()
+    # the same sites without the dependency: the projected Cholesky path
+    C2 = rng.random((700, 9))
+    m2 = pkg.update_model(pkg.RbfConfig(kernel="gaussian", polynomial_degree=1), C2, Y, ctx=ctx)
+    assert m2.info["path"] == _lib.PATH_PROJ_CHOL and m2.info["rel_residual"] < 1e-10, m2.info
+    m2.free()
+
+
 def test_small_fit_cluster_failure_repeats_with_one_workgroup():
     """n <= 512: the fit runs on a cluster of four workgroups per problem (small.hip); when a member does not arrive at a barrier
     (MRBF_OPT_DEBUG_FAULT bit 2) the siblings give up after MRBF_OPT_SPIN_MS, the same call repeats the launch with one workgroup per

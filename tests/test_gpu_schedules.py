@@ -45,3 +45,25 @@ def test_schedule_variant_factors_correctly(env):
         assert m, part
         assert int(m.group(1)) == 0, part
         assert float(m.group(2)) < 1e-13, part
+
+
+def test_fit_front_ends_agree(tmp_path):
+    """The fit's two front ends for d <= 64 -- tail basis, Q1'Y and projected right-hand sides in three launches (small.hip, TailQ,
+    the default) against the twelve-launch chain it replaces (MRBF_TAILQ=0) -- give the same models: weights and tail coefficients
+    agree to rounding-times-conditioning, both interpolate.  (The switch is read once per process: one child per setting.)"""
+    import numpy as np
+    outs = []
+    for v in ("1", "0"):
+        e = dict(os.environ)
+        e["MRBF_TAILQ"] = v
+        f = str(tmp_path / ("fit%s.npz" % v))
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fit_dump.py"), f], env=e, cwd=ROOT, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        outs.append(np.load(f))
+    a, b = outs
+    for ci in range(5):
+        assert int(a["path%d" % ci]) == 2 and int(b["path%d" % ci]) == 2  # the projected Cholesky path in both
+        assert float(a["res%d" % ci]) < 1e-7 and float(b["res%d" % ci]) < 1e-7, (ci, float(a["res%d" % ci]), float(b["res%d" % ci]))
+        for key in ("w", "lam"):
+            x, y = a["%s%d" % (key, ci)], b["%s%d" % (key, ci)]
+            assert np.abs(x - y).max() <= 1e-6 * np.abs(y).max(), (ci, key, np.abs(x - y).max(), np.abs(y).max())
