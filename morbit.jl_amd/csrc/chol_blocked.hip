@@ -14,6 +14,7 @@
 // 16-column k-chunks staged global -> registers -> LDS ([k][i] layout, 144-double rows: conflict-free
 // ds_read_b64 fragments), next chunk's global loads in flight under the current chunk's 64 MFMAs per wave.
 #include "common.hpp"
+#include "mega_gemm.hpp"
 
 namespace mrbf {
 
@@ -21,7 +22,6 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 
 constexpr int CNB = 128;  // block size of the factorisation
-constexpr int CBK = 16;   // k chunk
 
 enum { UPD_LOWER_SUB = 0, UPD_OVERWRITE = 1, UPD_FULL_SUB = 2, UPD_COLUMN_SUB = 3 };
 int launch_diag_v4(mrbf_ctx *ctx, hipStream_t st, double *Ajj, int64_t lda, double *Linv, int *dinfo, int col0);  // chol_diag.hip
@@ -37,13 +37,10 @@ __global__ __launch_bounds__(256, 2) void chol_update_kernel(const double *__res
                                                              double *__restrict__ C, int64_t ldc, int K,
                                                              const int *__restrict__ info, int mt_sq = 0, int ntiles_total = 0,
                                                              const double *__restrict__ cvec = nullptr, double cs = 0.0, int64_t cn = 0) {
-    constexpr int LDA_S = TM + 16;   // LDS row strides (doubles); (2*LD) % 64 == 32 -> k and k+1 rows hit disjoint banks
-    constexpr int LDB_S = 128 + 16;
     constexpr int NJ = (TM == 128) ? 4 : 2;  // 16-wide j tiles per wave
-    constexpr int AL = (TM == 128) ? 4 : 2;  // v2d loads per thread per A chunk
-    __shared__ __attribute__((aligned(16))) double smem[CBK * LDA_S + CBK * LDB_S];
-    double *As = smem;
-    double *Bs = smem + CBK * LDA_S;
+    // operand pipeline: the LDS-DMA ring of the persistent factorisation's jobs (mega_gemm.hpp; round 4 -- the register-staged loop
+    // this kernel had left the matrix pipe idle a third of the time: the projection's rank-2q update ran at 42 TFLOP/s)
+    __shared__ __attribute__((aligned(16))) double smem[mega::NSTG * mega::STG];
     if (info && *info != 0) return;  // an earlier diagonal block was not positive definite
     // panel-chain launches (T, U1) share SIMDs with the bulk update's waves: win the issue arbitration
     if (MODE == UPD_OVERWRITE || MODE == UPD_COLUMN_SUB) __builtin_amdgcn_s_setprio(2);
@@ -81,48 +78,8 @@ __global__ __launch_bounds__(256, 2) void chol_update_kernel(const double *__res
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[j][i] = (v4d){0.0, 0.0, 0.0, 0.0};
 
-    // global -> register staging maps (a wave reads whole columns: 1 KiB / 512 B contiguous)
-    const int a_i2 = (TM == 128) ? (tid & 63) * 2 : (tid & 31) * 2;
-    const int a_k0 = (TM == 128) ? (tid >> 6) : (tid >> 5);
-    constexpr int a_ks = (TM == 128) ? 4 : 8;
-    const int b_i2 = (tid & 63) * 2, b_k0 = tid >> 6;
-    const double *Ap = A + I0 + a_i2 + (int64_t)a_k0 * lda;
-    const double *Bp = B + J0 + b_i2 + (int64_t)b_k0 * ldb;
-    v2d ra[AL], rb[4];
-#pragma unroll
-    for (int u = 0; u < AL; ++u) ra[u] = *(const v2d *)(Ap + (int64_t)(a_ks * u) * lda);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) rb[u] = *(const v2d *)(Bp + (int64_t)(4 * u) * ldb);
-
-    const int nkc = K / CBK;
-    for (int kc = 0; kc < nkc; ++kc) {
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < AL; ++u) *(v2d *)&As[(a_k0 + a_ks * u) * LDA_S + a_i2] = ra[u];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) *(v2d *)&Bs[(b_k0 + 4 * u) * LDB_S + b_i2] = rb[u];
-        __syncthreads();
-        if (kc + 1 < nkc) {
-            const int64_t ko = (int64_t)(kc + 1) * CBK;
-#pragma unroll
-            for (int u = 0; u < AL; ++u) ra[u] = *(const v2d *)(Ap + (ko + a_ks * u) * lda);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) rb[u] = *(const v2d *)(Bp + (ko + 4 * u) * ldb);
-        }
-#pragma unroll
-        for (int kk = 0; kk < CBK / 4; ++kk) {
-            double a[4], b[NJ];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = As[(kk * 4 + l4) * LDA_S + ioff + i * 16 + l15];
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) b[j] = Bs[(kk * 4 + l4) * LDB_S + joff + j * 16 + l15];
-            // D[row = j][col = i] = sum_k Bp(j,k) Ap(i,k): the lane index (l & 15) runs along i, contiguous in C
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[j], a[i], acc[j][i], 0, 0, 0);
-        }
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (persistent launches: the previous tile's stores are out of the wave's counter)
+    mega::gemm_acc<TM>(A + I0, lda, B + J0, ldb, K, acc, smem);
     // epilogue (f64 C/D map: col = lane & 15 -> i, row = (lane >> 4) + 4 r -> j).  The read-modify-write is done in
     // batches of 16 values (all loads of a batch issued before its first store): element-wise `*dst -= acc` makes the
     // compiler serialise 64 dependent load -> store round trips, because it cannot prove the addresses distinct.
