@@ -21,6 +21,8 @@ rocprofv3 --kernel-trace --stats -d "$OUT/prof_c4" -o c4 -- python3 "$ROOT/bench
 echo "C4 trace done"
 rocprofv3 --kernel-trace --stats -d "$OUT/prof_c5" -o c5 -- python3 "$ROOT/bench.py" --config C5 --steps 2 --warmup 1 --problems 2 --no-cpu-baseline > "$OUT/bench_c5_under_profiler.json" 2> "$OUT/prof_c5.err"
 echo "C5 trace done"
+rocprofv3 --kernel-trace --stats -d "$OUT/prof_c2" -o c2 -- python3 "$ROOT/bench.py" --config C2 --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/bench_c2_under_profiler.json" 2> "$OUT/prof_c2.err"
+echo "C2 trace done"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc_w" -o w -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/pmc_w.json" 2> "$OUT/pmc_w.err"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmc_f" -o f -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/pmc_f.json" 2> "$OUT/pmc_f.err"
 echo "PMC passes done"
