@@ -77,10 +77,12 @@ __host__ __device__ inline int nbulk_updates(int i, int c, int slack, int slack_
 struct Edge {
     int head, tail_c0, srows_edge, pstream_edge;
     int shalf, sh_head, sh_tail_c0;  // shalf: streamed tiles of the block columns c < sh_head and c >= sh_tail_c0 as two 64-row jobs (see run_stream)
+    int tfull1;  // > 0: panel tiles more than tfull1 - 1 block rows below the streamed ones are ONE 128-row job (Job::w = 2), not two halves
 };
 __host__ __device__ inline bool edge_col(int c, const Edge &e) { return c < e.head || c >= e.tail_c0; }
 __host__ __device__ inline int srows_at(int c, int srows, const Edge &e) { return edge_col(c, e) ? e.srows_edge : srows; }
 __host__ __device__ inline bool shalf_at(int c, int srows, const Edge &e) { return e.shalf && (c < e.sh_head || c >= e.sh_tail_c0) && srows_at(c, srows, e) >= 5; }
+__host__ __device__ inline bool tfull_at(int i, int c, int srows, const Edge &e) { return e.tfull1 > 0 && i - c - srows_at(c, srows, e) > e.tfull1 - 1; }
 
 struct Args {
     double *A;
@@ -743,26 +745,28 @@ __device__ __attribute__((noinline)) bool run_diag(const Args &a, Shared &sh, co
 // T(i, half, c): rows [64 half, 64 half + 64) of tile (i,c).  Half-height tiles keep a row's column-to-column recurrence
 // L(i,c-1) -> update -> solve -> L(i,c) (two dependent 64 x 128 x 128 GEMMs on one CU that is shared with a bulk job)
 // faster than the diagonal chain; with 128-row tiles the rows fall behind it.
+template <bool FULL>
 __device__ __attribute__((noinline)) bool run_panel(const Args &a, Shared &sh, const Job jb) {
+    constexpr int TM = FULL ? 128 : 64;
     const int64_t lda = uni64(a.lda);
     double *const A = uni_ptr(a.A);
-    const int i = __builtin_amdgcn_readfirstlane(jb.i), c = __builtin_amdgcn_readfirstlane(jb.c), roff = 64 * __builtin_amdgcn_readfirstlane(jb.w);
-    if (!window_part<64>(a, sh, i, c, c, roff, nullptr)) return false;
+    const int i = __builtin_amdgcn_readfirstlane(jb.i), c = __builtin_amdgcn_readfirstlane(jb.c), roff = FULL ? 0 : 64 * __builtin_amdgcn_readfirstlane(jb.w);
+    if (!window_part<TM>(a, sh, i, c, c, roff, nullptr)) return false;
     JLOG(4);
     double *C = A + (int64_t)i * NB + roff + (int64_t)c * NB * lda;
     double *Linv = a.linv + (size_t)c * NB * NB;
     // L(i,c) = X * inv(L_cc)'
     if (!wg_wait(sh, a, a.tdone + (size_t)c * a.NT + c, 2u, nullptr, 0, nullptr, 0, 0x300u)) return false;
     JLOG(5);
-    v4d acc[2][4];
+    v4d acc[TM / 32][4];
     zero_acc(acc);
     // (the register-staged loop: X was written by this workgroup's plain stores a moment ago, and LDS-DMA loads of it came back
     //  wrong -- every other operand of gemm_acc is another workgroup's write-through data behind an acquire, or older; r04)
-    gemm_acc_v1<64>(C, lda, Linv, NB, NB, acc, sh.u.gemm);  // every wave's loads of X are complete behind the loop's last barrier
-    store_tile<64, false, false, true>(C, lda, acc);
+    gemm_acc_v1<TM>(C, lda, Linv, NB, NB, acc, sh.u.gemm);  // every wave's loads of X are complete behind the loop's last barrier
+    store_tile<TM, false, false, true>(C, lda, acc);
     wg_drain();
-    if (a.fault && i == a.MT - 1 && c == 0 && roff == 0) return true;  // test hook: this half tile is never published
-    if (threadIdx.x == 0) addf(a.tdone + (size_t)i * a.NT + c, 1u);
+    if (a.fault && i == a.MT - 1 && c == 0 && roff == 0) return true;  // test hook: this (half) tile is never published
+    if (threadIdx.x == 0) addf(a.tdone + (size_t)i * a.NT + c, FULL ? 2u : 1u);
     return true;
 }
 
@@ -1039,7 +1043,7 @@ __device__ __forceinline__ void mega_body(const Args &a) {
         jlog_begin(a, sh, kind == 1 ? a.pjobs[idx] : a.bjobs[idx]);
         if (kind == 1) {
             if (!dedicated) __builtin_amdgcn_s_setprio(1);
-            ok = run_panel(a, sh, a.pjobs[idx]);
+            ok = a.pjobs[idx].w == 2 ? run_panel<true>(a, sh, a.pjobs[idx]) : run_panel<false>(a, sh, a.pjobs[idx]);
             if (!dedicated) __builtin_amdgcn_s_setprio(0);
         } else {
             ok = a.bjobs[idx].kind == JOB_UH ? run_bulk<64>(a, sh, a.bjobs[idx]) : run_bulk<128>(a, sh, a.bjobs[idx]);
@@ -1100,7 +1104,10 @@ static void build_job_tables(int NT, int MT, int slack, int slack_chain, int fir
                 }
             }
             else
-                for (int h = 0; h < 2; ++h) pj.push_back(Job{JOB_T, (short)i, (short)c, (short)h});
+                if (tfull_at(i, c, srows, edge))
+                    pj.push_back(Job{JOB_T, (short)i, (short)c, (short)2});
+                else
+                    for (int h = 0; h < 2; ++h) pj.push_back(Job{JOB_T, (short)i, (short)c, (short)h});
         }
     }
     int nwin_max = 0;  // windows that reach at least one tile through a bulk job
@@ -1198,6 +1205,12 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
         edge.shalf = (sh_tail > 0 || sh_head > 0) ? 1 : 0;
         edge.sh_head = std::min(sh_head, NT);
         edge.sh_tail_c0 = std::max(edge.sh_head, NT - sh_tail);
+        // panel tiles far below the diagonal as 128-row jobs (MRBF_MEGA_TFULL = block rows below the streamed ones that stay halves; -1: all halves)
+        static const int env_tfull = getenv("MRBF_MEGA_TFULL") ? atoi(getenv("MRBF_MEGA_TFULL")) : -1;
+        // (64-row halves keep a block row's column-to-column recurrence ahead of the chain; at n >= 12288 the rows more than eight below
+        //  the streamed ones have the slack for 128-row jobs, whose GEMM loop shares the B operand between twice the MFMAs:
+        //  alternating A/B r04: n = 12288 / 16384: -0.9 / -1.1 %, n = 10240: 0; all panel tiles full at n <= 8192: +4 .. +28 %)
+        edge.tfull1 = env_tfull >= 0 ? env_tfull + 1 : (getenv("MRBF_MEGA_TFULL") ? 0 : (NTq >= 96 ? 9 : 0));
     }
     const int srows_max = std::max(srows, (edge.head > 0 || edge.tail_c0 < NT) ? edge.srows_edge : srows);
     // job tables: one set per (NT, MT, schedule parameters), kept in a small per-context LRU -- Morbit's training sets grow and shrink
@@ -1215,7 +1228,7 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
     const int tail_half_w = env_tail_half_w >= 0 ? env_tail_half_w : 1000;  // only the last so many window updates of such a tile
     const long tab_key = (chainq ? 50 : 0) + slack + 100000000000000L * tail_half + 10000000000000000L * std::min(tail_half_w, 99) + 100 * ctx->mega_half_cols + 10000 * slack_chain + 1000000 * first + 10000000 * win + 100000000 * (long)srows +
                          1000000000L * edge.head + 1000000000000L * edge.tail_c0;
-    const long tab_key2 = edge.shalf ? 1 + edge.sh_head + 1000L * edge.sh_tail_c0 : 0;
+    const long tab_key2 = (edge.shalf ? 1 + edge.sh_head + 1000L * edge.sh_tail_c0 : 0) + 1000000L * edge.tfull1;
     MegaTables *tab = nullptr;
     for (auto &t : ctx->mega_tables)
         if (t.nt == NT && t.mt == MT && t.key == tab_key && t.key2 == tab_key2) tab = &t;
@@ -1463,11 +1476,11 @@ static int32_t check_mega_tables(int nt, int mt, int slack, int slack_chain, int
             ++bad;
     }
     for (const Job &j : pj) {
-        if (j.kind != JOB_T || j.c >= nt || j.i <= j.c + sr(j.c) || j.i >= mt || (j.w != 0 && j.w != 1)) {
+        if (j.kind != JOB_T || j.c >= nt || j.i <= j.c + sr(j.c) || j.i >= mt || j.w < 0 || j.w > 2 || (j.w == 2) != tfull_at(j.i, j.c, srows, edge)) {
             ++bad;
             continue;
         }
-        fin[(size_t)j.i * nt + j.c] += 1;
+        fin[(size_t)j.i * nt + j.c] += j.w == 2 ? 2 : 1;  // a panel tile: one 128-row job or two halves
     }
     for (int c = 0; c < nt; ++c)
         for (int i = 0; i < mt; ++i) bad += fin[(size_t)i * nt + c] != (i >= c ? 2 : 0);
@@ -1533,6 +1546,7 @@ extern "C" int32_t mrbf_debug_mega_tables2(int32_t nt, int32_t mt, int32_t slack
     edge.tail_c0 = srows < edge.srows_edge ? std::max(edge.head, nt - opt5[1]) : nt;
     edge.shalf = (opt5[4] & 2) ? 1 : 0;  // (bit 1 of the last option: streamed tiles of five-row block columns as 64-row halves;
     edge.sh_head = (opt5[4] >> 2) & 0xff;  //  bits 2..9 / 10..17: only the first / last so many block columns, 0 / 0 = all)
-    edge.sh_tail_c0 = (opt5[4] >> 10) ? std::max(edge.sh_head, nt - ((opt5[4] >> 10) & 0xff)) : (edge.sh_head ? nt : 0);
+    edge.sh_tail_c0 = ((opt5[4] >> 10) & 0xff) ? std::max(edge.sh_head, nt - ((opt5[4] >> 10) & 0xff)) : (edge.sh_head ? nt : 0);
+    edge.tfull1 = (opt5[4] >> 18) & 0xff;  // bits 18..25: panel tiles more than this - 1 block rows below the streamed ones as one 128-row job
     return check_mega_tables(nt, mt, slack, slack_chain, first, win, srows, edge, half_cols, opt5[2], opt5[3] > 0 ? opt5[3] : 1000, (opt5[4] & 1) != 0, out);
 }

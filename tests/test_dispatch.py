@@ -337,6 +337,20 @@ def test_mega_job_tables_are_consistent():
         tiles = sum(mt - cc for cc in range(nt))
         extra = sum(min(5, mt - 1 - cc) for cc in cols)
         assert out[2] + out[0] // 2 == tiles + extra, (c, o, list(out))
+    # panel tiles more than t block rows below the streamed ones as ONE 128-row job (bits 18.. of the last option = t + 1): one panel job
+    # less per such tile, every tile still finished exactly once
+    for c, o, t in [((32, 33, 3, 6, 1, 4, 5, 0), (0, 16, 20, 0, 1 << 18), 0), ((64, 65, 3, 7, 1, 6, 3, 0), (0, 16, 20, 0, (4 << 18) | 2), 3),
+                    ((20, 24, 3, 9, 2, 5, 2, 1), (0, 0, 0, 0, 9 << 18), 8)]:
+        opt = (ctypes.c_int32 * 5)(*o)
+        assert lib.mrbf_debug_mega_tables2(*c, opt, out) == 0, (c, o)
+        assert out[5] == 0, (c, o, list(out))
+        nt, mt, srows = c[0], c[1], c[6]
+        def sr(cc):
+            edge = cc >= nt - o[1] and o[1] > 0 and srows < 5
+            return 5 if edge else srows
+        nfull = sum(1 for cc in range(nt) for i in range(cc + 1, mt) if i > cc + sr(cc) and i - cc - sr(cc) > t)
+        nhalf_tiles = sum(1 for cc in range(nt) for i in range(cc + 1, mt) if i > cc + sr(cc)) - nfull
+        assert out[0] == nfull + 2 * nhalf_tiles, (c, o, list(out), nfull, nhalf_tiles)
     opt = (ctypes.c_int32 * 5)(0, 0, 0, 0, 0)
     for c in cases[:6]:  # without options: the same tables as the plain entry point
         assert lib.mrbf_debug_mega_tables2(*c, opt, out) == 0 and out[4] == seen[c], c

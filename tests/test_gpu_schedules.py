@@ -26,6 +26,8 @@ VARIANTS = [
     {"MRBF_MEGA_SHALF": "12", "MRBF_MEGA_SHALF_HEAD": "3", "MRBF_MEGA_RESERVE": "40", "MRBF_MEGA_XCHAIN": "2"},  # halves at the edges only
     {"MRBF_MEGA_SHALF": "99", "MRBF_MEGA_CHAIN": "96", "MRBF_MEGA_XCHAIN": "8"},
     {"MRBF_MEGA_SHALF": "99", "MRBF_MEGA_CHAIN": "40", "MRBF_MEGA_XCHAIN": "0"},
+    {"MRBF_MEGA_TFULL": "0"},                                                 # every panel tile as one 128-row job
+    {"MRBF_MEGA_TFULL": "3", "MRBF_MEGA_SHALF": "0"},                         # only those more than three block rows below the streamed ones
 ]
 
 
