@@ -17,6 +17,8 @@
 #include "radial.hpp"
 #include "small.hpp"
 
+#include <utility>
+
 namespace mrbf {
 namespace smallfit {
 
@@ -247,8 +249,89 @@ __device__ __noinline__ int small_block(double *__restrict__ A, int ld, int real
     __syncthreads();
     return 0;
 }
+// Cholesky factor and its inverse of an m x m s.p.d. matrix, m <= 64, by one workgroup in registers: thread (i, w) = (tid & 63,
+// tid >> 6) holds the entries (i, 4 u + w), u = 0 .. 15, of G and of E (starts as the identity).  Column k of [G ; E] is published
+// unscaled through LDS (double buffered: ONE barrier per column), every thread scales what it reads with the pivot's reciprocal square
+// root itself and applies the column operation col_j -= col_k L(j, k) to its 16 + 16 entries: G becomes L, E becomes L^-T (the leaf's
+// trick of chol_diag_core.hpp at workgroup size).  ~0.25 us per column instead of the 1.5-3 us of small_block's one-wave loops
+// over LDS (fine for the 1 .. 16 real rows it was written for, 105 us at m = 32).
+// Returns the 1-based index of the first non-positive pivot or 0; on return g[u] = L(i, 4u + w) for 4u + w <= i, e[u] = inv(L)(4u + w, i).
+template <int K>
+__device__ __forceinline__ void chol64_step(double (&g)[16], double (&e)[16], int m, double *buf, int i, int w, int &bad) {
+    if (K >= m) return;  // uniform
+    constexpr int uk = K >> 2, wk = K & 3;
+    double *cb = buf + (K & 1) * 128;
+    if (w == wk) {
+        cb[i] = g[uk];
+        cb[64 + i] = e[uk];
+    }
+    __syncthreads();
+    const double piv = cb[K];
+    if (!(piv > 0.0) && bad == 0) bad = K + 1;
+    const double rinv = diagcore::fast_rsqrt_v4(piv);
+    const double ci = cb[i] * rinv, ei = cb[64 + i] * rinv;
+    constexpr int u0 = (K + 1) >> 2;  // the first group of four columns that reaches beyond K
+    double cj[16];
+#pragma unroll
+    for (int u = u0; u < 16; ++u) cj[u] = cb[4 * u + w];
+#pragma unroll
+    for (int u = u0; u < 16; ++u) {
+        const int j = 4 * u + w;
+        const double lj = cj[u] * rinv;
+        const bool beyond = j > K;
+        g[u] = (beyond && j <= i) ? fma(-ci, lj, g[u]) : g[u];
+        e[u] = beyond ? fma(-ei, lj, e[u]) : e[u];
+    }
+    if (w == wk) {
+        g[uk] = ci;
+        e[uk] = ei;
+    }
+}
+template <int... Ks>
+__device__ __forceinline__ void chol64_steps(double (&g)[16], double (&e)[16], int m, double *buf, int i, int w, int &bad, std::integer_sequence<int, Ks...>) {
+    (chol64_step<Ks>(g, e, m, buf, i, w, bad), ...);  // (a fold, not a loop: every register index is a constant whatever the unroller decides)
+}
+__device__ __forceinline__ int chol64_regs(double (&g)[16], double (&e)[16], int m, double *buf /* 2 x 2 x 64 doubles of LDS */) {
+    const int i = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int bad = 0;
+    chol64_steps(g, e, m, buf, i, w, bad, std::make_integer_sequence<int, 64>());
+    return bad;
+}
+
+// The same contract as small_block / diag_block for a 128 x 128 block whose leading `real` x `real` part (real <= 64) is not the identity:
+// L into the lower triangle of A, inv(L) as a full 128 x 128 block, the 1-based index of a bad pivot or 0.  ws: 64 * 65 + 256 doubles of LDS.
+__device__ __noinline__ int block64(double *__restrict__ A, int ld, int real, double *__restrict__ Linv, double *ws) {
+    double *Li = ws, *colbuf = ws + 64 * 65;
+    const int tid = threadIdx.x, i = tid & 63, w = tid >> 6;
+    double g[16], e[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int j = 4 * u + w;
+        g[u] = (i < real && j <= i) ? gld(&A[i + (int64_t)j * ld]) : (i == j ? 1.0 : 0.0);
+        e[u] = i == j ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    const int bad = chol64_regs(g, e, real, colbuf);
+    if (bad) return bad;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int j = 4 * u + w;  // this thread holds L(i, j) and E(i, j) = inv(L)(j, i)
+        Li[j * 65 + i] = (j < real && i <= j) ? e[u] : 0.0;
+        if (i < real && j <= i) gst(&A[i + (int64_t)j * ld], g[u]);
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 128 * 128; idx += 256) {
+        const int a = idx & 127, b = idx >> 7;
+        gst(&Linv[idx], (a < real && b < real) ? Li[a * 65 + b] : (a == b ? 1.0 : 0.0));
+    }
+    __syncthreads();
+    return 0;
+}
 __device__ __forceinline__ int diag_block_auto(double *__restrict__ A, int ld, int real, double *__restrict__ Linv, diagcore::DiagV4Shared &sh) {
-    return (real > 0 && real <= 32) ? small_block(A, ld, real, Linv, sh.LT) : diag_block(A, ld, Linv, sh);
+    // (small_block's one-wave loops over LDS: 2 us at 8 real rows, 13 at 16, 105 at 32; block64: ~0.4 us per column + 10)
+    if (real > 0 && real <= 12) return small_block(A, ld, real, Linv, sh.LT);
+    if (real > 0 && real <= 64) return block64(A, ld, real, Linv, sh.LT);
+    return diag_block(A, ld, Linv, sh);
 }
 
 // A problem is worked on by nc (1, 2, 4, 8 or 16) workgroups: every product and every elementwise pass deals its tiles / elements over
@@ -786,50 +869,6 @@ __global__ __launch_bounds__(256) void tailq_gram_kernel(TailQ t) {
         if (g == 0) gst(&out[4096 + c + 64 * l], (part4[0][c] + part4[1][c]) + (part4[2][c] + part4[3][c]));
         if (tid == 0) gst(&out[4096 + 1024 + l], (red[0] + red[1]) + (red[2] + red[3]));
     }
-}
-
-// Cholesky factor and its inverse of an m x m s.p.d. matrix, m <= 64, by one workgroup in registers: thread (i, w) = (tid & 63,
-// tid >> 6) holds the entries (i, 4 u + w), u = 0 .. 15, of G and of E (starts as the identity).  Column k of [G ; E] is published
-// unscaled through LDS (double buffered: ONE barrier per column), every thread scales what it reads with the pivot's reciprocal square
-// root itself and applies the column operation col_j -= col_k L(j, k) to its 16 + 16 entries: G becomes L, E becomes L^-T (the leaf's
-// trick of chol_diag_core.hpp at workgroup size).  ~0.25 us per column instead of the 1.5-3 us of small_block's one-wave loops
-// over LDS (fine for the 1 .. 16 real rows it was written for, 105 us at m = 32).
-// Returns the 1-based index of the first non-positive pivot or 0; on return g[u] = L(i, 4u + w) for 4u + w <= i, e[u] = inv(L)(4u + w, i).
-__device__ __forceinline__ int chol64_regs(double (&g)[16], double (&e)[16], int m, double *buf /* 2 x 2 x 64 doubles of LDS */) {
-    const int i = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int bad = 0;
-#pragma unroll
-    for (int k = 0; k < 64; ++k) {
-        if (k >= m) continue;  // uniform (no break: the loop has to unroll, the register arrays are indexed by k)
-        const int uk = k >> 2, wk = k & 3;
-        double *cb = buf + (k & 1) * 128;
-        if (w == wk) {
-            cb[i] = g[uk];
-            cb[64 + i] = e[uk];
-        }
-        __syncthreads();
-        const double piv = cb[k];
-        if (!(piv > 0.0) && bad == 0) bad = k + 1;
-        const double rinv = diagcore::fast_rsqrt_v4(piv);
-        const double ci = cb[i] * rinv, ei = cb[64 + i] * rinv;
-        double cj[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) cj[u] = cb[4 * u + w];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            if (4 * u + 3 <= k) continue;  // (compile time: no column of this group lies beyond k)
-            const int j = 4 * u + w;
-            const double lj = cj[u] * rinv;
-            const bool beyond = j > k;
-            g[u] = (beyond && j <= i) ? fma(-ci, lj, g[u]) : g[u];
-            e[u] = beyond ? fma(-ei, lj, e[u]) : e[u];
-        }
-        if (w == wk) {
-            g[uk] = ci;
-            e[uk] = ei;
-        }
-    }
-    return bad;
 }
 
 __global__ __launch_bounds__(256) void tailq_factor_kernel(TailQ t) {
