@@ -52,7 +52,7 @@ def test_schedule_variant_factors_correctly(env):
 def test_fit_front_ends_agree(tmp_path):
     """The fit's two front ends for d <= 64 -- tail basis, Q1'Y and projected right-hand sides in three launches (small.hip, TailQ,
     the default) against the twelve-launch chain it replaces (MRBF_TAILQ=0) -- give the same models: weights and tail coefficients
-    agree to rounding-times-conditioning, both interpolate.  (The switch is read once per process: one child per setting.)"""
+    agree to rounding-times-conditioning, both interpolate (eight shapes: d = 3 .. 64, k = 1 .. 16, n = 513 .. 3000 incl. non-multiples of 16).  (The switch is read once per process: one child per setting.)"""
     import numpy as np
     outs = []
     for v in ("1", "0"):
@@ -63,7 +63,7 @@ def test_fit_front_ends_agree(tmp_path):
         assert out.returncode == 0, out.stderr[-2000:]
         outs.append(np.load(f))
     a, b = outs
-    for ci in range(5):
+    for ci in range(8):
         assert int(a["path%d" % ci]) == 2 and int(b["path%d" % ci]) == 2  # the projected Cholesky path in both
         assert float(a["res%d" % ci]) < 1e-7 and float(b["res%d" % ci]) < 1e-7, (ci, float(a["res%d" % ci]), float(b["res%d" % ci]))
         for key in ("w", "lam"):

@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("morbit.jl_amd")
 
 out = {}
-cases = [(1500, 5, 3, "cubic"), (2048, 32, 1, "gaussian"), (1100, 64, 2, "multiquadric"), (3000, 33, 2, "cubic"), (640, 17, 16, "cubic")]
+cases = [(1500, 5, 3, "cubic"), (2048, 32, 1, "gaussian"), (1100, 64, 2, "multiquadric"), (3000, 33, 2, "cubic"), (640, 17, 16, "cubic"), (513, 3, 1, "cubic"), (777, 4, 3, "cubic"), (530, 64, 1, "gaussian")]
 for ci, (n, d, k, kernel) in enumerate(cases):
     rng = np.random.default_rng(100 + ci)
     C = rng.random((n, d))
