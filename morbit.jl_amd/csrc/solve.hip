@@ -752,8 +752,14 @@ int small_fit_verdict(const mrbf_model *M, const int *hflags, const double *hsca
     }
     return hflags[0] != 0 ? 1 : 0;
 }
-static int fit_small(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info *info, int *not_pd, int force_nc, int *nc_used) {
+static int fit_check_enqueue(mrbf_ctx *ctx, mrbf_model *M, const double *Y, double *h, hipEvent_t e0, hipEvent_t e1);
+static int fit_check_finish(mrbf_ctx *ctx, const mrbf_model *M, const double *h, mrbf_fit_info *info, hipEvent_t e0, hipEvent_t e1);
+// checked (optional): the residual check is enqueued behind the fit launch and read back in the same host round trip as the
+// fit's flags (it runs on whatever the launch left -- its kernels terminate on any input -- and is discarded when a flag is set)
+static int fit_small(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info *info, int *not_pd, int force_nc, int *nc_used,
+                     bool *checked = nullptr) {
     *not_pd = 0;
+    if (checked) *checked = false;
     smallfit::Prob P;
     const smallfit::Carve cv = smallfit::carve((int)M->npad, (int)round_up(std::max(M->q, 1), 16));
     double *ws, *scal;
@@ -780,7 +786,14 @@ static int fit_small(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_inf
         MRBF_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
         MRBF_HIP(ctx, hipMemcpyAsync(hflags, flags, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         MRBF_HIP(ctx, hipMemcpyAsync(hscal, scal, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        double hchk[3] = {0, 0, 0};
+        const bool with_check = checked && ctx->residual;
+        if (with_check) MRBF_TRY(fit_check_enqueue(ctx, M, Y, hchk, ctx->ev[2], ctx->ev[3]));
         MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (with_check && hflags[3] == 0 && hflags[0] == 0 && hflags[1] == 0 && hflags[2] == 0) {
+            MRBF_TRY(fit_check_finish(ctx, M, hchk, info, ctx->ev[2], ctx->ev[3]));
+            *checked = true;
+        }
         if (nc == 1) break;
         if (hflags[3] == 0) {
             ctx->small_timeouts = 0;
@@ -807,17 +820,17 @@ static int fit_small(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_inf
     return 0;
 }
 
-// residual ||s(C) - Y|| / ||Y|| through the evaluation kernels (an independent code path), and max |Pi' w|
-int fit_check(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info *info) {
+// residual ||s(C) - Y|| / ||Y|| through the evaluation kernels (an independent code path), and max |Pi' w|: the launches and the
+// download of the three sums into h (between the events e0, e1); the caller synchronises the stream and calls fit_check_finish
+static int fit_check_enqueue(mrbf_ctx *ctx, mrbf_model *M, const double *Y, double *h, hipEvent_t e0, hipEvent_t e1) {
     const int64_t n = M->n;
     const int k = M->k, q = M->q;
     double *V, *scal;
     MRBF_TRY(get_buf(ctx, S_STAGE_D, (size_t)n * k, &V));
-    MRBF_TRY(get_buf(ctx, S_MISC, (size_t)8, &scal));
-    MRBF_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    MRBF_TRY(get_buf(ctx, S_CHECK_SCAL, (size_t)8, &scal));
+    MRBF_HIP(ctx, hipEventRecord(e0, ctx->stream));
     MRBF_TRY(eval_model(ctx, M, n, M->C, V, nullptr, nullptr));
     hipLaunchKernelGGL(residual_kernel, dim3(1), dim3(256), 0, ctx->stream, V, Y, n * k, scal);
-    double h[3] = {0, 0, 0};
     if (q > 0) {
         double *Pi, *T;
         MRBF_TRY(get_buf(ctx, S_PI, (size_t)n * q, &Pi));
@@ -828,12 +841,20 @@ int fit_check(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info *info
     }
     MRBF_HIP(ctx, hipGetLastError());
     MRBF_HIP(ctx, hipMemcpyAsync(h, scal, 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    MRBF_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
-    MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    info->rel_residual = std::sqrt(h[0]) / std::max(std::sqrt(h[1]), 1e-300);
-    info->max_pitw = q > 0 ? h[2] : 0.0;
-    MRBF_HIP(ctx, hipEventElapsedTime(&info->ms_check, ctx->ev[0], ctx->ev[1]));
+    MRBF_HIP(ctx, hipEventRecord(e1, ctx->stream));
     return 0;
+}
+static int fit_check_finish(mrbf_ctx *ctx, const mrbf_model *M, const double *h, mrbf_fit_info *info, hipEvent_t e0, hipEvent_t e1) {
+    info->rel_residual = std::sqrt(h[0]) / std::max(std::sqrt(h[1]), 1e-300);
+    info->max_pitw = M->q > 0 ? h[2] : 0.0;
+    MRBF_HIP(ctx, hipEventElapsedTime(&info->ms_check, e0, e1));
+    return 0;
+}
+int fit_check(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info *info) {
+    double h[3] = {0, 0, 0};
+    MRBF_TRY(fit_check_enqueue(ctx, M, Y, h, ctx->ev[0], ctx->ev[1]));
+    MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return fit_check_finish(ctx, M, h, info, ctx->ev[0], ctx->ev[1]);
 }
 
 int fit_model(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info *info) {
@@ -847,6 +868,7 @@ int fit_model(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info *info
     const int order = cpd_order(M->kp.kid, M->kp.a, M->kp.b);
     int path = ctx->force_path;
     int small_nc_used = 0;
+    bool checked = false;
     if (path == 0) path = (order <= M->deg + 1 && M->n > M->q) ? (M->q > 0 ? MRBF_PATH_PROJ_CHOL : MRBF_PATH_CHOL) : MRBF_PATH_LU;
     if (M->n < M->q) path = MRBF_PATH_MINNORM;  // under-determined tail: minimum-norm coefficients
     if (path == MRBF_PATH_CHOL && M->q > 0) path = MRBF_PATH_PROJ_CHOL;
@@ -855,7 +877,7 @@ int fit_model(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info *info
         MRBF_TRY(fit_minnorm(ctx, M, Y, info));
     } else if (path != MRBF_PATH_LU && small_fit_applies(ctx, M->n, M->d, M->k, M->q, path)) {
         int not_pd = 0;
-        MRBF_TRY(fit_small(ctx, M, Y, info, &not_pd, 0, &small_nc_used));
+        MRBF_TRY(fit_small(ctx, M, Y, info, &not_pd, 0, &small_nc_used, &checked));
         if (not_pd) {
             info->fallbacks |= MRBF_FB_LU;
             if (ctx->force_path != 0)
@@ -885,7 +907,7 @@ int fit_model(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info *info
         }
     }
     if (path == MRBF_PATH_LU) MRBF_TRY(fit_lu(ctx, M, Y, info));
-    if (ctx->residual) MRBF_TRY(fit_check(ctx, M, Y, info));
+    if (ctx->residual && !(checked && path != MRBF_PATH_LU)) MRBF_TRY(fit_check(ctx, M, Y, info));
     if (ctx->residual && small_nc_used > 1 && path != MRBF_PATH_LU && !(info->rel_residual < 1e-6)) {
         // tripwire of the workgroup clusters (small.hip): a clustered fit that does not interpolate is repeated with one workgroup
         // per problem; only if THAT interpolates better was the cluster at fault (an ill-conditioned problem gives the same bits
