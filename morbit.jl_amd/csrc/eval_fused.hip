@@ -14,6 +14,9 @@
 // Every launch takes its operands from an EvalDesc: one by value for a single mrbf_eval, an array (blockIdx.z = problem) for the
 // batched entry points (mrbf_batch_run); the arithmetic per problem is the same, so a batch and single calls agree bit for bit.
 #include "radial.hpp"
+#ifndef MRBF_EVAL_DBG
+#define MRBF_EVAL_DBG 0  // diagnostics builds only (tools/build_variant.sh): 1 no Jacobian epilogue, 2 no Jacobian MFMAs, 64 unpaired epilogue
+#endif
 #include "small.hpp"
 
 namespace mrbf {
@@ -362,7 +365,7 @@ __global__ __launch_bounds__(512, 2) void eval_fused_split_kernel(EvalDesc one, 
                 }
             }
             // ---- phase 3: this group's H Jacobian columns
-            if (JAC) {
+            if (JAC && !(MRBF_EVAL_DBG & 2)) {
 #pragma unroll
                 for (int tt = 0; tt < HT; ++tt) {
 #pragma unroll
@@ -432,7 +435,7 @@ __global__ __launch_bounds__(512, 2) void eval_fused_split_kernel(EvalDesc one, 
             }
         }
     }
-    if (JAC && (!FINAL || jac)) {
+    if (JAC && (!FINAL || jac) && !(MRBF_EVAL_DBG & 1)) {
         __syncthreads();  // every wave is done with the last centre tile (and with the coefficient area)
         double *T = smem + wave * 16 * LDT;
         double *SA = Ws;  // KOUT x 64 is at most KOUT x ECT only for ECT = 64: the sums go to Sq's neighbour otherwise
@@ -442,8 +445,47 @@ __global__ __launch_bounds__(512, 2) void eval_fused_split_kernel(EvalDesc one, 
 #pragma unroll
             for (int l = 0; l < KOUT; ++l) SA[l * EQ + qw * 16 + l15] = sasum[l];
         }
+        // two outputs whose Jacobian entries are neighbours in memory (k even): both through the transpose area together, 32 columns
+        // at a time, one 16-byte store per (site, coordinate) -- the coordinates of a site are then written as whole lines, the
+        // query coordinate and the tail coefficients are fetched once (C4, 64 starts: the epilogue was 0.42 of the 2.34 ms)
+        bool paired = false;
+        if constexpr (FINAL && KOUT == 2) paired = (k & 1) == 0 && (l0 & 1) == 0 && l0 + 1 < k && !(MRBF_EVAL_DBG & 64);
+        if constexpr (FINAL && KOUT == 2) {
+            if (paired) {
+                constexpr int LDP = 33;
+                double *T2 = smem + wave * (2 * 16 * LDP);  // [l][qq][32 columns]
+#pragma unroll
+                for (int hq = 0; hq < H / 32; ++hq) {
+#pragma unroll
+                    for (int l = 0; l < 2; ++l)
+#pragma unroll
+                        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) T2[(l * 16 + l15) * LDP + 16 * tt + l4 + 4 * r] = JT[l][2 * hq + tt][r];
+                    __syncthreads();
+                    for (int e = lane; e < 16 * 32; e += 64) {
+                        const int qq = e >> 5, t = e & 31, col = H * grp + 32 * hq + t;
+                        const int64_t row = q0 + qw * 16 + qq;
+                        if (row < m && col < d) {
+                            const double x = Xq[row * D + col];
+                            v2d v;
+                            v.x = fma(SA[qw * 16 + qq], x, -T2[qq * LDP + t]);
+                            v.y = fma(SA[EQ + qw * 16 + qq], x, -T2[(16 + qq) * LDP + t]);
+                            if (q > 1) {
+                                const v2d lm = *(const v2d *)&lam[(int64_t)(col + 1) * k + l0];
+                                v.x += lm.x;
+                                v.y += lm.y;
+                            }
+                            *(v2d *)&jac[row * (int64_t)k * d + (int64_t)col * k + l0] = v;
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+        }
 #pragma unroll
         for (int l = 0; l < KOUT; ++l) {
+            if (paired) break;
 #pragma unroll
             for (int hc = 0; hc < H / 64; ++hc) {  // 64 Jacobian columns at a time through the transpose area
 #pragma unroll

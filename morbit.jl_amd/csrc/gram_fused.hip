@@ -252,7 +252,6 @@ __device__ __forceinline__ v4d pj_tile(const double *As, const double *Bs, int m
     v4d acc = {0.0, 0.0, 0.0, 0.0};
     const double *ap = As + (mt * 16 + l15) * PJ_LS + l4;
     const double *bp = Bs + (nt * 16 + l15) * PJ_LS + l4;
-#pragma unroll 4
     for (int k = 0; k < K; k += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[k], bp[k], acc, 0, 0, 0);
     return acc;
 }
