@@ -317,15 +317,31 @@ __global__ __launch_bounds__(512, 2) void eval_fused_split_kernel(EvalDesc one, 
             *(v2d *)&Cs[row * LDC + col] = stg[u];
         }
     };
+    // the tile's squared norms and weights travel with it (one value per thread: KOUT * ECT + ECT <= 512), requested a tile ahead like
+    // the coordinates -- fetched at the point of use they cost a memory round trip per tile with every wave waiting
+    static_assert((KOUT + 1) * ECT <= 512, "one staged scalar per thread");
+    double stg_w = 0.0;
+    auto load_scalars = [&](int64_t c0) {
+        if (tid < ECT)
+            stg_w = csq[c0 + tid];
+        else if (tid < (KOUT + 1) * ECT)
+            stg_w = Wc[(int64_t)(l0 + (tid - ECT) / ECT) * npad + c0 + ((tid - ECT) % ECT)];
+    };
     load_tile(c_begin);
+    load_scalars(c_begin);
     for (int tile = 0; tile < my_tiles; ++tile) {
         const int64_t c0 = c_begin + (int64_t)tile * ECT;
         __syncthreads();
         store_tile();
-        if (tid < ECT) Sq[tid] = csq[c0 + tid];
-        for (int e = tid; e < KOUT * ECT; e += 512) Ws[e] = Wc[(int64_t)(l0 + e / ECT) * npad + c0 + (e % ECT)];
+        if (tid < ECT)
+            Sq[tid] = stg_w;
+        else if (tid < (KOUT + 1) * ECT)
+            Ws[tid - ECT] = stg_w;
         __syncthreads();
-        if (tile + 1 < my_tiles) load_tile(c0 + ECT);
+        if (tile + 1 < my_tiles) {
+            load_tile(c0 + ECT);
+            load_scalars(c0 + ECT);
+        }
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) {
             if ((int)(c0 >> 4) + ct >= E.nsub) break;  // only padding from here on (uniform: every wave leaves before the barrier)
