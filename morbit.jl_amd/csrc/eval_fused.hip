@@ -78,6 +78,7 @@ __global__ __launch_bounds__(256, (DT <= 4) ? 2 : 1) void eval_fused_kernel(Eval
     const int64_t c_begin = (int64_t)split * tiles_per_split * EC;
     // the centre range is cut into gridDim.y nearly equal pieces (the last one may be shorter)
     const int ntiles_all = E.ntiles;
+    const int nsub = __builtin_amdgcn_readfirstlane(E.nsub);  // (E may live in global memory: read inside the centre loop it was a flat load + wait per 16-centre step)
     const int my_tiles = min(tiles_per_split, ntiles_all - split * tiles_per_split);
     constexpr int NLD = 2 * DT;  // 64 * D / 2 v2d over 256 threads
     v2d stg[NLD];
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(256, (DT <= 4) ? 2 : 1) void eval_fused_kernel(Eval
         if (tile + 1 < my_tiles) load_tile(c0 + EC);
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
-            if ((int)(c0 >> 4) + ct >= E.nsub) break;  // only padding from here on (zero weights: nothing to add)
+            if ((int)(c0 >> 4) + ct >= nsub) break;  // only padding from here on (zero weights: nothing to add)
             // ---- phase 1
             v4d S = {0.0, 0.0, 0.0, 0.0};
             const double *crow = &Cs[(16 * ct + l15) * LDC + l4];
@@ -301,6 +302,7 @@ __global__ __launch_bounds__(512, 2) void eval_fused_split_kernel(EvalDesc one, 
     // the descriptor counts centre tiles of EC = 64; this kernel walks them in pieces of ECT
     const int64_t c_begin = (int64_t)split * E.tiles_per_split * EC;
     const int ntiles_all = E.ntiles;
+    const int nsub = __builtin_amdgcn_readfirstlane(E.nsub);  // (E may live in global memory: read inside the centre loop it was a flat load + wait per 16-centre step)
     const int my_tiles = min(E.tiles_per_split, ntiles_all - split * E.tiles_per_split) * (EC / ECT);
     constexpr int NLD = ECT * D / 2 / 512;
     v2d stg[NLD];
@@ -344,7 +346,7 @@ __global__ __launch_bounds__(512, 2) void eval_fused_split_kernel(EvalDesc one, 
         }
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) {
-            if ((int)(c0 >> 4) + ct >= E.nsub) break;  // only padding from here on (uniform: every wave leaves before the barrier)
+            if ((int)(c0 >> 4) + ct >= nsub) break;  // only padding from here on (uniform: every wave leaves before the barrier)
             // ---- phase 1: this group's half of S', exchanged with the partner wave (same queries, other half)
             v4d Sp = {0.0, 0.0, 0.0, 0.0};
             const double *crow = &Cs[(16 * ct + l15) * LDC + H * grp + l4];
