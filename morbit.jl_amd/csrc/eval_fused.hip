@@ -95,15 +95,39 @@ __global__ __launch_bounds__(256, (DT <= 4) ? 2 : 1) void eval_fused_kernel(Eval
             *(v2d *)&Cs[row * LDC + col] = stg[u];
         }
     };
+    // the tile's squared norms and weights travel with it, requested a tile ahead like the coordinates (fetched at the point of use
+    // they were a memory round trip per 64-centre tile -- 128 per workgroup at n = 8192 -- with every wave waiting between two barriers)
+    constexpr int NSC = ((KOUT + 1) * EC + 255) / 256;
+    double stg_s[NSC];
+    auto load_scalars = [&](int64_t c0) {
+#pragma unroll
+        for (int u = 0; u < NSC; ++u) {
+            const int e = tid + 256 * u;
+            if (e < EC)
+                stg_s[u] = csq[c0 + e];
+            else if (e < (KOUT + 1) * EC)
+                stg_s[u] = Wc[(int64_t)(l0 + (e - EC) / EC) * npad + c0 + ((e - EC) % EC)];
+        }
+    };
     load_tile(c_begin);
+    load_scalars(c_begin);
     for (int tile = 0; tile < my_tiles; ++tile) {
         const int64_t c0 = c_begin + (int64_t)tile * EC;
         __syncthreads();
         store_tile();
-        if (tid < EC) Sq[tid] = csq[c0 + tid];
-        for (int e = tid; e < KOUT * EC; e += 256) Ws[e] = Wc[(int64_t)(l0 + e / EC) * npad + c0 + (e % EC)];
+#pragma unroll
+        for (int u = 0; u < NSC; ++u) {
+            const int e = tid + 256 * u;
+            if (e < EC)
+                Sq[e] = stg_s[u];
+            else if (e < (KOUT + 1) * EC)
+                Ws[e - EC] = stg_s[u];
+        }
         __syncthreads();
-        if (tile + 1 < my_tiles) load_tile(c0 + EC);
+        if (tile + 1 < my_tiles) {
+            load_tile(c0 + EC);
+            load_scalars(c0 + EC);
+        }
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
             if ((int)(c0 >> 4) + ct >= nsub) break;  // only padding from here on (zero weights: nothing to add)
