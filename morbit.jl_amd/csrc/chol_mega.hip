@@ -78,11 +78,14 @@ struct Edge {
     int head, tail_c0, srows_edge, pstream_edge;
     int shalf, sh_head, sh_tail_c0;  // shalf: streamed tiles of the block columns c < sh_head and c >= sh_tail_c0 as two 64-row jobs (see run_stream)
     int tfull1;  // > 0: panel tiles more than tfull1 - 1 block rows below the streamed ones are ONE 128-row job (Job::w = 2), not two halves
+    int xhalf;   // the block rows below the square (i >= NT: right-hand sides riding along) hold at most 64 non-zero rows: rows 64 .. 127 of
+                 // their tiles are zero and stay zero -- panel and bulk jobs work on the upper half only and publish for both (Job::w = 3 / half code 2)
 };
 __host__ __device__ inline bool edge_col(int c, const Edge &e) { return c < e.head || c >= e.tail_c0; }
 __host__ __device__ inline int srows_at(int c, int srows, const Edge &e) { return edge_col(c, e) ? e.srows_edge : srows; }
 __host__ __device__ inline bool shalf_at(int c, int srows, const Edge &e) { return e.shalf && (c < e.sh_head || c >= e.sh_tail_c0) && srows_at(c, srows, e) >= 5; }
 __host__ __device__ inline bool tfull_at(int i, int c, int srows, const Edge &e) { return e.tfull1 > 0 && i - c - srows_at(c, srows, e) > e.tfull1 - 1; }
+__host__ __device__ inline bool xhalf_at(int i, int nt, const Edge &e) { return e.xhalf && i >= nt; }
 
 struct Args {
     double *A;
@@ -356,7 +359,7 @@ __device__ __attribute__((noinline)) bool run_bulk(const Args &a, Shared &sh, co
     const int64_t lda = uni64(a.lda);
     double *const A = uni_ptr(a.A);
     const int i = __builtin_amdgcn_readfirstlane(jb.i), c = __builtin_amdgcn_readfirstlane(jb.c), jw = __builtin_amdgcn_readfirstlane(jb.w);
-    const int w = jw & 255, roff = (TM == 64) ? 64 * (jw >> 8) : 0;
+    const int w = jw & 255, hcode = jw >> 8, roff = (TM == 64 && hcode == 1) ? 64 : 0;  // (hcode 2: rows 0 .. 63 of a tile whose rows 64 .. 127 are zero)
     const int pl = wstart(w + 1, a.first, a.win) - 1;  // last panel of the window: rows finish their panels in order
     if (!wg_wait(sh, a, a.tdone + (size_t)i * a.NT + pl, 2u, a.tdone + (size_t)c * a.NT + pl, 2u, a.ucnt + (size_t)i * a.NT + c,
                  (unsigned)(2 * w), 0x100u))
@@ -378,7 +381,7 @@ __device__ __attribute__((noinline)) bool run_bulk(const Args &a, Shared &sh, co
     else
         store_tile<TM, false, false, true>(C, lda, acc);
     wg_drain();
-    if (threadIdx.x == 0) addf(a.ucnt + (size_t)i * a.NT + c, TM == 128 ? 2u : 1u);
+    if (threadIdx.x == 0) addf(a.ucnt + (size_t)i * a.NT + c, (TM == 128 || hcode == 2) ? 2u : 1u);
     return true;
 }
 
@@ -750,7 +753,8 @@ __device__ __attribute__((noinline)) bool run_panel(const Args &a, Shared &sh, c
     constexpr int TM = FULL ? 128 : 64;
     const int64_t lda = uni64(a.lda);
     double *const A = uni_ptr(a.A);
-    const int i = __builtin_amdgcn_readfirstlane(jb.i), c = __builtin_amdgcn_readfirstlane(jb.c), roff = FULL ? 0 : 64 * __builtin_amdgcn_readfirstlane(jb.w);
+    const int i = __builtin_amdgcn_readfirstlane(jb.i), c = __builtin_amdgcn_readfirstlane(jb.c), wcode = __builtin_amdgcn_readfirstlane(jb.w);
+    const int roff = (!FULL && wcode == 1) ? 64 : 0;  // (wcode 3: rows 0 .. 63 of a tile whose rows 64 .. 127 are zero and stay zero)
     if (!window_part<TM>(a, sh, i, c, c, roff, nullptr)) return false;
     JLOG(4);
     double *C = A + (int64_t)i * NB + roff + (int64_t)c * NB * lda;
@@ -766,7 +770,7 @@ __device__ __attribute__((noinline)) bool run_panel(const Args &a, Shared &sh, c
     store_tile<TM, false, false, true>(C, lda, acc);
     wg_drain();
     if (a.fault && i == a.MT - 1 && c == 0 && roff == 0) return true;  // test hook: this (half) tile is never published
-    if (threadIdx.x == 0) addf(a.tdone + (size_t)i * a.NT + c, FULL ? 2u : 1u);
+    if (threadIdx.x == 0) addf(a.tdone + (size_t)i * a.NT + c, (FULL || wcode == 3) ? 2u : 1u);
     return true;
 }
 
@@ -1104,7 +1108,9 @@ static void build_job_tables(int NT, int MT, int slack, int slack_chain, int fir
                 }
             }
             else
-                if (tfull_at(i, c, srows, edge))
+                if (xhalf_at(i, NT, edge))
+                    pj.push_back(Job{JOB_T, (short)i, (short)c, (short)3});
+                else if (tfull_at(i, c, srows, edge))
                     pj.push_back(Job{JOB_T, (short)i, (short)c, (short)2});
                 else
                     for (int h = 0; h < 2; ++h) pj.push_back(Job{JOB_T, (short)i, (short)c, (short)h});
@@ -1123,7 +1129,9 @@ static void build_job_tables(int NT, int MT, int slack, int slack_chain, int fir
                     if (((i - c <= sr) && chainq) != (cls == 1)) continue;  // chain tiles: queues of their own
                     const bool half = (i != c && c < wstart(w + 1, first, win) + slack + half_cols) ||
                                       (c >= NT - tail_half && w >= nbulk_updates(i, c, slack, slack_chain, first, win, sr) - tail_half_w);
-                    if (half) {
+                    if (xhalf_at(i, NT, edge)) {
+                        bj.push_back(Job{JOB_UH, (short)i, (short)c, (short)(w + 512)});  // upper half, counts for both
+                    } else if (half) {
                         bj.push_back(Job{JOB_UH, (short)i, (short)c, (short)w});
                         bj.push_back(Job{JOB_UH, (short)i, (short)c, (short)(w + 256)});
                     } else {
@@ -1211,6 +1219,9 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
         //  the streamed ones have the slack for 128-row jobs, whose GEMM loop shares the B operand between twice the MFMAs:
         //  alternating A/B r04: n = 12288 / 16384: -0.9 / -1.1 %, n = 10240: 0; all panel tiles full at n <= 8192: +4 .. +28 %)
         edge.tfull1 = env_tfull >= 0 ? env_tfull + 1 : (getenv("MRBF_MEGA_TFULL") ? 0 : (NTq >= 96 ? 9 : 0));
+        // rows below the square that are known to be zero (the fit's right-hand sides: k of the 128 rows of the extra block row)
+        static const int env_xhalf = getenv("MRBF_MEGA_XHALF") ? atoi(getenv("MRBF_MEGA_XHALF")) : 1;
+        edge.xhalf = (env_xhalf && MT == NT + 1 && ctx->mega_xreal > 0 && ctx->mega_xreal <= 64) ? 1 : 0;
     }
     const int srows_max = std::max(srows, (edge.head > 0 || edge.tail_c0 < NT) ? edge.srows_edge : srows);
     // job tables: one set per (NT, MT, schedule parameters), kept in a small per-context LRU -- Morbit's training sets grow and shrink
@@ -1228,7 +1239,7 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
     const int tail_half_w = env_tail_half_w >= 0 ? env_tail_half_w : 1000;  // only the last so many window updates of such a tile
     const long tab_key = (chainq ? 50 : 0) + slack + 100000000000000L * tail_half + 10000000000000000L * std::min(tail_half_w, 99) + 100 * ctx->mega_half_cols + 10000 * slack_chain + 1000000 * first + 10000000 * win + 100000000 * (long)srows +
                          1000000000L * edge.head + 1000000000000L * edge.tail_c0;
-    const long tab_key2 = (edge.shalf ? 1 + edge.sh_head + 1000L * edge.sh_tail_c0 : 0) + 1000000L * edge.tfull1;
+    const long tab_key2 = (edge.shalf ? 1 + edge.sh_head + 1000L * edge.sh_tail_c0 : 0) + 1000000L * edge.tfull1 + 1000000000L * edge.xhalf;
     MegaTables *tab = nullptr;
     for (auto &t : ctx->mega_tables)
         if (t.nt == NT && t.mt == MT && t.key == tab_key && t.key2 == tab_key2) tab = &t;
@@ -1476,11 +1487,13 @@ static int32_t check_mega_tables(int nt, int mt, int slack, int slack_chain, int
             ++bad;
     }
     for (const Job &j : pj) {
-        if (j.kind != JOB_T || j.c >= nt || j.i <= j.c + sr(j.c) || j.i >= mt || j.w < 0 || j.w > 2 || (j.w == 2) != tfull_at(j.i, j.c, srows, edge)) {
+        const bool xh = xhalf_at(j.i, nt, edge);
+        if (j.kind != JOB_T || j.c >= nt || j.i <= j.c + sr(j.c) || j.i >= mt || j.w < 0 || j.w > 3 || (j.w == 3) != xh ||
+            (!xh && (j.w == 2) != tfull_at(j.i, j.c, srows, edge))) {
             ++bad;
             continue;
         }
-        fin[(size_t)j.i * nt + j.c] += j.w == 2 ? 2 : 1;  // a panel tile: one 128-row job or two halves
+        fin[(size_t)j.i * nt + j.c] += j.w >= 2 ? 2 : 1;  // a panel tile: one 128-row job, two halves, or the upper half alone (the lower one is zero)
     }
     for (int c = 0; c < nt; ++c)
         for (int i = 0; i < mt; ++i) bad += fin[(size_t)i * nt + c] != (i >= c ? 2 : 0);
@@ -1500,7 +1513,10 @@ static int32_t check_mega_tables(int nt, int mt, int slack, int slack_chain, int
                 last_c = j.c;
                 if (j.c < wstart(w + 1, first, win)) ++bad;  // a window never reaches a block column it still belongs to
                 if (((j.i - j.c <= sr(j.c)) && chainq) != (cls == 1)) ++bad;  // chain tiles in their own queues, nothing else there
-                upd[(size_t)j.i * nt + j.c] += j.kind == JOB_U ? 2 : 1;
+                const int hcode = j.w >> 8;  // bulk halves: 0 / 1 = rows 0..63 / 64..127, 2 = the upper half of a tile whose lower half is zero
+                if (j.kind == JOB_U ? hcode != 0 : (hcode > 2 || (hcode == 2) != xhalf_at(j.i, nt, edge))) ++bad;
+                if (j.kind == JOB_U && xhalf_at(j.i, nt, edge)) ++bad;
+                upd[(size_t)j.i * nt + j.c] += (j.kind == JOB_U || hcode == 2) ? 2 : 1;
             }
         }
         for (int c = 0; c < nt; ++c)
@@ -1547,6 +1563,7 @@ extern "C" int32_t mrbf_debug_mega_tables2(int32_t nt, int32_t mt, int32_t slack
     edge.shalf = (opt5[4] & 2) ? 1 : 0;  // (bit 1 of the last option: streamed tiles of five-row block columns as 64-row halves;
     edge.sh_head = (opt5[4] >> 2) & 0xff;  //  bits 2..9 / 10..17: only the first / last so many block columns, 0 / 0 = all)
     edge.sh_tail_c0 = ((opt5[4] >> 10) & 0xff) ? std::max(edge.sh_head, nt - ((opt5[4] >> 10) & 0xff)) : (edge.sh_head ? nt : 0);
+    edge.xhalf = (opt5[4] >> 26) & 1;  // bit 26: the block rows below the square hold at most 64 non-zero rows
     edge.tfull1 = (opt5[4] >> 18) & 0xff;  // bits 18..25: panel tiles more than this - 1 block rows below the streamed ones as one 128-row job
     return check_mega_tables(nt, mt, slack, slack_chain, first, win, srows, edge, half_cols, opt5[2], opt5[3] > 0 ? opt5[3] : 1000, (opt5[4] & 1) != 0, out);
 }

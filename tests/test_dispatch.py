@@ -351,6 +351,17 @@ def test_mega_job_tables_are_consistent():
         nfull = sum(1 for cc in range(nt) for i in range(cc + 1, mt) if i > cc + sr(cc) and i - cc - sr(cc) > t)
         nhalf_tiles = sum(1 for cc in range(nt) for i in range(cc + 1, mt) if i > cc + sr(cc)) - nfull
         assert out[0] == nfull + 2 * nhalf_tiles, (c, o, list(out), nfull, nhalf_tiles)
+    # the block row below the square holds at most 64 non-zero rows (bit 26: the fit's right-hand sides): its panel tiles are ONE job on the
+    # upper half that publishes for both, its bulk updates one half job per window -- every tile still finished / updated exactly once
+    for c, o in [((32, 33, 3, 6, 1, 4, 5, 0), (0, 16, 20, 0, 1 << 26)), ((64, 65, 3, 7, 1, 6, 3, 0), (0, 16, 20, 0, (1 << 26) | 2)),
+                 ((96, 97, 3, 7, 1, 8, 3, 0), (0, 16, 20, 0, (1 << 26) | (9 << 18))), ((5, 6, 1, 1, 1, 1, 0, 0), (0, 0, 0, 0, 1 << 26))]:
+        opt = (ctypes.c_int32 * 5)(*o)
+        assert lib.mrbf_debug_mega_tables2(*c, opt, out) == 0, (c, o)
+        assert out[5] == 0, (c, o, list(out))
+        opt0 = (ctypes.c_int32 * 5)(o[0], o[1], o[2], o[3], o[4] & ~(1 << 26))
+        out0 = (ctypes.c_int64 * 6)()
+        assert lib.mrbf_debug_mega_tables2(*c, opt0, out0) == 0 and out0[5] == 0
+        assert out[0] < out0[0] and out[1] <= out0[1], (c, o, list(out), list(out0))  # fewer panel jobs, no more bulk jobs
     opt = (ctypes.c_int32 * 5)(0, 0, 0, 0, 0)
     for c in cases[:6]:  # without options: the same tables as the plain entry point
         assert lib.mrbf_debug_mega_tables2(*c, opt, out) == 0 and out[4] == seen[c], c
