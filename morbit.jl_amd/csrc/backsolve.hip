@@ -42,8 +42,13 @@ struct Shared {
 // M_t(j) = L(j+1+t, j) inv(L_jj), t = 0, 1 -> Mbuf[(2 j + t) 128^2], column-major, ld 128.  Four workgroups per product (32 columns
 // each; inv(L_jj) is lower triangular: columns >= c0 only meet rows k >= c0).  f64 MFMA 16x16x4, operands straight from global
 // memory in bursts of eight k-steps, the next burst in flight under this burst's MFMAs.
+// (also resets the chain's flag lines and marks the exchange buffers "not published yet" for the first pass of right-hand sides: two
+//  memset launches less in front of the persistent kernel)
 __global__ __launch_bounds__(256) void premul_kernel(const double *__restrict__ L, int64_t lda, const double *__restrict__ linv_all,
-                                                     double *__restrict__ Mbuf, int nb) {
+                                                     double *__restrict__ Mbuf, int nb, unsigned *__restrict__ flags, int nflags,
+                                                     unsigned long long *__restrict__ xb, int nxb) {
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < nflags; e += gridDim.x * 256) flags[e] = 0u;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < nxb; e += gridDim.x * 256) xb[e] = ~0ull;
     const int slab = blockIdx.x & 3, t = (blockIdx.x >> 2) & 1, j = blockIdx.x >> 3;
     const int i = j + 1 + t;
     if (i >= nb) return;
@@ -420,13 +425,13 @@ int backsolve_persistent(mrbf_ctx *ctx, int64_t npad, const double *L, int64_t l
         return backsolve_blocked(ctx, npad, L, lda, linv_all, Y, ldy, k);
     unsigned *flags;
     MRBF_TRY(get_buf(ctx, S_BSOLVE_FLAGS, (size_t)(nb + 1) * 32, &flags));  // one 128-byte line per block + the abort word
-    MRBF_HIP(ctx, hipMemsetAsync(flags, 0, (size_t)(nb + 1) * 32 * sizeof(unsigned), ctx->stream));
     const unsigned long long spin_ticks = (unsigned long long)std::max(1, ctx->spin_ms) * 100000ull;  // wall_clock64: 100 MHz
     const int fault = (ctx->debug_fault & 2) ? 1 : 0;
     double *xb, *Mbuf;
     MRBF_TRY(get_buf(ctx, S_BSOLVE_X, (size_t)2 * nb * 4 * NB, &xb));  // xb | zb
     MRBF_TRY(get_buf(ctx, S_BSOLVE_M, (size_t)nb * 2 * NB * NB, &Mbuf));
-    hipLaunchKernelGGL(premul_kernel, dim3((unsigned)(8 * (nb - 1))), dim3(256), 0, ctx->stream, L, lda, linv_all, Mbuf, nb);
+    hipLaunchKernelGGL(premul_kernel, dim3((unsigned)(8 * (nb - 1))), dim3(256), 0, ctx->stream, L, lda, linv_all, Mbuf, nb, flags, (nb + 1) * 32,
+                       reinterpret_cast<unsigned long long *>(xb), 2 * nb * 4 * NB);
     // debug (MRBF_BSOLVE_STAMPS=1): per block, wall_clock64 when x_{j+1} was seen, after the barrier, before the publication
     static const bool want_stamps = getenv("MRBF_BSOLVE_STAMPS") && atoi(getenv("MRBF_BSOLVE_STAMPS")) != 0;
     long long *stamps = nullptr;
@@ -439,7 +444,7 @@ int backsolve_persistent(mrbf_ctx *ctx, int64_t npad, const double *L, int64_t l
     for (int k0 = 0; k0 < k; k0 += 4) {
         const int kb = std::min(4, k - k0);
         ++epoch;
-        MRBF_HIP(ctx, hipMemsetAsync(xb, 0xff, (size_t)2 * nb * 4 * NB * sizeof(double), ctx->stream));  // "not published yet"
+        if (k0 > 0) MRBF_HIP(ctx, hipMemsetAsync(xb, 0xff, (size_t)2 * nb * 4 * NB * sizeof(double), ctx->stream));  // "not published yet" (first pass: premul_kernel)
 #define MRBF_BSP(KBV)                                                                                                          \
     hipLaunchKernelGGL((backsolve_persistent_kernel<KBV>), dim3((unsigned)(2 * nb)), dim3(NTHR), 0, ctx->stream, L, lda, linv_all, Mbuf, Y, ldy, k0, nb, \
                        flags, epoch, spin_ticks, status, fault, xb, xb + (size_t)nb * 4 * NB, stamps)

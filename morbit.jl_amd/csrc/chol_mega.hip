@@ -1303,7 +1303,7 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
     hnow();  // 1: buffers / job tables
     MRBF_HIP(ctx, hipMemsetAsync(fl, 0, nfl * sizeof(unsigned), ctx->stream));
     hnow();  // 2: first memset enqueued
-    MRBF_HIP(ctx, hipMemsetAsync(dinfo, 0, sizeof(int), ctx->stream));
+    if (!ctx->mega_info_clean) MRBF_HIP(ctx, hipMemsetAsync(dinfo, 0, sizeof(int), ctx->stream));  // (the fit zeroes its flag words itself, in front of everything)
     hnow();  // 3: second memset enqueued
     a.ctl = fl;
     a.wq_head = fl + CTL_WORDS;

@@ -84,6 +84,7 @@ struct mrbf_ctx {
     unsigned long long *mega_stat_dev = nullptr;
     long mega_stat_shape = 0;
     int mega_stat_pending = 0;
+    int mega_info_clean = 0;  // the caller of the tall factorisation has zeroed *dinfo on the same stream already
     int mega_xreal = 0;  // > 0: the caller of the tall factorisation knows that only so many of the rows below the square are non-zero (the fit's right-hand sides)
     float last_device_ms = 0.f;
     int slow_launches = 0;

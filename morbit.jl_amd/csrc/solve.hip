@@ -599,8 +599,10 @@ static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info
         MRBF_TRY(launch_pad_identity(ctx, Phi, n, npad, ld));
         if (q == 0) hipLaunchKernelGGL(set_rhs_rows_kernel, dim3(nblk(npad * xt)), dim3(256), 0, ctx->stream, Phi, ld, npad, xt, B, k);
         ctx->mega_xreal = k;  // (rows k .. xt - 1 of the extra block row are zero: the persistent factorisation skips their half tiles)
+        ctx->mega_info_clean = 1;  // (dinfo[0 .. 3] were zeroed at the top of this function; nothing has written dinfo[0] since)
         const int rc_potrf = potrf_blocked_tall(ctx, npad, npad + xt, Phi, ld, dinfo, linv_all);
         ctx->mega_xreal = 0;
+        ctx->mega_info_clean = 0;
         if (rc_potrf != 0) return rc_potrf;
         MRBF_HIP(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
     } else {
