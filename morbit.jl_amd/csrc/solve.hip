@@ -476,6 +476,155 @@ __global__ __launch_bounds__(256) void trsm_lt_small_kernel(const double *__rest
     }
 }
 
+// ---- behind the backward substitution: re-projection of the weights, tail coefficients and the scatter into the model in three launches
+// (were seven: copy, Q1'w, w -= Q1 (Q1'w), W'w, inv(Lx)' z, finish, scatter -- each 4-15 us behind the other).  The two reductions
+// over the sites are taken from the same w:  W'(w - Q1 T2) = W'w - (Q1'W)' T2  with  Q1'W = cg G  (cg = 1 when W = Phi Q1, 1/2 when
+// W = Phi Q1 - Q1 G / 2), so that z = T1 - W'w + cg G' T2 needs no second pass (T2 = Q1'w is at rounding level: w solves a system
+// whose right-hand side and matrix are projected).
+//   tail_dots_kernel    per 64 sites: partial Q1'w and W'w                                   (npad / 64 workgroups)
+//   tail_coeff_kernel   fixed-order sums, z, lam = inv(Lx)' z (tail of degree 1), constant term  (one workgroup)
+//   tail_apply_kernel   w -= Q1 T2, W / Wc / lam of the model                                  (npad / 64 workgroups)
+__global__ __launch_bounds__(256) void tail_dots_kernel(const double *__restrict__ Bw, int64_t ldb, const double *__restrict__ Q1,
+                                                        const double *__restrict__ Wm, int64_t ldq, int64_t n, int q, int k,
+                                                        double *__restrict__ part) {
+    __shared__ double ws[64 * 16];
+    __shared__ double red[4][2][64];
+    const int tid = threadIdx.x, g = tid >> 6, lane = tid & 63;
+    const int64_t R0 = (int64_t)blockIdx.x * 64;
+    for (int e = tid; e < 64 * k; e += 256) {
+        const int i = e & 63, l = e >> 6;
+        ws[e] = R0 + i < n ? Bw[R0 + i + (int64_t)l * ldb] : 0.0;
+    }
+    __syncthreads();
+    // thread (a, g): column a (< q <= 129 -> up to three passes of 64 columns), rows 16 g .. 16 g + 15; the four row groups are added in order
+    for (int a0 = 0; a0 < q; a0 += 64) {
+        const int a = a0 + lane;
+        double qv[16], wv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int64_t r = R0 + 16 * g + u;
+            const bool ok = a < q && r < n;
+            qv[u] = ok ? Q1[r + (int64_t)a * ldq] : 0.0;
+            wv[u] = ok ? Wm[r + (int64_t)a * ldq] : 0.0;
+        }
+        for (int l = 0; l < k; ++l) {
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const double w = ws[l * 64 + 16 * g + u];
+                s0 = fma(qv[u], w, s0);
+                s1 = fma(wv[u], w, s1);
+            }
+            __syncthreads();
+            red[g][0][lane] = s0;
+            red[g][1][lane] = s1;
+            __syncthreads();
+            if (g == 0 && a < q) {
+                double *o = part + ((size_t)blockIdx.x * 2 * k + l) * q + a;
+                o[0] = (red[0][0][lane] + red[1][0][lane]) + (red[2][0][lane] + red[3][0][lane]);
+                o[(size_t)k * q] = (red[0][1][lane] + red[1][1][lane]) + (red[2][1][lane] + red[3][1][lane]);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void tail_coeff_kernel(const double *__restrict__ part, int nch, int q, int k, int d, const double *__restrict__ T1,
+                                                         const double *__restrict__ G, double cg, const double *__restrict__ LxInv,
+                                                         double sqrtn, const double *__restrict__ mean, double *__restrict__ T2,
+                                                         double *__restrict__ lam_out) {
+    __shared__ double t2[129 * 16], zz[129 * 16], xx[129 * 16];
+    const int tid = threadIdx.x, nthr = blockDim.x;  // (1024 threads: 2 k q sums of up to 256 partials each, one per thread at k = 2, q = 65)
+    // fixed-order sums over the chunks, 32 loads in flight
+    for (int e = tid; e < 2 * k * q; e += nthr) {
+        double sv = 0.0;
+        for (int c0 = 0; c0 < nch; c0 += 32) {
+            double v[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) v[u] = c0 + u < nch ? part[(size_t)(c0 + u) * 2 * k * q + e] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 32; ++u) sv += v[u];
+        }
+        if (e < k * q)
+            t2[e] = sv;  // [l][a]
+        else
+            zz[e - k * q] = sv;
+    }
+    __syncthreads();
+    for (int e = tid; e < k * q; e += nthr) {
+        const int l = e / q, a = e % q;
+        double corr = 0.0;
+        for (int b0 = 0; b0 < q; b0 += 16) {  // sixteen loads of the column in flight
+            double gv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) gv[u] = b0 + u < q ? G[b0 + u + (int64_t)a * q] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) corr = fma(gv[u], b0 + u < q ? t2[l * q + b0 + u] : 0.0, corr);
+        }
+        zz[e] = T1[a + (int64_t)l * q] - zz[e] + cg * corr;
+        T2[a + (int64_t)l * q] = t2[e];
+    }
+    __syncthreads();
+    // lam_{1..d} = inv(Lx)' z_{1..d}:  x_j = sum_{i >= j} inv(Lx)(i, j) z_i  -- thread (j, l), sixteen loads of column j in flight
+    for (int e = tid; e < k * d; e += nthr) {
+        const int l = e / d, j = e % d;
+        double acc = 0.0;
+        for (int i0 = j; i0 < d; i0 += 16) {
+            double iv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) iv[u] = i0 + u < d ? LxInv[i0 + u + (int64_t)j * 128] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc = fma(iv[u], i0 + u < d ? zz[l * q + 1 + i0 + u] : 0.0, acc);
+        }
+        xx[l * q + 1 + j] = acc;
+    }
+    __syncthreads();
+    // constant term: lam_0 = z_0 / sqrt n - sum_t mean_t lam_t   (see finish_lambda_kernel)
+    if (tid < k) {
+        const int l = tid;
+        double dsum = 0.0;
+        for (int t0 = 1; t0 < q; t0 += 16) {
+            double mv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) mv[u] = t0 + u < q ? mean[t0 + u - 1] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) dsum = fma(mv[u], t0 + u < q ? xx[l * q + t0 + u] : 0.0, dsum);
+        }
+        xx[l * q] = zz[l * q] / sqrtn - dsum;
+    }
+    __syncthreads();
+    for (int e = tid; e < k * q; e += nthr) lam_out[(e % q) + (int64_t)(e / q) * q] = xx[e];  // q x k column-major like T1w
+}
+
+__global__ __launch_bounds__(256) void tail_apply_kernel(const double *__restrict__ Bw, int64_t ldb, const double *__restrict__ Q1, int64_t ldq,
+                                                         const double *__restrict__ T2, const double *__restrict__ lamsrc, int64_t n,
+                                                         int64_t npad, int q, int k, double *__restrict__ W, double *__restrict__ Wc,
+                                                         double *__restrict__ lam) {
+    __shared__ double part4[4][64];
+    const int tid = threadIdx.x, r = tid & 63, g = tid >> 6;
+    const int64_t row = (int64_t)blockIdx.x * 64 + r;
+    for (int l = 0; l < k; ++l) {
+        double s0 = 0.0, s1 = 0.0;
+        if (row < n) {
+            int t = g;
+            for (; t + 4 < q; t += 8) {
+                s0 = fma(Q1[row + (int64_t)t * ldq], T2[t + (int64_t)l * q], s0);
+                s1 = fma(Q1[row + (int64_t)(t + 4) * ldq], T2[t + 4 + (int64_t)l * q], s1);
+            }
+            if (t < q) s0 = fma(Q1[row + (int64_t)t * ldq], T2[t + (int64_t)l * q], s0);
+        }
+        __syncthreads();
+        part4[g][r] = s0 + s1;
+        __syncthreads();
+        if (g == 0 && row < npad) {
+            const double v = row < n ? Bw[row + (int64_t)l * ldb] - ((part4[0][r] + part4[1][r]) + (part4[2][r] + part4[3][r])) : 0.0;
+            Wc[row + (int64_t)l * npad] = v;
+            if (row < n) W[row * k + l] = v;
+        }
+    }
+    if (blockIdx.x == 0)
+        for (int e = tid; e < q * k; e += 256) lam[(int64_t)(e % q) * k + e / q] = lamsrc[(e % q) + (int64_t)(e / q) * q];
+}
+
 // returns 0 with *not_pd = 1 when a factorisation met a non-positive pivot (caller may retry with LU), and 0 with *gave_up = 1
 // when the persistent factorisation abandoned a dependency (caller re-runs this function with the host-driven factorisation)
 static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info *info, int *not_pd, int *gave_up) {
@@ -625,6 +774,21 @@ static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info
                 MRBF_TRY(backsolve_blocked(ctx, npad, Phi, ld, linv_all, B, npad, k));
         } else {
             MRBF_BLAS(ctx, rocsolver_dpotrs(ctx->blas, rocblas_fill_lower, (int)n, k, Phi, (int)ld, B, (int)npad));
+        }
+        static const int tail3 = getenv("MRBF_TAIL3") ? atoi(getenv("MRBF_TAIL3")) : 1;
+        if (tail3 && q > 0 && q <= 129 && k <= 16 && (q == 1 || LxInv)) {
+            // re-projection, tail coefficients and scatter in three launches (tail_dots / tail_coeff / tail_apply above)
+            const int nch = (int)(npad / 64);
+            double *T2, *part;
+            MRBF_TRY(get_buf(ctx, S_T2, (size_t)q * k, &T2));
+            MRBF_TRY(get_buf(ctx, S_TAIL_PART, (size_t)nch * 2 * k * q, &part));
+            hipLaunchKernelGGL(tail_dots_kernel, dim3((unsigned)nch), dim3(256), 0, ctx->stream, B, npad, Q1, Wm, npad, n, q, k, part);
+            hipLaunchKernelGGL(tail_coeff_kernel, dim3(1), dim3(1024), 0, ctx->stream, part, nch, q, k, q > 1 ? d : 0, T1, G, fused ? 1.0 : 0.5, LxInv,
+                               std::sqrt((double)n), M->mean, T2, T1w);
+            hipLaunchKernelGGL(tail_apply_kernel, dim3((unsigned)nch), dim3(256), 0, ctx->stream, B, npad, Q1, npad, T2, T1w, n, M->npad, q, k, M->W,
+                               M->Wc, M->lam);
+            MRBF_HIP(ctx, hipGetLastError());
+            return 0;
         }
         if (q > 0) {
             double *T2;
