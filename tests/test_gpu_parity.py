@@ -190,7 +190,8 @@ def _synthetic(n, d, k, seed):
 @pytest.mark.parametrize("kernel,deg,n,d", [("gaussian", -1, 700, 32), ("gaussian", 1, 513, 32), ("multiquadric", 1, 640, 64),
                                            ("cubic", 1, 389, 17), ("inv_multiquadric", 0, 300, 7),
                                            ("thin_plate_spline", 1, 200, 5), ("cubic", -1, 257, 9),
-                                           ("cubic", 1, 600, 200), ("multiquadric", 1, 500, 130), ("gaussian", 0, 300, 140)])
+                                           ("cubic", 1, 600, 200), ("multiquadric", 1, 500, 130), ("gaussian", 0, 300, 140),
+                                           ("cubic", 1, 700, 100), ("multiquadric", 1, 1029, 128)])
 def test_medium_sizes_against_oracle(ctx, kernel, deg, n, d):
     # ragged n (not a multiple of 64/128, odd), d not a multiple of 16
     C, Y = _synthetic(n, d, 2, seed=n + d)
