@@ -255,7 +255,11 @@ int32_t mrbf_debug_mega_tables(int32_t nt, int32_t mt, int32_t slack, int32_t sl
                                int32_t half_cols, int64_t *out6);
 /* The same with the round-4 schedule options: opt5 = { head columns, tail columns of the chain-bound edge regime, block columns at the
  * end whose bulk jobs are 64-row halves, only a tile's last so many windows as halves (0: all), chain tiles' window jobs in queues of
- * their own }.  The invariants cover both queue classes and the per-column number of streamed rows. */
+ * their own }.  The last option is a bit field: bit 0 chain tiles' queues; bit 1 streamed tiles of five-row block columns as two 64-row
+ * jobs (bits 2..9 / 10..17: only the first / last so many block columns, 0 / 0 = all); bits 18..25 = t + 1: panel tiles more than t
+ * block rows below the streamed ones as one 128-row job; bit 26: the block rows below the square hold at most 64 non-zero rows (one
+ * job per tile and window on the upper half that publishes for both).  The invariants cover both queue classes, the per-column
+ * number of streamed rows and every one of these job shapes (each tile finished / updated exactly once). */
 int32_t mrbf_debug_mega_tables2(int32_t nt, int32_t mt, int32_t slack, int32_t slack_chain, int32_t first, int32_t win, int32_t srows,
                                 int32_t half_cols, const int32_t *opt5, int64_t *out6);
 
