@@ -84,6 +84,7 @@ struct mrbf_ctx {
     unsigned long long *mega_stat_dev = nullptr;
     long mega_stat_shape = 0;
     int mega_stat_pending = 0;
+    unsigned long long *hpin = nullptr;  // 64 pinned host words: the small read-backs of a fit (flags, shift, device clock) land here in one round trip
     int mega_info_clean = 0;  // the caller of the tall factorisation has zeroed *dinfo on the same stream already
     int mega_xreal = 0;  // > 0: the caller of the tall factorisation knows that only so many of the rows below the square are non-zero (the fit's right-hand sides)
     float last_device_ms = 0.f;
@@ -177,5 +178,8 @@ void destroy_model(mrbf_ctx *ctx, mrbf_model *M);
 int fit_check(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info *info);
 // chol_mega.hip's launch clock: call after the stream has been synchronised behind a persistent factorisation
 int mega_collect_stat(mrbf_ctx *ctx);
+// the same in two halves: the download enqueued on the context's stream into pinned memory (nothing pending: no-op), evaluated after the caller's synchronisation
+int mega_stat_enqueue(mrbf_ctx *ctx);
+int mega_stat_finish(mrbf_ctx *ctx);
 
 }  // namespace mrbf

@@ -123,11 +123,29 @@ int finish_out(mrbf_ctx *ctx, double *user, const double *dev, size_t count) {
     return 0;
 }
 
+static void mega_stat_account(mrbf_ctx *ctx, unsigned long long ticks);
+int mega_stat_enqueue(mrbf_ctx *ctx) {
+    if (!ctx->mega_stat_pending || !ctx->mega_stat_dev || !ctx->hpin) return 0;
+    ctx->hpin[63] = ~0ull;
+    MRBF_HIP(ctx, hipMemcpyAsync(&ctx->hpin[63], ctx->mega_stat_dev, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    ctx->mega_stat_pending = 2;  // on its way
+    return 0;
+}
+int mega_stat_finish(mrbf_ctx *ctx) {
+    if (ctx->mega_stat_pending != 2) return mega_collect_stat(ctx);
+    ctx->mega_stat_pending = 0;
+    mega_stat_account(ctx, ctx->hpin[63]);
+    return 0;
+}
 int mega_collect_stat(mrbf_ctx *ctx) {
     if (!ctx->mega_stat_pending || !ctx->mega_stat_dev) return 0;
     ctx->mega_stat_pending = 0;
     unsigned long long ticks = 0;
     MRBF_HIP(ctx, hipMemcpy(&ticks, ctx->mega_stat_dev, sizeof(ticks), hipMemcpyDeviceToHost));
+    mega_stat_account(ctx, ticks);
+    return 0;
+}
+static void mega_stat_account(mrbf_ctx *ctx, unsigned long long ticks) {
     const float ms = (float)((double)ticks * 1e-5);  // wall_clock64 runs at 100 MHz
     ctx->last_device_ms = ms;
     if (ms > 0.f) {
@@ -140,7 +158,6 @@ int mega_collect_stat(mrbf_ctx *ctx) {
             if (ms < it->second) it->second = ms;
         }
     }
-    return 0;
 }
 
 }  // namespace mrbf
@@ -178,6 +195,10 @@ int32_t mrbf_init(int32_t device_id, mrbf_ctx **out) {
     if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess)
         return bail(MRBF_EHIP, "hipStreamCreate");
     ctx->stream = ctx->own_stream;
+    if (hipHostMalloc(reinterpret_cast<void **>(&ctx->hpin), 64 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->hpin = nullptr;  // (read-backs then go through pageable memory as before)
+    }
     if (rocblas_create_handle(&ctx->blas) != rocblas_status_success) return bail(MRBF_EBLAS, "rocblas_create_handle");
     rocblas_set_stream(ctx->blas, ctx->stream);
     rocblas_set_pointer_mode(ctx->blas, rocblas_pointer_mode_host);
@@ -248,6 +269,7 @@ int32_t mrbf_shutdown(mrbf_ctx *ctx) {
         if (b.p) (void)hipFree(b.p);
     for (auto &t : ctx->mega_tables)
         if (t.block) (void)hipFree(t.block);
+    if (ctx->hpin) (void)hipHostFree(ctx->hpin);
     for (auto &ev : ctx->ev)
         if (ev) (void)hipEventDestroy(ev);
     for (auto &ev : ctx->evx)

@@ -821,12 +821,18 @@ static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info
         // one host round trip for all the flags of this path, AFTER the solve has been enqueued: the solve kernels run on whatever
         // the factorisation left (they terminate on any input); if a flag is set their output is discarded and the caller falls
         // back to the LU path, which re-assembles Phi.  Reading the flags before the solve cost ~100 us of idle GPU per fit.
-        int hflags[4] = {0, 0, 0, 0};
-        double hscal[2] = {0.0, 0.0};
+        // (flags, shift and the factorisation's device clock land in pinned memory: three asynchronous downloads, ONE wait -- through
+        //  pageable memory every download was a round trip of its own, the clock's a synchronous one behind the others)
+        int hflags_local[4] = {0, 0, 0, 0};
+        double hscal_local[2] = {0.0, 0.0};
+        int *hflags = ctx->hpin ? reinterpret_cast<int *>(ctx->hpin) : hflags_local;
+        double *hscal = ctx->hpin ? reinterpret_cast<double *>(ctx->hpin + 4) : hscal_local;
+        hscal[0] = hscal[1] = 0.0;
         MRBF_HIP(ctx, hipMemcpyAsync(hflags, dinfo, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         if (q > 0) MRBF_HIP(ctx, hipMemcpyAsync(hscal, scal, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        MRBF_TRY(mega_stat_enqueue(ctx));
         MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        MRBF_TRY(mega_collect_stat(ctx));
+        MRBF_TRY(mega_stat_finish(ctx));
         info->ms_factor_device = ctx->last_device_ms;
         hinfo = hflags[0];
         if (hinfo < 0) {
