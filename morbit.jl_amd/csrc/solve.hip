@@ -951,8 +951,12 @@ static int fit_small(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_inf
         MRBF_TRY(get_buf(ctx, S_SMALL_DESC, (size_t)16, &dstamps));
         P.stamps = dstamps;
     }
-    int hflags[4] = {0, 0, 0, 0};
-    double hscal[2] = {0.0, 0.0};
+    // (read-backs through the context's pinned block where there is one: asynchronous downloads, one wait)
+    int hflags_local[4] = {0, 0, 0, 0};
+    double hscal_local[2] = {0.0, 0.0}, hchk_local[3] = {0, 0, 0};
+    int *hflags = ctx->hpin ? reinterpret_cast<int *>(ctx->hpin + 8) : hflags_local;
+    double *hscal = ctx->hpin ? reinterpret_cast<double *>(ctx->hpin + 12) : hscal_local;
+    double *hchk = ctx->hpin ? reinterpret_cast<double *>(ctx->hpin + 16) : hchk_local;
     int nc = force_nc > 0 ? force_nc : small_fit_cluster(ctx, 1);
     for (int attempt = 0; attempt < 2; ++attempt) {
         MRBF_HIP(ctx, hipMemsetAsync(cl, 0, smallfit::CL_WORDS * sizeof(int), ctx->stream));
@@ -961,7 +965,7 @@ static int fit_small(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_inf
         MRBF_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
         MRBF_HIP(ctx, hipMemcpyAsync(hflags, flags, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         MRBF_HIP(ctx, hipMemcpyAsync(hscal, scal, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        double hchk[3] = {0, 0, 0};
+        hchk[0] = hchk[1] = hchk[2] = 0.0;
         const bool with_check = checked && ctx->residual;
         if (with_check) MRBF_TRY(fit_check_enqueue(ctx, M, Y, hchk, ctx->ev[2], ctx->ev[3]));
         MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1026,7 +1030,9 @@ static int fit_check_finish(mrbf_ctx *ctx, const mrbf_model *M, const double *h,
     return 0;
 }
 int fit_check(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info *info) {
-    double h[3] = {0, 0, 0};
+    double h_local[3] = {0, 0, 0};
+    double *h = ctx->hpin ? reinterpret_cast<double *>(ctx->hpin + 20) : h_local;
+    h[0] = h[1] = h[2] = 0.0;
     MRBF_TRY(fit_check_enqueue(ctx, M, Y, h, ctx->ev[0], ctx->ev[1]));
     MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return fit_check_finish(ctx, M, h, info, ctx->ev[0], ctx->ev[1]);
