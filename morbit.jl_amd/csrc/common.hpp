@@ -84,6 +84,18 @@ struct mrbf_ctx {
     unsigned long long *mega_stat_dev = nullptr;
     long mega_stat_shape = 0;
     int mega_stat_pending = 0;
+    // pinned staging for small host buffers handed to / expected from the API (Julia and NumPy arrays): uploads are copied here and sent
+    // asynchronously, downloads land here and are copied out behind the call's one stream synchronisation (pin_flush) -- a transfer
+    // from / to pageable memory is a host round trip of its own.  Reset at the top of every API entry (each one ends synchronised).
+    char *pin_base = nullptr;
+    size_t pin_off = 0;
+    bool pin_armed = false;  // between pin_reset and pin_flush of an API entry that guarantees both
+    struct PinOut {
+        void *user;
+        const void *pin;
+        size_t bytes;
+    };
+    std::vector<PinOut> pin_out;
     unsigned long long *hpin = nullptr;  // 64 pinned host words: the small read-backs of a fit (flags, shift, device clock) land here in one round trip
     int mega_info_clean = 0;  // the caller of the tall factorisation has zeroed *dinfo on the same stream already
     int mega_xreal = 0;  // > 0: the caller of the tall factorisation knows that only so many of the rows below the square are non-zero (the fit's right-hand sides)
@@ -146,6 +158,8 @@ int stage_in(mrbf_ctx *ctx, Slot s, const double *user, size_t count, const doub
 // device buffer to produce an output into (user's own when device memory, else staging)
 int stage_out(mrbf_ctx *ctx, Slot s, double *user, size_t count, double **dev);
 int finish_out(mrbf_ctx *ctx, double *user, const double *dev, size_t count);
+void pin_reset(mrbf_ctx *ctx);   // top of an API entry
+void pin_flush(mrbf_ctx *ctx);   // behind the stream synchronisation that follows finish_out
 
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 

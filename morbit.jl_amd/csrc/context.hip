@@ -3,6 +3,8 @@
 
 #include "common.hpp"
 
+#include <cstring>
+
 namespace mrbf {
 
 static thread_local std::string g_init_err;
@@ -13,10 +15,13 @@ int fail(mrbf_ctx *ctx, int code, const char *fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
-    if (ctx)
+    if (ctx) {
         ctx->err = buf;
-    else
+        ctx->pin_armed = false;  // (an entry that fails does not reach its pin_flush: nothing may rely on the staging block after it)
+        ctx->pin_out.clear();
+    } else {
         g_init_err = buf;
+    }
     return code;
 }
 
@@ -97,6 +102,8 @@ bool is_device_ptr(const void *p) {
     return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
 }
 
+constexpr size_t PIN_BYTES = (size_t)8 << 20, PIN_MAX = (size_t)2 << 20;  // staging block, largest single transfer that goes through it
+
 int stage_in(mrbf_ctx *ctx, Slot s, const double *user, size_t count, const double **dev) {
     if (is_device_ptr(user)) {
         *dev = user;
@@ -104,7 +111,15 @@ int stage_in(mrbf_ctx *ctx, Slot s, const double *user, size_t count, const doub
     }
     double *b = nullptr;
     MRBF_TRY(get_buf(ctx, s, count, &b));
-    MRBF_HIP(ctx, hipMemcpyAsync(b, user, count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    const size_t bytes = count * sizeof(double);
+    if (ctx->pin_base && ctx->pin_armed && bytes <= PIN_MAX && ctx->pin_off + bytes <= PIN_BYTES) {
+        char *pin = ctx->pin_base + ctx->pin_off;
+        ctx->pin_off += (bytes + 63) & ~(size_t)63;
+        std::memcpy(pin, user, bytes);
+        MRBF_HIP(ctx, hipMemcpyAsync(b, pin, bytes, hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        MRBF_HIP(ctx, hipMemcpyAsync(b, user, bytes, hipMemcpyHostToDevice, ctx->stream));
+    }
     *dev = b;
     return 0;
 }
@@ -119,8 +134,27 @@ int stage_out(mrbf_ctx *ctx, Slot s, double *user, size_t count, double **dev) {
 
 int finish_out(mrbf_ctx *ctx, double *user, const double *dev, size_t count) {
     if (user == dev || user == nullptr) return 0;
-    MRBF_HIP(ctx, hipMemcpyAsync(user, dev, count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    const size_t bytes = count * sizeof(double);
+    if (ctx->pin_base && ctx->pin_armed && !is_device_ptr(user) && bytes <= PIN_MAX && ctx->pin_off + bytes <= PIN_BYTES) {
+        char *pin = ctx->pin_base + ctx->pin_off;
+        ctx->pin_off += (bytes + 63) & ~(size_t)63;
+        MRBF_HIP(ctx, hipMemcpyAsync(pin, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        ctx->pin_out.push_back({user, pin, bytes});
+        return 0;
+    }
+    MRBF_HIP(ctx, hipMemcpyAsync(user, dev, bytes, is_device_ptr(user) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
     return 0;
+}
+
+void pin_reset(mrbf_ctx *ctx) {
+    ctx->pin_off = 0;
+    ctx->pin_out.clear();
+    ctx->pin_armed = true;
+}
+void pin_flush(mrbf_ctx *ctx) {
+    for (const auto &o : ctx->pin_out) std::memcpy(o.user, o.pin, o.bytes);
+    ctx->pin_out.clear();
+    ctx->pin_armed = false;
 }
 
 static void mega_stat_account(mrbf_ctx *ctx, unsigned long long ticks);
@@ -199,6 +233,10 @@ int32_t mrbf_init(int32_t device_id, mrbf_ctx **out) {
         (void)hipGetLastError();
         ctx->hpin = nullptr;  // (read-backs then go through pageable memory as before)
     }
+    if (hipHostMalloc(reinterpret_cast<void **>(&ctx->pin_base), PIN_BYTES, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->pin_base = nullptr;
+    }
     if (rocblas_create_handle(&ctx->blas) != rocblas_status_success) return bail(MRBF_EBLAS, "rocblas_create_handle");
     rocblas_set_stream(ctx->blas, ctx->stream);
     rocblas_set_pointer_mode(ctx->blas, rocblas_pointer_mode_host);
@@ -270,6 +308,7 @@ int32_t mrbf_shutdown(mrbf_ctx *ctx) {
     for (auto &t : ctx->mega_tables)
         if (t.block) (void)hipFree(t.block);
     if (ctx->hpin) (void)hipHostFree(ctx->hpin);
+    if (ctx->pin_base) (void)hipHostFree(ctx->pin_base);
     for (auto &ev : ctx->ev)
         if (ev) (void)hipEventDestroy(ev);
     for (auto &ev : ctx->evx)
