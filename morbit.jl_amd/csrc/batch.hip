@@ -290,11 +290,20 @@ static int run_small_batch(mrbf_ctx *ctx, const std::vector<int64_t> &idx, const
     }
     {
         // one upload for the three descriptor arrays and the zeroed cluster words (the staging vector lives until the stream is synchronised below)
-        hdesc.assign(desc_bytes, 0);
-        memcpy(hdesc.data(), probs.data(), (size_t)P * sizeof(smallfit::Prob));
-        memcpy(hdesc.data() + ((char *)devs_ - ddesc), evs.data(), (size_t)2 * P * sizeof(EvalDesc));
-        memcpy(hdesc.data() + ((char *)dchk - ddesc), chk.data(), (size_t)P * sizeof(CheckDesc));
-        MRBF_HIP(ctx, hipMemcpyAsync(ddesc, hdesc.data(), desc_bytes, hipMemcpyHostToDevice, st));
+        // (staged in the context's pinned block when it fits: the upload is then asynchronous and the result words below come back
+        //  with the one synchronisation of the batch instead of a round trip of their own)
+        char *hd;
+        if (ctx->pin_base && desc_bytes <= ((size_t)4 << 20)) {
+            hd = ctx->pin_base;
+            memset(hd, 0, desc_bytes);
+        } else {
+            hdesc.assign(desc_bytes, 0);
+            hd = hdesc.data();
+        }
+        memcpy(hd, probs.data(), (size_t)P * sizeof(smallfit::Prob));
+        memcpy(hd + ((char *)devs_ - ddesc), evs.data(), (size_t)2 * P * sizeof(EvalDesc));
+        memcpy(hd + ((char *)dchk - ddesc), chk.data(), (size_t)P * sizeof(CheckDesc));
+        MRBF_HIP(ctx, hipMemcpyAsync(ddesc, hd, desc_bytes, hipMemcpyHostToDevice, st));
     }
     MRBF_HIP(ctx, hipEventRecord(ctx->ev[0], st));
     const int nc = force_nc > 0 ? force_nc : small_fit_cluster(ctx, P);
@@ -378,9 +387,16 @@ static int run_small_batch(mrbf_ctx *ctx, const std::vector<int64_t> &idx, const
     MRBF_HIP(ctx, hipGetLastError());
     MRBF_HIP(ctx, hipEventRecord(ctx->ev[2], st));
     // results
-    std::vector<double> hout((size_t)10 * P);
-    MRBF_HIP(ctx, hipMemcpyAsync(hout.data(), base + out0, hout.size() * sizeof(double), hipMemcpyDeviceToHost, st));
-    const int *hflags = reinterpret_cast<const int *>(hout.data() + (size_t)8 * P);
+    std::vector<double> hout_v;
+    double *hout;
+    if (ctx->pin_base && (size_t)10 * P * sizeof(double) <= ((size_t)1 << 20)) {
+        hout = reinterpret_cast<double *>(ctx->pin_base + ((size_t)4 << 20));  // (behind the descriptor staging area)
+    } else {
+        hout_v.resize((size_t)10 * P);
+        hout = hout_v.data();
+    }
+    MRBF_HIP(ctx, hipMemcpyAsync(hout, base + out0, (size_t)10 * P * sizeof(double), hipMemcpyDeviceToHost, st));
+    const int *hflags = reinterpret_cast<const int *>(hout + (size_t)8 * P);
     for (int i = 0; i < P; ++i) {
         const mrbf_problem &pr = problems[idx[i]];
         const Lay &L = lay[i];
