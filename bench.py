@@ -36,6 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (~6.3 TB/s achievable)
+GRAM_W_ISSUED_PER_N2D = 4   # gram_w_kernel computes every off-diagonal tile of X X^T in both orientations: n^2 d on top of the useful 3 n^2 d
 FP64_MFMA_PEAK_TF = 78.6   # MI355X FP64 matrix peak (spec; v_mfma_f64_16x16x4_f64 = 16 FMA/clk/SIMD x 1024 SIMD x 2.4 GHz)
 
 
@@ -428,28 +429,40 @@ def main():
             assert table.shape[0] == P and np.array_equal(table[:, 0], np.arange(P)), "record gather lost problems"
         if not dry:
             # The fit's own assembly at d <= 64 with a polynomial tail is gram_w_kernel (gram_fused.hip): lower triangle only, fused with
-            # W = Phi [1 Xc] -- 2 n^2 d (both orientations of the products with the centres) + 2 n^2 d (W) flops against 4 n^2 + 8 n d
-            # bytes, i.e. MFMA-bound; it is priced on those flops.  The full-matrix kernel behind mrbf_gram (RBF.get_matrices) is
-            # measured beside it below (kernels.gram_full: 8 n^2 + 8 n d bytes against the HBM roof).
+            # W = Phi [1 Xc].  USEFUL work: n^2 d (products with the centres on the lower triangle) + 2 n^2 d (W) = 3 n^2 d flops against
+            # 4 n^2 + 8 n d bytes, i.e. MFMA-bound; `frac` is priced on those useful flops.  What the kernel issues on top of that
+            # (mirrored tiles computed a second time, if the build still does) is reported beside it as `issued_flops`, never in `frac`.
+            # The full-matrix kernel behind mrbf_gram (RBF.get_matrices) is measured below (kernels.gram_full: 8 n^2 + 8 n d bytes, HBM roof).
             q_tail = 0 if cfg["deg"] < 0 else (1 if cfg["deg"] == 0 else d + 1)
             fused_gram = (not batched) and d <= 64 and q_tail >= 1 and n >= 1024 and args.gram_mode == 0
             gram_mfma = d >= 96 or fused_gram
-            gram_flops = 4.0 * n * n * d if fused_gram else alg["gram_flops"]
+            gram_flops = 3.0 * n * n * d if fused_gram else alg["gram_flops"]
+            # projection: with the fused assembly the product Phi Q1 (and its read of Phi) is inside gram_w_kernel and counted there; what
+            # the phase still does is the rank-2q update of the lower triangle: 2 n^2 q flops, lower triangle read + written = 2 * 4 n^2 B
+            proj_flops = 2.0 * n * n * q_tail if fused_gram else alg["project_flops"]
+            proj_bytes = 2.0 * 4.0 * n * n if fused_gram else alg["project_bytes"]
+            proj_mfma = proj_flops / (FP64_MFMA_PEAK_TF * 1e12) > (1.0 if fused_gram else 2.0) * proj_bytes / (HBM_PEAK_GBS * 1e9)
             kernels = {
                 "gram": dict(bound="mfma" if gram_mfma else "hbm",
                              achieved=(gram_flops / max(phases["gram"], 1e-9) / 1e9) if gram_mfma else alg["gram_bytes"] / max(phases["gram"], 1e-9) / 1e6,
                              peak=FP64_MFMA_PEAK_TF if gram_mfma else HBM_PEAK_GBS, unit="TFLOP/s" if gram_mfma else "GB/s", ms=phases["gram"]),
                 "factor": dict(bound="mfma", achieved=alg["factor_flops"] / max(phases["factor"] * 1e-3, 1e-12) / 1e12, peak=FP64_MFMA_PEAK_TF,
                                unit="TFLOP/s", ms=phases["factor"]),
-                # the projection's 4 n^2 q flops clearly outweigh its 3 x 8 n^2 bytes from q ~ 128 on (C5, q = 257: 3.5 ms at the fp64 peak
-                # against 0.8 ms at the HBM peak; C3, q = 65: 0.22 against 0.20 -- left on the HBM roof as in rounds 1 and 2)
-                "project": (dict(bound="mfma", achieved=alg["project_flops"] / max(phases["project"], 1e-9) / 1e9, peak=FP64_MFMA_PEAK_TF, unit="TFLOP/s",
-                                 ms=phases["project"]) if alg["project_flops"] / (FP64_MFMA_PEAK_TF * 1e12) > 2.0 * alg["project_bytes"] / (HBM_PEAK_GBS * 1e9) else
-                            dict(bound="hbm", achieved=alg["project_bytes"] / max(phases["project"], 1e-9) / 1e6, peak=HBM_PEAK_GBS, unit="GB/s",
-                                 ms=phases["project"], flops_tf=alg["project_flops"] / max(phases["project"], 1e-9) / 1e9)),
+                # general path: the projection's 4 n^2 q flops clearly outweigh its 3 x 8 n^2 bytes from q ~ 128 on (C5, q = 257: 3.5 ms at the
+                # fp64 peak against 0.8 ms at the HBM peak)
+                "project": (dict(bound="mfma", achieved=proj_flops / max(phases["project"], 1e-9) / 1e9, peak=FP64_MFMA_PEAK_TF, unit="TFLOP/s",
+                                 ms=phases["project"], bytes_gbs=proj_bytes / max(phases["project"], 1e-9) / 1e6) if proj_mfma else
+                            dict(bound="hbm", achieved=proj_bytes / max(phases["project"], 1e-9) / 1e6, peak=HBM_PEAK_GBS, unit="GB/s",
+                                 ms=phases["project"], flops_tf=proj_flops / max(phases["project"], 1e-9) / 1e9)),
             }
             if fused_gram:
-                kernels["gram"]["note"] = "gram_w_kernel: lower triangle + W = Phi [1 Xc] in one pass (4 n^2 d flops, 4 n^2 + 8 n d bytes)"
+                pair_ms = phases["gram"] + phases["project"]
+                kernels["gram_project"] = dict(bound="mfma", achieved=(gram_flops + proj_flops) / max(pair_ms, 1e-9) / 1e9, peak=FP64_MFMA_PEAK_TF,
+                                               unit="TFLOP/s", ms=pair_ms, note="assembly + projection together: 3 n^2 d + 2 n^2 q useful flops")
+            if fused_gram:
+                kernels["gram"]["note"] = "gram_w_kernel: lower triangle + W = Phi [1 Xc] in one pass (3 n^2 d useful flops, 4 n^2 + 8 n d bytes)"
+                kernels["gram"]["issued_flops"] = float(GRAM_W_ISSUED_PER_N2D) * n * n * d
+                kernels["project"]["note"] = "rank-2q update of the lower triangle (the product Phi Q1 is inside gram_w_kernel): 2 n^2 q flops, 8 n^2 bytes"
                 gf = gram_full_ms(workers[0], n, d) if workers and getattr(workers[0], "gram_inputs", None) else None
                 if gf:
                     kernels["gram_full"] = dict(bound="hbm", achieved=alg["gram_bytes"] / gf / 1e6, peak=HBM_PEAK_GBS, unit="GB/s", ms=gf,

@@ -25,6 +25,14 @@ rocprofv3 --kernel-trace --stats -d "$OUT/prof_c2" -o c2 -- python3 "$ROOT/bench
 echo "C2 trace done"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc_w" -o w -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/pmc_w.json" 2> "$OUT/pmc_w.err"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmc_f" -o f -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/pmc_f.json" 2> "$OUT/pmc_f.err"
+echo "C3 PMC passes done"
+# PMC passes of the other configurations (roofline.traffic must never be null): C2 (20 cycles), C4 (4 batches), C5 (2 problems x 2 steps)
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc_w_c2" -o w -- python3 "$ROOT/bench.py" --config C2 --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/pmc_w_c2.json" 2> "$OUT/pmc_w_c2.err"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmc_f_c2" -o f -- python3 "$ROOT/bench.py" --config C2 --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/pmc_f_c2.json" 2> "$OUT/pmc_f_c2.err"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc_w_c4" -o w -- python3 "$ROOT/bench.py" --config C4 --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/pmc_w_c4.json" 2> "$OUT/pmc_w_c4.err"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmc_f_c4" -o f -- python3 "$ROOT/bench.py" --config C4 --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/pmc_f_c4.json" 2> "$OUT/pmc_f_c4.err"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc_w_c5" -o w -- python3 "$ROOT/bench.py" --config C5 --steps 1 --warmup 1 --problems 2 --no-cpu-baseline > "$OUT/pmc_w_c5.json" 2> "$OUT/pmc_w_c5.err"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmc_f_c5" -o f -- python3 "$ROOT/bench.py" --config C5 --steps 1 --warmup 1 --problems 2 --no-cpu-baseline > "$OUT/pmc_f_c5.json" 2> "$OUT/pmc_f_c5.err"
 echo "PMC passes done"
 cd "$ROOT"
 python3 tools/round4_bench.py 64 10000 > "$OUT/round4_d64.txt" 2>&1

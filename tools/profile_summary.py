@@ -83,7 +83,7 @@ def pmc(wdb, fdb, prefix, inv, config):
     cur["_note"] = ("HBM-side bytes per cycle (gram, factor: one launch per cycle) from rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE in separate "
                     "passes; counter unit KB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B)")
     cur.setdefault("_detail", {})
-    cur["_detail"] = {config: detail}
+    cur["_detail"][config] = detail
     json.dump(cur, open(path, "w"), indent=1)
     print(json.dumps(out, indent=1))
 
