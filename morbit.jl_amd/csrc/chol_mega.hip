@@ -126,7 +126,6 @@ struct Args {
     unsigned long long *jlog;   // diagnostic launches only: 8 words per job (meta, claim, 5 stage stamps, end), jlog[0] = count
     int jlog_cap;
     int pstream;                // panels the diagonal job takes in step from streamed producers (1 or 2)
-    int panel_dma;              // MRBF_MEGA_PANELDMA: operand path of the panel jobs' triangular solve (0 registers; 1.. LDS-DMA variants, see run_panel)
     int trace_dbg;              // diagnostic launches only: dbg word of the diagonal core (4 = time wave 0, 4 + 8 + 16 w = time wave w)
     unsigned long long *trace;  // diagnostic launches only: 8 time stamps (10 ns units) per chain job (P(c), T(c+1,c))
 };
@@ -749,7 +748,6 @@ __device__ __attribute__((noinline)) bool run_diag(const Args &a, Shared &sh, co
 // T(i, half, c): rows [64 half, 64 half + 64) of tile (i,c).  Half-height tiles keep a row's column-to-column recurrence
 // L(i,c-1) -> update -> solve -> L(i,c) (two dependent 64 x 128 x 128 GEMMs on one CU that is shared with a bulk job)
 // faster than the diagonal chain; with 128-row tiles the rows fall behind it.
-__device__ unsigned long long g_pdma_dbg[8];  // MRBF_MEGA_PANELDMA=4 (diagnostic): count and first differing entry
 template <bool FULL>
 __device__ __attribute__((noinline)) bool run_panel(const Args &a, Shared &sh, const Job jb) {
     constexpr int TM = FULL ? 128 : 64;
@@ -768,44 +766,7 @@ __device__ __attribute__((noinline)) bool run_panel(const Args &a, Shared &sh, c
     zero_acc(acc);
     // (the register-staged loop: X was written by this workgroup's plain stores a moment ago, and LDS-DMA loads of it came back
     //  wrong -- every other operand of gemm_acc is another workgroup's write-through data behind an acquire, or older; r04)
-    const int pdma = __builtin_amdgcn_readfirstlane(a.panel_dma);
-    if (pdma == 0) {
-        gemm_acc_v1<TM>(C, lda, Linv, NB, NB, acc, sh.u.gemm);  // every wave's loads of X are complete behind the loop's last barrier
-    } else {
-        // diagnostic variants (tools/ldsdma_hazard.sh): the LDS-DMA ring on the tile this workgroup has just written with plain stores
-        //   1  as it stands        2  the reader drops its vector L1 first (buffer_inv sc1)        3  ... and the L2 view too (sc0 sc1)
-        if (pdma == 2) asm volatile("buffer_inv sc1" ::: "memory");
-        if (pdma == 3) asm volatile("buffer_inv sc0 sc1" ::: "memory");
-        if (pdma >= 2) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
-        gemm_acc_v2<TM>(C, lda, Linv, NB, NB, acc, sh.u.gemm);
-        if (pdma == 4) {  // both loops on the same operands; the first differing accumulator entry of the launch goes to g_pdma_dbg
-            v4d ref[TM / 32][4];
-            zero_acc(ref);
-            gemm_acc_v1<TM>(C, lda, Linv, NB, NB, ref, sh.u.gemm);
-#pragma unroll
-            for (int j = 0; j < TM / 32; ++j)
-#pragma unroll
-                for (int i2 = 0; i2 < 4; ++i2)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (!(acc[j][i2][r] == ref[j][i2][r])) {
-                            if (atomicAdd(&g_pdma_dbg[0], 1ull) == 0ull) {
-                                g_pdma_dbg[1] = ((unsigned long long)i << 32) | (unsigned)c;
-                                g_pdma_dbg[2] = ((unsigned long long)roff << 32) | threadIdx.x;
-                                g_pdma_dbg[3] = ((unsigned long long)j << 32) | (unsigned)(i2 * 4 + r);
-                                g_pdma_dbg[4] = (unsigned long long)__double_as_longlong(acc[j][i2][r]);
-                                g_pdma_dbg[5] = (unsigned long long)__double_as_longlong(ref[j][i2][r]);
-                            }
-                        }
-#pragma unroll
-            for (int j = 0; j < TM / 32; ++j)
-#pragma unroll
-                for (int i2 = 0; i2 < 4; ++i2) acc[j][i2] = ref[j][i2];
-        }
-    }
+    gemm_acc_v1<TM>(C, lda, Linv, NB, NB, acc, sh.u.gemm);  // every wave's loads of X are complete behind the loop's last barrier
     store_tile<TM, false, false, true>(C, lda, acc);
     wg_drain();
     if (a.fault && i == a.MT - 1 && c == 0 && roff == 0) return true;  // test hook: this (half) tile is never published
@@ -1379,10 +1340,6 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
         }
         a.nreserve = (e_head > 0 || e_tail_c0 < NT) ? (env_reserve >= 0 ? env_reserve : 12) : 0;
     }
-    {
-        static const int env_pdma = getenv("MRBF_MEGA_PANELDMA") ? atoi(getenv("MRBF_MEGA_PANELDMA")) : 0;
-        a.panel_dma = env_pdma;
-    }
     a.pstream = ctx->mega_pstream > 0 ? std::min(ctx->mega_pstream, srows) : (NTq <= 48 && srows >= 2 ? 2 : 1);
     a.spin_ticks = (unsigned long long)std::max(1, ctx->spin_ms) * 100000ull;  // wall_clock64 runs at 100 MHz
     a.fault = (ctx->debug_fault & 1) && MT > 1;
@@ -1413,16 +1370,6 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
     }
     hipLaunchKernelGGL(potrf_mega_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, a);
     hnow();  // 4: persistent kernel enqueued
-    if (a.panel_dma == 4) {
-        unsigned long long h[8] = {0};
-        MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        MRBF_HIP(ctx, hipMemcpyFromSymbol(h, HIP_SYMBOL(g_pdma_dbg), sizeof(h)));
-        double v2, v1;
-        memcpy(&v2, &h[4], 8);
-        memcpy(&v1, &h[5], 8);
-        fprintf(stderr, "PANELDMA=4: %llu differing accumulator entries so far; first: tile (%llu,%llu) roff %llu thread %llu j %llu entry %llu  dma %.17g  regs %.17g\n",
-                h[0], h[1] >> 32, h[1] & 0xffffffffull, h[2] >> 32, h[2] & 0xffffffffull, h[3] >> 32, h[3] & 0xffffffffull, v2, v1);
-    }
     if (jlog_path) {
         std::vector<unsigned long long> h((size_t)8 * a.jlog_cap + 16);
         MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
