@@ -79,6 +79,21 @@ __global__ __launch_bounds__(256, 2) void chol_update_kernel(const double *__res
         for (int i = 0; i < 4; ++i) acc[j][i] = (v4d){0.0, 0.0, 0.0, 0.0};
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (persistent launches: the previous tile's stores are out of the wave's counter)
+    // LOWER_SUB (the projection's rank-2q update, the host-driven trailing update): start from the negated tile instead of ending
+    // with a read-modify-write -- the 64 loads per lane travel under the operand ring's prologue and the first stages' MFMAs (they
+    // are older than every LDS-DMA load, so the ring's counted waits cover them), and the epilogue is stores only (round 5; the
+    // persistent factorisation's bulk jobs do the same, chol_mega.hip load_tile_neg)
+    constexpr bool NEG_START = (MODE == UPD_LOWER_SUB);
+    if (NEG_START) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t gj = J0 + joff + j * 16 + l4 + 4 * r;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[j][i][r] = -C[(I0 + ioff + i * 16 + l15) + gj * ldc];
+            }
+    }
     mega::gemm_acc<TM>(A + I0, lda, B + J0, ldb, K, acc, smem);
     // epilogue (f64 C/D map: col = lane & 15 -> i, row = (lane >> 4) + 4 r -> j).  The read-modify-write is done in
     // batches of 16 values (all loads of a batch issued before its first store): element-wise `*dst -= acc` makes the
@@ -106,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void chol_update_kernel(const double *__res
                 cej[r] = gj < cn ? 1.0 : 0.0;
             }
         }
-        if (MODE != UPD_OVERWRITE) {
+        if (MODE != UPD_OVERWRITE && !NEG_START) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int64_t gj = J0 + joff + j * 16 + l4 + 4 * r;
@@ -128,9 +143,9 @@ __global__ __launch_bounds__(256, 2) void chol_update_kernel(const double *__res
                 } else if (MODE == UPD_COLUMN_SUB) {
                     if (gi >= gj) *dst = cv[r][i] - acc[j][i][r];  // only the diagonal 128 x 128 block has gi < gj
                 } else {
-                    double x = acc[j][i][r];
-                    if (cvec) x += fma(cei[i], cvj[r], cvi[i] * cej[r]);  // cs (e_i v_j + v_i e_j)
-                    if (ti != tj || gi >= gj) *dst = cv[r][i] - x;
+                    double x = -acc[j][i][r];  // (acc = -C + A B': the new entry is -acc)
+                    if (cvec) x -= fma(cei[i], cvj[r], cvi[i] * cej[r]);  // cs (e_i v_j + v_i e_j)
+                    if (ti != tj || gi >= gj) *dst = x;
                 }
             }
         }

@@ -44,6 +44,14 @@ def problems():
     out["d64"] = (C, Y, "multiquadric", np.full(64, 0.9), 0.1)
     C, Y, _ = wl.problem("C4", 0)
     out["d128"] = (C, Y, "cubic", C[0].copy(), 0.1)
+    # conflicting objectives (round 5): the Pareto set of the two quadratics is the segment 0.3 * ones .. 0.7 * ones; a start at its
+    # middle, 0.5 * ones, pushed off it by +- 0.15 per coordinate (fixed seed) has gradients that nearly oppose each other -- a narrow
+    # descent cone, omega* small but not zero
+    for name, base in (("d64c", "d64"), ("d256c", "d256")):
+        C, Y, kernel, _, half = out[base]
+        d = C.shape[1]
+        x = 0.5 + 0.15 * (2.0 * np.random.default_rng(1000 + d).random(d) - 1.0)
+        out[name] = (C, Y, kernel, x, half)
     return out
 
 
@@ -95,12 +103,21 @@ def local_ideal_point(model, x, lb, ub, rng, nstart=4):
 
 
 def main():
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ps_omega.json")
     out = {"_doc": "omega* of the Pascoletti-Serafini subproblem by SciPy SLSQP on the oracle's model; see make_ps_omega.py"}
+    if os.path.exists(path) and "--all" not in sys.argv:   # keep what is on file, compute what is missing (--all: everything again)
+        out.update(json.load(open(path)))
+    fits = {}
     for name, (C, Y, kernel, x, half) in problems().items():
+        if name in out:
+            continue
         t0 = time.time()
         kid = orc.KERNEL_IDS[kernel]
         a, b = orc.kernel_params(kernel)
-        model = orc.fit(C, Y, kid, a, b, 1)
+        key = (id(C), kernel)
+        if key not in fits:
+            fits[key] = orc.fit(C, Y, kid, a, b, 1)
+        model = fits[key]
         lb, ub = np.maximum(x - half, 0.0), np.minimum(x + half, 1.0)
         mx = model.values(x[None, :])[0]
         rng = np.random.default_rng(99)
@@ -112,7 +129,7 @@ def main():
         out[name] = dict(n=int(C.shape[0]), d=int(C.shape[1]), kernel=kernel, mx=mx.tolist(), omega_bench=om_b, ideal=ideal.tolist(),
                          r_default=r_def.tolist(), omega_default=om_d, step_bench=float(np.abs(xb - x).max()))
         print("%-5s n=%d: omega* bench %.5f, default %.5f (r_default %s)  [%.1f s]" % (name, C.shape[0], om_b, om_d, np.round(r_def, 5), time.time() - t0))
-    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "ps_omega.json"), "w") as f:
+    with open(path, "w") as f:
         json.dump(out, f, indent=1)
 
 
