@@ -141,7 +141,7 @@ int32_t mrbf_gram(mrbf_ctx *ctx, int64_t n, int32_t d, const double *centres, in
     if (!Phi_out) return fail(ctx, -9, "Phi_out is NULL");
     if (n == 0) return MRBF_OK;
     (void)hipSetDevice(ctx->device);
-    pin_reset(ctx);
+    PinGuard pin(ctx);
     const int q = poly_dim(d, poly_deg);
     const int64_t npad = round_up(n, 128);
     const int dpad = (int)round_up(d, 16);
@@ -165,7 +165,7 @@ int32_t mrbf_gram(mrbf_ctx *ctx, int64_t n, int32_t d, const double *centres, in
     MRBF_TRY(finish_out(ctx, Phi_out, Phi, (size_t)n * n));
     if (Pi) MRBF_TRY(finish_out(ctx, Pi_out, Pi, (size_t)n * q));
     MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    pin_flush(ctx);
+    pin.flush();
     if (ms) MRBF_HIP(ctx, hipEventElapsedTime(ms, ctx->ev[1], ctx->ev[2]));
     return MRBF_OK;
 }
@@ -182,7 +182,7 @@ int32_t mrbf_cross_gram(mrbf_ctx *ctx, int64_t m, int64_t n, int32_t d, const do
     if (!centres) return fail(ctx, -6, "centres is NULL");
     if (!K_out) return fail(ctx, -10, "K_out is NULL");
     (void)hipSetDevice(ctx->device);
-    pin_reset(ctx);
+    PinGuard pin(ctx);
     const double *dX, *dC;
     double *dK;
     MRBF_TRY(stage_in(ctx, S_STAGE_A, X, (size_t)m * d, &dX));
@@ -191,7 +191,7 @@ int32_t mrbf_cross_gram(mrbf_ctx *ctx, int64_t m, int64_t n, int32_t d, const do
     MRBF_TRY(launch_cross_gram(ctx, dX, m, dC, n, d, make_kp(kernel_id, a, b), dK));
     MRBF_TRY(finish_out(ctx, K_out, dK, (size_t)m * n));
     MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    pin_flush(ctx);
+    pin.flush();
     return MRBF_OK;
 }
 
@@ -208,7 +208,7 @@ int32_t mrbf_fit(mrbf_ctx *ctx, int64_t n, int32_t d, int32_t k, const double *c
     if (!model) return fail(ctx, -11, "model is NULL");
     *model = nullptr;
     (void)hipSetDevice(ctx->device);
-    pin_reset(ctx);
+    PinGuard pin(ctx);
     const double *C, *Y;
     MRBF_TRY(stage_in(ctx, S_STAGE_A, centres, (size_t)n * d, &C));
     MRBF_TRY(stage_in(ctx, S_STAGE_B, values, (size_t)n * k, &Y));
@@ -224,7 +224,7 @@ int32_t mrbf_fit(mrbf_ctx *ctx, int64_t n, int32_t d, int32_t k, const double *c
         if (weights_out) MRBF_TRY(finish_out(ctx, weights_out, M->W, (size_t)n * k));
         if (poly_out && M->q > 0) MRBF_TRY(finish_out(ctx, poly_out, M->lam, (size_t)M->q * k));
         MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        pin_flush(ctx);
+        pin.flush();
         return 0;
     };
     rc = copy_out();
@@ -284,7 +284,7 @@ int32_t mrbf_eval(mrbf_ctx *ctx, const mrbf_model *model, int64_t m, const doubl
     if (m == 0) return MRBF_OK;
     if (!X) return fail(ctx, -4, "X is NULL");
     (void)hipSetDevice(ctx->device);
-    pin_reset(ctx);
+    PinGuard pin(ctx);
     const int d = model->d, k = model->k;
     const double *Xd;
     double *V = nullptr, *J = nullptr;
@@ -295,7 +295,7 @@ int32_t mrbf_eval(mrbf_ctx *ctx, const mrbf_model *model, int64_t m, const doubl
     if (V) MRBF_TRY(finish_out(ctx, vals_out, V, (size_t)m * k));
     if (J) MRBF_TRY(finish_out(ctx, jac_out, J, (size_t)m * k * d));
     MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    pin_flush(ctx);
+    pin.flush();
     return MRBF_OK;
 }
 

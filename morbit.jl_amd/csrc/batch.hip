@@ -195,6 +195,7 @@ static int run_small_batch(mrbf_ctx *ctx, const std::vector<int64_t> &idx, const
         if (rc != 0) return rc;
     }
     flags = reinterpret_cast<int *>(base + out0 + (size_t)8 * P);
+    PinGuard pin(ctx);  // this batch's share of the pinned staging block (descriptor upload, result words); released on every return path
     // descriptors: [Prob x P | EvalDesc x 2P | CheckDesc x P | CL_WORDS cluster words x P (zero)] in one device buffer
     const size_t desc_bytes = (size_t)P * (sizeof(smallfit::Prob) + 2 * sizeof(EvalDesc) + sizeof(CheckDesc) + smallfit::CL_WORDS * sizeof(int)) + 256;
     char *ddesc;
@@ -292,9 +293,8 @@ static int run_small_batch(mrbf_ctx *ctx, const std::vector<int64_t> &idx, const
         // one upload for the three descriptor arrays and the zeroed cluster words (the staging vector lives until the stream is synchronised below)
         // (staged in the context's pinned block when it fits: the upload is then asynchronous and the result words below come back
         //  with the one synchronisation of the batch instead of a round trip of their own)
-        char *hd;
-        if (ctx->pin_base && desc_bytes <= ((size_t)4 << 20)) {
-            hd = ctx->pin_base;
+        char *hd = desc_bytes <= ((size_t)4 << 20) ? pin_take(ctx, desc_bytes) : nullptr;  // (this batch's guard armed the block: `pin` below)
+        if (hd) {
             memset(hd, 0, desc_bytes);
         } else {
             hdesc.assign(desc_bytes, 0);
@@ -391,8 +391,8 @@ static int run_small_batch(mrbf_ctx *ctx, const std::vector<int64_t> &idx, const
     // results
     std::vector<double> hout_v;
     double *hout;
-    if (ctx->pin_base && (size_t)10 * P * sizeof(double) <= ((size_t)1 << 20)) {
-        hout = reinterpret_cast<double *>(ctx->pin_base + ((size_t)4 << 20));  // (behind the descriptor staging area)
+    if (char *ph = (size_t)10 * P * sizeof(double) <= ((size_t)1 << 20) ? pin_take(ctx, (size_t)10 * P * sizeof(double)) : nullptr) {
+        hout = reinterpret_cast<double *>(ph);  // (from the same allocator as the descriptor staging area)
     } else {
         hout_v.resize((size_t)10 * P);
         hout = hout_v.data();
@@ -414,18 +414,29 @@ static int run_small_batch(mrbf_ctx *ctx, const std::vector<int64_t> &idx, const
     MRBF_HIP(ctx, hipStreamSynchronize(st));
     if (nc > 1) {
         int worst = 0;
-        bool suspect = false;  // tripwire (small.hip, Cluster): a clustered fit that does not interpolate
+        std::vector<std::pair<int, double>> suspects;  // tripwire (small.hip, Cluster): clustered fits that do not interpolate, with their residual
         for (int i = 0; i < P; ++i) {
             worst = std::max(worst, hflags[(size_t)4 * i + 3]);
             const double *o = &hout[(size_t)8 * i];
             const bool flagged = hflags[(size_t)4 * i] != 0 || hflags[(size_t)4 * i + 1] != 0 || hflags[(size_t)4 * i + 2] != 0;
-            if (check && !flagged && !(std::sqrt(o[0]) < 1e-6 * std::max(std::sqrt(o[1]), 1e-300))) suspect = true;
+            const double rr = std::sqrt(o[0]) / std::max(std::sqrt(o[1]), 1e-300);
+            if (check && !flagged && !(rr < 1e-6)) suspects.emplace_back(idx[i], rr);
         }
-        if (worst != 0 || suspect) {
-            // members on different XCDs (2) or a residual one workgroup has to confirm: clusters off for this context; a barrier
-            // that timed out (1): this batch again with one workgroup per problem, clusters stay unless it keeps happening
-            if (worst == 2 || suspect || ++ctx->small_timeouts >= 3) ctx->small_nc = 1;
-            return run_small_batch(ctx, idx, problems, results, redo, 1);
+        if (worst != 0 || !suspects.empty()) {
+            // members on different XCDs (2): clusters off for this context; a barrier that timed out (1): this batch again with one workgroup
+            // per problem, clusters stay unless it keeps happening; a residual that is not small: one workgroup per problem has to confirm
+            // it -- clusters are switched off only if that run does BETTER on a suspect problem (as fit_model does for single fits,
+            // solve.hip).  A problem that is ill-conditioned in its own right (near-duplicate sites of a trust region) gives the same
+            // residual either way and must not cost a pooled context its clusters for the rest of the process.
+            if (worst == 2 || (worst == 1 && ++ctx->small_timeouts >= 3)) ctx->small_nc = 1;
+            const int rc1 = run_small_batch(ctx, idx, problems, results, redo, 1);
+            if (rc1 == 0 && worst == 0) {
+                for (const auto &sp : suspects) {
+                    const double r1 = results[sp.first].fit.rel_residual;
+                    if (std::isfinite(r1) && (r1 < 1e-6 || r1 < 0.1 * sp.second)) ctx->small_nc = 1;  // one workgroup interpolates, the cluster did not
+                }
+            }
+            return rc1;
         }
         ctx->small_timeouts = 0;
     }

@@ -158,8 +158,39 @@ int stage_in(mrbf_ctx *ctx, Slot s, const double *user, size_t count, const doub
 // device buffer to produce an output into (user's own when device memory, else staging)
 int stage_out(mrbf_ctx *ctx, Slot s, double *user, size_t count, double **dev);
 int finish_out(mrbf_ctx *ctx, double *user, const double *dev, size_t count);
-void pin_reset(mrbf_ctx *ctx);   // top of an API entry
-void pin_flush(mrbf_ctx *ctx);   // behind the stream synchronisation that follows finish_out
+void pin_reset(mrbf_ctx *ctx);   // top of an API entry (through PinGuard)
+void pin_flush(mrbf_ctx *ctx);   // behind the stream synchronisation that follows finish_out (through PinGuard::flush)
+void pin_discard(mrbf_ctx *ctx); // an entry that leaves early: queued outputs dropped, block disarmed
+char *pin_take(mrbf_ctx *ctx, size_t bytes);  // `bytes` of the armed staging block (64-byte aligned) or nullptr when they do not fit
+// One guard per API entry that stages through the pinned block: arms it on construction; flush() copies the queued outputs to the
+// user's buffers (call it behind the stream synchronisation that follows the last finish_out); an entry that returns before that --
+// whatever the path -- discards them in the destructor.  fail() does not touch the block: an error that an entry recovers from
+// (ENOMEM -> halves) leaves its queued outputs intact.
+struct PinGuard {
+    mrbf_ctx *ctx;
+    bool flushed = false;
+    explicit PinGuard(mrbf_ctx *c) : ctx(c) { pin_reset(c); }
+    void flush() {
+        pin_flush(ctx);
+        flushed = true;
+    }
+    ~PinGuard() {
+        if (!flushed) pin_discard(ctx);
+    }
+    PinGuard(const PinGuard &) = delete;
+    PinGuard &operator=(const PinGuard &) = delete;
+};
+// word offsets into mrbf_ctx::hpin (64 pinned host words for the small read-backs, each landing with its caller's one synchronisation)
+enum HpinSlot : int {
+    HPIN_FIT_FLAGS = 0,    // solve.hip fit_chol: 4 ints
+    HPIN_FIT_SCAL = 4,     // trace, shift (2 doubles) + the factorisation's flags
+    HPIN_SMALL_FLAGS = 8,  // solve.hip one-launch fit: 4 ints
+    HPIN_SMALL_SCAL = 12,  // 2 doubles
+    HPIN_SMALL_CHK = 16,   // 4 doubles
+    HPIN_RESIDUAL = 20,    // residual check: 3 doubles
+    HPIN_R4_COUNT = 24,    // round4.hip: accepted so far / in this block (2 ints)
+    HPIN_MEGA_STAT = 63,   // the persistent factorisation's device clock
+};
 
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 

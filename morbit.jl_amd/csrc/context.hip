@@ -16,9 +16,7 @@ int fail(mrbf_ctx *ctx, int code, const char *fmt, ...) {
     vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
     if (ctx) {
-        ctx->err = buf;
-        ctx->pin_armed = false;  // (an entry that fails does not reach its pin_flush: nothing may rely on the staging block after it)
-        ctx->pin_out.clear();
+        ctx->err = buf;  // (the pinned staging block is the entry's PinGuard's business, not this function's)
     } else {
         g_init_err = buf;
     }
@@ -156,19 +154,29 @@ void pin_flush(mrbf_ctx *ctx) {
     ctx->pin_out.clear();
     ctx->pin_armed = false;
 }
+void pin_discard(mrbf_ctx *ctx) {
+    ctx->pin_out.clear();
+    ctx->pin_armed = false;
+}
+char *pin_take(mrbf_ctx *ctx, size_t bytes) {
+    if (!ctx->pin_base || !ctx->pin_armed || ctx->pin_off + bytes > PIN_BYTES) return nullptr;
+    char *p = ctx->pin_base + ctx->pin_off;
+    ctx->pin_off += (bytes + 63) & ~(size_t)63;
+    return p;
+}
 
 static void mega_stat_account(mrbf_ctx *ctx, unsigned long long ticks);
 int mega_stat_enqueue(mrbf_ctx *ctx) {
     if (!ctx->mega_stat_pending || !ctx->mega_stat_dev || !ctx->hpin) return 0;
-    ctx->hpin[63] = ~0ull;
-    MRBF_HIP(ctx, hipMemcpyAsync(&ctx->hpin[63], ctx->mega_stat_dev, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    ctx->hpin[HPIN_MEGA_STAT] = ~0ull;
+    MRBF_HIP(ctx, hipMemcpyAsync(&ctx->hpin[HPIN_MEGA_STAT], ctx->mega_stat_dev, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     ctx->mega_stat_pending = 2;  // on its way
     return 0;
 }
 int mega_stat_finish(mrbf_ctx *ctx) {
     if (ctx->mega_stat_pending != 2) return mega_collect_stat(ctx);
     ctx->mega_stat_pending = 0;
-    mega_stat_account(ctx, ctx->hpin[63]);
+    mega_stat_account(ctx, ctx->hpin[HPIN_MEGA_STAT]);
     return 0;
 }
 int mega_collect_stat(mrbf_ctx *ctx) {

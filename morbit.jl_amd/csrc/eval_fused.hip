@@ -491,10 +491,16 @@ __global__ __launch_bounds__(512, 2) void eval_fused_split_kernel(EvalDesc one, 
         // at a time, one 16-byte store per (site, coordinate) -- the coordinates of a site are then written as whole lines, the
         // query coordinate and the tail coefficients are fetched once (C4, 64 starts: the epilogue was 0.42 of the 2.34 ms)
         bool paired = false;
-        if constexpr (FINAL && KOUT == 2) paired = (k & 1) == 0 && (l0 & 1) == 0 && l0 + 1 < k && !(MRBF_EVAL_DBG & 64);
+        // (the 16-byte accesses below need jac and lam 16-byte aligned: true for the arena, checked for a caller's device pointer)
+        if constexpr (FINAL && KOUT == 2)
+            paired = (k & 1) == 0 && (l0 & 1) == 0 && l0 + 1 < k && !(MRBF_EVAL_DBG & 64) &&
+                     (((uintptr_t)jac | (uintptr_t)lam) & 15) == 0;
         if constexpr (FINAL && KOUT == 2) {
             if (paired) {
                 constexpr int LDP = 33;
+                // T2 of the eight waves (8 x 2 x 16 x 33 doubles) reaches past the centre tile into Sx, where the value epilogue kept the
+                // tail coefficients: safe behind the __syncthreads at the top of this epilogue, and inside the block:
+                static_assert(8 * 2 * 16 * LDP <= ECT * LDC + 2 * 8 * 256, "paired Jacobian transpose area");
                 double *T2 = smem + wave * (2 * 16 * LDP);  // [l][qq][32 columns]
 #pragma unroll
                 for (int hq = 0; hq < H / 32; ++hq) {

@@ -493,7 +493,7 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
                                    st->Ginv, st->acc, cnt, Lblk, blkidx);
             hipLaunchKernelGGL(append_rows_kernel, dim3(nb((int64_t)SB * (nacc + SB))), dim3(256), 0, s, Rb, maxacc, nacc, Lblk, blkidx, cnt, st->LK, maxacc);
             int hc_local[2] = {0, 0};
-            int *hc = ctx->hpin ? reinterpret_cast<int *>(ctx->hpin + 24) : hc_local;  // (pinned: the download does not cost a round trip of its own)
+            int *hc = ctx->hpin ? reinterpret_cast<int *>(ctx->hpin + HPIN_R4_COUNT) : hc_local;  // (pinned: the download does not cost a round trip of its own)
             MRBF_HIP(ctx, hipMemcpyAsync(hc, cnt, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
             MRBF_HIP(ctx, hipStreamSynchronize(s));  // the next block's shapes depend on the number accepted so far
             nacc = hc[0];

@@ -825,8 +825,8 @@ static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info
         //  pageable memory every download was a round trip of its own, the clock's a synchronous one behind the others)
         int hflags_local[4] = {0, 0, 0, 0};
         double hscal_local[2] = {0.0, 0.0};
-        int *hflags = ctx->hpin ? reinterpret_cast<int *>(ctx->hpin) : hflags_local;
-        double *hscal = ctx->hpin ? reinterpret_cast<double *>(ctx->hpin + 4) : hscal_local;
+        int *hflags = ctx->hpin ? reinterpret_cast<int *>(ctx->hpin + HPIN_FIT_FLAGS) : hflags_local;
+        double *hscal = ctx->hpin ? reinterpret_cast<double *>(ctx->hpin + HPIN_FIT_SCAL) : hscal_local;
         hscal[0] = hscal[1] = 0.0;
         MRBF_HIP(ctx, hipMemcpyAsync(hflags, dinfo, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         if (q > 0) MRBF_HIP(ctx, hipMemcpyAsync(hscal, scal, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -954,9 +954,9 @@ static int fit_small(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_inf
     // (read-backs through the context's pinned block where there is one: asynchronous downloads, one wait)
     int hflags_local[4] = {0, 0, 0, 0};
     double hscal_local[2] = {0.0, 0.0}, hchk_local[3] = {0, 0, 0};
-    int *hflags = ctx->hpin ? reinterpret_cast<int *>(ctx->hpin + 8) : hflags_local;
-    double *hscal = ctx->hpin ? reinterpret_cast<double *>(ctx->hpin + 12) : hscal_local;
-    double *hchk = ctx->hpin ? reinterpret_cast<double *>(ctx->hpin + 16) : hchk_local;
+    int *hflags = ctx->hpin ? reinterpret_cast<int *>(ctx->hpin + HPIN_SMALL_FLAGS) : hflags_local;
+    double *hscal = ctx->hpin ? reinterpret_cast<double *>(ctx->hpin + HPIN_SMALL_SCAL) : hscal_local;
+    double *hchk = ctx->hpin ? reinterpret_cast<double *>(ctx->hpin + HPIN_SMALL_CHK) : hchk_local;
     int nc = force_nc > 0 ? force_nc : small_fit_cluster(ctx, 1);
     for (int attempt = 0; attempt < 2; ++attempt) {
         MRBF_HIP(ctx, hipMemsetAsync(cl, 0, smallfit::CL_WORDS * sizeof(int), ctx->stream));
@@ -1031,7 +1031,7 @@ static int fit_check_finish(mrbf_ctx *ctx, const mrbf_model *M, const double *h,
 }
 int fit_check(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info *info) {
     double h_local[3] = {0, 0, 0};
-    double *h = ctx->hpin ? reinterpret_cast<double *>(ctx->hpin + 20) : h_local;
+    double *h = ctx->hpin ? reinterpret_cast<double *>(ctx->hpin + HPIN_RESIDUAL) : h_local;
     h[0] = h[1] = h[2] = 0.0;
     MRBF_TRY(fit_check_enqueue(ctx, M, Y, h, ctx->ev[0], ctx->ev[1]));
     MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
