@@ -395,7 +395,7 @@ __device__ __forceinline__ void il_step(v4d (&acc)[4], const v4d (&pv)[4], const
 
 template <int MODE>
 __global__ __launch_bounds__(512, 1) void gram_il(const double *__restrict__ Xc, const double *__restrict__ sq, const double *__restrict__ E2,
-                                                  int64_t n, double *__restrict__ Phi, int64_t ld, double a2, const ILRange *__restrict__ ranges) {
+                                                  int64_t n, double *__restrict__ Phi, int64_t ld, double a2, const ILRange *__restrict__ ranges, int stride) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, l4 = lane >> 4;
@@ -438,10 +438,10 @@ __global__ __launch_bounds__(512, 1) void gram_il(const double *__restrict__ Xc,
     int pend = 0;                    // stores this wave has issued behind its newest B copy (0, 16 or 24)
     auto advance = [&](int &nti, int &nc) {
         nti = ti;
-        nc = c + 1;
-        if (nc == 4 * (ti + 1)) {
-            nti = ti + 1;
-            nc = 0;
+        nc = c + stride;  // stride 1: a wave walks consecutive strips; stride 8: the eight waves of a workgroup walk a range together
+        while (nc >= 4 * (nti + 1)) {
+            nc -= 4 * (nti + 1);
+            ++nti;
         }
     };
     auto wait_b = [&]() {
@@ -706,11 +706,12 @@ int main(int argc, char **argv) {
                 }
             return r;
         };
+        int il_stride = 1;
         auto run_il = [&](auto kern, const std::vector<ILRange> &r, const char *nm, bool check) {
             CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)IL_LDS));
             CK(hipMemcpy(dil, r.data(), NW * sizeof(ILRange), hipMemcpyHostToDevice));
             if (check) CK(hipMemset(Phi, 0, (size_t)ld * n * 8));
-            measure([&]() { hipLaunchKernelGGL(kern, dim3(256), dim3(512), IL_LDS, 0, dXa, dsq, dE2, n, Phi, ld, a2, dil); }, nm);
+            measure([&]() { hipLaunchKernelGGL(kern, dim3(256), dim3(512), IL_LDS, 0, dXa, dsq, dE2, n, Phi, ld, a2, dil, il_stride); }, nm);
             if (check) {
                 std::vector<double> hp((size_t)ld * n), hr((size_t)ld * n);
                 CK(hipMemcpy(hp.data(), Phi, hp.size() * 8, hipMemcpyDeviceToHost));
@@ -732,6 +733,41 @@ int main(int argc, char **argv) {
             snprintf(nm, sizeof nm, "il  per-wave streams, stores inside the MFMAs, rowpen %.1f", rowpen);
             run_il(gram_il<3>, make_il(rowpen), nm, rowpen == 2.0);
         }
+        // interleaved: a workgroup owns a contiguous range of strips (equal cost), its eight waves take every eighth strip of it -- at any
+        // time the eight waves write eight ADJACENT 128-byte column strips of the same rows (1 KB runs instead of isolated lines)
+        auto make_il8 = [&](double rowpen) {
+            std::vector<ILRange> r(NW, ILRange{0, 0, 0, 0});
+            const long nstrips = 2 * nt64 * (nt64 + 1);
+            std::vector<long> cut(257, nstrips);
+            const double total = (double)nstrips + rowpen * nt64;
+            double cst = 0;
+            long sidx = 0;
+            int wg = 0;
+            cut[0] = 0;
+            for (long ti = 0; ti < nt64; ++ti)
+                for (long c = 0; c < 4 * (ti + 1); ++c, ++sidx) {
+                    cst += 1.0 + (c == 0 ? rowpen : 0.0);
+                    if (wg + 1 < 256 && cst >= total * (wg + 1) / 256) cut[++wg] = sidx + 1;
+                }
+            for (int b = 0; b < 256; ++b)
+                for (int w2 = 0; w2 < 8; ++w2) {
+                    const long s0 = cut[b] + w2, s1 = cut[b + 1];
+                    if (s0 >= s1) continue;
+                    long ti = (long)((sqrt(1.0 + 2.0 * s0) - 1.0) / 2.0);
+                    while (2 * (ti + 1) * (ti + 2) <= s0) ++ti;
+                    while (2 * ti * (ti + 1) > s0) --ti;
+                    r[b * 8 + w2] = ILRange{(int)ti, (int)(s0 - 2 * ti * (ti + 1)), (int)((s1 - s0 + 7) / 8), 0};
+                }
+            return r;
+        };
+        il_stride = 8;
+        for (double rowpen : {2.0, 0.0, 4.0}) {
+            char nm[96];
+            snprintf(nm, sizeof nm, "il8 waves of a workgroup interleaved over its strips, rowpen %.1f", rowpen);
+            run_il(gram_il<3>, make_il8(rowpen), nm, rowpen == 2.0);
+        }
+        run_il(gram_il<2>, make_il8(2.0), "il8 stores + radial function, no MFMAs, rowpen 2", false);
+        il_stride = 1;
         run_il(gram_il<1>, make_il(2.0), "il  MFMA + radial function, no global stores, rowpen 2", false);
         run_il(gram_il<2>, make_il(2.0), "il  stores + radial function, no MFMAs, rowpen 2", false);
         {   // every wave 16 strips of one row (no row change, perfect balance; overwrites the same region -- timing only)
