@@ -92,6 +92,117 @@ __global__ void block_copy_kernel(const double *__restrict__ K, int64_t mc, int6
     const int r = idx % SB, c = idx / SB;
     S[idx] = (r < b && c < b) ? K[(i0 + r) + (i0 + c) * mc] : 0.0;
 }
+// Round 5: kappa on demand.  Rounds 3 / 4 built K = kappa(candidates, candidates) for ALL mc candidates up front (a cross-Gram block, two
+// mc x mc x n0 products, a pass over four mc x mc matrices: 4.3 of the 21 ms of a call with 10^4 candidates at d = 64, and 3.2 GB of
+// buffers) although the walk only ever reads the columns of the current block at the rows (accepted so far | the block itself), and
+// stops after 17 of the 79 blocks once max_points is reached.  Here one launch per block evaluates exactly those entries:
+//   kappa(xi, eta) = phi(|xi - eta|) - lam(xi).p(eta) - lam(eta).p(xi) + (lam(xi).f(eta) + lam(eta).f(xi)) / 2
+// with lam = LamT[:, .] (n0), p = P0c[:, .] = phi(X0, .), f = F[:, .] = Phi00 lam(.) -- the symmetrised form kappa_kernel wrote.
+// rows rr < nacc: accepted site acc[rr] -> Kab[rr + j ld]; rows nacc + r: candidate i0 + r -> S[r + j SB].  64 x 64 tiles, 4 x 4 per thread
+// (the shape of cross_gram_kernel: difference-form distances, then the four n0-term sums).
+template <int KID>
+__global__ __launch_bounds__(256) void kappa_block_kernel(const double *__restrict__ Xc, int d, const double *__restrict__ LamT,
+                                                          const double *__restrict__ P0c, const double *__restrict__ F, int n0, int have_tail,
+                                                          const int *__restrict__ acc, int nacc, int64_t i0, int b, KP kp,
+                                                          double *__restrict__ Kab, int ld, double *__restrict__ S) {
+    __shared__ double Ar[64][17], Ac[64][17];                    // distance phase: coordinates of the tile's rows / columns
+    __shared__ double Lr[64][17], Pr[64][17], Fr[64][17], Lc[64][17], Pc[64][17], Fc[64][17];
+    __shared__ int64_t rid[64];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int R0 = blockIdx.y * 64, C0 = blockIdx.x * 64, nrows = nacc + b;
+    if (tid < 64) {
+        const int rr = R0 + tid;
+        rid[tid] = rr < nacc ? (int64_t)acc[rr] : (rr < nrows ? i0 + (rr - nacc) : -1);
+    }
+    __syncthreads();
+    double dist[4][4] = {}, e1[4][4] = {}, e2[4][4] = {}, q1[4][4] = {}, q2[4][4] = {};
+    for (int k0 = 0; k0 < d; k0 += 16) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = ty + 16 * u, c = tx;
+            const bool kin = (k0 + c) < d;
+            const int64_t gr = rid[r];
+            Ar[r][c] = (gr >= 0 && kin) ? Xc[gr * d + k0 + c] : 0.0;
+            Ac[r][c] = (C0 + r < b && kin) ? Xc[(i0 + C0 + r) * d + k0 + c] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            double av[4], bv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) av[u] = Ar[ty + 16 * u][kk];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) bv[v] = Ac[tx + 16 * v][kk];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const double df = av[u] - bv[v];
+                    dist[u][v] = fma(df, df, dist[u][v]);
+                }
+        }
+        __syncthreads();
+    }
+    if (have_tail) {
+        for (int k0 = 0; k0 < n0; k0 += 16) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = ty + 16 * u, c = tx;
+                const bool kin = (k0 + c) < n0;
+                const int64_t gr = rid[r];
+                const bool rin = gr >= 0 && kin, cin = C0 + r < b && kin;
+                const int64_t ro = gr * n0 + k0 + c, co = (i0 + C0 + r) * n0 + k0 + c;
+                Lr[r][c] = rin ? LamT[ro] : 0.0;
+                Pr[r][c] = rin ? P0c[ro] : 0.0;
+                Fr[r][c] = rin ? F[ro] : 0.0;
+                Lc[r][c] = cin ? LamT[co] : 0.0;
+                Pc[r][c] = cin ? P0c[co] : 0.0;
+                Fc[r][c] = cin ? F[co] : 0.0;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                double lr[4], pr[4], fr[4], lc[4], pc[4], fc[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    lr[u] = Lr[ty + 16 * u][kk];
+                    pr[u] = Pr[ty + 16 * u][kk];
+                    fr[u] = Fr[ty + 16 * u][kk];
+                }
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    lc[v] = Lc[tx + 16 * v][kk];
+                    pc[v] = Pc[tx + 16 * v][kk];
+                    fc[v] = Fc[tx + 16 * v][kk];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        e1[u][v] = fma(lr[u], pc[v], e1[u][v]);
+                        e2[u][v] = fma(lc[v], pr[u], e2[u][v]);
+                        q1[u][v] = fma(lr[u], fc[v], q1[u][v]);
+                        q2[u][v] = fma(lc[v], fr[u], q2[u][v]);
+                    }
+            }
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int rr = R0 + ty + 16 * u, cc = C0 + tx + 16 * v;
+            if (rr >= nrows || cc >= b) continue;
+            double val = rbf_phi<KID>(dist[u][v], kp);
+            if (have_tail) val = (val - e1[u][v]) - e2[u][v] + 0.5 * (q1[u][v] + q2[u][v]);
+            if (rr < nacc)
+                Kab[rr + (int64_t)cc * ld] = val;
+            else
+                S[(rr - nacc) + cc * SB] = val;
+        }
+}
+
 // the sequential decisions inside one block: S = Schur complement of the block w.r.t. the accepted sites (SB x SB, global -> LDS);
 // cnt[0] = accepted so far (in / out), cnt[1] = accepted in this block (out); Lblk column a = in-block factor column of the a-th site
 // accepted here (rows = in-block candidate index), blkidx[a] = its in-block index
@@ -182,10 +293,18 @@ __global__ __launch_bounds__(SEL_THREADS) void select_block_reg_kernel(const dou
                                                                        int max_points, int maxacc, double thr, const double *__restrict__ Prow,
                                                                        double *__restrict__ Ginv, int *__restrict__ acc, int *__restrict__ cnt,
                                                                        double *__restrict__ Lblk, int *__restrict__ blkidx) {
-    extern __shared__ double smem[];  // S[SB * SB] | pi[q] | g[q] | part[16 * q] | red[16]
-    double *S = smem, *pi = S + SB * SB, *g = pi + q, *part = g + q, *red = part + 16 * q;
+    // Round 5: the Schur complement S lives in REGISTERS as well -- thread tid owns column c = tid & 127, rows (tid >> 7) + 8 k, k = 0 .. 15.
+    // With S in LDS the rank-1 update of an accepted candidate moved 32 bytes per entry of the whole 128 x 128 block through the LDS
+    // (~1.8 us of the 4.7 us per candidate, LDS bandwidth); now the owners of column j publish it (128 values, double buffered) with
+    // the candidate's pi and every thread updates its 16 entries from two broadcast reads each.
+    extern __shared__ double smem[];  // colj[2][SB] | pi[q] | g[q] | part[16 * q] | red[16]   (sized by the host for S[SB * SB] + ...: plenty)
+    double *colj = smem, *pi = colj + 2 * SB, *g = pi + q, *part = g + q, *red = part + 16 * q;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int e = tid; e < SB * SB; e += SEL_THREADS) S[e] = Sg[e];
+    static_assert(SEL_THREADS == 1024 && SB == 128, "thread -> (row, column) map of the register copy of S");
+    const int sc = tid & 127, sr0 = tid >> 7;
+    double Sr[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) Sr[k] = Sg[(sr0 + 8 * k) + sc * SB];
     double G[NA][NB_];
 #pragma unroll
     for (int a = 0; a < NA; ++a)
@@ -201,6 +320,11 @@ __global__ __launch_bounds__(SEL_THREADS) void select_block_reg_kernel(const dou
         if (n0 + nacc >= max_points || nacc >= maxacc) break;
         if (tid < q) pi[tid] = pnext;
         if (tid < q && j + 1 < b) pnext = Prow[(i0 + j + 1) * q + tid];  // in flight under this candidate's work
+        double *cj = colj + (j & 1) * SB;  // (the previous candidate's column may still be read by a slow wave: two buffers)
+        if (sc == j) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) cj[sr0 + 8 * k] = Sr[k];
+        }
         __syncthreads();
         // partial sums of Ginv pi over this wave's columns
 #pragma unroll
@@ -226,27 +350,44 @@ __global__ __launch_bounds__(SEL_THREADS) void select_block_reg_kernel(const dou
         for (int off = 32; off > 0; off >>= 1) pp += __shfl_xor(pp, off);
         if (lane == 0) red[wave] = pp;
         __syncthreads();
-        double ph = 1.0;
+        // every thread: the same sum in the same order (four interleaved chains instead of one of sixteen dependent additions)
+        double p4[4] = {1.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int w = 0; w < 16; ++w) ph += red[w];   // every thread: the same sum in the same order
-        const double pk = S[j + j * SB];
+        for (int w = 0; w < 16; ++w) p4[w & 3] += red[w];
+        const double ph = (p4[0] + p4[1]) + (p4[2] + p4[3]);
+        const double pk = cj[j];
         const double tau2 = pk / ph;
         const bool accept = pk > 0.0 && tau2 > thr && tau2 < 1e300;  // tau^2 > (theta^2)^2, RbfModel.jl:370, :452 (NaN fails)
         if (!accept) continue;
-        const double rs = 1.0 / sqrt(pk);
-        for (int r = tid; r < SB; r += SEL_THREADS) Lblk[r + nblk * SB] = (r > j && r < b) ? S[r + j * SB] * rs : (r == j ? pk * rs : 0.0);
-        for (int e = tid; e < SB * SB; e += SEL_THREADS) {  // rank-1 update of the trailing complement (lower part); column j is not touched
-            const int r = e % SB, c = e / SB;
-            if (c > j && r >= c && r < b) S[e] = fma(-(S[r + j * SB] * rs), S[c + j * SB] * rs, S[e]);
-        }
-        // Ginv <- Ginv - g g' / s_H   (Sherman-Morrison for G + pi pi')
+        // 1 / sqrt(pk) and 1 / ph from the hardware estimates + Newton steps (relative error <= ~2e-16): the IEEE sqrt + two divisions
+        // were ~150 dependent instructions on the critical path of every accepted candidate
+        double sq_, rs;
+        fast_sqrt_rsqrt(pk, sq_, rs);
+        (void)sq_;
+        for (int r = tid; r < SB; r += SEL_THREADS) Lblk[r + nblk * SB] = (r > j && r < b) ? cj[r] * rs : (r == j ? pk * rs : 0.0);
+        if (sc > j) {  // rank-1 update of the trailing complement (lower part); column j is not touched
+            const double lc = cj[sc] * rs;
 #pragma unroll
-        for (int a = 0; a < NA; ++a)
+            for (int k = 0; k < 16; ++k) {
+                const int r = sr0 + 8 * k;
+                if (r >= sc && r < b) Sr[k] = fma(-(cj[r] * rs), lc, Sr[k]);
+            }
+        }
+        // Ginv <- Ginv - g g' / s_H   (Sherman-Morrison for G + pi pi').  ONE reciprocal per candidate: g g' (1 / s_H) differs from
+        // g g' / s_H in the last bit of an update that is itself O(eps) accurate -- the accept test keeps its exact quotient pk / s_H
+        double rph = __builtin_amdgcn_rcp(ph);
+        rph = fma(fma(-ph, rph, 1.0), rph, rph);
+        rph = fma(fma(-ph, rph, 1.0), rph, rph);
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+            const int t = lane + 64 * a;
+            const double gt = t < q ? g[t] * rph : 0.0;
 #pragma unroll
             for (int bb = 0; bb < NB_; ++bb) {
-                const int t = lane + 64 * a, u = wave + 16 * bb;
-                if (t < q && u < q) G[a][bb] -= g[t] * g[u] / ph;
+                const int u = wave + 16 * bb;
+                if (t < q && u < q) G[a][bb] = fma(-gt, g[u], G[a][bb]);
             }
+        }
         if (tid == 0) {
             acc[nacc] = (int)(i0 + j);
             blkidx[nblk] = j;
@@ -386,8 +527,12 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
     // one allocation for everything that outlives the call
     auto *st = new mrbf_round4_state();
     st->n0 = n0; st->mc = mc; st->d = d; st->q = q; st->deg = poly_deg; st->kid = kernel_id; st->a = a; st->b = b; st->maxacc = maxacc;
+    // kappa(candidates, candidates) on demand, block by block (kappa_block_kernel; MRBF_R4_LAZY=0: the full mc x mc matrix up front as in rounds 3 / 4)
+    static const int lazy_env = getenv("MRBF_R4_LAZY") ? atoi(getenv("MRBF_R4_LAZY")) : 1;
+    const bool lazy = lazy_env != 0;
     const size_t cnt[11] = {(size_t)n0 * d, (size_t)mc * d, (size_t)n0 * n0, (size_t)n0 * mc, (size_t)n0 * std::max(q, 1), (size_t)n0 * mc,
-                            (size_t)mc * mc, (size_t)maxacc * maxacc, (size_t)mc, (size_t)mc * std::max(q, 1), (size_t)std::max(q, 1) * std::max(q, 1)};
+                            lazy ? (size_t)1 : (size_t)mc * mc, (size_t)maxacc * maxacc, (size_t)mc, (size_t)mc * std::max(q, 1),
+                            (size_t)std::max(q, 1) * std::max(q, 1)};
     size_t off[12];
     off[0] = 0;
     for (int i = 0; i < 11; ++i) off[i + 1] = off[i] + ((cnt[i] * sizeof(double) + 255) & ~size_t(255));
@@ -408,14 +553,16 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
         MRBF_HIP(ctx, hipMemcpyAsync(st->C0, start_sites, (size_t)n0 * d * sizeof(double), hipMemcpyDefault, s));
         MRBF_HIP(ctx, hipMemcpyAsync(st->Xc, cand_sites, (size_t)mc * d * sizeof(double), hipMemcpyDefault, s));
         // kernel blocks (difference-form arithmetic, like norm(x - c)): Phi00, phi(candidates, X0) (= P0c as n0 x mc column-major), Phicc
-        double *Phicc, *E, *Qm, *F, *T;
-        MRBF_TRY(get_buf(ctx, S_PHI, (size_t)mc * mc, &Phicc));
+        double *Phicc = nullptr, *E = nullptr, *Qm = nullptr, *F = nullptr, *T;
+        if (!lazy) MRBF_TRY(get_buf(ctx, S_PHI, (size_t)mc * mc, &Phicc));
         MRBF_TRY(launch_cross_gram(ctx, st->C0, n0, st->C0, n0, d, kp, st->Phi00));
         MRBF_TRY(launch_cross_gram(ctx, st->Xc, mc, st->C0, n0, d, kp, st->P0c));
-        MRBF_TRY(launch_cross_gram(ctx, st->Xc, mc, st->Xc, mc, d, kp, Phicc));
+        if (!lazy) MRBF_TRY(launch_cross_gram(ctx, st->Xc, mc, st->Xc, mc, d, kp, Phicc));
         if (q > 0) {
-            MRBF_TRY(get_buf(ctx, S_STAGE_C, (size_t)mc * mc, &E));
-            MRBF_TRY(get_buf(ctx, S_STAGE_D, (size_t)mc * mc, &Qm));
+            if (!lazy) {
+                MRBF_TRY(get_buf(ctx, S_STAGE_C, (size_t)mc * mc, &E));
+                MRBF_TRY(get_buf(ctx, S_STAGE_D, (size_t)mc * mc, &Qm));
+            }
             MRBF_TRY(get_buf(ctx, S_W1, (size_t)n0 * mc, &F));
             MRBF_TRY(get_buf(ctx, S_T1, (size_t)q * std::max<int64_t>(mc, q), &T));
             int *dinfo;
@@ -439,17 +586,19 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
             MRBF_BLAS(ctx, rocsolver_dpotrs(ctx->blas, rocblas_fill_lower, q, (int)mc, G0, q, T, q));
             MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, (int)n0, (int)mc, q, &one, st->Pi0, (int)n0, T, q,
                                          &zero, st->LamT, (int)n0));
-            // E = Lam Phi0c = LamT' P0c ; F = Phi00 LamT ; Q = LamT' F
-            MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, (int)mc, (int)mc, (int)n0, &one, st->LamT,
-                                         (int)n0, st->P0c, (int)n0, &zero, E, (int)mc));
+            // E = Lam Phi0c = LamT' P0c ; F = Phi00 LamT ; Q = LamT' F   (on demand: only F, the n0 x mc panel, is formed here)
+            if (!lazy)
+                MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, (int)mc, (int)mc, (int)n0, &one, st->LamT,
+                                             (int)n0, st->P0c, (int)n0, &zero, E, (int)mc));
             MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, (int)n0, (int)mc, (int)n0, &one, st->Phi00, (int)n0,
                                          st->LamT, (int)n0, &zero, F, (int)n0));
-            MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, (int)mc, (int)mc, (int)n0, &one, st->LamT,
-                                         (int)n0, F, (int)n0, &zero, Qm, (int)mc));
+            if (!lazy)
+                MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, (int)mc, (int)mc, (int)n0, &one, st->LamT,
+                                             (int)n0, F, (int)n0, &zero, Qm, (int)mc));
         } else {
             E = Qm = Phicc;
         }
-        hipLaunchKernelGGL(kappa_kernel, dim3(nb(mc * mc)), dim3(256), 0, s, Phicc, E, Qm, mc, st->K, st->diagK, q > 0 ? 1 : 0);
+        if (!lazy) hipLaunchKernelGGL(kappa_kernel, dim3(nb(mc * mc)), dim3(256), 0, s, Phicc, E, Qm, mc, st->K, st->diagK, q > 0 ? 1 : 0);
         const double thr = (theta_pivot_cholesky * theta_pivot_cholesky) * (theta_pivot_cholesky * theta_pivot_cholesky);
         const size_t shm = ((size_t)SB * SB + SB + 2 * (size_t)std::max(q, 1) + SEL_THREADS / 64) * sizeof(double);
         MRBF_HIP(ctx, hipFuncSetAttribute((const void *)select_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
@@ -473,9 +622,17 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
         int nacc = 0;
         for (int64_t i0 = 0; i0 < mc && (int64_t)n0 + nacc < max_points && nacc < maxacc; i0 += SB) {
             const int bsz = (int)std::min<int64_t>(SB, mc - i0);
-            hipLaunchKernelGGL(block_copy_kernel, dim3(nb(SB * SB)), dim3(256), 0, s, st->K, mc, i0, bsz, Sb);
+            if (lazy) {
+                if (bsz < SB) MRBF_HIP(ctx, hipMemsetAsync(Sb, 0, (size_t)SB * SB * sizeof(double), s));
+                const dim3 kgrid((unsigned)((bsz + 63) / 64), (unsigned)((nacc + bsz + 63) / 64));
+                MRBF_DISPATCH_KID(kp.kid, hipLaunchKernelGGL((kappa_block_kernel<KID>), kgrid, dim3(256), 0, s, st->Xc, d, st->LamT, st->P0c, F, (int)n0,
+                                                             q > 0 ? 1 : 0, st->acc, nacc, i0, bsz, kp, Rb, maxacc, Sb));
+            } else {
+                hipLaunchKernelGGL(block_copy_kernel, dim3(nb(SB * SB)), dim3(256), 0, s, st->K, mc, i0, bsz, Sb);
+            }
             if (nacc > 0) {
-                hipLaunchKernelGGL(gather_kab_kernel, dim3(nb((int64_t)nacc * bsz)), dim3(256), 0, s, st->K, mc, st->acc, nacc, i0, bsz, Rb, maxacc);
+                if (!lazy)
+                    hipLaunchKernelGGL(gather_kab_kernel, dim3(nb((int64_t)nacc * bsz)), dim3(256), 0, s, st->K, mc, st->acc, nacc, i0, bsz, Rb, maxacc);
                 MRBF_BLAS(ctx, rocblas_dtrsm(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, nacc, bsz,
                                              &one, st->LK, maxacc, Rb, maxacc));
                 const double mone = -1.0;
