@@ -288,8 +288,8 @@ __global__ __launch_bounds__(SEL_THREADS) void select_block_kernel(const double 
 // 16 partial sums per row through LDS, every thread takes the accept / reject decision itself from the same sums (same order: same
 // result), the factor column is read off S's column j, pi of the next candidate is fetched one candidate ahead: three barriers and
 // no global round trip per candidate.  Same arithmetic per entry as above except for the order of the q-term sums.
-template <int NA, int NB_>
-__global__ __launch_bounds__(SEL_THREADS) void select_block_reg_kernel(const double *__restrict__ Sg, int b, int64_t i0, int n0, int q,
+template <int NA, int NB_, int TW>  // TW waves: thread (lane, wave) owns Ginv[lane + 64 a][wave + TW bb]
+__global__ __launch_bounds__(64 * TW) void select_block_reg_kernel(const double *__restrict__ Sg, int b, int64_t i0, int n0, int q,
                                                                        int max_points, int maxacc, double thr, const double *__restrict__ Prow,
                                                                        double *__restrict__ Ginv, int *__restrict__ acc, int *__restrict__ cnt,
                                                                        double *__restrict__ Lblk, int *__restrict__ blkidx) {
@@ -297,20 +297,21 @@ __global__ __launch_bounds__(SEL_THREADS) void select_block_reg_kernel(const dou
     // With S in LDS the rank-1 update of an accepted candidate moved 32 bytes per entry of the whole 128 x 128 block through the LDS
     // (~1.8 us of the 4.7 us per candidate, LDS bandwidth); now the owners of column j publish it (128 values, double buffered) with
     // the candidate's pi and every thread updates its 16 entries from two broadcast reads each.
-    extern __shared__ double smem[];  // colj[2][SB] | pi[q] | g[q] | part[16 * q] | red[16]   (sized by the host for S[SB * SB] + ...: plenty)
-    double *colj = smem, *pi = colj + 2 * SB, *g = pi + q, *part = g + q, *red = part + 16 * q;
+    extern __shared__ double smem[];  // colj[2][SB] | pi[q] | g[q] | part[TW * q] | red[TW]   (sized by the host for S[SB * SB] + ...: plenty)
+    double *colj = smem, *pi = colj + 2 * SB, *g = pi + q, *part = g + q, *red = part + TW * q;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    static_assert(SEL_THREADS == 1024 && SB == 128, "thread -> (row, column) map of the register copy of S");
+    static_assert(SB == 128 && (TW == 16 || TW == 8), "thread -> (row, column) map of the register copy of S");
+    constexpr int TT = 64 * TW, RS = TT / 128, RK = 128 / RS;  // threads, row stride and rows per thread of the register copy of S
     const int sc = tid & 127, sr0 = tid >> 7;
-    double Sr[16];
+    double Sr[RK];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) Sr[k] = Sg[(sr0 + 8 * k) + sc * SB];
+    for (int k = 0; k < RK; ++k) Sr[k] = Sg[(sr0 + RS * k) + sc * SB];
     double G[NA][NB_];
 #pragma unroll
     for (int a = 0; a < NA; ++a)
 #pragma unroll
         for (int bb = 0; bb < NB_; ++bb) {
-            const int t = lane + 64 * a, u = wave + 16 * bb;
+            const int t = lane + 64 * a, u = wave + TW * bb;
             G[a][bb] = (t < q && u < q) ? Ginv[t + (int64_t)u * q] : 0.0;
         }
     int nacc = cnt[0], nblk = 0;
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_block_reg_kernel(const dou
         double *cj = colj + (j & 1) * SB;  // (the previous candidate's column may still be read by a slow wave: two buffers)
         if (sc == j) {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) cj[sr0 + 8 * k] = Sr[k];
+            for (int k = 0; k < RK; ++k) cj[sr0 + RS * k] = Sr[k];
         }
         __syncthreads();
         // partial sums of Ginv pi over this wave's columns
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_block_reg_kernel(const dou
             double sp = 0.0;
 #pragma unroll
             for (int bb = 0; bb < NB_; ++bb) {
-                const int u = wave + 16 * bb;
+                const int u = wave + TW * bb;
                 if (u < q) sp = fma(G[a][bb], pi[u], sp);
             }
             if (t < q) part[wave * q + t] = sp;
@@ -343,7 +344,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_block_reg_kernel(const dou
         if (tid < q) {
             double sg = 0.0;
 #pragma unroll
-            for (int w = 0; w < 16; ++w) sg += part[w * q + tid];
+            for (int w = 0; w < TW; ++w) sg += part[w * q + tid];
             g[tid] = sg;
             pp = pi[tid] * sg;
         }
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_block_reg_kernel(const dou
         // every thread: the same sum in the same order (four interleaved chains instead of one of sixteen dependent additions)
         double p4[4] = {1.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int w = 0; w < 16; ++w) p4[w & 3] += red[w];
+        for (int w = 0; w < TW; ++w) p4[w & 3] += red[w];
         const double ph = (p4[0] + p4[1]) + (p4[2] + p4[3]);
         const double pk = cj[j];
         const double tau2 = pk / ph;
@@ -364,12 +365,12 @@ __global__ __launch_bounds__(SEL_THREADS) void select_block_reg_kernel(const dou
         double sq_, rs;
         fast_sqrt_rsqrt(pk, sq_, rs);
         (void)sq_;
-        for (int r = tid; r < SB; r += SEL_THREADS) Lblk[r + nblk * SB] = (r > j && r < b) ? cj[r] * rs : (r == j ? pk * rs : 0.0);
+        for (int r = tid; r < SB; r += TT) Lblk[r + nblk * SB] = (r > j && r < b) ? cj[r] * rs : (r == j ? pk * rs : 0.0);
         if (sc > j) {  // rank-1 update of the trailing complement (lower part); column j is not touched
             const double lc = cj[sc] * rs;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int r = sr0 + 8 * k;
+            for (int k = 0; k < RK; ++k) {
+                const int r = sr0 + RS * k;
                 if (r >= sc && r < b) Sr[k] = fma(-(cj[r] * rs), lc, Sr[k]);
             }
         }
@@ -384,7 +385,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_block_reg_kernel(const dou
             const double gt = t < q ? g[t] * rph : 0.0;
 #pragma unroll
             for (int bb = 0; bb < NB_; ++bb) {
-                const int u = wave + 16 * bb;
+                const int u = wave + TW * bb;
                 if (t < q && u < q) G[a][bb] = fma(-gt, g[u], G[a][bb]);
             }
         }
@@ -399,7 +400,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_block_reg_kernel(const dou
     for (int a = 0; a < NA; ++a)
 #pragma unroll
         for (int bb = 0; bb < NB_; ++bb) {
-            const int t = lane + 64 * a, u = wave + 16 * bb;
+            const int t = lane + 64 * a, u = wave + TW * bb;
             if (t < q && u < q) Ginv[t + (int64_t)u * q] = G[a][bb];
         }
     if (tid == 0) {
@@ -606,10 +607,15 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
         static const int sel_env = getenv("MRBF_R4_SELECT") ? atoi(getenv("MRBF_R4_SELECT")) : 1;
         const int fast_sel = (sel_env && q >= 1 && q <= 80) ? 1 : ((sel_env && q >= 1 && q <= 128) ? 2 : 0);
         const size_t shm_reg = ((size_t)SB * SB + 2 * (size_t)std::max(q, 1) + 16 * (size_t)std::max(q, 1) + 16) * sizeof(double);
-        if (fast_sel == 1)
-            MRBF_HIP(ctx, hipFuncSetAttribute((const void *)select_block_reg_kernel<2, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_reg));
-        if (fast_sel == 2)
-            MRBF_HIP(ctx, hipFuncSetAttribute((const void *)select_block_reg_kernel<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_reg));
+        static const int selw = getenv("MRBF_R4_SELW") ? atoi(getenv("MRBF_R4_SELW")) : 16;  // waves of the decision kernel (8 or 16; 8 measured 6 % slower at d = 64)
+        if (fast_sel == 1) {
+            MRBF_HIP(ctx, hipFuncSetAttribute((const void *)select_block_reg_kernel<2, 5, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_reg));
+            MRBF_HIP(ctx, hipFuncSetAttribute((const void *)select_block_reg_kernel<2, 10, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_reg));
+        }
+        if (fast_sel == 2) {
+            MRBF_HIP(ctx, hipFuncSetAttribute((const void *)select_block_reg_kernel<2, 8, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_reg));
+            MRBF_HIP(ctx, hipFuncSetAttribute((const void *)select_block_reg_kernel<2, 16, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_reg));
+        }
         double *Rb, *Sb, *Lblk;
         int *cnt, *blkidx;
         MRBF_TRY(get_buf(ctx, S_Q1, (size_t)maxacc * SB, &Rb));          // R = L_acc^-1 K[acc, block]
@@ -639,11 +645,17 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
                 MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, bsz, bsz, nacc, &mone, Rb, maxacc, Rb, maxacc,
                                              &one, Sb, SB));
             }
-            if (fast_sel == 1)
-                hipLaunchKernelGGL((select_block_reg_kernel<2, 5>), dim3(1), dim3(SEL_THREADS), shm_reg, s, Sb, bsz, i0, (int)n0, q, (int)max_points, maxacc,
+            if (fast_sel == 1 && selw == 8)
+                hipLaunchKernelGGL((select_block_reg_kernel<2, 10, 8>), dim3(1), dim3(512), shm_reg, s, Sb, bsz, i0, (int)n0, q, (int)max_points, maxacc,
+                                   thr, st->Prow, st->Ginv, st->acc, cnt, Lblk, blkidx);
+            else if (fast_sel == 2 && selw == 8)
+                hipLaunchKernelGGL((select_block_reg_kernel<2, 16, 8>), dim3(1), dim3(512), shm_reg, s, Sb, bsz, i0, (int)n0, q, (int)max_points, maxacc,
+                                   thr, st->Prow, st->Ginv, st->acc, cnt, Lblk, blkidx);
+            else if (fast_sel == 1)
+                hipLaunchKernelGGL((select_block_reg_kernel<2, 5, 16>), dim3(1), dim3(SEL_THREADS), shm_reg, s, Sb, bsz, i0, (int)n0, q, (int)max_points, maxacc,
                                    thr, st->Prow, st->Ginv, st->acc, cnt, Lblk, blkidx);
             else if (fast_sel == 2)
-                hipLaunchKernelGGL((select_block_reg_kernel<2, 8>), dim3(1), dim3(SEL_THREADS), shm_reg, s, Sb, bsz, i0, (int)n0, q, (int)max_points, maxacc,
+                hipLaunchKernelGGL((select_block_reg_kernel<2, 8, 16>), dim3(1), dim3(SEL_THREADS), shm_reg, s, Sb, bsz, i0, (int)n0, q, (int)max_points, maxacc,
                                    thr, st->Prow, st->Ginv, st->acc, cnt, Lblk, blkidx);
             else
                 hipLaunchKernelGGL(select_block_kernel, dim3(1), dim3(SEL_THREADS), shm, s, Sb, bsz, i0, (int)n0, q, (int)max_points, maxacc, thr, st->Prow,
