@@ -100,41 +100,44 @@ __global__ void block_copy_kernel(const double *__restrict__ K, int64_t mc, int6
 // with lam = LamT[:, .] (n0), p = P0c[:, .] = phi(X0, .), f = F[:, .] = Phi00 lam(.) -- the symmetrised form kappa_kernel wrote.
 // rows rr < nacc: accepted site acc[rr] -> Kab[rr + j ld]; rows nacc + r: candidate i0 + r -> S[r + j SB].  64 x 64 tiles, 4 x 4 per thread
 // (the shape of cross_gram_kernel: difference-form distances, then the four n0-term sums).
-template <int KID>
+template <int KID, int RT>  // tile = 16 RT rows x 64 columns, RT x 4 entries per thread (RT = 1: up to 276 workgroups per block)
 __global__ __launch_bounds__(256) void kappa_block_kernel(const double *__restrict__ Xc, int d, const double *__restrict__ LamT,
                                                           const double *__restrict__ P0c, const double *__restrict__ F, int n0, int have_tail,
                                                           const int *__restrict__ acc, int nacc, int64_t i0, int b, KP kp,
                                                           double *__restrict__ Kab, int ld, double *__restrict__ S) {
-    __shared__ double Ar[64][17], Ac[64][17];                    // distance phase: coordinates of the tile's rows / columns
-    __shared__ double Lr[64][17], Pr[64][17], Fr[64][17], Lc[64][17], Pc[64][17], Fc[64][17];
-    __shared__ int64_t rid[64];
+    constexpr int TR = 16 * RT;
+    __shared__ double Ar[TR][17], Ac[64][17];                    // distance phase: coordinates of the tile's rows / columns
+    __shared__ double Lr[TR][17], Pr[TR][17], Fr[TR][17], Lc[64][17], Pc[64][17], Fc[64][17];
+    __shared__ int64_t rid[TR];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    const int R0 = blockIdx.y * 64, C0 = blockIdx.x * 64, nrows = nacc + b;
-    if (tid < 64) {
+    const int R0 = blockIdx.y * TR, C0 = blockIdx.x * 64, nrows = nacc + b;
+    if (tid < TR) {
         const int rr = R0 + tid;
         rid[tid] = rr < nacc ? (int64_t)acc[rr] : (rr < nrows ? i0 + (rr - nacc) : -1);
     }
     __syncthreads();
-    double dist[4][4] = {}, e1[4][4] = {}, e2[4][4] = {}, q1[4][4] = {}, q2[4][4] = {};
+    double dist[RT][4] = {}, e1[RT][4] = {}, e2[RT][4] = {}, q1[RT][4] = {}, q2[RT][4] = {};
     for (int k0 = 0; k0 < d; k0 += 16) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int r = ty + 16 * u, c = tx;
             const bool kin = (k0 + c) < d;
-            const int64_t gr = rid[r];
-            Ar[r][c] = (gr >= 0 && kin) ? Xc[gr * d + k0 + c] : 0.0;
+            if (u < RT) {
+                const int64_t gr = rid[r];
+                Ar[r][c] = (gr >= 0 && kin) ? Xc[gr * d + k0 + c] : 0.0;
+            }
             Ac[r][c] = (C0 + r < b && kin) ? Xc[(i0 + C0 + r) * d + k0 + c] : 0.0;
         }
         __syncthreads();
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
-            double av[4], bv[4];
+            double av[RT], bv[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) av[u] = Ar[ty + 16 * u][kk];
+            for (int u = 0; u < RT; ++u) av[u] = Ar[ty + 16 * u][kk];
 #pragma unroll
             for (int v = 0; v < 4; ++v) bv[v] = Ac[tx + 16 * v][kk];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < RT; ++u)
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     const double df = av[u] - bv[v];
@@ -149,12 +152,16 @@ __global__ __launch_bounds__(256) void kappa_block_kernel(const double *__restri
             for (int u = 0; u < 4; ++u) {
                 const int r = ty + 16 * u, c = tx;
                 const bool kin = (k0 + c) < n0;
-                const int64_t gr = rid[r];
-                const bool rin = gr >= 0 && kin, cin = C0 + r < b && kin;
-                const int64_t ro = gr * n0 + k0 + c, co = (i0 + C0 + r) * n0 + k0 + c;
-                Lr[r][c] = rin ? LamT[ro] : 0.0;
-                Pr[r][c] = rin ? P0c[ro] : 0.0;
-                Fr[r][c] = rin ? F[ro] : 0.0;
+                if (u < RT) {
+                    const int64_t gr = rid[r];
+                    const bool rin = gr >= 0 && kin;
+                    const int64_t ro = gr * n0 + k0 + c;
+                    Lr[r][c] = rin ? LamT[ro] : 0.0;
+                    Pr[r][c] = rin ? P0c[ro] : 0.0;
+                    Fr[r][c] = rin ? F[ro] : 0.0;
+                }
+                const bool cin = C0 + r < b && kin;
+                const int64_t co = (i0 + C0 + r) * n0 + k0 + c;
                 Lc[r][c] = cin ? LamT[co] : 0.0;
                 Pc[r][c] = cin ? P0c[co] : 0.0;
                 Fc[r][c] = cin ? F[co] : 0.0;
@@ -162,9 +169,9 @@ __global__ __launch_bounds__(256) void kappa_block_kernel(const double *__restri
             __syncthreads();
 #pragma unroll
             for (int kk = 0; kk < 16; ++kk) {
-                double lr[4], pr[4], fr[4], lc[4], pc[4], fc[4];
+                double lr[RT], pr[RT], fr[RT], lc[4], pc[4], fc[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < RT; ++u) {
                     lr[u] = Lr[ty + 16 * u][kk];
                     pr[u] = Pr[ty + 16 * u][kk];
                     fr[u] = Fr[ty + 16 * u][kk];
@@ -176,7 +183,7 @@ __global__ __launch_bounds__(256) void kappa_block_kernel(const double *__restri
                     fc[v] = Fc[tx + 16 * v][kk];
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < RT; ++u)
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
                         e1[u][v] = fma(lr[u], pc[v], e1[u][v]);
@@ -189,7 +196,7 @@ __global__ __launch_bounds__(256) void kappa_block_kernel(const double *__restri
         }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < RT; ++u)
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const int rr = R0 + ty + 16 * u, cc = C0 + tx + 16 * v;
@@ -630,8 +637,8 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
             const int bsz = (int)std::min<int64_t>(SB, mc - i0);
             if (lazy) {
                 if (bsz < SB) MRBF_HIP(ctx, hipMemsetAsync(Sb, 0, (size_t)SB * SB * sizeof(double), s));
-                const dim3 kgrid((unsigned)((bsz + 63) / 64), (unsigned)((nacc + bsz + 63) / 64));
-                MRBF_DISPATCH_KID(kp.kid, hipLaunchKernelGGL((kappa_block_kernel<KID>), kgrid, dim3(256), 0, s, st->Xc, d, st->LamT, st->P0c, F, (int)n0,
+                const dim3 kgrid((unsigned)((bsz + 63) / 64), (unsigned)((nacc + bsz + 15) / 16));
+                MRBF_DISPATCH_KID(kp.kid, hipLaunchKernelGGL((kappa_block_kernel<KID, 1>), kgrid, dim3(256), 0, s, st->Xc, d, st->LamT, st->P0c, F, (int)n0,
                                                              q > 0 ? 1 : 0, st->acc, nacc, i0, bsz, kp, Rb, maxacc, Sb));
             } else {
                 hipLaunchKernelGGL(block_copy_kernel, dim3(nb(SB * SB)), dim3(256), 0, s, st->K, mc, i0, bsz, Sb);

@@ -36,6 +36,7 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmc_f_c5" -o f -- python3 "$R
 echo "PMC passes done"
 cd "$ROOT"
 python3 tools/round4_bench.py 64 10000 > "$OUT/round4_d64.txt" 2>&1
+cd /tmp && rocprofv3 --kernel-trace --stats -d "$OUT/prof_r4" -o r4 -- python3 "$ROOT/tools/round4_bench.py" 64 10000 > "$OUT/round4_under_profiler.txt" 2>&1; cd "$ROOT"
 python3 tools/round4_bench.py 24 3000 > "$OUT/round4_d24.txt" 2>&1
 python3 tools/ps_bench2.py 64,128,256 > "$OUT/ps_step.txt" 2>&1
 python3 tools/ps_bench.py > "$OUT/ps_step_d12.txt" 2>&1 || true
