@@ -104,13 +104,13 @@ template <int KID, int RT>  // tile = 16 RT rows x 64 columns, RT x 4 entries pe
 __global__ __launch_bounds__(256) void kappa_block_kernel(const double *__restrict__ Xc, int d, const double *__restrict__ LamT,
                                                           const double *__restrict__ P0c, const double *__restrict__ F, int n0, int have_tail,
                                                           const int *__restrict__ acc, int nacc, int64_t i0, int b, KP kp,
-                                                          double *__restrict__ Kab, int ld, double *__restrict__ S) {
+                                                          double *__restrict__ Kab, int ld, double *__restrict__ S, int blockrows) {
     constexpr int TR = 16 * RT;
     __shared__ double Ar[TR][17], Ac[64][17];                    // distance phase: coordinates of the tile's rows / columns
     __shared__ double Lr[TR][17], Pr[TR][17], Fr[TR][17], Lc[64][17], Pc[64][17], Fc[64][17];
     __shared__ int64_t rid[TR];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    const int R0 = blockIdx.y * TR, C0 = blockIdx.x * 64, nrows = nacc + b;
+    const int R0 = blockIdx.y * TR, C0 = blockIdx.x * 64, nrows = nacc + (blockrows ? b : 0);  // (blockrows = 0: the listed rows only, any number of columns)
     if (tid < TR) {
         const int rr = R0 + tid;
         rid[tid] = rr < nacc ? (int64_t)acc[rr] : (rr < nrows ? i0 + (rr - nacc) : -1);
@@ -436,6 +436,50 @@ __global__ void append_rows_kernel(const double *__restrict__ R, int ldr, int na
         return;
     L[(nacc0 + a) + (int64_t)c * ldl] = v;
 }
+// ---- right-looking form of the walk (round 5): R(:, j) = L_acc^-1 kappa(acc, j) is kept for EVERY candidate still ahead and extended by
+// the rows of a block's accepted sites as soon as they are known, so that no block ever needs a triangular solve against the whole
+// accepted factor (rocBLAS dtrsm: a chain of ~25 small launches per block, 4 of the 16.5 ms at d = 64 / 10^4 candidates and all of the
+// 226 ms at d = 128 with 6000 accepted).  Per block:  Kn = kappa(new, ahead) - R(old, new)' R(old, ahead)  (one fat GEMM),
+// R(new, ahead) = L_bb^-1 Kn  (a 128-row triangular solve, one thread per candidate) -- the blocked right-looking Cholesky with skipped
+// columns that the walk is.  Same quantities as the left-looking form, summed in a different order.
+// A(:, a) = R(0 .. rows-1, i0 + blkidx[a])   (the new sites' columns of R, compact, for the GEMM)
+__global__ void gather_newcols_kernel(const double *__restrict__ R, int ldr, int rows, int64_t i0, const int *__restrict__ blkidx, int nblk,
+                                      double *__restrict__ A, int lda) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)rows * nblk) return;
+    const int r = (int)(idx % rows), a = (int)(idx / rows);
+    A[r + (int64_t)a * lda] = R[r + (i0 + blkidx[a]) * (int64_t)ldr];
+}
+// X = L_bb^-1 Kn for ncols candidates, L_bb(a, a') = Lblk[blkidx[a] + a' SB] (a' <= a); X(a, j) -> Rout[a + j ldr].  One thread per
+// candidate: the factor entry of a step is uniform (scalar loads), the partial solution lives in LDS, column-private.
+__global__ __launch_bounds__(64) void block_forward_kernel(const double *__restrict__ Kn, int ldk, const double *__restrict__ Lblk,
+                                                          const int *__restrict__ blkidx, int nblk, int64_t ncols, double *__restrict__ Rout,
+                                                          int ldr) {
+    extern __shared__ double fw_smem[];  // xs[SB][64] | bi[SB] (66 KB: dynamic, the host raises the limit)
+    double(*xs)[64] = reinterpret_cast<double(*)[64]>(fw_smem);
+    int *bi = reinterpret_cast<int *>(fw_smem + SB * 64);
+    const int tid = threadIdx.x;
+    const int64_t j = (int64_t)blockIdx.x * 64 + tid;
+    for (int a = tid; a < nblk; a += 64) bi[a] = blkidx[a];
+    __syncthreads();
+    if (j >= ncols) return;
+    for (int a = 0; a < nblk; ++a) {
+        double sacc = Kn[a + j * ldk];
+        const double *Lrow = Lblk + bi[a];  // L_bb(a, a') = Lrow[a' * SB]
+        int a2 = 0;
+        for (; a2 + 4 <= a; a2 += 4) {
+            sacc = fma(-Lrow[(a2 + 0) * SB], xs[a2 + 0][tid], sacc);
+            sacc = fma(-Lrow[(a2 + 1) * SB], xs[a2 + 1][tid], sacc);
+            sacc = fma(-Lrow[(a2 + 2) * SB], xs[a2 + 2][tid], sacc);
+            sacc = fma(-Lrow[(a2 + 3) * SB], xs[a2 + 3][tid], sacc);
+        }
+        for (; a2 < a; ++a2) sacc = fma(-Lrow[a2 * SB], xs[a2][tid], sacc);
+        const double x = sacc / Lrow[a * SB];
+        xs[a][tid] = x;
+        Rout[a + j * (int64_t)ldr] = x;
+    }
+}
+
 // dense j x j copy of the accepted factor
 __global__ void copy_factor_kernel(const double *__restrict__ L, int ldl, int j, double *__restrict__ out) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -536,7 +580,7 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
     auto *st = new mrbf_round4_state();
     st->n0 = n0; st->mc = mc; st->d = d; st->q = q; st->deg = poly_deg; st->kid = kernel_id; st->a = a; st->b = b; st->maxacc = maxacc;
     // kappa(candidates, candidates) on demand, block by block (kappa_block_kernel; MRBF_R4_LAZY=0: the full mc x mc matrix up front as in rounds 3 / 4)
-    static const int lazy_env = getenv("MRBF_R4_LAZY") ? atoi(getenv("MRBF_R4_LAZY")) : 1;
+    const int lazy_env = getenv("MRBF_R4_LAZY") ? atoi(getenv("MRBF_R4_LAZY")) : 1;  // (read per call: the tests switch it)
     const bool lazy = lazy_env != 0;
     const size_t cnt[11] = {(size_t)n0 * d, (size_t)mc * d, (size_t)n0 * n0, (size_t)n0 * mc, (size_t)n0 * std::max(q, 1), (size_t)n0 * mc,
                             lazy ? (size_t)1 : (size_t)mc * mc, (size_t)maxacc * maxacc, (size_t)mc, (size_t)mc * std::max(q, 1),
@@ -612,7 +656,8 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
         MRBF_HIP(ctx, hipFuncSetAttribute((const void *)select_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
         // the register variant of the decision kernel: q <= 80 (2 x 5 entries of Ginv per thread) or q <= 128 (2 x 8); needs q >= 1
         static const int sel_env = getenv("MRBF_R4_SELECT") ? atoi(getenv("MRBF_R4_SELECT")) : 1;
-        const int fast_sel = (sel_env && q >= 1 && q <= 80) ? 1 : ((sel_env && q >= 1 && q <= 128) ? 2 : 0);
+        // (3: q <= 192 -- d = 128 has q = 129 -- three rows x twelve columns of Ginv per thread)
+        const int fast_sel = (sel_env && q >= 1 && q <= 80) ? 1 : ((sel_env && q >= 1 && q <= 128) ? 2 : ((sel_env && q >= 1 && q <= 192) ? 3 : 0));
         const size_t shm_reg = ((size_t)SB * SB + 2 * (size_t)std::max(q, 1) + 16 * (size_t)std::max(q, 1) + 16) * sizeof(double);
         static const int selw = getenv("MRBF_R4_SELW") ? atoi(getenv("MRBF_R4_SELW")) : 16;  // waves of the decision kernel (8 or 16; 8 measured 6 % slower at d = 64)
         if (fast_sel == 1) {
@@ -623,8 +668,21 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
             MRBF_HIP(ctx, hipFuncSetAttribute((const void *)select_block_reg_kernel<2, 8, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_reg));
             MRBF_HIP(ctx, hipFuncSetAttribute((const void *)select_block_reg_kernel<2, 16, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_reg));
         }
-        double *Rb, *Sb, *Lblk;
+        if (fast_sel == 3)
+            MRBF_HIP(ctx, hipFuncSetAttribute((const void *)select_block_reg_kernel<3, 12, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_reg));
+        double *Rb, *Sb, *Lblk, *Rfull = nullptr, *Anew = nullptr, *Kn = nullptr;
         int *cnt, *blkidx;
+        // right-looking walk (see gather_newcols_kernel): needs the on-demand kappa; MRBF_R4_EAGER=0 keeps the per-block dtrsm
+        // default: right-looking when the walk may accept a third or more of the candidates (then most of R is used and the GEMMs replace
+        // ~nacc / 128 launch chains per block: d = 128, 6000 of 6000 accepted: 104 -> 60 ms); left-looking (dtrsm per block) when it will
+        // stop early and R for the candidates never reached would be wasted work (d = 64, 2080 of 10^4: 15.8 against 18.3 ms)
+        const int eager_env = getenv("MRBF_R4_EAGER") ? atoi(getenv("MRBF_R4_EAGER")) : -1;
+        const bool eager = lazy && (eager_env >= 0 ? eager_env != 0 : (int64_t)maxacc * 3 >= mc);
+        if (eager) {
+            MRBF_TRY(get_buf(ctx, S_PHI, (size_t)maxacc * mc, &Rfull));      // R(:, j) for every candidate j, ld = maxacc
+            MRBF_TRY(get_buf(ctx, S_STAGE_C, (size_t)maxacc * SB, &Anew));   // the new sites' columns of R, compact
+            MRBF_TRY(get_buf(ctx, S_STAGE_D, (size_t)SB * mc, &Kn));         // kappa(new, ahead) - R(old, new)' R(old, ahead), ld = SB
+        }
         MRBF_TRY(get_buf(ctx, S_Q1, (size_t)maxacc * SB, &Rb));          // R = L_acc^-1 K[acc, block]
         MRBF_TRY(get_buf(ctx, S_RHS, (size_t)2 * SB * SB, &Sb));          // Schur complement of the block | in-block factor columns
         Lblk = Sb + (size_t)SB * SB;
@@ -635,20 +693,23 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
         int nacc = 0;
         for (int64_t i0 = 0; i0 < mc && (int64_t)n0 + nacc < max_points && nacc < maxacc; i0 += SB) {
             const int bsz = (int)std::min<int64_t>(SB, mc - i0);
+            const double mone = -1.0;
+            if (eager) Rb = Rfull + i0 * (int64_t)maxacc;  // this block's columns of R are up to date: every earlier block extended them
             if (lazy) {
                 if (bsz < SB) MRBF_HIP(ctx, hipMemsetAsync(Sb, 0, (size_t)SB * SB * sizeof(double), s));
-                const dim3 kgrid((unsigned)((bsz + 63) / 64), (unsigned)((nacc + bsz + 15) / 16));
+                const int nlist = eager ? 0 : nacc;  // (eager: only kappa(block, block) is needed here)
+                const dim3 kgrid((unsigned)((bsz + 63) / 64), (unsigned)((nlist + bsz + 15) / 16));
                 MRBF_DISPATCH_KID(kp.kid, hipLaunchKernelGGL((kappa_block_kernel<KID, 1>), kgrid, dim3(256), 0, s, st->Xc, d, st->LamT, st->P0c, F, (int)n0,
-                                                             q > 0 ? 1 : 0, st->acc, nacc, i0, bsz, kp, Rb, maxacc, Sb));
+                                                             q > 0 ? 1 : 0, st->acc, nlist, i0, bsz, kp, Rb, maxacc, Sb, 1));
             } else {
                 hipLaunchKernelGGL(block_copy_kernel, dim3(nb(SB * SB)), dim3(256), 0, s, st->K, mc, i0, bsz, Sb);
             }
             if (nacc > 0) {
                 if (!lazy)
                     hipLaunchKernelGGL(gather_kab_kernel, dim3(nb((int64_t)nacc * bsz)), dim3(256), 0, s, st->K, mc, st->acc, nacc, i0, bsz, Rb, maxacc);
-                MRBF_BLAS(ctx, rocblas_dtrsm(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, nacc, bsz,
-                                             &one, st->LK, maxacc, Rb, maxacc));
-                const double mone = -1.0;
+                if (!eager)
+                    MRBF_BLAS(ctx, rocblas_dtrsm(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, nacc,
+                                                 bsz, &one, st->LK, maxacc, Rb, maxacc));
                 MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, bsz, bsz, nacc, &mone, Rb, maxacc, Rb, maxacc,
                                              &one, Sb, SB));
             }
@@ -664,6 +725,9 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
             else if (fast_sel == 2)
                 hipLaunchKernelGGL((select_block_reg_kernel<2, 8, 16>), dim3(1), dim3(SEL_THREADS), shm_reg, s, Sb, bsz, i0, (int)n0, q, (int)max_points, maxacc,
                                    thr, st->Prow, st->Ginv, st->acc, cnt, Lblk, blkidx);
+            else if (fast_sel == 3)
+                hipLaunchKernelGGL((select_block_reg_kernel<3, 12, 16>), dim3(1), dim3(SEL_THREADS), shm_reg, s, Sb, bsz, i0, (int)n0, q, (int)max_points, maxacc,
+                                   thr, st->Prow, st->Ginv, st->acc, cnt, Lblk, blkidx);
             else
                 hipLaunchKernelGGL(select_block_kernel, dim3(1), dim3(SEL_THREADS), shm, s, Sb, bsz, i0, (int)n0, q, (int)max_points, maxacc, thr, st->Prow,
                                    st->Ginv, st->acc, cnt, Lblk, blkidx);
@@ -672,7 +736,29 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
             int *hc = ctx->hpin ? reinterpret_cast<int *>(ctx->hpin + HPIN_R4_COUNT) : hc_local;  // (pinned: the download does not cost a round trip of its own)
             MRBF_HIP(ctx, hipMemcpyAsync(hc, cnt, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
             MRBF_HIP(ctx, hipStreamSynchronize(s));  // the next block's shapes depend on the number accepted so far
+            const int nacc_old = nacc, nblk = hc[1];
             nacc = hc[0];
+            const int64_t i1 = i0 + bsz, ahead = mc - i1;
+            if (eager && nblk > 0 && ahead > 0 && (int64_t)n0 + nacc < max_points && nacc < maxacc) {
+                // rows nacc_old .. nacc - 1 of R for every candidate ahead
+                const dim3 kgrid((unsigned)((ahead + 63) / 64), (unsigned)((nblk + 15) / 16));
+                MRBF_DISPATCH_KID(kp.kid, hipLaunchKernelGGL((kappa_block_kernel<KID, 1>), kgrid, dim3(256), 0, s, st->Xc, d, st->LamT, st->P0c, F, (int)n0,
+                                                             q > 0 ? 1 : 0, st->acc + nacc_old, nblk, i1, (int)ahead, kp, Kn, SB, (double *)nullptr, 0));
+                if (nacc_old > 0) {
+                    hipLaunchKernelGGL(gather_newcols_kernel, dim3(nb((int64_t)nacc_old * nblk)), dim3(256), 0, s, Rfull, maxacc, nacc_old, i0, blkidx, nblk,
+                                       Anew, maxacc);
+                    MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, nblk, (int)ahead, nacc_old, &mone, Anew,
+                                                 maxacc, Rfull + i1 * (int64_t)maxacc, maxacc, &one, Kn, SB));
+                }
+                const size_t fw_shm = (size_t)SB * 64 * sizeof(double) + SB * sizeof(int);
+                static bool fw_attr = false;
+                if (!fw_attr) {
+                    MRBF_HIP(ctx, hipFuncSetAttribute((const void *)block_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fw_shm));
+                    fw_attr = true;
+                }
+                hipLaunchKernelGGL(block_forward_kernel, dim3((unsigned)((ahead + 63) / 64)), dim3(64), fw_shm, s, Kn, SB, Lblk, blkidx, nblk, ahead,
+                                   Rfull + i1 * (int64_t)maxacc + nacc_old, maxacc);
+            }
         }
         MRBF_HIP(ctx, hipGetLastError());
         std::vector<int> hacc((size_t)maxacc + 1);

@@ -249,6 +249,50 @@ def test_round4_device_selection_and_factor_reuse(name, deg, d, n, k):
     st.free()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,deg,d,n,mp", [("cubic", 1, 130, 150, 231), ("multiquadric", 1, 12, 700, 91), ("gaussian", 1, 40, 900, 500)])
+def test_round4_walk_variants_agree(name, deg, d, n, mp):
+    """Round 5 gave the walk three forms: kappa on demand + per-block triangular solve (left-looking), kappa on demand + R kept for every
+    candidate ahead (right-looking, no triangular solve against the accepted factor), and the mc x mc construction of rounds 3 / 4
+    (MRBF_R4_LAZY=0).  They compute the same quantities in different orders: the accepted lists must be identical, the fits from the
+    kept factors equal to rounding, and the list equal to the independent oracle's.  d = 130: q = 131, the decision kernel's
+    three-row register variant; every case crosses at least one block boundary."""
+    import os
+
+    rng = np.random.default_rng(300 + d)
+    x = np.full(d, 0.5)
+    sites = np.vstack([x, x + 0.3 * (rng.random((d + n, d)) - 0.5)])
+    start = _start_set(x, sites, d)
+    assert len(start) == d + 1
+    cands = [i for i in range(len(sites)) if i not in start]
+    cfg = _cfg(name, deg, mp=mp)
+    kidp, ap, bp = pkg.rbf_model._get_kernel_params(1.0, cfg)
+    S0, Cc = sites[start], sites[cands]
+    results = {}
+    for tag, env in (("left", {"MRBF_R4_EAGER": "0"}), ("right", {"MRBF_R4_EAGER": "1"}), ("full", {"MRBF_R4_LAZY": "0"})):
+        os.environ.update(env)
+        try:
+            accepted, st = sampling.rbf_round4_device(cfg, S0, Cc, 1.0, keep_state=True)
+            S = st.training_sites
+            Y = np.stack([(S ** 2).sum(axis=1), np.sin(S.sum(axis=1))], axis=1)
+            mod = sampling.fit_from_round4(st, Y)
+            results[tag] = (accepted, mod.weights.copy(), mod.info["rel_residual"])
+            mod.free()
+            st.free()
+        finally:
+            for kk in env:
+                os.environ.pop(kk, None)
+    acc_l, w_l, r_l = results["left"]
+    for tag in ("right", "full"):
+        acc, w, r = results[tag]
+        assert acc == acc_l, tag
+        assert np.abs(w - w_l).max() <= 1e-8 * np.abs(w_l).max(), (tag, np.abs(w - w_l).max() / np.abs(w_l).max())
+        assert r < 1e-9 and r_l < 1e-9
+    want = so.rbf_round4(S0, Cc, kidp, ap, bp, deg, max_points=mp)
+    assert acc_l == want
+    print("round 4 walk variants d=%d: %d of %d accepted, identical lists" % (d, len(acc_l), len(cands)))
+
+
 def _lib_path_round4():
     from morbit.jl_amd import _lib
     return _lib.PATH_ROUND4
