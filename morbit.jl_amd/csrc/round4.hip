@@ -751,11 +751,8 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
                                                  maxacc, Rfull + i1 * (int64_t)maxacc, maxacc, &one, Kn, SB));
                 }
                 const size_t fw_shm = (size_t)SB * 64 * sizeof(double) + SB * sizeof(int);
-                static bool fw_attr = false;
-                if (!fw_attr) {
-                    MRBF_HIP(ctx, hipFuncSetAttribute((const void *)block_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fw_shm));
-                    fw_attr = true;
-                }
+                // (per call: the attribute is per device, and one process may drive several)
+                MRBF_HIP(ctx, hipFuncSetAttribute((const void *)block_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fw_shm));
                 hipLaunchKernelGGL(block_forward_kernel, dim3((unsigned)((ahead + 63) / 64)), dim3(64), fw_shm, s, Kn, SB, Lblk, blkidx, nblk, ahead,
                                    Rfull + i1 * (int64_t)maxacc + nacc_old, maxacc);
             }
