@@ -126,6 +126,7 @@ struct Args {
     unsigned long long *jlog;   // diagnostic launches only: 8 words per job (meta, claim, 5 stage stamps, end), jlog[0] = count
     int jlog_cap;
     int pstream;                // panels the diagonal job takes in step from streamed producers (1 or 2)
+    int panel_dma;              // the panel jobs' triangular solve on the LDS-DMA operand ring (MRBF_MEGA_PANELDMA=0: the register-staged loop)
     int trace_dbg;              // diagnostic launches only: dbg word of the diagonal core (4 = time wave 0, 4 + 8 + 16 w = time wave w)
     unsigned long long *trace;  // diagnostic launches only: 8 time stamps (10 ns units) per chain job (P(c), T(c+1,c))
 };
@@ -496,7 +497,7 @@ __device__ __attribute__((noinline)) bool run_stream(const Args &a, Shared &sh, 
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int col = 4 * wave + u;
-                if (!HALF || lane < 32) glds16(Lr + 2 * lane + (int64_t)(16 * b + col) * lda, sl + col * LDS_LD);  // (64 rows: half a wave)
+                glds16(Lr + 2 * (HALF ? (lane & 31) : lane) + (int64_t)(16 * b + col) * lda, sl + col * LDS_LD);  // (64 rows: half a wave; the upper lanes repeat them into the slot's unused rows -- no LDS-DMA inside divergent control flow, see mega_gemm.hpp)
                 glds16(Lc + 2 * lane + (int64_t)(16 * b + col) * lda, sl + PAN + col * LDS_LD);
             }
         };
@@ -766,7 +767,13 @@ __device__ __attribute__((noinline)) bool run_panel(const Args &a, Shared &sh, c
     zero_acc(acc);
     // (the register-staged loop: X was written by this workgroup's plain stores a moment ago, and LDS-DMA loads of it came back
     //  wrong -- every other operand of gemm_acc is another workgroup's write-through data behind an acquire, or older; r04)
-    gemm_acc_v1<TM>(C, lda, Linv, NB, NB, acc, sh.u.gemm);  // every wave's loads of X are complete behind the loop's last barrier
+    // (rounds 4 / 5: the LDS-DMA ring gave wrong results here and only here -- not a stale read of the tile this workgroup had just
+    //  written, as first thought, but a half-wave LDS-DMA inside divergent control flow that the compiler, knowing K and ldb at this call
+    //  site, merged with the full-wave ones behind a non-uniform LDS base; fixed in mega_gemm.hpp, profiles/r05_ldsdma_hazard.txt)
+    if (__builtin_amdgcn_readfirstlane(a.panel_dma))
+        gemm_acc_v2<TM>(C, lda, Linv, NB, NB, acc, sh.u.gemm);
+    else
+        gemm_acc_v1<TM>(C, lda, Linv, NB, NB, acc, sh.u.gemm);  // every wave's loads of X are complete behind the loop's last barrier
     store_tile<TM, false, false, true>(C, lda, acc);
     wg_drain();
     if (a.fault && i == a.MT - 1 && c == 0 && roff == 0) return true;  // test hook: this (half) tile is never published
@@ -1339,6 +1346,10 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
             if (c < NT) job += 1 + (shalf_at(c, srows, edge) ? 2 : 1) * std::min(srows_at(c, srows, edge), MT - 1 - c);
         }
         a.nreserve = (e_head > 0 || e_tail_c0 < NT) ? (env_reserve >= 0 ? env_reserve : 12) : 0;
+    }
+    {
+        static const int env_pdma = getenv("MRBF_MEGA_PANELDMA") ? atoi(getenv("MRBF_MEGA_PANELDMA")) : 1;
+        a.panel_dma = env_pdma;
     }
     a.pstream = ctx->mega_pstream > 0 ? std::min(ctx->mega_pstream, srows) : (NTq <= 48 && srows >= 2 ? 2 : 1);
     a.spin_ticks = (unsigned long long)std::max(1, ctx->spin_ms) * 100000ull;  // wall_clock64 runs at 100 MHz

@@ -26,6 +26,14 @@ constexpr int NB = 128, BK = 16, LDS_LD = NB + 16;  // (2*LD) % 64 == 32: k and 
 #ifndef MRBF_GEMM_NSTG
 #define MRBF_GEMM_NSTG 4
 #endif
+// The workgroup barrier of the operand ring.  `__builtin_amdgcn_s_barrier()` alone is IntrNoMem for the compiler: a plain LDS load that
+// follows it in the source may be moved in front of it (it is ordered with the volatile asm waits, not with memory).  The asm form with
+// a memory clobber is a barrier for the compiler as well as for the waves (round 5, profiles/r05_ldsdma_hazard.txt).
+#ifndef MRBF_GEMM_RAW_BARRIER
+#define MRBF_RING_BARRIER() asm volatile("s_barrier" ::: "memory")
+#else
+#define MRBF_RING_BARRIER() __builtin_amdgcn_s_barrier()
+#endif
 constexpr int SK = 8, NSTG = MRBF_GEMM_NSTG;  // columns per stage, stages in the ring
 constexpr int STG = 2 * SK * LDS_LD;     // doubles per stage: A columns [k][LDS_LD], then B columns
 typedef __attribute__((address_space(3))) void lds_void;
@@ -54,9 +62,16 @@ __device__ __forceinline__ void gemm_acc_v2(const double *__restrict__ Ag, int64
     const int joff = (TM == 128) ? (wave & 1) * 64 : wave * 32;
     const int nst = __builtin_amdgcn_readfirstlane(K / SK);
     // wave w stages the columns 2w, 2w+1 of both operands of every stage: four LDS-DMA instructions per wave and stage
-    const double *ap = Ag + (int64_t)(2 * wave) * lda + 2 * lane;
+    // A 64-row column is half a wave's worth: lanes 32 .. 63 fetch rows 0 .. 63 a second time (they land in rows 64 .. 127 of the
+    // column's LDS slot, which nobody reads).  NOT `if (lane < 32)` around the instruction: with K and ldb known at compile time
+    // (the panel solve: K = ldb = 128) the compiler unrolled the prologue, folded the identical B-column DMAs of the two sides of that
+    // divergent branch into one instruction stream and ended up with ONE wave-wide DMA whose LDS base differed between the halves of the
+    // wave -- it put the base through v_readfirstlane into M0, so the upper lanes' rows 64 .. 127 of the B columns went to the lower
+    // lanes' address (round 5: profiles/r05_ldsdma_hazard.txt; what round 4 had put down to a stale read).  The LDS base of an LDS-DMA
+    // must be wave-uniform: keep every LDS-DMA outside divergent control flow.
+    const double *ap = Ag + (int64_t)(2 * wave) * lda + 2 * ((TM == 128) ? lane : (lane & 31));
     const double *bp = Bg + (int64_t)(2 * wave) * ldb + 2 * lane;
-    const bool a_on = (TM == 128) || lane < 32;  // a 64-row column is half a wave's worth
+    constexpr bool a_on = true;
     auto issue = [&](int st) {
         double *sA = smem + (st % NSTG) * STG + 2 * wave * LDS_LD;
         double *sB = sA + SK * LDS_LD;
@@ -88,7 +103,7 @@ __device__ __forceinline__ void gemm_acc_v2(const double *__restrict__ Ag, int64
     for (int st = 0; st < npro; ++st) issue(st);
     wait_stages(npro - 1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    MRBF_RING_BARRIER();
     double xa[4], xb[NJ], ya[4], yb[NJ];
     frag(0, 0, xa, xb);
     int st = 0;
@@ -112,7 +127,7 @@ __device__ __forceinline__ void gemm_acc_v2(const double *__restrict__ Ag, int64
         else
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of stage st are in
-        __builtin_amdgcn_s_barrier();
+        MRBF_RING_BARRIER();
         issue(st + NSTG);
         __builtin_amdgcn_sched_barrier(0);
         MRBF_GEMM_HALF(ya, yb, frag(st + 1, 0, xa, xb));
@@ -122,7 +137,7 @@ __device__ __forceinline__ void gemm_acc_v2(const double *__restrict__ Ag, int64
         MRBF_GEMM_HALF(xa, xb, frag(st, 1, ya, yb));
         wait_stages(nst - 2 - st);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        MRBF_RING_BARRIER();
         __builtin_amdgcn_sched_barrier(0);
         MRBF_GEMM_HALF(ya, yb, frag(st + 1, 0, xa, xb));
     }

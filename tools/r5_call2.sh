@@ -2,9 +2,9 @@
 set -o pipefail
 OUT=gpurun_out/r5b
 mkdir -p $OUT
-rm -f $OUT/paneldma8.txt
-for v in 1 8; do
-echo "== MRBF_MEGA_PANELDMA=$v" >> $OUT/paneldma8.txt
-MRBF_MEGA_PANELDMA=$v timeout -k 10 300 python3 tools/mega_check.py 1024,2048,4096 3 2 >> $OUT/paneldma8.txt 2>&1; echo "rc=$?"
+rm -f $OUT/paneldma_fix.txt
+for v in 0 1 2; do
+echo "== MRBF_MEGA_PANELDMA=$v (ring barrier = asm volatile s_barrier with memory clobber)" >> $OUT/paneldma_fix.txt
+MRBF_MEGA_PANELDMA=$v timeout -k 10 300 python3 tools/mega_check.py 1024,2048,4096,8192 3 3 >> $OUT/paneldma_fix.txt 2>&1; echo "rc=$?"
 done
-cat $OUT/paneldma8.txt
+cat $OUT/paneldma_fix.txt
