@@ -79,3 +79,28 @@ def test_product_package_never_imports_the_oracle():
                 src = open(os.path.join(base, f), errors="ignore").read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f
                 assert "librbf_oracle" not in src, f
+
+
+def test_no_lds_dma_inside_lane_dependent_control_flow():
+    """Source rule of round 5 (csrc/mega_gemm.hpp, profiles/r05_ldsdma_hazard.txt): the LDS base of an LDS-DMA travels in M0 and must be
+    wave-uniform; a half-wave LDS-DMA under `if (lane < 32)` was merged by the compiler with the full-wave ones behind a non-uniform
+    base (v_readfirstlane into M0) and put rows 64..127 of the B operand at the wrong LDS address.  No line of the product issues an
+    LDS-DMA under a condition on the lane index (wave-uniform conditions are fine)."""
+    import glob
+    import re
+
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "morbit.jl_amd", "csrc")
+    dma = re.compile(r"\bglds16\s*(<[^>]*>)?\s*\(|__builtin_amdgcn_global_load_lds\s*\(")
+    offenders = []
+    for path in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.hpp"))):
+        lines = open(path).read().split("\n")
+        for i, line in enumerate(lines):
+            code = line.split("//")[0]
+            if not dma.search(code) or "__device__" in code:
+                continue
+            # the statement itself, or the `if (...)` line right above it, must not test the lane index
+            ctx = code + " " + (lines[i - 1].split("//")[0] if i > 0 and lines[i - 1].strip().startswith("if") else "")
+            m = re.search(r"if\s*\(([^)]*)\)", ctx)
+            if m and re.search(r"\blane\b|\btid\b|threadIdx", m.group(1)):
+                offenders.append("%s:%d: %s" % (os.path.basename(path), i + 1, line.strip()))
+    assert not offenders, "LDS-DMA under a lane-dependent condition:\n" + "\n".join(offenders)
