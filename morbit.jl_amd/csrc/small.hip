@@ -189,6 +189,19 @@ __device__ __noinline__ int diag_block(double *__restrict__ A, int ld, double *_
     return diagcore::diag_v4_core<false, false, false>(A, (int64_t)ld, Linv, sh, acc, nullptr, nullptr, 0);
 }
 
+// The same block by the persistent factorisation's core (chol_diag_core.hpp, diag_v6_core: one barrier per 16-column panel, 26 us against
+// the 40 of the v4 core above).  It streams its leaf inverses through `itg` (8 x 256 doubles of global scratch) and counts panels in `prog`.
+union DiagShared {
+    diagcore::DiagV4Shared v4;
+    diagcore::DiagV6Shared v6;
+};
+__device__ __noinline__ int diag_block6(double *__restrict__ A, int ld, double *__restrict__ Linv, diagcore::DiagV6Shared &sh, double *itg,
+                                        unsigned *prog) {
+    diagcore::v4d acc[diagcore::NSLOT6];
+    diagcore::diag_v6_load(A, (int64_t)ld, acc);
+    return diagcore::diag_v6_core(A, (int64_t)ld, Linv, sh, acc, itg, prog);
+}
+
 // A 128 x 128 diagonal block of which only the leading `real` x `real` part is not the identity (the last block of a padded matrix:
 // n = 2d + 1 = 257 leaves 16 real rows in its third block; the tail basis' Gram matrix of a problem with d <= 32): factor and invert
 // that part in LDS with one wave -- a few microseconds instead of the 40 of the register-resident 128 x 128 core.  Same contract as
@@ -327,10 +340,16 @@ __device__ __noinline__ int block64(double *__restrict__ A, int ld, int real, do
     __syncthreads();
     return 0;
 }
-__device__ __forceinline__ int diag_block_auto(double *__restrict__ A, int ld, int real, double *__restrict__ Linv, diagcore::DiagV4Shared &sh) {
+__device__ __forceinline__ int diag_block_auto(double *__restrict__ A, int ld, int real, double *__restrict__ Linv, diagcore::DiagV4Shared &sh,
+                                               double *itg6 = nullptr) {
     // (small_block's one-wave loops over LDS: 2 us at 8 real rows, 13 at 16, 105 at 32; block64: ~0.4 us per column + 10)
     if (real > 0 && real <= 12) return small_block(A, ld, real, Linv, sh.LT);
     if (real > 0 && real <= 64) return block64(A, ld, real, Linv, sh.LT);
+    if (itg6) {  // (the scratch is only handed in when the problem asks for the v6 core)
+        const int bad = diag_block6(A, ld, Linv, reinterpret_cast<DiagShared *>(&sh)->v6, itg6, reinterpret_cast<unsigned *>(itg6 + 8 * 256));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (its write-through stores of L and inv(L) have left the CU before the barrier that follows)
+        return bad;
+    }
     return diag_block(A, ld, Linv, sh);
 }
 
@@ -407,13 +426,13 @@ __device__ __forceinline__ bool cl_barrier(Cluster &cl) {
 // the panel and trailing products.  Linv: np x 128, block c at Linv + c * 128 * 128 holds inv(L_cc).  Returns 0, the 1-based index
 // of a bad pivot, or -1 when the cluster failed.
 __device__ int wg_potrf(double *__restrict__ A, int ld, int np, int rows16, double *__restrict__ Linv, double *__restrict__ Pt,
-                        diagcore::DiagV4Shared &sh, Cluster &cl) {
+                        diagcore::DiagV4Shared &sh, Cluster &cl, int diag6 = 0) {
     const int nb = np / 128;
     for (int c = 0; c < nb; ++c) {
         double *Acc = A + (int64_t)c * 128 * (ld + 1);
         double *Lc = Linv + (int64_t)c * 128 * 128;
         if (cl.member == 0) {
-            const int bad = diag_block_auto(Acc, ld, rows16 - 128 * c, Lc, sh);
+            const int bad = diag_block_auto(Acc, ld, rows16 - 128 * c, Lc, sh, diag6 ? Pt : nullptr);  // (Pt is free until the panel product)
             __syncthreads();
             if (threadIdx.x == 0 && bad) cl_store(cl.words + 1, 128 * c + bad);  // positive: a bad pivot, every member leaves
         }
@@ -481,7 +500,8 @@ __global__ __launch_bounds__(256) void small_mean_kernel(const Prob *__restrict_
 }
 
 __global__ __launch_bounds__(256, 1) void small_fit_kernel(Prob one, const Prob *__restrict__ many, int count, int nc) {
-    __shared__ __attribute__((aligned(16))) diagcore::DiagV4Shared sh;
+    __shared__ __attribute__((aligned(16))) DiagShared shu;
+    diagcore::DiagV4Shared &sh = shu.v4;
     __shared__ double red[4];
     __shared__ double s_mean[128];
     __shared__ int s_ok;
@@ -731,7 +751,7 @@ __global__ __launch_bounds__(256, 1) void small_fit_kernel(Prob one, const Prob 
     MRBF_STAMP();  // 6: rhs
     // ---- factorisation K = L L'
     {
-        const int bad = wg_potrf(Phi, np, np, n16, Linv, Pt, sh, cl);
+        const int bad = wg_potrf(Phi, np, np, n16, Linv, Pt, sh, cl, P.diag6);
         if (bad) {
             if (tid == 0 && (member == 0 || bad < 0)) P.flags[bad > 0 ? 0 : 3] = bad > 0 ? bad : 1;
             return;

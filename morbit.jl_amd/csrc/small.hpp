@@ -22,6 +22,7 @@ struct Prob {
                                              // queries beside the fit instead of after it
     unsigned long long spin_ticks;           // bound of a cluster barrier's spin (wall_clock64 ticks)
     int fault;                               // test hook (MRBF_OPT_DEBUG_FAULT bit 2 (value 4)): member 1 leaves before the third barrier
+    int diag6;                               // full 128 x 128 diagonal blocks by the persistent factorisation's one-barrier-per-panel core (diag_v6_core)
 };
 
 constexpr int CL_WORDS = 24;   // arrivals, failure word, XCD of up to 16 members

@@ -909,6 +909,10 @@ void fill_small_prob(const mrbf_ctx *ctx, const mrbf_model *M, const double *Y, 
     P->cl = cl;
     P->spin_ticks = (unsigned long long)std::max(1, ctx->spin_ms) * 100000ull;  // wall_clock64: 100 MHz
     P->fault = (ctx->debug_fault & 4) ? 1 : 0;
+    {
+        static const int d6 = getenv("MRBF_SMALL_DIAG6") ? atoi(getenv("MRBF_SMALL_DIAG6")) : 1;  // (round 5: n = 512 0.670 -> 0.628 ms, n = 100 0.171 -> 0.160 ms; 0 selects the v4 core)
+        P->diag6 = d6;
+    }
     P->mean_given = 0;
 }
 // what the flags of a small-problem fit mean for mrbf_fit_info (shared with the batched entry point): returns 1 when the problem
