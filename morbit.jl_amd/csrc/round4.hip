@@ -480,6 +480,162 @@ __global__ __launch_bounds__(64) void block_forward_kernel(const double *__restr
     }
 }
 
+// ---- the right-looking walk's own kernels (round 5, second half): rocBLAS ran the fat product at ~6 TFLOP/s (m = 128: one workgroup per 64
+// columns, no split over k) and the substitution took one thread per candidate (267 us per block).
+// P[s](a, j) = sum over the k slice s of  A(k, a) B(k, j):  A = Anew (K x nblk, the new sites' columns of R), B = R(old rows, candidates
+// ahead) (K x ncols); both operands are contiguous along k, so a lane fetches 32 contiguous bytes per 16-deep k group (k = 16 g + 4 (l >> 4)
+// + s for MFMA step s: the same permutation on both sides).  Workgroup = 128 rows a x 64 columns j (wave w: 32 rows), grid (ncols / 64,
+// ksplit); fragments double buffered in registers, no LDS.  lda, ldb multiples of 4 (32-byte aligned fragments).
+__global__ __launch_bounds__(256, 2) void r4_tn_gemm_kernel(const double *__restrict__ A, int lda, const double *__restrict__ B, int64_t ldb, int K,
+                                                            int64_t ncols, int kchunk, double *__restrict__ P, int64_t pstride) {
+    typedef double v4d __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    const int64_t j0 = (int64_t)blockIdx.x * 64;
+    const int k0 = blockIdx.y * kchunk, k1 = min(K, k0 + kchunk);
+    const double *ap[2], *bp[4];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) ap[it] = A + (int64_t)(32 * wave + 16 * it + l15) * lda + 4 * l4;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+        int64_t j = j0 + 16 * jt + l15;
+        j = j < ncols ? j : ncols - 1;  // (a ragged last tile re-reads the last column; its results are not stored)
+        bp[jt] = B + j * ldb + 4 * l4;
+    }
+    v4d acc[4][2];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int it = 0; it < 2; ++it) acc[jt][it] = (v4d){0.0, 0.0, 0.0, 0.0};
+    auto load = [&](int k, v4d (&a)[2], v4d (&b)[4]) {  // one 16-deep group at k (k + 15 < K checked by the caller, or the masked tail below)
+#pragma unroll
+        for (int it = 0; it < 2; ++it) a[it] = *(const v4d *)(ap[it] + k);
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) b[jt] = *(const v4d *)(bp[jt] + k);
+    };
+    auto mma = [&](const v4d (&a)[2], const v4d (&b)[4]) {
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                for (int it = 0; it < 2; ++it) acc[jt][it] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[jt][s4], a[it][s4], acc[jt][it], 0, 0, 0);
+    };
+    v4d a0[2], b0[4], a1[2], b1[4];
+    int k = k0;
+    const int kfull = k0 + ((k1 - k0) & ~15);
+    if (k < kfull) load(k, a0, b0);
+    for (; k + 32 <= kfull; k += 32) {
+        load(k + 16, a1, b1);
+        mma(a0, b0);
+        if (k + 32 < kfull) load(k + 32, a0, b0);
+        mma(a1, b1);
+    }
+    if (k < kfull) {
+        mma(a0, b0);
+        k += 16;
+    }
+    if (k < k1) {  // the ragged end of the k range: element-wise guards (rows >= K of R are not written yet)
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a0[it][e] = (k + 4 * l4 + e < k1) ? ap[it][k + e] : 0.0;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) b0[jt][e] = (k + 4 * l4 + e < k1) ? bp[jt][k + e] : 0.0;
+        mma(a0, b0);
+    }
+    // D(row = j within the tile = (l >> 4) + 4 r, col = a = l & 15): consecutive lanes write consecutive a of one column j
+    double *Ps = P + (int64_t)blockIdx.y * pstride;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t j = j0 + 16 * jt + l4 + 4 * r;
+            if (j < ncols) {
+#pragma unroll
+                for (int it = 0; it < 2; ++it) Ps[(32 * wave + 16 * it + l15) + j * SB] = acc[jt][it][r];
+            }
+        }
+}
+// X = L_bb^-1 (Kn - sum_s P[s]) on the matrix cores (a four-threads-per-candidate substitution out of LDS was latency-bound: 370 us per
+// block at two waves per CU; this form takes ~25 us).  One wave per 32 candidates.  L_bb is cut into 8 x 8 blocks of 16: X_s = inv(L_ss) (rhs_s - sum_{t < s} L_st X_t).  A block X_t in the f64 MFMA's
+// C/D layout (row = (l >> 4) + 4 r, column = l & 15) IS the B operand of the k slice r of the next product, so the blocks never leave
+// the registers; the A operands (-L_st, inv(L_ss)) come from LDS; the 16 x 16 inverses of the diagonal blocks are formed once per
+// workgroup by forward substitution on the identity (rocBLAS's trsm inverts 128 x 128 diagonal blocks the same way).  Rows >= nblk of the
+// padded system are identity rows with zero right-hand sides.
+__global__ __launch_bounds__(64) void block_forward_mfma_kernel(const double *__restrict__ Kn, const double *__restrict__ P, int ksplit, int64_t pstride,
+                                                           const double *__restrict__ Lblk, const int *__restrict__ blkidx, int nblk, int64_t ncols,
+                                                           double *__restrict__ Rout, int64_t ldr) {
+    typedef double v4d __attribute__((ext_vector_type(4)));
+    extern __shared__ double fwm_smem[];  // Lt[SB (SB + 1) / 2] | Iv[8][16][17] | bi[SB]
+    double *Lt = fwm_smem, *Iv = Lt + SB * (SB + 1) / 2;
+    int *bi = reinterpret_cast<int *>(Iv + 8 * 16 * 17);
+    const int lane = threadIdx.x, l15 = lane & 15, l4 = lane >> 4;
+    const int64_t jbase = (int64_t)blockIdx.x * 32;
+    for (int a = lane; a < SB; a += 64) bi[a] = a < nblk ? blkidx[a] : 0;
+    __syncthreads();
+    for (int e = lane; e < SB * SB; e += 64) {  // L_bb(a, a') = Lblk[blkidx[a] + a' SB] (a' <= a < nblk), identity beyond nblk
+        const int a = e >> 7, a2 = e & 127;
+        if (a2 <= a) Lt[a * (a + 1) / 2 + a2] = (a < nblk) ? Lblk[bi[a] + a2 * SB] : (a == a2 ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    // inverses of the eight diagonal 16 x 16 blocks: thread -> (block, column), two columns per thread
+    for (int u = 0; u < 2; ++u) {
+        const int blk = (lane + 64 * u) >> 4, col = (lane + 64 * u) & 15;
+        double x[16];
+#pragma unroll
+        for (int a = 0; a < 16; ++a) {
+            const int ga = 16 * blk + a;
+            const double *Lrow = Lt + ga * (ga + 1) / 2 + 16 * blk;
+            double acc = (a == col) ? 1.0 : 0.0;
+#pragma unroll
+            for (int a2 = 0; a2 < a; ++a2) acc = fma(-Lrow[a2], x[a2], acc);
+            x[a] = acc / Lrow[a];
+        }
+#pragma unroll
+        for (int a = 0; a < 16; ++a) Iv[(blk * 16 + a) * 17 + col] = x[a];  // inv(L_ss)(a, col)
+    }
+    __syncthreads();
+    for (int ct = 0; ct < 2; ++ct) {
+        const int64_t j = jbase + 16 * ct + l15;
+        const bool jin = j < ncols;
+        v4d X[8];
+#pragma unroll
+        for (int sb = 0; sb < 8; ++sb) {
+            v4d D;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int a = 16 * sb + l4 + 4 * r;
+                double v = 0.0;
+                if (jin && a < nblk) {
+                    v = Kn[a + j * SB];
+                    for (int s2 = 0; s2 < ksplit; ++s2) v -= P[(int64_t)s2 * pstride + a + j * SB];
+                }
+                D[r] = v;
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                if (t < sb) {
+                    const int ga = 16 * sb + l15;
+                    const double *Lrow = Lt + ga * (ga + 1) / 2 + 16 * t + l4;
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) D = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lrow[4 * r4], X[t][r4], D, 0, 0, 0);
+                }
+            }
+            v4d Xs = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) Xs = __builtin_amdgcn_mfma_f64_16x16x4f64(Iv[(sb * 16 + l15) * 17 + 4 * r4 + l4], D[r4], Xs, 0, 0, 0);
+            X[sb] = Xs;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int a = 16 * sb + l4 + 4 * r;
+                if (jin && a < nblk) Rout[a + j * ldr] = Xs[r];
+            }
+        }
+    }
+}
+
 // dense j x j copy of the accepted factor
 __global__ void copy_factor_kernel(const double *__restrict__ L, int ldl, int j, double *__restrict__ out) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -678,10 +834,15 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
         // stop early and R for the candidates never reached would be wasted work (d = 64, 2080 of 10^4: 15.8 against 18.3 ms)
         const int eager_env = getenv("MRBF_R4_EAGER") ? atoi(getenv("MRBF_R4_EAGER")) : -1;
         const bool eager = lazy && (eager_env >= 0 ? eager_env != 0 : (int64_t)maxacc * 3 >= mc);
+        const int ldr = eager ? (int)round_up(maxacc, 4) : maxacc;  // leading dimension of R (32-byte aligned columns for the right-looking kernels)
+        const int custom = eager && (getenv("MRBF_R4_CUSTOM") ? atoi(getenv("MRBF_R4_CUSTOM")) : 1);  // 0: rocBLAS dgemm + one thread per candidate
+        constexpr int KSPLIT_MAX = 8;
+        double *Ppart = nullptr;
         if (eager) {
-            MRBF_TRY(get_buf(ctx, S_PHI, (size_t)maxacc * mc, &Rfull));      // R(:, j) for every candidate j, ld = maxacc
-            MRBF_TRY(get_buf(ctx, S_STAGE_C, (size_t)maxacc * SB, &Anew));   // the new sites' columns of R, compact
-            MRBF_TRY(get_buf(ctx, S_STAGE_D, (size_t)SB * mc, &Kn));         // kappa(new, ahead) - R(old, new)' R(old, ahead), ld = SB
+            MRBF_TRY(get_buf(ctx, S_PHI, (size_t)ldr * mc, &Rfull));         // R(:, j) for every candidate j
+            MRBF_TRY(get_buf(ctx, S_STAGE_C, (size_t)ldr * SB, &Anew));      // the new sites' columns of R, compact
+            MRBF_TRY(get_buf(ctx, S_STAGE_D, (size_t)SB * mc, &Kn));         // kappa(new, ahead), ld = SB
+            if (custom) MRBF_TRY(get_buf(ctx, S_STAGE_A, (size_t)KSPLIT_MAX * SB * mc, &Ppart));  // the k slices of R(old, new)' R(old, ahead)
         }
         MRBF_TRY(get_buf(ctx, S_Q1, (size_t)maxacc * SB, &Rb));          // R = L_acc^-1 K[acc, block]
         MRBF_TRY(get_buf(ctx, S_RHS, (size_t)2 * SB * SB, &Sb));          // Schur complement of the block | in-block factor columns
@@ -694,7 +855,7 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
         for (int64_t i0 = 0; i0 < mc && (int64_t)n0 + nacc < max_points && nacc < maxacc; i0 += SB) {
             const int bsz = (int)std::min<int64_t>(SB, mc - i0);
             const double mone = -1.0;
-            if (eager) Rb = Rfull + i0 * (int64_t)maxacc;  // this block's columns of R are up to date: every earlier block extended them
+            if (eager) Rb = Rfull + i0 * (int64_t)ldr;  // this block's columns of R are up to date: every earlier block extended them
             if (lazy) {
                 if (bsz < SB) MRBF_HIP(ctx, hipMemsetAsync(Sb, 0, (size_t)SB * SB * sizeof(double), s));
                 const int nlist = eager ? 0 : nacc;  // (eager: only kappa(block, block) is needed here)
@@ -709,8 +870,8 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
                     hipLaunchKernelGGL(gather_kab_kernel, dim3(nb((int64_t)nacc * bsz)), dim3(256), 0, s, st->K, mc, st->acc, nacc, i0, bsz, Rb, maxacc);
                 if (!eager)
                     MRBF_BLAS(ctx, rocblas_dtrsm(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, nacc,
-                                                 bsz, &one, st->LK, maxacc, Rb, maxacc));
-                MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, bsz, bsz, nacc, &mone, Rb, maxacc, Rb, maxacc,
+                                                 bsz, &one, st->LK, maxacc, Rb, ldr));
+                MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, bsz, bsz, nacc, &mone, Rb, ldr, Rb, ldr,
                                              &one, Sb, SB));
             }
             if (fast_sel == 1 && selw == 8)
@@ -731,7 +892,7 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
             else
                 hipLaunchKernelGGL(select_block_kernel, dim3(1), dim3(SEL_THREADS), shm, s, Sb, bsz, i0, (int)n0, q, (int)max_points, maxacc, thr, st->Prow,
                                    st->Ginv, st->acc, cnt, Lblk, blkidx);
-            hipLaunchKernelGGL(append_rows_kernel, dim3(nb((int64_t)SB * (nacc + SB))), dim3(256), 0, s, Rb, maxacc, nacc, Lblk, blkidx, cnt, st->LK, maxacc);
+            hipLaunchKernelGGL(append_rows_kernel, dim3(nb((int64_t)SB * (nacc + SB))), dim3(256), 0, s, Rb, ldr, nacc, Lblk, blkidx, cnt, st->LK, maxacc);
             int hc_local[2] = {0, 0};
             int *hc = ctx->hpin ? reinterpret_cast<int *>(ctx->hpin + HPIN_R4_COUNT) : hc_local;  // (pinned: the download does not cost a round trip of its own)
             MRBF_HIP(ctx, hipMemcpyAsync(hc, cnt, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -744,17 +905,36 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
                 const dim3 kgrid((unsigned)((ahead + 63) / 64), (unsigned)((nblk + 15) / 16));
                 MRBF_DISPATCH_KID(kp.kid, hipLaunchKernelGGL((kappa_block_kernel<KID, 1>), kgrid, dim3(256), 0, s, st->Xc, d, st->LamT, st->P0c, F, (int)n0,
                                                              q > 0 ? 1 : 0, st->acc + nacc_old, nblk, i1, (int)ahead, kp, Kn, SB, (double *)nullptr, 0));
+                int ksplit = 0;
+                int64_t pstride = 0;
                 if (nacc_old > 0) {
-                    hipLaunchKernelGGL(gather_newcols_kernel, dim3(nb((int64_t)nacc_old * nblk)), dim3(256), 0, s, Rfull, maxacc, nacc_old, i0, blkidx, nblk,
-                                       Anew, maxacc);
-                    MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, nblk, (int)ahead, nacc_old, &mone, Anew,
-                                                 maxacc, Rfull + i1 * (int64_t)maxacc, maxacc, &one, Kn, SB));
+                    hipLaunchKernelGGL(gather_newcols_kernel, dim3(nb((int64_t)nacc_old * nblk)), dim3(256), 0, s, Rfull, ldr, nacc_old, i0, blkidx, nblk,
+                                       Anew, ldr);
+                    if (custom) {
+                        // enough (column tile, k slice) workgroups to fill the device twice over, slices of whole 16-deep groups
+                        const int ntile = (int)((ahead + 63) / 64);
+                        ksplit = std::max(1, std::min({KSPLIT_MAX, (512 + ntile - 1) / ntile, (nacc_old + 63) / 64}));
+                        const int kchunk = (int)round_up((nacc_old + ksplit - 1) / ksplit, 16);
+                        ksplit = (nacc_old + kchunk - 1) / kchunk;
+                        pstride = (int64_t)SB * ahead;
+                        hipLaunchKernelGGL(r4_tn_gemm_kernel, dim3((unsigned)ntile, (unsigned)ksplit), dim3(256), 0, s, Anew, ldr,
+                                           Rfull + i1 * (int64_t)ldr, (int64_t)ldr, nacc_old, ahead, kchunk, Ppart, pstride);
+                    } else {
+                        MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, nblk, (int)ahead, nacc_old, &mone, Anew,
+                                                     ldr, Rfull + i1 * (int64_t)ldr, ldr, &one, Kn, SB));
+                    }
                 }
                 const size_t fw_shm = (size_t)SB * 64 * sizeof(double) + SB * sizeof(int);
                 // (per call: the attribute is per device, and one process may drive several)
                 MRBF_HIP(ctx, hipFuncSetAttribute((const void *)block_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fw_shm));
+                if (custom) {
+                    const size_t fwm_shm = ((size_t)SB * (SB + 1) / 2 + (size_t)8 * 16 * 17) * sizeof(double) + SB * sizeof(int);
+                    MRBF_HIP(ctx, hipFuncSetAttribute((const void *)block_forward_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwm_shm));
+                    hipLaunchKernelGGL(block_forward_mfma_kernel, dim3((unsigned)((ahead + 31) / 32)), dim3(64), fwm_shm, s, Kn, Ppart, ksplit, pstride, Lblk,
+                                       blkidx, nblk, ahead, Rfull + i1 * (int64_t)ldr + nacc_old, (int64_t)ldr);
+                } else
                 hipLaunchKernelGGL(block_forward_kernel, dim3((unsigned)((ahead + 63) / 64)), dim3(64), fw_shm, s, Kn, SB, Lblk, blkidx, nblk, ahead,
-                                   Rfull + i1 * (int64_t)maxacc + nacc_old, maxacc);
+                                   Rfull + i1 * (int64_t)ldr + nacc_old, ldr);
             }
         }
         MRBF_HIP(ctx, hipGetLastError());
