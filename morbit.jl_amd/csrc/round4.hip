@@ -100,114 +100,108 @@ __global__ void block_copy_kernel(const double *__restrict__ K, int64_t mc, int6
 // with lam = LamT[:, .] (n0), p = P0c[:, .] = phi(X0, .), f = F[:, .] = Phi00 lam(.) -- the symmetrised form kappa_kernel wrote.
 // rows rr < nacc: accepted site acc[rr] -> Kab[rr + j ld]; rows nacc + r: candidate i0 + r -> S[r + j SB].  64 x 64 tiles, 4 x 4 per thread
 // (the shape of cross_gram_kernel: difference-form distances, then the four n0-term sums).
-template <int KID, int RT>  // tile = 16 RT rows x 64 columns, RT x 4 entries per thread (RT = 1: up to 276 workgroups per block)
+// Wide k chunks (64 coordinates, 32 tail terms per round, every load of a round in flight at once): with 16-wide rounds the kernel was a
+// chain of 9 (d = 64) to 17 (d = 128) load -> barrier -> sum round trips, 67 to 85 us whatever the size of the grid.  The sums run over k in
+// the same order as before.
+template <int KID, int RT>  // tile = 16 rows x 64 columns, 4 entries per thread (up to 276 workgroups per block)
 __global__ __launch_bounds__(256) void kappa_block_kernel(const double *__restrict__ Xc, int d, const double *__restrict__ LamT,
                                                           const double *__restrict__ P0c, const double *__restrict__ F, int n0, int have_tail,
                                                           const int *__restrict__ acc, int nacc, int64_t i0, int b, KP kp,
                                                           double *__restrict__ Kab, int ld, double *__restrict__ S, int blockrows) {
-    constexpr int TR = 16 * RT;
-    __shared__ double Ar[TR][17], Ac[64][17];                    // distance phase: coordinates of the tile's rows / columns
-    __shared__ double Lr[TR][17], Pr[TR][17], Fr[TR][17], Lc[64][17], Pc[64][17], Fc[64][17];
-    __shared__ int64_t rid[TR];
+    static_assert(RT == 1, "one row of entries per thread");
+    constexpr int TR = 16, NR = TR + 64, KD = 64, KT = 32;
+    __shared__ double sm[3 * NR * (KT + 1)];  // distance rounds: A[NR][KD + 1]; tail rounds: L | P | F, each [NR][KT + 1]
+    static_assert(NR * (KD + 1) <= 3 * NR * (KT + 1), "the distance tile fits the tail tiles' area");
+    __shared__ int64_t rid[NR];  // global site of a tile row (0 .. TR-1) / column (TR ..), -1 outside
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const int R0 = blockIdx.y * TR, C0 = blockIdx.x * 64, nrows = nacc + (blockrows ? b : 0);  // (blockrows = 0: the listed rows only, any number of columns)
     if (tid < TR) {
         const int rr = R0 + tid;
         rid[tid] = rr < nacc ? (int64_t)acc[rr] : (rr < nrows ? i0 + (rr - nacc) : -1);
+    } else if (tid < NR) {
+        const int c = C0 + tid - TR;
+        rid[tid] = c < b ? i0 + c : -1;
     }
     __syncthreads();
-    double dist[RT][4] = {}, e1[RT][4] = {}, e2[RT][4] = {}, q1[RT][4] = {}, q2[RT][4] = {};
-    for (int k0 = 0; k0 < d; k0 += 16) {
+    double dist[4] = {}, e1[4] = {}, e2[4] = {}, q1[4] = {}, q2[4] = {};
+    for (int k0 = 0; k0 < d; k0 += KD) {
+        double(*A)[KD + 1] = reinterpret_cast<double(*)[KD + 1]>(sm);
+        double t[NR * KD / 256];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int r = ty + 16 * u, c = tx;
-            const bool kin = (k0 + c) < d;
-            if (u < RT) {
-                const int64_t gr = rid[r];
-                Ar[r][c] = (gr >= 0 && kin) ? Xc[gr * d + k0 + c] : 0.0;
-            }
-            Ac[r][c] = (C0 + r < b && kin) ? Xc[(i0 + C0 + r) * d + k0 + c] : 0.0;
+        for (int it = 0; it < NR * KD / 256; ++it) {
+            const int e = tid + 256 * it, r = e / KD, c = e % KD;
+            const int64_t gr = rid[r];
+            t[it] = (gr >= 0 && k0 + c < d) ? Xc[gr * d + k0 + c] : 0.0;
+        }
+#pragma unroll
+        for (int it = 0; it < NR * KD / 256; ++it) {
+            const int e = tid + 256 * it;
+            A[e / KD][e % KD] = t[it];
         }
         __syncthreads();
+        const int kn = min(KD, d - k0);
+#pragma unroll 8
+        for (int kk = 0; kk < kn; ++kk) {
+            const double av = A[ty][kk];
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
-            double av[RT], bv[4];
-#pragma unroll
-            for (int u = 0; u < RT; ++u) av[u] = Ar[ty + 16 * u][kk];
-#pragma unroll
-            for (int v = 0; v < 4; ++v) bv[v] = Ac[tx + 16 * v][kk];
-#pragma unroll
-            for (int u = 0; u < RT; ++u)
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const double df = av[u] - bv[v];
-                    dist[u][v] = fma(df, df, dist[u][v]);
-                }
+            for (int v = 0; v < 4; ++v) {
+                const double df = av - A[TR + tx + 16 * v][kk];
+                dist[v] = fma(df, df, dist[v]);
+            }
         }
         __syncthreads();
     }
     if (have_tail) {
-        for (int k0 = 0; k0 < n0; k0 += 16) {
+        double(*Ls)[KT + 1] = reinterpret_cast<double(*)[KT + 1]>(sm);
+        double(*Ps)[KT + 1] = Ls + NR;
+        double(*Fs)[KT + 1] = Ps + NR;
+        for (int k0 = 0; k0 < n0; k0 += KT) {
+            double tl[NR * KT / 256], tp[NR * KT / 256], tf[NR * KT / 256];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int r = ty + 16 * u, c = tx;
-                const bool kin = (k0 + c) < n0;
-                if (u < RT) {
-                    const int64_t gr = rid[r];
-                    const bool rin = gr >= 0 && kin;
-                    const int64_t ro = gr * n0 + k0 + c;
-                    Lr[r][c] = rin ? LamT[ro] : 0.0;
-                    Pr[r][c] = rin ? P0c[ro] : 0.0;
-                    Fr[r][c] = rin ? F[ro] : 0.0;
-                }
-                const bool cin = C0 + r < b && kin;
-                const int64_t co = (i0 + C0 + r) * n0 + k0 + c;
-                Lc[r][c] = cin ? LamT[co] : 0.0;
-                Pc[r][c] = cin ? P0c[co] : 0.0;
-                Fc[r][c] = cin ? F[co] : 0.0;
+            for (int it = 0; it < NR * KT / 256; ++it) {
+                const int e = tid + 256 * it, r = e / KT, c = e % KT;
+                const int64_t gr = rid[r];
+                const bool in = gr >= 0 && k0 + c < n0;
+                const int64_t o = gr * n0 + k0 + c;
+                tl[it] = in ? LamT[o] : 0.0;
+                tp[it] = in ? P0c[o] : 0.0;
+                tf[it] = in ? F[o] : 0.0;
+            }
+#pragma unroll
+            for (int it = 0; it < NR * KT / 256; ++it) {
+                const int e = tid + 256 * it, r = e / KT, c = e % KT;
+                Ls[r][c] = tl[it];
+                Ps[r][c] = tp[it];
+                Fs[r][c] = tf[it];
             }
             __syncthreads();
-#pragma unroll
-            for (int kk = 0; kk < 16; ++kk) {
-                double lr[RT], pr[RT], fr[RT], lc[4], pc[4], fc[4];
-#pragma unroll
-                for (int u = 0; u < RT; ++u) {
-                    lr[u] = Lr[ty + 16 * u][kk];
-                    pr[u] = Pr[ty + 16 * u][kk];
-                    fr[u] = Fr[ty + 16 * u][kk];
-                }
+            const int kn = min(KT, n0 - k0);
+#pragma unroll 4
+            for (int kk = 0; kk < kn; ++kk) {
+                const double lr = Ls[ty][kk], pr = Ps[ty][kk], fr = Fs[ty][kk];
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
-                    lc[v] = Lc[tx + 16 * v][kk];
-                    pc[v] = Pc[tx + 16 * v][kk];
-                    fc[v] = Fc[tx + 16 * v][kk];
+                    const double lc = Ls[TR + tx + 16 * v][kk], pc = Ps[TR + tx + 16 * v][kk], fc = Fs[TR + tx + 16 * v][kk];
+                    e1[v] = fma(lr, pc, e1[v]);
+                    e2[v] = fma(lc, pr, e2[v]);
+                    q1[v] = fma(lr, fc, q1[v]);
+                    q2[v] = fma(lc, fr, q2[v]);
                 }
-#pragma unroll
-                for (int u = 0; u < RT; ++u)
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        e1[u][v] = fma(lr[u], pc[v], e1[u][v]);
-                        e2[u][v] = fma(lc[v], pr[u], e2[u][v]);
-                        q1[u][v] = fma(lr[u], fc[v], q1[u][v]);
-                        q2[u][v] = fma(lc[v], fr[u], q2[u][v]);
-                    }
             }
             __syncthreads();
         }
     }
 #pragma unroll
-    for (int u = 0; u < RT; ++u)
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int rr = R0 + ty + 16 * u, cc = C0 + tx + 16 * v;
-            if (rr >= nrows || cc >= b) continue;
-            double val = rbf_phi<KID>(dist[u][v], kp);
-            if (have_tail) val = (val - e1[u][v]) - e2[u][v] + 0.5 * (q1[u][v] + q2[u][v]);
-            if (rr < nacc)
-                Kab[rr + (int64_t)cc * ld] = val;
-            else
-                S[(rr - nacc) + cc * SB] = val;
-        }
+    for (int v = 0; v < 4; ++v) {
+        const int rr = R0 + ty, cc = C0 + tx + 16 * v;
+        if (rr >= nrows || cc >= b) continue;
+        double val = rbf_phi<KID>(dist[v], kp);
+        if (have_tail) val = (val - e1[v]) - e2[v] + 0.5 * (q1[v] + q2[v]);
+        if (rr < nacc)
+            Kab[rr + (int64_t)cc * ld] = val;
+        else
+            S[(rr - nacc) + cc * SB] = val;
+    }
 }
 
 // the sequential decisions inside one block: S = Schur complement of the block w.r.t. the accepted sites (SB x SB, global -> LDS);
@@ -417,6 +411,187 @@ __global__ __launch_bounds__(64 * TW) void select_block_reg_kernel(const double 
     }
 }
 
+// ---- Round 5, third form of the decision kernel.  The register kernel above still moved ~80 LDS reads per wave and candidate (column j
+// of S re-read for every owned row, pi and g broadcast per owned column, 16 partial sums per row of G pi, 16 partial sums of pi' g) through
+// the one LDS port of the CU -- 16 waves x 80 x 512 bytes at 128 bytes per clock = 2 of the 3.8 us per candidate -- and crossed three
+// workgroup barriers.  Here the ownership follows the reductions:
+//   S: thread (lane, wave) owns columns lane + 64 h, rows wave + 16 k: the rows of a wave are wave-uniform, so column j's entries for
+//      them come out of lane (j & 63)'s registers by v_readlane (scalar operands of the rank-1 update), no LDS;
+//   G: rows wave + 16 a, columns lane + 64 b: (G pi)[t] is a sum over the lanes of ONE wave -- a reduce-scatter over the two upper lane
+//      bits with the gfx950 lane swaps (v_permlane32_swap / v_permlane16_swap: one swap + one add per pair of rows), then row rotations
+//      (DPP) -- and pi' g is a wave reduction every wave repeats on the same data (same order: same bits in every wave).
+// One barrier per candidate (s_waitcnt lgkmcnt(0) + s_barrier: the prefetch of the next candidates' pi stays in flight), behind it five
+// LDS reads per thread.  S is updated as a full symmetric matrix (rows and columns > j; the register kernel kept the lower part: the
+// lower entries see the same operations).  Same arithmetic per entry as before except for the order of the q-term sums.
+__device__ __forceinline__ unsigned dlo(double x) { return (unsigned)(unsigned long long)__double_as_longlong(x); }
+__device__ __forceinline__ unsigned dhi(double x) { return (unsigned)((unsigned long long)__double_as_longlong(x) >> 32); }
+__device__ __forceinline__ double dmk(unsigned lo, unsigned hi) { return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo)); }
+// lanes < 32: sum of p over the two half-waves; lanes >= 32: the same of q
+__device__ __forceinline__ double rs32(double p, double q_) {
+    auto a = __builtin_amdgcn_permlane32_swap(dlo(p), dlo(q_), false, false);
+    auto b = __builtin_amdgcn_permlane32_swap(dhi(p), dhi(q_), false, false);
+    return dmk(a[0], b[0]) + dmk(a[1], b[1]);
+}
+// 16-lane rows 0, 2: sum of p over the row pair; rows 1, 3: the same of q
+__device__ __forceinline__ double rs16(double p, double q_) {
+    auto a = __builtin_amdgcn_permlane16_swap(dlo(p), dlo(q_), false, false);
+    auto b = __builtin_amdgcn_permlane16_swap(dhi(p), dhi(q_), false, false);
+    return dmk(a[0], b[0]) + dmk(a[1], b[1]);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double x) {
+    return dmk((unsigned)__builtin_amdgcn_update_dpp(0, (int)dlo(x), CTRL, 0xf, 0xf, false),
+               (unsigned)__builtin_amdgcn_update_dpp(0, (int)dhi(x), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ double row_allreduce(double x) {  // every lane of a 16-lane row: the row's sum (rotations by 8, 4, 2, 1)
+    x += dpp_d<0x128>(x);
+    x += dpp_d<0x124>(x);
+    x += dpp_d<0x122>(x);
+    x += dpp_d<0x121>(x);
+    return x;
+}
+__device__ __forceinline__ double readlane_d(double x, int l) {
+    return dmk((unsigned)__builtin_amdgcn_readlane((int)dlo(x), l), (unsigned)__builtin_amdgcn_readlane((int)dhi(x), l));
+}
+template <int NA, int NBC>  // rows of G per wave (q <= 16 NA), columns of G per lane (q <= 64 NBC)
+__global__ __launch_bounds__(1024) void select_block_walk_kernel(const double *__restrict__ Sg, int b, int64_t i0, int n0, int q, int max_points,
+                                                                 int maxacc, double thr, const double *__restrict__ Prow, double *__restrict__ Ginv,
+                                                                 int *__restrict__ acc, int *__restrict__ cnt, double *__restrict__ Lblk,
+                                                                 int *__restrict__ blkidx) {
+    static_assert(SB == 128 && NA <= 16 && NBC <= 3, "thread -> entry maps");
+    constexpr int NAP = NA <= 8 ? 8 : 16, NV = NAP / 4;  // rows padded for the reduce-scatter; sums per lane after it
+    __shared__ double cj_s[2][SB];        // column j of S (double buffered: a slow wave may still read the previous candidate's)
+    __shared__ double g_s[2][16 * NAP];   // g = G pi
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double Sr[2][8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) Sr[h][k] = Sg[(w + 16 * k) + (lane + 64 * h) * SB];
+    double G[NA][NBC];
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int bb = 0; bb < NBC; ++bb) {
+            const int t = w + 16 * a, u = lane + 64 * bb;
+            G[a][bb] = (t < q && u < q) ? Ginv[t + (int64_t)u * q] : 0.0;
+        }
+    int nacc = cnt[0], nblk = 0;
+    double p0[NBC], p1[NBC];  // pi of this candidate and the next (the one after is fetched inside the step)
+#pragma unroll
+    for (int bb = 0; bb < NBC; ++bb) {
+        const int u = lane + 64 * bb;
+        p0[bb] = (u < q && b > 0) ? Prow[i0 * q + u] : 0.0;
+        p1[bb] = (u < q && b > 1) ? Prow[(i0 + 1) * q + u] : 0.0;
+    }
+    for (int j = 0; j < b; ++j) {
+        if (n0 + nacc >= max_points || nacc >= maxacc) break;
+        double p2[NBC];
+#pragma unroll
+        for (int bb = 0; bb < NBC; ++bb) {
+            const int u = lane + 64 * bb;
+            p2[bb] = (u < q && j + 2 < b) ? Prow[(i0 + j + 2) * q + u] : 0.0;
+        }
+        const int par = j & 1, lj = j & 63;
+        double cr[8];  // S(w + 16 k, j): wave-uniform
+        if (j < 64) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) cr[k] = readlane_d(Sr[0][k], lj);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) cr[k] = readlane_d(Sr[1][k], lj);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) cj_s[par][w + 16 * k] = cr[k];
+        }
+        double v[NAP];
+#pragma unroll
+        for (int a = 0; a < NAP; ++a) {
+            double sp = 0.0;
+            if (a < NA) {
+#pragma unroll
+                for (int bb = 0; bb < NBC; ++bb) sp = fma(G[a][bb], p0[bb], sp);
+            }
+            v[a] = sp;
+        }
+        // sums over the 64 lanes: afterwards v[i] (i < NV) of the 16-lane row rho holds row a = i + NV rho of this wave
+#pragma unroll
+        for (int i = 0; i < NAP / 2; ++i) v[i] = rs32(v[i], v[i + NAP / 2]);
+#pragma unroll
+        for (int i = 0; i < NAP / 4; ++i) v[i] = rs16(v[i], v[i + NAP / 4]);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = row_allreduce(v[i]);
+        if ((lane & 15) == 0) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) g_s[par][w + 16 * (i + NV * (lane >> 4))] = v[i];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        double gu[NBC];
+#pragma unroll
+        for (int bb = 0; bb < NBC; ++bb) gu[bb] = g_s[par][lane + 64 * bb];
+        const double cc0 = cj_s[par][lane], cc1 = cj_s[par][lane + 64];
+        const double pk = cj_s[par][j];
+        double pp = 0.0;
+#pragma unroll
+        for (int bb = 0; bb < NBC; ++bb) pp = fma(p0[bb], gu[bb], pp);
+        pp = row_allreduce(pp);
+        pp = rs16(pp, pp);
+        pp = rs32(pp, pp);
+        const double ph = 1.0 + pp;
+#pragma unroll
+        for (int bb = 0; bb < NBC; ++bb) {
+            p0[bb] = p1[bb];
+            p1[bb] = p2[bb];
+        }
+        const double tau2 = pk / ph;
+        const bool accept = pk > 0.0 && tau2 > thr && tau2 < 1e300;  // tau^2 > (theta^2)^2, RbfModel.jl:370, :452 (NaN fails)
+        if (!accept) continue;
+        double sq_, rs;
+        fast_sqrt_rsqrt(pk, sq_, rs);
+        (void)sq_;
+        if (tid < SB) {
+            const double cme = tid < 64 ? cc0 : cc1;
+            Lblk[tid + nblk * SB] = (tid > j && tid < b) ? cme * rs : (tid == j ? pk * rs : 0.0);
+        }
+        const double lc0 = (lane > j) ? cc0 * rs : 0.0, lc1 = (lane + 64 > j) ? cc1 * rs : 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const double lr = ((w + 16 * k > j) ? cr[k] : 0.0) * rs;
+            Sr[0][k] = fma(-lr, lc0, Sr[0][k]);
+            Sr[1][k] = fma(-lr, lc1, Sr[1][k]);
+        }
+        // Ginv <- Ginv - g g' / s_H   (Sherman-Morrison for G + pi pi'), one reciprocal per candidate as in the register kernel
+        double rph = __builtin_amdgcn_rcp(ph);
+        rph = fma(fma(-ph, rph, 1.0), rph, rph);
+        rph = fma(fma(-ph, rph, 1.0), rph, rph);
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+            const double gt = readlane_d(v[a % NV], 16 * (a / NV)) * rph;
+#pragma unroll
+            for (int bb = 0; bb < NBC; ++bb) G[a][bb] = fma(-gt, gu[bb], G[a][bb]);
+        }
+        if (tid == 0) {
+            acc[nacc] = (int)(i0 + j);
+            blkidx[nblk] = j;
+        }
+        ++nacc;
+        ++nblk;
+    }
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int bb = 0; bb < NBC; ++bb) {
+            const int t = w + 16 * a, u = lane + 64 * bb;
+            if (t < q && u < q) Ginv[t + (int64_t)u * q] = G[a][bb];
+        }
+    if (tid == 0) {
+        cnt[0] = nacc;
+        cnt[1] = nblk;
+        acc[maxacc] = nacc;
+    }
+}
+
 // rows nacc0 .. nacc0 + nblk - 1 of the accepted factor: [ R(:, j_a)' | in-block factor entries | 0 ]
 __global__ void append_rows_kernel(const double *__restrict__ R, int ldr, int nacc0, const double *__restrict__ Lblk, const int *__restrict__ blkidx,
                                    const int *__restrict__ cnt, double *__restrict__ L, int ldl) {
@@ -558,31 +733,61 @@ __global__ __launch_bounds__(256, 2) void r4_tn_gemm_kernel(const double *__rest
             }
         }
 }
-// X = L_bb^-1 (Kn - sum_s P[s]) on the matrix cores (a four-threads-per-candidate substitution out of LDS was latency-bound: 370 us per
-// block at two waves per CU; this form takes ~25 us).  One wave per 32 candidates.  L_bb is cut into 8 x 8 blocks of 16: X_s = inv(L_ss) (rhs_s - sum_{t < s} L_st X_t).  A block X_t in the f64 MFMA's
-// C/D layout (row = (l >> 4) + 4 r, column = l & 15) IS the B operand of the k slice r of the next product, so the blocks never leave
-// the registers; the A operands (-L_st, inv(L_ss)) come from LDS; the 16 x 16 inverses of the diagonal blocks are formed once per
-// workgroup by forward substitution on the identity (rocBLAS's trsm inverts 128 x 128 diagonal blocks the same way).  Rows >= nblk of the
-// padded system are identity rows with zero right-hand sides.
-__global__ __launch_bounds__(64) void block_forward_mfma_kernel(const double *__restrict__ Kn, const double *__restrict__ P, int ksplit, int64_t pstride,
-                                                           const double *__restrict__ Lblk, const int *__restrict__ blkidx, int nblk, int64_t ncols,
-                                                           double *__restrict__ Rout, int64_t ldr) {
+// X = L_bb^-1 (Kn - sum_s P[s]) on the matrix cores (one thread per candidate took 267 us per block; four threads per candidate out of LDS
+// 370 us, both latency-bound).  Workgroup = 64 candidates, one wave per 16.  L_bb is cut into 8 x 8 blocks of 16:
+// X_s = inv(L_ss) (rhs_s - sum_{t < s} L_st X_t).  A block X_t in the f64 MFMA's C/D layout (row = (l >> 4) + 4 r, column = l & 15) IS the B
+// operand of the k slice r of the next product, so the blocks never leave the registers; the A operands (-L_st, inv(L_ss)) come from LDS;
+// the 16 x 16 inverses of the diagonal blocks are formed once per workgroup by forward substitution on the identity (rocBLAS's trsm
+// inverts its diagonal blocks the same way).  Rows >= nblk of the padded system are identity rows with zero right-hand sides.  The
+// right-hand sides (the k slices of the product summed in a fixed order: deterministic) are staged through LDS by all four waves with the
+// lanes along a -- 32 independent loads in flight per thread and slice -- and the solution leaves through the same tile, coalesced.
+constexpr int FWM_LDR = 132;  // row pitch of the right-hand-side tile: 4 j + (l >> 4) covers the 64 banks once per 16 x 4 lanes
+__global__ __launch_bounds__(256) void block_forward_mfma_kernel(const double *__restrict__ Kn, const double *__restrict__ P, int ksplit, int64_t pstride,
+                                                                const double *__restrict__ Lblk, const int *__restrict__ blkidx, int nblk, int64_t ncols,
+                                                                double *__restrict__ Rout, int64_t ldr) {
     typedef double v4d __attribute__((ext_vector_type(4)));
-    extern __shared__ double fwm_smem[];  // Lt[SB (SB + 1) / 2] | Iv[8][16][17] | bi[SB]
-    double *Lt = fwm_smem, *Iv = Lt + SB * (SB + 1) / 2;
-    int *bi = reinterpret_cast<int *>(Iv + 8 * 16 * 17);
-    const int lane = threadIdx.x, l15 = lane & 15, l4 = lane >> 4;
-    const int64_t jbase = (int64_t)blockIdx.x * 32;
-    for (int a = lane; a < SB; a += 64) bi[a] = a < nblk ? blkidx[a] : 0;
+    extern __shared__ double fwm_smem[];  // Lt[SB (SB + 1) / 2] | Iv[8][16][17] | Xt[64][FWM_LDR] | bi[SB]
+    double *Lt = fwm_smem, *Iv = Lt + SB * (SB + 1) / 2, *Xt = Iv + 8 * 16 * 17;
+    int *bi = reinterpret_cast<int *>(Xt + 64 * FWM_LDR);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    const int64_t jbase = (int64_t)blockIdx.x * 64;
+    if (tid < SB) bi[tid] = tid < nblk ? blkidx[tid] : 0;
     __syncthreads();
-    for (int e = lane; e < SB * SB; e += 64) {  // L_bb(a, a') = Lblk[blkidx[a] + a' SB] (a' <= a < nblk), identity beyond nblk
-        const int a = e >> 7, a2 = e & 127;
-        if (a2 <= a) Lt[a * (a + 1) / 2 + a2] = (a < nblk) ? Lblk[bi[a] + a2 * SB] : (a == a2 ? 1.0 : 0.0);
+    {  // L_bb(a, a') = Lblk[blkidx[a] + a' SB] (a' <= a < nblk), identity beyond nblk; thread -> row a (the accepted rows are near-contiguous)
+        const int a = tid & 127;
+        const double *src = Lblk + bi[a];
+        double *dst = Lt + a * (a + 1) / 2;
+        for (int a2 = tid >> 7; a2 <= a; a2 += 32) {  // sixteen loads in flight (one at a time is an L2 round trip per element: 50 us)
+            double t[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) t[u] = (a2 + 2 * u <= a && a < nblk) ? src[(a2 + 2 * u) * SB] : (a == a2 + 2 * u ? 1.0 : 0.0);
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (a2 + 2 * u <= a) dst[a2 + 2 * u] = t[u];
+        }
+    }
+    {  // right-hand sides: thread -> row a, every second column of the 64
+        const int a = tid & 127, c0 = tid >> 7;
+        double v[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            const int64_t j = jbase + c0 + 2 * u;
+            v[u] = (j < ncols && a < nblk) ? Kn[a + j * SB] : 0.0;
+        }
+        for (int s2 = 0; s2 < ksplit; ++s2) {
+            const double *Ps = P + (int64_t)s2 * pstride + a;
+#pragma unroll
+            for (int u = 0; u < 32; ++u) {
+                const int64_t j = jbase + c0 + 2 * u;
+                if (j < ncols && a < nblk) v[u] -= Ps[j * SB];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 32; ++u) Xt[(c0 + 2 * u) * FWM_LDR + a] = v[u];
     }
     __syncthreads();
-    // inverses of the eight diagonal 16 x 16 blocks: thread -> (block, column), two columns per thread
-    for (int u = 0; u < 2; ++u) {
-        const int blk = (lane + 64 * u) >> 4, col = (lane + 64 * u) & 15;
+    if (tid < SB) {  // inverses of the eight diagonal 16 x 16 blocks: thread -> (block, column)
+        const int blk = tid >> 4, col = tid & 15;
         double x[16];
 #pragma unroll
         for (int a = 0; a < 16; ++a) {
@@ -597,23 +802,14 @@ __global__ __launch_bounds__(64) void block_forward_mfma_kernel(const double *__
         for (int a = 0; a < 16; ++a) Iv[(blk * 16 + a) * 17 + col] = x[a];  // inv(L_ss)(a, col)
     }
     __syncthreads();
-    for (int ct = 0; ct < 2; ++ct) {
-        const int64_t j = jbase + 16 * ct + l15;
-        const bool jin = j < ncols;
+    {
+        double *xcol = Xt + (16 * wave + l15) * FWM_LDR + l4;  // this lane's column; rows l4 + 4 r of a block
         v4d X[8];
 #pragma unroll
         for (int sb = 0; sb < 8; ++sb) {
             v4d D;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int a = 16 * sb + l4 + 4 * r;
-                double v = 0.0;
-                if (jin && a < nblk) {
-                    v = Kn[a + j * SB];
-                    for (int s2 = 0; s2 < ksplit; ++s2) v -= P[(int64_t)s2 * pstride + a + j * SB];
-                }
-                D[r] = v;
-            }
+            for (int r = 0; r < 4; ++r) D[r] = xcol[16 * sb + 4 * r];
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
                 if (t < sb) {
@@ -628,9 +824,17 @@ __global__ __launch_bounds__(64) void block_forward_mfma_kernel(const double *__
             for (int r4 = 0; r4 < 4; ++r4) Xs = __builtin_amdgcn_mfma_f64_16x16x4f64(Iv[(sb * 16 + l15) * 17 + 4 * r4 + l4], D[r4], Xs, 0, 0, 0);
             X[sb] = Xs;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int a = 16 * sb + l4 + 4 * r;
-                if (jin && a < nblk) Rout[a + j * ldr] = Xs[r];
+            for (int r = 0; r < 4; ++r) xcol[16 * sb + 4 * r] = Xs[r];
+        }
+    }
+    __syncthreads();
+    {
+        const int a = tid & 127, c0 = tid >> 7;
+        if (a < nblk) {
+#pragma unroll 8
+            for (int u = 0; u < 32; ++u) {
+                const int64_t j = jbase + c0 + 2 * u;
+                if (j < ncols) Rout[a + j * ldr] = Xt[(c0 + 2 * u) * FWM_LDR + a];
             }
         }
     }
@@ -811,7 +1015,8 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
         const size_t shm = ((size_t)SB * SB + SB + 2 * (size_t)std::max(q, 1) + SEL_THREADS / 64) * sizeof(double);
         MRBF_HIP(ctx, hipFuncSetAttribute((const void *)select_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
         // the register variant of the decision kernel: q <= 80 (2 x 5 entries of Ginv per thread) or q <= 128 (2 x 8); needs q >= 1
-        static const int sel_env = getenv("MRBF_R4_SELECT") ? atoi(getenv("MRBF_R4_SELECT")) : 1;
+        const int sel_env = getenv("MRBF_R4_SELECT") ? atoi(getenv("MRBF_R4_SELECT")) : 2;  // 0: S and Ginv through memory; 1: registers, three barriers; 2: the one-barrier walk
+        const bool walk_sel = sel_env >= 2 && q >= 1 && q <= 192;
         // (3: q <= 192 -- d = 128 has q = 129 -- three rows x twelve columns of Ginv per thread)
         const int fast_sel = (sel_env && q >= 1 && q <= 80) ? 1 : ((sel_env && q >= 1 && q <= 128) ? 2 : ((sel_env && q >= 1 && q <= 192) ? 3 : 0));
         const size_t shm_reg = ((size_t)SB * SB + 2 * (size_t)std::max(q, 1) + 16 * (size_t)std::max(q, 1) + 16) * sizeof(double);
@@ -826,14 +1031,14 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
         }
         if (fast_sel == 3)
             MRBF_HIP(ctx, hipFuncSetAttribute((const void *)select_block_reg_kernel<3, 12, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_reg));
-        double *Rb, *Sb, *Lblk, *Rfull = nullptr, *Anew = nullptr, *Kn = nullptr;
-        int *cnt, *blkidx;
-        // right-looking walk (see gather_newcols_kernel): needs the on-demand kappa; MRBF_R4_EAGER=0 keeps the per-block dtrsm
-        // default: right-looking when the walk may accept a third or more of the candidates (then most of R is used and the GEMMs replace
-        // ~nacc / 128 launch chains per block: d = 128, 6000 of 6000 accepted: 104 -> 60 ms); left-looking (dtrsm per block) when it will
-        // stop early and R for the candidates never reached would be wasted work (d = 64, 2080 of 10^4: 15.8 against 18.3 ms)
+        double *Rb, *Sb, *Rfull = nullptr, *Anew = nullptr, *Kn = nullptr;
+        int *cnt;
+        // right-looking walk (see gather_newcols_kernel): needs the on-demand kappa; MRBF_R4_EAGER=0 keeps the per-block dtrsm.
+        // Default wherever R for every candidate fits (ldr x mc doubles <= 16 GB): with its own product and substitution kernels and the far
+        // columns' update on a second stream it wins at every shape measured (d = 64, 2080 of 10^4 accepted, where the walk stops after 17
+        // of 79 blocks and most of R(:, ahead) is never used, as well as d = 128, 6000 of 6000).
         const int eager_env = getenv("MRBF_R4_EAGER") ? atoi(getenv("MRBF_R4_EAGER")) : -1;
-        const bool eager = lazy && (eager_env >= 0 ? eager_env != 0 : (int64_t)maxacc * 3 >= mc);
+        const bool eager = lazy && (eager_env >= 0 ? eager_env != 0 : (int64_t)round_up(maxacc, 4) * mc <= ((int64_t)2 << 30));
         const int ldr = eager ? (int)round_up(maxacc, 4) : maxacc;  // leading dimension of R (32-byte aligned columns for the right-looking kernels)
         const int custom = eager && (getenv("MRBF_R4_CUSTOM") ? atoi(getenv("MRBF_R4_CUSTOM")) : 1);  // 0: rocBLAS dgemm + one thread per candidate
         constexpr int KSPLIT_MAX = 8;
@@ -845,16 +1050,40 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
             if (custom) MRBF_TRY(get_buf(ctx, S_STAGE_A, (size_t)KSPLIT_MAX * SB * mc, &Ppart));  // the k slices of R(old, new)' R(old, ahead)
         }
         MRBF_TRY(get_buf(ctx, S_Q1, (size_t)maxacc * SB, &Rb));          // R = L_acc^-1 K[acc, block]
-        MRBF_TRY(get_buf(ctx, S_RHS, (size_t)2 * SB * SB, &Sb));          // Schur complement of the block | in-block factor columns
-        Lblk = Sb + (size_t)SB * SB;
-        MRBF_TRY(get_buf(ctx, S_IPIV, (size_t)SB + 8, &cnt));
-        blkidx = cnt + 8;
+        MRBF_TRY(get_buf(ctx, S_RHS, (size_t)3 * SB * SB, &Sb));          // Schur complement of the block | in-block factor columns (two: see below)
+        double *const Lblk2[2] = {Sb + (size_t)SB * SB, Sb + (size_t)2 * SB * SB};
+        MRBF_TRY(get_buf(ctx, S_IPIV, (size_t)2 * SB + 8, &cnt));
+        int *const blkidx2[2] = {cnt + 8, cnt + 8 + SB};
+        // two streams (right-looking walk): after a block's decisions only the NEXT block's columns of R are needed at once; they are
+        // extended on the main stream, the far columns on the side stream while the next block's decision kernel -- one workgroup, 0.46
+        // to 0.8 ms -- runs.  The side stream reads the block's factor columns and indices while the next decision kernel writes its own:
+        // two copies, by block parity; the main stream waits for the side stream's previous update before it touches what that one
+        // reads or writes (Anew, Kn, Ppart, the next block's columns of R).
+        const bool split = eager && custom && (getenv("MRBF_R4_SPLIT") ? atoi(getenv("MRBF_R4_SPLIT")) != 0 : true) && ctx->bulk_stream && ctx->evx[0];
+        hipStream_t sfar = split ? ctx->bulk_stream : s;
+        bool far_pending = false;
+        int64_t far_from = 0;  // first candidate of the side stream's pending update
+        if (eager) {
+            const size_t fw_shm = (size_t)SB * 64 * sizeof(double) + SB * sizeof(int);
+            const size_t fwm_shm = ((size_t)SB * (SB + 1) / 2 + (size_t)8 * 16 * 17 + (size_t)64 * FWM_LDR) * sizeof(double) + SB * sizeof(int);
+            // (per call: the attribute is per device, and one process may drive several)
+            MRBF_HIP(ctx, hipFuncSetAttribute((const void *)block_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fw_shm));
+            MRBF_HIP(ctx, hipFuncSetAttribute((const void *)block_forward_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwm_shm));
+        }
+        int blkno = 0;
         MRBF_HIP(ctx, hipMemsetAsync(cnt, 0, 8 * sizeof(int), s));
         MRBF_HIP(ctx, hipMemsetAsync(st->LK, 0, (size_t)maxacc * maxacc * sizeof(double), s));
         int nacc = 0;
         for (int64_t i0 = 0; i0 < mc && (int64_t)n0 + nacc < max_points && nacc < maxacc; i0 += SB) {
             const int bsz = (int)std::min<int64_t>(SB, mc - i0);
             const double mone = -1.0;
+            if (far_pending && i0 >= far_from) {  // (a block without accepted sites in between: this block's columns were last touched by the side stream)
+                MRBF_HIP(ctx, hipStreamWaitEvent(s, ctx->evx[1], 0));
+                far_pending = false;
+            }
+            double *const Lblk = Lblk2[blkno & 1];
+            int *const blkidx = blkidx2[blkno & 1];
+            ++blkno;
             if (eager) Rb = Rfull + i0 * (int64_t)ldr;  // this block's columns of R are up to date: every earlier block extended them
             if (lazy) {
                 if (bsz < SB) MRBF_HIP(ctx, hipMemsetAsync(Sb, 0, (size_t)SB * SB * sizeof(double), s));
@@ -874,7 +1103,22 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
                 MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, bsz, bsz, nacc, &mone, Rb, ldr, Rb, ldr,
                                              &one, Sb, SB));
             }
-            if (fast_sel == 1 && selw == 8)
+            if (walk_sel) {
+#define MRBF_R4_WALK(NA_, NBC_)                                                                                                                     \
+    hipLaunchKernelGGL((select_block_walk_kernel<NA_, NBC_>), dim3(1), dim3(1024), 0, s, Sb, bsz, i0, (int)n0, q, (int)max_points, maxacc, thr, st->Prow, \
+                       st->Ginv, st->acc, cnt, Lblk, blkidx)
+                if (q <= 64)
+                    MRBF_R4_WALK(4, 1);
+                else if (q <= 80)
+                    MRBF_R4_WALK(5, 2);
+                else if (q <= 128)
+                    MRBF_R4_WALK(8, 2);
+                else if (q <= 144)
+                    MRBF_R4_WALK(9, 3);
+                else
+                    MRBF_R4_WALK(12, 3);
+#undef MRBF_R4_WALK
+            } else if (fast_sel == 1 && selw == 8)
                 hipLaunchKernelGGL((select_block_reg_kernel<2, 10, 8>), dim3(1), dim3(512), shm_reg, s, Sb, bsz, i0, (int)n0, q, (int)max_points, maxacc,
                                    thr, st->Prow, st->Ginv, st->acc, cnt, Lblk, blkidx);
             else if (fast_sel == 2 && selw == 8)
@@ -901,42 +1145,57 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
             nacc = hc[0];
             const int64_t i1 = i0 + bsz, ahead = mc - i1;
             if (eager && nblk > 0 && ahead > 0 && (int64_t)n0 + nacc < max_points && nacc < maxacc) {
-                // rows nacc_old .. nacc - 1 of R for every candidate ahead
-                const dim3 kgrid((unsigned)((ahead + 63) / 64), (unsigned)((nblk + 15) / 16));
-                MRBF_DISPATCH_KID(kp.kid, hipLaunchKernelGGL((kappa_block_kernel<KID, 1>), kgrid, dim3(256), 0, s, st->Xc, d, st->LamT, st->P0c, F, (int)n0,
-                                                             q > 0 ? 1 : 0, st->acc + nacc_old, nblk, i1, (int)ahead, kp, Kn, SB, (double *)nullptr, 0));
-                int ksplit = 0;
-                int64_t pstride = 0;
-                if (nacc_old > 0) {
+                // rows nacc_old .. nacc - 1 of R for the candidates [j0, j0 + ncols) on stream su; Kn, Ppart by absolute candidate index
+                const int64_t pstride = (int64_t)SB * mc;
+                auto extend = [&](int64_t j0, int64_t ncols, hipStream_t su) -> int {
+                    const dim3 kgrid((unsigned)((ncols + 63) / 64), (unsigned)((nblk + 15) / 16));
+                    MRBF_DISPATCH_KID(kp.kid, hipLaunchKernelGGL((kappa_block_kernel<KID, 1>), kgrid, dim3(256), 0, su, st->Xc, d, st->LamT, st->P0c, F,
+                                                                 (int)n0, q > 0 ? 1 : 0, st->acc + nacc_old, nblk, j0, (int)ncols, kp, Kn + j0 * SB, SB,
+                                                                 (double *)nullptr, 0));
+                    int ksplit = 0;
+                    if (nacc_old > 0) {
+                        if (custom) {
+                            // enough (column tile, k slice) workgroups to fill the device twice over, slices of whole 16-deep groups
+                            const int ntile = (int)((ncols + 63) / 64);
+                            ksplit = std::max(1, std::min({KSPLIT_MAX, (512 + ntile - 1) / ntile, (nacc_old + 63) / 64}));
+                            const int kchunk = (int)round_up((nacc_old + ksplit - 1) / ksplit, 16);
+                            ksplit = (nacc_old + kchunk - 1) / kchunk;
+                            hipLaunchKernelGGL(r4_tn_gemm_kernel, dim3((unsigned)ntile, (unsigned)ksplit), dim3(256), 0, su, Anew, ldr,
+                                               Rfull + j0 * (int64_t)ldr, (int64_t)ldr, nacc_old, ncols, kchunk, Ppart + j0 * SB, pstride);
+                        } else {
+                            MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, nblk, (int)ncols, nacc_old, &mone,
+                                                         Anew, ldr, Rfull + j0 * (int64_t)ldr, ldr, &one, Kn + j0 * SB, SB));
+                        }
+                    }
+                    if (custom)
+                        hipLaunchKernelGGL(block_forward_mfma_kernel, dim3((unsigned)((ncols + 63) / 64)), dim3(256),
+                                           ((size_t)SB * (SB + 1) / 2 + (size_t)8 * 16 * 17 + (size_t)64 * FWM_LDR) * sizeof(double) + SB * sizeof(int), su,
+                                           Kn + j0 * SB, Ppart + j0 * SB, ksplit, pstride, Lblk, blkidx, nblk, ncols,
+                                           Rfull + j0 * (int64_t)ldr + nacc_old, (int64_t)ldr);
+                    else
+                        hipLaunchKernelGGL(block_forward_kernel, dim3((unsigned)((ncols + 63) / 64)), dim3(64), (size_t)SB * 64 * sizeof(double) + SB * sizeof(int),
+                                           su, Kn + j0 * SB, SB, Lblk, blkidx, nblk, ncols, Rfull + j0 * (int64_t)ldr + nacc_old, ldr);
+                    return 0;
+                };
+                if (far_pending) MRBF_HIP(ctx, hipStreamWaitEvent(s, ctx->evx[1], 0));  // the side stream's update of the block before
+                if (nacc_old > 0)
                     hipLaunchKernelGGL(gather_newcols_kernel, dim3(nb((int64_t)nacc_old * nblk)), dim3(256), 0, s, Rfull, ldr, nacc_old, i0, blkidx, nblk,
                                        Anew, ldr);
-                    if (custom) {
-                        // enough (column tile, k slice) workgroups to fill the device twice over, slices of whole 16-deep groups
-                        const int ntile = (int)((ahead + 63) / 64);
-                        ksplit = std::max(1, std::min({KSPLIT_MAX, (512 + ntile - 1) / ntile, (nacc_old + 63) / 64}));
-                        const int kchunk = (int)round_up((nacc_old + ksplit - 1) / ksplit, 16);
-                        ksplit = (nacc_old + kchunk - 1) / kchunk;
-                        pstride = (int64_t)SB * ahead;
-                        hipLaunchKernelGGL(r4_tn_gemm_kernel, dim3((unsigned)ntile, (unsigned)ksplit), dim3(256), 0, s, Anew, ldr,
-                                           Rfull + i1 * (int64_t)ldr, (int64_t)ldr, nacc_old, ahead, kchunk, Ppart, pstride);
-                    } else {
-                        MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, nblk, (int)ahead, nacc_old, &mone, Anew,
-                                                     ldr, Rfull + i1 * (int64_t)ldr, ldr, &one, Kn, SB));
-                    }
+                const int64_t near = split ? std::min<int64_t>(SB, ahead) : ahead;
+                if (split && ahead > near) {
+                    MRBF_HIP(ctx, hipEventRecord(ctx->evx[0], s));  // the decisions, their factor columns and the gathered columns are there
+                    MRBF_HIP(ctx, hipStreamWaitEvent(sfar, ctx->evx[0], 0));
+                    MRBF_TRY(extend(i1 + near, ahead - near, sfar));
+                    MRBF_HIP(ctx, hipEventRecord(ctx->evx[1], sfar));
+                    far_pending = true;
+                    far_from = i1 + near;
+                } else {
+                    far_pending = false;
                 }
-                const size_t fw_shm = (size_t)SB * 64 * sizeof(double) + SB * sizeof(int);
-                // (per call: the attribute is per device, and one process may drive several)
-                MRBF_HIP(ctx, hipFuncSetAttribute((const void *)block_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fw_shm));
-                if (custom) {
-                    const size_t fwm_shm = ((size_t)SB * (SB + 1) / 2 + (size_t)8 * 16 * 17) * sizeof(double) + SB * sizeof(int);
-                    MRBF_HIP(ctx, hipFuncSetAttribute((const void *)block_forward_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwm_shm));
-                    hipLaunchKernelGGL(block_forward_mfma_kernel, dim3((unsigned)((ahead + 31) / 32)), dim3(64), fwm_shm, s, Kn, Ppart, ksplit, pstride, Lblk,
-                                       blkidx, nblk, ahead, Rfull + i1 * (int64_t)ldr + nacc_old, (int64_t)ldr);
-                } else
-                hipLaunchKernelGGL(block_forward_kernel, dim3((unsigned)((ahead + 63) / 64)), dim3(64), fw_shm, s, Kn, SB, Lblk, blkidx, nblk, ahead,
-                                   Rfull + i1 * (int64_t)ldr + nacc_old, ldr);
+                MRBF_TRY(extend(i1, near, s));
             }
         }
+        if (far_pending) MRBF_HIP(ctx, hipStreamWaitEvent(s, ctx->evx[1], 0));  // (the buffers go back to the pool after this stream's work)
         MRBF_HIP(ctx, hipGetLastError());
         std::vector<int> hacc((size_t)maxacc + 1);
         MRBF_HIP(ctx, hipMemcpyAsync(hacc.data(), st->acc, hacc.size() * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -950,6 +1209,7 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
     const int rc = run();
     if (rc != 0 || !state_out) {
         (void)hipStreamSynchronize(ctx->stream);
+        if (ctx->bulk_stream) (void)hipStreamSynchronize(ctx->bulk_stream);  // (an error return may leave the side stream's update in flight)
         (void)hipFree(st->block);
         delete st;
         return rc;

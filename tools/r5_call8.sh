@@ -4,7 +4,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/r5h
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-export MRBF_R4_EAGER=1
+export MRBF_R4_EAGER=-1
 for cfg in "64 10000" "128 6000"; do
 tag=$(echo $cfg | tr ' ' '_')
 rocprofv3 --kernel-trace --stats -d $OUT/prof_e$tag -o r4 -- python3 $ROOT/tools/round4_bench.py $cfg > $OUT/r4e$tag.txt 2>&1; echo "rc=$?"

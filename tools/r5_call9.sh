@@ -1,7 +1,9 @@
 #!/bin/bash
+# sampling tests, then the right-looking walk timed and traced at the two reference shapes
 set -o pipefail
-OUT=gpurun_out/r5j
+OUT=gpurun_out/r5g
 mkdir -p $OUT
-bash tools/ab_r4.sh "MRBF_MEGA_PANELDMA=0" "MRBF_MEGA_PANELDMA=1" 1024,2048,4096,6144,8192,12288,16384 15 3 > $OUT/ab_paneldma.txt 2>&1
-cat $OUT/ab_paneldma.txt
-timeout -k 10 900 python3 -m pytest tests/test_gpu_schedules.py tests/test_gpu_parity.py tests/test_gpu_configs.py -x -q -m gpu 2>&1 | tail -3
+timeout -k 10 600 python3 -m pytest tests/test_sampling.py -x -q -m gpu > $OUT/pytest_sampling.txt 2>&1; rc=$?; echo "pytest rc=$rc"; tail -3 $OUT/pytest_sampling.txt
+[ $rc -ne 0 ] && exit $rc
+for e in "MRBF_R4_SELECT=2" "MRBF_R4_SELECT=1"; do echo "$e"; env $e python3 tools/round4_bench.py 64 10000 2>&1 | tail -2 | cut -c1-110; env $e python3 tools/round4_bench.py 128 6000 2>&1 | tail -1 | cut -c1-110;  env $e python3 tools/round4_bench.py 24 3000 2>&1 | tail -1 | cut -c1-110; done
+bash tools/r5_call8.sh
