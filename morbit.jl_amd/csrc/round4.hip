@@ -417,31 +417,21 @@ __global__ __launch_bounds__(64 * TW) void select_block_reg_kernel(const double 
 // workgroup barriers.  Here the ownership follows the reductions:
 //   S: thread (lane, wave) owns columns lane + 64 h, rows wave + 16 k: the rows of a wave are wave-uniform, so column j's entries for
 //      them come out of lane (j & 63)'s registers by v_readlane (scalar operands of the rank-1 update), no LDS;
-//   G: rows wave + 16 a, columns lane + 64 b: (G pi)[t] is a sum over the lanes of ONE wave -- a reduce-scatter over the two upper lane
-//      bits with the gfx950 lane swaps (v_permlane32_swap / v_permlane16_swap: one swap + one add per pair of rows), then row rotations
-//      (DPP) -- and pi' g is a wave reduction every wave repeats on the same data (same order: same bits in every wave).
-// One barrier per candidate (s_waitcnt lgkmcnt(0) + s_barrier: the prefetch of the next candidates' pi stays in flight), behind it five
-// LDS reads per thread.  S is updated as a full symmetric matrix (rows and columns > j; the register kernel kept the lower part: the
-// lower entries see the same operations).  Same arithmetic per entry as before except for the order of the q-term sums.
+//   G: the 16-lane row rho of wave w owns rows w + 16 rho + 64 a, its lane l columns l + 16 b: (G pi)[t] is a sum over ONE 16-lane row
+//      (four DPP rotations), the result is row-uniform -- exactly where the Sherman-Morrison update needs it -- and pi' g is the same
+//      16-lane reduction repeated by every row on the same data (same order: same bits everywhere).
+// One barrier per candidate (s_waitcnt lgkmcnt(0) + s_barrier: the prefetch of the next candidates' pi stays in flight), behind it
+// 3 + q / 16 LDS reads per thread.  S is updated as a full symmetric matrix (rows and columns > j; the register kernel kept the lower
+// part: the lower entries see the same operations).  The kernel is bound by VALU issue (16 waves, ~300 instructions per wave and
+// candidate): hence the accept test by a product (the quotient only when the two are within 1e-13 of each other) and DPP moves without an
+// `old` operand.  Same arithmetic per entry as before except for the order of the q-term sums.
 __device__ __forceinline__ unsigned dlo(double x) { return (unsigned)(unsigned long long)__double_as_longlong(x); }
 __device__ __forceinline__ unsigned dhi(double x) { return (unsigned)((unsigned long long)__double_as_longlong(x) >> 32); }
 __device__ __forceinline__ double dmk(unsigned lo, unsigned hi) { return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo)); }
-// lanes < 32: sum of p over the two half-waves; lanes >= 32: the same of q
-__device__ __forceinline__ double rs32(double p, double q_) {
-    auto a = __builtin_amdgcn_permlane32_swap(dlo(p), dlo(q_), false, false);
-    auto b = __builtin_amdgcn_permlane32_swap(dhi(p), dhi(q_), false, false);
-    return dmk(a[0], b[0]) + dmk(a[1], b[1]);
-}
-// 16-lane rows 0, 2: sum of p over the row pair; rows 1, 3: the same of q
-__device__ __forceinline__ double rs16(double p, double q_) {
-    auto a = __builtin_amdgcn_permlane16_swap(dlo(p), dlo(q_), false, false);
-    auto b = __builtin_amdgcn_permlane16_swap(dhi(p), dhi(q_), false, false);
-    return dmk(a[0], b[0]) + dmk(a[1], b[1]);
-}
 template <int CTRL>
-__device__ __forceinline__ double dpp_d(double x) {
-    return dmk((unsigned)__builtin_amdgcn_update_dpp(0, (int)dlo(x), CTRL, 0xf, 0xf, false),
-               (unsigned)__builtin_amdgcn_update_dpp(0, (int)dhi(x), CTRL, 0xf, 0xf, false));
+__device__ __forceinline__ double dpp_d(double x) {  // (bound_ctrl with full masks: every lane is written, no `old` value to set up)
+    return dmk((unsigned)__builtin_amdgcn_update_dpp(0, (int)dlo(x), CTRL, 0xf, 0xf, true),
+               (unsigned)__builtin_amdgcn_update_dpp(0, (int)dhi(x), CTRL, 0xf, 0xf, true));
 }
 __device__ __forceinline__ double row_allreduce(double x) {  // every lane of a 16-lane row: the row's sum (rotations by 8, 4, 2, 1)
     x += dpp_d<0x128>(x);
@@ -453,99 +443,115 @@ __device__ __forceinline__ double row_allreduce(double x) {  // every lane of a 
 __device__ __forceinline__ double readlane_d(double x, int l) {
     return dmk((unsigned)__builtin_amdgcn_readlane((int)dlo(x), l), (unsigned)__builtin_amdgcn_readlane((int)dhi(x), l));
 }
-template <int NA, int NBC>  // rows of G per wave (q <= 16 NA), columns of G per lane (q <= 64 NBC)
-__global__ __launch_bounds__(1024) void select_block_walk_kernel(const double *__restrict__ Sg, int b, int64_t i0, int n0, int q, int max_points,
-                                                                 int maxacc, double thr, const double *__restrict__ Prow, double *__restrict__ Ginv,
-                                                                 int *__restrict__ acc, int *__restrict__ cnt, double *__restrict__ Lblk,
-                                                                 int *__restrict__ blkidx) {
-    static_assert(SB == 128 && NA <= 16 && NBC <= 3, "thread -> entry maps");
-    constexpr int NAP = NA <= 8 ? 8 : 16, NV = NAP / 4;  // rows padded for the reduce-scatter; sums per lane after it
-    __shared__ double cj_s[2][SB];        // column j of S (double buffered: a slow wave may still read the previous candidate's)
-    __shared__ double g_s[2][16 * NAP];   // g = G pi
-    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    double Sr[2][8];
+template <int TW, int NA, int NB_>  // waves; rows of G per 16-lane row (q <= 4 TW NA); columns of G per lane (q <= 16 NB_)
+__global__ __launch_bounds__(64 * TW) void select_block_walk_kernel(const double *__restrict__ Sg, int b, int64_t i0, int n0, int q, int max_points,
+                                                                    int maxacc, double thr, const double *__restrict__ Prow,
+                                                                    double *__restrict__ Ginv, int *__restrict__ acc, int *__restrict__ cnt,
+                                                                    double *__restrict__ Lblk, int *__restrict__ blkidx) {
+    static_assert(SB == 128 && (TW == 8 || TW == 16) && NB_ <= 12, "thread -> entry maps");
+    constexpr int RK = SB / TW;                                            // rows of S per wave: w + TW k
+    constexpr int GL = (4 * TW * NA > 16 * NB_) ? 4 * TW * NA : 16 * NB_;  // rows of G of a 16-lane row: w + TW rho + 4 TW a
+    constexpr bool DEEP = NB_ <= 5;  // pi two candidates ahead (registers permitting), else one
+    __shared__ double cj_s[2][SB];   // column j of S (double buffered: a slow wave may still read the previous candidate's)
+    __shared__ double g_s[2][GL];    // g = G pi
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, rho = lane >> 4, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double Sr[2][RK];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int k = 0; k < 8; ++k) Sr[h][k] = Sg[(w + 16 * k) + (lane + 64 * h) * SB];
-    double G[NA][NBC];
+        for (int k = 0; k < RK; ++k) Sr[h][k] = Sg[(w + TW * k) + (lane + 64 * h) * SB];
+    double G[NA][NB_];
 #pragma unroll
     for (int a = 0; a < NA; ++a)
 #pragma unroll
-        for (int bb = 0; bb < NBC; ++bb) {
-            const int t = w + 16 * a, u = lane + 64 * bb;
+        for (int bb = 0; bb < NB_; ++bb) {
+            const int t = w + TW * rho + 4 * TW * a, u = l15 + 16 * bb;
             G[a][bb] = (t < q && u < q) ? Ginv[t + (int64_t)u * q] : 0.0;
         }
     int nacc = cnt[0], nblk = 0;
-    double p0[NBC], p1[NBC];  // pi of this candidate and the next (the one after is fetched inside the step)
+    double p0[NB_], p1[NB_];  // pi of this candidate and the next (DEEP: the one after is fetched inside the step)
 #pragma unroll
-    for (int bb = 0; bb < NBC; ++bb) {
-        const int u = lane + 64 * bb;
+    for (int bb = 0; bb < NB_; ++bb) {
+        const int u = l15 + 16 * bb;
         p0[bb] = (u < q && b > 0) ? Prow[i0 * q + u] : 0.0;
-        p1[bb] = (u < q && b > 1) ? Prow[(i0 + 1) * q + u] : 0.0;
+        p1[bb] = (DEEP && u < q && b > 1) ? Prow[(i0 + 1) * q + u] : 0.0;
     }
+    for (int e = tid; e < 2 * GL; e += 64 * TW) (&g_s[0][0])[e] = 0.0;
+    // every load of the prologue has landed before the loop: inside it the compiler then has nothing older than the pi prefetch to
+    // wait for (it merged the prologue's pending loads into the loop header and drained the memory queue at the top of every step)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int k = 0; k < RK; ++k) asm volatile("" : "+v"(Sr[h][k]));
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int bb = 0; bb < NB_; ++bb) asm volatile("" : "+v"(G[a][bb]));
+#pragma unroll
+    for (int bb = 0; bb < NB_; ++bb) {
+        asm volatile("" : "+v"(p0[bb]));
+        asm volatile("" : "+v"(p1[bb]));
+    }
+    __syncthreads();
     for (int j = 0; j < b; ++j) {
         if (n0 + nacc >= max_points || nacc >= maxacc) break;
-        double p2[NBC];
+        double p2[NB_];
 #pragma unroll
-        for (int bb = 0; bb < NBC; ++bb) {
-            const int u = lane + 64 * bb;
-            p2[bb] = (u < q && j + 2 < b) ? Prow[(i0 + j + 2) * q + u] : 0.0;
+        for (int bb = 0; bb < NB_; ++bb) {
+            const int u = l15 + 16 * bb, ahead = DEEP ? 2 : 1;
+            p2[bb] = (u < q && j + ahead < b) ? Prow[(i0 + j + ahead) * q + u] : 0.0;
         }
         const int par = j & 1, lj = j & 63;
-        double cr[8];  // S(w + 16 k, j): wave-uniform
+        double cr[RK];  // S(w + TW k, j): wave-uniform
         if (j < 64) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) cr[k] = readlane_d(Sr[0][k], lj);
+            for (int k = 0; k < RK; ++k) cr[k] = readlane_d(Sr[0][k], lj);
+            if (lane == lj) {
+#pragma unroll
+                for (int k = 0; k < RK; ++k) cj_s[par][w + TW * k] = Sr[0][k];
+            }
         } else {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) cr[k] = readlane_d(Sr[1][k], lj);
-        }
-        if (lane == 0) {
+            for (int k = 0; k < RK; ++k) cr[k] = readlane_d(Sr[1][k], lj);
+            if (lane == lj) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) cj_s[par][w + 16 * k] = cr[k];
-        }
-        double v[NAP];
-#pragma unroll
-        for (int a = 0; a < NAP; ++a) {
-            double sp = 0.0;
-            if (a < NA) {
-#pragma unroll
-                for (int bb = 0; bb < NBC; ++bb) sp = fma(G[a][bb], p0[bb], sp);
+                for (int k = 0; k < RK; ++k) cj_s[par][w + TW * k] = Sr[1][k];
             }
-            v[a] = sp;
         }
-        // sums over the 64 lanes: afterwards v[i] (i < NV) of the 16-lane row rho holds row a = i + NV rho of this wave
+        double v[NA];  // g at this 16-lane row's rows
 #pragma unroll
-        for (int i = 0; i < NAP / 2; ++i) v[i] = rs32(v[i], v[i + NAP / 2]);
+        for (int a = 0; a < NA; ++a) {
+            double sp = 0.0;
 #pragma unroll
-        for (int i = 0; i < NAP / 4; ++i) v[i] = rs16(v[i], v[i + NAP / 4]);
+            for (int bb = 0; bb < NB_; ++bb) sp = fma(G[a][bb], p0[bb], sp);
+            v[a] = row_allreduce(sp);
+        }
+        if (l15 == 0) {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) v[i] = row_allreduce(v[i]);
-        if ((lane & 15) == 0) {
-#pragma unroll
-            for (int i = 0; i < NV; ++i) g_s[par][w + 16 * (i + NV * (lane >> 4))] = v[i];
+            for (int a = 0; a < NA; ++a) g_s[par][w + TW * rho + 4 * TW * a] = v[a];
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        double gu[NBC];
+        double gu[NB_];
 #pragma unroll
-        for (int bb = 0; bb < NBC; ++bb) gu[bb] = g_s[par][lane + 64 * bb];
+        for (int bb = 0; bb < NB_; ++bb) gu[bb] = g_s[par][l15 + 16 * bb];
         const double cc0 = cj_s[par][lane], cc1 = cj_s[par][lane + 64];
         const double pk = cj_s[par][j];
         double pp = 0.0;
 #pragma unroll
-        for (int bb = 0; bb < NBC; ++bb) pp = fma(p0[bb], gu[bb], pp);
-        pp = row_allreduce(pp);
-        pp = rs16(pp, pp);
-        pp = rs32(pp, pp);
-        const double ph = 1.0 + pp;
+        for (int bb = 0; bb < NB_; ++bb) pp = fma(p0[bb], gu[bb], pp);
+        const double ph = 1.0 + row_allreduce(pp);
 #pragma unroll
-        for (int bb = 0; bb < NBC; ++bb) {
-            p0[bb] = p1[bb];
+        for (int bb = 0; bb < NB_; ++bb) {
+            p0[bb] = DEEP ? p1[bb] : p2[bb];
             p1[bb] = p2[bb];
         }
-        const double tau2 = pk / ph;
-        const bool accept = pk > 0.0 && tau2 > thr && tau2 < 1e300;  // tau^2 > (theta^2)^2, RbfModel.jl:370, :452 (NaN fails)
+        // tau^2 = pk / ph > (theta^2)^2, RbfModel.jl:370, :452 (NaN fails): decided by the product unless the two sides are within 1e-13
+        const double tp = thr * ph;
+        bool accept = pk > 0.0 && pk > tp && pk < 1e300 * ph;
+        if (fabs(pk - tp) <= 1e-13 * tp) {
+            const double tau2 = pk / ph;
+            accept = pk > 0.0 && tau2 > thr && tau2 < 1e300;
+        }
         if (!accept) continue;
         double sq_, rs;
         fast_sqrt_rsqrt(pk, sq_, rs);
@@ -556,8 +562,8 @@ __global__ __launch_bounds__(1024) void select_block_walk_kernel(const double *_
         }
         const double lc0 = (lane > j) ? cc0 * rs : 0.0, lc1 = (lane + 64 > j) ? cc1 * rs : 0.0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const double lr = ((w + 16 * k > j) ? cr[k] : 0.0) * rs;
+        for (int k = 0; k < RK; ++k) {
+            const double lr = ((w + TW * k > j) ? cr[k] : 0.0) * rs;
             Sr[0][k] = fma(-lr, lc0, Sr[0][k]);
             Sr[1][k] = fma(-lr, lc1, Sr[1][k]);
         }
@@ -567,9 +573,9 @@ __global__ __launch_bounds__(1024) void select_block_walk_kernel(const double *_
         rph = fma(fma(-ph, rph, 1.0), rph, rph);
 #pragma unroll
         for (int a = 0; a < NA; ++a) {
-            const double gt = readlane_d(v[a % NV], 16 * (a / NV)) * rph;
+            const double gt = v[a] * rph;
 #pragma unroll
-            for (int bb = 0; bb < NBC; ++bb) G[a][bb] = fma(-gt, gu[bb], G[a][bb]);
+            for (int bb = 0; bb < NB_; ++bb) G[a][bb] = fma(-gt, gu[bb], G[a][bb]);
         }
         if (tid == 0) {
             acc[nacc] = (int)(i0 + j);
@@ -581,8 +587,8 @@ __global__ __launch_bounds__(1024) void select_block_walk_kernel(const double *_
 #pragma unroll
     for (int a = 0; a < NA; ++a)
 #pragma unroll
-        for (int bb = 0; bb < NBC; ++bb) {
-            const int t = w + 16 * a, u = lane + 64 * bb;
+        for (int bb = 0; bb < NB_; ++bb) {
+            const int t = w + TW * rho + 4 * TW * a, u = l15 + 16 * bb;
             if (t < q && u < q) Ginv[t + (int64_t)u * q] = G[a][bb];
         }
     if (tid == 0) {
@@ -1016,7 +1022,8 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
         MRBF_HIP(ctx, hipFuncSetAttribute((const void *)select_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
         // the register variant of the decision kernel: q <= 80 (2 x 5 entries of Ginv per thread) or q <= 128 (2 x 8); needs q >= 1
         const int sel_env = getenv("MRBF_R4_SELECT") ? atoi(getenv("MRBF_R4_SELECT")) : 2;  // 0: S and Ginv through memory; 1: registers, three barriers; 2: the one-barrier walk
-        const bool walk_sel = sel_env >= 2 && q >= 1 && q <= 192;
+        const bool walk_sel = sel_env >= 2 && q >= 1 && q <= 144;  // (beyond: the register kernel; the walk's <8, 6, 12> shape spills)
+        const int walkw = getenv("MRBF_R4_WALKW") ? atoi(getenv("MRBF_R4_WALKW")) : 8;  // waves of the walk kernel for q <= 80 (8 or 16; d = 64: 8.8 against 9.2 ms)
         // (3: q <= 192 -- d = 128 has q = 129 -- three rows x twelve columns of Ginv per thread)
         const int fast_sel = (sel_env && q >= 1 && q <= 80) ? 1 : ((sel_env && q >= 1 && q <= 128) ? 2 : ((sel_env && q >= 1 && q <= 192) ? 3 : 0));
         const size_t shm_reg = ((size_t)SB * SB + 2 * (size_t)std::max(q, 1) + 16 * (size_t)std::max(q, 1) + 16) * sizeof(double);
@@ -1104,19 +1111,26 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
                                              &one, Sb, SB));
             }
             if (walk_sel) {
-#define MRBF_R4_WALK(NA_, NBC_)                                                                                                                     \
-    hipLaunchKernelGGL((select_block_walk_kernel<NA_, NBC_>), dim3(1), dim3(1024), 0, s, Sb, bsz, i0, (int)n0, q, (int)max_points, maxacc, thr, st->Prow, \
-                       st->Ginv, st->acc, cnt, Lblk, blkidx)
-                if (q <= 64)
-                    MRBF_R4_WALK(4, 1);
+#define MRBF_R4_WALK(TW_, NA_, NB__)                                                                                                              \
+    hipLaunchKernelGGL((select_block_walk_kernel<TW_, NA_, NB__>), dim3(1), dim3(64 * TW_), 0, s, Sb, bsz, i0, (int)n0, q, (int)max_points, maxacc, thr, \
+                       st->Prow, st->Ginv, st->acc, cnt, Lblk, blkidx)
+                // sixteen waves while Ginv, pi and g fit their 128 registers (q <= 80), eight beyond
+                if (q <= 32 && walkw == 16)
+                    MRBF_R4_WALK(16, 1, 2);
+                else if (q <= 64 && walkw == 16)
+                    MRBF_R4_WALK(16, 1, 4);
+                else if (q <= 80 && walkw == 16)
+                    MRBF_R4_WALK(16, 2, 5);
+                else if (q <= 32)
+                    MRBF_R4_WALK(8, 1, 2);
+                else if (q <= 64)
+                    MRBF_R4_WALK(8, 2, 4);
                 else if (q <= 80)
-                    MRBF_R4_WALK(5, 2);
+                    MRBF_R4_WALK(8, 3, 5);
                 else if (q <= 128)
-                    MRBF_R4_WALK(8, 2);
-                else if (q <= 144)
-                    MRBF_R4_WALK(9, 3);
+                    MRBF_R4_WALK(8, 4, 8);
                 else
-                    MRBF_R4_WALK(12, 3);
+                    MRBF_R4_WALK(8, 5, 9);
 #undef MRBF_R4_WALK
             } else if (fast_sel == 1 && selw == 8)
                 hipLaunchKernelGGL((select_block_reg_kernel<2, 10, 8>), dim3(1), dim3(512), shm_reg, s, Sb, bsz, i0, (int)n0, q, (int)max_points, maxacc,
