@@ -107,8 +107,15 @@ template <int KID, int RT>  // tile = 16 rows x 64 columns, 4 entries per thread
 __global__ __launch_bounds__(256) void kappa_block_kernel(const double *__restrict__ Xc, int d, const double *__restrict__ LamT,
                                                           const double *__restrict__ P0c, const double *__restrict__ F, int n0, int have_tail,
                                                           const int *__restrict__ acc, int nacc, int64_t i0, int b, KP kp,
-                                                          double *__restrict__ Kab, int ld, double *__restrict__ S, int blockrows) {
+                                                          double *__restrict__ Kab, int ld, double *__restrict__ S, int blockrows,
+                                                          int64_t batch_total = 0) {
     static_assert(RT == 1, "one row of entries per thread");
+    if (batch_total > 0) {  // blockIdx.z = block number: kappa(block, block) of every block of the walk in one launch (S: SB x SB per block)
+        const int64_t off = (int64_t)blockIdx.z * SB;
+        i0 += off;
+        b = (int)min((int64_t)SB, batch_total - off);
+        S += off * SB;
+    }
     constexpr int TR = 16, NR = TR + 64, KD = 64, KT = 32;
     __shared__ double sm[3 * NR * (KT + 1)];  // distance rounds: A[NR][KD + 1]; tail rounds: L | P | F, each [NR][KT + 1]
     static_assert(NR * (KD + 1) <= 3 * NR * (KT + 1), "the distance tile fits the tail tiles' area");
@@ -748,48 +755,62 @@ __global__ __launch_bounds__(256, 2) void r4_tn_gemm_kernel(const double *__rest
 // right-hand sides (the k slices of the product summed in a fixed order: deterministic) are staged through LDS by all four waves with the
 // lanes along a -- 32 independent loads in flight per thread and slice -- and the solution leaves through the same tile, coalesced.
 constexpr int FWM_LDR = 132;  // row pitch of the right-hand-side tile: 4 j + (l >> 4) covers the 64 banks once per 16 x 4 lanes
+constexpr size_t fwm_shm_bytes(int ncol) { return ((size_t)SB * (SB + 1) / 2 + (size_t)8 * 16 * 17 + (size_t)ncol * FWM_LDR) * sizeof(double) + SB * sizeof(int); }
+template <int NCOL>  // candidates per workgroup: 64 (one wave per 16) or 16 (few columns: more workgroups, every load of a thread in flight at once)
 __global__ __launch_bounds__(256) void block_forward_mfma_kernel(const double *__restrict__ Kn, const double *__restrict__ P, int ksplit, int64_t pstride,
                                                                 const double *__restrict__ Lblk, const int *__restrict__ blkidx, int nblk, int64_t ncols,
                                                                 double *__restrict__ Rout, int64_t ldr) {
     typedef double v4d __attribute__((ext_vector_type(4)));
-    extern __shared__ double fwm_smem[];  // Lt[SB (SB + 1) / 2] | Iv[8][16][17] | Xt[64][FWM_LDR] | bi[SB]
+    extern __shared__ double fwm_smem[];  // Lt[SB (SB + 1) / 2] | Iv[8][16][17] | Xt[NCOL][FWM_LDR] | bi[SB]
     double *Lt = fwm_smem, *Iv = Lt + SB * (SB + 1) / 2, *Xt = Iv + 8 * 16 * 17;
-    int *bi = reinterpret_cast<int *>(Xt + 64 * FWM_LDR);
+    int *bi = reinterpret_cast<int *>(Xt + NCOL * FWM_LDR);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
-    const int64_t jbase = (int64_t)blockIdx.x * 64;
+    const int64_t jbase = (int64_t)blockIdx.x * NCOL;
     if (tid < SB) bi[tid] = tid < nblk ? blkidx[tid] : 0;
     __syncthreads();
     {  // L_bb(a, a') = Lblk[blkidx[a] + a' SB] (a' <= a < nblk), identity beyond nblk; thread -> row a (the accepted rows are near-contiguous)
         const int a = tid & 127;
         const double *src = Lblk + bi[a];
         double *dst = Lt + a * (a + 1) / 2;
-        for (int a2 = tid >> 7; a2 <= a; a2 += 32) {  // sixteen loads in flight (one at a time is an L2 round trip per element: 50 us)
-            double t[16];
+        for (int a2 = tid >> 7; a2 <= a; a2 += 64) {  // 32 loads in flight (one at a time is an L2 round trip per element: 50 us)
+            double t[32];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) t[u] = (a2 + 2 * u <= a && a < nblk) ? src[(a2 + 2 * u) * SB] : (a == a2 + 2 * u ? 1.0 : 0.0);
+            for (int u = 0; u < 32; ++u) t[u] = (a2 + 2 * u <= a && a < nblk) ? src[(a2 + 2 * u) * SB] : (a == a2 + 2 * u ? 1.0 : 0.0);
 #pragma unroll
-            for (int u = 0; u < 16; ++u)
+            for (int u = 0; u < 32; ++u)
                 if (a2 + 2 * u <= a) dst[a2 + 2 * u] = t[u];
         }
     }
-    {  // right-hand sides: thread -> row a, every second column of the 64
+    {  // right-hand sides: thread -> row a, every second column; eight columns x eight slices of the product in flight per round, the
+       // slices subtracted in their fixed order
         const int a = tid & 127, c0 = tid >> 7;
-        double v[32];
+        const bool ain = a < nblk;
+#pragma unroll 1
+        for (int u0 = 0; u0 < NCOL / 2; u0 += 8) {
+            double v[8];
 #pragma unroll
-        for (int u = 0; u < 32; ++u) {
-            const int64_t j = jbase + c0 + 2 * u;
-            v[u] = (j < ncols && a < nblk) ? Kn[a + j * SB] : 0.0;
-        }
-        for (int s2 = 0; s2 < ksplit; ++s2) {
-            const double *Ps = P + (int64_t)s2 * pstride + a;
-#pragma unroll
-            for (int u = 0; u < 32; ++u) {
-                const int64_t j = jbase + c0 + 2 * u;
-                if (j < ncols && a < nblk) v[u] -= Ps[j * SB];
+            for (int u = 0; u < 8; ++u) {
+                const int64_t j = jbase + c0 + 2 * (u0 + u);
+                v[u] = (j < ncols && ain) ? Kn[a + j * SB] : 0.0;
             }
-        }
+#pragma unroll 1
+            for (int s0 = 0; s0 < ksplit; s0 += 8) {
+                double t[8][8];
 #pragma unroll
-        for (int u = 0; u < 32; ++u) Xt[(c0 + 2 * u) * FWM_LDR + a] = v[u];
+                for (int s2 = 0; s2 < 8; ++s2)
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int64_t j = jbase + c0 + 2 * (u0 + u);
+                        t[s2][u] = (s0 + s2 < ksplit && j < ncols && ain) ? P[(int64_t)(s0 + s2) * pstride + a + j * SB] : 0.0;
+                    }
+#pragma unroll
+                for (int s2 = 0; s2 < 8; ++s2)
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] -= t[s2][u];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) Xt[(c0 + 2 * (u0 + u)) * FWM_LDR + a] = v[u];
+        }
     }
     __syncthreads();
     if (tid < SB) {  // inverses of the eight diagonal 16 x 16 blocks: thread -> (block, column)
@@ -808,7 +829,7 @@ __global__ __launch_bounds__(256) void block_forward_mfma_kernel(const double *_
         for (int a = 0; a < 16; ++a) Iv[(blk * 16 + a) * 17 + col] = x[a];  // inv(L_ss)(a, col)
     }
     __syncthreads();
-    {
+    if (16 * wave < NCOL) {
         double *xcol = Xt + (16 * wave + l15) * FWM_LDR + l4;  // this lane's column; rows l4 + 4 r of a block
         v4d X[8];
 #pragma unroll
@@ -838,12 +859,28 @@ __global__ __launch_bounds__(256) void block_forward_mfma_kernel(const double *_
         const int a = tid & 127, c0 = tid >> 7;
         if (a < nblk) {
 #pragma unroll 8
-            for (int u = 0; u < 32; ++u) {
+            for (int u = 0; u < NCOL / 2; ++u) {
                 const int64_t j = jbase + c0 + 2 * u;
                 if (j < ncols) Rout[a + j * ldr] = Xt[(c0 + 2 * u) * FWM_LDR + a];
             }
         }
     }
+}
+// Sb = kappa(block, block) - sum of the k slices of R(:, block)' R(:, block), zero outside the block's b rows and columns (the decision
+// kernel is one workgroup: it must not be the one to read 33 x 128 KB)
+__global__ void schur_reduce_kernel(const double *__restrict__ Kbb, const double *__restrict__ Spart, int ksplit, int b, double *__restrict__ Sb) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= SB * SB) return;
+    const int r = e % SB, c = e / SB;
+    double x = Kbb[e];
+    for (int s0 = 0; s0 < ksplit; s0 += 8) {
+        double t[8];
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) t[s2] = (s0 + s2 < ksplit) ? Spart[(size_t)(s0 + s2) * SB * SB + e] : 0.0;
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) x -= t[s2];
+    }
+    Sb[e] = (r < b && c < b) ? x : 0.0;
 }
 
 // dense j x j copy of the accepted factor
@@ -1051,10 +1088,22 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
         constexpr int KSPLIT_MAX = 8;
         double *Ppart = nullptr;
         if (eager) {
-            MRBF_TRY(get_buf(ctx, S_PHI, (size_t)ldr * mc, &Rfull));         // R(:, j) for every candidate j
+            MRBF_TRY(get_buf(ctx, S_PHI, (size_t)ldr * (mc + SB), &Rfull));  // R(:, j) for every candidate j (+ one block: the products read whole 128-column tiles)
             MRBF_TRY(get_buf(ctx, S_STAGE_C, (size_t)ldr * SB, &Anew));      // the new sites' columns of R, compact
             MRBF_TRY(get_buf(ctx, S_STAGE_D, (size_t)SB * mc, &Kn));         // kappa(new, ahead), ld = SB
             if (custom) MRBF_TRY(get_buf(ctx, S_STAGE_A, (size_t)KSPLIT_MAX * SB * mc, &Ppart));  // the k slices of R(old, new)' R(old, ahead)
+        }
+        // the block's own Schur complement without rocBLAS (right-looking walk): kappa(block, block) of every block in one launch up front,
+        // R(:, block)' R(:, block) by the split-k product kernel (rocBLAS ran this 128 x 128 x nacc product on two workgroups: 165 us at
+        // nacc = 5000), slices summed by schur_reduce_kernel
+        constexpr int KSPLIT_NEAR = 32;
+        const bool own_schur = custom && (getenv("MRBF_R4_SCHUR") ? atoi(getenv("MRBF_R4_SCHUR")) != 0 : true);
+        const int64_t nblocks = (mc + SB - 1) / SB;
+        double *KbbAll = nullptr, *Spart = nullptr, *Pnear = nullptr;
+        if (own_schur) {
+            MRBF_TRY(get_buf(ctx, S_OUT_A, (size_t)SB * SB * nblocks, &KbbAll));
+            MRBF_TRY(get_buf(ctx, S_STAGE_B, (size_t)2 * KSPLIT_NEAR * SB * SB, &Spart));
+            Pnear = Spart + (size_t)KSPLIT_NEAR * SB * SB;  // the k slices of the next block's update (few columns: split 32 ways)
         }
         MRBF_TRY(get_buf(ctx, S_Q1, (size_t)maxacc * SB, &Rb));          // R = L_acc^-1 K[acc, block]
         MRBF_TRY(get_buf(ctx, S_RHS, (size_t)3 * SB * SB, &Sb));          // Schur complement of the block | in-block factor columns (two: see below)
@@ -1072,10 +1121,16 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
         int64_t far_from = 0;  // first candidate of the side stream's pending update
         if (eager) {
             const size_t fw_shm = (size_t)SB * 64 * sizeof(double) + SB * sizeof(int);
-            const size_t fwm_shm = ((size_t)SB * (SB + 1) / 2 + (size_t)8 * 16 * 17 + (size_t)64 * FWM_LDR) * sizeof(double) + SB * sizeof(int);
             // (per call: the attribute is per device, and one process may drive several)
             MRBF_HIP(ctx, hipFuncSetAttribute((const void *)block_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fw_shm));
-            MRBF_HIP(ctx, hipFuncSetAttribute((const void *)block_forward_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwm_shm));
+            MRBF_HIP(ctx, hipFuncSetAttribute((const void *)block_forward_mfma_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwm_shm_bytes(64)));
+            MRBF_HIP(ctx, hipFuncSetAttribute((const void *)block_forward_mfma_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwm_shm_bytes(16)));
+        }
+        if (own_schur) {
+            MRBF_HIP(ctx, hipMemsetAsync(KbbAll + (size_t)SB * SB * (nblocks - 1), 0, (size_t)SB * SB * sizeof(double), s));  // (the last block may be partial)
+            const dim3 kgrid(2, SB / 16, (unsigned)nblocks);
+            MRBF_DISPATCH_KID(kp.kid, hipLaunchKernelGGL((kappa_block_kernel<KID, 1>), kgrid, dim3(256), 0, s, st->Xc, d, st->LamT, st->P0c, F, (int)n0,
+                                                         q > 0 ? 1 : 0, st->acc, 0, (int64_t)0, SB, kp, (double *)nullptr, 0, KbbAll, 1, mc));
         }
         int blkno = 0;
         MRBF_HIP(ctx, hipMemsetAsync(cnt, 0, 8 * sizeof(int), s));
@@ -1092,7 +1147,18 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
             int *const blkidx = blkidx2[blkno & 1];
             ++blkno;
             if (eager) Rb = Rfull + i0 * (int64_t)ldr;  // this block's columns of R are up to date: every earlier block extended them
-            if (lazy) {
+            if (own_schur) {
+                int ks = 0;
+                if (nacc > 0) {
+                    const int ntile = (bsz + 63) / 64;
+                    ks = std::max(1, std::min(KSPLIT_NEAR, (nacc + 63) / 64));
+                    const int kchunk = (int)round_up((nacc + ks - 1) / ks, 16);
+                    ks = (nacc + kchunk - 1) / kchunk;
+                    hipLaunchKernelGGL(r4_tn_gemm_kernel, dim3((unsigned)ntile, (unsigned)ks), dim3(256), 0, s, Rb, ldr, Rb, (int64_t)ldr, nacc, (int64_t)bsz,
+                                       kchunk, Spart, (int64_t)SB * SB);
+                }
+                hipLaunchKernelGGL(schur_reduce_kernel, dim3(SB * SB / 256), dim3(256), 0, s, KbbAll + (size_t)(i0 / SB) * SB * SB, Spart, ks, bsz, Sb);
+            } else if (lazy) {
                 if (bsz < SB) MRBF_HIP(ctx, hipMemsetAsync(Sb, 0, (size_t)SB * SB * sizeof(double), s));
                 const int nlist = eager ? 0 : nacc;  // (eager: only kappa(block, block) is needed here)
                 const dim3 kgrid((unsigned)((bsz + 63) / 64), (unsigned)((nlist + bsz + 15) / 16));
@@ -1101,7 +1167,7 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
             } else {
                 hipLaunchKernelGGL(block_copy_kernel, dim3(nb(SB * SB)), dim3(256), 0, s, st->K, mc, i0, bsz, Sb);
             }
-            if (nacc > 0) {
+            if (nacc > 0 && !own_schur) {
                 if (!lazy)
                     hipLaunchKernelGGL(gather_kab_kernel, dim3(nb((int64_t)nacc * bsz)), dim3(256), 0, s, st->K, mc, st->acc, nacc, i0, bsz, Rb, maxacc);
                 if (!eager)
@@ -1161,31 +1227,37 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
             if (eager && nblk > 0 && ahead > 0 && (int64_t)n0 + nacc < max_points && nacc < maxacc) {
                 // rows nacc_old .. nacc - 1 of R for the candidates [j0, j0 + ncols) on stream su; Kn, Ppart by absolute candidate index
                 const int64_t pstride = (int64_t)SB * mc;
-                auto extend = [&](int64_t j0, int64_t ncols, hipStream_t su) -> int {
+                // (is_near: the next block's columns, on the critical path: the product split 32 ways into its own small slice buffer and the
+                // substitution in 16-column workgroups)
+                auto extend = [&](int64_t j0, int64_t ncols, hipStream_t su, bool is_near) -> int {
                     const dim3 kgrid((unsigned)((ncols + 63) / 64), (unsigned)((nblk + 15) / 16));
                     MRBF_DISPATCH_KID(kp.kid, hipLaunchKernelGGL((kappa_block_kernel<KID, 1>), kgrid, dim3(256), 0, su, st->Xc, d, st->LamT, st->P0c, F,
                                                                  (int)n0, q > 0 ? 1 : 0, st->acc + nacc_old, nblk, j0, (int)ncols, kp, Kn + j0 * SB, SB,
                                                                  (double *)nullptr, 0));
                     int ksplit = 0;
+                    const bool small = is_near && Pnear && ncols <= SB;
+                    double *const Pb = small ? Pnear : Ppart + j0 * SB;
+                    const int64_t ps = small ? (int64_t)SB * SB : pstride;
                     if (nacc_old > 0) {
                         if (custom) {
                             // enough (column tile, k slice) workgroups to fill the device twice over, slices of whole 16-deep groups
                             const int ntile = (int)((ncols + 63) / 64);
-                            ksplit = std::max(1, std::min({KSPLIT_MAX, (512 + ntile - 1) / ntile, (nacc_old + 63) / 64}));
+                            ksplit = std::max(1, std::min({small ? KSPLIT_NEAR : KSPLIT_MAX, (512 + ntile - 1) / ntile, (nacc_old + 63) / 64}));
                             const int kchunk = (int)round_up((nacc_old + ksplit - 1) / ksplit, 16);
                             ksplit = (nacc_old + kchunk - 1) / kchunk;
                             hipLaunchKernelGGL(r4_tn_gemm_kernel, dim3((unsigned)ntile, (unsigned)ksplit), dim3(256), 0, su, Anew, ldr,
-                                               Rfull + j0 * (int64_t)ldr, (int64_t)ldr, nacc_old, ncols, kchunk, Ppart + j0 * SB, pstride);
+                                               Rfull + j0 * (int64_t)ldr, (int64_t)ldr, nacc_old, ncols, kchunk, Pb, ps);
                         } else {
                             MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, nblk, (int)ncols, nacc_old, &mone,
                                                          Anew, ldr, Rfull + j0 * (int64_t)ldr, ldr, &one, Kn + j0 * SB, SB));
                         }
                     }
-                    if (custom)
-                        hipLaunchKernelGGL(block_forward_mfma_kernel, dim3((unsigned)((ncols + 63) / 64)), dim3(256),
-                                           ((size_t)SB * (SB + 1) / 2 + (size_t)8 * 16 * 17 + (size_t)64 * FWM_LDR) * sizeof(double) + SB * sizeof(int), su,
-                                           Kn + j0 * SB, Ppart + j0 * SB, ksplit, pstride, Lblk, blkidx, nblk, ncols,
-                                           Rfull + j0 * (int64_t)ldr + nacc_old, (int64_t)ldr);
+                    if (custom && ncols <= 1024)
+                        hipLaunchKernelGGL(block_forward_mfma_kernel<16>, dim3((unsigned)((ncols + 15) / 16)), dim3(256), fwm_shm_bytes(16), su, Kn + j0 * SB, Pb,
+                                           ksplit, ps, Lblk, blkidx, nblk, ncols, Rfull + j0 * (int64_t)ldr + nacc_old, (int64_t)ldr);
+                    else if (custom)
+                        hipLaunchKernelGGL(block_forward_mfma_kernel<64>, dim3((unsigned)((ncols + 63) / 64)), dim3(256), fwm_shm_bytes(64), su, Kn + j0 * SB, Pb,
+                                           ksplit, ps, Lblk, blkidx, nblk, ncols, Rfull + j0 * (int64_t)ldr + nacc_old, (int64_t)ldr);
                     else
                         hipLaunchKernelGGL(block_forward_kernel, dim3((unsigned)((ncols + 63) / 64)), dim3(64), (size_t)SB * 64 * sizeof(double) + SB * sizeof(int),
                                            su, Kn + j0 * SB, SB, Lblk, blkidx, nblk, ncols, Rfull + j0 * (int64_t)ldr + nacc_old, ldr);
@@ -1195,18 +1267,20 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
                 if (nacc_old > 0)
                     hipLaunchKernelGGL(gather_newcols_kernel, dim3(nb((int64_t)nacc_old * nblk)), dim3(256), 0, s, Rfull, ldr, nacc_old, i0, blkidx, nblk,
                                        Anew, ldr);
+                // the next block's columns first, alone on the device (started together, the far update's 150 workgroups doubled the
+                // duration of these few); the far columns then run under the next block's Schur product and decisions
                 const int64_t near = split ? std::min<int64_t>(SB, ahead) : ahead;
+                MRBF_TRY(extend(i1, near, s, split));
                 if (split && ahead > near) {
-                    MRBF_HIP(ctx, hipEventRecord(ctx->evx[0], s));  // the decisions, their factor columns and the gathered columns are there
+                    MRBF_HIP(ctx, hipEventRecord(ctx->evx[0], s));
                     MRBF_HIP(ctx, hipStreamWaitEvent(sfar, ctx->evx[0], 0));
-                    MRBF_TRY(extend(i1 + near, ahead - near, sfar));
+                    MRBF_TRY(extend(i1 + near, ahead - near, sfar, false));
                     MRBF_HIP(ctx, hipEventRecord(ctx->evx[1], sfar));
                     far_pending = true;
                     far_from = i1 + near;
                 } else {
                     far_pending = false;
                 }
-                MRBF_TRY(extend(i1, near, s));
             }
         }
         if (far_pending) MRBF_HIP(ctx, hipStreamWaitEvent(s, ctx->evx[1], 0));  // (the buffers go back to the pool after this stream's work)
