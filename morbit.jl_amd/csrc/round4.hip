@@ -23,6 +23,7 @@
 // so the fit costs two triangular solves instead of an n^3 / 3 factorisation.  Checked against an independent from-scratch
 // restatement (oracle/sampling_oracle.py) in tests/test_sampling.py.
 #include "radial.hpp"
+#include "walk_kernel.hpp"
 
 namespace mrbf {
 
@@ -76,7 +77,7 @@ __global__ void kappa_kernel(const double *__restrict__ Phicc, const double *__r
 }
 
 // ---- blocked walk: per block of SB candidates --------------------------------------------------------------------------------
-constexpr int SB = 128;
+// (SB = 128, the block of candidates decided inside one kernel: walk_kernel.hpp)
 // Kab[a + j * ld] = K[acc[a]][i0 + j]  (rows = accepted sites so far, columns = the block's candidates)
 __global__ void gather_kab_kernel(const double *__restrict__ K, int64_t mc, const int *__restrict__ acc, int nacc, int64_t i0, int b,
                                   double *__restrict__ Kab, int ld) {
@@ -409,193 +410,6 @@ __global__ __launch_bounds__(64 * TW) void select_block_reg_kernel(const double 
 #pragma unroll
         for (int bb = 0; bb < NB_; ++bb) {
             const int t = lane + 64 * a, u = wave + TW * bb;
-            if (t < q && u < q) Ginv[t + (int64_t)u * q] = G[a][bb];
-        }
-    if (tid == 0) {
-        cnt[0] = nacc;
-        cnt[1] = nblk;
-        acc[maxacc] = nacc;
-    }
-}
-
-// ---- Round 5, third form of the decision kernel.  The register kernel above still moved ~80 LDS reads per wave and candidate (column j
-// of S re-read for every owned row, pi and g broadcast per owned column, 16 partial sums per row of G pi, 16 partial sums of pi' g) through
-// the one LDS port of the CU -- 16 waves x 80 x 512 bytes at 128 bytes per clock = 2 of the 3.8 us per candidate -- and crossed three
-// workgroup barriers.  Here the ownership follows the reductions:
-//   S: thread (lane, wave) owns columns lane + 64 h, rows wave + 16 k: the rows of a wave are wave-uniform, so column j's entries for
-//      them come out of lane (j & 63)'s registers by v_readlane (scalar operands of the rank-1 update), no LDS;
-//   G: the 16-lane row rho of wave w owns rows w + 16 rho + 64 a, its lane l columns l + 16 b: (G pi)[t] is a sum over ONE 16-lane row
-//      (four DPP rotations), the result is row-uniform -- exactly where the Sherman-Morrison update needs it -- and pi' g is the same
-//      16-lane reduction repeated by every row on the same data (same order: same bits everywhere).
-// One barrier per candidate (s_waitcnt lgkmcnt(0) + s_barrier: the prefetch of the next candidates' pi stays in flight), behind it
-// 3 + q / 16 LDS reads per thread.  S is updated as a full symmetric matrix (rows and columns > j; the register kernel kept the lower
-// part: the lower entries see the same operations).  The kernel is bound by VALU issue (16 waves, ~300 instructions per wave and
-// candidate): hence the accept test by a product (the quotient only when the two are within 1e-13 of each other) and DPP moves without an
-// `old` operand.  Same arithmetic per entry as before except for the order of the q-term sums.
-__device__ __forceinline__ unsigned dlo(double x) { return (unsigned)(unsigned long long)__double_as_longlong(x); }
-__device__ __forceinline__ unsigned dhi(double x) { return (unsigned)((unsigned long long)__double_as_longlong(x) >> 32); }
-__device__ __forceinline__ double dmk(unsigned lo, unsigned hi) { return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo)); }
-template <int CTRL>
-__device__ __forceinline__ double dpp_d(double x) {  // (bound_ctrl with full masks: every lane is written, no `old` value to set up)
-    return dmk((unsigned)__builtin_amdgcn_update_dpp(0, (int)dlo(x), CTRL, 0xf, 0xf, true),
-               (unsigned)__builtin_amdgcn_update_dpp(0, (int)dhi(x), CTRL, 0xf, 0xf, true));
-}
-__device__ __forceinline__ double row_allreduce(double x) {  // every lane of a 16-lane row: the row's sum (rotations by 8, 4, 2, 1)
-    x += dpp_d<0x128>(x);
-    x += dpp_d<0x124>(x);
-    x += dpp_d<0x122>(x);
-    x += dpp_d<0x121>(x);
-    return x;
-}
-__device__ __forceinline__ double readlane_d(double x, int l) {
-    return dmk((unsigned)__builtin_amdgcn_readlane((int)dlo(x), l), (unsigned)__builtin_amdgcn_readlane((int)dhi(x), l));
-}
-template <int TW, int NA, int NB_>  // waves; rows of G per 16-lane row (q <= 4 TW NA); columns of G per lane (q <= 16 NB_)
-__global__ __launch_bounds__(64 * TW) void select_block_walk_kernel(const double *__restrict__ Sg, int b, int64_t i0, int n0, int q, int max_points,
-                                                                    int maxacc, double thr, const double *__restrict__ Prow,
-                                                                    double *__restrict__ Ginv, int *__restrict__ acc, int *__restrict__ cnt,
-                                                                    double *__restrict__ Lblk, int *__restrict__ blkidx) {
-    static_assert(SB == 128 && (TW == 8 || TW == 16) && NB_ <= 12, "thread -> entry maps");
-    constexpr int RK = SB / TW;                                            // rows of S per wave: w + TW k
-    constexpr int GL = (4 * TW * NA > 16 * NB_) ? 4 * TW * NA : 16 * NB_;  // rows of G of a 16-lane row: w + TW rho + 4 TW a
-    constexpr bool DEEP = NB_ <= 5;  // pi two candidates ahead (registers permitting), else one
-    __shared__ double cj_s[2][SB];   // column j of S (double buffered: a slow wave may still read the previous candidate's)
-    __shared__ double g_s[2][GL];    // g = G pi
-    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, rho = lane >> 4, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    double Sr[2][RK];
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int k = 0; k < RK; ++k) Sr[h][k] = Sg[(w + TW * k) + (lane + 64 * h) * SB];
-    double G[NA][NB_];
-#pragma unroll
-    for (int a = 0; a < NA; ++a)
-#pragma unroll
-        for (int bb = 0; bb < NB_; ++bb) {
-            const int t = w + TW * rho + 4 * TW * a, u = l15 + 16 * bb;
-            G[a][bb] = (t < q && u < q) ? Ginv[t + (int64_t)u * q] : 0.0;
-        }
-    int nacc = cnt[0], nblk = 0;
-    double p0[NB_], p1[NB_];  // pi of this candidate and the next (DEEP: the one after is fetched inside the step)
-#pragma unroll
-    for (int bb = 0; bb < NB_; ++bb) {
-        const int u = l15 + 16 * bb;
-        p0[bb] = (u < q && b > 0) ? Prow[i0 * q + u] : 0.0;
-        p1[bb] = (DEEP && u < q && b > 1) ? Prow[(i0 + 1) * q + u] : 0.0;
-    }
-    for (int e = tid; e < 2 * GL; e += 64 * TW) (&g_s[0][0])[e] = 0.0;
-    // every load of the prologue has landed before the loop: inside it the compiler then has nothing older than the pi prefetch to
-    // wait for (it merged the prologue's pending loads into the loop header and drained the memory queue at the top of every step)
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int k = 0; k < RK; ++k) asm volatile("" : "+v"(Sr[h][k]));
-#pragma unroll
-    for (int a = 0; a < NA; ++a)
-#pragma unroll
-        for (int bb = 0; bb < NB_; ++bb) asm volatile("" : "+v"(G[a][bb]));
-#pragma unroll
-    for (int bb = 0; bb < NB_; ++bb) {
-        asm volatile("" : "+v"(p0[bb]));
-        asm volatile("" : "+v"(p1[bb]));
-    }
-    __syncthreads();
-    for (int j = 0; j < b; ++j) {
-        if (n0 + nacc >= max_points || nacc >= maxacc) break;
-        double p2[NB_];
-#pragma unroll
-        for (int bb = 0; bb < NB_; ++bb) {
-            const int u = l15 + 16 * bb, ahead = DEEP ? 2 : 1;
-            p2[bb] = (u < q && j + ahead < b) ? Prow[(i0 + j + ahead) * q + u] : 0.0;
-        }
-        const int par = j & 1, lj = j & 63;
-        double cr[RK];  // S(w + TW k, j): wave-uniform
-        if (j < 64) {
-#pragma unroll
-            for (int k = 0; k < RK; ++k) cr[k] = readlane_d(Sr[0][k], lj);
-            if (lane == lj) {
-#pragma unroll
-                for (int k = 0; k < RK; ++k) cj_s[par][w + TW * k] = Sr[0][k];
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < RK; ++k) cr[k] = readlane_d(Sr[1][k], lj);
-            if (lane == lj) {
-#pragma unroll
-                for (int k = 0; k < RK; ++k) cj_s[par][w + TW * k] = Sr[1][k];
-            }
-        }
-        double v[NA];  // g at this 16-lane row's rows
-#pragma unroll
-        for (int a = 0; a < NA; ++a) {
-            double sp = 0.0;
-#pragma unroll
-            for (int bb = 0; bb < NB_; ++bb) sp = fma(G[a][bb], p0[bb], sp);
-            v[a] = row_allreduce(sp);
-        }
-        if (l15 == 0) {
-#pragma unroll
-            for (int a = 0; a < NA; ++a) g_s[par][w + TW * rho + 4 * TW * a] = v[a];
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        double gu[NB_];
-#pragma unroll
-        for (int bb = 0; bb < NB_; ++bb) gu[bb] = g_s[par][l15 + 16 * bb];
-        const double cc0 = cj_s[par][lane], cc1 = cj_s[par][lane + 64];
-        const double pk = cj_s[par][j];
-        double pp = 0.0;
-#pragma unroll
-        for (int bb = 0; bb < NB_; ++bb) pp = fma(p0[bb], gu[bb], pp);
-        const double ph = 1.0 + row_allreduce(pp);
-#pragma unroll
-        for (int bb = 0; bb < NB_; ++bb) {
-            p0[bb] = DEEP ? p1[bb] : p2[bb];
-            p1[bb] = p2[bb];
-        }
-        // tau^2 = pk / ph > (theta^2)^2, RbfModel.jl:370, :452 (NaN fails): decided by the product unless the two sides are within 1e-13
-        const double tp = thr * ph;
-        bool accept = pk > 0.0 && pk > tp && pk < 1e300 * ph;
-        if (fabs(pk - tp) <= 1e-13 * tp) {
-            const double tau2 = pk / ph;
-            accept = pk > 0.0 && tau2 > thr && tau2 < 1e300;
-        }
-        if (!accept) continue;
-        double sq_, rs;
-        fast_sqrt_rsqrt(pk, sq_, rs);
-        (void)sq_;
-        if (tid < SB) {
-            const double cme = tid < 64 ? cc0 : cc1;
-            Lblk[tid + nblk * SB] = (tid > j && tid < b) ? cme * rs : (tid == j ? pk * rs : 0.0);
-        }
-        const double lc0 = (lane > j) ? cc0 * rs : 0.0, lc1 = (lane + 64 > j) ? cc1 * rs : 0.0;
-#pragma unroll
-        for (int k = 0; k < RK; ++k) {
-            const double lr = ((w + TW * k > j) ? cr[k] : 0.0) * rs;
-            Sr[0][k] = fma(-lr, lc0, Sr[0][k]);
-            Sr[1][k] = fma(-lr, lc1, Sr[1][k]);
-        }
-        // Ginv <- Ginv - g g' / s_H   (Sherman-Morrison for G + pi pi'), one reciprocal per candidate as in the register kernel
-        double rph = __builtin_amdgcn_rcp(ph);
-        rph = fma(fma(-ph, rph, 1.0), rph, rph);
-        rph = fma(fma(-ph, rph, 1.0), rph, rph);
-#pragma unroll
-        for (int a = 0; a < NA; ++a) {
-            const double gt = v[a] * rph;
-#pragma unroll
-            for (int bb = 0; bb < NB_; ++bb) G[a][bb] = fma(-gt, gu[bb], G[a][bb]);
-        }
-        if (tid == 0) {
-            acc[nacc] = (int)(i0 + j);
-            blkidx[nblk] = j;
-        }
-        ++nacc;
-        ++nblk;
-    }
-#pragma unroll
-    for (int a = 0; a < NA; ++a)
-#pragma unroll
-        for (int bb = 0; bb < NB_; ++bb) {
-            const int t = w + TW * rho + 4 * TW * a, u = l15 + 16 * bb;
             if (t < q && u < q) Ginv[t + (int64_t)u * q] = G[a][bb];
         }
     if (tid == 0) {
@@ -1060,7 +874,6 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
         // the register variant of the decision kernel: q <= 80 (2 x 5 entries of Ginv per thread) or q <= 128 (2 x 8); needs q >= 1
         const int sel_env = getenv("MRBF_R4_SELECT") ? atoi(getenv("MRBF_R4_SELECT")) : 2;  // 0: S and Ginv through memory; 1: registers, three barriers; 2: the one-barrier walk
         const bool walk_sel = sel_env >= 2 && q >= 1 && q <= 144;  // (beyond: the register kernel; the walk's <8, 6, 12> shape spills)
-        const int walkw = getenv("MRBF_R4_WALKW") ? atoi(getenv("MRBF_R4_WALKW")) : 8;  // waves of the walk kernel for q <= 80 (8 or 16; d = 64: 8.8 against 9.2 ms)
         // (3: q <= 192 -- d = 128 has q = 129 -- three rows x twelve columns of Ginv per thread)
         const int fast_sel = (sel_env && q >= 1 && q <= 80) ? 1 : ((sel_env && q >= 1 && q <= 128) ? 2 : ((sel_env && q >= 1 && q <= 192) ? 3 : 0));
         const size_t shm_reg = ((size_t)SB * SB + 2 * (size_t)std::max(q, 1) + 16 * (size_t)std::max(q, 1) + 16) * sizeof(double);
@@ -1178,16 +991,15 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
             }
             if (walk_sel) {
 #define MRBF_R4_WALK(TW_, NA_, NB__)                                                                                                              \
-    hipLaunchKernelGGL((select_block_walk_kernel<TW_, NA_, NB__>), dim3(1), dim3(64 * TW_), 0, s, Sb, bsz, i0, (int)n0, q, (int)max_points, maxacc, thr, \
-                       st->Prow, st->Ginv, st->acc, cnt, Lblk, blkidx)
-                // sixteen waves while Ginv, pi and g fit their 128 registers (q <= 80), eight beyond
-                if (q <= 32 && walkw == 16)
-                    MRBF_R4_WALK(16, 1, 2);
-                else if (q <= 64 && walkw == 16)
-                    MRBF_R4_WALK(16, 1, 4);
-                else if (q <= 80 && walkw == 16)
-                    MRBF_R4_WALK(16, 2, 5);
-                else if (q <= 32)
+    do {                                                                                                                                          \
+        const size_t pis = (size_t)SB * 16 * NB__ * sizeof(double);                                                                               \
+        if (blkno == 1)                                                                                                                           \
+            MRBF_HIP(ctx, hipFuncSetAttribute((const void *)select_block_walk_kernel<TW_, NA_, NB__>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                              (int)pis));                                                                                         \
+        hipLaunchKernelGGL((select_block_walk_kernel<TW_, NA_, NB__>), dim3(1), dim3(64 * TW_), pis, s, Sb, bsz, i0, (int)n0, q, (int)max_points, \
+                           maxacc, thr, st->Prow, st->Ginv, st->acc, cnt, Lblk, blkidx, (unsigned long long *)nullptr);                           \
+    } while (0)
+                if (q <= 32)
                     MRBF_R4_WALK(8, 1, 2);
                 else if (q <= 64)
                     MRBF_R4_WALK(8, 2, 4);
