@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void kappa_block_kernel(const double *__restri
                                                           const double *__restrict__ P0c, const double *__restrict__ F, int n0, int have_tail,
                                                           const int *__restrict__ acc, int nacc, int64_t i0, int b, KP kp,
                                                           double *__restrict__ Kab, int ld, double *__restrict__ S, int blockrows,
-                                                          int64_t batch_total = 0) {
+                                                          int64_t batch_total = 0, int64_t rbase = -1, int rcount = 0) {
     static_assert(RT == 1, "one row of entries per thread");
     if (batch_total > 0) {  // blockIdx.z = block number: kappa(block, block) of every block of the walk in one launch (S: SB x SB per block)
         const int64_t off = (int64_t)blockIdx.z * SB;
@@ -122,10 +122,11 @@ __global__ __launch_bounds__(256) void kappa_block_kernel(const double *__restri
     static_assert(NR * (KD + 1) <= 3 * NR * (KT + 1), "the distance tile fits the tail tiles' area");
     __shared__ int64_t rid[NR];  // global site of a tile row (0 .. TR-1) / column (TR ..), -1 outside
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    const int R0 = blockIdx.y * TR, C0 = blockIdx.x * 64, nrows = nacc + (blockrows ? b : 0);  // (blockrows = 0: the listed rows only, any number of columns)
+    const int R0 = blockIdx.y * TR, C0 = blockIdx.x * 64;
+    const int nrows = nacc + (rbase >= 0 ? rcount : (blockrows ? b : 0));  // (blockrows = 0: the listed rows only, any number of columns; rbase: rcount rows of another block)
     if (tid < TR) {
         const int rr = R0 + tid;
-        rid[tid] = rr < nacc ? (int64_t)acc[rr] : (rr < nrows ? i0 + (rr - nacc) : -1);
+        rid[tid] = rr < nacc ? (int64_t)acc[rr] : (rr < nrows ? (rbase >= 0 ? rbase : i0) + (rr - nacc) : -1);  // (rbase: block rows from another block)
     } else if (tid < NR) {
         const int c = C0 + tid - TR;
         rid[tid] = c < b ? i0 + c : -1;
@@ -489,14 +490,20 @@ __global__ __launch_bounds__(64) void block_forward_kernel(const double *__restr
 // + s for MFMA step s: the same permutation on both sides).  Workgroup = 128 rows a x 64 columns j (wave w: 32 rows), grid (ncols / 64,
 // ksplit); fragments double buffered in registers, no LDS.  lda, ldb multiples of 4 (32-byte aligned fragments).
 __global__ __launch_bounds__(256, 2) void r4_tn_gemm_kernel(const double *__restrict__ A, int lda, const double *__restrict__ B, int64_t ldb, int K,
-                                                            int64_t ncols, int kchunk, double *__restrict__ P, int64_t pstride) {
+                                                            int64_t ncols, int kchunk, double *__restrict__ P, int64_t pstride,
+                                                            const int *__restrict__ aidx = nullptr, int na = 0) {
     typedef double v4d __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
     const int64_t j0 = (int64_t)blockIdx.x * 64;
     const int k0 = blockIdx.y * kchunk, k1 = min(K, k0 + kchunk);
     const double *ap[2], *bp[4];
 #pragma unroll
-    for (int it = 0; it < 2; ++it) ap[it] = A + (int64_t)(32 * wave + 16 * it + l15) * lda + 4 * l4;
+    for (int it = 0; it < 2; ++it) {
+        // (aidx: column a of the left operand is column aidx[a] of A -- the new sites' columns of R, read in place -- for a < na)
+        const int a = 32 * wave + 16 * it + l15;
+        const int64_t col = aidx ? (a < na ? aidx[a] : 0) : a;
+        ap[it] = A + col * lda + 4 * l4;
+    }
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) {
         int64_t j = j0 + 16 * jt + l15;
@@ -573,7 +580,8 @@ constexpr size_t fwm_shm_bytes(int ncol) { return ((size_t)SB * (SB + 1) / 2 + (
 template <int NCOL>  // candidates per workgroup: 64 (one wave per 16) or 16 (few columns: more workgroups, every load of a thread in flight at once)
 __global__ __launch_bounds__(256) void block_forward_mfma_kernel(const double *__restrict__ Kn, const double *__restrict__ P, int ksplit, int64_t pstride,
                                                                 const double *__restrict__ Lblk, const int *__restrict__ blkidx, int nblk, int64_t ncols,
-                                                                double *__restrict__ Rout, int64_t ldr) {
+                                                                double *__restrict__ Rout, int64_t ldr, int kn_by_idx = 0) {
+    // (kn_by_idx: Kn holds kappa(every candidate of the block, .), row a of the system is its row blkidx[a])
     typedef double v4d __attribute__((ext_vector_type(4)));
     extern __shared__ double fwm_smem[];  // Lt[SB (SB + 1) / 2] | Iv[8][16][17] | Xt[NCOL][FWM_LDR] | bi[SB]
     double *Lt = fwm_smem, *Iv = Lt + SB * (SB + 1) / 2, *Xt = Iv + 8 * 16 * 17;
@@ -599,13 +607,14 @@ __global__ __launch_bounds__(256) void block_forward_mfma_kernel(const double *_
        // slices subtracted in their fixed order
         const int a = tid & 127, c0 = tid >> 7;
         const bool ain = a < nblk;
+        const int ka = kn_by_idx ? bi[a] : a;
 #pragma unroll 1
         for (int u0 = 0; u0 < NCOL / 2; u0 += 8) {
             double v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int64_t j = jbase + c0 + 2 * (u0 + u);
-                v[u] = (j < ncols && ain) ? Kn[a + j * SB] : 0.0;
+                v[u] = (j < ncols && ain) ? Kn[ka + j * SB] : 0.0;
             }
 #pragma unroll 1
             for (int s0 = 0; s0 < ksplit; s0 += 8) {
@@ -912,11 +921,12 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
         constexpr int KSPLIT_NEAR = 32;
         const bool own_schur = custom && (getenv("MRBF_R4_SCHUR") ? atoi(getenv("MRBF_R4_SCHUR")) != 0 : true);
         const int64_t nblocks = (mc + SB - 1) / SB;
-        double *KbbAll = nullptr, *Spart = nullptr, *Pnear = nullptr;
+        double *KbbAll = nullptr, *Spart = nullptr, *Pnear = nullptr, *Kpre = nullptr;
         if (own_schur) {
             MRBF_TRY(get_buf(ctx, S_OUT_A, (size_t)SB * SB * nblocks, &KbbAll));
-            MRBF_TRY(get_buf(ctx, S_STAGE_B, (size_t)2 * KSPLIT_NEAR * SB * SB, &Spart));
+            MRBF_TRY(get_buf(ctx, S_STAGE_B, (size_t)(2 * KSPLIT_NEAR + 1) * SB * SB, &Spart));
             Pnear = Spart + (size_t)KSPLIT_NEAR * SB * SB;  // the k slices of the next block's update (few columns: split 32 ways)
+            Kpre = Pnear + (size_t)KSPLIT_NEAR * SB * SB;   // kappa(every candidate of the block, the next block's columns)
         }
         MRBF_TRY(get_buf(ctx, S_Q1, (size_t)maxacc * SB, &Rb));          // R = L_acc^-1 K[acc, block]
         MRBF_TRY(get_buf(ctx, S_RHS, (size_t)3 * SB * SB, &Sb));          // Schur complement of the block | in-block factor columns (two: see below)
@@ -930,6 +940,9 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
         // reads or writes (Anew, Kn, Ppart, the next block's columns of R).
         const bool split = eager && custom && (getenv("MRBF_R4_SPLIT") ? atoi(getenv("MRBF_R4_SPLIT")) != 0 : true) && ctx->bulk_stream && ctx->evx[0];
         hipStream_t sfar = split ? ctx->bulk_stream : s;
+        // kappa(block, next block) for ALL the block's candidates on the side stream while they are being decided: the update of the next
+        // block's columns then starts from rows picked out of it instead of a kappa launch of its own on the critical path
+        const bool prek = split && own_schur && ctx->evx[2] && (getenv("MRBF_R4_PREK") ? atoi(getenv("MRBF_R4_PREK")) != 0 : true);
         bool far_pending = false;
         int64_t far_from = 0;  // first candidate of the side stream's pending update
         if (eager) {
@@ -946,6 +959,10 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
                                                          q > 0 ? 1 : 0, st->acc, 0, (int64_t)0, SB, kp, (double *)nullptr, 0, KbbAll, 1, mc));
         }
         int blkno = 0;
+        if (prek) {  // the side stream's first kernel reads what the main stream has just set up (lambda, F, the candidates' coordinates)
+            MRBF_HIP(ctx, hipEventRecord(ctx->evx[0], s));
+            MRBF_HIP(ctx, hipStreamWaitEvent(sfar, ctx->evx[0], 0));
+        }
         MRBF_HIP(ctx, hipMemsetAsync(cnt, 0, 8 * sizeof(int), s));
         MRBF_HIP(ctx, hipMemsetAsync(st->LK, 0, (size_t)maxacc * maxacc * sizeof(double), s));
         int nacc = 0;
@@ -960,6 +977,15 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
             int *const blkidx = blkidx2[blkno & 1];
             ++blkno;
             if (eager) Rb = Rfull + i0 * (int64_t)ldr;  // this block's columns of R are up to date: every earlier block extended them
+            const int64_t near_next = std::min<int64_t>(SB, mc - (i0 + bsz));
+            const bool have_prek = prek && near_next > 0;
+            if (have_prek) {
+                const dim3 kgrid((unsigned)((near_next + 63) / 64), (unsigned)((bsz + 15) / 16));
+                MRBF_DISPATCH_KID(kp.kid, hipLaunchKernelGGL((kappa_block_kernel<KID, 1>), kgrid, dim3(256), 0, sfar, st->Xc, d, st->LamT, st->P0c, F, (int)n0,
+                                                             q > 0 ? 1 : 0, st->acc, 0, i0 + bsz, (int)near_next, kp, (double *)nullptr, 0, Kpre, 1,
+                                                             (int64_t)0, i0, bsz));
+                MRBF_HIP(ctx, hipEventRecord(ctx->evx[2], sfar));
+            }
             if (own_schur) {
                 int ks = 0;
                 if (nacc > 0) {
@@ -1028,11 +1054,17 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
             else
                 hipLaunchKernelGGL(select_block_kernel, dim3(1), dim3(SEL_THREADS), shm, s, Sb, bsz, i0, (int)n0, q, (int)max_points, maxacc, thr, st->Prow,
                                    st->Ginv, st->acc, cnt, Lblk, blkidx);
-            hipLaunchKernelGGL(append_rows_kernel, dim3(nb((int64_t)SB * (nacc + SB))), dim3(256), 0, s, Rb, ldr, nacc, Lblk, blkidx, cnt, st->LK, maxacc);
             int hc_local[2] = {0, 0};
             int *hc = ctx->hpin ? reinterpret_cast<int *>(ctx->hpin + HPIN_R4_COUNT) : hc_local;  // (pinned: the download does not cost a round trip of its own)
             MRBF_HIP(ctx, hipMemcpyAsync(hc, cnt, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
-            MRBF_HIP(ctx, hipStreamSynchronize(s));  // the next block's shapes depend on the number accepted so far
+            // the next block's shapes depend on the number accepted so far: the host waits for the counts only, the factor's new rows are
+            // appended under the round trip
+            if (ctx->evx[3]) MRBF_HIP(ctx, hipEventRecord(ctx->evx[3], s));
+            hipLaunchKernelGGL(append_rows_kernel, dim3(nb((int64_t)SB * (nacc + SB))), dim3(256), 0, s, Rb, ldr, nacc, Lblk, blkidx, cnt, st->LK, maxacc);
+            if (ctx->evx[3])
+                MRBF_HIP(ctx, hipEventSynchronize(ctx->evx[3]));
+            else
+                MRBF_HIP(ctx, hipStreamSynchronize(s));
             const int nacc_old = nacc, nblk = hc[1];
             nacc = hc[0];
             const int64_t i1 = i0 + bsz, ahead = mc - i1;
@@ -1042,12 +1074,18 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
                 // (is_near: the next block's columns, on the critical path: the product split 32 ways into its own small slice buffer and the
                 // substitution in 16-column workgroups)
                 auto extend = [&](int64_t j0, int64_t ncols, hipStream_t su, bool is_near) -> int {
-                    const dim3 kgrid((unsigned)((ncols + 63) / 64), (unsigned)((nblk + 15) / 16));
-                    MRBF_DISPATCH_KID(kp.kid, hipLaunchKernelGGL((kappa_block_kernel<KID, 1>), kgrid, dim3(256), 0, su, st->Xc, d, st->LamT, st->P0c, F,
-                                                                 (int)n0, q > 0 ? 1 : 0, st->acc + nacc_old, nblk, j0, (int)ncols, kp, Kn + j0 * SB, SB,
-                                                                 (double *)nullptr, 0));
-                    int ksplit = 0;
                     const bool small = is_near && Pnear && ncols <= SB;
+                    const bool pre = small && have_prek;  // kappa(block, these columns) is there already, for every candidate of the block
+                    if (pre) {
+                        MRBF_HIP(ctx, hipStreamWaitEvent(su, ctx->evx[2], 0));
+                    } else {
+                        const dim3 kgrid((unsigned)((ncols + 63) / 64), (unsigned)((nblk + 15) / 16));
+                        MRBF_DISPATCH_KID(kp.kid, hipLaunchKernelGGL((kappa_block_kernel<KID, 1>), kgrid, dim3(256), 0, su, st->Xc, d, st->LamT, st->P0c, F,
+                                                                     (int)n0, q > 0 ? 1 : 0, st->acc + nacc_old, nblk, j0, (int)ncols, kp, Kn + j0 * SB, SB,
+                                                                     (double *)nullptr, 0));
+                    }
+                    const double *const Kin = pre ? Kpre : Kn + j0 * SB;
+                    int ksplit = 0;
                     double *const Pb = small ? Pnear : Ppart + j0 * SB;
                     const int64_t ps = small ? (int64_t)SB * SB : pstride;
                     if (nacc_old > 0) {
@@ -1057,26 +1095,27 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
                             ksplit = std::max(1, std::min({small ? KSPLIT_NEAR : KSPLIT_MAX, (512 + ntile - 1) / ntile, (nacc_old + 63) / 64}));
                             const int kchunk = (int)round_up((nacc_old + ksplit - 1) / ksplit, 16);
                             ksplit = (nacc_old + kchunk - 1) / kchunk;
-                            hipLaunchKernelGGL(r4_tn_gemm_kernel, dim3((unsigned)ntile, (unsigned)ksplit), dim3(256), 0, su, Anew, ldr,
-                                               Rfull + j0 * (int64_t)ldr, (int64_t)ldr, nacc_old, ncols, kchunk, Pb, ps);
+                            // (left operand: the new sites' columns of R in place, through the block's index list)
+                            hipLaunchKernelGGL(r4_tn_gemm_kernel, dim3((unsigned)ntile, (unsigned)ksplit), dim3(256), 0, su, Rfull + i0 * (int64_t)ldr, ldr,
+                                               Rfull + j0 * (int64_t)ldr, (int64_t)ldr, nacc_old, ncols, kchunk, Pb, ps, blkidx, nblk);
                         } else {
                             MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, nblk, (int)ncols, nacc_old, &mone,
                                                          Anew, ldr, Rfull + j0 * (int64_t)ldr, ldr, &one, Kn + j0 * SB, SB));
                         }
                     }
                     if (custom && ncols <= 1024)
-                        hipLaunchKernelGGL(block_forward_mfma_kernel<16>, dim3((unsigned)((ncols + 15) / 16)), dim3(256), fwm_shm_bytes(16), su, Kn + j0 * SB, Pb,
-                                           ksplit, ps, Lblk, blkidx, nblk, ncols, Rfull + j0 * (int64_t)ldr + nacc_old, (int64_t)ldr);
+                        hipLaunchKernelGGL(block_forward_mfma_kernel<16>, dim3((unsigned)((ncols + 15) / 16)), dim3(256), fwm_shm_bytes(16), su, Kin, Pb, ksplit, ps,
+                                           Lblk, blkidx, nblk, ncols, Rfull + j0 * (int64_t)ldr + nacc_old, (int64_t)ldr, pre ? 1 : 0);
                     else if (custom)
-                        hipLaunchKernelGGL(block_forward_mfma_kernel<64>, dim3((unsigned)((ncols + 63) / 64)), dim3(256), fwm_shm_bytes(64), su, Kn + j0 * SB, Pb,
-                                           ksplit, ps, Lblk, blkidx, nblk, ncols, Rfull + j0 * (int64_t)ldr + nacc_old, (int64_t)ldr);
+                        hipLaunchKernelGGL(block_forward_mfma_kernel<64>, dim3((unsigned)((ncols + 63) / 64)), dim3(256), fwm_shm_bytes(64), su, Kin, Pb, ksplit, ps,
+                                           Lblk, blkidx, nblk, ncols, Rfull + j0 * (int64_t)ldr + nacc_old, (int64_t)ldr, 0);
                     else
                         hipLaunchKernelGGL(block_forward_kernel, dim3((unsigned)((ncols + 63) / 64)), dim3(64), (size_t)SB * 64 * sizeof(double) + SB * sizeof(int),
                                            su, Kn + j0 * SB, SB, Lblk, blkidx, nblk, ncols, Rfull + j0 * (int64_t)ldr + nacc_old, ldr);
                     return 0;
                 };
                 if (far_pending) MRBF_HIP(ctx, hipStreamWaitEvent(s, ctx->evx[1], 0));  // the side stream's update of the block before
-                if (nacc_old > 0)
+                if (nacc_old > 0 && !custom)
                     hipLaunchKernelGGL(gather_newcols_kernel, dim3(nb((int64_t)nacc_old * nblk)), dim3(256), 0, s, Rfull, ldr, nacc_old, i0, blkidx, nblk,
                                        Anew, ldr);
                 // the next block's columns first, alone on the device (started together, the far update's 150 workgroups doubled the
