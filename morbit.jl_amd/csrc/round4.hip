@@ -882,6 +882,7 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
         MRBF_HIP(ctx, hipFuncSetAttribute((const void *)select_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
         // the register variant of the decision kernel: q <= 80 (2 x 5 entries of Ginv per thread) or q <= 128 (2 x 8); needs q >= 1
         const int sel_env = getenv("MRBF_R4_SELECT") ? atoi(getenv("MRBF_R4_SELECT")) : 2;  // 0: S and Ginv through memory; 1: registers, three barriers; 2: the one-barrier walk
+        const bool duo = getenv("MRBF_R4_DUO") ? atoi(getenv("MRBF_R4_DUO")) != 0 : true;
         const bool walk_sel = sel_env >= 2 && q >= 1 && q <= 144;  // (beyond: the register kernel; the walk's <8, 6, 12> shape spills)
         // (3: q <= 192 -- d = 128 has q = 129 -- three rows x twelve columns of Ginv per thread)
         const int fast_sel = (sel_env && q >= 1 && q <= 80) ? 1 : ((sel_env && q >= 1 && q <= 128) ? 2 : ((sel_env && q >= 1 && q <= 192) ? 3 : 0));
@@ -1025,7 +1026,23 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
         hipLaunchKernelGGL((select_block_walk_kernel<TW_, NA_, NB__>), dim3(1), dim3(64 * TW_), pis, s, Sb, bsz, i0, (int)n0, q, (int)max_points, \
                            maxacc, thr, st->Prow, st->Ginv, st->acc, cnt, Lblk, blkidx, (unsigned long long *)nullptr);                           \
     } while (0)
-                if (q <= 32)
+#define MRBF_R4_DUO(N_)                                                                                                                             \
+    do {                                                                                                                                            \
+        const size_t pis = (size_t)SB * 16 * N_ * sizeof(double);                                                                                   \
+        if (blkno == 1)                                                                                                                             \
+            MRBF_HIP(ctx, hipFuncSetAttribute((const void *)select_block_duo_kernel<N_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pis));     \
+        hipLaunchKernelGGL((select_block_duo_kernel<N_>), dim3(1), dim3(512), pis, s, Sb, bsz, i0, (int)n0, q, (int)max_points, maxacc, thr, st->Prow, \
+                           st->Ginv, st->acc, cnt, Lblk, blkidx, (unsigned long long *)nullptr);                                                    \
+    } while (0)
+                // q <= 80: the two halves of a step on different waves (same bits; 119 against 140 us per block at q = 65); beyond, the G waves'
+                // share (2 q^2 / 256 entries per thread + q / 16 row sums) outweighs the S waves' and every wave does both
+                if (q <= 32 && duo)
+                    MRBF_R4_DUO(2);
+                else if (q <= 64 && duo)
+                    MRBF_R4_DUO(4);
+                else if (q <= 80 && duo)
+                    MRBF_R4_DUO(5);
+                else if (q <= 32)
                     MRBF_R4_WALK(8, 1, 2);
                 else if (q <= 64)
                     MRBF_R4_WALK(8, 2, 4);
@@ -1035,6 +1052,7 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
                     MRBF_R4_WALK(8, 4, 8);
                 else
                     MRBF_R4_WALK(8, 5, 9);
+#undef MRBF_R4_DUO
 #undef MRBF_R4_WALK
             } else if (fast_sel == 1 && selw == 8)
                 hipLaunchKernelGGL((select_block_reg_kernel<2, 10, 8>), dim3(1), dim3(512), shm_reg, s, Sb, bsz, i0, (int)n0, q, (int)max_points, maxacc,

@@ -74,9 +74,18 @@ __global__ __launch_bounds__(64 * TW) void select_block_walk_kernel(const double
             G[a][bb] = (t < q && u < q) ? Ginv[t + (int64_t)u * q] : 0.0;
         }
     int nacc = cnt[0], nblk = 0;
-    for (int e = tid; e < b * 16 * NB_; e += 64 * TW) {
-        const int jj = e / (16 * NB_), u = e % (16 * NB_);
-        pi_s[e] = u < q ? Prow[(i0 + jj) * q + u] : 0.0;
+    for (int e0 = 0; e0 < b * 16 * NB_; e0 += 8 * 64 * TW) {  // (eight loads in flight per thread: one at a time is 20 L2 round trips)
+        double t[8];
+#pragma unroll
+        for (int x = 0; x < 8; ++x) {
+            const int e = e0 + tid + x * 64 * TW, jj = e / (16 * NB_), u = e % (16 * NB_);
+            t[x] = (e < b * 16 * NB_ && u < q) ? Prow[(i0 + jj) * q + u] : 0.0;
+        }
+#pragma unroll
+        for (int x = 0; x < 8; ++x) {
+            const int e = e0 + tid + x * 64 * TW;
+            if (e < b * 16 * NB_) pi_s[e] = t[x];
+        }
     }
     for (int e = tid; e < 2 * GL; e += 64 * TW) (&g_s[0][0])[e] = 0.0;
     // every load of the prologue has landed before the loop (the compiler otherwise merges the prologue's pending loads into the loop header
@@ -213,6 +222,228 @@ __global__ __launch_bounds__(64 * TW) void select_block_walk_kernel(const double
         cnt[0] = nacc;
         cnt[1] = nblk;
         acc[maxacc] = nacc;
+    }
+}
+
+// tau^2 = pk / ph > (theta^2)^2, RbfModel.jl:370, :452 (NaN fails): decided by the product unless the two sides are within 1e-13
+__device__ __forceinline__ bool walk_accept(double pk, double ph, double thr) {
+    const double tp = thr * ph;
+    bool accept = pk > 0.0 && pk > tp && pk < 1e300 * ph;
+    if (fabs(pk - tp) <= 1e-13 * tp) {
+        const double tau2 = pk / ph;
+        accept = pk > 0.0 && tau2 > thr && tau2 < 1e300;
+    }
+    return accept;
+}
+
+// ---- The same walk with the two halves of a step on different waves.  In the kernel above every wave does its share of both updates one
+// after the other, and a step is one dependent chain: G pi -> row sums -> barrier -> pi' g -> decision -> S update -> G update (1.1 us per
+// candidate at q = 65, 1.5 at q = 129, VALU issue and latency about even).  Here waves 0-3 own S (8 x 8 tiles), waves 4-7 own G (rows
+// w + 4 rho + 16 a of the 16-lane row rho, columns l + 16 b): each SIMD holds one wave of either kind, the S update runs under the other
+// wave's G update and row sums, and both kinds take the decision themselves from the same published g and row j (same sums in the same
+// order: same bits).  One barrier per candidate, crossed by all eight waves.
+template <int N, bool PROF = false>  // q <= 16 N
+__global__ __launch_bounds__(512) void select_block_duo_kernel(const double *__restrict__ Sg, int b, int64_t i0, int n0, int q, int max_points, int maxacc,
+                                                               double thr, const double *__restrict__ Prow, double *__restrict__ Ginv,
+                                                               int *__restrict__ acc, int *__restrict__ cnt, double *__restrict__ Lblk,
+                                                               int *__restrict__ blkidx, unsigned long long *__restrict__ prof = nullptr) {
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    static_assert(SB == 128 && N <= 9, "thread -> entry maps");
+    constexpr int GL = 16 * N;
+    __shared__ __attribute__((aligned(16))) double cj_s[2][SB];  // row j of S, double buffered
+    __shared__ double g_s[2][GL];                                  // g = G pi
+    extern __shared__ double pi_s[];                               // pi of the block's candidates, [b][16 N] (zero beyond q)
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, rho = lane >> 4, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int nacc = cnt[0], nblk = 0;
+    for (int e0 = 0; e0 < b * GL; e0 += 8 * 512) {  // (eight loads in flight per thread: one at a time is 20 L2 round trips)
+        double t[8];
+#pragma unroll
+        for (int x = 0; x < 8; ++x) {
+            const int e = e0 + tid + x * 512, jj = e / GL, u = e % GL;
+            t[x] = (e < b * GL && u < q) ? Prow[(i0 + jj) * q + u] : 0.0;
+        }
+#pragma unroll
+        for (int x = 0; x < 8; ++x) {
+            const int e = e0 + tid + x * 512;
+            if (e < b * GL) pi_s[e] = t[x];
+        }
+    }
+    unsigned long long tprof[4] = {0, 0, 0, 0}, tlast = 0;
+    auto stamp = [&](int ph) {
+        if constexpr (PROF) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            tprof[ph] += t - tlast;
+            tlast = t;
+        }
+    };
+    if (w < 4) {
+        // ---- S waves: thread t owns rows 8 (t >> 4) .., columns 8 (t & 15) .. (read through the transpose: 64 contiguous bytes per row)
+        const int ri = tid >> 4, ci = tid & 15;
+        double Sr[8][8];
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int c = 0; c < 8; c += 2) {
+                const v2d t = *reinterpret_cast<const v2d *>(Sg + (8 * ci + c) + (8 * ri + a) * SB);
+                Sr[a][c] = t.x;
+                Sr[a][c + 1] = t.y;
+            }
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) asm volatile("" : "+v"(Sr[a][c]));
+        __syncthreads();
+        if constexpr (PROF) tlast = __builtin_amdgcn_s_memtime();
+        for (int j = 0; j < b; ++j) {
+            if (n0 + nacc >= max_points || nacc >= maxacc) break;
+            const int par = j & 1;
+            if (ri == (j >> 3)) {  // the sixteen lanes that hold row j
+                v2d *dst = reinterpret_cast<v2d *>(&cj_s[par][8 * ci]);
+                switch (j & 7) {
+#define MRBF_DUO_ROW(A_)                      \
+    case A_:                                  \
+        dst[0] = (v2d){Sr[A_][0], Sr[A_][1]}; \
+        dst[1] = (v2d){Sr[A_][2], Sr[A_][3]}; \
+        dst[2] = (v2d){Sr[A_][4], Sr[A_][5]}; \
+        dst[3] = (v2d){Sr[A_][6], Sr[A_][7]}; \
+        break;
+                    MRBF_DUO_ROW(0) MRBF_DUO_ROW(1) MRBF_DUO_ROW(2) MRBF_DUO_ROW(3) MRBF_DUO_ROW(4) MRBF_DUO_ROW(5) MRBF_DUO_ROW(6) MRBF_DUO_ROW(7)
+#undef MRBF_DUO_ROW
+                }
+            }
+            stamp(0);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            stamp(1);
+            double pp = 0.0;
+#pragma unroll
+            for (int bb = 0; bb < N; ++bb) pp = fma(pi_s[j * GL + l15 + 16 * bb], g_s[par][l15 + 16 * bb], pp);
+            const double pk = cj_s[par][j];
+            double ur[8], uc[8];  // row j at this tile's rows and columns
+#pragma unroll
+            for (int a = 0; a < 8; a += 2) {
+                const v2d t = *reinterpret_cast<const v2d *>(&cj_s[par][8 * ri + a]);
+                ur[a] = t.x;
+                ur[a + 1] = t.y;
+            }
+#pragma unroll
+            for (int c = 0; c < 8; c += 2) {
+                const v2d t = *reinterpret_cast<const v2d *>(&cj_s[par][8 * ci + c]);
+                uc[c] = t.x;
+                uc[c + 1] = t.y;
+            }
+            const double ph = 1.0 + row_allreduce(pp);
+            const bool accept = walk_accept(pk, ph, thr);
+            stamp(2);
+            if (!accept) continue;
+            if (tid < SB) {  // the factor column (two waves): L(r, j) = S(r, j) / sqrt(pk)
+                double sq_, rs;
+                fast_sqrt_rsqrt(pk, sq_, rs);
+                (void)sq_;
+                Lblk[tid + nblk * SB] = (tid > j && tid < b) ? cj_s[par][tid] * rs : (tid == j ? pk * rs : 0.0);
+            }
+            // S(r, c) -= S(r, j) S(j, c) / pk for every entry, one reciprocal per candidate
+            double rpk = __builtin_amdgcn_rcp(pk);
+            rpk = fma(fma(-pk, rpk, 1.0), rpk, rpk);
+            rpk = fma(fma(-pk, rpk, 1.0), rpk, rpk);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) uc[c] *= rpk;
+#pragma unroll
+            for (int a = 0; a < 8; ++a)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) Sr[a][c] = fma(-ur[a], uc[c], Sr[a][c]);
+            if (tid == 0) {
+                acc[nacc] = (int)(i0 + j);
+                blkidx[nblk] = j;
+            }
+            ++nacc;
+            ++nblk;
+            stamp(3);
+        }
+        if (tid == 0) {
+            cnt[0] = nacc;
+            cnt[1] = nblk;
+            acc[maxacc] = nacc;
+        }
+    } else {
+        // ---- G waves
+        const int w2 = w - 4;
+        double G[N][N];
+#pragma unroll
+        for (int a = 0; a < N; ++a)
+#pragma unroll
+            for (int bb = 0; bb < N; ++bb) {
+                const int t = w2 + 4 * rho + 16 * a, u = l15 + 16 * bb;
+                G[a][bb] = (t < q && u < q) ? Ginv[t + (int64_t)u * q] : 0.0;
+            }
+#pragma unroll
+        for (int a = 0; a < N; ++a)
+#pragma unroll
+            for (int bb = 0; bb < N; ++bb) asm volatile("" : "+v"(G[a][bb]));
+        __syncthreads();
+        if constexpr (PROF) tlast = __builtin_amdgcn_s_memtime();
+        double p0[N];
+#pragma unroll
+        for (int bb = 0; bb < N; ++bb) p0[bb] = pi_s[l15 + 16 * bb];
+        for (int j = 0; j < b; ++j) {
+            if (n0 + nacc >= max_points || nacc >= maxacc) break;
+            const int par = j & 1;
+            double v[N];  // g at this 16-lane row's rows
+#pragma unroll
+            for (int a = 0; a < N; ++a) {
+                double sp = 0.0;
+#pragma unroll
+                for (int bb = 0; bb < N; ++bb) sp = fma(G[a][bb], p0[bb], sp);
+                v[a] = sp;
+            }
+#pragma unroll
+            for (int a = 0; a < N; ++a) v[a] = row_allreduce(v[a]);
+            if (l15 == 0) {
+#pragma unroll
+                for (int a = 0; a < N; ++a) g_s[par][w2 + 4 * rho + 16 * a] = v[a];
+            }
+            stamp(0);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            stamp(1);
+            double gu[N];
+#pragma unroll
+            for (int bb = 0; bb < N; ++bb) gu[bb] = g_s[par][l15 + 16 * bb];
+            const double pk = cj_s[par][j];
+            double pp = 0.0;
+#pragma unroll
+            for (int bb = 0; bb < N; ++bb) pp = fma(p0[bb], gu[bb], pp);
+            if (j + 1 < b) {  // (the next candidate's pi: in flight under the decision)
+#pragma unroll
+                for (int bb = 0; bb < N; ++bb) p0[bb] = pi_s[(j + 1) * GL + l15 + 16 * bb];
+            }
+            const double ph = 1.0 + row_allreduce(pp);
+            const bool accept = walk_accept(pk, ph, thr);
+            stamp(2);
+            if (!accept) continue;
+            // Ginv <- Ginv - g g' / s_H   (Sherman-Morrison for G + pi pi'), one reciprocal per candidate as in the register kernel
+            double rph = __builtin_amdgcn_rcp(ph);
+            rph = fma(fma(-ph, rph, 1.0), rph, rph);
+            rph = fma(fma(-ph, rph, 1.0), rph, rph);
+#pragma unroll
+            for (int a = 0; a < N; ++a) {
+                const double gt = v[a] * rph;
+#pragma unroll
+                for (int bb = 0; bb < N; ++bb) G[a][bb] = fma(-gt, gu[bb], G[a][bb]);
+            }
+            ++nacc;
+            ++nblk;
+            stamp(3);
+        }
+#pragma unroll
+        for (int a = 0; a < N; ++a)
+#pragma unroll
+            for (int bb = 0; bb < N; ++bb) {
+                const int t = w2 + 4 * rho + 16 * a, u = l15 + 16 * bb;
+                if (t < q && u < q) Ginv[t + (int64_t)u * q] = G[a][bb];
+            }
+    }
+    if constexpr (PROF) {
+        if (lane == 0 && prof)
+            for (int ph = 0; ph < 4; ++ph) prof[w * 4 + ph] = tprof[ph];
     }
 }
 
