@@ -882,6 +882,9 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
         MRBF_HIP(ctx, hipFuncSetAttribute((const void *)select_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
         // the register variant of the decision kernel: q <= 80 (2 x 5 entries of Ginv per thread) or q <= 128 (2 x 8); needs q >= 1
         const int sel_env = getenv("MRBF_R4_SELECT") ? atoi(getenv("MRBF_R4_SELECT")) : 2;  // 0: S and Ginv through memory; 1: registers, three barriers; 2: the one-barrier walk
+        // the decision kernel asks for (nearly) the whole LDS of its compute unit: no workgroup of the side stream's kappa / substitution
+        // kernels then fits beside it (sharing the unit's VALUs cost the one sequential kernel of the walk 40 us per block)
+        constexpr size_t R4_SEL_LDS = 152 * 1024;
         const bool duo = getenv("MRBF_R4_DUO") ? atoi(getenv("MRBF_R4_DUO")) != 0 : true;
         const bool walk_sel = sel_env >= 2 && q >= 1 && q <= 144;  // (beyond: the register kernel; the walk's <8, 6, 12> shape spills)
         // (3: q <= 192 -- d = 128 has q = 129 -- three rows x twelve columns of Ginv per thread)
@@ -939,12 +942,17 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
         // to 0.8 ms -- runs.  The side stream reads the block's factor columns and indices while the next decision kernel writes its own:
         // two copies, by block parity; the main stream waits for the side stream's previous update before it touches what that one
         // reads or writes (Anew, Kn, Ppart, the next block's columns of R).
+        // The side stream's work is released by an event recorded just before the decision kernel's launch: the decision kernel's one
+        // workgroup is then placed at about the same time as the side stream's first workgroups, and with (nearly) the whole LDS of its
+        // compute unit asked for, none of them joins it there.  (Tried and dropped: a stream of its own for the walk, with or without the
+        // lowest priority -- the process's fifth stream lands on a hardware queue it shares with the main stream, and every small kernel
+        // of the walk became 2 to 4 times slower, 5.4 -> 11.3 ms at d = 64.  The context's bulk stream has a queue of its own.)
         const bool split = eager && custom && (getenv("MRBF_R4_SPLIT") ? atoi(getenv("MRBF_R4_SPLIT")) != 0 : true) && ctx->bulk_stream && ctx->evx[0];
         hipStream_t sfar = split ? ctx->bulk_stream : s;
         // kappa(block, next block) for ALL the block's candidates on the side stream while they are being decided: the update of the next
         // block's columns then starts from rows picked out of it instead of a kappa launch of its own on the critical path
         const bool prek = split && own_schur && ctx->evx[2] && (getenv("MRBF_R4_PREK") ? atoi(getenv("MRBF_R4_PREK")) != 0 : true);
-        bool far_pending = false;
+        bool far_pending = false, prek_any = false;
         int64_t far_from = 0;  // first candidate of the side stream's pending update
         if (eager) {
             const size_t fw_shm = (size_t)SB * 64 * sizeof(double) + SB * sizeof(int);
@@ -959,6 +967,65 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
             MRBF_DISPATCH_KID(kp.kid, hipLaunchKernelGGL((kappa_block_kernel<KID, 1>), kgrid, dim3(256), 0, s, st->Xc, d, st->LamT, st->P0c, F, (int)n0,
                                                          q > 0 ? 1 : 0, st->acc, 0, (int64_t)0, SB, kp, (double *)nullptr, 0, KbbAll, 1, mc));
         }
+        // rows nacc_old .. nacc_old + nblk - 1 of R for the candidates [j0, j0 + ncols) on stream su (Kn, Ppart by absolute candidate index)
+        struct ExtJob {
+            int64_t i0, j0, ncols;
+            int nacc_old, nblk;
+            double *Lblk;
+            int *blkidx;
+            bool is_near, pre, valid;
+        };
+        const int64_t pstride = (int64_t)SB * mc;
+        // (is_near: the next block's columns, on the critical path: the product split 32 ways into its own small slice buffer and the
+        // substitution in 16-column workgroups)
+        auto extend = [&](const ExtJob &J, hipStream_t su) -> int {
+            const int64_t i0 = J.i0, j0 = J.j0, ncols = J.ncols;
+            const int nacc_old = J.nacc_old, nblk = J.nblk;
+            double *const Lblk = J.Lblk;
+            int *const blkidx = J.blkidx;
+            const bool is_near = J.is_near;
+            const double mone = -1.0;
+            const bool small = is_near && Pnear && ncols <= SB;
+            const bool pre = small && J.pre;  // kappa(block, these columns) is there already, for every candidate of the block
+            if (pre) {
+                MRBF_HIP(ctx, hipStreamWaitEvent(su, ctx->evx[2], 0));
+            } else {
+                const dim3 kgrid((unsigned)((ncols + 63) / 64), (unsigned)((nblk + 15) / 16));
+                MRBF_DISPATCH_KID(kp.kid, hipLaunchKernelGGL((kappa_block_kernel<KID, 1>), kgrid, dim3(256), 0, su, st->Xc, d, st->LamT, st->P0c, F,
+                                                             (int)n0, q > 0 ? 1 : 0, st->acc + nacc_old, nblk, j0, (int)ncols, kp, Kn + j0 * SB, SB,
+                                                             (double *)nullptr, 0));
+            }
+            const double *const Kin = pre ? Kpre : Kn + j0 * SB;
+            int ksplit = 0;
+            double *const Pb = small ? Pnear : Ppart + j0 * SB;
+            const int64_t ps = small ? (int64_t)SB * SB : pstride;
+            if (nacc_old > 0) {
+                if (custom) {
+                    // enough (column tile, k slice) workgroups to fill the device twice over, slices of whole 16-deep groups
+                    const int ntile = (int)((ncols + 63) / 64);
+                    ksplit = std::max(1, std::min({small ? KSPLIT_NEAR : KSPLIT_MAX, (512 + ntile - 1) / ntile, (nacc_old + 63) / 64}));
+                    const int kchunk = (int)round_up((nacc_old + ksplit - 1) / ksplit, 16);
+                    ksplit = (nacc_old + kchunk - 1) / kchunk;
+                    // (left operand: the new sites' columns of R in place, through the block's index list)
+                    hipLaunchKernelGGL(r4_tn_gemm_kernel, dim3((unsigned)ntile, (unsigned)ksplit), dim3(256), 0, su, Rfull + i0 * (int64_t)ldr, ldr,
+                                       Rfull + j0 * (int64_t)ldr, (int64_t)ldr, nacc_old, ncols, kchunk, Pb, ps, blkidx, nblk);
+                } else {
+                    MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, nblk, (int)ncols, nacc_old, &mone,
+                                                 Anew, ldr, Rfull + j0 * (int64_t)ldr, ldr, &one, Kn + j0 * SB, SB));
+                }
+            }
+            if (custom && ncols <= 1024)
+                hipLaunchKernelGGL(block_forward_mfma_kernel<16>, dim3((unsigned)((ncols + 15) / 16)), dim3(256), fwm_shm_bytes(16), su, Kin, Pb, ksplit, ps,
+                                   Lblk, blkidx, nblk, ncols, Rfull + j0 * (int64_t)ldr + nacc_old, (int64_t)ldr, pre ? 1 : 0);
+            else if (custom)
+                hipLaunchKernelGGL(block_forward_mfma_kernel<64>, dim3((unsigned)((ncols + 63) / 64)), dim3(256), fwm_shm_bytes(64), su, Kin, Pb, ksplit, ps,
+                                   Lblk, blkidx, nblk, ncols, Rfull + j0 * (int64_t)ldr + nacc_old, (int64_t)ldr, 0);
+            else
+                hipLaunchKernelGGL(block_forward_kernel, dim3((unsigned)((ncols + 63) / 64)), dim3(64), (size_t)SB * 64 * sizeof(double) + SB * sizeof(int),
+                                   su, Kn + j0 * SB, SB, Lblk, blkidx, nblk, ncols, Rfull + j0 * (int64_t)ldr + nacc_old, ldr);
+            return 0;
+        };
+        ExtJob far_job{};  // the far columns' update of the block before: issued after this block's decision kernel is on its way
         int blkno = 0;
         if (prek) {  // the side stream's first kernel reads what the main stream has just set up (lambda, F, the candidates' coordinates)
             MRBF_HIP(ctx, hipEventRecord(ctx->evx[0], s));
@@ -980,13 +1047,6 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
             if (eager) Rb = Rfull + i0 * (int64_t)ldr;  // this block's columns of R are up to date: every earlier block extended them
             const int64_t near_next = std::min<int64_t>(SB, mc - (i0 + bsz));
             const bool have_prek = prek && near_next > 0;
-            if (have_prek) {
-                const dim3 kgrid((unsigned)((near_next + 63) / 64), (unsigned)((bsz + 15) / 16));
-                MRBF_DISPATCH_KID(kp.kid, hipLaunchKernelGGL((kappa_block_kernel<KID, 1>), kgrid, dim3(256), 0, sfar, st->Xc, d, st->LamT, st->P0c, F, (int)n0,
-                                                             q > 0 ? 1 : 0, st->acc, 0, i0 + bsz, (int)near_next, kp, (double *)nullptr, 0, Kpre, 1,
-                                                             (int64_t)0, i0, bsz));
-                MRBF_HIP(ctx, hipEventRecord(ctx->evx[2], sfar));
-            }
             if (own_schur) {
                 int ks = 0;
                 if (nacc > 0) {
@@ -1016,10 +1076,11 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
                 MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, bsz, bsz, nacc, &mone, Rb, ldr, Rb, ldr,
                                              &one, Sb, SB));
             }
+            if (far_job.valid) MRBF_HIP(ctx, hipEventRecord(ctx->evx[0], s));  // (releases the side stream's update: see `split`)
             if (walk_sel) {
 #define MRBF_R4_WALK(TW_, NA_, NB__)                                                                                                              \
     do {                                                                                                                                          \
-        const size_t pis = (size_t)SB * 16 * NB__ * sizeof(double);                                                                               \
+        const size_t pis = std::max<size_t>((size_t)SB * 16 * NB__ * sizeof(double), R4_SEL_LDS);                                                  \
         if (blkno == 1)                                                                                                                           \
             MRBF_HIP(ctx, hipFuncSetAttribute((const void *)select_block_walk_kernel<TW_, NA_, NB__>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                               (int)pis));                                                                                         \
@@ -1028,7 +1089,7 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
     } while (0)
 #define MRBF_R4_DUO(N_)                                                                                                                             \
     do {                                                                                                                                            \
-        const size_t pis = (size_t)SB * 16 * N_ * sizeof(double);                                                                                   \
+        const size_t pis = std::max<size_t>((size_t)SB * 16 * N_ * sizeof(double), R4_SEL_LDS);                                                      \
         if (blkno == 1)                                                                                                                             \
             MRBF_HIP(ctx, hipFuncSetAttribute((const void *)select_block_duo_kernel<N_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pis));     \
         hipLaunchKernelGGL((select_block_duo_kernel<N_>), dim3(1), dim3(512), pis, s, Sb, bsz, i0, (int)n0, q, (int)max_points, maxacc, thr, st->Prow, \
@@ -1072,6 +1133,25 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
             else
                 hipLaunchKernelGGL(select_block_kernel, dim3(1), dim3(SEL_THREADS), shm, s, Sb, bsz, i0, (int)n0, q, (int)max_points, maxacc, thr, st->Prow,
                                    st->Ginv, st->acc, cnt, Lblk, blkidx);
+            // side stream, issued only now (the host calls cost ~40 us; ahead of the Schur product and the decision kernel they delayed the
+            // critical path by as much): the far columns' update of the block before, then kappa(this block, next block)
+            auto issue_side = [&]() -> int {
+                if (far_job.valid) {
+                    MRBF_HIP(ctx, hipStreamWaitEvent(sfar, ctx->evx[0], 0));
+                    MRBF_TRY(extend(far_job, sfar));
+                    MRBF_HIP(ctx, hipEventRecord(ctx->evx[1], sfar));
+                    far_job.valid = false;
+                }
+                if (have_prek) {
+                    const dim3 kgrid((unsigned)((near_next + 63) / 64), (unsigned)((bsz + 15) / 16));
+                    MRBF_DISPATCH_KID(kp.kid, hipLaunchKernelGGL((kappa_block_kernel<KID, 1>), kgrid, dim3(256), 0, sfar, st->Xc, d, st->LamT, st->P0c, F, (int)n0,
+                                                                 q > 0 ? 1 : 0, st->acc, 0, i0 + bsz, (int)near_next, kp, (double *)nullptr, 0, Kpre, 1,
+                                                                 (int64_t)0, i0, bsz));
+                    MRBF_HIP(ctx, hipEventRecord(ctx->evx[2], sfar));
+                    prek_any = true;
+                }
+                return 0;
+            };
             int hc_local[2] = {0, 0};
             int *hc = ctx->hpin ? reinterpret_cast<int *>(ctx->hpin + HPIN_R4_COUNT) : hc_local;  // (pinned: the download does not cost a round trip of its own)
             MRBF_HIP(ctx, hipMemcpyAsync(hc, cnt, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -1079,6 +1159,7 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
             // appended under the round trip
             if (ctx->evx[3]) MRBF_HIP(ctx, hipEventRecord(ctx->evx[3], s));
             hipLaunchKernelGGL(append_rows_kernel, dim3(nb((int64_t)SB * (nacc + SB))), dim3(256), 0, s, Rb, ldr, nacc, Lblk, blkidx, cnt, st->LK, maxacc);
+            MRBF_TRY(issue_side());
             if (ctx->evx[3])
                 MRBF_HIP(ctx, hipEventSynchronize(ctx->evx[3]));
             else
@@ -1087,51 +1168,6 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
             nacc = hc[0];
             const int64_t i1 = i0 + bsz, ahead = mc - i1;
             if (eager && nblk > 0 && ahead > 0 && (int64_t)n0 + nacc < max_points && nacc < maxacc) {
-                // rows nacc_old .. nacc - 1 of R for the candidates [j0, j0 + ncols) on stream su; Kn, Ppart by absolute candidate index
-                const int64_t pstride = (int64_t)SB * mc;
-                // (is_near: the next block's columns, on the critical path: the product split 32 ways into its own small slice buffer and the
-                // substitution in 16-column workgroups)
-                auto extend = [&](int64_t j0, int64_t ncols, hipStream_t su, bool is_near) -> int {
-                    const bool small = is_near && Pnear && ncols <= SB;
-                    const bool pre = small && have_prek;  // kappa(block, these columns) is there already, for every candidate of the block
-                    if (pre) {
-                        MRBF_HIP(ctx, hipStreamWaitEvent(su, ctx->evx[2], 0));
-                    } else {
-                        const dim3 kgrid((unsigned)((ncols + 63) / 64), (unsigned)((nblk + 15) / 16));
-                        MRBF_DISPATCH_KID(kp.kid, hipLaunchKernelGGL((kappa_block_kernel<KID, 1>), kgrid, dim3(256), 0, su, st->Xc, d, st->LamT, st->P0c, F,
-                                                                     (int)n0, q > 0 ? 1 : 0, st->acc + nacc_old, nblk, j0, (int)ncols, kp, Kn + j0 * SB, SB,
-                                                                     (double *)nullptr, 0));
-                    }
-                    const double *const Kin = pre ? Kpre : Kn + j0 * SB;
-                    int ksplit = 0;
-                    double *const Pb = small ? Pnear : Ppart + j0 * SB;
-                    const int64_t ps = small ? (int64_t)SB * SB : pstride;
-                    if (nacc_old > 0) {
-                        if (custom) {
-                            // enough (column tile, k slice) workgroups to fill the device twice over, slices of whole 16-deep groups
-                            const int ntile = (int)((ncols + 63) / 64);
-                            ksplit = std::max(1, std::min({small ? KSPLIT_NEAR : KSPLIT_MAX, (512 + ntile - 1) / ntile, (nacc_old + 63) / 64}));
-                            const int kchunk = (int)round_up((nacc_old + ksplit - 1) / ksplit, 16);
-                            ksplit = (nacc_old + kchunk - 1) / kchunk;
-                            // (left operand: the new sites' columns of R in place, through the block's index list)
-                            hipLaunchKernelGGL(r4_tn_gemm_kernel, dim3((unsigned)ntile, (unsigned)ksplit), dim3(256), 0, su, Rfull + i0 * (int64_t)ldr, ldr,
-                                               Rfull + j0 * (int64_t)ldr, (int64_t)ldr, nacc_old, ncols, kchunk, Pb, ps, blkidx, nblk);
-                        } else {
-                            MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, nblk, (int)ncols, nacc_old, &mone,
-                                                         Anew, ldr, Rfull + j0 * (int64_t)ldr, ldr, &one, Kn + j0 * SB, SB));
-                        }
-                    }
-                    if (custom && ncols <= 1024)
-                        hipLaunchKernelGGL(block_forward_mfma_kernel<16>, dim3((unsigned)((ncols + 15) / 16)), dim3(256), fwm_shm_bytes(16), su, Kin, Pb, ksplit, ps,
-                                           Lblk, blkidx, nblk, ncols, Rfull + j0 * (int64_t)ldr + nacc_old, (int64_t)ldr, pre ? 1 : 0);
-                    else if (custom)
-                        hipLaunchKernelGGL(block_forward_mfma_kernel<64>, dim3((unsigned)((ncols + 63) / 64)), dim3(256), fwm_shm_bytes(64), su, Kin, Pb, ksplit, ps,
-                                           Lblk, blkidx, nblk, ncols, Rfull + j0 * (int64_t)ldr + nacc_old, (int64_t)ldr, 0);
-                    else
-                        hipLaunchKernelGGL(block_forward_kernel, dim3((unsigned)((ncols + 63) / 64)), dim3(64), (size_t)SB * 64 * sizeof(double) + SB * sizeof(int),
-                                           su, Kn + j0 * SB, SB, Lblk, blkidx, nblk, ncols, Rfull + j0 * (int64_t)ldr + nacc_old, ldr);
-                    return 0;
-                };
                 if (far_pending) MRBF_HIP(ctx, hipStreamWaitEvent(s, ctx->evx[1], 0));  // the side stream's update of the block before
                 if (nacc_old > 0 && !custom)
                     hipLaunchKernelGGL(gather_newcols_kernel, dim3(nb((int64_t)nacc_old * nblk)), dim3(256), 0, s, Rfull, ldr, nacc_old, i0, blkidx, nblk,
@@ -1139,20 +1175,19 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
                 // the next block's columns first, alone on the device (started together, the far update's 150 workgroups doubled the
                 // duration of these few); the far columns then run under the next block's Schur product and decisions
                 const int64_t near = split ? std::min<int64_t>(SB, ahead) : ahead;
-                MRBF_TRY(extend(i1, near, s, split));
+                MRBF_TRY(extend(ExtJob{i0, i1, near, nacc_old, nblk, Lblk, blkidx, split, have_prek, true}, s));
                 if (split && ahead > near) {
-                    MRBF_HIP(ctx, hipEventRecord(ctx->evx[0], s));
-                    MRBF_HIP(ctx, hipStreamWaitEvent(sfar, ctx->evx[0], 0));
-                    MRBF_TRY(extend(i1 + near, ahead - near, sfar, false));
-                    MRBF_HIP(ctx, hipEventRecord(ctx->evx[1], sfar));
-                    far_pending = true;
+                    far_job = ExtJob{i0, i1 + near, ahead - near, nacc_old, nblk, Lblk, blkidx, false, false, true};
+                    far_pending = true;  // (its event is recorded when it is issued: before the next host wait)
                     far_from = i1 + near;
                 } else {
                     far_pending = false;
                 }
             }
         }
-        if (far_pending) MRBF_HIP(ctx, hipStreamWaitEvent(s, ctx->evx[1], 0));  // (the buffers go back to the pool after this stream's work)
+        // (the buffers go back to the pool after this stream's work; a far update that was never issued -- the walk ended -- is dropped)
+        if (far_pending && !far_job.valid) MRBF_HIP(ctx, hipStreamWaitEvent(s, ctx->evx[1], 0));
+        if (prek_any) MRBF_HIP(ctx, hipStreamWaitEvent(s, ctx->evx[2], 0));
         MRBF_HIP(ctx, hipGetLastError());
         std::vector<int> hacc((size_t)maxacc + 1);
         MRBF_HIP(ctx, hipMemcpyAsync(hacc.data(), st->acc, hacc.size() * sizeof(int), hipMemcpyDeviceToHost, s));
