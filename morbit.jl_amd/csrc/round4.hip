@@ -104,13 +104,12 @@ __global__ void block_copy_kernel(const double *__restrict__ K, int64_t mc, int6
 // Wide k chunks (64 coordinates, 32 tail terms per round, every load of a round in flight at once): with 16-wide rounds the kernel was a
 // chain of 9 (d = 64) to 17 (d = 128) load -> barrier -> sum round trips, 67 to 85 us whatever the size of the grid.  The sums run over k in
 // the same order as before.
-template <int KID, int RT>  // tile = 16 rows x 64 columns, 4 entries per thread (up to 276 workgroups per block)
+template <int KID, int TL>  // tile = 16 rows x 64 columns, 4 entries per thread; TL = 0: distances only (a third of the LDS: the tail goes through the product kernel)
 __global__ __launch_bounds__(256) void kappa_block_kernel(const double *__restrict__ Xc, int d, const double *__restrict__ LamT,
                                                           const double *__restrict__ P0c, const double *__restrict__ F, int n0, int have_tail,
                                                           const int *__restrict__ acc, int nacc, int64_t i0, int b, KP kp,
                                                           double *__restrict__ Kab, int ld, double *__restrict__ S, int blockrows,
                                                           int64_t batch_total = 0, int64_t rbase = -1, int rcount = 0) {
-    static_assert(RT == 1, "one row of entries per thread");
     if (batch_total > 0) {  // blockIdx.z = block number: kappa(block, block) of every block of the walk in one launch (S: SB x SB per block)
         const int64_t off = (int64_t)blockIdx.z * SB;
         i0 += off;
@@ -118,7 +117,7 @@ __global__ __launch_bounds__(256) void kappa_block_kernel(const double *__restri
         S += off * SB;
     }
     constexpr int TR = 16, NR = TR + 64, KD = 64, KT = 32;
-    __shared__ double sm[3 * NR * (KT + 1)];  // distance rounds: A[NR][KD + 1]; tail rounds: L | P | F, each [NR][KT + 1]
+    __shared__ double sm[TL ? 3 * NR * (KT + 1) : NR * (KD + 1)];  // distance rounds: A[NR][KD + 1]; tail rounds: L | P | F, each [NR][KT + 1]
     static_assert(NR * (KD + 1) <= 3 * NR * (KT + 1), "the distance tile fits the tail tiles' area");
     __shared__ int64_t rid[NR];  // global site of a tile row (0 .. TR-1) / column (TR ..), -1 outside
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
@@ -160,7 +159,7 @@ __global__ __launch_bounds__(256) void kappa_block_kernel(const double *__restri
         }
         __syncthreads();
     }
-    if (have_tail) {
+    if (TL && have_tail) {
         double(*Ls)[KT + 1] = reinterpret_cast<double(*)[KT + 1]>(sm);
         double(*Ps)[KT + 1] = Ls + NR;
         double(*Fs)[KT + 1] = Ps + NR;
@@ -205,7 +204,7 @@ __global__ __launch_bounds__(256) void kappa_block_kernel(const double *__restri
         const int rr = R0 + ty, cc = C0 + tx + 16 * v;
         if (rr >= nrows || cc >= b) continue;
         double val = rbf_phi<KID>(dist[v], kp);
-        if (have_tail) val = (val - e1[v]) - e2[v] + 0.5 * (q1[v] + q2[v]);
+        if (TL && have_tail) val = (val - e1[v]) - e2[v] + 0.5 * (q1[v] + q2[v]);
         if (rr < nacc)
             Kab[rr + (int64_t)cc * ld] = val;
         else
@@ -481,6 +480,27 @@ __global__ __launch_bounds__(64) void block_forward_kernel(const double *__restr
         xs[a][tid] = x;
         Rout[a + j * (int64_t)ldr] = x;
     }
+}
+
+// The tail part of kappa as a product: kappa(xi, eta) = phi - TA(:, xi)' TB(:, eta) with the stacked vectors
+//   TA(:, s) = [lam_s; p_s; -lam_s / 2; -f_s / 2],  TB(:, s) = [p_s; lam_s; f_s; lam_s]   (4 n0 entries per site)
+// so that the update of the far columns takes it as one more k slice of the product kernel (MFMA) instead of 4 n0 multiply-adds per
+// entry in kappa_block_kernel, which was latency-bound at two workgroups per compute unit (92 us per block at d = 64, 25 without).
+__global__ void tail_forms_kernel(const double *__restrict__ LamT, const double *__restrict__ P0c, const double *__restrict__ F, int n0, int64_t mc,
+                                  double *__restrict__ TA, double *__restrict__ TB) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)n0 * mc) return;
+    const int k = (int)(idx % n0);
+    const int64_t site = idx / n0, o = site * 4 * n0;
+    const double l = LamT[idx], pv = P0c[idx], f = F[idx];
+    TA[o + k] = l;
+    TA[o + n0 + k] = pv;
+    TA[o + 2 * n0 + k] = -0.5 * l;
+    TA[o + 3 * n0 + k] = -0.5 * f;
+    TB[o + k] = pv;
+    TB[o + n0 + k] = l;
+    TB[o + 2 * n0 + k] = f;
+    TB[o + 3 * n0 + k] = l;
 }
 
 // ---- the right-looking walk's own kernels (round 5, second half): rocBLAS ran the fat product at ~6 TFLOP/s (m = 128: one workgroup per 64
@@ -917,7 +937,7 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
             MRBF_TRY(get_buf(ctx, S_PHI, (size_t)ldr * (mc + SB), &Rfull));  // R(:, j) for every candidate j (+ one block: the products read whole 128-column tiles)
             MRBF_TRY(get_buf(ctx, S_STAGE_C, (size_t)ldr * SB, &Anew));      // the new sites' columns of R, compact
             MRBF_TRY(get_buf(ctx, S_STAGE_D, (size_t)SB * mc, &Kn));         // kappa(new, ahead), ld = SB
-            if (custom) MRBF_TRY(get_buf(ctx, S_STAGE_A, (size_t)KSPLIT_MAX * SB * mc, &Ppart));  // the k slices of R(old, new)' R(old, ahead)
+            if (custom) MRBF_TRY(get_buf(ctx, S_STAGE_A, (size_t)(KSPLIT_MAX + 1) * SB * mc, &Ppart));  // the k slices of R(old, new)' R(old, ahead) (+ the tail's)
         }
         // the block's own Schur complement without rocBLAS (right-looking walk): kappa(block, block) of every block in one launch up front,
         // R(:, block)' R(:, block) by the split-k product kernel (rocBLAS ran this 128 x 128 x nacc product on two workgroups: 165 us at
@@ -925,12 +945,18 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
         constexpr int KSPLIT_NEAR = 32;
         const bool own_schur = custom && (getenv("MRBF_R4_SCHUR") ? atoi(getenv("MRBF_R4_SCHUR")) != 0 : true);
         const int64_t nblocks = (mc + SB - 1) / SB;
-        double *KbbAll = nullptr, *Spart = nullptr, *Pnear = nullptr, *Kpre = nullptr;
+        double *KbbAll = nullptr, *Spart = nullptr, *Pnear = nullptr, *Kpre = nullptr, *TA = nullptr, *TB = nullptr;
+        const bool tailgemm = own_schur && q > 0 && (getenv("MRBF_R4_TAILGEMM") ? atoi(getenv("MRBF_R4_TAILGEMM")) != 0 : true);
+        const int L4 = 4 * (int)n0;
         if (own_schur) {
             MRBF_TRY(get_buf(ctx, S_OUT_A, (size_t)SB * SB * nblocks, &KbbAll));
-            MRBF_TRY(get_buf(ctx, S_STAGE_B, (size_t)(2 * KSPLIT_NEAR + 1) * SB * SB, &Spart));
-            Pnear = Spart + (size_t)KSPLIT_NEAR * SB * SB;  // the k slices of the next block's update (few columns: split 32 ways)
-            Kpre = Pnear + (size_t)KSPLIT_NEAR * SB * SB;   // kappa(every candidate of the block, the next block's columns)
+            MRBF_TRY(get_buf(ctx, S_STAGE_B, (size_t)(2 * KSPLIT_NEAR + 2) * SB * SB, &Spart));
+            Pnear = Spart + (size_t)KSPLIT_NEAR * SB * SB;       // the k slices of the next block's update (few columns: split 32 ways; + the tail's)
+            Kpre = Pnear + (size_t)(KSPLIT_NEAR + 1) * SB * SB;  // kappa(every candidate of the block, the next block's columns)
+            if (tailgemm) {
+                MRBF_TRY(get_buf(ctx, S_T2, (size_t)4 * n0 * mc, &TA));
+                MRBF_TRY(get_buf(ctx, S_OUT_B, (size_t)4 * n0 * mc, &TB));
+            }
         }
         MRBF_TRY(get_buf(ctx, S_Q1, (size_t)maxacc * SB, &Rb));          // R = L_acc^-1 K[acc, block]
         MRBF_TRY(get_buf(ctx, S_RHS, (size_t)3 * SB * SB, &Sb));          // Schur complement of the block | in-block factor columns (two: see below)
@@ -967,6 +993,7 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
             MRBF_DISPATCH_KID(kp.kid, hipLaunchKernelGGL((kappa_block_kernel<KID, 1>), kgrid, dim3(256), 0, s, st->Xc, d, st->LamT, st->P0c, F, (int)n0,
                                                          q > 0 ? 1 : 0, st->acc, 0, (int64_t)0, SB, kp, (double *)nullptr, 0, KbbAll, 1, mc));
         }
+        if (tailgemm) hipLaunchKernelGGL(tail_forms_kernel, dim3(nb((int64_t)n0 * mc)), dim3(256), 0, s, st->LamT, st->P0c, F, (int)n0, mc, TA, TB);
         // rows nacc_old .. nacc_old + nblk - 1 of R for the candidates [j0, j0 + ncols) on stream su (Kn, Ppart by absolute candidate index)
         struct ExtJob {
             int64_t i0, j0, ncols;
@@ -991,9 +1018,15 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
                 MRBF_HIP(ctx, hipStreamWaitEvent(su, ctx->evx[2], 0));
             } else {
                 const dim3 kgrid((unsigned)((ncols + 63) / 64), (unsigned)((nblk + 15) / 16));
-                MRBF_DISPATCH_KID(kp.kid, hipLaunchKernelGGL((kappa_block_kernel<KID, 1>), kgrid, dim3(256), 0, su, st->Xc, d, st->LamT, st->P0c, F,
-                                                             (int)n0, q > 0 ? 1 : 0, st->acc + nacc_old, nblk, j0, (int)ncols, kp, Kn + j0 * SB, SB,
-                                                             (double *)nullptr, 0));
+                if (tailgemm) {
+                    MRBF_DISPATCH_KID(kp.kid, hipLaunchKernelGGL((kappa_block_kernel<KID, 0>), kgrid, dim3(256), 0, su, st->Xc, d, st->LamT, st->P0c, F,
+                                                                 (int)n0, 0, st->acc + nacc_old, nblk, j0, (int)ncols, kp, Kn + j0 * SB, SB,
+                                                                 (double *)nullptr, 0));
+                } else {
+                    MRBF_DISPATCH_KID(kp.kid, hipLaunchKernelGGL((kappa_block_kernel<KID, 1>), kgrid, dim3(256), 0, su, st->Xc, d, st->LamT, st->P0c, F,
+                                                                 (int)n0, q > 0 ? 1 : 0, st->acc + nacc_old, nblk, j0, (int)ncols, kp, Kn + j0 * SB, SB,
+                                                                 (double *)nullptr, 0));
+                }
             }
             const double *const Kin = pre ? Kpre : Kn + j0 * SB;
             int ksplit = 0;
@@ -1013,6 +1046,11 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
                     MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, nblk, (int)ncols, nacc_old, &mone,
                                                  Anew, ldr, Rfull + j0 * (int64_t)ldr, ldr, &one, Kn + j0 * SB, SB));
                 }
+            }
+            if (tailgemm && !pre) {  // the tail of kappa(new, these columns): one more slice, TA(:, new)' TB(:, columns)
+                hipLaunchKernelGGL(r4_tn_gemm_kernel, dim3((unsigned)((ncols + 63) / 64), 1), dim3(256), 0, su, TA + i0 * (int64_t)L4, L4, TB + j0 * (int64_t)L4,
+                                   (int64_t)L4, L4, ncols, (int)round_up(L4, 16), Pb + (int64_t)ksplit * ps, ps, blkidx, nblk);
+                ++ksplit;
             }
             if (custom && ncols <= 1024)
                 hipLaunchKernelGGL(block_forward_mfma_kernel<16>, dim3((unsigned)((ncols + 15) / 16)), dim3(256), fwm_shm_bytes(16), su, Kin, Pb, ksplit, ps,
