@@ -253,7 +253,7 @@ def test_round4_device_selection_and_factor_reuse(name, deg, d, n, k):
 @pytest.mark.parametrize("name,deg,d,n,mp", [("cubic", 1, 130, 150, 231), ("multiquadric", 1, 12, 700, 91), ("gaussian", 1, 40, 900, 500),
                                              ("inv_multiquadric", 0, 8, 333, 200), ("gaussian", -1, 6, 300, 180)])
 def test_round4_walk_variants_agree(name, deg, d, n, mp):
-    """Round 5 gave the walk three forms: kappa on demand + per-block triangular solve (left-looking), kappa on demand + R kept for every
+    """Round 5 gave the walk three forms (and the right-looking one a set of switches that select its earlier stages): kappa on demand + per-block triangular solve (left-looking), kappa on demand + R kept for every
     candidate ahead (right-looking, no triangular solve against the accepted factor), and the mc x mc construction of rounds 3 / 4
     (MRBF_R4_LAZY=0).  They compute the same quantities in different orders: the accepted lists must be identical, the fits from the
     kept factors equal to rounding, and the list equal to the independent oracle's.  d = 130: q = 131, the decision kernel's
@@ -270,7 +270,14 @@ def test_round4_walk_variants_agree(name, deg, d, n, mp):
     kidp, ap, bp = pkg.rbf_model._get_kernel_params(1.0, cfg)
     S0, Cc = sites[start], sites[cands]
     results = {}
-    for tag, env in (("left", {"MRBF_R4_EAGER": "0"}), ("right", {"MRBF_R4_EAGER": "1"}), ("full", {"MRBF_R4_LAZY": "0"})):
+    # (right-looking walk: also with the register / memory decision kernels of rounds 4 / 3, every wave doing both halves of a step, one
+    # stream, rocBLAS for the block's Schur complement, the tail of kappa inside the kappa kernel, no kappa ahead of the decisions)
+    variants = (("left", {"MRBF_R4_EAGER": "0"}), ("right", {"MRBF_R4_EAGER": "1"}), ("full", {"MRBF_R4_LAZY": "0"}),
+                ("right/select1", {"MRBF_R4_SELECT": "1"}), ("right/select0", {"MRBF_R4_SELECT": "0"}), ("right/noduo", {"MRBF_R4_DUO": "0"}),
+                ("right/onestream", {"MRBF_R4_SPLIT": "0"}), ("right/blas-schur", {"MRBF_R4_SCHUR": "0"}),
+                ("right/tail-in-kappa", {"MRBF_R4_TAILGEMM": "0"}), ("right/no-prek", {"MRBF_R4_PREK": "0"}),
+                ("right/blas-update", {"MRBF_R4_CUSTOM": "0"}))
+    for tag, env in variants:
         os.environ.update(env)
         try:
             accepted, st = sampling.rbf_round4_device(cfg, S0, Cc, 1.0, keep_state=True)
@@ -287,7 +294,7 @@ def test_round4_walk_variants_agree(name, deg, d, n, mp):
             for kk in env:
                 os.environ.pop(kk, None)
     acc_l, w_l, r_l = results["left"]
-    for tag in ("right", "full"):
+    for tag, _ in variants[1:]:
         acc, w, r = results[tag]
         assert acc == acc_l, tag
         assert np.abs(w - w_l).max() <= 1e-8 * np.abs(w_l).max(), (tag, np.abs(w - w_l).max() / np.abs(w_l).max())
