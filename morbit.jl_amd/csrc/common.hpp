@@ -35,7 +35,7 @@ enum Slot {
     S_XC = 0, S_SQ, S_MEAN, S_PHI, S_PI, S_Q1, S_W1, S_G, S_R, S_TAU, S_RHS, S_T1, S_T2, S_IPIV, S_INFO,
     S_STAGE_A, S_STAGE_B, S_STAGE_C, S_STAGE_D, S_EVAL_E, S_EVAL_A, S_EVAL_J, S_EVAL_SA, S_EVAL_XC, S_EVAL_XSQ,
     S_OUT_A, S_OUT_B, S_CHOL_WS, S_MISC, S_MEGA_JOBS, S_MEGA_FLAGS, S_MEGA_WQ, S_MEGA_IT, S_BSOLVE_FLAGS, S_MEGA_TRACE, S_MEGA_JLOG,
-    S_T1W, S_PS_STATE, S_PS_STAT, S_PS_POLISH, S_BSOLVE_X, S_V0, S_QR_INV, S_DIAG_SCR, S_SMALL_WS, S_SMALL_DESC, S_SMALL_FLAGS, S_MEGA_STAT, S_BSOLVE_M, S_SMALL_CL, S_GW_PART, S_GW_RS, S_GW_GP, S_GW_M, S_CHECK_SCAL, S_TAIL_PART, S_NSLOTS
+    S_T1W, S_PS_STATE, S_PS_STAT, S_PS_POLISH, S_BSOLVE_X, S_V0, S_QR_INV, S_DIAG_SCR, S_SMALL_WS, S_SMALL_DESC, S_SMALL_FLAGS, S_MEGA_STAT, S_BSOLVE_M, S_SMALL_CL, S_GW_PART, S_GW_RS, S_GW_GP, S_GW_M, S_CHECK_SCAL, S_TAIL_PART, S_PS_RANK, S_NSLOTS
 };
 struct Buf {
     void *p = nullptr;

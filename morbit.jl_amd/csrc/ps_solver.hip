@@ -37,6 +37,16 @@ constexpr int MAXMODELS = 8;   // grouped models of one container
 constexpr int MAXOBJ = 8;
 constexpr int MAXCON = 32;     // modelled (nonlinear) constraint rows
 constexpr int RANK_THREADS = 1024;
+// ranking of a large population on several compute units (ps_rank_sort_kernel): workgroups per run, phases per chunk (= halo width),
+// smallest population that takes this path, longest window (owned part + two halos) of one workgroup
+constexpr int RS_THREADS = 512, RS_W = 16, RS_B = 256, RS_MINLAM = 2048;
+constexpr int RS_MAXWIN = ((MAXLAM + RS_W - 1) / RS_W + 2) + 2 * RS_B;
+constexpr int RS_SYNC = 64;  // sync words per run: [0] arrivals, [1] failure, [2] the run asks for the sort, [3] buffer that holds the result, [4 + c] chunk c moved something
+struct RankWs {  // device work space of the multi-workgroup ranking, run r at offset r * MAXLAM (r * RS_SYNC)
+    double *f[2], *phi[2];
+    int *idx[2];
+    int *sync;
+};
 
 struct Run {  // one (mu, lambda) run; all pointers into device arenas
     int nvar;       // 1 + d for the PS run (chi = [t; x]), d for an ideal-point run
@@ -72,7 +82,7 @@ struct Args {
     unsigned long long seed;
     double xtol_rel;
     int gen;
-    int dbg;  // experiments (MRBF_PS_DBG): 1 no ranking, 2 no breeding, 4 transposition phases also when a sort would do, 8 t stays a free
+    int dbg;  // experiments (MRBF_PS_DBG): 64 the multi-workgroup ranking gives up at once (fallback test), 1 no ranking, 2 no breeding, 4 transposition phases also when a sort would do, 8 t stays a free
               // variable (no repair), 16 uniform start population
 };
 
@@ -238,7 +248,10 @@ __device__ __forceinline__ bool cand_better(const Cand &x, const Cand &y) {
 }
 
 // ---- one workgroup per run: best so far, stop tests, ranking
-__global__ __launch_bounds__(RANK_THREADS) void ps_rank_kernel(Args a) {
+// mode 0: everything in this launch.  Large populations with infeasible individuals (mode 1 / 2): mode 1 does the bookkeeping and, when
+// the transposition phases are due, hands them to ps_rank_sort_kernel (sixteen workgroups per run); mode 2 picks the order up (or runs the
+// phases here after all if that kernel gave up: it never touches f / phi) and finishes the generation.
+__global__ __launch_bounds__(RANK_THREADS) void ps_rank_kernel(Args a, int mode, RankWs ws) {
     extern __shared__ double smem[];
     __shared__ double s_red[2 * (RANK_THREADS / 64)];
     __shared__ int s_ired[2 * (RANK_THREADS / 64)];
@@ -246,14 +259,19 @@ __global__ __launch_bounds__(RANK_THREADS) void ps_rank_kernel(Args a) {
     const int run = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const Run &R = a.runs[run];
     if (R.stat[1]) return;
+    int *const sy = ws.sync ? ws.sync + run * RS_SYNC : nullptr;
+    if (mode == 2 && sy[2] == 0) return;  // (this run's generation was finished in mode 1)
     const int n = R.nvar, lam = R.lam, mu = R.mu, gen = a.gen;
     const double *X = R.X[gen & 1];
     const int evals0 = R.stat[0];
     const int m = min(lam, R.max_evals - evals0);
-    if (tid == 0) s_infeas = 0;
+    if (tid == 0) {
+        s_infeas = mode == 2 ? 1 : 0;
+        s_stop = 0;
+    }
     __syncthreads();
     // ---- this generation's best individual and whether any individual inside the budget violates a constraint
-    {
+    if (mode != 2) {
         Cand mine{0.0, -1, 0x7fffffff};
         bool infeas = false;
         for (int i = tid; i < m; i += RANK_THREADS) {
@@ -309,8 +327,18 @@ __global__ __launch_bounds__(RANK_THREADS) void ps_rank_kernel(Args a) {
     // and lam phases of the stable transposition sort end in THE sorted order (ties by index): a bitonic network over the padded
     // array reaches the same order in log2(N) (log2(N) + 1) / 2 phases (91 instead of 5160 at lam = 5160).
     const bool plain_sort = s_infeas == 0 && !(a.dbg & 4);
+    if (mode == 1) {
+        const bool hand_over = !plain_sort && !(a.dbg & 1) && lam >= RS_MINLAM;
+        if (tid < RS_SYNC) sy[tid] = (tid == 2 && hand_over) ? 1 : 0;
+        if (hand_over) return;
+    }
     int *sidx;
-    if (a.dbg & 1) {
+    if (mode == 2 && sy[1] == 0) {  // the order found by ps_rank_sort_kernel
+        sidx = (int *)smem;
+        const int *src = ws.idx[sy[3]] + (size_t)run * MAXLAM;
+        for (int i = tid; i < lam; i += RANK_THREADS) sidx[i] = src[i];
+        __syncthreads();
+    } else if (a.dbg & 1) {
         sidx = (int *)smem;
         for (int i = tid; i < lam; i += RANK_THREADS) sidx[i] = i;
         __syncthreads();
@@ -443,6 +471,122 @@ __global__ __launch_bounds__(RANK_THREADS) void ps_rank_kernel(Args a) {
             R.stat[1] = 1;
         else
             R.stat[3] = gen + 1;  // breed the next generation
+    }
+}
+
+// ---- the transposition phases of one run on RS_W workgroups.  A phase moves information by one position, so a workgroup that loads
+// its part of the array plus RS_B positions on either side can run RS_B phases on its own and its part comes out exactly as if the
+// whole array had been worked on (the halo positions go wrong from the window's edges inwards, one position per phase, and are thrown
+// away); every comparison is a function of (pair, phase, values) -- the Philox counter is the pair and the four-phase group, as in
+// ps_rank_kernel -- so the redundant comparisons in the halos agree with the owner's.  Between chunks the parts are exchanged through
+// global memory (write-through stores, coherent loads: the workgroups sit behind different L2s) and the workgroups of a run meet at a
+// counter.  A chunk in which no workgroup moved anything inside its own part ends the ranking (the one-workgroup kernel tests every
+// sixteen phases).  The counter wait is bounded: on a time-out the failure word is set and ps_rank_kernel (mode 2) runs the phases
+// itself -- this kernel never writes f / phi.
+__device__ __forceinline__ unsigned long long rs_clock() { return __builtin_amdgcn_s_memrealtime(); }  // 100 MHz
+__global__ __launch_bounds__(RS_THREADS) void ps_rank_sort_kernel(Args a, RankWs ws) {
+    __shared__ double sf[RS_MAXWIN], sphi[RS_MAXWIN];
+    __shared__ int sidx[RS_MAXWIN];
+    __shared__ int s_sw, s_ok, s_any;
+    const int run = blockIdx.y, w = blockIdx.x, tid = threadIdx.x;
+    const Run &R = a.runs[run];
+    int *const sy = ws.sync + run * RS_SYNC;
+    if (R.stat[1] || sy[2] == 0) return;
+    if (a.dbg & 64) {  // (test switch: give up at once, as after a counter time-out)
+        if (threadIdx.x == 0) __hip_atomic_store(sy + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    const int lam = R.lam, gen = a.gen;
+    const int per = ((lam + RS_W - 1) / RS_W + 1) & ~1;  // even: windows start at even positions (a thread keeps its pair slot over both parities)
+    const int s0 = min(lam, w * per), e0 = min(lam, s0 + per);
+    const int ws0 = max(0, s0 - RS_B), we0 = min(lam, e0 + RS_B), wn = we0 - ws0;
+    const size_t ro = (size_t)run * MAXLAM;
+    const int nch = (lam + RS_B - 1) / RS_B;
+    for (int c = 0; c < nch; ++c) {
+        const int sb = c & 1, db = sb ^ 1;
+        for (int i = tid; i < wn; i += RS_THREADS) {
+            const int g = ws0 + i;
+            if (c == 0) {
+                sf[i] = R.f[g];
+                sphi[i] = R.phi[g];
+                sidx[i] = g;
+            } else {
+                sf[i] = __hip_atomic_load(ws.f[sb] + ro + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sphi[i] = __hip_atomic_load(ws.phi[sb] + ro + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sidx[i] = __hip_atomic_load(ws.idx[sb] + ro + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (tid == 0) s_sw = 0;
+        __syncthreads();
+        const int ph_end = min(lam, (c + 1) * RS_B);
+        for (int ph0 = c * RS_B; ph0 < ph_end; ph0 += 4) {
+            unsigned c4[4];
+            bool drawn = false;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int ph = ph0 + q4;
+                if (ph < lam) {
+                    const int j = ws0 + (ph & 1) + 2 * tid;  // (ws0 even)
+                    if (j + 1 < we0 && s0 < e0) {
+                        const int li = j - ws0;
+                        const double fa = sf[li], fb = sf[li + 1], pa = sphi[li], pb = sphi[li + 1];
+                        bool by_f = pa == 0.0 && pb == 0.0;
+                        if (!by_f) {
+                            if (!drawn) {
+                                c4[0] = (unsigned)(j >> 1);
+                                c4[1] = (unsigned)ph0;
+                                c4[2] = (unsigned)(gen * 16 + 1);
+                                c4[3] = (unsigned)run;
+                                philox(c4, (unsigned)a.seed, (unsigned)(a.seed >> 32));
+                                drawn = true;
+                            }
+                            by_f = ((double)c4[q4] + 0.5) * (1.0 / 4294967296.0) < 0.45;
+                        }
+                        const bool worse = by_f ? (fa > fb) : (pa > pb);
+                        if (worse) {
+                            const int ia = sidx[li], ib = sidx[li + 1];
+                            sf[li] = fb;
+                            sf[li + 1] = fa;
+                            sphi[li] = pb;
+                            sphi[li + 1] = pa;
+                            sidx[li] = ib;
+                            sidx[li + 1] = ia;
+                            if (j >= s0 && j < e0) s_sw = 1;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        for (int i = tid; i < e0 - s0; i += RS_THREADS) {
+            const int li = s0 - ws0 + i;
+            __hip_atomic_store(ws.f[db] + ro + s0 + i, sf[li], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(ws.phi[db] + ro + s0 + i, sphi[li], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(ws.idx[db] + ro + s0 + i, sidx[li], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have left the CU
+        __syncthreads();
+        if (tid == 0) {
+            if (s_sw) __hip_atomic_fetch_or(sy + 4 + c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(sy, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (the part's stores are write-through and counted out: no L2 write-back needed)
+            const int target = RS_W * (c + 1);
+            const unsigned long long t0 = rs_clock();
+            bool ok = true;
+            while (__hip_atomic_load(sy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                if (__hip_atomic_load(sy + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || rs_clock() - t0 > 2000000ull) {  // 20 ms
+                    __hip_atomic_store(sy + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = false;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            s_ok = ok ? 1 : 0;
+            s_any = __hip_atomic_load(sy + 4 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (!s_ok) return;
+        if (w == 0 && tid == 0) sy[3] = db;  // (the result so far; read by the next kernel in the stream)
+        if (!s_any) return;                  // nothing moved in RS_B phases: ranked under the drawn rules
     }
 }
 
@@ -898,6 +1042,21 @@ extern "C" int32_t mrbf_ps_step_problem(mrbf_ctx *ctx, const mrbf_ps_problem *pr
         while (N < maxlam) N <<= 1;
         const size_t shm = std::max((size_t)20 * maxlam, (size_t)12 * N);
         MRBF_HIP(ctx, hipFuncSetAttribute((const void *)ps_rank_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        // large populations: the transposition phases on RS_W workgroups per run (MRBF_PS_MULTI=0: one workgroup as in rounds 3 / 4)
+        RankWs rw{};
+        const bool multi = maxlam >= RS_MINLAM && ctx->ncu >= RS_W * a.nruns && !(getenv("MRBF_PS_MULTI") && atoi(getenv("MRBF_PS_MULTI")) == 0);
+        if (multi) {
+            double *wsb;
+            const size_t per_run = (size_t)MAXLAM * 5 + RS_SYNC / 2;  // f, phi twice, idx twice (as doubles: 2 x 1/2), sync words
+            MRBF_TRY(get_buf(ctx, S_PS_RANK, per_run * MAXRUNS + 64, &wsb));
+            rw.f[0] = wsb;
+            rw.f[1] = rw.f[0] + (size_t)MAXLAM * MAXRUNS;
+            rw.phi[0] = rw.f[1] + (size_t)MAXLAM * MAXRUNS;
+            rw.phi[1] = rw.phi[0] + (size_t)MAXLAM * MAXRUNS;
+            rw.idx[0] = reinterpret_cast<int *>(rw.phi[1] + (size_t)MAXLAM * MAXRUNS);
+            rw.idx[1] = rw.idx[0] + (size_t)MAXLAM * MAXRUNS;
+            rw.sync = rw.idx[1] + (size_t)MAXLAM * MAXRUNS;
+        }
         hipLaunchKernelGGL(ps_init_kernel, dim3((unsigned)((maxel + 255) / 256), (unsigned)a.nruns), dim3(256), 0, ctx->stream, a, start, t0);
         std::vector<int> hstat((size_t)4 * a.nruns);
         const unsigned wave_blocks = (unsigned)((a.rows + 3) / 4);
@@ -906,7 +1065,11 @@ extern "C" int32_t mrbf_ps_step_problem(mrbf_ctx *ctx, const mrbf_ps_problem *pr
             for (int j = 0; j < P.nmodels; ++j)
                 MRBF_TRY(eval_model(ctx, P.models[j], a.rows, a.Xeval, const_cast<double *>(a.F[j]), nullptr, nullptr));
             hipLaunchKernelGGL(ps_score_kernel, dim3(wave_blocks), dim3(256), 0, ctx->stream, a);
-            hipLaunchKernelGGL(ps_rank_kernel, dim3((unsigned)a.nruns), dim3(RANK_THREADS), shm, ctx->stream, a);
+            hipLaunchKernelGGL(ps_rank_kernel, dim3((unsigned)a.nruns), dim3(RANK_THREADS), shm, ctx->stream, a, multi ? 1 : 0, rw);
+            if (multi) {
+                hipLaunchKernelGGL(ps_rank_sort_kernel, dim3(RS_W, (unsigned)a.nruns), dim3(RS_THREADS), 0, ctx->stream, a, rw);
+                hipLaunchKernelGGL(ps_rank_kernel, dim3((unsigned)a.nruns), dim3(RANK_THREADS), shm, ctx->stream, a, 2, rw);
+            }
             hipLaunchKernelGGL(ps_breed_kernel, dim3(wave_blocks), dim3(256), 0, ctx->stream, a);
             if ((g & 7) == 7 || g + 1 == max_gens) {  // status words every 8 generations: stop when every run is done
                 MRBF_HIP(ctx, hipMemcpyAsync(hstat.data(), a.runs[0].stat, hstat.size() * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));

@@ -223,6 +223,43 @@ def _check_ps_contract(ev_obj, ev_con, x, lb, ub, fx, omega, xt, mt, stats, lin=
 
 
 @pytest.mark.gpu
+def test_ps_ranking_on_several_compute_units_is_the_same_ranking():
+    """Populations of 2048 individuals and more (d >= 102) are ranked by sixteen workgroups per run (ps_rank_sort_kernel: chunks of 256
+    transposition phases on windows with halos, exchanged through global memory).  Same comparisons, same draws: the step must be THE
+    step of the one-workgroup ranking (MRBF_PS_MULTI=0) bit for bit -- also when the several-workgroup kernel gives up (MRBF_PS_DBG=64:
+    the failure word is set at once and the finishing launch runs the phases itself), and when the phases are forced on generations
+    that a sort would rank (MRBF_PS_DBG=4)."""
+    import os
+    d, n = 110, 400
+    rng = np.random.default_rng(77)
+    C = rng.random((n, d))
+    Y = np.stack([np.sum((C - 0.3) ** 2, axis=1), np.sum((C - 0.7) ** 2, axis=1) + 0.1 * np.sin(5 * C[:, 0])], axis=1) / d
+    mod = pkg.update_model(pkg.RbfConfig(kernel="cubic"), C, Y)
+    x = np.full(d, 0.5)
+    x[1], x[3] = 0.85, 0.2
+    lb, ub = x - 0.1, x + 0.1
+    fx = pkg.eval_models_at_sites(mod, None, x[None, :])[0]
+    cfg = ps.PascolettiSerafiniConfig()
+    out = {}
+    for tag, env in (("multi", {}), ("single", {"MRBF_PS_MULTI": "0"}), ("gave-up", {"MRBF_PS_DBG": "64"}), ("multi/phases", {"MRBF_PS_DBG": "4"}),
+                     ("single/phases", {"MRBF_PS_MULTI": "0", "MRBF_PS_DBG": "4"})):
+        os.environ.update(env)
+        try:
+            st = {}
+            omega, (xt, mt, _) = ps.get_criticality_device(cfg, mod, x, x, fx, lb, ub, seed=3, stats=st)
+            out[tag] = (omega, xt.copy(), st["evals_ideal"] + st["evals_ps"], st["ms_total"])
+        finally:
+            for kk in env:
+                os.environ.pop(kk, None)
+    for tag in ("single", "gave-up", "multi/phases", "single/phases"):
+        assert out[tag][0] == out["multi"][0] and np.array_equal(out[tag][1], out["multi"][1]) and out[tag][2] == out["multi"][2], tag
+    assert out["multi"][0] > 0
+    print("PS ranking d=%d (lambda %d): %.1f ms on sixteen workgroups per run, %.1f ms on one, %.1f ms after a give-up; identical steps"
+          % (d, 20 * (d + 2), out["multi"][3], out["single"][3], out["gave-up"][3]))
+    mod.free()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("d", [24, 64, 128, 256])
 def test_ps_step_on_device_at_baseline_dimensions(d):
     """The device solver at the dimensions of BASELINE.json: d = 64 on a C3-shaped model (the C3 centres, n = 8192, multiquadric),
