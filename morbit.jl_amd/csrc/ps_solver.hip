@@ -39,7 +39,7 @@ constexpr int MAXCON = 32;     // modelled (nonlinear) constraint rows
 constexpr int RANK_THREADS = 1024;
 // ranking of a large population on several compute units (ps_rank_sort_kernel): workgroups per run, phases per chunk (= halo width),
 // smallest population that takes this path, longest window (owned part + two halos) of one workgroup
-constexpr int RS_THREADS = 512, RS_W = 16, RS_B = 256, RS_MINLAM = 2048;
+constexpr int RS_THREADS = 512, RS_W = 16, RS_B = 256, RS_MINLAM = 1024;
 constexpr int RS_MAXWIN = ((MAXLAM + RS_W - 1) / RS_W + 2) + 2 * RS_B;
 constexpr int RS_SYNC = 64;  // sync words per run: [0] arrivals, [1] failure, [2] the run asks for the sort, [3] buffer that holds the result, [4 + c] chunk c moved something
 struct RankWs {  // device work space of the multi-workgroup ranking, run r at offset r * MAXLAM (r * RS_SYNC)

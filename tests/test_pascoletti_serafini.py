@@ -224,7 +224,7 @@ def _check_ps_contract(ev_obj, ev_con, x, lb, ub, fx, omega, xt, mt, stats, lin=
 
 @pytest.mark.gpu
 def test_ps_ranking_on_several_compute_units_is_the_same_ranking():
-    """Populations of 2048 individuals and more (d >= 102) are ranked by sixteen workgroups per run (ps_rank_sort_kernel: chunks of 256
+    """Populations of 1024 individuals and more (d >= 51) are ranked by sixteen workgroups per run (ps_rank_sort_kernel: chunks of 256
     transposition phases on windows with halos, exchanged through global memory).  Same comparisons, same draws: the step must be THE
     step of the one-workgroup ranking (MRBF_PS_MULTI=0) bit for bit -- also when the several-workgroup kernel gives up (MRBF_PS_DBG=64:
     the failure word is set at once and the finishing launch runs the phases itself), and when the phases are forced on generations
