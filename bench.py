@@ -14,7 +14,7 @@ Workloads (morbit.jl_amd/workloads.py):
                          strong scaling, `value` = problems of the batch / wall time of the slowest rank.
   --config C2            single build+solve (no evaluations)
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2|C3|C4|C5] [--problems P] [--no-cpu-baseline]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2|C3|C4|C5] [--problems P] [--no-cpu-baseline] [--no-callers]
 With --gpus N > 1 and no torch.distributed environment the script launches the N ranks itself (python -m torch.distributed.run,
 rendezvous on 127.0.0.1) BEFORE anything touches a GPU, and exits with the launcher's code; under an external
 `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` it runs as one rank.
@@ -50,6 +50,8 @@ def parse_args():
     ap.add_argument("--problems", type=int, default=None, help="problems per step of the many-start configs (default: C4 64, C5 8 per rank)")
     ap.add_argument("--workers", type=int, default=0, help="host threads (contexts) per rank for the many-start configs (default: 4 for n <= 2048, else 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--callers-only", action="store_true", help="(internal) print the callers' side measurement as one JSON line and exit")
+    ap.add_argument("--no-callers", action="store_true", help="skip the side measurement of the path's callers (site selection round 4, Pascoletti-Serafini step)")
     ap.add_argument("--dry-run", action="store_true")
     ap.add_argument("--gram-mode", type=int, default=0)
     ap.add_argument("--chol-impl", type=int, default=0)
@@ -161,8 +163,71 @@ def gram_full_ms(worker, n, d, reps=7):
         return None
 
 
+def measure_callers():
+    """Side measurement, not part of `value`: the callers either side of the hot path at the BASELINE dimensions,
+    through the same library -- wall time of mrbf_round4 (incl. the upload of the candidates) at d = 64 with 10^4 candidates and at
+    d = 128 with 6000 (all accepted), and of one Pascoletti-Serafini step with Morbit's default budgets at d = 64 / 128 / 256 (workloads
+    of tools/round4_bench.py and tools/ps_bench2.py; best of three / two calls after one warm-up call)."""
+    import numpy as np
+    import morbit.jl_amd as pkg
+    from morbit.jl_amd import sampling, workloads as wl
+    from morbit.jl_amd import pascoletti_serafini as ps
+    res = {}
+    try:
+        for d, mc in ((64, 10000), (128, 6000)):
+            rng = np.random.default_rng(1)
+            x = np.full(d, 0.5)
+            start = np.vstack([x[None, :], x[None, :] + 0.3 * np.eye(d)])
+            cand = x[None, :] + 0.4 * (2.0 * rng.random((mc, d)) - 1.0)
+            cfg = pkg.RbfConfig(kernel="cubic")
+            best, nacc = 1e30, 0
+            for rep in range(3):
+                t0 = time.perf_counter()
+                acc, st = sampling.rbf_round4_device(cfg, start, cand, 1.0, keep_state=True)
+                dt = (time.perf_counter() - t0) * 1e3
+                st.free()
+                nacc = len(acc)
+                if rep > 0:
+                    best = min(best, dt)
+            res["round4_d%d_%dcand" % (d, mc)] = {"ms": round(best, 3), "accepted": nacc}
+        for d in (64, 128, 256):
+            if d == 64:
+                C = wl.problem("C3")[0]
+                Y = np.stack([((C - 0.3) ** 2).sum(1), ((C - 0.7) ** 2).sum(1)], 1) / d
+                cfg = pkg.RbfConfig(kernel="multiquadric")
+            elif d == 128:
+                C, Y, _ = wl.problem("C4", 0)
+                cfg = pkg.RbfConfig(kernel="cubic")
+            else:
+                rng = np.random.default_rng(5)
+                C = rng.random((2048, d))
+                Y = np.stack([((C - 0.3) ** 2).sum(1), ((C - 0.7) ** 2).sum(1)], 1) / d
+                cfg = pkg.RbfConfig(kernel="cubic")
+            mod = pkg.update_model(cfg, C, Y)
+            x = C[0].copy() if d == 128 else np.full(d, 0.5)
+            lb, ub = np.maximum(x - 0.1, 0), np.minimum(x + 0.1, 1)
+            fx = pkg.eval_models_at_sites(mod, None, x[None, :])[0]
+            best, omega, ne = 1e30, 0.0, 0
+            for rep in range(3):
+                stt = {}
+                t0 = time.perf_counter()
+                o = ps.get_criticality_device(ps.PascolettiSerafiniConfig(), mod, x, x, fx, lb, ub, seed=0, stats=stt)
+                dt = (time.perf_counter() - t0) * 1e3
+                if rep > 0:
+                    best = min(best, dt)
+                omega, ne = float(o[0]), int(stt["evals_ideal"] + stt["evals_ps"])
+            mod.free()
+            res["ps_step_d%d" % d] = {"ms": round(best, 3), "evaluations": ne, "omega": omega, "n": int(C.shape[0])}
+    except Exception as e:  # the side measurement must never cost the bench line
+        res["error"] = repr(e)
+    return res
+
+
 def main():
     args = parse_args()
+    if args.callers_only:  # child process of the default run (see `callers` below)
+        print(json.dumps(measure_callers()), flush=True)
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))  # nothing below has run: no GPU call in the parent
@@ -510,6 +575,15 @@ def main():
                 port, faithful = cpu_baselines(cfg, C, Y, X)
                 out["cpu_baseline"] = port
                 out["cpu_baseline_faithful"] = faithful
+            if not args.no_callers and world == 1 and args.config == "C3":
+                # in a child process of its own: a second context in THIS process would share hardware queues with the bench's streams
+                # (the walk's two streams then serialise: 6.5 instead of 5.1 ms) -- a caller of the library has one context
+                import subprocess
+                try:
+                    cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--callers-only"], capture_output=True, text=True, timeout=300)
+                    out["callers"] = json.loads(cp.stdout.strip().splitlines()[-1])
+                except Exception as e:  # the side measurement must never cost the bench line
+                    out["callers"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -15,7 +15,7 @@ python3 bench.py --config C4 --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/ben
 python3 bench.py --config C5 --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/bench_c5.json" 2> "$OUT/bench_c5.err"
 echo "bench lines done"
 cd /tmp
-rocprofv3 --kernel-trace --stats -d "$OUT/prof_c3" -o c3 -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench_c3_under_profiler.json" 2> "$OUT/prof_c3.err"
+rocprofv3 --kernel-trace --stats -d "$OUT/prof_c3" -o c3 -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-callers > "$OUT/bench_c3_under_profiler.json" 2> "$OUT/prof_c3.err"
 echo "C3 trace done"
 rocprofv3 --kernel-trace --stats -d "$OUT/prof_c4" -o c4 -- python3 "$ROOT/bench.py" --config C4 --steps 4 --warmup 1 --no-cpu-baseline > "$OUT/bench_c4_under_profiler.json" 2> "$OUT/prof_c4.err"
 echo "C4 trace done"
@@ -23,8 +23,8 @@ rocprofv3 --kernel-trace --stats -d "$OUT/prof_c5" -o c5 -- python3 "$ROOT/bench
 echo "C5 trace done"
 rocprofv3 --kernel-trace --stats -d "$OUT/prof_c2" -o c2 -- python3 "$ROOT/bench.py" --config C2 --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/bench_c2_under_profiler.json" 2> "$OUT/prof_c2.err"
 echo "C2 trace done"
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc_w" -o w -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/pmc_w.json" 2> "$OUT/pmc_w.err"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmc_f" -o f -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/pmc_f.json" 2> "$OUT/pmc_f.err"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc_w" -o w -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-callers > "$OUT/pmc_w.json" 2> "$OUT/pmc_w.err"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmc_f" -o f -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-callers > "$OUT/pmc_f.json" 2> "$OUT/pmc_f.err"
 echo "C3 PMC passes done"
 # PMC passes of the other configurations (roofline.traffic must never be null): C2 (20 cycles), C4 (4 batches), C5 (2 problems x 2 steps)
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc_w_c2" -o w -- python3 "$ROOT/bench.py" --config C2 --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/pmc_w_c2.json" 2> "$OUT/pmc_w_c2.err"
