@@ -405,6 +405,7 @@ __global__ __launch_bounds__(RANK_THREADS) void ps_rank_kernel(Args a, int mode,
                         const int j = 2 * p + (ph & 1);
                         if (j + 1 < lam) {
                             const double fa = sf[j], fb = sf[j + 1], pa = sphi[j], pb = sphi[j + 1];
+                            const int ia = sidx[j], ib = sidx[j + 1];  // (with the keys: a swap then costs no second LDS round trip)
                             bool by_f = pa == 0.0 && pb == 0.0;
                             if (!by_f) {
                                 if (!drawn[s]) {
@@ -419,7 +420,6 @@ __global__ __launch_bounds__(RANK_THREADS) void ps_rank_kernel(Args a, int mode,
                             }
                             const bool worse = by_f ? (fa > fb) : (pa > pb);
                             if (worse) {
-                                const int ia = sidx[j], ib = sidx[j + 1];
                                 sf[j] = fb;
                                 sf[j + 1] = fa;
                                 sphi[j] = pb;
@@ -530,6 +530,7 @@ __global__ __launch_bounds__(RS_THREADS) void ps_rank_sort_kernel(Args a, RankWs
                     if (j + 1 < we0 && s0 < e0) {
                         const int li = j - ws0;
                         const double fa = sf[li], fb = sf[li + 1], pa = sphi[li], pb = sphi[li + 1];
+                        const int ia = sidx[li], ib = sidx[li + 1];  // (with the keys: a swap then costs no second LDS round trip)
                         bool by_f = pa == 0.0 && pb == 0.0;
                         if (!by_f) {
                             if (!drawn) {
@@ -544,7 +545,6 @@ __global__ __launch_bounds__(RS_THREADS) void ps_rank_sort_kernel(Args a, RankWs
                         }
                         const bool worse = by_f ? (fa > fb) : (pa > pb);
                         if (worse) {
-                            const int ia = sidx[li], ib = sidx[li + 1];
                             sf[li] = fb;
                             sf[li + 1] = fa;
                             sphi[li] = pb;
