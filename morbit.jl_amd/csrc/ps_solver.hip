@@ -573,8 +573,9 @@ __global__ __launch_bounds__(RS_THREADS) void ps_rank_sort_kernel(Args a, RankWs
             const unsigned long long t0 = rs_clock();
             bool ok = true;
             while (__hip_atomic_load(sy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                if (__hip_atomic_load(sy + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || rs_clock() - t0 > 2000000ull) {  // 20 ms
+                if (__hip_atomic_load(sy + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || rs_clock() - t0 > 500000ull) {  // 5 ms
                     __hip_atomic_store(sy + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(ws.sync + RS_SYNC * MAXRUNS, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (sticky: the host stops using this kernel)
                     ok = false;
                     break;
                 }
@@ -1044,7 +1045,10 @@ extern "C" int32_t mrbf_ps_step_problem(mrbf_ctx *ctx, const mrbf_ps_problem *pr
         MRBF_HIP(ctx, hipFuncSetAttribute((const void *)ps_rank_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
         // large populations: the transposition phases on RS_W workgroups per run (MRBF_PS_MULTI=0: one workgroup as in rounds 3 / 4)
         RankWs rw{};
-        const bool multi = maxlam >= RS_MINLAM && ctx->ncu >= RS_W * a.nruns && !(getenv("MRBF_PS_MULTI") && atoi(getenv("MRBF_PS_MULTI")) == 0);
+        // (a counter wait that times out -- the workgroups of a run not resident together: a device shared with other work -- costs 5 ms; the
+        // host sees the sticky failure word with the status words, every eight generations, and keeps to one workgroup per run from then on)
+        bool multi = maxlam >= RS_MINLAM && ctx->ncu >= RS_W * a.nruns && !ctx->ps_multi_off &&
+                     !(getenv("MRBF_PS_MULTI") && atoi(getenv("MRBF_PS_MULTI")) == 0);
         if (multi) {
             double *wsb;
             const size_t per_run = (size_t)MAXLAM * 5 + RS_SYNC / 2;  // f, phi twice, idx twice (as doubles: 2 x 1/2), sync words
@@ -1056,6 +1060,7 @@ extern "C" int32_t mrbf_ps_step_problem(mrbf_ctx *ctx, const mrbf_ps_problem *pr
             rw.idx[0] = reinterpret_cast<int *>(rw.phi[1] + (size_t)MAXLAM * MAXRUNS);
             rw.idx[1] = rw.idx[0] + (size_t)MAXLAM * MAXRUNS;
             rw.sync = rw.idx[1] + (size_t)MAXLAM * MAXRUNS;
+            MRBF_HIP(ctx, hipMemsetAsync(rw.sync + RS_SYNC * MAXRUNS, 0, sizeof(int), ctx->stream));
         }
         hipLaunchKernelGGL(ps_init_kernel, dim3((unsigned)((maxel + 255) / 256), (unsigned)a.nruns), dim3(256), 0, ctx->stream, a, start, t0);
         std::vector<int> hstat((size_t)4 * a.nruns);
@@ -1073,7 +1078,13 @@ extern "C" int32_t mrbf_ps_step_problem(mrbf_ctx *ctx, const mrbf_ps_problem *pr
             hipLaunchKernelGGL(ps_breed_kernel, dim3(wave_blocks), dim3(256), 0, ctx->stream, a);
             if ((g & 7) == 7 || g + 1 == max_gens) {  // status words every 8 generations: stop when every run is done
                 MRBF_HIP(ctx, hipMemcpyAsync(hstat.data(), a.runs[0].stat, hstat.size() * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+                int hfail = 0;
+                if (multi) MRBF_HIP(ctx, hipMemcpyAsync(&hfail, rw.sync + RS_SYNC * MAXRUNS, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
                 MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                if (hfail && !(a.dbg & 64)) {
+                    multi = false;
+                    ctx->ps_multi_off = 1;
+                }
                 bool all = true;
                 for (int q2 = 0; q2 < a.nruns; ++q2) all = all && hstat[(size_t)4 * q2 + 1] != 0;
                 if (all) break;
