@@ -856,6 +856,7 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
         MRBF_TRY(launch_cross_gram(ctx, st->C0, n0, st->C0, n0, d, kp, st->Phi00));
         MRBF_TRY(launch_cross_gram(ctx, st->Xc, mc, st->C0, n0, d, kp, st->P0c));
         if (!lazy) MRBF_TRY(launch_cross_gram(ctx, st->Xc, mc, st->Xc, mc, d, kp, Phicc));
+        int *dinfo = nullptr;  // info word of the start set's factorisation (read with the first block's counts)
         if (q > 0) {
             if (!lazy) {
                 MRBF_TRY(get_buf(ctx, S_STAGE_C, (size_t)mc * mc, &E));
@@ -863,7 +864,6 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
             }
             MRBF_TRY(get_buf(ctx, S_W1, (size_t)n0 * mc, &F));
             MRBF_TRY(get_buf(ctx, S_T1, (size_t)q * std::max<int64_t>(mc, q), &T));
-            int *dinfo;
             MRBF_TRY(get_buf(ctx, S_INFO, (size_t)4, &dinfo));
             MRBF_TRY(launch_poly_matrix(ctx, st->C0, n0, d, q, st->Pi0, n0));
             hipLaunchKernelGGL(poly_rows_kernel, dim3(nb(mc * q)), dim3(256), 0, s, st->Xc, mc, d, q, st->Prow);
@@ -873,15 +873,14 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
             MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, q, q, (int)n0, &one, st->Pi0, (int)n0,
                                          st->Pi0, (int)n0, &zero, G0, q));
             MRBF_BLAS(ctx, rocsolver_dpotrf(ctx->blas, rocblas_fill_lower, q, G0, q, dinfo));
-            int hinfo = 0;
-            MRBF_HIP(ctx, hipMemcpyAsync(&hinfo, dinfo, sizeof(int), hipMemcpyDeviceToHost, s));
-            MRBF_HIP(ctx, hipStreamSynchronize(s));
-            if (hinfo != 0) return fail(ctx, MRBF_ESINGULAR, "the start set's polynomial matrix is rank deficient (potrf info %d): use the host mirror", hinfo);
+            // (the factorisation's info word is read with the first block's counts -- no host round trip of its own; a rank-deficient start
+            // set fills the walk with NaNs, which accept nothing, and the call then returns MRBF_ESINGULAR)
             hipLaunchKernelGGL(identity_kernel, dim3(nb(q * q)), dim3(256), 0, s, st->Ginv, q);
             MRBF_BLAS(ctx, rocsolver_dpotrs(ctx->blas, rocblas_fill_lower, q, q, G0, q, st->Ginv, q));
-            // Prow (mc x q row-major) is P' (q x mc) column-major
-            MRBF_HIP(ctx, hipMemcpyAsync(T, st->Prow, (size_t)q * mc * sizeof(double), hipMemcpyDeviceToDevice, s));
-            MRBF_BLAS(ctx, rocsolver_dpotrs(ctx->blas, rocblas_fill_lower, q, (int)mc, G0, q, T, q));
+            // T = G0^-1 P' as a product with the inverse the decision kernel starts from anyway (rocSOLVER's potrs on mc right-hand sides
+            // is a chain of ~ mc / 640 substitution + GEMM launches: 0.2 ms at mc = 10^4); Prow (mc x q row-major) is P' (q x mc) column-major
+            MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, q, (int)mc, q, &one, st->Ginv, q, st->Prow, q, &zero, T,
+                                         q));
             MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, (int)n0, (int)mc, q, &one, st->Pi0, (int)n0, T, q,
                                          &zero, st->LamT, (int)n0));
             // E = Lam Phi0c = LamT' P0c ; F = Phi00 LamT ; Q = LamT' F   (on demand: only F, the n0 x mc panel, is formed here)
@@ -1193,6 +1192,8 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
             int hc_local[2] = {0, 0};
             int *hc = ctx->hpin ? reinterpret_cast<int *>(ctx->hpin + HPIN_R4_COUNT) : hc_local;  // (pinned: the download does not cost a round trip of its own)
             MRBF_HIP(ctx, hipMemcpyAsync(hc, cnt, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+            const bool check_info = blkno == 1 && q > 0 && ctx->hpin;
+            if (check_info) MRBF_HIP(ctx, hipMemcpyAsync(hc + 2, dinfo, sizeof(int), hipMemcpyDeviceToHost, s));
             // the next block's shapes depend on the number accepted so far: the host waits for the counts only, the factor's new rows are
             // appended under the round trip
             if (ctx->evx[3]) MRBF_HIP(ctx, hipEventRecord(ctx->evx[3], s));
@@ -1202,6 +1203,8 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
                 MRBF_HIP(ctx, hipEventSynchronize(ctx->evx[3]));
             else
                 MRBF_HIP(ctx, hipStreamSynchronize(s));
+            if (check_info && hc[2] != 0)
+                return fail(ctx, MRBF_ESINGULAR, "the start set's polynomial matrix is rank deficient (potrf info %d): use the host mirror", hc[2]);
             const int nacc_old = nacc, nblk = hc[1];
             nacc = hc[0];
             const int64_t i1 = i0 + bsz, ahead = mc - i1;
