@@ -29,6 +29,7 @@ namespace mrbf {
 
 int launch_cross_gram(mrbf_ctx *ctx, const double *X, int64_t m, const double *C, int64_t n, int d, const KP &kp, double *K);
 int launch_poly_matrix(mrbf_ctx *ctx, const double *C, int64_t n, int d, int q, double *Pi, int64_t ldpi);
+int potrf_blocked_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int64_t lda, int *dinfo, double *linv_all);  // chol_blocked.hip
 int build_model_shell(mrbf_ctx *ctx, int64_t n, int d, int k, const double *Cdev, int kid, double a, double b, int deg, mrbf_model **out);
 void destroy_model(mrbf_ctx *ctx, mrbf_model *M);
 int fit_check(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info *info);
@@ -726,6 +727,14 @@ __global__ void schur_reduce_kernel(const double *__restrict__ Kbb, const double
     Sb[e] = (r < b && c < b) ? x : 0.0;
 }
 
+// Gp (SB x SB) = [G (q x q) 0; 0 I]
+__global__ void pad_identity_kernel(const double *__restrict__ G, int q, double *__restrict__ Gp) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= SB * SB) return;
+    const int i = idx % SB, j = idx / SB;
+    Gp[idx] = (i < q && j < q) ? G[i + j * q] : (i == j ? 1.0 : 0.0);
+}
+
 // dense j x j copy of the accepted factor
 __global__ void copy_factor_kernel(const double *__restrict__ L, int ldl, int j, double *__restrict__ out) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -872,11 +881,23 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
             MRBF_TRY(get_buf(ctx, S_G, (size_t)q * q, &G0));
             MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, q, q, (int)n0, &one, st->Pi0, (int)n0,
                                          st->Pi0, (int)n0, &zero, G0, q));
-            MRBF_BLAS(ctx, rocsolver_dpotrf(ctx->blas, rocblas_fill_lower, q, G0, q, dinfo));
             // (the factorisation's info word is read with the first block's counts -- no host round trip of its own; a rank-deficient start
             // set fills the walk with NaNs, which accept nothing, and the call then returns MRBF_ESINGULAR)
-            hipLaunchKernelGGL(identity_kernel, dim3(nb(q * q)), dim3(256), 0, s, st->Ginv, q);
-            MRBF_BLAS(ctx, rocsolver_dpotrs(ctx->blas, rocblas_fill_lower, q, q, G0, q, st->Ginv, q));
+            static const int own_g0 = getenv("MRBF_R4_OWNG0") ? atoi(getenv("MRBF_R4_OWNG0")) : 1;
+            if (q <= SB && own_g0) {
+                // q <= 128: the library's own diagonal-block kernel on G0 padded with the identity -- factor and inverse of the factor in one
+                // launch -- and G0^-1 = inv(L)' inv(L)  (rocSOLVER: potf2 59 us + two substitution launches on the identity 94 us)
+                double *Gp, *Li;
+                MRBF_TRY(get_buf(ctx, S_R, (size_t)SB * SB, &Gp));
+                MRBF_TRY(get_buf(ctx, S_PI, (size_t)SB * SB, &Li));
+                hipLaunchKernelGGL(pad_identity_kernel, dim3(nb(SB * SB)), dim3(256), 0, s, G0, q, Gp);
+                MRBF_TRY(potrf_blocked_tall(ctx, SB, SB, Gp, SB, dinfo, Li));
+                MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, q, q, q, &one, Li, SB, Li, SB, &zero, st->Ginv, q));
+            } else {
+                MRBF_BLAS(ctx, rocsolver_dpotrf(ctx->blas, rocblas_fill_lower, q, G0, q, dinfo));
+                hipLaunchKernelGGL(identity_kernel, dim3(nb(q * q)), dim3(256), 0, s, st->Ginv, q);
+                MRBF_BLAS(ctx, rocsolver_dpotrs(ctx->blas, rocblas_fill_lower, q, q, G0, q, st->Ginv, q));
+            }
             // T = G0^-1 P' as a product with the inverse the decision kernel starts from anyway (rocSOLVER's potrs on mc right-hand sides
             // is a chain of ~ mc / 640 substitution + GEMM launches: 0.2 ms at mc = 10^4); Prow (mc x q row-major) is P' (q x mc) column-major
             MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, q, (int)mc, q, &one, st->Ginv, q, st->Prow, q, &zero, T,
