@@ -647,14 +647,20 @@ int eval_nsplit(const mrbf_ctx *ctx, int64_t m, int ntiles) {
     // few centre tiles (n <= 512): never split -- a workgroup's prologue and epilogue (query fragments in, 64 x D Jacobian tile
     // out) cost more than the handful of tiles it would shed, the unsplit kernel finishes values and Jacobians itself (no partials,
     // no combine pass), and such models are evaluated in batches that fill the chip anyway (mrbf_batch_run, the PS solver)
+    // -- unless the query batch is small as well (at most an eighth of the workgroup slots: the populations of a PS step at d <= 24,
+    // single points): the launch then is one workgroup's walk over the tiles, 35 us at n = 512 whatever m; one tile per workgroup
+    // + the combine pass: 10 + 7 us (PS step d = 12, n = 512: 7.25 -> 5.15 ms; MRBF_EVAL_NSPLIT_SMALL=1 keeps them unsplit)
+    static const int small_split = getenv("MRBF_EVAL_NSPLIT_SMALL") ? atoi(getenv("MRBF_EVAL_NSPLIT_SMALL")) : 8;
+    if (ntiles >= 4 && ntiles <= 8 && small_split > 1 && qtiles * 8 <= slots) return std::min(small_split, ntiles);
     if (ntiles <= 8) return 1;
+    static const double comb_small = getenv("MRBF_EVAL_COMB_SMALL") ? atof(getenv("MRBF_EVAL_COMB_SMALL")) : 0.1;
     int nsplit = 1;
     double best_cost = 1e300;
     for (int s = 1; s <= std::min(ntiles, 32); ++s) {
         const int tps_s = (ntiles + s - 1) / s;
         if ((int64_t)(s - 1) * tps_s >= ntiles) continue;  // the last piece would be empty
         const double rounds = std::ceil((double)(qtiles * s) / slots);
-        const double cost = rounds * tps_s + 0.75 * s;
+        const double cost = rounds * tps_s + (qtiles * 8 <= slots ? comb_small : 0.75) * s;  // (a small query batch: the combine pass reads next to nothing)
         if (cost < best_cost) {
             best_cost = cost;
             nsplit = s;
