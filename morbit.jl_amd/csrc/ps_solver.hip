@@ -257,6 +257,7 @@ __global__ __launch_bounds__(RANK_THREADS) void ps_rank_kernel(Args a, int mode,
     __shared__ int s_ired[2 * (RANK_THREADS / 64)];
     __shared__ int s_swapped, s_stop, s_best, s_infeas;
     const int run = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int NT = (int)blockDim.x;  // 64 .. RANK_THREADS: a small population is ranked by as many waves as it has pairs (a barrier of three waves instead of sixteen)
     const Run &R = a.runs[run];
     if (R.stat[1]) return;
     int *const sy = ws.sync ? ws.sync + run * RS_SYNC : nullptr;
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(RANK_THREADS) void ps_rank_kernel(Args a, int mode,
     if (mode != 2) {
         Cand mine{0.0, -1, 0x7fffffff};
         bool infeas = false;
-        for (int i = tid; i < m; i += RANK_THREADS) {
+        for (int i = tid; i < m; i += NT) {
             const double fi = R.f[i], pi = R.phi[i];
             if (pi > 0.0 && pi < INFINITY) infeas = true;
             if (pi == INFINITY) continue;
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(RANK_THREADS) void ps_rank_kernel(Args a, int mode,
         __syncthreads();
         if (tid == 0) {
             Cand b{0.0, -1, 0x7fffffff};
-            for (int w = 0; w < RANK_THREADS / 64; ++w) {
+            for (int w = 0; w < NT / 64; ++w) {
                 const Cand c{s_red[w], s_ired[2 * w], s_ired[2 * w + 1]};
                 if (cand_better(c, b)) b = c;
             }
@@ -316,7 +317,7 @@ __global__ __launch_bounds__(RANK_THREADS) void ps_rank_kernel(Args a, int mode,
         }
         __syncthreads();
         if (s_best >= 0)
-            for (int c = tid; c < n; c += RANK_THREADS) R.best[c] = X[(size_t)s_best * n + c];
+            for (int c = tid; c < n; c += NT) R.best[c] = X[(size_t)s_best * n + c];
     }
     if (s_stop) {
         if (tid == 0) R.stat[1] = 1;
@@ -336,25 +337,25 @@ __global__ __launch_bounds__(RANK_THREADS) void ps_rank_kernel(Args a, int mode,
     if (mode == 2 && sy[1] == 0) {  // the order found by ps_rank_sort_kernel
         sidx = (int *)smem;
         const int *src = ws.idx[sy[3]] + (size_t)run * MAXLAM;
-        for (int i = tid; i < lam; i += RANK_THREADS) sidx[i] = src[i];
+        for (int i = tid; i < lam; i += NT) sidx[i] = src[i];
         __syncthreads();
     } else if (a.dbg & 1) {
         sidx = (int *)smem;
-        for (int i = tid; i < lam; i += RANK_THREADS) sidx[i] = i;
+        for (int i = tid; i < lam; i += NT) sidx[i] = i;
         __syncthreads();
     } else if (plain_sort) {
         int N = 1;
         while (N < lam) N <<= 1;
         double *sf = smem;      // N keys: violation is 0 or inf here, and inf comes with f = inf
         sidx = (int *)(sf + N);
-        for (int i = tid; i < N; i += RANK_THREADS) {
+        for (int i = tid; i < N; i += NT) {
             sf[i] = i < lam ? R.f[i] : INFINITY;
             sidx[i] = i < lam ? i : 0x7fffffff;
         }
         __syncthreads();
         for (int kk = 2; kk <= N; kk <<= 1)
             for (int j = kk >> 1; j > 0; j >>= 1) {
-                for (int t = tid; t < N / 2; t += RANK_THREADS) {
+                for (int t = tid; t < N / 2; t += NT) {
                     const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;  // the t-th pair of this stage
                     const double fa = sf[i], fb = sf[l];
                     const int ia = sidx[i], ib = sidx[l];
@@ -375,7 +376,7 @@ __global__ __launch_bounds__(RANK_THREADS) void ps_rank_kernel(Args a, int mode,
         // pair; one barrier per phase; the no-swap exit is tested every 16 phases.
         double *sf = smem, *sphi = sf + lam;
         sidx = (int *)(sphi + lam);
-        for (int i = tid; i < lam; i += RANK_THREADS) {
+        for (int i = tid; i < lam; i += NT) {
             sf[i] = R.f[i];
             sphi[i] = R.phi[i];
             sidx[i] = i;
@@ -401,7 +402,7 @@ __global__ __launch_bounds__(RANK_THREADS) void ps_rank_kernel(Args a, int mode,
                 if (ph < lam) {
 #pragma unroll
                     for (int s = 0; s < PSLOTS; ++s) {
-                        const int p = tid + s * RANK_THREADS;
+                        const int p = tid + s * NT;
                         const int j = 2 * p + (ph & 1);
                         if (j + 1 < lam) {
                             const double fa = sf[j], fb = sf[j + 1], pa = sphi[j], pb = sphi[j + 1];
@@ -437,12 +438,12 @@ __global__ __launch_bounds__(RANK_THREADS) void ps_rank_kernel(Args a, int mode,
         __syncthreads();
     }
     // the parents, in rank order
-    for (int i = tid; i < mu; i += RANK_THREADS) R.order[i] = sidx[i];
+    for (int i = tid; i < mu; i += NT) R.order[i] = sidx[i];
     // ---- stop like NLopt's xtol_rel, on the survivors' spread: variable by variable, leaving at the first one that still spreads
     bool converged = true;
     for (int c = 0; c < n; ++c) {
         double lo = INFINITY, hi = -INFINITY;
-        for (int s2 = tid; s2 < mu; s2 += RANK_THREADS) {
+        for (int s2 = tid; s2 < mu; s2 += NT) {
             const double v = X[(size_t)sidx[s2] * n + c];
             lo = fmin(lo, v);
             hi = fmax(hi, v);
@@ -457,7 +458,7 @@ __global__ __launch_bounds__(RANK_THREADS) void ps_rank_kernel(Args a, int mode,
             s_red[2 * wave + 1] = hi;
         }
         __syncthreads();
-        for (int w = 0; w < RANK_THREADS / 64; ++w) {
+        for (int w = 0; w < NT / 64; ++w) {
             lo = fmin(lo, s_red[2 * w]);
             hi = fmax(hi, s_red[2 * w + 1]);
         }
@@ -1043,6 +1044,8 @@ extern "C" int32_t mrbf_ps_step_problem(mrbf_ctx *ctx, const mrbf_ps_problem *pr
         while (N < maxlam) N <<= 1;
         const size_t shm = std::max((size_t)20 * maxlam, (size_t)12 * N);
         MRBF_HIP(ctx, hipFuncSetAttribute((const void *)ps_rank_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        // one thread per pair of the largest population (the bitonic network's N / 2 pairs), whole waves, at most RANK_THREADS
+        const int rank_threads = (int)std::min<int64_t>(RANK_THREADS, std::max<int64_t>(64, round_up(N / 2, 64)));
         // large populations: the transposition phases on RS_W workgroups per run (MRBF_PS_MULTI=0: one workgroup as in rounds 3 / 4)
         RankWs rw{};
         // (a counter wait that times out -- the workgroups of a run not resident together: a device shared with other work -- costs 5 ms; the
@@ -1070,10 +1073,10 @@ extern "C" int32_t mrbf_ps_step_problem(mrbf_ctx *ctx, const mrbf_ps_problem *pr
             for (int j = 0; j < P.nmodels; ++j)
                 MRBF_TRY(eval_model(ctx, P.models[j], a.rows, a.Xeval, const_cast<double *>(a.F[j]), nullptr, nullptr));
             hipLaunchKernelGGL(ps_score_kernel, dim3(wave_blocks), dim3(256), 0, ctx->stream, a);
-            hipLaunchKernelGGL(ps_rank_kernel, dim3((unsigned)a.nruns), dim3(RANK_THREADS), shm, ctx->stream, a, multi ? 1 : 0, rw);
+            hipLaunchKernelGGL(ps_rank_kernel, dim3((unsigned)a.nruns), dim3(rank_threads), shm, ctx->stream, a, multi ? 1 : 0, rw);
             if (multi) {
                 hipLaunchKernelGGL(ps_rank_sort_kernel, dim3(RS_W, (unsigned)a.nruns), dim3(RS_THREADS), 0, ctx->stream, a, rw);
-                hipLaunchKernelGGL(ps_rank_kernel, dim3((unsigned)a.nruns), dim3(RANK_THREADS), shm, ctx->stream, a, 2, rw);
+                hipLaunchKernelGGL(ps_rank_kernel, dim3((unsigned)a.nruns), dim3(rank_threads), shm, ctx->stream, a, 2, rw);
             }
             hipLaunchKernelGGL(ps_breed_kernel, dim3(wave_blocks), dim3(256), 0, ctx->stream, a);
             if ((g & 7) == 7 || g + 1 == max_gens) {  // status words every 8 generations: stop when every run is done
