@@ -161,7 +161,7 @@ static int run_small_batch(mrbf_ctx *ctx, const std::vector<int64_t> &idx, const
         L.ws = take(smallfit::carve((int)L.npad, q16).total);
         // evaluation 0: the fit's residual at the sites; evaluation 1: the caller's queries
         L.mpad0 = check ? round_up(pr.n, 64) : 0;
-        L.nsplit0 = check ? eval_nsplit(ctx, pr.n, (int)((pr.n + 63) / 64)) : 1;
+        L.nsplit0 = check ? eval_nsplit(ctx, pr.n, (int)((pr.n + 63) / 64), true) : 1;
         L.Xq0 = take((size_t)L.mpad0 * L.D);
         L.xsq0 = take((size_t)L.mpad0);
         L.vp0 = take(L.nsplit0 > 1 ? (size_t)L.nsplit0 * L.mpad0 * L.KO * 2 : 0);
@@ -328,7 +328,7 @@ static int run_small_batch(mrbf_ctx *ctx, const std::vector<int64_t> &idx, const
         ctx->stream = st;
         if (rc != 0) return rc;
     }
-    // evaluation launches per group of equal (kernel, fast flag, padded dimension, outputs, Jacobians wanted): usually two groups,
+    // evaluation launches per group of equal (kernel, fast flag, padded dimension, outputs, Jacobians wanted, centre range split or not): usually two groups,
     // the residual evaluations at the sites (no Jacobians; on the side stream, beside the evaluation of the queries, together with
     // part 0 of the check kernel) and the evaluations of the queries
     if (side != st) {
@@ -354,8 +354,10 @@ static int run_small_batch(mrbf_ctx *ctx, const std::vector<int64_t> &idx, const
             std::vector<size_t> members;
             for (size_t b = a; b < (is_check ? (size_t)P : evs.size()); ++b) {
                 const mrbf_problem &pb = problems[idx[b % P]];
+                // (members that split their centre range and members that do not -- few query points against few centre tiles are split since
+                // the end of round 5, eval_nsplit -- go into different launches: the group's kernels either all write partials or none does)
                 if (!done[b] && evs[b].kp.kid == kpa.kid && evs[b].kp.fast == kpa.fast && lay[b % P].D == lay[a % P].D && pb.k == pa.k &&
-                    (evs[b].jac != nullptr) == ja) {
+                    (evs[b].jac != nullptr) == ja && (evs[b].nsplit > 1) == (evs[a].nsplit > 1)) {
                     done[b] = 1;
                     if (evs[b].m > 0) members.push_back(b);
                 }

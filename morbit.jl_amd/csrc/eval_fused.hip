@@ -637,7 +637,7 @@ __global__ void center_pad_batch_kernel(const EvalDesc *__restrict__ many, int D
     if (lane == 0) E.xsq[row] = s;
 }
 
-int eval_nsplit(const mrbf_ctx *ctx, int64_t m, int ntiles) {
+int eval_nsplit(const mrbf_ctx *ctx, int64_t m, int ntiles, bool check_call) {
     const int64_t mpad = round_up(m, EQ);
     // Split the centre range so that the grid fills the resident workgroup slots (2 per CU) in whole rounds: the cost of a
     // split count is (rounds of workgroups) x (tiles per workgroup) plus the combine pass, which reads one partial per split.
@@ -651,7 +651,11 @@ int eval_nsplit(const mrbf_ctx *ctx, int64_t m, int ntiles) {
     // single points): the launch then is one workgroup's walk over the tiles, 35 us at n = 512 whatever m; one tile per workgroup
     // + the combine pass: 10 + 7 us (PS step d = 12, n = 512: 7.25 -> 5.15 ms; MRBF_EVAL_NSPLIT_SMALL=1 keeps them unsplit)
     static const int small_split = getenv("MRBF_EVAL_NSPLIT_SMALL") ? atoi(getenv("MRBF_EVAL_NSPLIT_SMALL")) : 8;
-    if (ntiles >= 4 && ntiles <= 8 && small_split > 1 && qtiles * 8 <= slots) return std::min(small_split, ntiles);
+    // (the same rule for a member of a batch -- bit-identical to the single call --: batch.hip launches split and unsplit members apart)
+    // Not for the residual check (the model at its own sites: m = n): in a batch of 64 starts those launches fill the chip together and
+    // splitting them cost C4 1.6 % (19 540 against 19 870 problems/s, three alternating runs); the single fit's check follows the same rule.
+    const bool small_batch = !check_call && qtiles * 8 <= slots;
+    if (ntiles >= 4 && ntiles <= 8 && small_split > 1 && small_batch) return std::min(small_split, ntiles);
     if (ntiles <= 8) return 1;
     static const double comb_small = getenv("MRBF_EVAL_COMB_SMALL") ? atof(getenv("MRBF_EVAL_COMB_SMALL")) : 0.1;
     int nsplit = 1;
@@ -660,7 +664,7 @@ int eval_nsplit(const mrbf_ctx *ctx, int64_t m, int ntiles) {
         const int tps_s = (ntiles + s - 1) / s;
         if ((int64_t)(s - 1) * tps_s >= ntiles) continue;  // the last piece would be empty
         const double rounds = std::ceil((double)(qtiles * s) / slots);
-        const double cost = rounds * tps_s + (qtiles * 8 <= slots ? comb_small : 0.75) * s;  // (a small query batch: the combine pass reads next to nothing)
+        const double cost = rounds * tps_s + (small_batch ? comb_small : 0.75) * s;  // (a small query batch: the combine pass reads next to nothing)
         if (cost < best_cost) {
             best_cost = cost;
             nsplit = s;
@@ -783,7 +787,7 @@ int eval_fused_batch(mrbf_ctx *ctx, const KP &kp, int D, int k, bool want_jac, c
     }
     // one launch per group: either every member finishes inside the kernel (no split of the centre range anywhere) or every member
     // carries partial buffers -- a group that mixes the two would run the partial-writing kernels on members without buffers
-    // (batch.hip sizes them by the member's own split); unreachable while the batch holds models of <= 8 centre tiles, refused otherwise
+    // (batch.hip sizes them by the member's own split and keeps the two kinds in different groups); refused otherwise
     if (max_split > 1)
         for (int p = 0; p < count; ++p)
             if (host_descs[p].nsplit == 1 && host_descs[p].m > 0)
@@ -803,7 +807,7 @@ int eval_fused(mrbf_ctx *ctx, const mrbf_model *M, int64_t m, const double *X, d
     const int64_t mpad = round_up(m, EQ);
     // (n = 2d + 1 = 257 sites are five tiles, not the six of the 128-padded storage: a sixth of a C4 evaluation)
     const int ntiles = (int)((M->n + EC - 1) / EC);
-    const int nsplit = eval_nsplit(ctx, m, ntiles);
+    const int nsplit = eval_nsplit(ctx, m, ntiles, ctx->eval_check_call != 0);
     const int KO = outputs_per_pass(k, D);
     EvalDesc E;
     std::memset(&E, 0, sizeof(E));

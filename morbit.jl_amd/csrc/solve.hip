@@ -1012,7 +1012,10 @@ static int fit_check_enqueue(mrbf_ctx *ctx, mrbf_model *M, const double *Y, doub
     MRBF_TRY(get_buf(ctx, S_STAGE_D, (size_t)n * k, &V));
     MRBF_TRY(get_buf(ctx, S_CHECK_SCAL, (size_t)8, &scal));
     MRBF_HIP(ctx, hipEventRecord(e0, ctx->stream));
-    MRBF_TRY(eval_model(ctx, M, n, M->C, V, nullptr, nullptr));
+    ctx->eval_check_call = 1;  // (the residual check keeps the split rule its batch twin uses: eval_nsplit)
+    const int rc_eval = eval_model(ctx, M, n, M->C, V, nullptr, nullptr);
+    ctx->eval_check_call = 0;
+    if (rc_eval != 0) return rc_eval;
     hipLaunchKernelGGL(residual_kernel, dim3(1), dim3(256), 0, ctx->stream, V, Y, n * k, scal);
     if (q > 0) {
         double *Pi, *T;
