@@ -514,7 +514,10 @@ def test_batch_run_mixed_shapes_matches_single_calls(ctx):
     specs = [  # kernel, deg, n, d, k, m, want_jac
         ("cubic", 1, 150, 6, 2, 20, True), ("multiquadric", 1, 257, 100, 2, 70, True), ("cubic", 1, 90, 6, 1, 33, False),
         ("gaussian", -1, 200, 12, 3, 40, True), ("multiquadric", 1, 300, 100, 2, 64, False), ("cubic", 1, 160, 6, 2, 0, False),
-        ("inv_multiquadric", 0, 120, 70, 2, 25, True), ("cubic", 1, 700, 10, 2, 30, True), ("cubic", 1, 140, 6, 2, 50, True)]
+        ("inv_multiquadric", 0, 120, 70, 2, 25, True), ("cubic", 1, 700, 10, 2, 30, True), ("cubic", 1, 140, 6, 2, 50, True),
+        # few query points against 4 .. 8 centre tiles split the centre range (end of round 5); 150 / 140 sites (3 tiles) do not: the same
+        # (kernel, dimension, outputs, Jacobians) group then holds both kinds and is launched in two parts
+        ("cubic", 1, 300, 6, 2, 40, True), ("cubic", 1, 500, 6, 2, 12, True), ("multiquadric", 1, 260, 100, 2, 9, True)]
     P = len(specs)
     arr = (_lib.Problem * P)()
     res = (_lib.Result * P)()
