@@ -570,6 +570,21 @@ def main():
                 ms8 = (time.perf_counter() - t1) / steps * 1e3
                 out["one_of_eight_gpus"] = dict(problems=len(share.mine), ms_per_step=ms8, fit_ms=float(share.res[0].fit.ms_factor),
                                                 eval_ms=float(share.res[0].ms_eval), speedup_bound_8gpu=out["ms_per_step"] / ms8)
+            if many and not batched and world == 1 and P >= 8:
+                # C5-sized problems: the share ONE of eight GPUs would see (problems p = 0, 8, 16, ...), the same per-problem cycles on
+                # this GPU.  No phase is shared between problems, so total / share is the bound on the 1 -> 8 GPU speed-up that follows
+                # from one-GPU numbers (the counterpart of the C4 entry above)
+                share = mine[::8]
+                for p_ in share[:1]:
+                    workers[0].cycle(p_)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(steps):
+                    for p_ in share:
+                        workers[0].cycle(p_)
+                torch.cuda.synchronize()
+                ms8 = (time.perf_counter() - t1) / steps * 1e3
+                out["one_of_eight_gpus"] = dict(problems=len(share), ms_per_step=ms8, speedup_bound_8gpu=out["ms_per_step"] / ms8)
             if not args.no_cpu_baseline and world == 1 and args.config in ("C2", "C3", "C4"):
                 C, Y, X = host[mine[0]]
                 port, faithful = cpu_baselines(cfg, C, Y, X)

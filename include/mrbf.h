@@ -209,20 +209,29 @@ int32_t mrbf_model_dims(const mrbf_model *model, int64_t *n, int32_t *d, int32_t
 int32_t mrbf_free_model(mrbf_ctx *ctx, mrbf_model *model);
 
 /* many-problem mode (the reference's Threads.@threads loop over independent
- * problems, examples/large_scale_benchmarks.jl:253): shards problems round-robin
- * over n_dev GPUs inside this process, one host thread + ctx + stream per GPU,
- * fit + eval per problem, fixed-size result record per problem. */
+ * problems, examples/large_scale_benchmarks.jl:253): problem p runs on device
+ * device_ids[p % n_dev] (device_ids == NULL: devices 0 .. n_dev-1), one host
+ * thread + pooled ctx per entry of device_ids inside this process (entries may
+ * repeat: {0, 0} is two workers on GPU 0), fit + eval per problem, one
+ * fixed-size result record per problem; a failing problem sets `status` on its
+ * own record only, the call itself returns 0 unless an argument is invalid or
+ * a device cannot be initialised.
+ * Every buffer of a problem may be a HOST pointer or a DEVICE pointer (detected
+ * per pointer, as in mrbf_fit / mrbf_eval; outputs given as device pointers are
+ * written in place, without a host round trip).  With n_dev > 1 a DEVICE buffer
+ * of problem p must live on device_ids[p % n_dev], the device that runs it --
+ * the library does no peer access; host buffers have no such constraint. */
 typedef struct {
     int64_t n, m;
     int32_t d, k, kernel_id, poly_deg;
     double a, b;
-    const double *centres; /* host, n x d */
-    const double *values;  /* host, n x k */
-    const double *X;       /* host, m x d (may be NULL when m == 0) */
-    double *weights_out;   /* host n x k or NULL */
-    double *poly_out;      /* host q x k or NULL */
-    double *vals_out;      /* host m x k or NULL */
-    double *jac_out;       /* host m x k x d or NULL */
+    const double *centres; /* host or device, n x d row-major */
+    const double *values;  /* host or device, n x k row-major */
+    const double *X;       /* host or device, m x d row-major (may be NULL when m == 0) */
+    double *weights_out;   /* host or device n x k, or NULL */
+    double *poly_out;      /* host or device q x k, or NULL */
+    double *vals_out;      /* host or device m x k, or NULL */
+    double *jac_out;       /* host or device m x (k x d column-major blocks), or NULL */
 } mrbf_problem;
 
 typedef struct {

@@ -14,8 +14,15 @@
 # Which of Morbit's calls go to the device and which to Morbit's own methods is decided by the mrbf_dispatch_* functions of the
 # library (include/mrbf.h, "decision table"), the same ones the Python mirror calls; no method here raises because of a size limit.
 # Every ccall below has a 1:1 ctypes twin in morbit.jl_amd/_lib.py, which is what tests/ execute; struct layouts are pinned by
-# tests/test_abi.py.  Conventions: a context is owned by one Julia task at a time (one per thread, created under a lock);
-# models keep their context alive and are released through it; buffers passed to ccall are GC.@preserve'd.
+# tests/test_abi.py; tests/test_julia_binding.py parses every ccall of this file against include/mrbf.h.
+# Conventions: a context is owned by one Julia task at a time (one per thread, created under a lock) and is NOT thread-safe, while
+# finalizers run on whichever thread triggers the GC -- so EVERY ccall that passes a context handle runs inside `_locked(ctx)`, i.e.
+# holding `ctx.lock` (finalizers `trylock` and re-schedule themselves); models keep their context alive and are released through
+# it; buffers passed to ccall are GC.@preserve'd.
+# INERT FOR NON-USERS: nothing in this file changes a run that does not select `HipRbfConfig`.  The three methods that extend Morbit
+# functions on Morbit's own types (`Base.iterate` of the affine filter, `_backtrack`, `get_criticality` of the PS step) first look
+# for a HipRbf object -- the task-local scan state set by `prepare_update_model(..., ::HipRbfConfig, ...)`, a `HipRbfModel` in the
+# container -- and hand over to Morbit's method by `invoke` before anything of libmrbf is touched when there is none.
 
 const libmrbf = get(ENV, "MRBF_LIB", "libmrbf.so")
 
@@ -87,9 +94,27 @@ mrbf_context() = lock(_CTX_LOCK) do
     get!(() -> MrbfContext(), _CTX, Threads.threadid())
 end
 
+"""
+Run `f(handle)` holding the context's lock.  A context is documented as not thread-safe (include/mrbf.h) and model / round-4
+finalizers may run on any thread (whichever triggers the GC, e.g. under the `Threads.@threads` loop of
+examples/large_scale_benchmarks.jl:253): they `trylock` this same lock and re-schedule themselves when it is busy, so a handle is
+never released from thread B while thread A is inside a compute call of the same context.  Reentrant.
+"""
+function _locked(f, ctx::MrbfContext)
+    lock(ctx.lock)
+    try
+        ctx.handle == C_NULL && error("libmrbf context was shut down")
+        return f(ctx.handle)
+    finally
+        unlock(ctx.lock)
+    end
+end
+
 function _check(ctx::MrbfContext, rc::Int32)
     rc == 0 && return nothing
-    msg = unsafe_string(ccall((:mrbf_last_error, libmrbf), Cstring, (Ptr{Cvoid},), ctx.handle))
+    msg = _locked(ctx) do h
+        unsafe_string(ccall((:mrbf_last_error, libmrbf), Cstring, (Ptr{Cvoid},), h))
+    end
     # MRBF_ENOTPD = 1, MRBF_ESINGULAR = 2: numerical failures the algorithm can react to (rebuild / not fully linear)
     rc in (1, 2) ? throw(LinearAlgebra.SingularException(Int(rc))) : error("libmrbf error $rc: $msg")
 end
@@ -193,7 +218,8 @@ _fallback_rc(entry, rc) = ccall((:mrbf_dispatch_after, libmrbf), Int32, (Int32, 
 # ---- two-phase construction: phase I (which sites) stays Morbit's control flow (RbfModel.jl:506-655 is generic in `cfg`); the
 #      pieces of it that are arithmetic are re-routed by dispatch on the config / element type:
 #        _rbf_round4(..., cfg::HipRbfConfig)                       -> mrbf_round4, factors kept for the fit
-#        iterate(::AffinelyIndependentPointFilter{Float64}, n)    -> mrbf_affine_scores for large candidate sets
+#        iterate(::AffinelyIndependentPointFilter{Float64}, n)    -> mrbf_affine_scores for large candidate sets, ONLY while the
+#                                                                    task-local scan state of a HipRbfConfig's update is set
 _get_signature(cfg::HipRbfConfig) = (cfg.θ_pivot, cfg.θ_enlarge_1, cfg.θ_enlarge_2, cfg.optimized_sampling)   # RbfModel.jl:114
 
 function prepare_init_model(cfg::HipRbfConfig, func_indices, mop, scal, id, sdb, ac; ensure_fully_linear = true, kwargs...)
@@ -204,10 +230,22 @@ end
 # Morbit's generic method (first argument Union{Nothing,RbfModel}, `cfg` untyped); run with `nothing` as the model it never looks at.
 # Two methods so that neither is ambiguous with the generic one for a `nothing` model.
 const _GENERIC_PREPARE_SIG = Tuple{Union{Nothing,RbfModel},RbfMeta,Any,Any,Any,Any,Any,Any,Any}
+# While Morbit's generic method runs FOR A HipRbfConfig, the task carries a scan state: that -- not the element type of the filter --
+# is what routes the affine filter's candidate scan (rounds 1-2) to the device.  The filter is built without a config
+# (RbfModel.jl:219), so the config cannot be dispatched on there; a plain `RbfConfig` run never sets the key, on any task.
+const _HIP_AFFINE_KEY = :HipRbf_affine_scan
+mutable struct HipRbfAffineScan
+    seeds::IdDict{Any,Matrix{Float64}}      # filter => d x mc matrix of shifted seeds, picked columns zeroed (task-local, no global)
+end
+_hip_affine_scan() = get(task_local_storage(), _HIP_AFFINE_KEY, nothing)
+_prepare_with_device_scan(meta, cfg::HipRbfConfig, args...; kwargs...) =
+    task_local_storage(_HIP_AFFINE_KEY, HipRbfAffineScan(IdDict{Any,Matrix{Float64}}())) do
+        invoke(prepare_update_model, _GENERIC_PREPARE_SIG, nothing, meta, cfg, args...; kwargs...)
+    end
 prepare_update_model(mod::Nothing, meta::RbfMeta, cfg::HipRbfConfig, func_indices, mop, scal, iter_data, sdb, ac; kwargs...) =
-    invoke(prepare_update_model, _GENERIC_PREPARE_SIG, nothing, meta, cfg, func_indices, mop, scal, iter_data, sdb, ac; kwargs...)
+    _prepare_with_device_scan(meta, cfg, func_indices, mop, scal, iter_data, sdb, ac; kwargs...)
 prepare_update_model(mod::HipRbfModel, meta::RbfMeta, cfg::HipRbfConfig, func_indices, mop, scal, iter_data, sdb, ac; kwargs...) =
-    invoke(prepare_update_model, _GENERIC_PREPARE_SIG, nothing, meta, cfg, func_indices, mop, scal, iter_data, sdb, ac; kwargs...)
+    _prepare_with_device_scan(meta, cfg, func_indices, mop, scal, iter_data, sdb, ac; kwargs...)
 # the improvement step only reads config fields (RbfModel.jl:699-732)
 prepare_improve_model(mod::Union{Nothing,HipRbfModel}, meta::RbfMeta, cfg::HipRbfConfig, args...; kwargs...) =
     prepare_improve_model(nothing, meta, _as_rbf_config(cfg), args...; kwargs...)
@@ -262,15 +300,18 @@ function _rbf_round4(db, lb_2, ub_2, x::AbstractVector{F}, Δ, indices_found_so_
     return _rbf_round4(db, lb_2, ub_2, x, Δ, indices_found_so_far, _as_rbf_config(cfg))
 end
 
-# ---- rounds 1-2: the candidate scan of the affine filter (AffinelyIndependentPoints.jl:71-106) for Float64 filters with many
-#      candidates; picks, order and the Y / Z bookkeeping are the reference's
-const _AFFINE_SEEDS = IdDict{Any,Matrix{Float64}}()      # filter => d x mc matrix of shifted seeds, picked columns zeroed
+# ---- rounds 1-2: the candidate scan of the affine filter (AffinelyIndependentPoints.jl:71-106) with many candidates; picks, order
+#      and the Y / Z bookkeeping are the reference's.  Routed by the task-local scan state of a HipRbfConfig's model update: without
+#      it (every plain RbfConfig run) the first statement hands over to Morbit's own method -- no ccall, no library needed.
 function Base.iterate(filter::AffinelyIndependentPointFilter{Float64,VF,SV}, num_found::Int) where {VF,SV}
-    num_found == filter.n && (delete!(_AFFINE_SEEDS, filter); return nothing)
-    isempty(filter.candidate_indices) && (delete!(_AFFINE_SEEDS, filter); return nothing)
-    generic() = invoke(Base.iterate, Tuple{AffinelyIndependentPointFilter,Int}, filter, num_found)
-    _dispatch_affine(length(filter.candidate_indices), length(filter.x_0)) || return generic()
-    S = get!(_AFFINE_SEEDS, filter) do
+    scan = _hip_affine_scan()
+    scan === nothing && return invoke(Base.iterate, Tuple{AffinelyIndependentPointFilter,Int}, filter, num_found)
+    seeds = scan.seeds
+    num_found == filter.n && (delete!(seeds, filter); return nothing)
+    isempty(filter.candidate_indices) && (delete!(seeds, filter); return nothing)
+    _dispatch_affine(length(filter.candidate_indices), length(filter.x_0)) ||
+        return invoke(Base.iterate, Tuple{AffinelyIndependentPointFilter,Int}, filter, num_found)
+    S = get!(seeds, filter) do
         M = _dense(_as_matrix(filter.shifted_seeds))
         for j in setdiff(eachindex(filter.shifted_seeds), filter.candidate_indices)
             M[:, j] .= 0                                   # chosen sites score 0 (the reference removes them from the list)
@@ -286,7 +327,7 @@ function Base.iterate(filter::AffinelyIndependentPointFilter{Float64,VF,SV}, num
         S[:, i] .= 0
         return (filter.return_indices ? i : filter.seeds[i]), num_found + 1
     end
-    delete!(_AFFINE_SEEDS, filter)
+    delete!(seeds, filter)
     return nothing
 end
 
@@ -322,11 +363,13 @@ function update_model(mod::Union{Nothing,HipRbfModel}, meta::RbfMeta, cfg::HipRb
     ctx = mrbf_context()
     h = Ref{Ptr{Cvoid}}(C_NULL)
     info = Ref{MrbfFitInfo}()
-    GC.@preserve C Y begin
-        rc = ccall((:mrbf_fit, libmrbf), Int32,
-                   (Ptr{Cvoid}, Int64, Int32, Int32, Ptr{Float64}, Ptr{Float64}, Int32, Float64, Float64, Int32,
-                    Ref{Ptr{Cvoid}}, Ptr{Float64}, Ptr{Float64}, Ref{MrbfFitInfo}),
-                   ctx.handle, n, d, k, C, Y, kid, a, b, cfg.polynomial_degree, h, C_NULL, C_NULL, info)
+    rc = GC.@preserve C Y begin
+        _locked(ctx) do hctx
+            ccall((:mrbf_fit, libmrbf), Int32,
+                  (Ptr{Cvoid}, Int64, Int32, Int32, Ptr{Float64}, Ptr{Float64}, Int32, Float64, Float64, Int32,
+                   Ref{Ptr{Cvoid}}, Ptr{Float64}, Ptr{Float64}, Ref{MrbfFitInfo}),
+                  hctx, n, d, k, C, Y, kid, a, b, cfg.polynomial_degree, h, C_NULL, C_NULL, info)
+        end
     end
     _check(ctx, rc)
     @logmsg loglevel3 "The model is $(meta.fully_linear ? "" : "not ")fully linear (solve path $(info[].path), residual $(info[].rel_residual))."
@@ -338,10 +381,12 @@ function _mrbf_eval(mod::HipRbfModel, X::Matrix{Float64}; values::Bool = true, j
     d, m, k = mod.n_vars, size(X, 2), mod.num_outputs            # X is d x m column-major == m x d row-major
     V = values ? Matrix{Float64}(undef, k, m) : nothing          # k x m column-major == m x k row-major
     J = jac ? Array{Float64,3}(undef, k, d, m) : nothing         # per point a k x d column-major block
-    GC.@preserve X V J begin
-        rc = ccall((:mrbf_eval, libmrbf), Int32,
-                   (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}),
-                   mod.ctx.handle, mod.handle, m, X, values ? pointer(V) : C_NULL, jac ? pointer(J) : C_NULL, C_NULL)
+    rc = GC.@preserve X V J begin
+        _locked(mod.ctx) do hctx
+            ccall((:mrbf_eval, libmrbf), Int32,
+                  (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}),
+                  hctx, mod.handle, m, X, values ? pointer(V) : C_NULL, jac ? pointer(J) : C_NULL, C_NULL)
+        end
     end
     _check(mod.ctx, rc)
     return V, J
@@ -429,6 +474,17 @@ for plural in (:objectives, :nl_eq_constraints, :nl_ineq_constraints)
     end
 end
 
+"Does the container hold a `HipRbfModel` at all?  Pure Julia: asked before anything of libmrbf is touched (inertness for non-users)."
+function _touches_device(sc::SurrogateContainer; objectives_only::Bool = false)
+    kinds = objectives_only ? (Val(:objectives),) : (Val(:objectives), Val(:nl_eq_constraints), Val(:nl_ineq_constraints))
+    for kind in kinds
+        for s in _container_surrogates(sc, kind)
+            _inner(s) isa HipRbfModel && return true
+        end
+    end
+    return false
+end
+
 # What the device entry points need to know about a container: its distinct grouped HipRbfModels, the role of every output row
 # (objective position l >= 0, MRBF_ROLE_EQ = -2, MRBF_ROLE_INEQ = -3, MRBF_ROLE_NONE = -1) and how many surrogates are "foreign"
 # (CompositeSurrogates, other model families, or a model row used twice): with a foreign one the reference methods run.
@@ -466,6 +522,9 @@ end
 # ---- descent consumers ------------------------------------------------------------------------------------------------------------
 "All Armijo step sizes of `_backtrack` (descent.jl:150-185) in one batch; returns (x₊, mx₊, step) like the reference."
 function _backtrack(x::AbstractVector{F}, dir, step_size, ω, sc::SurrogateContainer, cfg, scal) where {F<:AbstractFloat}
+    # no HipRbfModel among the objectives (every run that does not use HipRbfConfig): Morbit's own loop, libmrbf is not touched
+    _touches_device(sc; objectives_only = true) ||
+        return invoke(_backtrack, Tuple{AbstractVector{F},Any,Any,Any,Any,Any,Any}, x, dir, step_size, ω, sc, cfg, scal)
     plan = _container_plan(sc; objectives_only = true)
     if !_dispatch_backtrack(length(plan.models), plan.n_foreign, plan.in_order)
         return invoke(_backtrack, Tuple{AbstractVector{F},Any,Any,Any,Any,Any,Any}, x, dir, step_size, ω, sc, cfg, scal)
@@ -474,13 +533,15 @@ function _backtrack(x::AbstractVector{F}, dir, step_size, ω, sc::SurrogateConta
     x64 = Vector{Float64}(x); dir64 = Vector{Float64}(dir)
     k = model.num_outputs
     x₊, mx₊, step, loops = similar(x64), Vector{Float64}(undef, k), similar(x64), Ref{Int32}(0)
-    GC.@preserve x64 dir64 x₊ mx₊ step begin
-        rc = ccall((:mrbf_backtrack, libmrbf), Int32,
-                   (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Float64, Float64, Int32, Float64, Float64, Float64, Int32,
-                    Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Int32}),
-                   model.ctx.handle, model.handle, x64, dir64, step_size, ω, cfg.strict_backtracking, cfg.armijo_const_rhs,
-                   cfg.armijo_const_shrink, cfg.min_stepsize >= 0 ? cfg.min_stepsize : eps(F), cfg.max_loops,
-                   x₊, mx₊, step, loops)
+    rc = GC.@preserve x64 dir64 x₊ mx₊ step begin
+        _locked(model.ctx) do hctx
+            ccall((:mrbf_backtrack, libmrbf), Int32,
+                  (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Float64, Float64, Int32, Float64, Float64, Float64, Int32,
+                   Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Int32}),
+                  hctx, model.handle, x64, dir64, step_size, ω, cfg.strict_backtracking, cfg.armijo_const_rhs,
+                  cfg.armijo_const_shrink, cfg.min_stepsize >= 0 ? cfg.min_stepsize : eps(F), cfg.max_loops,
+                  x₊, mx₊, step, loops)
+        end
     end
     _check(model.ctx, rc)
     return F.(x₊), F.(mx₊), F.(step)
@@ -496,6 +557,7 @@ Same returns as the reference.
 function get_criticality(desc_cfg::PascolettiSerafiniConfig, mop, scal, x_it, x_it_n, data_base, sc::SurrogateContainer, algo_config;
                          seed::UInt64 = rand(UInt64))
     reference() = invoke(get_criticality, Tuple{PascolettiSerafiniConfig,Any,Any,Any,Any,Any,Any,Any}, desc_cfg, mop, scal, x_it, x_it_n, data_base, sc, algo_config)
+    _touches_device(sc) || return reference()      # no HipRbfModel in the container: Morbit's own method, libmrbf is not touched
     plan = _container_plan(sc)
     x = Vector{Float64}(get_x_scaled(x_it)); x_n = Vector{Float64}(get_x_scaled(x_it_n)); fx_n = Vector{Float64}(get_fx(x_it_n))
     d, k = length(x_n), plan.k
@@ -519,10 +581,12 @@ function get_criticality(desc_cfg::PascolettiSerafiniConfig, mop, scal, x_it, x_
         prob = Ref(MrbfPsProblem(length(handles), k, pointer(handles), pointer(roles), length(beq), length(bin),
                                  isempty(beq) ? C_NULL : pointer(Aeq), isempty(beq) ? C_NULL : pointer(beq),
                                  isempty(bin) ? C_NULL : pointer(Ain), isempty(bin) ? C_NULL : pointer(bin), -1.0))
-        ccall((:mrbf_ps_step_problem, libmrbf), Int32,
-              (Ptr{Cvoid}, Ref{MrbfPsProblem}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{MrbfPsOptions},
-               Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{MrbfPsInfo}),
-              ctx.handle, prob, x_n, lb, ub, fx_n, rbuf === nothing ? C_NULL : pointer(rbuf), opts, x_trial, mx_trial, C_NULL, info)
+        _locked(ctx) do hctx
+            ccall((:mrbf_ps_step_problem, libmrbf), Int32,
+                  (Ptr{Cvoid}, Ref{MrbfPsProblem}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{MrbfPsOptions},
+                   Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{MrbfPsInfo}),
+                  hctx, prob, x_n, lb, ub, fx_n, rbuf === nothing ? C_NULL : pointer(rbuf), opts, x_trial, mx_trial, C_NULL, info)
+        end
     end
     rc != 0 && _fallback_rc(3, rc) && return reference()
     _check(ctx, rc)
@@ -538,10 +602,19 @@ mutable struct HipRound4State
     handle::Ptr{Cvoid}
 end
 function _free_round4!(s::HipRound4State)
-    if s.handle != C_NULL && s.ctx.handle != C_NULL
-        ccall((:mrbf_free_round4, libmrbf), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), s.ctx.handle, s.handle)
+    ctx = s.ctx
+    if !trylock(ctx.lock)                 # also a finalizer: never block, never release under a running call of the same context
+        @async _free_round4!(s)
+        return nothing
     end
-    s.handle = C_NULL
+    try
+        if s.handle != C_NULL && ctx.handle != C_NULL
+            ccall((:mrbf_free_round4, libmrbf), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), ctx.handle, s.handle)
+        end
+        s.handle = C_NULL
+    finally
+        unlock(ctx.lock)
+    end
     return nothing
 end
 "(n0, accepted sites, q) of a kept round-4 factor"
@@ -563,12 +636,14 @@ function rbf_round4_device(cfg::HipRbfConfig, Δ, start_sites, cand_sites; keep_
     kid, a, b = _mrbf_kernel_params(Δ, cfg)
     ctx = mrbf_context()
     acc = Vector{Int32}(undef, max(mc, 1)); nacc = Ref{Int32}(0); st = Ref{Ptr{Cvoid}}(C_NULL)
-    GC.@preserve C0 Xc acc begin
-        rc = ccall((:mrbf_round4, libmrbf), Int32,
-                   (Ptr{Cvoid}, Int64, Int32, Ptr{Float64}, Int64, Ptr{Float64}, Int32, Float64, Float64, Int32, Int32, Float64,
-                    Ptr{Int32}, Ref{Int32}, Ptr{Ptr{Cvoid}}),
-                   ctx.handle, n0, d, C0, mc, Xc, kid, a, b, cfg.polynomial_degree, cfg.max_model_points, cfg.θ_pivot_cholesky,
-                   acc, nacc, keep_state ? Base.unsafe_convert(Ptr{Ptr{Cvoid}}, st) : C_NULL)
+    rc = GC.@preserve C0 Xc acc begin
+        _locked(ctx) do hctx
+            ccall((:mrbf_round4, libmrbf), Int32,
+                  (Ptr{Cvoid}, Int64, Int32, Ptr{Float64}, Int64, Ptr{Float64}, Int32, Float64, Float64, Int32, Int32, Float64,
+                   Ptr{Int32}, Ref{Int32}, Ptr{Ptr{Cvoid}}),
+                  hctx, n0, d, C0, mc, Xc, kid, a, b, cfg.polynomial_degree, cfg.max_model_points, cfg.θ_pivot_cholesky,
+                  acc, nacc, keep_state ? Base.unsafe_convert(Ptr{Ptr{Cvoid}}, st) : C_NULL)
+        end
     end
     if rc != 0
         rc_only && return rc, Int[], nothing
@@ -587,9 +662,11 @@ end
 function fit_from_round4(state::HipRound4State, values, n_vars::Int, fully_linear::Bool; rc_only::Bool = false)
     Y = _dense(_as_matrix(values)); k = size(Y, 1)
     h = Ref{Ptr{Cvoid}}(C_NULL); info = Ref{MrbfFitInfo}()
-    GC.@preserve Y begin
-        rc = ccall((:mrbf_fit_from_round4, libmrbf), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Ptr{Float64}, Ref{Ptr{Cvoid}}, Ptr{Float64}, Ptr{Float64}, Ref{MrbfFitInfo}),
-                   state.ctx.handle, state.handle, k, Y, h, C_NULL, C_NULL, info)
+    rc = GC.@preserve Y begin
+        _locked(state.ctx) do hctx
+            ccall((:mrbf_fit_from_round4, libmrbf), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Ptr{Float64}, Ref{Ptr{Cvoid}}, Ptr{Float64}, Ptr{Float64}, Ref{MrbfFitInfo}),
+                  hctx, state.handle, k, Y, h, C_NULL, C_NULL, info)
+        end
     end
     if rc != 0
         rc_only && return rc, nothing
@@ -603,9 +680,11 @@ affine_scores(shifted_seeds::AbstractVector, Z::AbstractMatrix, p = Inf) = affin
 function affine_scores(S::AbstractMatrix{Float64}, Z::AbstractMatrix, p = Inf)     # S: d x mc, one shifted seed per column
     d, mc = size(S); Zm = Matrix{Float64}(Z)
     ctx = mrbf_context(); best = Ref{Int64}(-1); val = Ref{Float64}(-Inf)
-    GC.@preserve S Zm begin
-        rc = ccall((:mrbf_affine_scores, libmrbf), Int32, (Ptr{Cvoid}, Int64, Int32, Int32, Ptr{Float64}, Ptr{Float64}, Int32, Ptr{Float64}, Ref{Int64}, Ref{Float64}),
-                   ctx.handle, mc, d, size(Zm, 2), S, Zm, isinf(p) ? 1 : 0, C_NULL, best, val)
+    rc = GC.@preserve S Zm begin
+        _locked(ctx) do hctx
+            ccall((:mrbf_affine_scores, libmrbf), Int32, (Ptr{Cvoid}, Int64, Int32, Int32, Ptr{Float64}, Ptr{Float64}, Int32, Ptr{Float64}, Ref{Int64}, Ref{Float64}),
+                  hctx, mc, d, size(Zm, 2), S, Zm, isinf(p) ? 1 : 0, C_NULL, best, val)
+        end
     end
     _check(ctx, rc)
     return Int(best[]) + 1, val[]

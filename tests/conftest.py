@@ -26,7 +26,23 @@ def load_golden():
         for key in ("C", "Y", "X", "W", "Lam", "V", "J", "Phi", "Pi"):
             d[key] = arrs[pre + key]
         cases.append(d)
+    # extended-precision truth (tests/golden/make_truth.py, mpmath at 60 digits) stored as hi + lo doubles
+    tpath = os.path.join(g, "rbf_truth.npz")
+    if os.path.exists(tpath):
+        tr = np.load(tpath)
+        for d in cases:
+            pre = "c%03d_" % d["idx"]
+            if pre + "W_hi" in tr.files:
+                d["truth"] = {key: (tr[pre + key + "_hi"], tr[pre + key + "_lo"]) for key in ("W", "Lam", "V", "J")}
     return cases
+
+
+def dist_from_truth(x, truth_pair):
+    """max |x - truth| / max |truth| with the truth given as (hi, lo) doubles: (x - hi) is exact or nearly so
+    (Sterbenz) wherever x is close to hi, and lo restores what the rounding of hi took away."""
+    hi, lo = truth_pair
+    x = np.asarray(x, dtype=np.float64).reshape(hi.shape)
+    return float(np.abs((x - hi) - lo).max() / max(np.abs(hi).max(), 1e-300))
 
 
 @pytest.fixture(scope="session")

@@ -182,7 +182,7 @@ def test_c5_full_size_single_problem(ctx):
                                                           info["ms_solve"], t_oracle, threads, ew, ev, ej, be, be_o))
     assert be <= 50 * EPS, be
     assert ev < 1e-8 and ej < 1e-8, (ev, ej)
-    assert ew < 1e-10 or np.linalg.norm(xg - sol) / np.linalg.norm(sol) <= 4 * float(np.linalg.cond(S, 1)) * (be + be_o), (ew, be, be_o)
+    assert ew < 1e-10, (ew, be, be_o)          # outright (observed 1.8e-11)
     mod.free()
 
 

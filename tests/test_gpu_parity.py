@@ -2,9 +2,11 @@
 CPU oracle, the committed golden fixtures, and size-independent properties at BASELINE.json sizes.
 
 Tolerances (BASELINE.json north_star): 1e-10 relative on interpolation weights, 1e-8 on surrogate values.
-Weights: asserted at 1e-10 outright on every case with cond < 1e6; on every case (any conditioning) the GPU
-solution must solve the oracle's saddle system with a normwise backward error <= 50 eps; the (two) cases above
-1e-10 are listed with the reason in gpurun_out/parity_report.json and bounded by cond x measured backward error.
+Weights: asserted at 1e-10 outright against the fp64 oracle on every case with cond < 1e6 and on every medium / full-size
+problem; on every case (any conditioning) the GPU solution must solve the oracle's saddle system with a normwise backward
+error <= 50 eps; and every fixture case is MEASURED against an extended-precision truth (tests/golden/rbf_truth.npz, mpmath at
+60 digits): GPU weights within 1e-10 of the true weights, or no further from them than twice the fp64 LAPACK LU is (C1 as
+BASELINE.json writes it, cond 5.7e11, where no fp64 solver reaches 1e-10).  No case is justified by a perturbation bound.
 """
 import ctypes
 import json
@@ -13,7 +15,7 @@ import os
 import numpy as np
 import pytest
 
-from tests.conftest import ROOT, has_gpu
+from tests.conftest import ROOT, dist_from_truth, has_gpu
 
 pytestmark = pytest.mark.gpu
 
@@ -126,16 +128,24 @@ def test_fit_and_eval_match_golden(ctx, golden):
         # (2) the north-star weight tolerance, outright, wherever the problem is well conditioned
         if cond < WELL_CONDITIONED and not under:
             assert ew < W_TOL, (c["name"], ew, cond)
-        elif ew >= W_TOL:
-            # ill-conditioned: two backward-stable solutions differ by <= cond * (sum of backward errors) -- standard
-            # perturbation theory, asserted with the MEASURED backward errors instead of a blanket eps * cond window
-            xg, xo = np.vstack([mod.weights, mod.poly]), np.vstack([c["W"], c["Lam"]])
-            ef = np.linalg.norm(xg - xo) / np.linalg.norm(xo)
-            assert ef <= 4 * cond * (be + be_oracle), (c["name"], ef, cond, be, be_oracle)
-            exceeded.append(dict(name=c["name"], weight_err=ew, cond=cond, backward_error=be, why=(
-                "cond %.1e: the oracle's LU and the GPU's projected Cholesky are both backward stable (backward errors %.1e / %.1e); "
-                "their weights differ by <= cond * backward error; values %.1e and Jacobians %.1e still meet 1e-8"
-                % (cond, be_oracle, be, ev, ej))))
+        # (3) MEASURED against the extended-precision truth (tests/golden/make_truth.py: the same saddle system solved by
+        # mpmath at 60 digits): the GPU weights are within 1e-10 of the true weights, or -- where fp64 itself cannot deliver
+        # that -- no further from them than twice the reference-pattern solver (LAPACK LU of the saddle system) is.
+        if "truth" in c:
+            t = c["truth"]
+            tw_gpu, tw_orc = dist_from_truth(mod.weights, t["W"]), dist_from_truth(c["W"], t["W"])
+            tv = dist_from_truth(V, t["V"]) * np.abs(t["V"][0]).max() / max(1.0, np.abs(t["V"][0]).max())
+            tj = dist_from_truth(J, t["J"]) * np.abs(t["J"][0]).max() / max(1.0, np.abs(t["J"][0]).max())
+            rows[-1].update(w_vs_truth=tw_gpu, w_oracle_vs_truth=tw_orc, v_vs_truth=tv, j_vs_truth=tj)
+            assert tw_gpu <= max(W_TOL, 2.0 * tw_orc), (c["name"], tw_gpu, tw_orc, cond)
+            assert tv < 1e-8 and tj < 1e-8, (c["name"], tv, tj)
+            if ew >= W_TOL:
+                exceeded.append(dict(name=c["name"], weight_err_vs_oracle=ew, cond=cond, gpu_vs_truth=tw_gpu, oracle_vs_truth=tw_orc,
+                                     values_vs_truth=tv, jac_vs_truth=tj, why=(
+                    "cond %.1e: measured against the 60-digit solution the GPU weights are %.1e from the truth and the fp64 "
+                    "LAPACK LU %.1e; the two fp64 solutions differ by %.1e from each other" % (cond, tw_gpu, tw_orc, ew))))
+        else:
+            assert under, c["name"]   # only minimum-norm (n < q) cases have no truth entry
         assert ev < 1e-8, (c["name"], ev, cond)
         assert ej < 1e-8, (c["name"], ej, cond)
         assert mod.info["rel_residual"] < 1e-11, (c["name"], mod.info)
@@ -148,8 +158,9 @@ def test_fit_and_eval_match_golden(ctx, golden):
     REPORT["weights_above_1e-10"] = exceeded
     paths = {r["path"] for r in rows}
     assert paths == {1, 2, 3}, paths  # all three solve paths are exercised by the grid
-    # only the two known ill-conditioned cases may exceed 1e-10; BASELINE config C1 with a bounded-conditioning shape meets it outright
-    assert {e["name"] for e in exceeded} <= {"c1_two_parabolas", "mq_beta1p5"}, exceeded
+    # no name whitelist: every case above is decided by the measurement against the truth; what differs from the fp64 oracle by
+    # more than 1e-10 is listed in the report with both distances.  BASELINE config C1 with a bounded-conditioning shape meets
+    # 1e-10 outright
     c1b = next(r for r in rows if r["name"] == "c1_two_parabolas_shape_2_over_delta")
     assert c1b["w"] < W_TOL and c1b["cond"] < WELL_CONDITIONED
 
@@ -216,9 +227,7 @@ def test_medium_sizes_against_oracle(ctx, kernel, deg, n, d):
     REPORT[key].update(cond=cond, backward_error=be, backward_error_oracle=be_o)
     assert be <= 50 * EPS, be
     xg, xo = np.vstack([mod.weights, mod.poly]), np.vstack([ref.w, ref.lam])
-    assert ew < W_TOL or np.linalg.norm(xg - xo) / np.linalg.norm(xo) <= 4 * cond * (be + be_o), (ew, cond, be, be_o)
-    if cond < WELL_CONDITIONED:
-        assert ew < W_TOL, (ew, cond)
+    assert ew < W_TOL, (ew, cond, be, be_o)   # outright at every conditioning of this list (cond up to 9e7: observed <= 7e-12)
     assert mod.info["rel_residual"] < 1e-10
     mod.free()
 
@@ -363,6 +372,23 @@ def test_full_size_properties_c2_c3(ctx):
         assert mod.info["path"] == _lib.PATH_PROJ_CHOL
         assert mod.info["rel_residual"] < 1e-10, mod.info
         assert mod.info["max_pitw"] < 1e-8 * max(1.0, np.abs(mod.weights).max())
+        if name == "C2":
+            # C2 WITH its degree-1 tail against the oracle's LAPACK LU of the 2081 x 2081 saddle system (C3's and C5's
+            # counterparts: test_c3_bench_workload_eval_against_oracle, test_c5_full_size): north-star tolerances outright
+            kid, a, b = pkg.rbf_model._get_kernel_params(1.0, cfg)
+            ref = orc.fit(C, Y, kid, a, b, 1)
+            Phi, Pi = orc.gram(C, kid, a, b, 1)
+            case = dict(Phi=Phi, Pi=Pi, Y=Y)
+            be, be_o = _backward_error(case, mod.weights, mod.poly), _backward_error(case, ref.w, ref.lam)
+            ew = np.abs(mod.weights - ref.w).max() / np.abs(ref.w).max()
+            Xo = np.random.Generator(np.random.PCG64(6)).random((128, d))
+            Vo, Jo = mod.eval_sites(Xo, want_values=True, want_jac=True)
+            evo = np.abs(Vo - ref.values(Xo)).max() / max(1.0, np.abs(Vo).max())
+            ejo = np.abs(Jo - ref.jacs(Xo)).max() / max(1.0, np.abs(Jo).max())
+            out[name].update(weights_vs_oracle_lu=ew, backward_error=be, backward_error_oracle=be_o, values_vs_oracle=evo, jac_vs_oracle=ejo)
+            assert be <= 50 * EPS, be
+            assert ew < W_TOL, (ew, be, be_o)
+            assert evo < 1e-8 and ejo < 1e-8, (evo, ejo)
         # values at a subset of training sites reproduce the data to 1e-8 (the north-star value tolerance)
         idx = np.arange(0, n, max(1, n // 97))
         V = pkg.eval_models_at_sites(mod, None, C[idx])
@@ -448,7 +474,7 @@ def test_c3_bench_workload_eval_against_oracle(ctx):
           % (t_oracle, threads, ew, be, be_o, ev_o, ej_o))
     assert be <= 50 * EPS, be
     assert ev_o < 1e-8 and ej_o < 1e-8, (ev_o, ej_o)
-    assert ew < W_TOL or np.linalg.norm(xg - sol) / np.linalg.norm(sol) <= 4 * float(np.linalg.cond(S, 1)) * (be + be_o), (ew, be, be_o)
+    assert ew < W_TOL, (ew, be, be_o)          # outright (observed 4e-12)
     REPORT["c3_bench_workload"] = dict(values=ev, jac=ej, rel_residual=mod.info["rel_residual"], weights_vs_oracle_lu=ew,
                                        backward_error=be, values_vs_oracle=ev_o, jac_vs_oracle=ej_o)
     mod.free()
@@ -473,7 +499,7 @@ def test_c2_full_size_without_tail(ctx):
     cond = float(np.linalg.cond(Phi))
     assert be <= 50 * EPS, be
     ew = np.abs(mod.weights - ref.w).max() / np.abs(ref.w).max()
-    assert ew < W_TOL or ew <= 4 * cond * (be + be_o), (ew, cond, be, be_o)
+    assert ew < W_TOL, (ew, cond, be, be_o)
     X = np.random.Generator(np.random.PCG64(6)).random((200, 32))
     V, J = mod.eval_sites(X, want_values=True, want_jac=True)
     assert np.abs(V - ref.values(X)).max() < 1e-8 * max(1.0, np.abs(V).max(), cond * EPS * 1e8)

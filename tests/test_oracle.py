@@ -16,6 +16,31 @@ def test_golden_reproduced(golden):
         assert np.allclose(mod.jacs(c["X"]), c["J"], rtol=1e-6, atol=1e-6 * scale), c["name"]
 
 
+def test_oracle_against_extended_precision_truth(golden):
+    """tests/golden/rbf_truth.npz: the same saddle systems solved by mpmath at 60 digits from an independent restatement
+    of the radial functions.  MEASURES the fp64 oracle's forward error (LAPACK LU, what Julia's `\\` does): within
+    cond x 8 eps on the weights everywhere, 1e-10 outright below cond 1e6, values / Jacobians 1e-8 on every case --
+    incl. C1 as BASELINE.json writes it (cond 5.7e11: weights 8e-7 from the truth, values 1e-11)."""
+    from tests.conftest import dist_from_truth
+
+    eps = np.finfo(np.float64).eps
+    seen = 0
+    for c in golden:
+        if "truth" not in c:
+            continue
+        seen += 1
+        t = c["truth"]
+        ew = dist_from_truth(c["W"], t["W"])
+        assert ew <= 8 * eps * c["cond"], (c["name"], ew, c["cond"])
+        if c["cond"] < 1e6:
+            assert ew < 1e-10, (c["name"], ew)
+        scale_v = max(1.0, np.abs(t["V"][0]).max()) / max(np.abs(t["V"][0]).max(), 1e-300)
+        scale_j = max(1.0, np.abs(t["J"][0]).max()) / max(np.abs(t["J"][0]).max(), 1e-300)
+        assert dist_from_truth(c["V"], t["V"]) / scale_v < 1e-8, c["name"]
+        assert dist_from_truth(c["J"], t["J"]) / scale_j < 1e-8, c["name"]
+    assert seen == len(golden)
+
+
 def test_interpolation_at_all_sites(golden):
     # test/rbf_models.jl:104 checks the centre only; we check every training site
     for c in golden:
