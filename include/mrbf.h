@@ -248,6 +248,11 @@ int32_t mrbf_batch_run(int32_t n_dev, const int32_t *device_ids, int64_t n_probl
                        mrbf_result *results);
 
 /* debug / test hooks (exported so the parity tests can pin kernel-level behaviour) */
+/* Environment switches.  The library reads a number of MRBF_* variables (schedule experiments of the persistent factorisation,
+ * earlier forms of kernels kept selectable for A/B runs, diagnostics: INTEGRATION.md "Tuning knobs").  NONE of them is honoured
+ * unless MRBF_EXPERIMENTS=1 is set in the same environment: a stray variable never changes the algorithm of a production run.
+ * mrbf_debug_env (host only): 1 if switch `name` is set and the gate is open, else 0. */
+int32_t mrbf_debug_env(const char *name);
 int32_t mrbf_debug_mfma_layout(mrbf_ctx *ctx, double *out16x16_a_times_b, const double *A16x4, const double *B4x16);
 int32_t mrbf_debug_potrf(mrbf_ctx *ctx, int64_t n, double *A_colmajor_inout, int32_t impl, int32_t *info, float *ms);
 int32_t mrbf_debug_diag(mrbf_ctx *ctx, const double *A128, int32_t reps, float *ms_per_call, double *shader_cycles,
@@ -324,6 +329,12 @@ typedef struct {
 int32_t mrbf_ps_step_problem(mrbf_ctx *ctx, const mrbf_ps_problem *problem, const double *x_n, const double *lb_eff,
                              const double *ub_eff, const double *fx_n, const double *r_or_null, const mrbf_ps_options *opts,
                              double *x_trial, double *mx_trial, double *r_out, mrbf_ps_info *info);
+/* test hook: ONE stochastic ranking (the ISRES-style pairwise rule of the PS solver, descent.jl:478-510's optimiser) of a given
+ * generation -- f[lam] objective values, phi[lam] constraint violations (0 feasible, inf outside the budget) -- by the kernels of
+ * the step: impl 0 one workgroup, 1 sixteen workgroups (lam >= 1024), 2 sixteen workgroups that give up at once (the time-out path).
+ * order_out[lam]: individuals in rank order; *gave_up: the several-workgroup kernel's failure word. */
+int32_t mrbf_debug_ps_rank(mrbf_ctx *ctx, int32_t lam, const double *f, const double *phi, uint64_t seed, int32_t gen, int32_t impl,
+                           int32_t *order_out, int32_t *gave_up);
 
 /* ---- the decision table of the host bindings ---------------------------------------------------------------------------
  * Which implementation a binding (morbit.jl_amd/julia/HipRbf.jl, the Python mirror) takes for one call of Morbit's interface:

@@ -116,7 +116,9 @@ SIGNATURES = {
                                         ctypes.POINTER(Result)]),
     "mrbf_debug_mfma_layout": (ctypes.c_int32, [c_vp, c_vp, c_vp, c_vp]),
     "mrbf_debug_potrf": (ctypes.c_int32, [c_vp, ctypes.c_int64, c_vp, ctypes.c_int32, c_ip, c_fp]),
+    "mrbf_debug_env": (ctypes.c_int32, [ctypes.c_char_p]),
     "mrbf_debug_diag": (ctypes.c_int32, [c_vp, c_vp, ctypes.c_int32, c_fp, c_dp, c_dp]),
+    "mrbf_debug_ps_rank": (ctypes.c_int32, [c_vp, ctypes.c_int32, c_vp, c_vp, ctypes.c_uint64, ctypes.c_int32, ctypes.c_int32, c_ip, c_ip]),
     "mrbf_debug_mfma_peak": (ctypes.c_int32, [c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_fp, c_dp]),
     "mrbf_debug_mfma_asm": (ctypes.c_int32, [c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_fp, c_dp, c_dp]),
     "mrbf_debug_dgemm": (ctypes.c_int32, [c_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_fp, c_dp]),

@@ -61,7 +61,7 @@ int batch_run_chain(int n_dev, const int *devs, const std::vector<int64_t> &whic
     int64_t nmax = 0;
     for (int64_t p : which) nmax = std::max<int64_t>(nmax, problems[p].n);
     int per_dev = (nmax <= 2048) ? 4 : 1;
-    if (const char *e = getenv("MRBF_BATCH_WORKERS")) per_dev = std::max(1, atoi(e));
+    if (const char *e = mrbf_env("MRBF_BATCH_WORKERS")) per_dev = std::max(1, atoi(e));
     per_dev = (int)std::max<int64_t>(1, std::min<int64_t>(per_dev, ((int64_t)which.size() + n_dev - 1) / n_dev));
     std::vector<std::vector<int64_t>> per_gpu(n_dev);
     for (int64_t p : which) per_gpu[p % n_dev].push_back(p);
@@ -410,4 +410,10 @@ extern "C" int32_t mrbf_stochastic_rank(int32_t lam, const double *f, const doub
         if (!swapped) break;
     }
     return MRBF_OK;
+}
+
+// Host only: is the environment switch `name` honoured right now (set, and MRBF_EXPERIMENTS=1 opens the gate)?  1 / 0; -1 for NULL.
+extern "C" int32_t mrbf_debug_env(const char *name) {
+    if (!name) return -1;
+    return mrbf::mrbf_env(name) ? 1 : 0;
 }

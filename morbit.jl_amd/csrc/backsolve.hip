@@ -417,7 +417,7 @@ int backsolve_persistent(mrbf_ctx *ctx, int64_t npad, const double *L, int64_t l
                          int *status) {
     using namespace bsolve;
     const int nb = (int)(npad / NB);
-    static const int force_old = getenv("MRBF_BACKSOLVE_LAUNCHES") ? atoi(getenv("MRBF_BACKSOLVE_LAUNCHES")) : 0;
+    static const int force_old = mrbf_env("MRBF_BACKSOLVE_LAUNCHES") ? atoi(mrbf_env("MRBF_BACKSOLVE_LAUNCHES")) : 0;
     // two 512-thread workgroups per block column, one per CU; beyond the CU count the later positions of the chain start as the first
     // ones leave (dispatch order is chain order), up to twice the CU count
     const int ncu = ctx->ncu;
@@ -433,7 +433,7 @@ int backsolve_persistent(mrbf_ctx *ctx, int64_t npad, const double *L, int64_t l
     hipLaunchKernelGGL(premul_kernel, dim3((unsigned)(8 * (nb - 1))), dim3(256), 0, ctx->stream, L, lda, linv_all, Mbuf, nb, flags, (nb + 1) * 32,
                        reinterpret_cast<unsigned long long *>(xb), 2 * nb * 4 * NB);
     // debug (MRBF_BSOLVE_STAMPS=1): per block, wall_clock64 when x_{j+1} was seen, after the barrier, before the publication
-    static const bool want_stamps = getenv("MRBF_BSOLVE_STAMPS") && atoi(getenv("MRBF_BSOLVE_STAMPS")) != 0;
+    static const bool want_stamps = mrbf_env("MRBF_BSOLVE_STAMPS") && atoi(mrbf_env("MRBF_BSOLVE_STAMPS")) != 0;
     long long *stamps = nullptr;
     if (want_stamps) {
         static long long *dbg = nullptr;  // debug only: one allocation for the largest case, never freed

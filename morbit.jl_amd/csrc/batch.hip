@@ -180,7 +180,7 @@ static int run_small_batch(mrbf_ctx *ctx, const std::vector<int64_t> &idx, const
     // the arena of one launch group is bounded (MRBF_BATCH_ARENA_MB, default 8192): a batch that needs more -- 10^4 problems would ask
     // for tens of GB in one piece -- is worked off in halves, and an allocation that fails is retried in halves as well instead of
     // failing every problem of the device
-    const size_t arena_budget = (size_t)(getenv("MRBF_BATCH_ARENA_MB") ? atoll(getenv("MRBF_BATCH_ARENA_MB")) : 8192) << 20;
+    const size_t arena_budget = (size_t)(mrbf_env("MRBF_BATCH_ARENA_MB") ? atoll(mrbf_env("MRBF_BATCH_ARENA_MB")) : 8192) << 20;
     auto halves = [&]() -> int {
         const std::vector<int64_t> lo(idx.begin(), idx.begin() + P / 2), hi(idx.begin() + P / 2, idx.end());
         MRBF_TRY(run_small_batch(ctx, lo, problems, results, redo, force_nc));

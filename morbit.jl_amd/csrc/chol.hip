@@ -59,7 +59,7 @@ extern "C" int32_t mrbf_debug_potrf(mrbf_ctx *ctx, int64_t n, double *A, int32_t
     MRBF_HIP(ctx, hipMemcpy2DAsync(dA, (size_t)npad * sizeof(double), A, (size_t)n * sizeof(double), (size_t)n * sizeof(double),
                                    (size_t)n, in, ctx->stream));
     int hinfo = 0;
-    static const double host_trace_ms = getenv("MRBF_MEGA_HOSTTRACE") ? atof(getenv("MRBF_MEGA_HOSTTRACE")) : 0.0;
+    static const double host_trace_ms = mrbf_env("MRBF_MEGA_HOSTTRACE") ? atof(mrbf_env("MRBF_MEGA_HOSTTRACE")) : 0.0;
     auto now_ms = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double h0 = now_ms();
     MRBF_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
@@ -93,7 +93,7 @@ extern "C" int32_t mrbf_debug_diag(mrbf_ctx *ctx, const double *A128, int32_t re
     if (ms_per_call) *ms_per_call = ms;
     if (shader_cycles) *shader_cycles = (double)st[0];
     if (realtime_us) *realtime_us = (double)st[1] / 100.0;
-    if (getenv("MRBF_DIAG_VERBOSE"))
+    if (mrbf_env("MRBF_DIAG_VERBOSE"))
         fprintf(stderr, "diag segments (cycles over 128 columns, wave 0): barrier %llu read %llu critical %llu rest %llu\n", st[2], st[3],
                 st[4], st[5]);
     return MRBF_OK;

@@ -449,7 +449,7 @@ int debug_diag(mrbf_ctx *ctx, const double *A128_dev, int reps, float *ms_per_ca
     float t;
     MRBF_HIP(ctx, hipEventElapsedTime(&t, ctx->ev[0], ctx->ev[1]));
     *ms_per_call = t / reps;
-    if (const char *e = getenv("MRBF_DIAG_DBG")) {
+    if (const char *e = mrbf_env("MRBF_DIAG_DBG")) {
         if (atoi(e) & 4) {  // per-segment cycle counters of the last launch (chol_diag_core.hpp)
             double seg[6];
             MRBF_HIP(ctx, hipMemcpy(seg, Linv, sizeof(seg), hipMemcpyDeviceToHost));

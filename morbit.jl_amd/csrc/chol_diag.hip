@@ -28,8 +28,8 @@ __global__ __launch_bounds__(256, 1) void chol_diag_v6_kernel(double *__restrict
 }
 
 int launch_diag_v4(mrbf_ctx *ctx, hipStream_t st, double *Ajj, int64_t lda, double *Linv, int *dinfo, int col0) {
-    static const int dbg = getenv("MRBF_DIAG_DBG") ? atoi(getenv("MRBF_DIAG_DBG")) : 0;
-    static const int impl = getenv("MRBF_DIAG_KERNEL") ? atoi(getenv("MRBF_DIAG_KERNEL")) : 6;
+    static const int dbg = mrbf_env("MRBF_DIAG_DBG") ? atoi(mrbf_env("MRBF_DIAG_DBG")) : 0;
+    static const int impl = mrbf_env("MRBF_DIAG_KERNEL") ? atoi(mrbf_env("MRBF_DIAG_KERNEL")) : 6;
     if (impl == 6 && dbg == 0) {
         double *scr;
         MRBF_TRY(get_buf(ctx, S_DIAG_SCR, (size_t)8 * 256 + 16, &scr));

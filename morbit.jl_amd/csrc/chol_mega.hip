@@ -1160,7 +1160,7 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
     const int NT = (int)(ncols / NB), MT = (int)(mrows / NB);
     if (MT > 32000) return fail(ctx, MRBF_EHIP, "potrf_mega: too many block rows");
     // MRBF_MEGA_HOSTTRACE=<ms>: host-side time of every runtime call of this launcher, printed when the call as a whole took longer
-    static const double host_trace_ms = getenv("MRBF_MEGA_HOSTTRACE") ? atof(getenv("MRBF_MEGA_HOSTTRACE")) : 0.0;
+    static const double host_trace_ms = mrbf_env("MRBF_MEGA_HOSTTRACE") ? atof(mrbf_env("MRBF_MEGA_HOSTTRACE")) : 0.0;
     double hstamp[8];
     int nh = 0;
     auto hnow = [&]() {
@@ -1189,8 +1189,8 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
     // streamed tiles as 64-row halves where the whole factorisation is chain-bound (n <= 4096), with twice the chain workgroups (each
     // on a CU of its own: four XCDs).  Measured r04 (tools/sweep_shalf.sh): n = 1024 / 2048 / 3072 / 4096: -8.6 / -10 / -9 /
     // -6 %; n >= 6144: the halves cost more matrix-pipe time than the chain gains (in the last 16 block columns only: -2.6 .. 0 %).
-    static const int env_shalf = getenv("MRBF_MEGA_SHALF") ? atoi(getenv("MRBF_MEGA_SHALF")) : -1;
-    static const int env_shalf_head = getenv("MRBF_MEGA_SHALF_HEAD") ? atoi(getenv("MRBF_MEGA_SHALF_HEAD")) : -1;
+    static const int env_shalf = mrbf_env("MRBF_MEGA_SHALF") ? atoi(mrbf_env("MRBF_MEGA_SHALF")) : -1;
+    static const int env_shalf_head = mrbf_env("MRBF_MEGA_SHALF_HEAD") ? atoi(mrbf_env("MRBF_MEGA_SHALF_HEAD")) : -1;
     const int sh_tail = env_shalf >= 0 ? env_shalf : (NTq <= 40 ? 1 << 20 : 0), sh_head = env_shalf_head >= 0 ? env_shalf_head : 0;
     const bool shalf_all = sh_tail >= NTq;
     // (n = 4608 / 5120 with 48 chain workgroups on two XCDs: -9 / -8 %, with 64 on four: -7 / -6 %; n = 6144: +4 %, left alone)
@@ -1202,9 +1202,9 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
     const int first = std::min(win, std::max(1, ctx->mega_first_window));
     const int srows = ctx->mega_srows > 0 ? ctx->mega_srows : srows_auto;  // streamed tiles below each diagonal block
     // the edge regime (first / last block columns: chain-bound at every size, see mega::Edge); only where the middle differs from it
-    static const int env_head = getenv("MRBF_MEGA_HEAD") ? atoi(getenv("MRBF_MEGA_HEAD")) : -1;
-    static const int env_tail = getenv("MRBF_MEGA_TAIL") ? atoi(getenv("MRBF_MEGA_TAIL")) : -1;
-    static const int env_reserve = getenv("MRBF_MEGA_RESERVE") ? atoi(getenv("MRBF_MEGA_RESERVE")) : -1;
+    static const int env_head = mrbf_env("MRBF_MEGA_HEAD") ? atoi(mrbf_env("MRBF_MEGA_HEAD")) : -1;
+    static const int env_tail = mrbf_env("MRBF_MEGA_TAIL") ? atoi(mrbf_env("MRBF_MEGA_TAIL")) : -1;
+    static const int env_reserve = mrbf_env("MRBF_MEGA_RESERVE") ? atoi(mrbf_env("MRBF_MEGA_RESERVE")) : -1;
     Edge edge{};
     edge.srows_edge = std::max(srows, 5);
     edge.pstream_edge = 2;
@@ -1221,28 +1221,28 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
         edge.sh_head = std::min(sh_head, NT);
         edge.sh_tail_c0 = std::max(edge.sh_head, NT - sh_tail);
         // panel tiles far below the diagonal as 128-row jobs (MRBF_MEGA_TFULL = block rows below the streamed ones that stay halves; -1: all halves)
-        static const int env_tfull = getenv("MRBF_MEGA_TFULL") ? atoi(getenv("MRBF_MEGA_TFULL")) : -1;
+        static const int env_tfull = mrbf_env("MRBF_MEGA_TFULL") ? atoi(mrbf_env("MRBF_MEGA_TFULL")) : -1;
         // (64-row halves keep a block row's column-to-column recurrence ahead of the chain; at n >= 12288 the rows more than eight below
         //  the streamed ones have the slack for 128-row jobs, whose GEMM loop shares the B operand between twice the MFMAs:
         //  alternating A/B r04: n = 12288 / 16384: -0.9 / -1.1 %, n = 10240: 0; all panel tiles full at n <= 8192: +4 .. +28 %)
-        edge.tfull1 = env_tfull >= 0 ? env_tfull + 1 : (getenv("MRBF_MEGA_TFULL") ? 0 : (NTq >= 96 ? 9 : 0));
+        edge.tfull1 = env_tfull >= 0 ? env_tfull + 1 : (mrbf_env("MRBF_MEGA_TFULL") ? 0 : (NTq >= 96 ? 9 : 0));
         // rows below the square that are known to be zero (the fit's right-hand sides: k of the 128 rows of the extra block row)
-        static const int env_xhalf = getenv("MRBF_MEGA_XHALF") ? atoi(getenv("MRBF_MEGA_XHALF")) : 1;
+        static const int env_xhalf = mrbf_env("MRBF_MEGA_XHALF") ? atoi(mrbf_env("MRBF_MEGA_XHALF")) : 1;
         edge.xhalf = (env_xhalf && MT == NT + 1 && ctx->mega_xreal > 0 && ctx->mega_xreal <= 64) ? 1 : 0;
     }
     const int srows_max = std::max(srows, (edge.head > 0 || edge.tail_c0 < NT) ? edge.srows_edge : srows);
     // job tables: one set per (NT, MT, schedule parameters), kept in a small per-context LRU -- Morbit's training sets grow and shrink
     // by a few sites between iterations, so n keeps crossing 128-boundaries back and forth; rebuilding the tables on every change
     // cost three copies and a stream synchronisation inside the factorisation phase
-    static const int chainq = getenv("MRBF_MEGA_CHAINQ") ? atoi(getenv("MRBF_MEGA_CHAINQ")) : 0;
-    static const int cboost = getenv("MRBF_MEGA_CBOOST") ? atoi(getenv("MRBF_MEGA_CBOOST")) : 12;
+    static const int chainq = mrbf_env("MRBF_MEGA_CHAINQ") ? atoi(mrbf_env("MRBF_MEGA_CHAINQ")) : 0;
+    static const int cboost = mrbf_env("MRBF_MEGA_CBOOST") ? atoi(mrbf_env("MRBF_MEGA_CBOOST")) : 12;
     // bulk jobs of the last block columns as 64-row halves (diagonal tiles included): there the machine runs empty and what is left
     // are per-tile chains of window updates -- each a K = 128 win GEMM of one workgroup, one after the other on the same tile --
     // that the diagonal chain ends up waiting for (job log r04: P(56) at n = 8192 waited 146 us for the last three windows of its
     // tile); two workgroups per tile halve every link.  n = 4096: -1.8 %, smaller: no change.
-    static const int env_tail_half = getenv("MRBF_MEGA_TAILHALF") ? atoi(getenv("MRBF_MEGA_TAILHALF")) : -1;
+    static const int env_tail_half = mrbf_env("MRBF_MEGA_TAILHALF") ? atoi(mrbf_env("MRBF_MEGA_TAILHALF")) : -1;
     const int tail_half = env_tail_half >= 0 ? env_tail_half : (NT >= 32 ? 20 : 0);
-    static const int env_tail_half_w = getenv("MRBF_MEGA_TAILHALF_W") ? atoi(getenv("MRBF_MEGA_TAILHALF_W")) : -1;
+    static const int env_tail_half_w = mrbf_env("MRBF_MEGA_TAILHALF_W") ? atoi(mrbf_env("MRBF_MEGA_TAILHALF_W")) : -1;
     const int tail_half_w = env_tail_half_w >= 0 ? env_tail_half_w : 1000;  // only the last so many window updates of such a tile
     const long tab_key = (chainq ? 50 : 0) + slack + 100000000000000L * tail_half + 10000000000000000L * std::min(tail_half_w, 99) + 100 * ctx->mega_half_cols + 10000 * slack_chain + 1000000 * first + 10000000 * win + 100000000 * (long)srows +
                          1000000000L * edge.head + 1000000000000L * edge.tail_c0;
@@ -1348,7 +1348,7 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
         a.nreserve = (e_head > 0 || e_tail_c0 < NT) ? (env_reserve >= 0 ? env_reserve : 12) : 0;
     }
     {
-        static const int env_pdma = getenv("MRBF_MEGA_PANELDMA") ? atoi(getenv("MRBF_MEGA_PANELDMA")) : 1;
+        static const int env_pdma = mrbf_env("MRBF_MEGA_PANELDMA") ? atoi(mrbf_env("MRBF_MEGA_PANELDMA")) : 1;
         a.panel_dma = env_pdma;
     }
     a.pstream = ctx->mega_pstream > 0 ? std::min(ctx->mega_pstream, srows) : (NTq <= 48 && srows >= 2 ? 2 : 1);
@@ -1359,21 +1359,21 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
     if (a.nchain < 1) a.nchain = 1;
     if (a.nchain + a.ndedicated >= grid) a.ndedicated = std::max(0, grid / 2 - a.nchain);
     {
-        static const int env_xc = getenv("MRBF_MEGA_XCHAIN") ? atoi(getenv("MRBF_MEGA_XCHAIN")) : -1;
+        static const int env_xc = mrbf_env("MRBF_MEGA_XCHAIN") ? atoi(mrbf_env("MRBF_MEGA_XCHAIN")) : -1;
         const int xc = env_xc >= 0 ? env_xc : (a.nchain > 48 ? 4 : (a.nchain > 32 ? 2 : 1));
         a.xchain = (xc > 0 && 8 * a.nchain <= std::min(xc, 8) * grid) ? std::min(xc, 8) : 0;  // enough blocks = 0 .. xc-1 (mod 8) for the chain
         // (n = 16384: the CU partners of the 12 chain workgroups join the bulk work until 32 block columns are left: 27.0 -> 26.5 ms;
         //  at n <= 8192 the chain is never far from critical and pausing the partners throughout is as good or better)
-        static const int qt = getenv("MRBF_MEGA_QUIET_TAIL") ? atoi(getenv("MRBF_MEGA_QUIET_TAIL")) : -1;
+        static const int qt = mrbf_env("MRBF_MEGA_QUIET_TAIL") ? atoi(mrbf_env("MRBF_MEGA_QUIET_TAIL")) : -1;
         a.quiet_tail = qt >= 0 ? qt : (NTq > 96 ? 32 : 1 << 20);
     }
-    const char *trace_path = getenv("MRBF_MEGA_TRACE");
+    const char *trace_path = mrbf_env("MRBF_MEGA_TRACE");
     if (trace_path) {
-        a.trace_dbg = getenv("MRBF_MEGA_TRACE_WAVE") ? 12 + 16 * (atoi(getenv("MRBF_MEGA_TRACE_WAVE")) & 3) : 4;
+        a.trace_dbg = mrbf_env("MRBF_MEGA_TRACE_WAVE") ? 12 + 16 * (atoi(mrbf_env("MRBF_MEGA_TRACE_WAVE")) & 3) : 4;
         MRBF_TRY(get_buf(ctx, S_MEGA_TRACE, (size_t)NT * 80 + 4 * 1024, &a.trace));
         MRBF_HIP(ctx, hipMemsetAsync(a.trace, 0, ((size_t)NT * 80 + 4 * 1024) * sizeof(unsigned long long), ctx->stream));
     }
-    const char *jlog_path = getenv("MRBF_MEGA_JLOG");
+    const char *jlog_path = mrbf_env("MRBF_MEGA_JLOG");
     if (jlog_path) {
         a.jlog_cap = ctx->mega_npanel + ctx->mega_nbulk + ctx->mega_nchainjobs + 16;
         MRBF_TRY(get_buf(ctx, S_MEGA_JLOG, (size_t)8 * a.jlog_cap + 16, &a.jlog));
@@ -1450,7 +1450,7 @@ int potrf_mega_tall(mrbf_ctx *ctx, int64_t ncols, int64_t mrows, double *A, int6
     if (host_trace_ms > 0.0 && nh == 6 && hstamp[5] - hstamp[0] > host_trace_ms)
         fprintf(stderr, "potrf_mega_tall host trace (NT %d): buffers/tables %.3f ms | memset flags %.3f | memset info %.3f | kernel launch %.3f | status launch %.3f\n", NT,
                 hstamp[1] - hstamp[0], hstamp[2] - hstamp[1], hstamp[3] - hstamp[2], hstamp[4] - hstamp[3], hstamp[5] - hstamp[4]);
-    if (getenv("MRBF_MEGA_DEBUG")) {
+    if (mrbf_env("MRBF_MEGA_DEBUG")) {
         unsigned h[CTL_WORDS];
         MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
         MRBF_HIP(ctx, hipMemcpy(h, fl, sizeof(h), hipMemcpyDeviceToHost));

@@ -5,6 +5,7 @@
 #include <rocsolver/rocsolver.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -195,6 +196,15 @@ enum HpinSlot : int {
 };
 
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// EVERY environment switch of the library (MRBF_MEGA_*, MRBF_R4_*, MRBF_PS_*, MRBF_EVAL_*, ... -- schedule experiments, A/B forms kept for
+// the record, diagnostics) is read through this function and is honoured only while MRBF_EXPERIMENTS=1 is set: a drop-in library must
+// not change algorithm because of a stray variable in a user's environment.  Not cached (the tests toggle switches inside one process).
+inline const char *mrbf_env(const char *name) {
+    const char *gate = std::getenv("MRBF_EXPERIMENTS");
+    if (!gate || std::atoi(gate) == 0) return nullptr;
+    return std::getenv(name);
+}
 
 // ---- launchers implemented in the .hip files (all asynchronous on ctx->stream) ----------
 // prep.hip

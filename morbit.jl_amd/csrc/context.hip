@@ -261,24 +261,24 @@ int32_t mrbf_init(int32_t device_id, mrbf_ctx **out) {
     {
         // bulk stream: every XCD keeps its last 4 CUs (32 of 256) out of the mask, so the panel chain's kernels
         // (1 workgroup for D, ~m/64 for T / U1) always find idle CUs while a rank-512 trailing update is running
-        if (const char *bg = getenv("MRBF_BULK_GRID")) ctx->bulk_grid = atoi(bg);
-        if (const char *e = getenv("MRBF_CHOL_IMPL")) ctx->chol_impl = atoi(e);
-        if (const char *e = getenv("MRBF_MEGA_GRID")) ctx->mega_grid = atoi(e);
-        if (const char *e = getenv("MRBF_MEGA_DEDICATED")) ctx->mega_dedicated = atoi(e);
-        if (const char *e = getenv("MRBF_MEGA_LOOK")) ctx->mega_look = atoi(e);
-        if (const char *e = getenv("MRBF_MEGA_MIN")) ctx->mega_min = atoi(e);
-        if (const char *e = getenv("MRBF_MEGA_QUIET")) ctx->mega_quiet = atoi(e);
-        if (const char *e = getenv("MRBF_MEGA_CHAIN")) ctx->mega_chain = atoi(e);
-        if (const char *e = getenv("MRBF_MEGA_SLACK")) ctx->mega_slack = atoi(e);
-        if (const char *e = getenv("MRBF_MEGA_SLACK_CHAIN")) ctx->mega_slack_chain = atoi(e);
-        if (const char *e = getenv("MRBF_MEGA_HALF_COLS")) ctx->mega_half_cols = atoi(e);
-        if (const char *e = getenv("MRBF_MEGA_FIRST_WINDOW")) ctx->mega_first_window = atoi(e);
-        if (const char *e = getenv("MRBF_MEGA_WIN")) ctx->mega_win = atoi(e);
-        if (const char *e = getenv("MRBF_MEGA_WBIAS")) ctx->mega_wbias = atoi(e);
-        if (const char *e = getenv("MRBF_MEGA_SROWS")) ctx->mega_srows = atoi(e);
-        if (const char *e = getenv("MRBF_MEGA_PSTREAM")) ctx->mega_pstream = atoi(e);
-        if (const char *e = getenv("MRBF_MEGA_MAX")) ctx->mega_max = atoi(e);
-        if (const char *e = getenv("MRBF_SPIN_MS")) ctx->spin_ms = std::max(1, atoi(e));
+        if (const char *bg = mrbf_env("MRBF_BULK_GRID")) ctx->bulk_grid = atoi(bg);
+        if (const char *e = mrbf_env("MRBF_CHOL_IMPL")) ctx->chol_impl = atoi(e);
+        if (const char *e = mrbf_env("MRBF_MEGA_GRID")) ctx->mega_grid = atoi(e);
+        if (const char *e = mrbf_env("MRBF_MEGA_DEDICATED")) ctx->mega_dedicated = atoi(e);
+        if (const char *e = mrbf_env("MRBF_MEGA_LOOK")) ctx->mega_look = atoi(e);
+        if (const char *e = mrbf_env("MRBF_MEGA_MIN")) ctx->mega_min = atoi(e);
+        if (const char *e = mrbf_env("MRBF_MEGA_QUIET")) ctx->mega_quiet = atoi(e);
+        if (const char *e = mrbf_env("MRBF_MEGA_CHAIN")) ctx->mega_chain = atoi(e);
+        if (const char *e = mrbf_env("MRBF_MEGA_SLACK")) ctx->mega_slack = atoi(e);
+        if (const char *e = mrbf_env("MRBF_MEGA_SLACK_CHAIN")) ctx->mega_slack_chain = atoi(e);
+        if (const char *e = mrbf_env("MRBF_MEGA_HALF_COLS")) ctx->mega_half_cols = atoi(e);
+        if (const char *e = mrbf_env("MRBF_MEGA_FIRST_WINDOW")) ctx->mega_first_window = atoi(e);
+        if (const char *e = mrbf_env("MRBF_MEGA_WIN")) ctx->mega_win = atoi(e);
+        if (const char *e = mrbf_env("MRBF_MEGA_WBIAS")) ctx->mega_wbias = atoi(e);
+        if (const char *e = mrbf_env("MRBF_MEGA_SROWS")) ctx->mega_srows = atoi(e);
+        if (const char *e = mrbf_env("MRBF_MEGA_PSTREAM")) ctx->mega_pstream = atoi(e);
+        if (const char *e = mrbf_env("MRBF_MEGA_MAX")) ctx->mega_max = atoi(e);
+        if (const char *e = mrbf_env("MRBF_SPIN_MS")) ctx->spin_ms = std::max(1, atoi(e));
         hipDeviceProp_t prop;
         int ncu = 256;
         bool gfx950 = false;
@@ -289,7 +289,7 @@ int32_t mrbf_init(int32_t device_id, mrbf_ctx **out) {
         ctx->ncu = ncu;
         // workgroup clusters of the small fit (small.hip) rest on 8 XCDs x 32 CUs with round-robin block placement: only there
         ctx->small_cluster_ok = (gfx950 && ncu == 256) ? 1 : 0;
-        const char *env = getenv("MRBF_BULK_RESERVE");
+        const char *env = mrbf_env("MRBF_BULK_RESERVE");
         const int reserve_per_32 = env ? atoi(env) : 0;  // measured: masking costs more than it buys
         std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
         for (int cu = 0; cu < ncu; ++cu)

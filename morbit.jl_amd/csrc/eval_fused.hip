@@ -650,14 +650,14 @@ int eval_nsplit(const mrbf_ctx *ctx, int64_t m, int ntiles, bool check_call) {
     // -- unless the query batch is small as well (at most an eighth of the workgroup slots: the populations of a PS step at d <= 24,
     // single points): the launch then is one workgroup's walk over the tiles, 35 us at n = 512 whatever m; one tile per workgroup
     // + the combine pass: 10 + 7 us (PS step d = 12, n = 512: 7.25 -> 5.15 ms; MRBF_EVAL_NSPLIT_SMALL=1 keeps them unsplit)
-    static const int small_split = getenv("MRBF_EVAL_NSPLIT_SMALL") ? atoi(getenv("MRBF_EVAL_NSPLIT_SMALL")) : 8;
+    static const int small_split = mrbf_env("MRBF_EVAL_NSPLIT_SMALL") ? atoi(mrbf_env("MRBF_EVAL_NSPLIT_SMALL")) : 8;
     // (the same rule for a member of a batch -- bit-identical to the single call --: batch.hip launches split and unsplit members apart)
     // Not for the residual check (the model at its own sites: m = n): in a batch of 64 starts those launches fill the chip together and
     // splitting them cost C4 1.6 % (19 540 against 19 870 problems/s, three alternating runs); the single fit's check follows the same rule.
     const bool small_batch = !check_call && qtiles * 8 <= slots;
     if (ntiles >= 4 && ntiles <= 8 && small_split > 1 && small_batch) return std::min(small_split, ntiles);
     if (ntiles <= 8) return 1;
-    static const double comb_small = getenv("MRBF_EVAL_COMB_SMALL") ? atof(getenv("MRBF_EVAL_COMB_SMALL")) : 0.1;
+    static const double comb_small = mrbf_env("MRBF_EVAL_COMB_SMALL") ? atof(mrbf_env("MRBF_EVAL_COMB_SMALL")) : 0.1;
     int nsplit = 1;
     double best_cost = 1e300;
     for (int s = 1; s <= std::min(ntiles, 32); ++s) {
@@ -670,7 +670,7 @@ int eval_nsplit(const mrbf_ctx *ctx, int64_t m, int ntiles, bool check_call) {
             nsplit = s;
         }
     }
-    static const int force_split = getenv("MRBF_EVAL_NSPLIT") ? atoi(getenv("MRBF_EVAL_NSPLIT")) : 0;
+    static const int force_split = mrbf_env("MRBF_EVAL_NSPLIT") ? atoi(mrbf_env("MRBF_EVAL_NSPLIT")) : 0;
     if (force_split > 0 && force_split <= ntiles && (int64_t)(force_split - 1) * ((ntiles + force_split - 1) / force_split) < ntiles)
         nsplit = force_split;
     return nsplit;
@@ -678,7 +678,7 @@ int eval_nsplit(const mrbf_ctx *ctx, int64_t m, int ntiles, bool check_call) {
 
 // outputs per pass: two when the model has several (at D = 128 with the query block in LDS)
 int outputs_per_pass(int k, int D) {
-    static const int ko128 = getenv("MRBF_EVAL_KO128") ? atoi(getenv("MRBF_EVAL_KO128")) : 2;
+    static const int ko128 = mrbf_env("MRBF_EVAL_KO128") ? atoi(mrbf_env("MRBF_EVAL_KO128")) : 2;
     if (D == 256) return 1;  // the Jacobian tiles of one output fill the accumulator budget
     return k >= 2 ? (D == 128 ? ko128 : 2) : 1;
 }
@@ -734,7 +734,7 @@ static int run_passes(mrbf_ctx *ctx, const KP &kp, int D, int k, bool want_jac, 
     for (int l0 = 0; l0 < k; l0 += KO) {
         const int ko = std::min(KO, k - l0);
 #define MRBF_EF(KOV, DTV, QL) MRBF_DISPATCH_KID(kp.kid, MRBF_TRY((launch_fused<KID, KOV, DTV, QL>(ctx, want_jac, final_, grid, kp, one, many, l0))))
-        static const int split128 = getenv("MRBF_EVAL_SPLIT128") ? atoi(getenv("MRBF_EVAL_SPLIT128")) : 1;
+        static const int split128 = mrbf_env("MRBF_EVAL_SPLIT128") ? atoi(mrbf_env("MRBF_EVAL_SPLIT128")) : 1;
 #define MRBF_EF128(KOV) MRBF_DISPATCH_KID(kp.kid, MRBF_TRY((launch_split<KID, KOV, 64, 64>(ctx, want_jac, final_, grid, kp, one, many, l0))))
 #define MRBF_EF256() MRBF_DISPATCH_KID(kp.kid, MRBF_TRY((launch_split<KID, 1, 128, 32>(ctx, want_jac, final_, grid, kp, one, many, l0))))
         if (D == 256) {

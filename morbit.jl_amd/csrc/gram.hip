@@ -393,11 +393,11 @@ int launch_gram(mrbf_ctx *ctx, int mode, const double *C, const double *Xc, cons
         const int64_t nt = (n + GBM - 1) / GBM;  // tiles that hold at least one real row
         const int64_t nb = nt * (nt + 1) / 2;
         const int aligned16 = ((ld & 1) == 0) && ((reinterpret_cast<uintptr_t>(Phi) & 15) == 0);
-        static const int occ3 = getenv("MRBF_GRAM_OCC3") ? atoi(getenv("MRBF_GRAM_OCC3")) : 0;
-        static const int rows64 = getenv("MRBF_GRAM_ROWS64") ? atoi(getenv("MRBF_GRAM_ROWS64")) : 1;
+        static const int occ3 = mrbf_env("MRBF_GRAM_OCC3") ? atoi(mrbf_env("MRBF_GRAM_OCC3")) : 0;
+        static const int rows64 = mrbf_env("MRBF_GRAM_ROWS64") ? atoi(mrbf_env("MRBF_GRAM_ROWS64")) : 1;
         if (kp.fast && rows64 && nb >= 512) {
             // the remap needs whole groups of 16 blocks (8 pairs x 2 halves); a ragged tail falls back to the plain order inside the kernel
-            static const int remap_env = getenv("MRBF_GRAM_REMAP") ? atoi(getenv("MRBF_GRAM_REMAP")) : 1;
+            static const int remap_env = mrbf_env("MRBF_GRAM_REMAP") ? atoi(mrbf_env("MRBF_GRAM_REMAP")) : 1;
             const int remap = (remap_env && nb % 8 == 0) ? 1 : 0;
             MRBF_DISPATCH_KID(kp.kid, hipLaunchKernelGGL((gram_mfma64_kernel<KID, true>), dim3((unsigned)(2 * nb)), dim3(256), 0, ctx->stream,
                                                          Xc, sq, n, dpad, Phi, ld, kp, aligned16, (int)nb, remap));

@@ -481,7 +481,7 @@ __global__ __launch_bounds__(256) void proj_panels_kernel(const double *__restri
 }
 
 bool gram_w_applies(const mrbf_ctx *ctx, const mrbf_model *M) {
-    static const int on = getenv("MRBF_GRAM_FUSED") ? atoi(getenv("MRBF_GRAM_FUSED")) : 1;
+    static const int on = mrbf_env("MRBF_GRAM_FUSED") ? atoi(mrbf_env("MRBF_GRAM_FUSED")) : 1;
     if (!on || ctx->gram_mode != 0) return false;
     if (M->dpad != 64 || M->q < 1 || M->q > 65 || M->n < 1024) return false;
     return M->kp.fast || M->kp.kid == MRBF_GAUSSIAN || M->kp.kid == MRBF_THIN_PLATE_SPLINE;
@@ -490,8 +490,8 @@ bool gram_w_applies(const mrbf_ctx *ctx, const mrbf_model *M) {
 // Phi (lower triangle, column-major, leading dimension ld) + the partial panels of W' = Phi Xc and of the row sums
 int launch_gram_w(mrbf_ctx *ctx, const mrbf_model *M, double *Phi, int64_t ld, double **Wpart_out, double **rspart_out, int *nseg_out) {
     const int nt = (int)(M->npad / 128);
-    static const int dbg = getenv("MRBF_GW_DBG") ? atoi(getenv("MRBF_GW_DBG")) : 0;
-    static const int wgs = getenv("MRBF_GW_WGS") ? atoi(getenv("MRBF_GW_WGS")) : 512;
+    static const int dbg = mrbf_env("MRBF_GW_DBG") ? atoi(mrbf_env("MRBF_GW_DBG")) : 0;
+    static const int wgs = mrbf_env("MRBF_GW_WGS") ? atoi(mrbf_env("MRBF_GW_WGS")) : 512;
     int nseg = wgs / nt;  // two workgroups per compute unit
     if (nseg < 1) nseg = 1;
     if (nseg > nt) nseg = nt;

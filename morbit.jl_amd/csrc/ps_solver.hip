@@ -373,7 +373,7 @@ __global__ __launch_bounds__(RANK_THREADS) void ps_rank_kernel(Args a, int mode,
     } else {
         // lam phases of odd-even transposition; a pair is compared by f when both are feasible or with probability 0.45, else by
         // the constraint violation (Runarsson & Yao).  The records themselves are swapped; one Philox call feeds four phases of a
-        // pair; one barrier per phase; the no-swap exit is tested every 16 phases.
+        // pair; one barrier per phase.
         double *sf = smem, *sphi = sf + lam;
         sidx = (int *)(sphi + lam);
         for (int i = tid; i < lam; i += NT) {
@@ -384,11 +384,17 @@ __global__ __launch_bounds__(RANK_THREADS) void ps_rank_kernel(Args a, int mode,
         if (tid == 0) s_swapped = 1;
         __syncthreads();
         constexpr int PSLOTS = (MAXLAM / 2 + RANK_THREADS - 1) / RANK_THREADS;  // pairs per thread and phase
+        // ONE exit rule for a population size, whichever kernel ranks it: with stochastic comparisons a stretch of phases without a
+        // swap is not a fixed point (a pair that disagrees on f and phi can still swap on a later draw), so WHERE the no-swap test
+        // sits decides the order that comes out.  Populations of RS_MINLAM and more -- the ones ps_rank_sort_kernel takes, which can
+        // only test at its chunk boundaries -- are tested every RS_B phases here too (this code is also that kernel's fallback after
+        // a time-out and the MRBF_PS_MULTI=0 path); smaller ones every sixteen.
+        const int quiet = lam >= RS_MINLAM ? RS_B : 16;
         for (int ph0 = 0; ph0 < lam; ph0 += 4) {
-            if ((ph0 & 15) == 0) {
+            if (ph0 % quiet == 0) {
                 const int sw = s_swapped;
                 __syncthreads();
-                if (!sw) break;  // sixteen phases without a swap: sorted under the drawn rules
+                if (!sw) break;  // `quiet` phases without a swap: ranked under the drawn rules
                 if (tid == 0) s_swapped = 0;
                 __syncthreads();
             }
@@ -481,8 +487,8 @@ __global__ __launch_bounds__(RANK_THREADS) void ps_rank_kernel(Args a, int mode,
 // away); every comparison is a function of (pair, phase, values) -- the Philox counter is the pair and the four-phase group, as in
 // ps_rank_kernel -- so the redundant comparisons in the halos agree with the owner's.  Between chunks the parts are exchanged through
 // global memory (write-through stores, coherent loads: the workgroups sit behind different L2s) and the workgroups of a run meet at a
-// counter.  A chunk in which no workgroup moved anything inside its own part ends the ranking (the one-workgroup kernel tests every
-// sixteen phases).  The counter wait is bounded: on a time-out the failure word is set and ps_rank_kernel (mode 2) runs the phases
+// counter.  A chunk in which no workgroup moved anything inside its own part ends the ranking (ps_rank_kernel applies the same test
+// at the same phases for these population sizes: one exit rule, hence one order, whichever kernel runs).  The counter wait is bounded: on a time-out the failure word is set and ps_rank_kernel (mode 2) runs the phases
 // itself -- this kernel never writes f / phi.
 __device__ __forceinline__ unsigned long long rs_clock() { return __builtin_amdgcn_s_memrealtime(); }  // 100 MHz
 __global__ __launch_bounds__(RS_THREADS) void ps_rank_sort_kernel(Args a, RankWs ws) {
@@ -569,11 +575,13 @@ __global__ __launch_bounds__(RS_THREADS) void ps_rank_sort_kernel(Args a, RankWs
         __syncthreads();
         if (tid == 0) {
             if (s_sw) __hip_atomic_fetch_or(sy + 4 + c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_add(sy, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (the part's stores are write-through and counted out: no L2 write-back needed)
+            // arrival = RELEASE (orders the part's stores and the "moved" flag before the count, by the memory model and not only by
+            // the s_waitcnt above), the wait ends with an ACQUIRE load of the same counter before s_any and the next chunk's loads
+            __hip_atomic_fetch_add(sy, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             const int target = RS_W * (c + 1);
             const unsigned long long t0 = rs_clock();
             bool ok = true;
-            while (__hip_atomic_load(sy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            while (__hip_atomic_load(sy, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
                 if (__hip_atomic_load(sy + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || rs_clock() - t0 > 500000ull) {  // 5 ms
                     __hip_atomic_store(sy + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(ws.sync + RS_SYNC * MAXRUNS, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (sticky: the host stops using this kernel)
@@ -1003,7 +1011,7 @@ extern "C" int32_t mrbf_ps_step_problem(mrbf_ctx *ctx, const mrbf_ps_problem *pr
     // reference's defaults the step at d = 128 stayed at 7 % of what the subproblem allows).  A tenth of every global budget is
     // therefore kept back for gradient steps from the strategy's best point (ps_descend) -- the evaluations are counted against the
     // same budget, so the call never evaluates more than the configuration allows.  MRBF_PS_DBG bit 5 (32): the strategy alone.
-    const int dbg_env = getenv("MRBF_PS_DBG") ? atoi(getenv("MRBF_PS_DBG")) : 0;
+    const int dbg_env = mrbf_env("MRBF_PS_DBG") ? atoi(mrbf_env("MRBF_PS_DBG")) : 0;
     const auto reserve = [&](int budget) { return (dbg_env & 32) || budget < 20 * 13 ? 0 : budget / 10; };
     const int res_ip = reserve(max_ip), res_ps = opts->max_polish_evals > 0 ? 0 : reserve(max_ps);
     const double xtol = opts->xtol_rel > 0.0 ? opts->xtol_rel : 1e-3;                        // descent.jl:379, :485
@@ -1051,7 +1059,7 @@ extern "C" int32_t mrbf_ps_step_problem(mrbf_ctx *ctx, const mrbf_ps_problem *pr
         // (a counter wait that times out -- the workgroups of a run not resident together: a device shared with other work -- costs 5 ms; the
         // host sees the sticky failure word with the status words, every eight generations, and keeps to one workgroup per run from then on)
         bool multi = maxlam >= RS_MINLAM && ctx->ncu >= RS_W * a.nruns && !ctx->ps_multi_off &&
-                     !(getenv("MRBF_PS_MULTI") && atoi(getenv("MRBF_PS_MULTI")) == 0);
+                     !(mrbf_env("MRBF_PS_MULTI") && atoi(mrbf_env("MRBF_PS_MULTI")) == 0);
         if (multi) {
             double *wsb;
             const size_t per_run = (size_t)MAXLAM * 5 + RS_SYNC / 2;  // f, phi twice, idx twice (as doubles: 2 x 1/2), sync words
@@ -1242,4 +1250,79 @@ extern "C" int32_t mrbf_ps_step(mrbf_ctx *ctx, const mrbf_model *model, const do
     prob.roles = roles;
     prob.eq_tol = -1.0;
     return mrbf_ps_step_problem(ctx, &prob, x_n, lb_eff, ub_eff, fx_n, r_or_null, opts, x_trial, mx_trial, r_out, info);
+}
+
+// Test hook: ONE ranking of a given generation (objective values f, violations phi; inf = outside the budget) by the kernels of the
+// step above -- impl 0: ps_rank_kernel alone (one workgroup); 1: hand-over to ps_rank_sort_kernel (sixteen workgroups) and the
+// finishing launch; 2: the same with the sort kernel giving up at once (what a counter time-out leaves behind).  order_out[lam] = the
+// individuals in rank order.  Lets the tests put crafted populations (nearly ranked, a few infeasible individuals: the no-swap exit
+// is taken early) through both kernels and compare the orders entry by entry.
+extern "C" int32_t mrbf_debug_ps_rank(mrbf_ctx *ctx, int32_t lam, const double *f, const double *phi, uint64_t seed, int32_t gen,
+                                      int32_t impl, int32_t *order_out, int32_t *gave_up) {
+    if (!ctx) return -1;
+    using namespace ps;
+    if (lam < 2 || lam > MAXLAM) return fail(ctx, -2, "mrbf_debug_ps_rank: lam = %d outside 2..%d", lam, MAXLAM);
+    if (!f || !phi) return fail(ctx, -3, "f / phi is NULL");
+    if (gen < 0) return fail(ctx, -6, "gen < 0");
+    if (impl < 0 || impl > 2) return fail(ctx, -7, "impl must be 0, 1 or 2");
+    if (impl != 0 && lam < RS_MINLAM) return fail(ctx, -7, "mrbf_debug_ps_rank: the several-workgroup ranking takes populations >= %d", RS_MINLAM);
+    if (!order_out) return fail(ctx, -8, "order_out is NULL");
+    (void)hipSetDevice(ctx->device);
+    double *base;
+    int *stat;
+    MRBF_TRY(get_buf(ctx, S_PS_STATE, (size_t)4 * lam + 16, &base));
+    MRBF_TRY(get_buf(ctx, S_PS_STAT, (size_t)4 * MAXRUNS, &stat));
+    Args a{};
+    Run &R = a.runs[0];
+    a.nruns = 1;
+    a.seed = seed;
+    a.gen = gen;
+    a.xtol_rel = 1e-3;
+    a.dbg = impl == 2 ? 64 : 0;
+    R.nvar = 1;
+    R.lam = R.mu = lam;          // mu = lam: the whole order comes out
+    R.max_evals = 1 << 30;
+    R.X[0] = R.X[1] = base;      // one dummy variable per individual
+    R.best = base + lam;         // [x, f, phi]
+    R.f = base + lam + 4;
+    R.phi = R.f + lam;
+    R.order = reinterpret_cast<int *>(R.phi + lam);
+    R.stat = stat;
+    std::vector<double> h((size_t)lam + 4, 0.0);
+    h[lam + 1] = h[lam + 2] = INFINITY;
+    MRBF_HIP(ctx, hipMemcpyAsync(base, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    MRBF_HIP(ctx, hipMemcpyAsync(R.f, f, (size_t)lam * sizeof(double), hipMemcpyDefault, ctx->stream));
+    MRBF_HIP(ctx, hipMemcpyAsync(R.phi, phi, (size_t)lam * sizeof(double), hipMemcpyDefault, ctx->stream));
+    MRBF_HIP(ctx, hipMemsetAsync(stat, 0, (size_t)4 * MAXRUNS * sizeof(int), ctx->stream));
+    int N = 1;
+    while (N < lam) N <<= 1;
+    const size_t shm = std::max((size_t)20 * lam, (size_t)12 * N);
+    MRBF_HIP(ctx, hipFuncSetAttribute((const void *)ps_rank_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    const int rank_threads = (int)std::min<int64_t>(RANK_THREADS, std::max<int64_t>(64, round_up(N / 2, 64)));
+    RankWs rw{};
+    if (impl != 0) {
+        double *wsb;
+        const size_t per_run = (size_t)MAXLAM * 5 + RS_SYNC / 2;
+        MRBF_TRY(get_buf(ctx, S_PS_RANK, per_run * MAXRUNS + 64, &wsb));
+        rw.f[0] = wsb;
+        rw.f[1] = rw.f[0] + (size_t)MAXLAM * MAXRUNS;
+        rw.phi[0] = rw.f[1] + (size_t)MAXLAM * MAXRUNS;
+        rw.phi[1] = rw.phi[0] + (size_t)MAXLAM * MAXRUNS;
+        rw.idx[0] = reinterpret_cast<int *>(rw.phi[1] + (size_t)MAXLAM * MAXRUNS);
+        rw.idx[1] = rw.idx[0] + (size_t)MAXLAM * MAXRUNS;
+        rw.sync = rw.idx[1] + (size_t)MAXLAM * MAXRUNS;
+        MRBF_HIP(ctx, hipMemsetAsync(rw.sync + RS_SYNC * MAXRUNS, 0, sizeof(int), ctx->stream));
+    }
+    hipLaunchKernelGGL(ps_rank_kernel, dim3(1), dim3(rank_threads), shm, ctx->stream, a, impl != 0 ? 1 : 0, rw);
+    if (impl != 0) {
+        hipLaunchKernelGGL(ps_rank_sort_kernel, dim3(RS_W, 1), dim3(RS_THREADS), 0, ctx->stream, a, rw);
+        hipLaunchKernelGGL(ps_rank_kernel, dim3(1), dim3(rank_threads), shm, ctx->stream, a, 2, rw);
+    }
+    MRBF_HIP(ctx, hipGetLastError());
+    int hsync[2] = {0, 0};
+    if (impl != 0) MRBF_HIP(ctx, hipMemcpyAsync(hsync, rw.sync, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    MRBF_HIP(ctx, hipMemcpyAsync(order_out, R.order, (size_t)lam * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (gave_up) *gave_up = hsync[1];
+    return MRBF_OK;
 }

@@ -52,6 +52,7 @@ struct mrbf_round4_state {
 
 namespace mrbf {
 namespace r4 {
+constexpr int KSPLIT_MAX_R4 = 8;  // most k slices of the right-looking update's product (sizes Ppart and the memory estimate)
 
 // Prow[i*q + t] = [1, x_i][t]
 __global__ void poly_rows_kernel(const double *__restrict__ X, int64_t m, int d, int q, double *__restrict__ P) {
@@ -835,7 +836,7 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
     auto *st = new mrbf_round4_state();
     st->n0 = n0; st->mc = mc; st->d = d; st->q = q; st->deg = poly_deg; st->kid = kernel_id; st->a = a; st->b = b; st->maxacc = maxacc;
     // kappa(candidates, candidates) on demand, block by block (kappa_block_kernel; MRBF_R4_LAZY=0: the full mc x mc matrix up front as in rounds 3 / 4)
-    const int lazy_env = getenv("MRBF_R4_LAZY") ? atoi(getenv("MRBF_R4_LAZY")) : 1;  // (read per call: the tests switch it)
+    const int lazy_env = mrbf_env("MRBF_R4_LAZY") ? atoi(mrbf_env("MRBF_R4_LAZY")) : 1;  // (read per call: the tests switch it)
     const bool lazy = lazy_env != 0;
     const size_t cnt[11] = {(size_t)n0 * d, (size_t)mc * d, (size_t)n0 * n0, (size_t)n0 * mc, (size_t)n0 * std::max(q, 1), (size_t)n0 * mc,
                             lazy ? (size_t)1 : (size_t)mc * mc, (size_t)maxacc * maxacc, (size_t)mc, (size_t)mc * std::max(q, 1),
@@ -883,7 +884,7 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
                                          st->Pi0, (int)n0, &zero, G0, q));
             // (the factorisation's info word is read with the first block's counts -- no host round trip of its own; a rank-deficient start
             // set fills the walk with NaNs, which accept nothing, and the call then returns MRBF_ESINGULAR)
-            static const int own_g0 = getenv("MRBF_R4_OWNG0") ? atoi(getenv("MRBF_R4_OWNG0")) : 1;
+            static const int own_g0 = mrbf_env("MRBF_R4_OWNG0") ? atoi(mrbf_env("MRBF_R4_OWNG0")) : 1;
             if (q <= SB && own_g0) {
                 // q <= 128: the library's own diagonal-block kernel on G0 padded with the identity -- factor and inverse of the factor in one
                 // launch -- and G0^-1 = inv(L)' inv(L)  (rocSOLVER: potf2 59 us + two substitution launches on the identity 94 us)
@@ -921,16 +922,16 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
         const size_t shm = ((size_t)SB * SB + SB + 2 * (size_t)std::max(q, 1) + SEL_THREADS / 64) * sizeof(double);
         MRBF_HIP(ctx, hipFuncSetAttribute((const void *)select_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
         // the register variant of the decision kernel: q <= 80 (2 x 5 entries of Ginv per thread) or q <= 128 (2 x 8); needs q >= 1
-        const int sel_env = getenv("MRBF_R4_SELECT") ? atoi(getenv("MRBF_R4_SELECT")) : 2;  // 0: S and Ginv through memory; 1: registers, three barriers; 2: the one-barrier walk
+        const int sel_env = mrbf_env("MRBF_R4_SELECT") ? atoi(mrbf_env("MRBF_R4_SELECT")) : 2;  // 0: S and Ginv through memory; 1: registers, three barriers; 2: the one-barrier walk
         // the decision kernel asks for (nearly) the whole LDS of its compute unit: no workgroup of the side stream's kappa / substitution
         // kernels then fits beside it (sharing the unit's VALUs cost the one sequential kernel of the walk 40 us per block)
         constexpr size_t R4_SEL_LDS = 152 * 1024;
-        const bool duo = getenv("MRBF_R4_DUO") ? atoi(getenv("MRBF_R4_DUO")) != 0 : true;
+        const bool duo = mrbf_env("MRBF_R4_DUO") ? atoi(mrbf_env("MRBF_R4_DUO")) != 0 : true;
         const bool walk_sel = sel_env >= 2 && q >= 1 && q <= 144;  // (beyond: the register kernel; the walk's <8, 6, 12> shape spills)
         // (3: q <= 192 -- d = 128 has q = 129 -- three rows x twelve columns of Ginv per thread)
         const int fast_sel = (sel_env && q >= 1 && q <= 80) ? 1 : ((sel_env && q >= 1 && q <= 128) ? 2 : ((sel_env && q >= 1 && q <= 192) ? 3 : 0));
         const size_t shm_reg = ((size_t)SB * SB + 2 * (size_t)std::max(q, 1) + 16 * (size_t)std::max(q, 1) + 16) * sizeof(double);
-        static const int selw = getenv("MRBF_R4_SELW") ? atoi(getenv("MRBF_R4_SELW")) : 16;  // waves of the decision kernel (8 or 16; 8 measured 6 % slower at d = 64)
+        static const int selw = mrbf_env("MRBF_R4_SELW") ? atoi(mrbf_env("MRBF_R4_SELW")) : 16;  // waves of the decision kernel (8 or 16; 8 measured 6 % slower at d = 64)
         if (fast_sel == 1) {
             MRBF_HIP(ctx, hipFuncSetAttribute((const void *)select_block_reg_kernel<2, 5, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_reg));
             MRBF_HIP(ctx, hipFuncSetAttribute((const void *)select_block_reg_kernel<2, 10, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_reg));
@@ -944,14 +945,23 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
         double *Rb, *Sb, *Rfull = nullptr, *Anew = nullptr, *Kn = nullptr;
         int *cnt;
         // right-looking walk (see gather_newcols_kernel): needs the on-demand kappa; MRBF_R4_EAGER=0 keeps the per-block dtrsm.
-        // Default wherever R for every candidate fits (ldr x mc doubles <= 16 GB): with its own product and substitution kernels and the far
+        // Default wherever R for every candidate fits (see below): with its own product and substitution kernels and the far
         // columns' update on a second stream it wins at every shape measured (d = 64, 2080 of 10^4 accepted, where the walk stops after 17
         // of 79 blocks and most of R(:, ahead) is never used, as well as d = 128, 6000 of 6000).
-        const int eager_env = getenv("MRBF_R4_EAGER") ? atoi(getenv("MRBF_R4_EAGER")) : -1;
-        const bool eager = lazy && (eager_env >= 0 ? eager_env != 0 : (int64_t)round_up(maxacc, 4) * mc <= ((int64_t)2 << 30));
+        const int eager_env = mrbf_env("MRBF_R4_EAGER") ? atoi(mrbf_env("MRBF_R4_EAGER")) : -1;
+        //  the right-looking form keeps R for every candidate plus (KSPLIT_MAX + 2) 128-row panels over all candidates in the
+        // context's pool for the life of the process: by default only while that is at most 2 GB of R and all of it fits into half of the
+        // card's free memory -- beyond, the left-looking form (maxacc x 128 per block) does the same walk
+        bool eager_fits = (int64_t)round_up(maxacc, 4) * mc <= ((int64_t)1 << 28);
+        if (eager_fits) {
+            size_t free_b = 0, total_b = 0;
+            const size_t need = ((size_t)round_up(maxacc, 4) * (mc + 2 * SB) + (size_t)(KSPLIT_MAX_R4 + 2) * SB * mc) * sizeof(double);
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > free_b / 2) eager_fits = false;
+        }
+        const bool eager = lazy && (eager_env >= 0 ? eager_env != 0 : eager_fits);
         const int ldr = eager ? (int)round_up(maxacc, 4) : maxacc;  // leading dimension of R (32-byte aligned columns for the right-looking kernels)
-        const int custom = eager && (getenv("MRBF_R4_CUSTOM") ? atoi(getenv("MRBF_R4_CUSTOM")) : 1);  // 0: rocBLAS dgemm + one thread per candidate
-        constexpr int KSPLIT_MAX = 8;
+        const int custom = eager && (mrbf_env("MRBF_R4_CUSTOM") ? atoi(mrbf_env("MRBF_R4_CUSTOM")) : 1);  // 0: rocBLAS dgemm + one thread per candidate
+        constexpr int KSPLIT_MAX = KSPLIT_MAX_R4;
         double *Ppart = nullptr;
         if (eager) {
             MRBF_TRY(get_buf(ctx, S_PHI, (size_t)ldr * (mc + SB), &Rfull));  // R(:, j) for every candidate j (+ one block: the products read whole 128-column tiles)
@@ -963,10 +973,10 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
         // R(:, block)' R(:, block) by the split-k product kernel (rocBLAS ran this 128 x 128 x nacc product on two workgroups: 165 us at
         // nacc = 5000), slices summed by schur_reduce_kernel
         constexpr int KSPLIT_NEAR = 32;
-        const bool own_schur = custom && (getenv("MRBF_R4_SCHUR") ? atoi(getenv("MRBF_R4_SCHUR")) != 0 : true);
+        const bool own_schur = custom && (mrbf_env("MRBF_R4_SCHUR") ? atoi(mrbf_env("MRBF_R4_SCHUR")) != 0 : true);
         const int64_t nblocks = (mc + SB - 1) / SB;
         double *KbbAll = nullptr, *Spart = nullptr, *Pnear = nullptr, *Kpre = nullptr, *TA = nullptr, *TB = nullptr;
-        const bool tailgemm = own_schur && q > 0 && (getenv("MRBF_R4_TAILGEMM") ? atoi(getenv("MRBF_R4_TAILGEMM")) != 0 : true);
+        const bool tailgemm = own_schur && q > 0 && (mrbf_env("MRBF_R4_TAILGEMM") ? atoi(mrbf_env("MRBF_R4_TAILGEMM")) != 0 : true);
         const int L4 = 4 * (int)n0;
         if (own_schur) {
             MRBF_TRY(get_buf(ctx, S_OUT_A, (size_t)SB * SB * nblocks, &KbbAll));
@@ -993,11 +1003,11 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
         // compute unit asked for, none of them joins it there.  (Tried and dropped: a stream of its own for the walk, with or without the
         // lowest priority -- the process's fifth stream lands on a hardware queue it shares with the main stream, and every small kernel
         // of the walk became 2 to 4 times slower, 5.4 -> 11.3 ms at d = 64.  The context's bulk stream has a queue of its own.)
-        const bool split = eager && custom && (getenv("MRBF_R4_SPLIT") ? atoi(getenv("MRBF_R4_SPLIT")) != 0 : true) && ctx->bulk_stream && ctx->evx[0];
+        const bool split = eager && custom && (mrbf_env("MRBF_R4_SPLIT") ? atoi(mrbf_env("MRBF_R4_SPLIT")) != 0 : true) && ctx->bulk_stream && ctx->evx[0];
         hipStream_t sfar = split ? ctx->bulk_stream : s;
         // kappa(block, next block) for ALL the block's candidates on the side stream while they are being decided: the update of the next
         // block's columns then starts from rows picked out of it instead of a kappa launch of its own on the critical path
-        const bool prek = split && own_schur && ctx->evx[2] && (getenv("MRBF_R4_PREK") ? atoi(getenv("MRBF_R4_PREK")) != 0 : true);
+        const bool prek = split && own_schur && ctx->evx[2] && (mrbf_env("MRBF_R4_PREK") ? atoi(mrbf_env("MRBF_R4_PREK")) != 0 : true);
         bool far_pending = false, prek_any = false;
         int64_t far_from = 0;  // first candidate of the side stream's pending update
         if (eager) {
@@ -1085,6 +1095,7 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
         };
         ExtJob far_job{};  // the far columns' update of the block before: issued after this block's decision kernel is on its way
         int blkno = 0;
+        bool info_checked = false;
         if (prek) {  // the side stream's first kernel reads what the main stream has just set up (lambda, F, the candidates' coordinates)
             MRBF_HIP(ctx, hipEventRecord(ctx->evx[0], s));
             MRBF_HIP(ctx, hipStreamWaitEvent(sfar, ctx->evx[0], 0));
@@ -1210,10 +1221,11 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
                 }
                 return 0;
             };
-            int hc_local[2] = {0, 0};
+            int hc_local[3] = {0, 0, 0};
             int *hc = ctx->hpin ? reinterpret_cast<int *>(ctx->hpin + HPIN_R4_COUNT) : hc_local;  // (pinned: the download does not cost a round trip of its own)
             MRBF_HIP(ctx, hipMemcpyAsync(hc, cnt, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
-            const bool check_info = blkno == 1 && q > 0 && ctx->hpin;
+            const bool check_info = blkno == 1 && q > 0;   // (with or without the pinned block: a rank-deficient start set must be reported)
+            info_checked = info_checked || check_info;
             if (check_info) MRBF_HIP(ctx, hipMemcpyAsync(hc + 2, dinfo, sizeof(int), hipMemcpyDeviceToHost, s));
             // the next block's shapes depend on the number accepted so far: the host waits for the counts only, the factor's new rows are
             // appended under the round trip
@@ -1253,7 +1265,11 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
         MRBF_HIP(ctx, hipGetLastError());
         std::vector<int> hacc((size_t)maxacc + 1);
         MRBF_HIP(ctx, hipMemcpyAsync(hacc.data(), st->acc, hacc.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+        int hinfo = 0;
+        if (!info_checked && q > 0) MRBF_HIP(ctx, hipMemcpyAsync(&hinfo, dinfo, sizeof(int), hipMemcpyDeviceToHost, s));  // (no block ran)
         MRBF_HIP(ctx, hipStreamSynchronize(s));
+        if (hinfo != 0)
+            return fail(ctx, MRBF_ESINGULAR, "the start set's polynomial matrix is rank deficient (potrf info %d): use the host mirror", hinfo);
         st->nacc = hacc[maxacc];
         *n_accepted = st->nacc;
         if (accepted_out)

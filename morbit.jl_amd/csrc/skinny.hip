@@ -290,7 +290,7 @@ int symm_panel(mrbf_ctx *ctx, int64_t n, int64_t npad, int q, const double *Phi,
             break;
         }
     const int ngroups = (njt + pick - 1) / pick;
-    static const int nsplit_env = getenv("MRBF_SYMM_SPLIT") ? atoi(getenv("MRBF_SYMM_SPLIT")) : 0;
+    static const int nsplit_env = mrbf_env("MRBF_SYMM_SPLIT") ? atoi(mrbf_env("MRBF_SYMM_SPLIT")) : 0;
     const int nsplit = nsplit_env > 0 ? nsplit_env : 8;
     const int klen = (int)(round_up((n + nsplit - 1) / nsplit, 16));
     const int qp = ngroups * pick * 16 + (cf ? 16 : 0);

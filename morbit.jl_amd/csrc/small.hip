@@ -1005,13 +1005,13 @@ __global__ __launch_bounds__(256) void tailq_q1_kernel(TailQ t) {
 }  // namespace smallfit
 
 bool small_fit_applies(const mrbf_ctx *ctx, int64_t n, int d, int k, int q, int path) {
-    static const int off = getenv("MRBF_SMALL_FIT") ? atoi(getenv("MRBF_SMALL_FIT")) == 0 : 0;
+    static const int off = mrbf_env("MRBF_SMALL_FIT") ? atoi(mrbf_env("MRBF_SMALL_FIT")) == 0 : 0;
     if (off || ctx->chol_impl == 1 || ctx->gram_mode == 1) return false;
     return n >= 1 && n <= 512 && d >= 1 && d <= 128 && k >= 1 && k <= 16 && n > q && (path == MRBF_PATH_CHOL || path == MRBF_PATH_PROJ_CHOL);
 }
 
 int small_fit_cluster(const mrbf_ctx *ctx, int count) {
-    static const int env = getenv("MRBF_SMALL_NC") ? atoi(getenv("MRBF_SMALL_NC")) : 0;
+    static const int env = mrbf_env("MRBF_SMALL_NC") ? atoi(mrbf_env("MRBF_SMALL_NC")) : 0;
     if (env == 1 || ctx->small_nc == 1 || !ctx->small_cluster_ok) return 1;
     const int groups = (std::max(count, 1) + 7) / 8;  // clusters are dealt in groups of eight problems (one per XCD)
     int nc = 1;
@@ -1040,7 +1040,7 @@ int launch_small_means(mrbf_ctx *ctx, const smallfit::Prob *dev_probs, int count
 
 // The tail basis and the projected right-hand sides in three launches (see TailQ above); applies to d <= 64 (dpad 64), k <= 16, q = d + 1.
 bool tail_basis_applies(const mrbf_model *M) {
-    static const int on = getenv("MRBF_TAILQ") ? atoi(getenv("MRBF_TAILQ")) : 1;
+    static const int on = mrbf_env("MRBF_TAILQ") ? atoi(mrbf_env("MRBF_TAILQ")) : 1;
     return on && M->dpad == 64 && M->d >= 1 && M->d <= 64 && M->q == M->d + 1 && M->k >= 1 && M->k <= 16 && M->npad % 64 == 0;
 }
 int launch_tail_basis(mrbf_ctx *ctx, const mrbf_model *M, const double *Y, double *scratch, double *LinvX, double *T1, double *Q1, double *B,

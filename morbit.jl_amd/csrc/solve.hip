@@ -775,7 +775,7 @@ static int fit_chol(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_info
         } else {
             MRBF_BLAS(ctx, rocsolver_dpotrs(ctx->blas, rocblas_fill_lower, (int)n, k, Phi, (int)ld, B, (int)npad));
         }
-        static const int tail3 = getenv("MRBF_TAIL3") ? atoi(getenv("MRBF_TAIL3")) : 1;
+        static const int tail3 = mrbf_env("MRBF_TAIL3") ? atoi(mrbf_env("MRBF_TAIL3")) : 1;
         if (tail3 && q > 0 && q <= 129 && k <= 16 && (q == 1 || LxInv)) {
             // re-projection, tail coefficients and scatter in three launches (tail_dots / tail_coeff / tail_apply above)
             const int nch = (int)(npad / 64);
@@ -910,7 +910,7 @@ void fill_small_prob(const mrbf_ctx *ctx, const mrbf_model *M, const double *Y, 
     P->spin_ticks = (unsigned long long)std::max(1, ctx->spin_ms) * 100000ull;  // wall_clock64: 100 MHz
     P->fault = (ctx->debug_fault & 4) ? 1 : 0;
     {
-        static const int d6 = getenv("MRBF_SMALL_DIAG6") ? atoi(getenv("MRBF_SMALL_DIAG6")) : 1;  // (round 5: n = 512 0.670 -> 0.628 ms, n = 100 0.171 -> 0.160 ms; 0 selects the v4 core)
+        static const int d6 = mrbf_env("MRBF_SMALL_DIAG6") ? atoi(mrbf_env("MRBF_SMALL_DIAG6")) : 1;  // (round 5: n = 512 0.670 -> 0.628 ms, n = 100 0.171 -> 0.160 ms; 0 selects the v4 core)
         P->diag6 = d6;
     }
     P->mean_given = 0;
@@ -949,7 +949,7 @@ static int fit_small(mrbf_ctx *ctx, mrbf_model *M, const double *Y, mrbf_fit_inf
     int *cl;
     MRBF_TRY(get_buf(ctx, S_SMALL_CL, (size_t)smallfit::CL_WORDS, &cl));
     fill_small_prob(ctx, M, Y, ws, flags, scal, cl, &P);
-    static const int want_stamps = getenv("MRBF_SMALL_STAMPS") ? atoi(getenv("MRBF_SMALL_STAMPS")) : 0;
+    static const int want_stamps = mrbf_env("MRBF_SMALL_STAMPS") ? atoi(mrbf_env("MRBF_SMALL_STAMPS")) : 0;
     long long *dstamps = nullptr;
     if (want_stamps) {
         MRBF_TRY(get_buf(ctx, S_SMALL_DESC, (size_t)16, &dstamps));

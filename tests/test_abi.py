@@ -104,3 +104,40 @@ def test_no_lds_dma_inside_lane_dependent_control_flow():
             if m and re.search(r"\blane\b|\btid\b|threadIdx", m.group(1)):
                 offenders.append("%s:%d: %s" % (os.path.basename(path), i + 1, line.strip()))
     assert not offenders, "LDS-DMA under a lane-dependent condition:\n" + "\n".join(offenders)
+
+
+def test_environment_switches_sit_behind_one_gate(lib):
+    """VERDICT r5 hygiene: some seventy MRBF_* environment switches select schedule experiments and earlier kernel forms.  A drop-in
+    library must not change algorithm on a stray variable: every read goes through mrbf_env() (csrc/common.hpp), which answers only
+    while MRBF_EXPERIMENTS=1 is set.  Pinned: the gate's behaviour (host-only hook) and that no source file reads an MRBF_* variable
+    any other way."""
+    import glob
+
+    keep = {k: os.environ.get(k) for k in ("MRBF_EXPERIMENTS", "MRBF_PS_MULTI")}
+    try:
+        os.environ["MRBF_PS_MULTI"] = "0"
+        os.environ.pop("MRBF_EXPERIMENTS", None)
+        assert lib.mrbf_debug_env(b"MRBF_PS_MULTI") == 0            # set, but the gate is closed: ignored
+        os.environ["MRBF_EXPERIMENTS"] = "0"
+        assert lib.mrbf_debug_env(b"MRBF_PS_MULTI") == 0
+        os.environ["MRBF_EXPERIMENTS"] = "1"
+        assert lib.mrbf_debug_env(b"MRBF_PS_MULTI") == 1            # gate open: honoured
+        assert lib.mrbf_debug_env(b"MRBF_NO_SUCH_SWITCH") == 0
+        assert lib.mrbf_debug_env(None) == -1
+    finally:
+        for k, v in keep.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    csrc = os.path.join(ROOT, "morbit.jl_amd", "csrc")
+    raw, gated = [], 0
+    for path in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.hpp"))):
+        for i, line in enumerate(open(path).read().split("\n")):
+            code = line.split("//")[0]
+            gated += len(re.findall(r"\bmrbf_env\(\"MRBF_", code))
+            for m in re.finditer(r"(?<![_\w])(?:std::)?getenv\(\s*\"?([A-Za-z_]*)", code):
+                if not (os.path.basename(path) == "common.hpp" and m.group(1) in ("MRBF_EXPERIMENTS", "name")):
+                    raw.append("%s:%d: %s" % (os.path.basename(path), i + 1, line.strip()))
+    assert not raw, "environment read outside the gate:\n" + "\n".join(raw)
+    assert gated >= 100

@@ -376,8 +376,8 @@ def test_ps_step_omega_conflicting_objectives(name):
     off the segment 0.3 * ones .. 0.7 * ones by +- 0.15 per coordinate --, the two gradients nearly oppose each other and the descent
     cone is narrow: omega* (SciPy SLSQP on the oracle's model, tests/golden/make_ps_omega.py) is small but not zero.  Asserted, each as
     ONE condition: benchmark budgets: omega >= 0.5 omega*; Morbit's defaults: what the device's step achieves, measured in the
-    REFERENCE's direction r* = f(x) - ideal point*, is at least a quarter of omega*_default.  The achieved ratios are appended to
-    gpurun_out/ps_omega_ratios.txt (promoted to profiles/r05_ps_omega.txt)."""
+    REFERENCE's direction r* = f(x) - ideal point*, is at least a quarter of omega*_default.  The achieved ratios are printed and, with
+    MRBF_TEST_WRITE_RATIOS=1, appended to gpurun_out/ps_omega_ratios.txt (promoted to profiles/r05_ps_omega.txt)."""
     import importlib.util
     import json
     import os
@@ -422,13 +422,14 @@ def test_ps_step_omega_conflicting_objectives(name):
 def _append_ratio_line(line):
     import os
 
-    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
-    try:
-        os.makedirs(out, exist_ok=True)
-        with open(os.path.join(out, "ps_omega_ratios.txt"), "a") as f:
-            f.write(line + "\n")
-    except OSError:
-        pass
+    if os.environ.get("MRBF_TEST_WRITE_RATIOS"):      # opt-in side effect: the ratio lines for profiles/
+        out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        try:
+            os.makedirs(out, exist_ok=True)
+            with open(os.path.join(out, "ps_omega_ratios.txt"), "a") as f:
+                f.write(line + "\n")
+        except OSError:
+            pass
 
 
 @pytest.mark.gpu
@@ -508,3 +509,90 @@ def test_ps_step_device_critical_and_argument_errors():
     bad = _lib.PsOptions(-1, -1, 0, 0, 1, 0.5, 1e-3)
     assert f(ctx.h, mod.model, *args(), ctypes.byref(bad), _lib.as_ptr(buf), _lib.as_ptr(buf), None, ctypes.byref(info)) == -8
     mod.free()
+
+
+def _rank_fixtures(lam, seed):
+    """populations for one ranking: (name, f, phi)"""
+    rng = np.random.default_rng(seed)
+    out = []
+    f = np.sort(rng.random(lam))
+    # (a) a CONSISTENT population (feasible individuals ranked by f on top, a tenth infeasible at the bottom with violation and
+    #     objective rising together), shuffled inside windows of eight: ranked after a few phases -- a true fixed point, the no-swap
+    #     exit is taken at the first test after it
+    nin = lam // 10
+    fa, pa = f.copy(), np.zeros(lam)
+    pa[lam - nin:] = np.sort(rng.random(nin)) + 0.1
+    perm = np.arange(lam)
+    for s in range(0, lam - 8, 8):
+        perm[s:s + 8] = rng.permutation(perm[s:s + 8])
+    out.append(("consistent-window-shuffled", fa[perm], pa[perm]))
+    # (b) ranked, but the last individual is infeasible with the BEST objective value: by phi it belongs where it is, by f (drawn
+    #     with probability 0.45 per comparison) it moves up and drifts back -- sixteen quiet phases happen now and then while it sits
+    #     at the bottom and are NOT a fixed point; 256 quiet phases practically never are taken
+    fb, pb = f.copy(), np.zeros(lam)
+    fb[-1], pb[-1] = -1.0, 0.5
+    out.append(("one-dissenter-at-the-bottom", fb, pb))
+    # (c) a random generation with a third infeasible and a few individuals outside the budget (phi = inf): no early exit
+    fc, pc = rng.random(lam), np.where(rng.random(lam) < 0.33, rng.random(lam), 0.0)
+    fc[-7:], pc[-7:] = np.inf, np.inf
+    out.append(("random-third-infeasible", fc, pc))
+    return out
+
+
+# (lam, seed) for which, on fixture (b), a no-swap test every sixteen phases leaves early with another order than the test every 256
+RULE_SENSITIVE = {1024: 35, 1320: 24}
+
+
+def test_rank_oracle_quiet_stretch_is_not_a_fixed_point():
+    """CPU: the plain NumPy ranking (oracle/ps_rank_oracle.py).  Deterministic comparisons end in the sorted order; a consistent
+    population is a fixed point whatever the test distance; with one dissenting individual the place of the no-swap test changes the
+    order -- the ADVICE r5 finding, and the reason the two device kernels must share one rule per population size."""
+    from oracle import ps_rank_oracle as pro
+
+    f = np.random.default_rng(0).random(300)
+    order, phases = pro.stochastic_rank(f, np.zeros(300), seed=5, gen=2)
+    assert np.array_equal(order, np.argsort(f, kind="stable")) and phases <= 300
+    for lam, seed in RULE_SENSITIVE.items():
+        fx = _rank_fixtures(lam, seed=lam)
+        o256, p256 = pro.stochastic_rank(fx[0][1], fx[0][2], seed=seed, gen=3)
+        o16, p16 = pro.stochastic_rank(fx[0][1], fx[0][2], seed=seed, gen=3, quiet=16)
+        assert p16 < p256 < lam and np.array_equal(o256, o16)            # fixed point: same order, both leave early
+        o256, p256 = pro.stochastic_rank(fx[1][1], fx[1][2], seed=seed, gen=3)
+        o16, p16 = pro.stochastic_rank(fx[1][1], fx[1][2], seed=seed, gen=3, quiet=16)
+        assert p16 < lam and p256 == lam and not np.array_equal(o256, o16), (lam, p16, p256)
+        assert sorted(o256) == list(range(lam))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lam", [1024, 1320, 2600, 5160])
+def test_ps_ranking_kernels_share_one_exit_rule(lam):
+    """the one-workgroup ranking used to leave after sixteen quiet phases, the sixteen-workgroup ranking only at its
+    256-phase chunk boundaries -- different orders whenever the exit is taken early, e.g. after a counter time-out on a shared device.
+    Now one rule per population size.  Crafted generations (nearly ranked, a few infeasible individuals at the parent boundary: the
+    exit IS taken early) through mrbf_debug_ps_rank: one workgroup == sixteen workgroups == sixteen workgroups giving up at once ==
+    the plain NumPy loop of oracle/ps_rank_oracle.py, entry by entry."""
+    import ctypes
+
+    from morbit.jl_amd import _lib
+    from oracle import ps_rank_oracle as pro
+
+    ctx = pkg.Context()
+    try:
+        took_early = 0
+        for seed, gen in ((RULE_SENSITIVE.get(lam, 11), 3), (2 ** 40 + 17, 0)):
+            for name, f, phi in _rank_fixtures(lam, seed=lam):
+                want, phases = pro.stochastic_rank(f, phi, seed=seed, gen=gen)
+                took_early += phases < lam
+                got = {}
+                for impl in (0, 1, 2):
+                    order = np.empty(lam, dtype=np.int32)
+                    gave_up = ctypes.c_int32(-1)
+                    ctx.check(ctx.lib.mrbf_debug_ps_rank(ctx.h, lam, _lib.as_ptr(f), _lib.as_ptr(phi), seed, gen, impl,
+                                                         order.ctypes.data_as(_lib.c_ip), ctypes.byref(gave_up)))
+                    assert gave_up.value == (1 if impl == 2 else 0), (name, impl, gave_up.value)
+                    got[impl] = order
+                for impl in (0, 1, 2):
+                    assert np.array_equal(got[impl], want), (lam, name, seed, gen, impl, int(np.argmax(got[impl] != want)))
+        assert took_early >= 2, took_early     # the fixtures do exercise the early exit
+    finally:
+        ctx.close()

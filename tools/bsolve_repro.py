@@ -1,6 +1,7 @@
 """Sequential single fits of changing size on ONE context against the host-launched block solve (MRBF_BACKSOLVE_LAUNCHES=1 in a child
 process): finds results that depend on what the context solved before."""
 import os, sys, subprocess, pickle
+os.environ.setdefault("MRBF_EXPERIMENTS", "1")  # the library honours its MRBF_* switches only behind this gate
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sizes = [640, 900, 640, 1300, 900, 2048, 777, 900, 1800, 900]

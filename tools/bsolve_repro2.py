@@ -1,6 +1,7 @@
 """test_batch_run_concurrent_persistent_kernels as a script: batch (four contexts at a time) and single calls against the host-launched
 block solve computed in a child process."""
 import os, sys, subprocess, pickle
+os.environ.setdefault("MRBF_EXPERIMENTS", "1")  # the library honours its MRBF_* switches only behind this gate
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

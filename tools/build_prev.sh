@@ -1,4 +1,5 @@
 #!/bin/bash
+export MRBF_EXPERIMENTS=1   # the library honours its MRBF_* switches only behind this gate
 # Build morbit.jl_amd/libmrbf_prev.so from the committed (HEAD) version of the given csrc files and the current objects of the rest:
 # same-box A/B of a kernel change (MRBF_LIB=.../libmrbf_prev.so python tools/...).   usage: tools/build_prev.sh chol_mega.hip [more.hip]
 set -e

@@ -1,4 +1,5 @@
 #!/bin/bash
+export MRBF_EXPERIMENTS=1   # the library honours its MRBF_* switches only behind this gate
 # Build morbit.jl_amd/libmrbf_<name>.so with one translation unit compiled with extra flags (same-box A/B of a kernel variant:
 # MRBF_LIB=.../libmrbf_<name>.so python tools/...).   usage: tools/build_variant.sh <name> <file.hip> <flags...>
 set -e

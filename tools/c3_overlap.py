@@ -1,5 +1,7 @@
 """Experiment: C3 cycles from W concurrent contexts (host threads), optionally with smaller persistent grids: does overlapping one problem's
 chain-bound tail with another's bulk phases raise cycles/s?"""
+import os
+os.environ.setdefault("MRBF_EXPERIMENTS", "1")  # the library honours its MRBF_* switches only behind this gate
 import ctypes, os, sys, threading, time
 import numpy as np
 import torch

@@ -1,3 +1,5 @@
+import os
+os.environ.setdefault("MRBF_EXPERIMENTS", "1")  # the library honours its MRBF_* switches only behind this gate
 import ctypes, os, sys, time
 import numpy as np
 sys.path.insert(0, ".")

@@ -1,4 +1,6 @@
 """Kernel-only time of mrbf_eval (events inside the library) for the C3 model: python tools/eval_time.py  (MRBF_LIB selects the build)"""
+import os
+os.environ.setdefault("MRBF_EXPERIMENTS", "1")  # the library honours its MRBF_* switches only behind this gate
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

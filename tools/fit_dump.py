@@ -3,6 +3,7 @@ the fit (MRBF_TAILQ=1: tail basis in three launches, small.hip TailQ; =0: the tw
 this script once per setting.   usage: python tools/fit_dump.py out.npz"""
 import importlib
 import os
+os.environ.setdefault("MRBF_EXPERIMENTS", "1")  # the library honours its MRBF_* switches only behind this gate
 import sys
 
 import numpy as np

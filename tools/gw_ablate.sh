@@ -1,4 +1,5 @@
 #!/bin/bash
+export MRBF_EXPERIMENTS=1   # the library honours its MRBF_* switches only behind this gate
 # ablation of gram_w_kernel on the C3 workload under rocprofv3 (kernel time from the trace; an ablated kernel makes the fit fall
 # back to the LU path, which does not matter here): MRBF_GW_DBG bits 1 no stores, 2 no radial function, 4 no W product, 8 no Gram
 # product, 16 no staging; MRBF_GW_WGS workgroups (512 = two per CU).

@@ -2,6 +2,7 @@
 """Many-start throughput (BASELINE.json configs[3], C4: d=128, n=257 cubic, 64 starts) through mrbf_batch_run."""
 import ctypes
 import os
+os.environ.setdefault("MRBF_EXPERIMENTS", "1")  # the library honours its MRBF_* switches only behind this gate
 import sys
 import time
 

@@ -1,5 +1,7 @@
 """Cross-block hand-off of the diagonal chain: from one traced + logged launch (MRBF_MEGA_TRACE=t.txt MRBF_MEGA_JLOG=j.txt) print, per
 block column c, when P(c) had published its last 16-column panel, when S(c+1,c) saw it / finished, and when P(c+1) started factoring."""
+import os
+os.environ.setdefault("MRBF_EXPERIMENTS", "1")  # the library honours its MRBF_* switches only behind this gate
 import sys
 import numpy as np
 T = np.loadtxt(sys.argv[1])

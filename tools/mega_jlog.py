@@ -1,6 +1,8 @@
 """Analyse a job log of the persistent factorisation (MRBF_MEGA_JLOG=file).
 columns: kind i c w wg claim s2 s3 s4 s5 s6 end   (us; -1 = not stamped)
 kinds: 0 U (bulk), 1 T (half panel tile; w = half), 2 P (diag), 3 S (streamed panel tile), 4 UH"""
+import os
+os.environ.setdefault("MRBF_EXPERIMENTS", "1")  # the library honours its MRBF_* switches only behind this gate
 import sys
 import numpy as np
 L = np.loadtxt(sys.argv[1])

@@ -1,4 +1,5 @@
 #!/bin/bash
+export MRBF_EXPERIMENTS=1   # the library honours its MRBF_* switches only behind this gate
 # job log + chain trace of one persistent factorisation of the C3 matrix (n = 8192) -> gpurun_out/<tag>_{jlog,trace}.txt and their summaries
 TAG=${1:-mp}; N=${2:-8192}
 cat > gpurun_out/mp_run.py <<PY

@@ -1,6 +1,8 @@
 """Print the chain breakdown of one traced persistent factorisation (MRBF_MEGA_TRACE=file).
 Stamps per diagonal job P(c): 0 claimed, 1 GEMM-loop part done, 2 last panel folded in (factorisation starts), 3 factor + inverse done,
 4 published."""
+import os
+os.environ.setdefault("MRBF_EXPERIMENTS", "1")  # the library honours its MRBF_* switches only behind this gate
 import sys
 import numpy as np
 rows = np.loadtxt(sys.argv[1])

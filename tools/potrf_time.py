@@ -4,6 +4,7 @@ prints per size: min / median ms over the repetitions and the TFLOP/s of n^3 / 3
 import ctypes
 import importlib
 import os
+os.environ.setdefault("MRBF_EXPERIMENTS", "1")  # the library honours its MRBF_* switches only behind this gate
 import sys
 
 import numpy as np

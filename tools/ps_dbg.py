@@ -1,5 +1,6 @@
 """timing experiments for the device PS step (MRBF_PS_DBG bits: 1 no ranking, 2 no breeding)"""
 import os, sys, time
+os.environ.setdefault("MRBF_EXPERIMENTS", "1")  # the library honours its MRBF_* switches only behind this gate
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import morbit.jl_amd as pkg

@@ -1,4 +1,5 @@
 #!/bin/bash
+export MRBF_EXPERIMENTS=1   # the library honours its MRBF_* switches only behind this gate
 # round 5, first GPU call: LDS-DMA hazard (stand-alone + in the factorisation), Gram lab, bench line with the new accounting
 set -o pipefail
 OUT=gpurun_out/r5a

@@ -1,4 +1,5 @@
 #!/bin/bash
+export MRBF_EXPERIMENTS=1   # the library honours its MRBF_* switches only behind this gate
 set -o pipefail
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/r5h

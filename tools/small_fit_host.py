@@ -1,4 +1,6 @@
 """Where a small fit's wall time goes: host arrays vs device tensors handed to mrbf_fit, and the kernel's own time (MRBF_SMALL_STAMPS)."""
+import os
+os.environ.setdefault("MRBF_EXPERIMENTS", "1")  # the library honours its MRBF_* switches only behind this gate
 import ctypes, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

@@ -1,5 +1,6 @@
 """Wall time of single small fits (n <= 512: the one-launch path) for a few shapes; MRBF_LIB selects the build."""
 import os, sys, time
+os.environ.setdefault("MRBF_EXPERIMENTS", "1")  # the library honours its MRBF_* switches only behind this gate
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import morbit.jl_amd as pkg

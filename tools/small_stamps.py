@@ -1,5 +1,7 @@
 """Phase times of the one-launch small fit (MRBF_SMALL_STAMPS=1 prints them per call): C4 start, then shapes that separate the
 cost of the operands (d) from the cost per output element (n)."""
+import os
+os.environ.setdefault("MRBF_EXPERIMENTS", "1")  # the library honours its MRBF_* switches only behind this gate
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("MRBF_SMALL_STAMPS", "1")

@@ -1,4 +1,5 @@
 #!/bin/bash
+export MRBF_EXPERIMENTS=1   # the library honours its MRBF_* switches only behind this gate
 # sweep of the persistent factorisation's scheduling knobs after the deferred bulk-update wait (round 2)
 run() { echo "$@"; env "$@" timeout -k 10 100 python tools/mega_check.py 8192 3 4 2>&1 | grep "n="; }
 run MRBF_X=0

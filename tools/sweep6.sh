@@ -1,4 +1,5 @@
 #!/bin/bash
+export MRBF_EXPERIMENTS=1   # the library honours its MRBF_* switches only behind this gate
 run() { echo -n "$* : "; env "$@" timeout -k 10 100 python bench.py --steps 60 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys;o=json.loads(sys.stdin.read());print(round(o['value'],2), round(o['phases_ms']['factor'],4), o['check']['factor_ms']['min'])"; }
 run MRBF_X=0

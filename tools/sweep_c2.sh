@@ -1,4 +1,5 @@
 #!/bin/bash
+export MRBF_EXPERIMENTS=1   # the library honours its MRBF_* switches only behind this gate
 # knobs of the persistent factorisation on a chain-bound size (C2: n = 2048, 16 block columns): factor phase of bench.py
 run() { echo -n "$* : "; env "$@" timeout -k 10 100 python bench.py --config C2 --steps 300 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys;o=json.loads(sys.stdin.read());print(round(o['value'],1), round(o['phases_ms']['factor'],4))"; }

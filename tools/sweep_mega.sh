@@ -1,4 +1,5 @@
 #!/bin/bash
+export MRBF_EXPERIMENTS=1   # the library honours its MRBF_* switches only behind this gate
 # Parameter sweeps of the persistent factorisation (environment knobs of chol_mega.hip / context.hip), e.g.
 #   MRBF_MEGA_SLACK, MRBF_MEGA_SLACK_CHAIN, MRBF_MEGA_WIN, MRBF_MEGA_WBIAS, MRBF_MEGA_DEDICATED, MRBF_MEGA_CHAIN, MRBF_MEGA_LOOK,
 #   MRBF_MEGA_FIRST_WINDOW, MRBF_MEGA_SROWS; MRBF_MEGA_DEBUG=1 prints which dependency a bounded spin gave up on.

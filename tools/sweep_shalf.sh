@@ -1,4 +1,5 @@
 #!/bin/bash
+export MRBF_EXPERIMENTS=1   # the library honours its MRBF_* switches only behind this gate
 # half-height streamed jobs (MRBF_MEGA_SHALF = last so many block columns) against chain / reserve workgroup counts
 run() { echo -n "$* : "; env "$@" timeout -k 10 120 python3 tools/potrf_time.py $SIZES 9 2>&1 | tail -1; }
 SIZES=2048,4096,4608,5120,6144

@@ -1,4 +1,5 @@
 #!/bin/bash
+export MRBF_EXPERIMENTS=1   # the library honours its MRBF_* switches only behind this gate
 # chain-bound sizes: streamed rows, stream depth, look-ahead against the defaults (halves on, 64 chain workgroups on four XCDs)
 run() { echo -n "$* : "; env "$@" timeout -k 10 120 python3 tools/potrf_time.py $SIZES 9 2>&1 | tail -1; }
 SIZES=1024,2048,3072,4096

@@ -1,4 +1,5 @@
 #!/bin/bash
+export MRBF_EXPERIMENTS=1   # the library honours its MRBF_* switches only behind this gate
 # n = 8192 (fit-shaped): streamed tiles as halves in the last block columns, with enough reserve chain workgroups on their own CUs
 run() { echo -n "$* : "; env "$@" timeout -k 10 200 python3 tools/fit_factor_time.py ${SIZES:-8192} 2>&1 | tail -1; }
 run MRBF_X=0
