@@ -88,6 +88,9 @@ enum {
                                   between the events */
     MRBF_OPT_SLOW_LAUNCHES = 12,  /* read only: persistent factorisations of this context that took more than twice the shortest seen
                                   at their shape (cumulative) */
+    MRBF_OPT_ARENA_BYTES = 13,   /* read only: bytes of device memory the context's grow-only arena (named work buffers) and its pool of released
+                                  * model blocks hold: constant in steady state (a caller can watch it over its iterations) */
+    MRBF_OPT_LIVE_HANDLES = 14,  /* read only: models + round-4 states created through this context and not yet released */
     MRBF_OPT_DEBUG_FAULT = 10  /* test hook: bit 0 = one workgroup of the persistent factorisation skips a publish, bit 1 = one workgroup of
                                   the persistent backward substitution does (the next fit must fall back and still return the right weights), bit 2 = one
                                   member of a small fit's workgroup cluster leaves early (the fit is repeated with one workgroup per problem) */

@@ -17,6 +17,7 @@ MRBF_OK, MRBF_ENOTPD, MRBF_ESINGULAR, MRBF_EHIP, MRBF_EBLAS, MRBF_ENOMEM, MRBF_E
 PATH_CHOL, PATH_PROJ_CHOL, PATH_LU, PATH_MINNORM, PATH_ROUND4 = 1, 2, 3, 4, 5
 OPT_GRAM_MODE, OPT_RESIDUAL, OPT_FORCE_PATH, OPT_CHOL_IMPL, OPT_EVAL_IMPL, OPT_TIMING, OPT_DIAG_IMPL, OPT_CHOL_WINDOW = 1, 2, 3, 4, 5, 6, 7, 8
 OPT_SPIN_MS, OPT_DEBUG_FAULT, OPT_LAST_DEVICE_MS, OPT_SLOW_LAUNCHES = 9, 10, 11, 12
+OPT_ARENA_BYTES, OPT_LIVE_HANDLES = 13, 14   # read only
 FB_CHOL_HOST_DRIVEN, FB_BACKSOLVE_BLOCKED, FB_LU = 1, 2, 4
 
 

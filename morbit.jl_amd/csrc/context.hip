@@ -79,8 +79,8 @@ int get_buf(mrbf_ctx *ctx, Slot s, size_t bytes, void **out) {
             b.p = nullptr;
             b.bytes = 0;
         }
-        size_t want = bytes + bytes / 8;  // slack so slowly growing problems do not realloc every call
-        want = (want + 255) & ~size_t(255);
+        size_t want = bytes + bytes / 4;  // slack so slowly growing problems (a model gains a site per iteration: n^2 grows by ~1 % a call) do not realloc every call
+        want = std::max<size_t>((want + 255) & ~size_t(255), size_t(64) << 10);  // small work buffers (candidate lists, per-call scalars) never regrow below 64 KB
         MRBF_HIP(ctx, hipMalloc(&b.p, want));
         b.bytes = want;
     }
@@ -370,6 +370,14 @@ int32_t mrbf_get_option(const mrbf_ctx *ctx, int32_t key, double *value) {
         case MRBF_OPT_DEBUG_FAULT: *value = ctx->debug_fault; break;
         case MRBF_OPT_LAST_DEVICE_MS: *value = ctx->last_device_ms; break;
         case MRBF_OPT_SLOW_LAUNCHES: *value = ctx->slow_launches; break;
+        case MRBF_OPT_ARENA_BYTES: {
+            double bytes = 0.0;
+            for (int i = 0; i < S_NSLOTS; ++i) bytes += (double)ctx->slots[i].bytes;
+            for (auto &b : ctx->model_pool) bytes += (double)b.bytes;
+            *value = bytes;
+            break;
+        }
+        case MRBF_OPT_LIVE_HANDLES: *value = ctx->live_models + ctx->live_round4; break;
         default: return -2;
     }
     return MRBF_OK;

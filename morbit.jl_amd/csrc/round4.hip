@@ -806,6 +806,7 @@ extern "C" int32_t mrbf_free_round4(mrbf_ctx *ctx, mrbf_round4_state *st) {
     (void)hipStreamSynchronize(ctx->stream);
     if (st->block) (void)hipFree(st->block);
     delete st;
+    --ctx->live_round4;
     return MRBF_OK;
 }
 
@@ -1285,6 +1286,7 @@ extern "C" int32_t mrbf_round4(mrbf_ctx *ctx, int64_t n0, int32_t d, const doubl
         return rc;
     }
     *state_out = st;
+    ++ctx->live_round4;
     return MRBF_OK;
 }
 
@@ -1366,7 +1368,17 @@ extern "C" int32_t mrbf_fit_from_round4(mrbf_ctx *ctx, const mrbf_round4_state *
                            M->Wc, M->lam);
         MRBF_HIP(ctx, hipGetLastError());
         MRBF_HIP(ctx, hipEventRecord(ctx->ev[6], s));
-        if (ctx->residual) MRBF_TRY(fit_check(ctx, M, Y, info));
+        if (ctx->residual) {
+            MRBF_TRY(fit_check(ctx, M, Y, info));
+            // The kept factor is only as good as the start set it was built on: kappa is formed with cancellation against the start set's
+            // polynomial interpolant, and a start set that barely passes the affine filter's pivot test (a shrunken trust region over
+            // far-apart database sites; seen in the iteration rehearsal: residual 7e-8) takes the fit outside the 1e-8 value tolerance.
+            // The interpolation residual is the tripwire: beyond 1e-9 the caller is told to take the ordinary fit (the decision table
+            // maps MRBF_ENOTPD of this entry point to it) -- accuracy is never traded for the two triangular solves.
+            if (!(info->rel_residual <= 1e-9))
+                return fail(ctx, MRBF_ENOTPD, "kept round-4 factor too inaccurate for this training set (relative residual %.2e): use mrbf_fit",
+                            info->rel_residual);
+        }
         if (weights_out) MRBF_HIP(ctx, hipMemcpyAsync(weights_out, M->W, (size_t)n * k * sizeof(double), hipMemcpyDefault, s));
         if (poly_out && q > 0) MRBF_HIP(ctx, hipMemcpyAsync(poly_out, M->lam, (size_t)q * k * sizeof(double), hipMemcpyDefault, s));
         MRBF_HIP(ctx, hipStreamSynchronize(s));

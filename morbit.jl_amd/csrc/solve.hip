@@ -123,6 +123,7 @@ static inline unsigned nblk(int64_t cnt) { return (unsigned)((cnt + 255) / 256);
 
 void destroy_model(mrbf_ctx *ctx, mrbf_model *M) {
     if (!M) return;
+    if (ctx && M->block) --ctx->live_models;
     if (M->block) {
         size_t pooled = 0;
         if (ctx)
@@ -182,6 +183,7 @@ int build_model_shell(mrbf_ctx *ctx, int64_t n, int d, int k, const double *Cdev
         }
         M->block_bytes = total;
     }
+    ++ctx->live_models;  // (MRBF_OPT_LIVE_HANDLES: models and round-4 states created through this context and not yet released)
     char *base = (char *)M->block;
     M->C = (double *)(base + off[0]);
     M->Xc = (double *)(base + off[1]);

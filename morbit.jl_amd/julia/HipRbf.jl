@@ -234,12 +234,50 @@ const _GENERIC_PREPARE_SIG = Tuple{Union{Nothing,RbfModel},RbfMeta,Any,Any,Any,A
 # is what routes the affine filter's candidate scan (rounds 1-2) to the device.  The filter is built without a config
 # (RbfModel.jl:219), so the config cannot be dispatched on there; a plain `RbfConfig` run never sets the key, on any task.
 const _HIP_AFFINE_KEY = :HipRbf_affine_scan
+# Householder QR of Y = [y_1 .. y_j] kept up to date as the filter picks sites, with the FULL orthogonal factor explicit: appending a
+# column is one reflector on the trailing rows, Q <- Q diag(I_j, H) -- a rank-1 update of Q's trailing columns, O(d^2) per pick.  Morbit
+# re-factors Y after every pick (`_orthogonal_complement_matrix`, AffinelyIndependentPoints.jl:4-11: O(d^3) per pick, O(d^4) per filter;
+# 140-280 ms per model update at d = 128, more than round 4, the fit and the descent step together -- profiles/r06_iteration_c4.txt).
+# Same reflectors as LAPACK's geqrf (larfg: beta = -sign(alpha) |x|, v_1 = 1): Q equals qr(Y)'s to rounding, the picks are Morbit's.
+# (1:1 twin of `_GrowingQR` in morbit.jl_amd/sampling.py, which tests/test_sampling.py holds against the from-scratch factorisation.)
+mutable struct HipRbfGrowingQR
+    Q::Matrix{Float64}
+    j::Int
+end
+function HipRbfGrowingQR(Y::AbstractMatrix)
+    d = size(Y, 1)
+    Q = size(Y, 2) == 0 ? Matrix{Float64}(I, d, d) : qr(Matrix{Float64}(Y)).Q * Matrix{Float64}(I, d, d)
+    return HipRbfGrowingQR(Q, size(Y, 2))
+end
+function _append!(g::HipRbfGrowingQR, y::AbstractVector)
+    d = size(g.Q, 1); j = g.j
+    j >= d && return g
+    Qt = view(g.Q, :, j+1:d)
+    x = Qt' * Vector{Float64}(y)                       # the new column in the current basis, trailing part
+    α = x[1]; xn = norm(view(x, 2:length(x)))
+    if xn != 0
+        β = -copysign(hypot(α, xn), α)
+        τ = (β - α) / β
+        v = x ./ (α - β); v[1] = 1.0
+        Qt .-= (Qt * v) * (τ .* v)'                    # Q[:, j+1:d] H
+    end
+    g.j = j + 1
+    return g
+end
+function _complement(g::HipRbfGrowingQR, p)
+    Z = g.Q[:, g.j+1:end]
+    size(Z, 2) > 0 && (Z ./= norm.(eachcol(Z), p)')   # AffinelyIndependentPoints.jl:7-9
+    return Z
+end
+
 mutable struct HipRbfAffineScan
     seeds::IdDict{Any,Matrix{Float64}}      # filter => d x mc matrix of shifted seeds, picked columns zeroed (task-local, no global)
+    qrs::IdDict{Any,HipRbfGrowingQR}        # filter => the growing factorisation of its Y
 end
+HipRbfAffineScan() = HipRbfAffineScan(IdDict{Any,Matrix{Float64}}(), IdDict{Any,HipRbfGrowingQR}())
 _hip_affine_scan() = get(task_local_storage(), _HIP_AFFINE_KEY, nothing)
 _prepare_with_device_scan(meta, cfg::HipRbfConfig, args...; kwargs...) =
-    task_local_storage(_HIP_AFFINE_KEY, HipRbfAffineScan(IdDict{Any,Matrix{Float64}}())) do
+    task_local_storage(_HIP_AFFINE_KEY, HipRbfAffineScan()) do
         invoke(prepare_update_model, _GENERIC_PREPARE_SIG, nothing, meta, cfg, args...; kwargs...)
     end
 prepare_update_model(mod::Nothing, meta::RbfMeta, cfg::HipRbfConfig, func_indices, mop, scal, iter_data, sdb, ac; kwargs...) =
@@ -306,29 +344,37 @@ end
 function Base.iterate(filter::AffinelyIndependentPointFilter{Float64,VF,SV}, num_found::Int) where {VF,SV}
     scan = _hip_affine_scan()
     scan === nothing && return invoke(Base.iterate, Tuple{AffinelyIndependentPointFilter,Int}, filter, num_found)
-    seeds = scan.seeds
-    num_found == filter.n && (delete!(seeds, filter); return nothing)
-    isempty(filter.candidate_indices) && (delete!(seeds, filter); return nothing)
-    _dispatch_affine(length(filter.candidate_indices), length(filter.x_0)) ||
-        return invoke(Base.iterate, Tuple{AffinelyIndependentPointFilter,Int}, filter, num_found)
-    S = get!(seeds, filter) do
-        M = _dense(_as_matrix(filter.shifted_seeds))
+    done() = (delete!(scan.seeds, filter); delete!(scan.qrs, filter); nothing)
+    num_found == filter.n && return done()
+    isempty(filter.candidate_indices) && return done()
+    S = get!(scan.seeds, filter) do
+        M = Matrix{Float64}(_as_matrix(filter.shifted_seeds))    # a copy: picked columns are zeroed below
         for j in setdiff(eachindex(filter.shifted_seeds), filter.candidate_indices)
             M[:, j] .= 0                                   # chosen sites score 0 (the reference removes them from the list)
         end
         M
     end
-    best_index, best_val = affine_scores(S, filter.Z, filter.p)
+    # the scan: on the device for many candidates (decision table), else two host BLAS products -- the same scores either way
+    best_index, best_val = _dispatch_affine(length(filter.candidate_indices), length(filter.x_0)) ?
+                           affine_scores(S, filter.Z, filter.p) : _affine_scores_host(S, filter.Z, filter.p)
     if best_index >= 1 && best_val > filter.pivot_val
         i = best_index
+        g = get!(() -> HipRbfGrowingQR(filter.Y), scan.qrs, filter)     # (factor of the sites found so far, before this one joins)
         filter.Y = hcat(filter.Y, filter.shifted_seeds[i])
-        filter.Z = _orthogonal_complement_matrix(filter.Y, filter.p)
+        _append!(g, filter.shifted_seeds[i])
+        filter.Z = _complement(g, filter.p)
         setdiff!(filter.candidate_indices, i)
         S[:, i] .= 0
         return (filter.return_indices ? i : filter.seeds[i]), num_found + 1
     end
-    delete!(seeds, filter)
-    return nothing
+    return done()
+end
+"`‖Z (Zᵀ s)‖_p` of every column s of S on the host; first maximiser like the `>` scan of AffinelyIndependentPoints.jl:80-89"
+function _affine_scores_host(S::Matrix{Float64}, Z::AbstractMatrix, p)
+    size(Z, 2) == 0 && return 0, -Inf
+    P = Z * (Z' * S)
+    best_val, best = findmax([norm(view(P, :, c), p) for c in axes(P, 2)])
+    return best, best_val
 end
 
 # ---- phase II: the fit.  With a kept round-4 factor that describes exactly this training set: two triangular solves

@@ -25,6 +25,44 @@ def _orthogonal_complement_matrix(Y, p=np.inf):
     return Z
 
 
+class _GrowingQR:
+    """Householder QR of Y = [y_1 .. y_j] kept up to date as columns are appended, with the FULL orthogonal factor Q (d x d)
+    explicit: appending y_{j+1} is one reflector H on the trailing rows, Q <- Q diag(I_j, H), i.e. a rank-1 update of Q's trailing
+    columns -- O(d^2) per pick.  The reference re-factors Y from scratch after every pick (`_orthogonal_complement_matrix`,
+    AffinelyIndependentPoints.jl:4-11: qr(Y), O(d^3) per pick, O(d^4) per filter -- 140-280 ms per model update at d = 128 in the
+    iteration rehearsal, more than round 4, the fit and the Pascoletti-Serafini step together).  Same reflectors as LAPACK's dgeqrf
+    (dlarfg: beta = -sign(alpha) ||x||, v_1 = 1), so Q agrees with qr(Y)'s to rounding and the picks are the reference's."""
+
+    def __init__(self, d, Y=None):
+        self.d = d
+        if Y is None or Y.shape[1] == 0:
+            self.Q, self.j = np.eye(d), 0
+        else:
+            self.Q, _ = np.linalg.qr(Y, mode="complete")
+            self.j = Y.shape[1]
+
+    def append(self, y):
+        j, Q = self.j, self.Q
+        if j >= self.d:
+            return
+        x = Q[:, j:].T @ y                      # the new column in the current basis, trailing part
+        alpha, xn = x[0], np.linalg.norm(x[1:])
+        if xn != 0.0:                           # dlarfg
+            beta = -math.copysign(math.hypot(alpha, xn), alpha)
+            tau = (beta - alpha) / beta
+            v = x / (alpha - beta)
+            v[0] = 1.0
+            Qt = Q[:, j:]
+            Qt -= np.outer(Qt @ v, tau * v)     # Q[:, j:] H
+        self.j = j + 1
+
+    def complement(self, p=np.inf):
+        Z = self.Q[:, self.j:].copy()
+        if Z.shape[1] > 0:
+            Z /= np.linalg.norm(Z, ord=p, axis=0)[None, :]
+        return Z
+
+
 class AffinelyIndependentPointFilter:
     """Greedy filter: repeatedly the candidate maximising ||Z Z'(xi - x0)||_p, accepted while it exceeds pivot_val."""
 
@@ -50,14 +88,19 @@ class AffinelyIndependentPointFilter:
                                              1 if np.isinf(self.p) else 0, None, ctypes.byref(best), ctypes.byref(val)))
         return int(best.value), float(val.value)
 
+    def _take(self, qr, i):
+        self.Y = np.hstack([self.Y, self.shifted[i][:, None]])
+        qr.append(self.shifted[i])
+        self.Z = qr.complement(self.p)
+
     def collect(self):
         out = []
         if not self.shifted:
             return out
         i = int(np.argmax([np.linalg.norm(s, ord=self.p) for s in self.shifted]))
         cand = [c for c in range(len(self.shifted)) if c != i]
-        self.Y = np.hstack([self.Y, self.shifted[i][:, None]])
-        self.Z = _orthogonal_complement_matrix(self.Y, self.p)
+        qr = _GrowingQR(self.x_0.size, self.Y)
+        self._take(qr, i)
         out.append(i)
         S = np.array(self.shifted) if self.shifted else np.empty((0, self.x_0.size))
         on_device = self.ctx is not None or \
@@ -70,8 +113,7 @@ class AffinelyIndependentPointFilter:
                 best, vb = self._scores_device(Sd)
                 if best < 0 or not vb > self.pivot_val:
                     break
-                self.Y = np.hstack([self.Y, self.shifted[best][:, None]])
-                self.Z = _orthogonal_complement_matrix(self.Y, self.p)
+                self._take(qr, best)
                 cand.remove(best)
                 Sd[best] = 0.0
                 out.append(best)
@@ -85,8 +127,7 @@ class AffinelyIndependentPointFilter:
             if not vals[b] > self.pivot_val:
                 break
             best = cand[b]
-            self.Y = np.hstack([self.Y, self.shifted[best][:, None]])
-            self.Z = _orthogonal_complement_matrix(self.Y, self.p)
+            self._take(qr, best)
             cand.remove(best)
             out.append(best)
         return out

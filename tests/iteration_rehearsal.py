@@ -1,0 +1,165 @@
+"""TEST INFRASTRUCTURE: the call sequence of ONE Morbit iteration, repeated on ONE context.
+
+Not a port of /root/reference/src/algorithm.jl: no filter, no normal step, no stopping tests, no scaler -- only the ORDER in which
+`iterate!` reaches the hot path (algorithm.jl:682-688 model update -> :721 criticality -> :756 trial point -> acceptance / radius
+update :806-870 with the defaults of AbstractConfigInterface.jl:28-78), so that what the unit tests cover call by call is exercised
+as a sequence: the database grows by a site per iteration, n changes between fits (arena growth, job-table LRU of the persistent
+factorisation), the factor round 4 keeps is consumed by the next fit, every model / round-4 handle is released by its owner.
+
+  box candidates (Databases.jl:324-327) -> affine filter rounds 1-2 (mrbf_affine_scores when the decision table says so)
+  -> round 3 along the improving directions (RbfModel.jl:269-307) -> _rbf_round4 (mrbf_round4, factor kept)
+  -> update_model (mrbf_fit_from_round4 / mrbf_fit) -> get_criticality (PS step: mrbf_ps_step_problem)
+  -> _backtrack (mrbf_backtrack) towards the PS trial point -> objectives at the trial point, new database site, rho, radius.
+"""
+import time
+
+import numpy as np
+
+import morbit  # noqa: F401
+import morbit.jl_amd as pkg
+from morbit.jl_amd import _lib
+from morbit.jl_amd import descent
+from morbit.jl_amd import pascoletti_serafini as ps
+from morbit.jl_amd import sampling as sp
+from morbit.jl_amd import surrogates as sg
+
+
+def _absmax_step(x, direction, lb, ub):
+    """signed length of the longer feasible segment from x along +-direction inside [lb, ub] (intersect_box, :absmax)"""
+    with np.errstate(divide="ignore", invalid="ignore"):
+        tp = np.where(direction > 0, (ub - x) / direction, np.where(direction < 0, (lb - x) / direction, np.inf))
+        tm = np.where(direction > 0, (x - lb) / direction, np.where(direction < 0, (x - ub) / direction, np.inf))
+    pos, neg = float(np.min(tp)), float(np.min(tm))
+    return pos if pos >= neg else -neg
+
+
+class Rehearsal:
+    def __init__(self, objectives, x0, lb=None, ub=None, sites=None, values=None, cfg=None, ps_cfg=None, delta0=0.1, delta_max=0.5, seed=0,
+                 on_critical=None):
+        self.f = objectives
+        self.cfg = cfg or pkg.RbfConfig(kernel="cubic")
+        self.ps_cfg = ps_cfg or ps.PascolettiSerafiniConfig()
+        self.bt_cfg = descent.SteepestDescentConfig()
+        x0 = np.asarray(x0, dtype=np.float64)
+        self.d = x0.size
+        self.lb = np.full(self.d, -np.inf) if lb is None else np.asarray(lb, dtype=np.float64)
+        self.ub = np.full(self.d, np.inf) if ub is None else np.asarray(ub, dtype=np.float64)
+        self.sites = [x0.copy()] if sites is None else [np.array(s, dtype=np.float64) for s in sites]
+        self.values = [self.f(x0[None, :])[0]] if values is None else [np.array(v, dtype=np.float64) for v in values]
+        self.xi = 0                                  # database index of the iterate
+        self.delta, self.delta_max, self.delta0 = float(delta0), float(delta_max), float(delta0)
+        self.on_critical, self.starts = on_critical, 0   # many-start pattern: a critical iterate hands over to the next start point
+        self.seed = seed
+        self.keeper = sp.Round4Keeper()
+        self.ctx = _lib.default_context()            # ONE context for every call, like the binding's per-thread context
+        self.log = []                                # one record per iteration
+
+    def _box(self, x, radius):
+        return np.maximum(x - radius, self.lb), np.minimum(x + radius, self.ub)
+
+    def iterate(self, it):
+        cfg, d = self.cfg, self.d
+        S = np.array(self.sites)
+        x, fx = S[self.xi], self.values[self.xi]
+        rec = dict(it=it, n_db=len(self.sites), delta=self.delta, ms={})
+        clock = lambda: time.perf_counter()
+        # ---- rounds 1-2: box candidates -> affine filter (RbfModel.jl:558-600)
+        d1, d2 = cfg.θ_enlarge_1 * self.delta, cfg.θ_enlarge_2 * self.delta_max
+        lb1, ub1 = self._box(x, d1)
+        lb2, ub2 = self._box(x, d2)
+        piv = cfg.θ_pivot * d1
+        t0 = clock()
+        r1, dirs, cand1, Y1, Z1 = sp._find_suitable_points(S, lb1, ub1, x, self.xi, piv)
+        r2 = []
+        if len(r1) < d:
+            r2, _, _, _, _ = sp._find_suitable_points(S, lb2, ub2, x, self.xi, piv, already_inspected_indices=cand1, Y=Y1, Z=Z1,
+                                                      n_missing=d - len(r1), collect_improving_directions=False)
+        rec["ms"]["affine_filter"] = (clock() - t0) * 1e3
+        rec["affine_on_device"] = bool(_lib.load().mrbf_dispatch_affine(max(len(cand1) - 1, 0), d) == _lib.DISPATCH_DEVICE)
+        # ---- round 3: new sites along the improving directions (RbfModel.jl:269-307).  A direction along which the box leaves no
+        # room (the iterate sits on a bound: ZDT1's Pareto set does) fails the threshold test: the model is then rebuilt along the
+        # coordinate axes (:286-289 -> :617-622, force_rebuild), rounds 1-2 discarded
+        offsets = [_absmax_step(x, direction, lb1, ub1) * direction for direction in dirs[: d - len(r1) - len(r2)]]
+        if any(np.abs(o).max() <= piv for o in offsets):
+            r1, r2 = [], []
+            offsets = [_absmax_step(x, e, lb1, ub1) * e for e in np.eye(d)]
+            rec["rebuilt"] = True
+        r3 = []
+        for o in offsets:
+            self.sites.append(x + o)
+            self.values.append(self.f((x + o)[None, :])[0])
+            r3.append(len(self.sites) - 1)
+        S = np.array(self.sites)
+        found = [self.xi, *r1, *r2, *r3]
+        # ---- round 4 (RbfModel.jl:352-499) with the factor kept for the fit
+        st = {}
+        t0 = clock()
+        r4 = sp._rbf_round4(S, lb2, ub2, x, self.delta, found, cfg, keeper=self.keeper, db_key="db", stats=st)
+        rec["ms"]["round4"] = (clock() - t0) * 1e3
+        training = found + list(r4)
+        # ---- update_model (RbfModel.jl:743-767)
+        t0 = clock()
+        mod = sp.update_model_from_selection(cfg, S, np.array(self.values), training, self.delta, fully_linear=True, keeper=self.keeper,
+                                             db_key="db", stats=st)
+        rec["ms"]["update_model"] = (clock() - t0) * 1e3
+        rec.update(n=len(training), training_indices=list(training), round4=st.get("round4", "-"), fit=st.get("fit"), path=mod.info["path"], residual=mod.info["rel_residual"])
+        sc = sg.SurrogateContainer(objectives=[sg.RefSurrogate(mod, list(range(mod.num_outputs)))])
+        # ---- criticality: Pascoletti-Serafini step in the trust region (descent.jl:512-581)
+        lbe, ube = self._box(x, self.delta)
+        pst = {}
+        t0 = clock()
+        out = ps.get_criticality_container(self.ps_cfg, sc, None, x, x, fx, lbe, ube, seed=self.seed + it, stats=pst)
+        rec["ms"]["ps_step"] = (clock() - t0) * 1e3
+        omega = float(out[0])
+        rec.update(omega=omega, ps_evals=pst.get("evals_ideal", 0) + pst.get("evals_ps", 0) + pst.get("evals_polish", 0))
+        if omega <= 0.0:
+            # critical for the model.  Morbit stops here (algorithm.jl:734-739); the rehearsal goes on like the many-start driver
+            # (examples/large_scale_benchmarks.jl:102-109): the next start point and its sites join the database -- or, without
+            # further starts, the radius shrinks
+            if self.on_critical is not None:
+                self.starts += 1
+                new_sites, new_values = self.on_critical(self.starts)
+                self.xi = len(self.sites)
+                self.sites.extend(np.array(v, dtype=np.float64) for v in new_sites)
+                self.values.extend(np.array(v, dtype=np.float64) for v in new_values)
+                self.delta = self.delta0
+            else:
+                self.delta *= 0.51
+            rec.update(rho=float("nan"), accepted=False, critical=True)
+            mod.free()
+            rec["arena_bytes"] = self.ctx.get_option(_lib.OPT_ARENA_BYTES)
+            rec["live_handles"] = int(self.ctx.get_option(_lib.OPT_LIVE_HANDLES))
+            self.log.append(rec)
+            return rec
+        x_trial = out[1][0]
+        # ---- backtracking towards the trial point (descent.jl:150-185: all step sizes in one device batch)
+        t0 = clock()
+        xp, mxp, step, loops = descent._backtrack(x, x_trial - x, 1.0, omega, sc, self.bt_cfg)
+        rec["ms"]["backtrack"] = (clock() - t0) * 1e3
+        mx = pkg.eval_models(mod, None, x)
+        # ---- objectives at the trial point, acceptance test and radius update (algorithm.jl:806-870, strict test)
+        f_trial = self.f(xp[None, :])[0]
+        self.sites.append(xp.copy())
+        self.values.append(f_trial)
+        denom = mx - mxp
+        rho = float(np.min((fx - f_trial) / denom)) if np.all(denom != 0) else -np.inf
+        if rho >= 0.2:                                # nu_success
+            self.xi = len(self.sites) - 1
+            self.delta = min(self.delta_max, 2.0 * self.delta)
+        elif rho >= 0.0:                              # nu_accept, models fully linear
+            self.xi = len(self.sites) - 1
+            self.delta *= 0.75
+        else:
+            self.delta *= 0.51
+        rec.update(rho=rho, accepted=rho >= 0.0, backtrack_loops=int(loops), interpolation=float(np.abs(mx - fx).max()))
+        mod.free()                                    # models are replaced wholesale each update (SurrogateContainer.jl:376-388)
+        rec["arena_bytes"] = self.ctx.get_option(_lib.OPT_ARENA_BYTES)
+        rec["live_handles"] = int(self.ctx.get_option(_lib.OPT_LIVE_HANDLES))
+        self.log.append(rec)
+        return rec
+
+    def run(self, iterations):
+        for it in range(iterations):
+            self.iterate(it)
+        self.keeper.drop("db")                        # the last round-4 factor nobody consumed
+        return np.array(self.sites[self.xi]), self.values[self.xi]

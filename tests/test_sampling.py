@@ -367,3 +367,26 @@ def test_affinely_independent_filter_on_device(d, n, piv):
     Sm[2] = Sm[5] = 3.0
     ctx.check(ctx.lib.mrbf_affine_scores(ctx.h, 8, d, d, _lib.as_ptr(Sm), _lib.as_ptr(np.asfortranarray(np.eye(d))), 1, None, ctypes.byref(best), ctypes.byref(val)))
     assert best.value == 2 and val.value == 3.0
+
+
+@pytest.mark.parametrize("d", [3, 17, 64, 128])
+def test_growing_qr_equals_refactoring_from_scratch(d):
+    """The filter keeps the Householder factorisation of its Y up to date by one reflector per pick (`sampling._GrowingQR`, twin of
+    `HipRbfGrowingQR` in HipRbf.jl) where the reference re-factors Y after every pick (AffinelyIndependentPoints.jl:4-11, :59-60,
+    :93-94).  Same reflectors: the normalised complement Z agrees with `_orthogonal_complement_matrix(Y)` to rounding after every
+    appended column -- entry by entry, signs included -- also when the factorisation starts from a given Y (round 2)."""
+    rng = np.random.default_rng(d)
+    Ys = rng.standard_normal((d, d))
+    qr = sampling._GrowingQR(d)
+    for j in range(d):
+        qr.append(Ys[:, j])
+        Zi, Zf = qr.complement(), sampling._orthogonal_complement_matrix(Ys[:, : j + 1])
+        assert Zi.shape == Zf.shape == (d, d - j - 1)
+        if Zi.size:
+            assert np.abs(Zi - Zf).max() < 1e-12, (d, j)
+    j0 = max(1, d // 3)
+    qr = sampling._GrowingQR(d, Ys[:, :j0])
+    qr.append(Ys[:, j0])
+    Zf = sampling._orthogonal_complement_matrix(Ys[:, : j0 + 1])
+    if Zf.size:
+        assert np.abs(qr.complement() - Zf).max() < 1e-12
