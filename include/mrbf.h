@@ -187,6 +187,16 @@ int32_t mrbf_backtrack(mrbf_ctx *ctx, const mrbf_model *model, const double *x, 
  * filter's default in _find_suitable_points, RbfModel.jl:226), 0 = 2-norm.  vals_out (mc) may be NULL. */
 int32_t mrbf_affine_scores(mrbf_ctx *ctx, int64_t mc, int32_t d, int32_t dz, const double *shifted, const double *Z, int32_t p_is_inf,
                            double *vals_out, int64_t *argmax, double *maxval);
+/* The whole pick loop of the filter in one call (round 6): from the directions chosen so far -- Q0, d x d column-major, an orthogonal
+ * matrix whose first j0 columns span them (the Q of qr(Y), full; NULL with j0 = 0) -- pick up to max_picks further candidates, each
+ * time the first maximiser of || Z (Z' (xi - x0)) ||_p while that exceeds pivot_val (AffinelyIndependentPoints.jl:71-106), with the
+ * Householder factorisation of Y = [chosen directions] grown by one reflector per pick on the device instead of qr(Y) from scratch
+ * after every pick (:59-60, :93-94): O(d^2 + d mc) per pick, no host round trip between picks.  shifted: mc x d row-major rows
+ * xi - x0 (host or device; sites chosen already: zero rows).  picked_out[max_picks]: positions of the picked candidates in pick order;
+ * Z_out (d x (d - j0 - *n_picked), column-major, host or device, may be NULL): the p-normalised complement basis afterwards -- the
+ * filter's final Z (its improving directions, RbfModel.jl:231-235). */
+int32_t mrbf_affine_select(mrbf_ctx *ctx, int64_t mc, int32_t d, const double *shifted, int32_t j0, const double *Q0, int32_t max_picks,
+                           double pivot_val, int32_t p_is_inf, int64_t *picked_out, int32_t *n_picked, double *Z_out);
 
 /* ---- round 4 of the training-site selection on the device, with factor reuse -------------------------------------------
  * mrbf_round4 replaces _rbf_round4 (src/models/RbfModel.jl:352-499): start_sites (n0 x d, the sites found so far -- centre and

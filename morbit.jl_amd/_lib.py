@@ -106,6 +106,8 @@ SIGNATURES = {
                                         c_vp, c_ip]),
     "mrbf_affine_scores": (ctypes.c_int32, [c_vp, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, c_vp, c_vp, ctypes.c_int32, c_vp,
                                             ctypes.POINTER(ctypes.c_int64), c_dp]),
+    "mrbf_affine_select": (ctypes.c_int32, [c_vp, ctypes.c_int64, ctypes.c_int32, c_vp, ctypes.c_int32, c_vp, ctypes.c_int32, ctypes.c_double,
+                                            ctypes.c_int32, ctypes.POINTER(ctypes.c_int64), c_ip, c_vp]),
     "mrbf_round4": (ctypes.c_int32, [c_vp, ctypes.c_int64, ctypes.c_int32, c_vp, ctypes.c_int64, c_vp, ctypes.c_int32, ctypes.c_double,
                                      ctypes.c_double, ctypes.c_int32, ctypes.c_int32, ctypes.c_double, c_vp, c_ip, ctypes.POINTER(c_vp)]),
     "mrbf_fit_from_round4": (ctypes.c_int32, [c_vp, c_vp, ctypes.c_int32, c_vp, ctypes.POINTER(c_vp), c_vp, c_vp, ctypes.POINTER(FitInfo)]),

@@ -59,6 +59,142 @@ __global__ __launch_bounds__(1024) void argmax_first_kernel(const double *__rest
     }
 }
 
+
+// ---- the WHOLE pick loop on the device (round 6) ---------------------------------------------------------------------------------
+// After a pick the reference re-factors Y = [picked directions] from scratch (qr(Y), AffinelyIndependentPoints.jl:4-11, :93-94) and
+// scans the candidates again.  Here the Householder factorisation grows by ONE reflector per pick and everything stays on the device:
+//   Q   d x d  the full orthogonal factor (columns j.. = the unnormalised complement basis);  C = Q' S  the candidates in that basis
+//   pick i  ->  x = C[j:, i]  gives the reflector (larfg: beta = -sign(x_0) |x|, v_0 = 1);  Q[:, j:] <- Q[:, j:] H,  C[j:, :] <- H C[j:, :]
+//   scores  ->  U = Zs C[j:, :] with Zs = Q[:, j:] D^2 (D = 1 / column p-norms: the reference's normalised Z enters as Z Z'), val = |U|_p by column
+// No host round trip between picks (the host only looks at the "done" word every sixteen picks); same reflectors as LAPACK's geqrf, so
+// the picks are the reference's (ties aside, which need scores equal to the last bit).
+struct AffSel {
+    double *Q, *C, *Zs, *U, *val, *hv;  // hv: [0] tau, [1 .. d] v (over the trailing rows), [1 + d .. 2 d] w = Q[:, j:] v
+    long long *picks;
+    int *state;                         // [0] done, [1] picks so far
+    int d, use_inf;
+    int64_t mc;
+    double pivot;
+};
+
+// one workgroup: first maximiser of val, pivot test, the pick's reflector and w; the picked candidate becomes the zero vector
+__global__ __launch_bounds__(1024) void affsel_decide_kernel(AffSel a, int j) {
+    __shared__ double sv[1024];
+    __shared__ long long si[1024];
+    __shared__ double s_red[1024];
+    const int tid = threadIdx.x, d = a.d, dz = d - j;
+    if (a.state[0]) return;
+    double bv = -INFINITY;
+    long long bi = -1;
+    for (int64_t c = tid; c < a.mc; c += 1024) {
+        const double v = a.val[c];
+        if (v > bv) {
+            bv = v;
+            bi = c;
+        }
+    }
+    sv[tid] = bv;
+    si[tid] = bi;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if (tid < w) {
+            const double ov = sv[tid + w];
+            const long long oi = si[tid + w];
+            if (oi >= 0 && (si[tid] < 0 || ov > sv[tid] || (ov == sv[tid] && oi < si[tid]))) {
+                sv[tid] = ov;
+                si[tid] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    const long long best = si[0];
+    const double bestv = sv[0];
+    __syncthreads();
+    if (best < 0 || !(bestv > a.pivot)) {  // "No point was sufficiently linearly independent" (AffinelyIndependentPoints.jl:104)
+        if (tid == 0) a.state[0] = 1;
+        return;
+    }
+    double *x = a.C + (size_t)best * d + j;  // the new direction in the current basis, trailing part (dz entries)
+    double part = 0.0;
+    for (int c = 1 + tid; c < dz; c += 1024) part = fma(x[c], x[c], part);
+    s_red[tid] = part;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if (tid < w) s_red[tid] += s_red[tid + w];
+        __syncthreads();
+    }
+    const double alpha = x[0], xn = sqrt(s_red[0]);
+    double tau = 0.0, scale = 0.0;
+    if (xn != 0.0) {
+        const double beta = -copysign(hypot(alpha, xn), alpha);
+        tau = (beta - alpha) / beta;
+        scale = 1.0 / (alpha - beta);
+    }
+    __syncthreads();
+    double *v = a.hv + 1, *w = a.hv + 1 + d;
+    for (int c = tid; c < dz; c += 1024) v[c] = c == 0 ? 1.0 : x[c] * scale;
+    if (tid == 0) {
+        a.hv[0] = tau;
+        a.picks[a.state[1]] = best;
+        a.state[1] += 1;
+    }
+    __syncthreads();
+    // w = Q[:, j:] v (d x dz), row r by thread r (column-major Q: consecutive threads read consecutive rows)
+    for (int r = tid; r < d; r += 1024) {
+        double acc = 0.0;
+        for (int c = 0; c < dz; ++c) acc = fma(a.Q[(size_t)(j + c) * d + r], v[c], acc);
+        w[r] = acc;
+    }
+    __syncthreads();
+    for (int r = tid; r < d; r += 1024) a.C[(size_t)best * d + r] = 0.0;  // chosen sites score 0 from now on (the reference drops them from the list)
+}
+
+// blocks 0 .. d - jq - 1: column jq + b of Q gets the reflector (apply != 0) and, for columns >= jz, its p-normalised-twice copy goes to Zs;
+// the blocks behind them: four candidate columns of C each (C[jq:, col] <- H C[jq:, col])
+__global__ __launch_bounds__(256) void affsel_update_kernel(AffSel a, int jq, int jz, int apply) {
+    __shared__ double red[256];
+    const int tid = threadIdx.x, d = a.d, ncol = d - jq;
+    if (a.state[0]) return;
+    const double tau = apply ? a.hv[0] : 0.0;
+    const double *v = a.hv + 1, *w = a.hv + 1 + d;
+    if ((int)blockIdx.x < ncol) {
+        const int c = blockIdx.x;
+        double *q = a.Q + (size_t)(jq + c) * d;
+        const double tv = apply ? tau * v[c] : 0.0;
+        double m = 0.0;
+        for (int r = tid; r < d; r += 256) {
+            double e = q[r];
+            if (apply) {
+                e = fma(-tv, w[r], e);
+                q[r] = e;
+            }
+            m = a.use_inf ? fmax(m, fabs(e)) : fma(e, e, m);
+        }
+        if (jq + c < jz) return;
+        red[tid] = m;
+        __syncthreads();
+        for (int s2 = 128; s2 > 0; s2 >>= 1) {
+            if (tid < s2) red[tid] = a.use_inf ? fmax(red[tid], red[tid + s2]) : red[tid] + red[tid + s2];
+            __syncthreads();
+        }
+        const double nrm = a.use_inf ? red[0] : sqrt(red[0]);
+        const double s2n = 1.0 / (nrm * nrm);  // Z Z' = Q2 D^2 Q2'
+        double *z = a.Zs + (size_t)(jq + c - jz) * d;
+        for (int r = tid; r < d; r += 256) z[r] = q[r] * s2n;
+        return;
+    }
+    if (!apply) return;
+    const int64_t col = ((int64_t)blockIdx.x - ncol) * 4 + (tid >> 6);
+    const int lane = tid & 63;
+    if (col >= a.mc) return;
+    double *x = a.C + (size_t)col * d + jq;
+    double dot = 0.0;
+    for (int c = lane; c < ncol; c += 64) dot = fma(v[c], x[c], dot);
+    for (int off = 32; off > 0; off >>= 1) dot += __shfl_xor(dot, off);
+    const double td = tau * dot;
+    for (int c = lane; c < ncol; c += 64) x[c] = fma(-td, v[c], x[c]);
+}
+
 }  // namespace mrbf
 
 using namespace mrbf;
@@ -100,5 +236,94 @@ extern "C" int32_t mrbf_affine_scores(mrbf_ctx *ctx, int64_t mc, int32_t d, int3
     MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (argmax) *argmax = (int64_t)h[0];
     if (maxval) *maxval = h[1];
+    return MRBF_OK;
+}
+
+
+extern "C" int32_t mrbf_affine_select(mrbf_ctx *ctx, int64_t mc, int32_t d, const double *shifted, int32_t j0, const double *Q0, int32_t max_picks,
+                                      double pivot_val, int32_t p_is_inf, int64_t *picked_out, int32_t *n_picked, double *Z_out) {
+    if (!ctx) return -1;
+    if (mc < 0 || mc > ((int64_t)1 << 26)) return fail(ctx, -2, "mc out of range");
+    if (d < 1 || d > 4096) return fail(ctx, -3, "d out of range");
+    if (j0 < 0 || j0 > d) return fail(ctx, -5, "j0 must lie in [0, d]");
+    if (j0 > 0 && !Q0) return fail(ctx, -6, "Q0 is NULL");
+    if (max_picks < 0) return fail(ctx, -7, "max_picks < 0");
+    if (!n_picked) return fail(ctx, -11, "n_picked is NULL");
+    *n_picked = 0;
+    max_picks = std::min(max_picks, d - j0);
+    if (mc > 0 && !shifted) return fail(ctx, -4, "shifted is NULL");
+    if (max_picks > 0 && !picked_out) return fail(ctx, -10, "picked_out is NULL");
+    (void)hipSetDevice(ctx->device);
+    hipStream_t s = ctx->stream;
+    AffSel a{};
+    a.d = d;
+    a.mc = mc;
+    a.use_inf = p_is_inf ? 1 : 0;
+    a.pivot = pivot_val;
+    MRBF_TRY(get_buf(ctx, S_PHI, (size_t)d * d, &a.Q));
+    MRBF_TRY(get_buf(ctx, S_STAGE_B, (size_t)d * std::max<int64_t>(mc, 1), &a.C));
+    MRBF_TRY(get_buf(ctx, S_G, (size_t)d * d, &a.Zs));
+    MRBF_TRY(get_buf(ctx, S_STAGE_D, (size_t)d * std::max<int64_t>(mc, 1), &a.U));
+    MRBF_TRY(get_buf(ctx, S_EVAL_SA, (size_t)std::max<int64_t>(mc, 1), &a.val));
+    MRBF_TRY(get_buf(ctx, S_RHS, (size_t)2 * d + 8, &a.hv));
+    MRBF_TRY(get_buf(ctx, S_IPIV, (size_t)std::max(max_picks, 1) + 2, &a.picks));
+    MRBF_TRY(get_buf(ctx, S_INFO, (size_t)4, &a.state));
+    MRBF_HIP(ctx, hipMemsetAsync(a.state, 0, 4 * sizeof(int), s));
+    const double one = 1.0, zero = 0.0;
+    std::vector<double> hq;
+    if (j0 > 0) {
+        const double *Qd;
+        MRBF_TRY(stage_in(ctx, S_STAGE_C, Q0, (size_t)d * d, &Qd));
+        MRBF_HIP(ctx, hipMemcpyAsync(a.Q, Qd, (size_t)d * d * sizeof(double), hipMemcpyDeviceToDevice, s));
+    } else {
+        hq.assign((size_t)d * d, 0.0);
+        for (int i = 0; i < d; ++i) hq[(size_t)i * d + i] = 1.0;
+        MRBF_HIP(ctx, hipMemcpyAsync(a.Q, hq.data(), hq.size() * sizeof(double), hipMemcpyHostToDevice, s));
+    }
+    int npick = 0;
+    if (mc > 0 && max_picks > 0) {
+        const double *S;
+        MRBF_TRY(stage_in(ctx, S_STAGE_A, shifted, (size_t)mc * d, &S));
+        // C = Q' S' (the candidates, mc x d row-major, are S' d x mc column-major)
+        MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, d, (int)mc, d, &one, a.Q, d, S, d, &zero, a.C, d));
+        hipLaunchKernelGGL(affsel_update_kernel, dim3((unsigned)(d - j0)), dim3(256), 0, s, a, j0, j0, 0);  // Zs of the start basis
+        int hstate[2] = {0, 0};
+        for (int t = 0; t < max_picks; ++t) {
+            const int j = j0 + t, dz = d - j;
+            MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, d, (int)mc, dz, &one, a.Zs, d, a.C + j, d, &zero, a.U, d));
+            hipLaunchKernelGGL(col_norms_kernel, dim3((unsigned)((mc + 3) / 4)), dim3(256), 0, s, a.U, d, mc, a.use_inf, a.val);
+            hipLaunchKernelGGL(affsel_decide_kernel, dim3(1), dim3(1024), 0, s, a, j);
+            hipLaunchKernelGGL(affsel_update_kernel, dim3((unsigned)(dz + (mc + 3) / 4)), dim3(256), 0, s, a, j, j + 1, 1);
+            if ((t & 15) == 15 && t + 1 < max_picks) {  // the filter may stop early: look at the "done" word now and then
+                MRBF_HIP(ctx, hipMemcpyAsync(hstate, a.state, sizeof(hstate), hipMemcpyDeviceToHost, s));
+                MRBF_HIP(ctx, hipStreamSynchronize(s));
+                if (hstate[0]) break;
+            }
+        }
+        MRBF_HIP(ctx, hipGetLastError());
+        MRBF_HIP(ctx, hipMemcpyAsync(hstate, a.state, sizeof(hstate), hipMemcpyDeviceToHost, s));
+        MRBF_HIP(ctx, hipStreamSynchronize(s));
+        npick = hstate[1];
+        if (npick > 0) {
+            std::vector<long long> hp((size_t)npick);
+            MRBF_HIP(ctx, hipMemcpy(hp.data(), a.picks, hp.size() * sizeof(long long), hipMemcpyDeviceToHost));
+            for (int i = 0; i < npick; ++i) picked_out[i] = (int64_t)hp[i];
+        }
+    }
+    *n_picked = npick;
+    if (Z_out) {  // the normalised complement basis of everything chosen so far: Q[:, j0 + npick :] with unit p-norm columns
+        const int jf = j0 + npick, dz = d - jf;
+        if (dz > 0) {
+            hq.resize((size_t)d * dz);
+            MRBF_HIP(ctx, hipMemcpy(hq.data(), a.Q + (size_t)jf * d, hq.size() * sizeof(double), hipMemcpyDeviceToHost));
+            for (int c = 0; c < dz; ++c) {
+                double nrm = 0.0;
+                for (int r = 0; r < d; ++r) nrm = p_is_inf ? std::max(nrm, std::fabs(hq[(size_t)c * d + r])) : nrm + hq[(size_t)c * d + r] * hq[(size_t)c * d + r];
+                if (!p_is_inf) nrm = std::sqrt(nrm);
+                for (int r = 0; r < d; ++r) hq[(size_t)c * d + r] /= nrm;
+            }
+            MRBF_HIP(ctx, hipMemcpy(Z_out, hq.data(), hq.size() * sizeof(double), hipMemcpyDefault));
+        }
+    }
     return MRBF_OK;
 }

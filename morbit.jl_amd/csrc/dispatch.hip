@@ -29,6 +29,10 @@ int32_t mrbf_dispatch_backtrack(int32_t n_objective_models, int32_t n_foreign, i
 
 int32_t mrbf_dispatch_affine(int64_t n_candidates, int32_t d) {
     if (d < 1 || n_candidates < 1) return MRBF_DISPATCH_REFERENCE;
+    // round 6: the device entry point is the whole pick loop (mrbf_affine_select, ~50 us per pick whatever the candidate count); on the host a
+    // pick costs two products of d x (d - j) x candidates.  From d = 64 on the device wins as soon as there are more candidates than
+    // directions (d = 128, 255 candidates: 6.5 against 22 ms per model update, profiles/r06_iteration_c4.txt); below, only for large boxes
+    if (d >= 64 && n_candidates >= d) return MRBF_DISPATCH_DEVICE;
     return n_candidates * (int64_t)d >= AFFINE_MIN_WORK ? MRBF_DISPATCH_DEVICE : MRBF_DISPATCH_REFERENCE;
 }
 

@@ -270,11 +270,17 @@ function _complement(g::HipRbfGrowingQR, p)
     return Z
 end
 
+mutable struct HipRbfPickQueue               # what ONE mrbf_affine_select call picked for a filter, handed out pick by pick
+    picks::Vector{Int}
+    pos::Int
+    Z::Matrix{Float64}                      # the filter's final complement basis
+end
 mutable struct HipRbfAffineScan
     seeds::IdDict{Any,Matrix{Float64}}      # filter => d x mc matrix of shifted seeds, picked columns zeroed (task-local, no global)
-    qrs::IdDict{Any,HipRbfGrowingQR}        # filter => the growing factorisation of its Y
+    qrs::IdDict{Any,HipRbfGrowingQR}        # filter => the growing factorisation of its Y (host scan)
+    queues::IdDict{Any,HipRbfPickQueue}     # filter => the device's picks (device scan)
 end
-HipRbfAffineScan() = HipRbfAffineScan(IdDict{Any,Matrix{Float64}}(), IdDict{Any,HipRbfGrowingQR}())
+HipRbfAffineScan() = HipRbfAffineScan(IdDict{Any,Matrix{Float64}}(), IdDict{Any,HipRbfGrowingQR}(), IdDict{Any,HipRbfPickQueue}())
 _hip_affine_scan() = get(task_local_storage(), _HIP_AFFINE_KEY, nothing)
 _prepare_with_device_scan(meta, cfg::HipRbfConfig, args...; kwargs...) =
     task_local_storage(_HIP_AFFINE_KEY, HipRbfAffineScan()) do
@@ -344,7 +350,7 @@ end
 function Base.iterate(filter::AffinelyIndependentPointFilter{Float64,VF,SV}, num_found::Int) where {VF,SV}
     scan = _hip_affine_scan()
     scan === nothing && return invoke(Base.iterate, Tuple{AffinelyIndependentPointFilter,Int}, filter, num_found)
-    done() = (delete!(scan.seeds, filter); delete!(scan.qrs, filter); nothing)
+    done() = (delete!(scan.seeds, filter); delete!(scan.qrs, filter); delete!(scan.queues, filter); nothing)
     num_found == filter.n && return done()
     isempty(filter.candidate_indices) && return done()
     S = get!(scan.seeds, filter) do
@@ -354,9 +360,24 @@ function Base.iterate(filter::AffinelyIndependentPointFilter{Float64,VF,SV}, num
         end
         M
     end
-    # the scan: on the device for many candidates (decision table), else two host BLAS products -- the same scores either way
-    best_index, best_val = _dispatch_affine(length(filter.candidate_indices), length(filter.x_0)) ?
-                           affine_scores(S, filter.Z, filter.p) : _affine_scores_host(S, filter.Z, filter.p)
+    if haskey(scan.queues, filter) || _dispatch_affine(length(filter.candidate_indices), length(filter.x_0))
+        # many candidates (decision table): the whole remaining selection is ONE device call (mrbf_affine_select: the factorisation of Y
+        # grows by a reflector per pick on the device, no host round trip between picks); its picks are handed out one per call
+        queue = get!(scan.queues, filter) do
+            g = HipRbfGrowingQR(filter.Y)
+            picks, Zf = affine_select(S, g.Q, g.j, filter.n - num_found, Float64(filter.pivot_val), filter.p)
+            HipRbfPickQueue(picks, 0, Zf)
+        end
+        queue.pos >= length(queue.picks) && return done()
+        queue.pos += 1
+        i = queue.picks[queue.pos]
+        filter.Y = hcat(filter.Y, filter.shifted_seeds[i])
+        setdiff!(filter.candidate_indices, i)
+        queue.pos == length(queue.picks) && (filter.Z = queue.Z)
+        return (filter.return_indices ? i : filter.seeds[i]), num_found + 1
+    end
+    # few candidates: two host BLAS products per pick -- the same scores -- and the factorisation grown by a reflector per pick
+    best_index, best_val = _affine_scores_host(S, filter.Z, filter.p)
     if best_index >= 1 && best_val > filter.pivot_val
         i = best_index
         g = get!(() -> HipRbfGrowingQR(filter.Y), scan.qrs, filter)     # (factor of the sites found so far, before this one joins)
@@ -720,6 +741,27 @@ function fit_from_round4(state::HipRound4State, values, n_vars::Int, fully_linea
     end
     model = HipRbfModel(state.ctx, h[], n_vars, k, fully_linear, info[])
     return rc_only ? (rc, model) : model
+end
+"""
+The filter's whole pick loop in one device call (`mrbf_affine_select`): `S` d x mc shifted seeds (picked columns zero), `Q0` the full
+orthogonal factor of the directions chosen so far (first `j0` columns), up to `want` further picks above `pivot_val`.  Returns the
+1-based positions in pick order and the final p-normalised complement basis.
+"""
+function affine_select(S::Matrix{Float64}, Q0::Matrix{Float64}, j0::Int, want::Int, pivot_val::Float64, p)
+    d, mc = size(S)
+    ctx = mrbf_context()
+    picks = Vector{Int64}(undef, max(want, 1)); npick = Ref{Int32}(0)
+    Zbuf = Matrix{Float64}(undef, d, max(d - j0, 1))
+    rc = GC.@preserve S Q0 picks Zbuf begin
+        _locked(ctx) do hctx
+            ccall((:mrbf_affine_select, libmrbf), Int32,
+                  (Ptr{Cvoid}, Int64, Int32, Ptr{Float64}, Int32, Ptr{Float64}, Int32, Float64, Int32, Ptr{Int64}, Ref{Int32}, Ptr{Float64}),
+                  hctx, mc, d, S, j0, Q0, want, pivot_val, isinf(p) ? 1 : 0, picks, npick, Zbuf)
+        end
+    end
+    _check(ctx, rc)
+    np = Int(npick[])
+    return Int.(picks[1:np]) .+ 1, Zbuf[:, 1:(d - j0 - np)]
 end
 "Scores `‖Z (Zᵀ(ξ - x₀))‖_p` of all filter candidates and the first maximiser (AffinelyIndependentPoints.jl:71-106)."
 affine_scores(shifted_seeds::AbstractVector, Z::AbstractMatrix, p = Inf) = affine_scores(_dense(_as_matrix(shifted_seeds)), Z, p)

@@ -88,6 +88,20 @@ class AffinelyIndependentPointFilter:
                                              1 if np.isinf(self.p) else 0, None, ctypes.byref(best), ctypes.byref(val)))
         return int(best.value), float(val.value)
 
+    def _select_device(self, Sd, qr, want):
+        """up to `want` further picks from the rows of Sd (picked rows zeroed) after the directions in `qr`: (positions, final Z)"""
+        ctx = self.ctx or _lib.default_context()
+        d = self.x_0.size
+        picks = np.empty(max(want, 1), dtype=np.int64)
+        npick = ctypes.c_int32(0)
+        Zbuf = np.empty((max(d - qr.j, 1), d))                          # (column-major d x dz)
+        Q0 = np.asfortranarray(qr.Q)
+        ctx.check(ctx.lib.mrbf_affine_select(ctx.h, Sd.shape[0], d, _lib.as_ptr(Sd), qr.j, _lib.as_ptr(Q0), want, float(self.pivot_val),
+                                             1 if np.isinf(self.p) else 0, picks.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)),
+                                             ctypes.byref(npick), _lib.as_ptr(Zbuf)))
+        got = [int(v) for v in picks[: npick.value]]
+        return got, Zbuf[: d - qr.j - len(got)].T.copy()
+
     def _take(self, qr, i):
         self.Y = np.hstack([self.Y, self.shifted[i][:, None]])
         qr.append(self.shifted[i])
@@ -106,18 +120,18 @@ class AffinelyIndependentPointFilter:
         on_device = self.ctx is not None or \
             _lib.load().mrbf_dispatch_affine(len(cand), self.x_0.size) == _lib.DISPATCH_DEVICE
         if on_device:
+            # the whole pick loop in ONE device call (mrbf_affine_select): the factorisation grows by a reflector per pick on the
+            # device, no host round trip between picks (until round 6: one mrbf_affine_scores call + a host QR update per pick)
             Sd = np.ascontiguousarray(S, dtype=np.float64)
             Sd[i] = 0.0   # chosen sites score 0 (the reference removes them from the candidate list)
+            want = min(self.n - len(out), self.x_0.size - qr.j)
+            got, Z = self._select_device(Sd, qr, want)
+            if got:
+                self.Y = np.hstack([self.Y, S[got].T])
+                self.Z = Z
+                out.extend(got)
+            return out
         while len(out) < self.n and cand:
-            if on_device:
-                best, vb = self._scores_device(Sd)
-                if best < 0 or not vb > self.pivot_val:
-                    break
-                self._take(qr, best)
-                cand.remove(best)
-                Sd[best] = 0.0
-                out.append(best)
-                continue
             if self.Z.shape[1]:
                 P = (S[cand] @ self.Z) @ self.Z.T                     # all candidates at once: rows Z Z'(xi - x0)
                 vals = np.linalg.norm(P, ord=self.p, axis=1)

@@ -38,6 +38,7 @@ def test_decision_table(lib):
     assert lib.mrbf_dispatch_backtrack(0, 1, 0) == R                     # only an ExactModel: Morbit's own loop
     # affine scan
     assert lib.mrbf_dispatch_affine(10, 5) == R and lib.mrbf_dispatch_affine(20000, 24) == D and lib.mrbf_dispatch_affine(0, 5) == R
+    assert lib.mrbf_dispatch_affine(255, 128) == D and lib.mrbf_dispatch_affine(100, 128) == R and lib.mrbf_dispatch_affine(500, 48) == R
     # round 4: the start set must be able to carry the tail
     assert lib.mrbf_dispatch_round4(4, 3, 1, 50) == D and lib.mrbf_dispatch_round4(3, 3, 1, 50) == R
     assert lib.mrbf_dispatch_round4(1, 3, -1, 50) == D and lib.mrbf_dispatch_round4(1, 3, 0, 50) == D and lib.mrbf_dispatch_round4(4, 3, 1, 0) == R
@@ -265,18 +266,30 @@ def test_affine_filter_routing(monkeypatch):
     x = rng.random(d)
     calls = []
 
-    def fake_scores(self, S):
-        calls.append(S.shape)
-        P = (S @ self.Z) @ self.Z.T
-        v = np.abs(P).max(axis=1)
-        return int(np.argmax(v)), float(v.max())
+    def fake_select(self, Sd, qr, want):       # what mrbf_affine_select does, on the host: scan + one reflector per pick
+        calls.append(Sd.shape)
+        got = []
+        Z = qr.complement(self.p)
+        while len(got) < want:
+            v = np.abs((Sd @ Z) @ Z.T).max(axis=1)
+            b = int(np.argmax(v))
+            if not v[b] > self.pivot_val:
+                break
+            qr.append(Sd[b].copy())
+            Sd[b] = 0.0
+            Z = qr.complement(self.p)
+            got.append(b)
+        return got, Z
 
-    monkeypatch.setattr(sampling.AffinelyIndependentPointFilter, "_scores_device", fake_scores)
+    monkeypatch.setattr(sampling.AffinelyIndependentPointFilter, "_select_device", fake_select)
     small = [x + 0.1 * rng.standard_normal(d) for _ in range(50)]
     assert len(sampling.AffinelyIndependentPointFilter(x, small, pivot_val=1e-3).collect()) == d and not calls     # host BLAS
     big = [x + 0.1 * rng.standard_normal(d) for _ in range(9000)]
-    got = sampling.AffinelyIndependentPointFilter(x, big, pivot_val=1e-3).collect()
-    assert len(got) == d and len(calls) == d - 1 and calls[0] == (9000, d)                                           # device scan
+    flt = sampling.AffinelyIndependentPointFilter(x, big, pivot_val=1e-3)
+    got = flt.collect()
+    assert len(got) == d and calls == [(9000, d)] and flt.Y.shape == (d, d) and flt.Z.shape == (d, 0)              # ONE device call
+    ref = sampling.AffinelyIndependentPointFilter(x, big[:50], pivot_val=1e-3)                                     # host path, same rule
+    assert ref.collect() == sampling.AffinelyIndependentPointFilter(x, big[:50], pivot_val=1e-3, ctx=object()).collect()
 
 
 def test_mega_job_tables_are_consistent():

@@ -390,3 +390,51 @@ def test_growing_qr_equals_refactoring_from_scratch(d):
     Zf = sampling._orthogonal_complement_matrix(Ys[:, : j0 + 1])
     if Zf.size:
         assert np.abs(qr.complement() - Zf).max() < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,n,piv,p", [(128, 300, 0.05, np.inf), (64, 2000, 0.02, np.inf), (33, 500, 0.2, 2), (128, 90, 0.05, np.inf), (7, 5000, 0.45, np.inf)])
+def test_affine_select_on_device_is_the_filter(d, n, piv, p):
+    """mrbf_affine_select (round 6): the filter's whole pick loop in one device call, the Householder factorisation of the chosen
+    directions grown by a reflector per pick on the device.  Against the host filter (same rule, host scan + `_GrowingQR`) and the
+    independent oracle: same picks in the same order, the same final Y, the final Z to rounding -- from scratch (round 1), continuing
+    from a given Y / Z with fewer picks wanted (round 2, RbfModel.jl:252-266), with the 2-norm, with fewer candidates than directions,
+    and when the pivot test stops the loop early."""
+    x, sites = _db(90 + d, d, n)
+    seeds = sites[1:]
+    host = sampling.AffinelyIndependentPointFilter(x, seeds, n=d, pivot_val=piv, p=p)
+    monkey = host.collect.__func__            # force the host path whatever the decision table says
+    import morbit.jl_amd._lib as L
+    real = L.load().mrbf_dispatch_affine
+    try:
+        L.load().mrbf_dispatch_affine = lambda *a: L.DISPATCH_REFERENCE
+        want = monkey(host)
+    finally:
+        L.load().mrbf_dispatch_affine = real
+    dev = sampling.AffinelyIndependentPointFilter(x, seeds, n=d, pivot_val=piv, p=p, ctx=pkg.default_context())
+    got = dev.collect()
+    assert got == want, (len(got), len(want))
+    np.testing.assert_allclose(dev.Y, host.Y, atol=0)
+    assert dev.Z.shape == host.Z.shape
+    if dev.Z.size:
+        # the complement basis is unique up to rounding: same reflectors on host and device
+        assert np.abs(dev.Z - host.Z).max() < 1e-10, np.abs(dev.Z - host.Z).max()
+        assert np.abs(dev.Z.T @ dev.Y).max() < 1e-12 * max(1.0, np.abs(dev.Y).max())          # orthogonal to everything chosen
+    if np.isinf(p):
+        idx, Yw, _ = so.affinely_independent_indices(x, seeds, d, piv)
+        assert got == idx
+    # round 2: continue from the first half of the picks with a new, larger candidate set
+    if len(got) >= 4:
+        half = len(got) // 2
+        Y0 = host.Y[:, :half]
+        Z0 = sampling._orthogonal_complement_matrix(Y0, p)
+        more = list(seeds) + [x + 0.9 * (s - x) for s in seeds[: n // 2]]
+        h2 = sampling.AffinelyIndependentPointFilter(x, more, n=3, Y=Y0, Z=Z0, pivot_val=piv, p=p)
+        try:
+            L.load().mrbf_dispatch_affine = lambda *a: L.DISPATCH_REFERENCE
+            w2 = monkey(h2)
+        finally:
+            L.load().mrbf_dispatch_affine = real
+        d2 = sampling.AffinelyIndependentPointFilter(x, more, n=3, Y=Y0, Z=Z0, pivot_val=piv, p=p, ctx=pkg.default_context())
+        assert d2.collect() == w2 and len(w2) <= 3
+        np.testing.assert_allclose(d2.Y, h2.Y, atol=0)
