@@ -77,6 +77,74 @@ struct AffSel {
     double pivot;
 };
 
+// val[c] = | Zs C[j:, c] |_p for eight candidates per workgroup (no rocBLAS inside the pick loop: its lazily loaded kernels cost 50-90 ms the
+// first time a new shape class turns up -- three such hiccups in the twenty iterations of the rehearsal).  Thread t owns rows t, t + 256, ...
+// of the eight products; Zs is read column by column (coalesced), the candidates' trailing coordinates sit in LDS.
+constexpr int AFF_G = 8;
+__global__ __launch_bounds__(256) void affsel_score_kernel(AffSel a, int j) {
+    extern __shared__ double sx[];  // [AFF_G][dz]
+    __shared__ double red[256];
+    const int tid = threadIdx.x, d = a.d, dz = d - j;
+    if (a.state[0]) return;
+    const int64_t c0 = (int64_t)blockIdx.x * AFF_G;
+    for (int e = tid; e < AFF_G * dz; e += 256) {
+        const int g = e / dz, k = e % dz;
+        sx[e] = c0 + g < a.mc ? a.C[(size_t)(c0 + g) * d + j + k] : 0.0;
+    }
+    __syncthreads();
+    double nrm[AFF_G];
+#pragma unroll
+    for (int g = 0; g < AFF_G; ++g) nrm[g] = 0.0;
+    for (int r = tid; r < d; r += 256) {
+        double u[AFF_G];
+#pragma unroll
+        for (int g = 0; g < AFF_G; ++g) u[g] = 0.0;
+        for (int k = 0; k < dz; ++k) {
+            const double z = a.Zs[(size_t)k * d + r];
+#pragma unroll
+            for (int g = 0; g < AFF_G; ++g) u[g] = fma(z, sx[g * dz + k], u[g]);
+        }
+#pragma unroll
+        for (int g = 0; g < AFF_G; ++g) nrm[g] = a.use_inf ? fmax(nrm[g], fabs(u[g])) : fma(u[g], u[g], nrm[g]);
+    }
+    for (int g = 0; g < AFF_G; ++g) {
+        __syncthreads();
+        red[tid] = nrm[g];
+        __syncthreads();
+        for (int s2 = 128; s2 > 0; s2 >>= 1) {
+            if (tid < s2) red[tid] = a.use_inf ? fmax(red[tid], red[tid + s2]) : red[tid] + red[tid + s2];
+            __syncthreads();
+        }
+        if (tid == 0 && c0 + g < a.mc) a.val[c0 + g] = a.use_inf ? red[0] : sqrt(red[0]);
+    }
+}
+
+// C[:, c] = Q' s_c for eight candidates per workgroup (once per call): thread i owns row i of the eight products
+__global__ __launch_bounds__(256) void affsel_project_kernel(AffSel a, const double *__restrict__ S) {
+    extern __shared__ double sx[];  // [AFF_G][d]
+    const int tid = threadIdx.x, d = a.d;
+    const int64_t c0 = (int64_t)blockIdx.x * AFF_G;
+    for (int e = tid; e < AFF_G * d; e += 256) {
+        const int g = e / d, k = e % d;
+        sx[e] = c0 + g < a.mc ? S[(size_t)(c0 + g) * d + k] : 0.0;
+    }
+    __syncthreads();
+    for (int i = tid; i < d; i += 256) {
+        double u[AFF_G];
+#pragma unroll
+        for (int g = 0; g < AFF_G; ++g) u[g] = 0.0;
+        const double *q = a.Q + (size_t)i * d;
+        for (int r = 0; r < d; ++r) {
+            const double z = q[r];
+#pragma unroll
+            for (int g = 0; g < AFF_G; ++g) u[g] = fma(z, sx[g * d + r], u[g]);
+        }
+#pragma unroll
+        for (int g = 0; g < AFF_G; ++g)
+            if (c0 + g < a.mc) a.C[(size_t)(c0 + g) * d + i] = u[g];
+    }
+}
+
 // one workgroup: first maximiser of val, pivot test, the pick's reflector and w; the picked candidate becomes the zero vector
 __global__ __launch_bounds__(1024) void affsel_decide_kernel(AffSel a, int j) {
     __shared__ double sv[1024];
@@ -285,13 +353,23 @@ extern "C" int32_t mrbf_affine_select(mrbf_ctx *ctx, int64_t mc, int32_t d, cons
         const double *S;
         MRBF_TRY(stage_in(ctx, S_STAGE_A, shifted, (size_t)mc * d, &S));
         // C = Q' S' (the candidates, mc x d row-major, are S' d x mc column-major)
-        MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, d, (int)mc, d, &one, a.Q, d, S, d, &zero, a.C, d));
+        const unsigned ngrp = (unsigned)((mc + AFF_G - 1) / AFF_G);
+        const size_t shm = (size_t)AFF_G * d * sizeof(double);
+        if (shm > 64 * 1024) {  // (d > 1024: beyond the kernels' LDS budget -- rocBLAS for the products, as before)
+            MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, d, (int)mc, d, &one, a.Q, d, S, d, &zero, a.C, d));
+        } else {
+            hipLaunchKernelGGL(affsel_project_kernel, dim3(ngrp), dim3(256), shm, s, a, S);
+        }
         hipLaunchKernelGGL(affsel_update_kernel, dim3((unsigned)(d - j0)), dim3(256), 0, s, a, j0, j0, 0);  // Zs of the start basis
         int hstate[2] = {0, 0};
         for (int t = 0; t < max_picks; ++t) {
             const int j = j0 + t, dz = d - j;
-            MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, d, (int)mc, dz, &one, a.Zs, d, a.C + j, d, &zero, a.U, d));
-            hipLaunchKernelGGL(col_norms_kernel, dim3((unsigned)((mc + 3) / 4)), dim3(256), 0, s, a.U, d, mc, a.use_inf, a.val);
+            if (shm > 64 * 1024) {
+                MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, d, (int)mc, dz, &one, a.Zs, d, a.C + j, d, &zero, a.U, d));
+                hipLaunchKernelGGL(col_norms_kernel, dim3((unsigned)((mc + 3) / 4)), dim3(256), 0, s, a.U, d, mc, a.use_inf, a.val);
+            } else {
+                hipLaunchKernelGGL(affsel_score_kernel, dim3(ngrp), dim3(256), (size_t)AFF_G * dz * sizeof(double), s, a, j);
+            }
             hipLaunchKernelGGL(affsel_decide_kernel, dim3(1), dim3(1024), 0, s, a, j);
             hipLaunchKernelGGL(affsel_update_kernel, dim3((unsigned)(dz + (mc + 3) / 4)), dim3(256), 0, s, a, j, j + 1, 1);
             if ((t & 15) == 15 && t + 1 < max_picks) {  // the filter may stop early: look at the "done" word now and then

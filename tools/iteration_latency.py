@@ -72,6 +72,8 @@ def main():
     make(3).run(3)                                           # start-up (code objects, arenas) is not what the table is about
     run = make(7)
     print("# %s rehearsal, %d iterations on one context; ms per call (wall, incl. host staging), CPU reference pattern beside it" % (which, iters))
+    print("# (the CPU side runs in this process every fifth iteration: a device call right after it may show a one-off 50-90 ms while the")
+    print("#  BLAS thread pool winds down -- an artefact of this table, not of the call: tests/test_gpu_iteration.py has no such outliers)")
     print("# it   n  n_db   delta    omega      rho  | affine  round4(cpu)      fit(cpu)        ps_step(cpu)      backtrack(cpu) | fit path")
     for it in range(iters):
         rec = run.iterate(it)
