@@ -47,6 +47,9 @@ python3 tools/r4_timeline.py "$OUT/prof_r4_d128/r4_results.db" 300 360 > "$OUT/r
 ./tools/walklab/walklab 129 8 5 >> "$OUT/walklab.txt" 2>&1 || true
 ./tools/walklab/walklab 25 2 5 >> "$OUT/walklab.txt" 2>&1 || true
 python3 tools/ps_bench2.py 64,128,256 > "$OUT/ps_step.txt" 2>&1
+python3 tools/typical_latency.py > "$OUT/typical_latency.txt" 2>&1 || true
+python3 tools/iteration_latency.py C1 20 > "$OUT/iteration_c1.txt" 2>&1 || true
+python3 tools/iteration_latency.py C4 20 > "$OUT/iteration_c4.txt" 2>&1 || true
 python3 tools/ps_bench.py > "$OUT/ps_step_d12.txt" 2>&1 || true
 ls "$OUT"
 # the raw traces are large: keep the databases only

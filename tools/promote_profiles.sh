@@ -23,4 +23,5 @@ python3 tools/profile_summary.py pmc $IN/pmc_w_c5/w_results.db $IN/pmc_f_c5/f_re
 { echo "# per-launch timeline of the last round-4 call under rocprofv3 (tools/r4_timeline.py): start / duration in us, grid, queue (q1 main, the other the side stream)"; echo "## d = 64, 10^4 candidates"; cat $IN/round4_timeline_d64.txt; echo "## d = 128, 6000 candidates"; cat $IN/round4_timeline_d128.txt; } > $P/${TAG}_round4_timeline.txt
 cp $IN/walklab.txt $P/${TAG}_walklab.txt
 { cat $IN/ps_step.txt; cat $IN/ps_step_d12.txt 2>/dev/null || true; } > $P/${TAG}_ps_step_timing.txt
+for f in typical_latency iteration_c1 iteration_c4; do [ -f $IN/$f.txt ] && grep -v amdgpu.ids $IN/$f.txt > $P/${TAG}_$f.txt; done
 ls $P | grep "^${TAG}_"
