@@ -71,7 +71,8 @@ __global__ __launch_bounds__(1024) void argmax_first_kernel(const double *__rest
 struct AffSel {
     double *Q, *C, *Zs, *U, *val, *hv;  // hv: [0] tau, [1 .. d] v (over the trailing rows), [1 + d .. 2 d] w = Q[:, j:] v
     long long *picks;
-    int *state;                         // [0] done, [1] picks so far
+    int *state;                         // [0] done, [1] picks so far, [2] ticket
+    unsigned long long *stamps;         // diagnostic (MRBF_AFFINE_STAMPS=1): 100 MHz clock at the phases of the last workgroup of a launch
     int d, use_inf;
     int64_t mc;
     double pivot;
@@ -143,6 +144,283 @@ __global__ __launch_bounds__(256) void affsel_project_kernel(AffSel a, const dou
         for (int g = 0; g < AFF_G; ++g)
             if (c0 + g < a.mc) a.C[(size_t)(c0 + g) * d + i] = u[g];
     }
+}
+
+// ONE launch per pick (inf-norm, d < 1024).  Every workgroup first brings its eight candidates up to date with the reflector of the pick
+// before (C[jq:, c] <- H C[jq:, c], jq = j - 1), scores them against Zs, and the LAST workgroup to finish (a ticket) takes the decision for
+// the whole grid and prepares the next launch: the new pick's reflector, Q[:, j:] <- Q[:, j:] H in place (every reader of this launch has
+// finished), the new Zs columns with their norms, the picked candidate zeroed.  No assumption about residency (the last-block pattern is
+// safe at any occupancy); the maximum over a column is order-independent, so the step is reproducible whichever workgroup comes last.
+__device__ __forceinline__ double wave_max(double v) {
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+    return v;
+}
+constexpr int AFF_NT = 1024;  // threads of the one-launch-per-pick kernel: the last workgroup's tail (d x (d - j) elements, three passes) is
+                              // latency-bound on one CU -- sixteen waves and eight independent loads per thread hide it
+__global__ __launch_bounds__(AFF_NT) void affsel_pick_kernel(AffSel a, int j, int apply) {
+    extern __shared__ double sx[];  // [AFF_G][dz + 1]: the candidates' coordinates from row j - 1 on (last block afterwards: column maxima)
+    __shared__ double red[AFF_NT];
+    __shared__ long long redi[AFF_NT];
+    __shared__ double s_scal[4];
+    __shared__ int s_last;
+    const int tid = threadIdx.x, lane = tid & 63, d = a.d, dz = d - j, ldx = dz + 1;
+    if (a.state[0]) return;
+    unsigned long long st[12];
+    int nst = 0;
+#define AFF_STAMP() do { if (a.stamps && tid == 0 && nst < 12) st[nst++] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    AFF_STAMP();
+    const int64_t c0 = (int64_t)blockIdx.x * AFF_G;
+    const int jq = j - 1;
+    for (int e = tid; e < AFF_G * ldx; e += AFF_NT) {
+        const int g = e / ldx, k = e % ldx;  // k = 0 is row j - 1 (only read when a reflector is pending)
+        sx[e] = (c0 + g < a.mc && (k > 0 || apply)) ? a.C[(size_t)(c0 + g) * d + jq + k] : 0.0;
+    }
+    __syncthreads();
+    if (apply) {  // x <- x - tau v (v' x) over rows jq .. d - 1, 32 lanes per candidate
+        if (tid < 32 * AFF_G) {
+            const double tau = a.hv[0];
+            const double *v = a.hv + 1;
+            const int g = tid >> 5, l = tid & 31;
+            double dot = 0.0;
+            for (int k8 = l; k8 < ldx; k8 += 32 * 8) {
+                double vv[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) vv[t] = k8 + 32 * t < ldx ? v[k8 + 32 * t] : 0.0;
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+                    if (k8 + 32 * t < ldx) dot = fma(vv[t], sx[g * ldx + k8 + 32 * t], dot);
+            }
+            for (int off = 16; off > 0; off >>= 1) dot += __shfl_xor(dot, off);
+            const double td = tau * dot;
+            for (int k = l; k < ldx; k += 32) {
+                const double xn = fma(-td, v[k], sx[g * ldx + k]);
+                sx[g * ldx + k] = xn;
+                if (c0 + g < a.mc) __hip_atomic_store(&a.C[(size_t)(c0 + g) * d + jq + k], xn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (write-through: the last workgroup may sit behind another L2)
+            }
+        }
+        __syncthreads();
+    }
+    AFF_STAMP();  // 1: candidates loaded, pending reflector applied
+    // scores: rows r by thread, the k range split over the thread groups beyond the first d threads (d = 128: eight groups of sixteen k)
+    int dr = 64;
+    while (dr < d) dr <<= 1;            // rows rounded up to a power of two (<= 1024): thread = (row, chunk)
+    const int nch = AFF_NT / dr, row = tid & (dr - 1), ch = tid / dr;
+    {
+        const int kw = (dz + nch - 1) / nch, k0 = ch * kw, k1 = min(dz, k0 + kw);
+        double u[AFF_G];
+#pragma unroll
+        for (int g = 0; g < AFF_G; ++g) u[g] = 0.0;
+        if (row < d)
+            for (int k8 = k0; k8 < k1; k8 += 8) {  // eight independent loads per batch (a load per iteration is a memory round trip each)
+                double z[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) z[t] = k8 + t < k1 ? a.Zs[(size_t)(k8 + t) * d + row] : 0.0;
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+                    if (k8 + t < k1) {
+#pragma unroll
+                        for (int g = 0; g < AFF_G; ++g) u[g] = fma(z[t], sx[g * ldx + 1 + k8 + t], u[g]);
+                    }
+            }
+        AFF_STAMP();  // 2: products
+        // sum over the chunks (fixed order), max over the rows: four candidates per round through LDS, wave shuffles for the maxima
+        // (a block-wide tree per candidate was 112 barriers of sixteen waves: 30 of the kernel's 43 us)
+        double *sum4 = reinterpret_cast<double *>(redi);  // two candidates per round: red and (the bytes of) redi hold their partial sums
+        const int wave = tid >> 6;
+        for (int g0 = 0; g0 < AFF_G; g0 += 2) {
+            __syncthreads();
+            red[tid] = u[g0];
+            sum4[tid] = u[g0 + 1];
+            __syncthreads();
+            double nv0 = 0.0, nv1 = 0.0;
+            if (tid < dr) {
+                double s0 = 0.0, s1 = 0.0;
+                for (int c2 = 0; c2 < nch; ++c2) {
+                    s0 += red[c2 * dr + tid];
+                    s1 += sum4[c2 * dr + tid];
+                }
+                if (tid < d) {
+                    nv0 = fabs(s0);
+                    nv1 = fabs(s1);
+                }
+            }
+            nv0 = wave_max(nv0);
+            nv1 = wave_max(nv1);
+            __syncthreads();
+            if (lane == 0 && tid < dr) {
+                red[wave] = nv0;
+                sum4[wave] = nv1;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                double m0 = 0.0, m1 = 0.0;
+                for (int w2 = 0; w2 < dr / 64; ++w2) {
+                    m0 = fmax(m0, red[w2]);
+                    m1 = fmax(m1, sum4[w2]);
+                }
+                if (c0 + g0 < a.mc) __hip_atomic_store(a.val + c0 + g0, m0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (c0 + g0 + 1 < a.mc) __hip_atomic_store(a.val + c0 + g0 + 1, m1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    // ---- ticket: the last workgroup decides
+    AFF_STAMP();  // 3: scores reduced and stored
+    // (the codebase's hand-off: write-through stores counted out of vmcnt, workgroup barrier, ONE agent-scope atomic; the reader drops its
+    // own caches with an acquire fence and reads what others wrote with coherent loads -- no agent-scope release: that writes back the L2)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const int t = __hip_atomic_fetch_add(a.state + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = t == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    AFF_STAMP();  // 4: ticket taken (last workgroup from here on)
+    if (tid == 0) a.state[2] = 0;
+    double bv = -INFINITY;
+    long long bi = -1;
+    for (int64_t c = tid; c < a.mc; c += AFF_NT) {
+        const double v = __hip_atomic_load(a.val + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v > bv) {
+            bv = v;
+            bi = c;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {  // first maximiser inside the wave, then over the sixteen waves
+        const double ov = __shfl_xor(bv, off);
+        const long long oi = __shfl_xor(bi, off);
+        if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi < bi))) {
+            bv = ov;
+            bi = oi;
+        }
+    }
+    __syncthreads();
+    if (lane == 0) {
+        red[tid >> 6] = bv;
+        redi[tid >> 6] = bi;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w2 = 1; w2 < AFF_NT / 64; ++w2) {
+            const double ov = red[w2];
+            const long long oi = redi[w2];
+            if (oi >= 0 && (redi[0] < 0 || ov > red[0] || (ov == red[0] && oi < redi[0]))) {
+                red[0] = ov;
+                redi[0] = oi;
+            }
+        }
+    }
+    __syncthreads();
+    const long long best = redi[0];
+    const double bestv = red[0];
+    __syncthreads();
+    AFF_STAMP();  // 5: first maximiser
+    if (best < 0 || !(bestv > a.pivot)) {
+        if (tid == 0) a.state[0] = 1;
+        return;
+    }
+    double *x = a.C + (size_t)best * d + j;
+    double part = 0.0;
+    for (int c = 1 + tid; c < dz; c += AFF_NT) {
+        const double xv = __hip_atomic_load(x + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        part = fma(xv, xv, part);
+    }
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+    __syncthreads();
+    if (lane == 0) red[tid >> 6] = part;
+    __syncthreads();
+    if (tid == 0) {
+        double ssq = 0.0;
+        for (int w2 = 0; w2 < AFF_NT / 64; ++w2) ssq += red[w2];
+        const double alpha = __hip_atomic_load(x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), xn = sqrt(ssq);
+        double tau = 0.0, scale = 0.0;
+        if (xn != 0.0) {
+            const double beta = -copysign(hypot(alpha, xn), alpha);
+            tau = (beta - alpha) / beta;
+            scale = 1.0 / (alpha - beta);
+        }
+        s_scal[0] = tau;
+        s_scal[1] = scale;
+        a.hv[0] = tau;
+        a.picks[a.state[1]] = best;
+        a.state[1] += 1;
+    }
+    __syncthreads();
+    const double tau = s_scal[0], scale = s_scal[1];
+    double *v = a.hv + 1, *w = a.hv + 1 + d;
+    unsigned long long *cmax = reinterpret_cast<unsigned long long *>(sx);  // (non-negative doubles order like their bit patterns)
+    double *sv = sx + dz;                                                    // v in LDS behind the column maxima (2 dz <= AFF_G (dz + 1))
+    for (int c = tid; c < dz; c += AFF_NT) {
+        const double vc = c == 0 ? 1.0 : __hip_atomic_load(x + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * scale;
+        v[c] = vc;
+        sv[c] = vc;
+        cmax[c] = 0ull;
+    }
+    __syncthreads();
+    AFF_STAMP();  // 6: reflector
+    // thread = (row, column chunk): w = Q[:, j:] v as partial sums over the chunks, then Q[:, j:] <- Q[:, j:] - tau w v' with the column maxima
+    // of the NEW trailing columns j + 1 .., then their doubly normalised copies -- eight independent loads per thread and batch
+    const int cw = (dz + nch - 1) / nch, cb = ch * cw, ce = min(dz, cb + cw);
+    double acc = 0.0;
+    if (row < d)
+        for (int c8 = cb; c8 < ce; c8 += 8) {
+            double q[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) q[u] = c8 + u < ce ? a.Q[(size_t)(j + c8 + u) * d + row] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = fma(q[u], c8 + u < ce ? sv[c8 + u] : 0.0, acc);
+        }
+    red[tid] = acc;
+    __syncthreads();
+    if (tid < dr) {
+        double sum = 0.0;
+        for (int c2 = 0; c2 < nch; ++c2) sum += red[c2 * dr + tid];
+        if (tid < d) w[tid] = sum;
+        redi[tid] = __double_as_longlong(sum);  // (w for every chunk's threads)
+    }
+    __syncthreads();
+    AFF_STAMP();  // 7: w
+    const double tw = tau * __longlong_as_double(redi[row]);
+    for (int c8 = cb; c8 < ce; c8 += 8) {  // (uniform per wave: a wave holds 64 consecutive rows of ONE chunk)
+        double q[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) q[u] = (row < d && c8 + u < ce) ? a.Q[(size_t)(j + c8 + u) * d + row] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = c8 + u;
+            double e = 0.0;
+            if (row < d && c < ce) {
+                e = fma(-tw, sv[c], q[u]);
+                a.Q[(size_t)(j + c) * d + row] = e;
+            }
+            q[u] = e;
+            if (c < ce && c > 0) {
+                const double m = wave_max(fabs(e));
+                if (lane == 0) atomicMax(&cmax[c], (unsigned long long)__double_as_longlong(m));
+            }
+        }
+    }
+    __syncthreads();
+    AFF_STAMP();  // 8: Q updated, column maxima
+    if (row < d)
+        for (int c8 = max(cb, 1); c8 < ce; c8 += 8) {
+            double q[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) q[u] = c8 + u < ce ? a.Q[(size_t)(j + c8 + u) * d + row] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (c8 + u < ce) {
+                    const double nrmc = __longlong_as_double((long long)cmax[c8 + u]);
+                    const double s2n = 1.0 / (nrmc * nrmc);  // (the same expression as affsel_update_kernel: Z Z' = Q2 D^2 Q2')
+                    a.Zs[(size_t)(c8 + u - 1) * d + row] = q[u] * s2n;
+                }
+        }
+    for (int r = tid; r < d; r += AFF_NT) a.C[(size_t)best * d + r] = 0.0;
+    AFF_STAMP();  // 9: Zs written
+    if (a.stamps && tid == 0)
+        for (int q2 = 0; q2 < nst; ++q2) a.stamps[q2] = st[q2];
+#undef AFF_STAMP
 }
 
 // one workgroup: first maximiser of val, pivot test, the pick's reflector and w; the picked candidate becomes the zero vector
@@ -337,6 +615,9 @@ extern "C" int32_t mrbf_affine_select(mrbf_ctx *ctx, int64_t mc, int32_t d, cons
     MRBF_TRY(get_buf(ctx, S_IPIV, (size_t)std::max(max_picks, 1) + 2, &a.picks));
     MRBF_TRY(get_buf(ctx, S_INFO, (size_t)4, &a.state));
     MRBF_HIP(ctx, hipMemsetAsync(a.state, 0, 4 * sizeof(int), s));
+    static const int want_stamps = mrbf_env("MRBF_AFFINE_STAMPS") ? atoi(mrbf_env("MRBF_AFFINE_STAMPS")) : 0;
+    a.stamps = nullptr;
+    if (want_stamps) MRBF_TRY(get_buf(ctx, S_MISC, (size_t)16, &a.stamps));
     const double one = 1.0, zero = 0.0;
     std::vector<double> hq;
     if (j0 > 0) {
@@ -362,8 +643,22 @@ extern "C" int32_t mrbf_affine_select(mrbf_ctx *ctx, int64_t mc, int32_t d, cons
         }
         hipLaunchKernelGGL(affsel_update_kernel, dim3((unsigned)(d - j0)), dim3(256), 0, s, a, j0, j0, 0);  // Zs of the start basis
         int hstate[2] = {0, 0};
+        // one launch per pick (affsel_pick_kernel) for the filter's own norm (p = inf) while the candidates' coordinates fit the LDS budget;
+        // the three-launch form otherwise (2-norm: its column sums would depend on the order of arrival)
+        const size_t shm_pick = (size_t)AFF_G * (d + 1) * sizeof(double);
+        static const int fused_env = mrbf_env("MRBF_AFFINE_FUSED") ? atoi(mrbf_env("MRBF_AFFINE_FUSED")) : 1;
+        const bool fused = a.use_inf && shm_pick <= 64 * 1024 && fused_env != 0;
         for (int t = 0; t < max_picks; ++t) {
             const int j = j0 + t, dz = d - j;
+            if (fused) {
+                hipLaunchKernelGGL(affsel_pick_kernel, dim3(ngrp), dim3(AFF_NT), (size_t)AFF_G * (dz + 1) * sizeof(double), s, a, j, t > 0 ? 1 : 0);
+                if ((t & 15) == 15 && t + 1 < max_picks) {
+                    MRBF_HIP(ctx, hipMemcpyAsync(hstate, a.state, sizeof(hstate), hipMemcpyDeviceToHost, s));
+                    MRBF_HIP(ctx, hipStreamSynchronize(s));
+                    if (hstate[0]) break;
+                }
+                continue;
+            }
             if (shm > 64 * 1024) {
                 MRBF_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, d, (int)mc, dz, &one, a.Zs, d, a.C + j, d, &zero, a.U, d));
                 hipLaunchKernelGGL(col_norms_kernel, dim3((unsigned)((mc + 3) / 4)), dim3(256), 0, s, a.U, d, mc, a.use_inf, a.val);
@@ -382,6 +677,13 @@ extern "C" int32_t mrbf_affine_select(mrbf_ctx *ctx, int64_t mc, int32_t d, cons
         MRBF_HIP(ctx, hipMemcpyAsync(hstate, a.state, sizeof(hstate), hipMemcpyDeviceToHost, s));
         MRBF_HIP(ctx, hipStreamSynchronize(s));
         npick = hstate[1];
+        if (a.stamps) {  // phases of the last launch's last workgroup, us since its start
+            unsigned long long hs[12];
+            MRBF_HIP(ctx, hipMemcpy(hs, a.stamps, sizeof(hs), hipMemcpyDeviceToHost));
+            fprintf(stderr, "affsel_pick_kernel phases (us):");
+            for (int q2 = 1; q2 < 10; ++q2) fprintf(stderr, " %.2f", (double)(hs[q2] - hs[0]) * 0.01);
+            fprintf(stderr, "\n");
+        }
         if (npick > 0) {
             std::vector<long long> hp((size_t)npick);
             MRBF_HIP(ctx, hipMemcpy(hp.data(), a.picks, hp.size() * sizeof(long long), hipMemcpyDeviceToHost));
