@@ -223,47 +223,41 @@ __global__ __launch_bounds__(AFF_NT) void affsel_pick_kernel(AffSel a, int j, in
                     }
             }
         AFF_STAMP();  // 2: products
-        // sum over the chunks (fixed order), max over the rows: four candidates per round through LDS, wave shuffles for the maxima
-        // (a block-wide tree per candidate was 112 barriers of sixteen waves: 30 of the kernel's 43 us)
-        double *sum4 = reinterpret_cast<double *>(redi);  // two candidates per round: red and (the bytes of) redi hold their partial sums
+        // sum over the chunks (fixed order), max over the rows -- all eight candidates in ONE round through LDS (8 x 1024 partial sums behind
+        // the candidates' coordinates), wave shuffles for the maxima: three barriers (a block-wide tree per candidate was 112)
+        double *ps = sx + (size_t)AFF_G * (d + 1);   // [AFF_G][AFF_NT]
         const int wave = tid >> 6;
-        for (int g0 = 0; g0 < AFF_G; g0 += 2) {
-            __syncthreads();
-            red[tid] = u[g0];
-            sum4[tid] = u[g0 + 1];
-            __syncthreads();
-            double nv0 = 0.0, nv1 = 0.0;
-            if (tid < dr) {
-                double s0 = 0.0, s1 = 0.0;
-                for (int c2 = 0; c2 < nch; ++c2) {
-                    s0 += red[c2 * dr + tid];
-                    s1 += sum4[c2 * dr + tid];
-                }
-                if (tid < d) {
-                    nv0 = fabs(s0);
-                    nv1 = fabs(s1);
-                }
-            }
-            nv0 = wave_max(nv0);
-            nv1 = wave_max(nv1);
-            __syncthreads();
-            if (lane == 0 && tid < dr) {
-                red[wave] = nv0;
-                sum4[wave] = nv1;
-            }
-            __syncthreads();
-            if (tid == 0) {
-                double m0 = 0.0, m1 = 0.0;
-                for (int w2 = 0; w2 < dr / 64; ++w2) {
-                    m0 = fmax(m0, red[w2]);
-                    m1 = fmax(m1, sum4[w2]);
-                }
-                if (c0 + g0 < a.mc) __hip_atomic_store(a.val + c0 + g0, m0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (c0 + g0 + 1 < a.mc) __hip_atomic_store(a.val + c0 + g0 + 1, m1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < AFF_G; ++g) ps[g * AFF_NT + tid] = u[g];
+        __syncthreads();
+        double nv[AFF_G];
+#pragma unroll
+        for (int g = 0; g < AFF_G; ++g) nv[g] = 0.0;
+        if (tid < dr) {
+#pragma unroll
+            for (int g = 0; g < AFF_G; ++g) {
+                double sum = 0.0;
+                for (int c2 = 0; c2 < nch; ++c2) sum += ps[g * AFF_NT + c2 * dr + tid];
+                nv[g] = tid < d ? fabs(sum) : 0.0;
             }
         }
+        if (tid < dr) {  // (whole waves: dr is a multiple of 64)
+#pragma unroll
+            for (int g = 0; g < AFF_G; ++g) nv[g] = wave_max(nv[g]);
+        }
+        __syncthreads();
+        if (lane == 0 && tid < dr) {
+#pragma unroll
+            for (int g = 0; g < AFF_G; ++g) red[g * 16 + wave] = nv[g];
+        }
+        __syncthreads();
+        if (tid < AFF_G && c0 + tid < a.mc) {
+            double m = 0.0;
+            for (int w2 = 0; w2 < dr / 64; ++w2) m = fmax(m, red[tid * 16 + w2]);
+            __hip_atomic_store(a.val + c0 + tid, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
-    // ---- ticket: the last workgroup decides
     AFF_STAMP();  // 3: scores reduced and stored
     // (the codebase's hand-off: write-through stores counted out of vmcnt, workgroup barrier, ONE agent-scope atomic; the reader drops its
     // own caches with an acquire fence and reads what others wrote with coherent loads -- no agent-scope release: that writes back the L2)
@@ -648,10 +642,12 @@ extern "C" int32_t mrbf_affine_select(mrbf_ctx *ctx, int64_t mc, int32_t d, cons
         const size_t shm_pick = (size_t)AFF_G * (d + 1) * sizeof(double);
         static const int fused_env = mrbf_env("MRBF_AFFINE_FUSED") ? atoi(mrbf_env("MRBF_AFFINE_FUSED")) : 1;
         const bool fused = a.use_inf && shm_pick <= 64 * 1024 && fused_env != 0;
+        const size_t shm_pick_total = shm_pick + (size_t)AFF_G * AFF_NT * sizeof(double);  // coordinates + the 8 x 1024 partial sums (<= 128 KB of the CU's 160)
+        if (fused) MRBF_HIP(ctx, hipFuncSetAttribute((const void *)affsel_pick_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_pick_total));
         for (int t = 0; t < max_picks; ++t) {
             const int j = j0 + t, dz = d - j;
             if (fused) {
-                hipLaunchKernelGGL(affsel_pick_kernel, dim3(ngrp), dim3(AFF_NT), (size_t)AFF_G * (dz + 1) * sizeof(double), s, a, j, t > 0 ? 1 : 0);
+                hipLaunchKernelGGL(affsel_pick_kernel, dim3(ngrp), dim3(AFF_NT), shm_pick_total, s, a, j, t > 0 ? 1 : 0);
                 if ((t & 15) == 15 && t + 1 < max_picks) {
                     MRBF_HIP(ctx, hipMemcpyAsync(hstate, a.state, sizeof(hstate), hipMemcpyDeviceToHost, s));
                     MRBF_HIP(ctx, hipStreamSynchronize(s));
