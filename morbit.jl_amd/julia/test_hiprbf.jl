@@ -156,3 +156,56 @@ end
         @test all(isfinite, fx)
     end
 end
+
+# Round 6: the plug-in is inert for users who do not select HipRbfConfig.  A plain RbfConfig run -- model update with many database
+# sites (the affine filter iterates), steepest descent (`_backtrack`) and the Pascoletti-Serafini step (`get_criticality`) -- makes no
+# ccall: it gives Morbit's own result and creates no context.  (Run this testset FIRST in a fresh session to see that it also works
+# with MRBF_LIB pointing nowhere: the three methods the plug-in adds on Morbit's own types hand over before libmrbf is touched.)
+@testset "inert for plain RbfConfig runs" begin
+    n_ctx = length(Morbit._CTX)
+    g1 = x -> sum((x .- 1) .^ 2)
+    g2 = x -> sum((x .+ 1) .^ 2)
+    for descent_method in [:steepest_descent, :ps]
+        mop = MOP(2)
+        add_objective!(mop, g1; n_out = 1, model_cfg = RbfConfig(; kernel = :multiquadric))
+        add_objective!(mop, g2; n_out = 1, model_cfg = RbfConfig(; kernel = :multiquadric))
+        x, fx, ret_code, _ = optimize(mop, [-π, 2.71828]; algo_config = AlgorithmConfig(; descent_method, max_iter = 10))
+        @test all(isfinite, fx)
+    end
+    @test length(Morbit._CTX) == n_ctx                       # no context was created: nothing of libmrbf ran
+    @test Morbit._hip_affine_scan() === nothing              # the task-local scan state only lives inside a HipRbfConfig update
+end
+
+# Round 6: the filter's growing Householder factorisation against qr(Y) from scratch (what `_orthogonal_complement_matrix` does after
+# every pick, AffinelyIndependentPoints.jl:4-11), and the device selection against the host loop
+@testset "affine filter: one reflector per pick, device selection" begin
+    for d in (3, 17, 64)
+        Y = randn(d, d)
+        g = Morbit.HipRbfGrowingQR(Matrix{Float64}(undef, d, 0))
+        for j = 1:d
+            Morbit._append!(g, Y[:, j])
+            Z = Morbit._complement(g, Inf)
+            Zf = Morbit._orthogonal_complement_matrix(Y[:, 1:j], Inf)
+            @test size(Z) == size(Zf)
+            isempty(Z) || @test maximum(abs.(Z .- Zf)) < 1e-12
+        end
+        g2 = Morbit.HipRbfGrowingQR(Y[:, 1:2])               # round 2: continue from a given Y
+        Morbit._append!(g2, Y[:, 3])
+        d >= 4 && @test maximum(abs.(Morbit._complement(g2, Inf) .- Morbit._orthogonal_complement_matrix(Y[:, 1:3], Inf))) < 1e-12
+    end
+    d, mc = 64, 400
+    x0 = rand(d); S = 0.2 .* (2 .* rand(d, mc) .- 1)
+    first = argmax([norm(S[:, c], Inf) for c = 1:mc])
+    g = Morbit.HipRbfGrowingQR(reshape(S[:, first], d, 1))
+    Sd = copy(S); Sd[:, first] .= 0
+    picks, Zf = Morbit.affine_select(Sd, g.Q, g.j, d - 1, 0.02, Inf)
+    # the host loop with the same rule
+    want = Int[]; Sh = copy(Sd); gh = Morbit.HipRbfGrowingQR(reshape(S[:, first], d, 1))
+    while length(want) < d - 1
+        i, v = Morbit._affine_scores_host(Sh, Morbit._complement(gh, Inf), Inf)
+        (i >= 1 && v > 0.02) || break
+        push!(want, i); Morbit._append!(gh, S[:, i]); Sh[:, i] .= 0
+    end
+    @test picks == want
+    @test size(Zf, 2) == d - 1 - length(picks)
+end
