@@ -699,7 +699,18 @@ static int ps_eval_points(mrbf_ctx *ctx, const ps::Problem &P, const double *x_h
     for (int j = 0; j < P.nmodels; ++j) cnt += (size_t)P.models[j]->k * d;
     MRBF_TRY(get_buf(ctx, S_PS_POLISH, cnt, &dX));
     double *dV = dX + (size_t)m * d, *dJ = dV + (size_t)m * P.nftot;
-    MRBF_HIP(ctx, hipMemcpyAsync(dX, x_host, (size_t)m * d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    // The descent phase calls this some 140 times per step with a few KB each way.  Transfers from / to pageable memory are a
+    // synchronous round trip of their own (round 6: 285 copies = a sixth of the d = 128 step): the points go up and the values /
+    // Jacobians come down through the context's pinned block (free during a PS step: no entry point arms it here), enqueued
+    // asynchronously in front of ONE stream synchronisation.
+    const size_t up_cnt = (size_t)m * d, down_cnt = cnt - up_cnt;
+    double *pin = (ctx->pin_base && !ctx->pin_armed && cnt * sizeof(double) <= ((size_t)1 << 20)) ? reinterpret_cast<double *>(ctx->pin_base) : nullptr;
+    if (pin) {
+        std::memcpy(pin, x_host, up_cnt * sizeof(double));
+        MRBF_HIP(ctx, hipMemcpyAsync(dX, pin, up_cnt * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        MRBF_HIP(ctx, hipMemcpyAsync(dX, x_host, up_cnt * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    }
     std::vector<double *> jp(P.nmodels, nullptr), vp(P.nmodels, nullptr);
     for (int j = 0; j < P.nmodels; ++j) {
         bool need = false;
@@ -709,14 +720,27 @@ static int ps_eval_points(mrbf_ctx *ctx, const ps::Problem &P, const double *x_h
         MRBF_TRY(eval_model(ctx, P.models[j], m, dX, vp[j], jp[j], nullptr));
         dJ += (size_t)P.models[j]->k * d;
     }
-    std::vector<double> blocks((size_t)m * P.nftot);
-    MRBF_HIP(ctx, hipMemcpyAsync(blocks.data(), dV, blocks.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    std::vector<std::vector<double>> Jm(P.nmodels);
-    for (int j = 0; j < P.nmodels; ++j)
-        if (jp[j]) {
-            Jm[j].resize((size_t)P.models[j]->k * d);
-            MRBF_HIP(ctx, hipMemcpyAsync(Jm[j].data(), jp[j], Jm[j].size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        }
+    std::vector<double> blocks_v;
+    std::vector<std::vector<double>> Jm_v(P.nmodels);
+    const double *blocks;
+    std::vector<const double *> Jm(P.nmodels, nullptr);
+    if (pin) {
+        double *down = pin + up_cnt;  // the values, then every model's Jacobian block at its device offset: one download
+        MRBF_HIP(ctx, hipMemcpyAsync(down, dV, down_cnt * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        blocks = down;
+        for (int j = 0; j < P.nmodels; ++j)
+            if (jp[j]) Jm[j] = down + (jp[j] - dV);
+    } else {
+        blocks_v.resize((size_t)m * P.nftot);
+        MRBF_HIP(ctx, hipMemcpyAsync(blocks_v.data(), dV, blocks_v.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        blocks = blocks_v.data();
+        for (int j = 0; j < P.nmodels; ++j)
+            if (jp[j]) {
+                Jm_v[j].resize((size_t)P.models[j]->k * d);
+                MRBF_HIP(ctx, hipMemcpyAsync(Jm_v[j].data(), jp[j], Jm_v[j].size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+                Jm[j] = Jm_v[j].data();
+            }
+    }
     MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     allF.resize((size_t)m * P.nftot);
     for (int j = 0; j < P.nmodels; ++j) {
