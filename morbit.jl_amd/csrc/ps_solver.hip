@@ -82,7 +82,7 @@ struct Args {
     unsigned long long seed;
     double xtol_rel;
     int gen;
-    int dbg;  // experiments (MRBF_PS_DBG): 64 the multi-workgroup ranking gives up at once (fallback test), 1 no ranking, 2 no breeding, 4 transposition phases also when a sort would do, 8 t stays a free
+    int dbg;  // experiments (MRBF_PS_DBG): 128 the plain sort as one pair per thread through LDS (the form before round 6), 64 the multi-workgroup ranking gives up at once (fallback test), 1 no ranking, 2 no breeding, 4 transposition phases also when a sort would do, 8 t stays a free
               // variable (no repair), 16 uniform start population
 };
 
@@ -247,6 +247,166 @@ __device__ __forceinline__ bool cand_better(const Cand &x, const Cand &y) {
     return x.idx < y.idx;
 }
 
+// ---- the bitonic network of the plain sort with E elements per thread in registers (position p = tid * E + e): compare-exchanges at
+// distance j < E stay inside the thread, j < 64 E go through wave shuffles, only the rest through LDS with a barrier -- 10 of the 78
+// stages at N = 4096 (the one-pair-per-thread form paid an LDS round trip and a sixteen-wave barrier per stage: 60-80 us per generation at
+// d = 128, 2.4 ms per step).  Same network, same comparator (objective, ties by index): the same order.  On return sidx[p] holds the order.
+__device__ __forceinline__ int npow2(int lam) {
+    int N = 1;
+    while (N < lam) N <<= 1;
+    return N;
+}
+template <int J, int E>
+__device__ __forceinline__ void bitonic_inthread(double (&f)[E], int (&ix)[E], int base, int kk) {
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+        if ((e & J) == 0) {
+            const int l = e | J;
+            const bool greater = f[e] > f[l] || (f[e] == f[l] && ix[e] > ix[l]);
+            const bool up = ((base + e) & kk) == 0;
+            if (greater == up) {
+                const double tf = f[e];
+                f[e] = f[l];
+                f[l] = tf;
+                const int ti = ix[e];
+                ix[e] = ix[l];
+                ix[l] = ti;
+            }
+        }
+}
+template <int E>
+__device__ __forceinline__ void bitonic_regs(const double *__restrict__ fin, const int *__restrict__ iin, int lam, int N, double *sf, int *sidx) {
+    const int tid = threadIdx.x, base = tid * E;
+    double f[E];
+    int ix[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int p = base + e;
+        f[e] = p < lam ? fin[p] : INFINITY;
+        ix[e] = p < lam ? (iin ? iin[p] : p) : 0x7fffffff;
+    }
+    if (iin) __syncthreads();  // (the inputs may live where the stages exchange their elements)
+    for (int kk = 2; kk <= N; kk <<= 1)
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            if (j < E) {
+                if constexpr (E > 1) {
+                    if (j == 1) bitonic_inthread<1, E>(f, ix, base, kk);
+                }
+                if constexpr (E > 2) {
+                    if (j == 2) bitonic_inthread<2, E>(f, ix, base, kk);
+                }
+                if constexpr (E > 4) {
+                    if (j == 4) bitonic_inthread<4, E>(f, ix, base, kk);
+                }
+            } else if (j < 64 * E) {
+                const int dl = j / E;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int p = base + e;
+                    const double of = __shfl_xor(f[e], dl);
+                    const int oi = __shfl_xor(ix[e], dl);
+                    const bool keep_min = ((p & j) == 0) == ((p & kk) == 0);
+                    const bool greater = f[e] > of || (f[e] == of && ix[e] > oi);
+                    if (keep_min == greater) {
+                        f[e] = of;
+                        ix[e] = oi;
+                    }
+                }
+            } else {
+                __syncthreads();  // (the partners' reads of the stage before)
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    sf[base + e] = f[e];
+                    sidx[base + e] = ix[e];
+                }
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int p = base + e, q = p ^ j;
+                    const double of = sf[q];
+                    const int oi = sidx[q];
+                    const bool keep_min = ((p & j) == 0) == ((p & kk) == 0);
+                    const bool greater = f[e] > of || (f[e] == of && ix[e] > oi);
+                    if (keep_min == greater) {
+                        f[e] = of;
+                        ix[e] = oi;
+                    }
+                }
+            }
+        }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < E; ++e) sidx[base + e] = ix[e];
+    __syncthreads();
+}
+
+// ---- only the mu best individuals of a plain sort are ever read (the parents, and the spread test over them): find them without sorting
+// the other six sevenths.  A threshold from blockDim evenly spaced samples (each sample ranks itself among the samples by counting:
+// no sort), placed three standard deviations of the sample quantile above rank mu; one pass counts and compacts the individuals at or
+// below it (ties included, so the compacted set always CONTAINS the mu best with their index order intact); if that set holds at least mu
+// and at most blockDim individuals it is padded to blockDim and sorted one element per thread (shuffles up to distance 32, LDS beyond:
+// 10 barrier stages of 55) -- else the caller sorts everything as before.  The parents and their order are those of the full sort.
+// scratch: 2 blockDim doubles + 2 blockDim ints behind `sf` (the caller's N >= 2 blockDim doubles + N ints cover it).
+__device__ __forceinline__ bool select_parents(const double *__restrict__ fin, int lam, int mu, double *sf, int *sidx_out) {
+    __shared__ int s_cnt[32];
+    __shared__ double s_thr;
+    const int tid = threadIdx.x, NT = (int)blockDim.x, lane = tid & 63, wave = tid >> 6, nw = NT >> 6;
+    double *ssamp = sf, *csf = sf + NT;
+    int *cidx = reinterpret_cast<int *>(sf + 2 * NT);
+    // target rank: mu plus three standard deviations of the S-sample quantile estimate (in ranks)
+    const int S = NT;
+    const double p0 = (double)mu / lam;
+    const double sd = lam * sqrt(fmax(p0 * (1.0 - p0), 0.0) / S);
+    const double T = mu + 3.0 * sd + 2.0 * lam / S;
+    if (!(T <= 0.9 * NT) || lam <= NT) return false;
+    const int rstar = min(S - 1, (int)ceil(T * S / lam));
+    const double mine = fin[(int)(((long long)tid * lam) / S)];
+    ssamp[tid] = mine;
+    __syncthreads();
+    int rank = 0;
+    for (int q = 0; q < S; ++q) {
+        const double o = ssamp[q];  // (broadcast read)
+        rank += (o < mine || (o == mine && q < tid)) ? 1 : 0;
+    }
+    if (rank == rstar) s_thr = mine;
+    __syncthreads();
+    const double thr = s_thr;
+    int cnt = 0;
+    for (int i = tid; i < lam; i += NT) cnt += fin[i] <= thr ? 1 : 0;
+    // exclusive scan of the per-thread counts: inside the wave by shuffles, across the waves through LDS
+    int incl = cnt;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
+    }
+    if (lane == 63) s_cnt[wave] = incl;
+    __syncthreads();
+    int wbase = 0, total = 0;
+    for (int w2 = 0; w2 < nw; ++w2) {
+        if (w2 < wave) wbase += s_cnt[w2];
+        total += s_cnt[w2];
+    }
+    if (total < mu || total > NT) return false;  // (uniform: every thread sees the same counts)
+    int pos = wbase + incl - cnt;
+    for (int i = tid; i < lam; i += NT) {
+        const double v = fin[i];
+        if (v <= thr) {
+            csf[pos] = v;
+            cidx[pos] = i;
+            ++pos;
+        }
+    }
+    for (int i = total + tid; i < NT; i += NT) {
+        csf[i] = INFINITY;
+        cidx[i] = 0x7fffffff;
+    }
+    __syncthreads();
+    // (a thread's compacted elements are not in index order across threads -- thread t holds i = t, t + NT, .. -- which is fine: the
+    // sort's comparator is (objective, index))
+    bitonic_regs<1>(csf, cidx, NT, NT, ssamp, sidx_out);
+    return true;
+}
+
 // ---- one workgroup per run: best so far, stop tests, ranking
 // mode 0: everything in this launch.  Large populations with infeasible individuals (mode 1 / 2): mode 1 does the bookkeeping and, when
 // the transposition phases are due, hands them to ps_rank_sort_kernel (sixteen workgroups per run); mode 2 picks the order up (or runs the
@@ -343,6 +503,22 @@ __global__ __launch_bounds__(RANK_THREADS) void ps_rank_kernel(Args a, int mode,
         sidx = (int *)smem;
         for (int i = tid; i < lam; i += NT) sidx[i] = i;
         __syncthreads();
+    } else if (plain_sort && !(a.dbg & (128 | 256)) && NT >= 256 && mu * 4 <= lam && (npow2(lam) >= 8 * NT || (a.dbg & 512)) &&
+               select_parents(R.f, lam, mu, smem, (int *)(smem + npow2(lam)))) {  // (measured: pays from lam > 4096 on -- 135 against 195 us per ranking at
+                                                                                  // lam = 5160; below, its sampling pass costs what the shorter sort saves; dbg 512 forces it)
+        sidx = (int *)(smem + npow2(lam));  // (parents found and ranked without sorting the rest: see select_parents)
+    } else if (plain_sort && !(a.dbg & 128) && (npow2(lam) == 2 * NT || npow2(lam) == 4 * NT || npow2(lam) == 8 * NT)) {
+        // (the launch's thread count follows the LARGEST population: N / 2 up to N = 2048, 1024 beyond; a run whose padded size is not
+        // 2, 4 or 8 elements per thread -- a much smaller run in the same launch -- takes the one-pair-per-thread form below)
+        const int N = npow2(lam);
+        double *sf = smem;      // N keys: violation is 0 or inf here, and inf comes with f = inf
+        sidx = (int *)(sf + N);
+        if (N == 2 * NT)
+            bitonic_regs<2>(R.f, nullptr, lam, N, sf, sidx);
+        else if (N == 4 * NT)
+            bitonic_regs<4>(R.f, nullptr, lam, N, sf, sidx);
+        else
+            bitonic_regs<8>(R.f, nullptr, lam, N, sf, sidx);
     } else if (plain_sort) {
         int N = 1;
         while (N < lam) N <<= 1;
@@ -1288,8 +1464,8 @@ extern "C" int32_t mrbf_debug_ps_rank(mrbf_ctx *ctx, int32_t lam, const double *
     if (lam < 2 || lam > MAXLAM) return fail(ctx, -2, "mrbf_debug_ps_rank: lam = %d outside 2..%d", lam, MAXLAM);
     if (!f || !phi) return fail(ctx, -3, "f / phi is NULL");
     if (gen < 0) return fail(ctx, -6, "gen < 0");
-    if (impl < 0 || impl > 2) return fail(ctx, -7, "impl must be 0, 1 or 2");
-    if (impl != 0 && lam < RS_MINLAM) return fail(ctx, -7, "mrbf_debug_ps_rank: the several-workgroup ranking takes populations >= %d", RS_MINLAM);
+    if (impl < 0 || impl > 5) return fail(ctx, -7, "impl must be 0 .. 5");
+    if ((impl == 1 || impl == 2) && lam < RS_MINLAM) return fail(ctx, -7, "mrbf_debug_ps_rank: the several-workgroup ranking takes populations >= %d", RS_MINLAM);
     if (!order_out) return fail(ctx, -8, "order_out is NULL");
     (void)hipSetDevice(ctx->device);
     double *base;
@@ -1302,9 +1478,10 @@ extern "C" int32_t mrbf_debug_ps_rank(mrbf_ctx *ctx, int32_t lam, const double *
     a.seed = seed;
     a.gen = gen;
     a.xtol_rel = 1e-3;
-    a.dbg = impl == 2 ? 64 : 0;
+    a.dbg = impl == 2 ? 64 : (impl == 3 ? 128 : (impl == 5 ? 256 : (impl == 4 ? 512 : 0)));  // (3: the plain sort as one pair per thread through LDS; 5: no parent selection)
     R.nvar = 1;
-    R.lam = R.mu = lam;          // mu = lam: the whole order comes out
+    R.lam = lam;
+    R.mu = (impl == 4 || impl == 5) ? (lam + 6) / 7 : lam;  // mu = lam: the whole order comes out; 4 / 5: the step's own mu (order_out beyond it: -1)
     R.max_evals = 1 << 30;
     R.X[0] = R.X[1] = base;      // one dummy variable per individual
     R.best = base + lam;         // [x, f, phi]
@@ -1324,7 +1501,7 @@ extern "C" int32_t mrbf_debug_ps_rank(mrbf_ctx *ctx, int32_t lam, const double *
     MRBF_HIP(ctx, hipFuncSetAttribute((const void *)ps_rank_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
     const int rank_threads = (int)std::min<int64_t>(RANK_THREADS, std::max<int64_t>(64, round_up(N / 2, 64)));
     RankWs rw{};
-    if (impl != 0) {
+    if (impl == 1 || impl == 2) {
         double *wsb;
         const size_t per_run = (size_t)MAXLAM * 5 + RS_SYNC / 2;
         MRBF_TRY(get_buf(ctx, S_PS_RANK, per_run * MAXRUNS + 64, &wsb));
@@ -1337,14 +1514,15 @@ extern "C" int32_t mrbf_debug_ps_rank(mrbf_ctx *ctx, int32_t lam, const double *
         rw.sync = rw.idx[1] + (size_t)MAXLAM * MAXRUNS;
         MRBF_HIP(ctx, hipMemsetAsync(rw.sync + RS_SYNC * MAXRUNS, 0, sizeof(int), ctx->stream));
     }
-    hipLaunchKernelGGL(ps_rank_kernel, dim3(1), dim3(rank_threads), shm, ctx->stream, a, impl != 0 ? 1 : 0, rw);
-    if (impl != 0) {
+    hipLaunchKernelGGL(ps_rank_kernel, dim3(1), dim3(rank_threads), shm, ctx->stream, a, (impl == 1 || impl == 2) ? 1 : 0, rw);
+    if (impl == 1 || impl == 2) {
         hipLaunchKernelGGL(ps_rank_sort_kernel, dim3(RS_W, 1), dim3(RS_THREADS), 0, ctx->stream, a, rw);
         hipLaunchKernelGGL(ps_rank_kernel, dim3(1), dim3(rank_threads), shm, ctx->stream, a, 2, rw);
     }
     MRBF_HIP(ctx, hipGetLastError());
     int hsync[2] = {0, 0};
-    if (impl != 0) MRBF_HIP(ctx, hipMemcpyAsync(hsync, rw.sync, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    if (impl == 1 || impl == 2) MRBF_HIP(ctx, hipMemcpyAsync(hsync, rw.sync, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    MRBF_HIP(ctx, hipMemsetAsync(R.order + R.mu, 0xff, (size_t)(lam - R.mu) * sizeof(int), ctx->stream));
     MRBF_HIP(ctx, hipMemcpyAsync(order_out, R.order, (size_t)lam * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (gave_up) *gave_up = hsync[1];

@@ -53,6 +53,7 @@ class Rehearsal:
         self.keeper = sp.Round4Keeper()
         self.ctx = _lib.default_context()            # ONE context for every call, like the binding's per-thread context
         self.log = []                                # one record per iteration
+        self.arena0 = self.ctx.get_option(_lib.OPT_ARENA_BYTES)   # (the default context may have served other callers before)
 
     def _box(self, x, radius):
         return np.maximum(x - radius, self.lb), np.minimum(x + radius, self.ub)

@@ -51,7 +51,7 @@ def _common_asserts(run, f0, iters):
     if max(r["n"] for r in log) <= 2 * log[3]["n"]:
         assert len(set(arena[3:])) <= 3 and arena[-1] <= 1.02 * arena[3], arena
     nmax = max(r["n"] for r in log)
-    assert arena[-1] <= 64 * 8.0 * max(nmax, 512) ** 2 + (64 << 20), (arena[-1], nmax)
+    assert arena[-1] - run.arena0 <= 64 * 8.0 * max(nmax, 512) ** 2 + (64 << 20), (arena[-1], run.arena0, nmax)   # (growth of THIS run)
     assert all(r["residual"] < 1e-9 for r in log), [r["residual"] for r in log]
     assert all(r["interpolation"] < 1e-7 * max(1.0, np.abs(f0).max()) for r in log if "interpolation" in r)   # model == data at the iterate
     assert all(r["omega"] >= 0 for r in log)

@@ -596,3 +596,53 @@ def test_ps_ranking_kernels_share_one_exit_rule(lam):
         assert took_early >= 2, took_early     # the fixtures do exercise the early exit
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lam", [130, 700, 1320, 2600, 5160, 7000])
+def test_ps_plain_sort_in_registers_is_the_sort(lam):
+    """A generation without infeasible individuals is ranked by a bitonic network (ps_rank_kernel).  Round 6: E = 2 / 4 / 8 elements per
+    thread in registers -- compare-exchanges inside the thread, through wave shuffles, and only the widest strides through LDS.  Against
+    NumPy's stable order (objective, ties by index; individuals outside the budget -- f = phi = inf -- last) and against the
+    one-pair-per-thread form it replaces (impl 3): identical orders, also with duplicated objective values."""
+    import ctypes
+
+    from morbit.jl_amd import _lib
+
+    ctx = pkg.Context()
+    try:
+        rng = np.random.default_rng(lam)
+        for case in range(3):
+            f = rng.random(lam)
+            phi = np.zeros(lam)
+            if case == 1:
+                f = np.round(f, 2)                       # many ties: the index decides
+            if case == 2:
+                f[-9:], phi[-9:] = np.inf, np.inf        # outside the budget
+                f[: lam // 3] = f[lam // 3: 2 * (lam // 3)]
+            want = np.lexsort((np.arange(lam), f))
+            got = {}
+            for impl in (0, 3):
+                order = np.empty(lam, dtype=np.int32)
+                ctx.check(ctx.lib.mrbf_debug_ps_rank(ctx.h, lam, _lib.as_ptr(f), _lib.as_ptr(phi), 5, 1, impl, order.ctypes.data_as(_lib.c_ip), None))
+                got[impl] = order
+            assert np.array_equal(got[0], want), (lam, case, int(np.argmax(got[0] != want)))
+            assert np.array_equal(got[3], want), (lam, case)
+            # the step itself only reads the mu = ceil(lam / 7) parents: they are found by a sampled threshold + compaction and ranked
+            # alone (select_parents) -- the same parents in the same order as the full sort's prefix (impl 5), whatever the ties
+            mu = (lam + 6) // 7
+            for impl in (4, 5):
+                order = np.empty(lam, dtype=np.int32)
+                ctx.check(ctx.lib.mrbf_debug_ps_rank(ctx.h, lam, _lib.as_ptr(f), _lib.as_ptr(phi), 5, 1, impl, order.ctypes.data_as(_lib.c_ip), None))
+                assert np.array_equal(order[:mu], want[:mu]), (lam, case, impl, int(np.argmax(order[:mu] != want[:mu])))
+                assert np.all(order[mu:] == -1)
+        # massive ties (every objective value equal: the PS run's t = 0 individuals): the threshold takes everything, the selection
+        # steps aside for the full sort -- same parents
+        f = np.zeros(lam)
+        phi = np.zeros(lam)
+        for impl in (4, 5):
+            order = np.empty(lam, dtype=np.int32)
+            ctx.check(ctx.lib.mrbf_debug_ps_rank(ctx.h, lam, _lib.as_ptr(f), _lib.as_ptr(phi), 5, 1, impl, order.ctypes.data_as(_lib.c_ip), None))
+            assert np.array_equal(order[: (lam + 6) // 7], np.arange((lam + 6) // 7)), (lam, impl)
+    finally:
+        ctx.close()
