@@ -344,11 +344,13 @@ int32_t mrbf_ps_step_problem(mrbf_ctx *ctx, const mrbf_ps_problem *problem, cons
                              double *x_trial, double *mx_trial, double *r_out, mrbf_ps_info *info);
 /* test hook: ONE stochastic ranking (the ISRES-style pairwise rule of the PS solver, descent.jl:478-510's optimiser) of a given
  * generation -- f[lam] objective values, phi[lam] constraint violations (0 feasible, inf outside the budget) -- by the kernels of
- * the step: impl 0 one workgroup, 1 sixteen workgroups (lam >= 1024), 2 sixteen workgroups that give up at once (the time-out path),
+ * the step: impl 0 one workgroup, 1 several compute units (lam >= 1024: one wave per 64 individuals, the records in registers),
+ * 2 the same giving up at once (the time-out path), 6 the sixteen-workgroup form of round 5 (records in LDS),
+ * 7 a timing experiment (1 without the wait for the neighbours: not a ranking),
  * 3 one workgroup with the plain sort of a feasible generation in its one-pair-per-thread form (the form before round 6),
  * 4 one workgroup with the step's own mu = ceil(lam / 7): only the parents are ranked (order_out[mu ..] = -1), 5 the same without
  * the parent selection (the whole population sorted).
- * order_out[lam]: individuals in rank order; *gave_up: the several-workgroup kernel's failure word. */
+ * order_out[lam]: individuals in rank order; *gave_up: the several-compute-unit kernel's failure word. */
 int32_t mrbf_debug_ps_rank(mrbf_ctx *ctx, int32_t lam, const double *f, const double *phi, uint64_t seed, int32_t gen, int32_t impl,
                            int32_t *order_out, int32_t *gave_up);
 

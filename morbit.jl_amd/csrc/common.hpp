@@ -107,6 +107,7 @@ struct mrbf_ctx {
     int small_timeouts = 0;      // barrier time-outs of clustered launches in a row (three: clusters off for this context)
     int eval_check_call = 0;     // set around the residual check's evaluation at the model's own sites: eval_nsplit keeps the pre-round-5 rule for it (batch.hip does the same)
     int live_models = 0, live_round4 = 0;  // handles created through this context and not yet released (MRBF_OPT_LIVE_HANDLES)
+    unsigned ps_rank_epoch = 0;  // launches of the PS ranking's wave kernel so far (part of the tag its exchanged records carry)
     int ps_multi_off = 0;        // the several-workgroup PS ranking timed out on this context (a device shared with other work): one workgroup per run from then on
     std::map<long, float> mega_best_ms;
     std::vector<mrbf::MegaTables> mega_tables;  // LRU of job tables, one set per shape

@@ -42,10 +42,12 @@ constexpr int RANK_THREADS = 1024;
 constexpr int RS_THREADS = 512, RS_W = 16, RS_B = 256, RS_MINLAM = 1024;
 constexpr int RS_MAXWIN = ((MAXLAM + RS_W - 1) / RS_W + 2) + 2 * RS_B;
 constexpr int RS_SYNC = 64;  // sync words per run: [0] arrivals, [1] failure, [2] the run asks for the sort, [3] buffer that holds the result, [4 + c] chunk c moved something
+
 struct RankWs {  // device work space of the multi-workgroup ranking, run r at offset r * MAXLAM (r * RS_SYNC)
     double *f[2], *phi[2];
     int *idx[2];
     int *sync;
+    int *cnt;  // ps_rank_wave_kernel's keys: per run MAXLAM counts for f, MAXLAM for phi
 };
 
 struct Run {  // one (mu, lambda) run; all pointers into device arenas
@@ -489,9 +491,17 @@ __global__ __launch_bounds__(RANK_THREADS) void ps_rank_kernel(Args a, int mode,
     // array reaches the same order in log2(N) (log2(N) + 1) / 2 phases (91 instead of 5160 at lam = 5160).
     const bool plain_sort = s_infeas == 0 && !(a.dbg & 4);
     if (mode == 1) {
-        const bool hand_over = !plain_sort && !(a.dbg & 1) && lam >= RS_MINLAM;
-        if (tid < RS_SYNC) sy[tid] = (tid == 2 && hand_over) ? 1 : 0;
-        if (hand_over) return;
+        // (a NaN has no rank -- ps_rank_wave_kernel's keys are ranks -- so a generation that holds one stays here)
+        bool nan = false;
+        if (!plain_sort)
+            for (int i = tid; i < lam; i += NT) nan = nan || R.f[i] != R.f[i] || R.phi[i] != R.phi[i];
+        const bool hand_over = !plain_sort && !(a.dbg & 1) && lam >= RS_MINLAM && !__syncthreads_or(nan ? 1 : 0);
+        for (int i = tid; i < RS_SYNC; i += NT) sy[i] = (i == 2 && hand_over) ? 1 : 0;
+        if (hand_over) {
+            int *cnt = ws.cnt + (size_t)run * 2 * MAXLAM;
+            for (int i = tid; i < lam; i += NT) cnt[i] = cnt[MAXLAM + i] = 0;
+            return;
+        }
     }
     int *sidx;
     if (mode == 2 && sy[1] == 0) {  // the order found by ps_rank_sort_kernel
@@ -776,6 +786,262 @@ __global__ __launch_bounds__(RS_THREADS) void ps_rank_sort_kernel(Args a, RankWs
     }
 }
 
+// ---- the same phases with one WAVE per part and the records in registers (round 6; ps_rank_sort_kernel above stays as the A/B form,
+// MRBF_PS_MULTI=2).  The workgroup form pays an LDS round trip and a barrier of eight waves per phase (0.32 us: 425 us per ranking at
+// lam = 1320) and works on a window seven times its own part.  Here a wave holds a window of 128 records, two per lane (its own
+// RW_OWN = 64 in the middle, RW_H = 32 of either neighbour on each side), so an even phase is lane-local, an odd phase takes the
+// neighbouring lane's record by DPP (wave_shl / wave_shr), and no phase needs a barrier; after RW_H phases the waves publish their parts
+// (write-through stores of self-describing records: see the kernel) and take the neighbours' halves -- a wave waits for its two
+// neighbours only.  Every RS_B phases all waves of the run meet at the arrival counter for the one exit rule.
+// A wave alone on its SIMD issues one instruction every four cycles whatever its kind, so the instruction count of a phase IS its
+// time (measured 0.11 us with records of two doubles + index: 22 vector + 14 scalar instructions).  Two things are therefore taken
+// out of the phases and done beforehand on the whole chip by ps_rank_prep_kernel, since neither depends on the order so far:
+//   * the draws (Philox is 40 quarter-rate multiplies per four phases): one byte per (four-phase group, pair slot), bit q = "phase
+//     q of the group compares by objective";
+//   * the keys: the pairwise rule only ever asks fa > fb, pa > pb and pa == pb == 0, and rank(x) = #{j : x_j < x} answers the first
+//     two exactly (ties stay ties), so a record is TWO words -- (rank of f) << 16 | (0 if phi == 0, else 1 + rank of phi), and the
+//     index -- instead of five, compared by 16-bit integer compares.  (NaN has no rank: ps_rank_kernel does not hand such a
+//     generation over.)
+constexpr int RW_OWN = 64, RW_H = 32;
+constexpr int RW_CNT_T = 256;  // individuals per counting workgroup
+__host__ __device__ inline int rw_waves(int lam) { return (lam + RW_OWN - 1) / RW_OWN; }
+__host__ __device__ inline int rw_pitch(int lam) { return ((lam / 2 + RW_OWN + 63) / 64) * 64; }  // pair slots of a group, plus the last window's overhang
+__host__ __device__ inline int rw_jsplit(int lam) { return lam > 2048 ? 32 : 8; }                 // the counting's split of the "other individual" loop
+
+typedef unsigned long long u64;
+// grid.x = [draw workgroups | counting workgroups]; the counts (ws.cnt: lam objective counts, then lam violation counts per run) are
+// zeroed by ps_rank_kernel (mode 1) when it hands the generation over
+__global__ __launch_bounds__(256) void ps_rank_prep_kernel(Args a, RankWs ws, u64 *draws, size_t per_run, int draw_blocks) {
+    __shared__ double sf[RW_CNT_T], sp[RW_CNT_T];
+    const int run = blockIdx.y;
+    const Run &R = a.runs[run];
+    const int *sy = ws.sync + run * RS_SYNC;
+    if (R.stat[1] || sy[2] == 0) return;
+    const int lam = R.lam;
+    if ((int)blockIdx.x < draw_blocks) {
+        const int pitch = rw_pitch(lam), nblk = (lam + RW_H - 1) / RW_H, npair = lam / 2;
+        u64 *out = draws + (size_t)run * per_run;  // [block of RW_H phases][pair slot]: byte g = the block's g-th group of four phases
+        for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < (int64_t)nblk * pitch; e += (int64_t)draw_blocks * 256) {
+            const int blk = (int)(e / pitch), m = (int)(e % pitch);
+            u64 bits = 0;
+            if (m < npair) {
+#pragma unroll
+                for (int g = 0; g < RW_H / 4; ++g) {
+                    unsigned c4[4] = {(unsigned)m, (unsigned)(blk * RW_H + 4 * g), (unsigned)(a.gen * 16 + 1), (unsigned)run};
+                    philox(c4, (unsigned)a.seed, (unsigned)(a.seed >> 32));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        bits |= (((double)c4[q] + 0.5) * (1.0 / 4294967296.0) < 0.45) ? (1ull << (8 * g + q)) : 0ull;
+                }
+            }
+            out[e] = bits;
+        }
+        return;
+    }
+    // counting: workgroup (ib, js) counts, for its 256 individuals i, the j of its share with f_j < f_i and with phi_j < phi_i
+    const int cb = (int)blockIdx.x - draw_blocks, nib = (lam + RW_CNT_T - 1) / RW_CNT_T, js = cb / nib, ib = cb % nib, nsplit = rw_jsplit(lam);
+    if (js >= nsplit) return;
+    const int i = ib * RW_CNT_T + threadIdx.x;
+    const double fi = i < lam ? R.f[i] : 0.0, pi = i < lam ? R.phi[i] : 0.0;
+    const int per = (lam + nsplit - 1) / nsplit, j0 = js * per, j1 = min(lam, j0 + per);
+    int cf = 0, cp = 0;
+    for (int jb = j0; jb < j1; jb += RW_CNT_T) {
+        const int nj = min(RW_CNT_T, j1 - jb);
+        __syncthreads();
+        if ((int)threadIdx.x < nj) {
+            sf[threadIdx.x] = R.f[jb + threadIdx.x];
+            sp[threadIdx.x] = R.phi[jb + threadIdx.x];
+        }
+        __syncthreads();
+        for (int j = 0; j < nj; ++j) {
+            cf += sf[j] < fi ? 1 : 0;
+            cp += sp[j] < pi ? 1 : 0;
+        }
+    }
+    if (i < lam) {
+        int *cnt = ws.cnt + (size_t)run * 2 * MAXLAM;
+        atomicAdd(cnt + i, cf);
+        atomicAdd(cnt + MAXLAM + i, cp);
+    }
+}
+
+// lane mask in a scalar register pair ? a : b
+__device__ __forceinline__ unsigned msel(u64 m, unsigned a, unsigned b) {
+    unsigned d;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(d) : "v"(b), "v"(a), "s"(m));
+    return d;
+}
+// 16-bit compares of the two halves of a key, straight into a lane mask
+__device__ __forceinline__ u64 gt_hi16(unsigned a, unsigned b) {
+    u64 m;
+    asm("v_cmp_gt_u16_sdwa %0, %1, %2 src0_sel:WORD_1 src1_sel:WORD_1" : "=s"(m) : "v"(a), "v"(b));
+    return m;
+}
+__device__ __forceinline__ u64 gt_lo16(unsigned a, unsigned b) {
+    u64 m;
+    asm("v_cmp_gt_u16_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b));
+    return m;
+}
+__device__ __forceinline__ u64 zero_lo16(unsigned a) {
+    u64 m;
+    asm("v_cmp_eq_u16_e64 %0, 0, %1" : "=s"(m) : "v"(a));
+    return m;
+}
+// (bound_ctrl: the lane without a source reads 0 -- its pair is masked off -- and the move needs no initialised destination)
+__device__ __forceinline__ unsigned dpp_from_next(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true); }  // wave_shl:1 -- lane l reads lane l + 1
+__device__ __forceinline__ unsigned dpp_from_prev(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true); }  // wave_shr:1 -- lane l reads lane l - 1
+
+// RW_H phases on a window (KA / KB the keys, IA / IB the individuals of this lane's two positions).  TAIL: the ranking's last, short
+// block -- phases from nph on do nothing.
+template <bool TAIL>
+__device__ __forceinline__ void rw_block(unsigned &KA, unsigned &KB, unsigned &IA, unsigned &IB, u64 dbits, int nph, u64 mPairE, u64 mPairO, u64 mOwnE,
+                                         u64 mOwnO, u64 &moved) {
+#pragma unroll
+    for (int g = 0; g < RW_H / 4; ++g) {
+        const unsigned dg = (unsigned)(dbits >> (8 * g));  // (g < 4: low word, else high word -- resolved at compile time)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const u64 live = (!TAIL || 4 * g + q < nph) ? ~0ull : 0ull;
+            const u64 mDraw = __builtin_amdgcn_ballot_w64((dg & (1u << q)) != 0u);
+            if ((q & 1) == 0) {
+                const u64 gtf = gt_hi16(KA, KB), gtp = gt_lo16(KA, KB);
+                const u64 byf = zero_lo16(KA | KB) | mDraw;
+                u64 worse = mPairE & (gtp ^ (byf & (gtf ^ gtp)));
+                if (TAIL) worse &= live;
+                const unsigned tk = KA, ti = IA;
+                KA = msel(worse, KB, KA);
+                IA = msel(worse, IB, IA);
+                KB = msel(worse, tk, KB);
+                IB = msel(worse, ti, IB);
+                moved |= worse & mOwnE;
+            } else {
+                const unsigned KN = dpp_from_next(KA);
+                const u64 gtf = gt_hi16(KB, KN), gtp = gt_lo16(KB, KN);
+                const u64 byf = zero_lo16(KB | KN) | mDraw;
+                u64 worse = mPairO & (gtp ^ (byf & (gtf ^ gtp)));
+                if (TAIL) worse &= live;
+                const u64 wprev = worse << 1;  // lane l + 1 takes lane l's second record when lane l's pair swaps
+                const unsigned IN = dpp_from_next(IA), KP = dpp_from_prev(KB), IP = dpp_from_prev(IB);
+                KB = msel(worse, KN, KB);
+                IB = msel(worse, IN, IB);
+                KA = msel(wprev, KP, KA);
+                IA = msel(wprev, IP, IA);
+                moved |= worse & mOwnO;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void ps_rank_wave_kernel(Args a, RankWs ws, const u64 *draws, size_t per_run, unsigned epoch) {
+    const int run = blockIdx.y, w = blockIdx.x, lane = threadIdx.x;
+    const Run &R = a.runs[run];
+    int *const sy = ws.sync + run * RS_SYNC;
+    if (R.stat[1] || sy[2] == 0) return;
+    const int lam = R.lam, nw = rw_waves(lam);
+    if (w >= nw) return;
+    if (a.dbg & 64) {  // (test switch: give up at once, as after a counter time-out)
+        if (lane == 0) __hip_atomic_store(sy + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    const size_t ro = (size_t)run * MAXLAM;
+    // exchange buffers (the words of ws.f): a record travels as ONE 64-bit word -- key << 32 | tag << 16 | individual, tag = (launch, block)
+    // -- so the word itself says when it has arrived: the reader polls the records it needs, there is no flag to write after the data
+    // and no wait for the stores to be acknowledged (one trip through memory per exchange instead of three).  A buffer is rewritten
+    // every second block and neighbours are never more than one block apart (a wave publishes block b + 1 only after it has taken
+    // its neighbours' block b), so a reader cannot miss a record; records of earlier launches carry another launch number.
+    u64 *const xr[2] = {reinterpret_cast<u64 *>(ws.f[0]) + ro, reinterpret_cast<u64 *>(ws.f[1]) + ro};
+    const int s0 = w * RW_OWN, e0 = min(lam, s0 + RW_OWN), ws0 = s0 - RW_H;  // (ws0 even; negative for the first wave)
+    const int gA = ws0 + 2 * lane, gB = gA + 1;                              // this lane's two positions
+    const bool inA = gA >= 0 && gA < lam, inB = gB >= 0 && gB < lam;
+    const bool ownA = gA >= s0 && gA < e0, ownB = gB >= s0 && gB < e0;
+    const bool needA = inA && !ownA, needB = inB && !ownB;
+    // lane masks (scalar registers): the decisions of a phase are mask arithmetic on the scalar unit, the vector unit compares and selects
+    const u64 mPairE = __builtin_amdgcn_ballot_w64(inA && inB);                          // even phases: (gA, gB), lane-local
+    const u64 mPairO = __builtin_amdgcn_ballot_w64(inB && gB + 1 < lam && lane < 63);    // odd phases: (gB, next lane's gA)
+    const u64 mOwnE = __builtin_amdgcn_ballot_w64(ownA), mOwnO = __builtin_amdgcn_ballot_w64(ownB);  // the pair's left position lies in this wave's part
+    const int slot = max(0, gA >> 1);  // pair slot of both of this lane's pairs
+    const int pitch = rw_pitch(lam);
+    const u64 *dr = draws + (size_t)run * per_run + slot;
+    const int *cnt = ws.cnt + (size_t)run * 2 * MAXLAM;
+    unsigned KA = 0, KB = 0, IA = (unsigned)gA, IB = (unsigned)gB;
+    if (inA) KA = ((unsigned)cnt[gA] << 16) | (R.phi[gA] == 0.0 ? 0u : 1u + (unsigned)cnt[MAXLAM + gA]);
+    if (inB) KB = ((unsigned)cnt[gB] << 16) | (R.phi[gB] == 0.0 ? 0u : 1u + (unsigned)cnt[MAXLAM + gB]);
+    const int nblk = (lam + RW_H - 1) / RW_H;
+    u64 moved = 0;
+    u64 dnext = dr[0];
+    for (int blk = 0; blk < nblk; ++blk) {
+        const int phb = blk * RW_H;
+        const u64 dbits = dnext;
+        if (blk + 1 < nblk) dnext = dr[(size_t)(blk + 1) * pitch];  // (next block's draws: in flight over this block)
+        if (phb + RW_H <= lam)
+            rw_block<false>(KA, KB, IA, IB, dbits, RW_H, mPairE, mPairO, mOwnE, mOwnO, moved);
+        else
+            rw_block<true>(KA, KB, IA, IB, dbits, lam - phb, mPairE, mPairO, mOwnE, mOwnO, moved);
+        // ---- publish this wave's part
+        const int db = blk & 1;
+        const unsigned tag = ((epoch & 0xffu) << 8) | (unsigned)(blk + 1);
+        if (ownA) __hip_atomic_store(xr[db] + gA, ((u64)KA << 32) | (tag << 16) | IA, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ownB) __hip_atomic_store(xr[db] + gB, ((u64)KB << 32) | (tag << 16) | IB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool chunk_end = ((blk + 1) * RW_H) % RS_B == 0 || blk + 1 == nblk;
+        const int c = (blk * RW_H) / RS_B;
+        const unsigned long long t0 = rs_clock();
+        int ok = 1, any = 1;
+        if (chunk_end) {  // ---- every RS_B phases: all waves of the run meet for the exit rule
+            if (lane == 0) {
+                if (moved != 0) __hip_atomic_fetch_or(sy + 4 + c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(sy, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);  // (orders the "moved" flag before the count)
+                int spins = 0;
+                while (__hip_atomic_load(sy, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < nw * (c + 1)) {
+                    if ((++spins & 15) == 0 && (__hip_atomic_load(sy + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || rs_clock() - t0 > 500000ull)) {  // 5 ms
+                        ok = 0;
+                        break;
+                    }
+                }
+                if (ok) any = __hip_atomic_load(sy + 4 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            ok = __builtin_amdgcn_readfirstlane(ok);
+            any = __builtin_amdgcn_readfirstlane(any);
+            moved = 0;
+            if (ok && (!any || blk + 1 == nblk)) {  // nothing moved in RS_B phases (ranked under the drawn rules), or all phases done
+                int *out = ws.idx[0] + ro;          // the order, for the finishing launch
+                if (ownA) out[gA] = (int)IA;
+                if (ownB) out[gB] = (int)IB;
+                if (w == 0 && lane == 0) sy[3] = 0;
+                return;
+            }
+        }
+        // ---- take the neighbours' halves: poll the records until they carry this block's tag
+        if (ok && !(a.dbg & 1024)) {  // (1024, a timing experiment: no wait for the neighbours -- the result is not a ranking)
+            int spins = 0;
+            for (;;) {
+                const u64 ra = needA ? __hip_atomic_load(xr[db] + gA, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                const u64 rb = needB ? __hip_atomic_load(xr[db] + gB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                const bool okA = !needA || (((unsigned)ra >> 16) == tag), okB = !needB || (((unsigned)rb >> 16) == tag);
+                if (okA && needA) {
+                    KA = (unsigned)(ra >> 32);
+                    IA = (unsigned)ra & 0xffffu;
+                }
+                if (okB && needB) {
+                    KB = (unsigned)(rb >> 32);
+                    IB = (unsigned)rb & 0xffffu;
+                }
+                if (__builtin_amdgcn_ballot_w64(!(okA && okB)) == 0) break;
+                if ((++spins & 15) == 0 && (__hip_atomic_load(sy + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || rs_clock() - t0 > 500000ull)) {  // 5 ms
+                    ok = 0;
+                    break;
+                }
+            }
+        }
+        if (!ok) {
+            if (lane == 0) {
+                __hip_atomic_store(sy + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(ws.sync + RS_SYNC * MAXRUNS, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (sticky: the host stops using this kernel)
+            }
+            return;
+        }
+    }
+}
+
 // ---- next generation: one wave per offspring, lanes over the components
 __global__ __launch_bounds__(256) void ps_breed_kernel(Args a) {
     const int lane = threadIdx.x & 63;
@@ -868,6 +1134,40 @@ struct Problem {
 }  // namespace ps
 
 // all model outputs at m points (row-major m x nftot) and, optionally (m == 1), the objectives' Jacobian rows
+// work space of the several-compute-unit ranking + the launches of its phases (form 1: one wave per part, ps_rank_wave_kernel, after
+// the draws; form 2: the workgroup form of round 5, ps_rank_sort_kernel)
+// work space of the several-compute-unit ranking + the launches of its phases (form 1: one wave per part, ps_rank_wave_kernel, after
+// the draws and the keys; form 2: the workgroup form of round 5, ps_rank_sort_kernel)
+static int rank_ws_setup(mrbf_ctx *ctx, int maxlam, ps::RankWs &rw, unsigned long long **draws, size_t *draws_per_run) {
+    using namespace ps;
+    double *wsb;
+    const size_t per_run = (size_t)MAXLAM * 6 + RS_SYNC / 2;  // f, phi twice, idx twice and the two counts (as doubles: 4 x 1/2), sync words
+    *draws_per_run = (size_t)((maxlam + RW_H - 1) / RW_H) * rw_pitch(maxlam);
+    MRBF_TRY(get_buf(ctx, S_PS_RANK, per_run * MAXRUNS + 64 + *draws_per_run * MAXRUNS, &wsb));
+    rw.f[0] = wsb;
+    rw.f[1] = rw.f[0] + (size_t)MAXLAM * MAXRUNS;
+    rw.phi[0] = rw.f[1] + (size_t)MAXLAM * MAXRUNS;
+    rw.phi[1] = rw.phi[0] + (size_t)MAXLAM * MAXRUNS;
+    rw.idx[0] = reinterpret_cast<int *>(rw.phi[1] + (size_t)MAXLAM * MAXRUNS);
+    rw.idx[1] = rw.idx[0] + (size_t)MAXLAM * MAXRUNS;
+    rw.cnt = rw.idx[1] + (size_t)MAXLAM * MAXRUNS;
+    rw.sync = rw.cnt + (size_t)2 * MAXLAM * MAXRUNS;
+    *draws = reinterpret_cast<unsigned long long *>(wsb + per_run * MAXRUNS + 64);
+    MRBF_HIP(ctx, hipMemsetAsync(rw.sync + RS_SYNC * MAXRUNS, 0, sizeof(int), ctx->stream));
+    return MRBF_OK;
+}
+static void rank_phases_launch(mrbf_ctx *ctx, const ps::Args &a, const ps::RankWs &rw, unsigned long long *draws, size_t draws_per_run, int maxlam, int form) {
+    using namespace ps;
+    if (form == 2) {
+        hipLaunchKernelGGL(ps_rank_sort_kernel, dim3(RS_W, (unsigned)a.nruns), dim3(RS_THREADS), 0, ctx->stream, a, rw);
+        return;
+    }
+    const int draw_blocks = (int)std::min<size_t>(512, (draws_per_run + 255) / 256);
+    const int count_blocks = ((maxlam + RW_CNT_T - 1) / RW_CNT_T) * rw_jsplit(maxlam);
+    hipLaunchKernelGGL(ps_rank_prep_kernel, dim3((unsigned)(draw_blocks + count_blocks), (unsigned)a.nruns), dim3(256), 0, ctx->stream, a, rw, draws, draws_per_run, draw_blocks);
+    hipLaunchKernelGGL(ps_rank_wave_kernel, dim3((unsigned)rw_waves(maxlam), (unsigned)a.nruns), dim3(64), 0, ctx->stream, a, rw, draws, draws_per_run, ++ctx->ps_rank_epoch);
+}
+
 static int ps_eval_points(mrbf_ctx *ctx, const ps::Problem &P, const double *x_host, int m, std::vector<double> &allF, std::vector<double> *Jobj) {
     const int d = P.d;
     double *dX;
@@ -1258,21 +1558,11 @@ extern "C" int32_t mrbf_ps_step_problem(mrbf_ctx *ctx, const mrbf_ps_problem *pr
         RankWs rw{};
         // (a counter wait that times out -- the workgroups of a run not resident together: a device shared with other work -- costs 5 ms; the
         // host sees the sticky failure word with the status words, every eight generations, and keeps to one workgroup per run from then on)
-        bool multi = maxlam >= RS_MINLAM && ctx->ncu >= RS_W * a.nruns && !ctx->ps_multi_off &&
-                     !(mrbf_env("MRBF_PS_MULTI") && atoi(mrbf_env("MRBF_PS_MULTI")) == 0);
-        if (multi) {
-            double *wsb;
-            const size_t per_run = (size_t)MAXLAM * 5 + RS_SYNC / 2;  // f, phi twice, idx twice (as doubles: 2 x 1/2), sync words
-            MRBF_TRY(get_buf(ctx, S_PS_RANK, per_run * MAXRUNS + 64, &wsb));
-            rw.f[0] = wsb;
-            rw.f[1] = rw.f[0] + (size_t)MAXLAM * MAXRUNS;
-            rw.phi[0] = rw.f[1] + (size_t)MAXLAM * MAXRUNS;
-            rw.phi[1] = rw.phi[0] + (size_t)MAXLAM * MAXRUNS;
-            rw.idx[0] = reinterpret_cast<int *>(rw.phi[1] + (size_t)MAXLAM * MAXRUNS);
-            rw.idx[1] = rw.idx[0] + (size_t)MAXLAM * MAXRUNS;
-            rw.sync = rw.idx[1] + (size_t)MAXLAM * MAXRUNS;
-            MRBF_HIP(ctx, hipMemsetAsync(rw.sync + RS_SYNC * MAXRUNS, 0, sizeof(int), ctx->stream));
-        }
+        const int multi_env = mrbf_env("MRBF_PS_MULTI") ? atoi(mrbf_env("MRBF_PS_MULTI")) : 1;  // 0: one workgroup per run; 2: the workgroup form of round 5
+        bool multi = maxlam >= RS_MINLAM && ctx->ncu >= RS_W * a.nruns && !ctx->ps_multi_off && multi_env != 0;
+        unsigned long long *draws = nullptr;
+        size_t draws_per_run = 0;
+        if (multi) MRBF_TRY(rank_ws_setup(ctx, maxlam, rw, &draws, &draws_per_run));
         hipLaunchKernelGGL(ps_init_kernel, dim3((unsigned)((maxel + 255) / 256), (unsigned)a.nruns), dim3(256), 0, ctx->stream, a, start, t0);
         std::vector<int> hstat((size_t)4 * a.nruns);
         const unsigned wave_blocks = (unsigned)((a.rows + 3) / 4);
@@ -1283,7 +1573,7 @@ extern "C" int32_t mrbf_ps_step_problem(mrbf_ctx *ctx, const mrbf_ps_problem *pr
             hipLaunchKernelGGL(ps_score_kernel, dim3(wave_blocks), dim3(256), 0, ctx->stream, a);
             hipLaunchKernelGGL(ps_rank_kernel, dim3((unsigned)a.nruns), dim3(rank_threads), shm, ctx->stream, a, multi ? 1 : 0, rw);
             if (multi) {
-                hipLaunchKernelGGL(ps_rank_sort_kernel, dim3(RS_W, (unsigned)a.nruns), dim3(RS_THREADS), 0, ctx->stream, a, rw);
+                rank_phases_launch(ctx, a, rw, draws, draws_per_run, maxlam, multi_env == 2 ? 2 : 1);
                 hipLaunchKernelGGL(ps_rank_kernel, dim3((unsigned)a.nruns), dim3(rank_threads), shm, ctx->stream, a, 2, rw);
             }
             hipLaunchKernelGGL(ps_breed_kernel, dim3(wave_blocks), dim3(256), 0, ctx->stream, a);
@@ -1453,8 +1743,9 @@ extern "C" int32_t mrbf_ps_step(mrbf_ctx *ctx, const mrbf_model *model, const do
 }
 
 // Test hook: ONE ranking of a given generation (objective values f, violations phi; inf = outside the budget) by the kernels of the
-// step above -- impl 0: ps_rank_kernel alone (one workgroup); 1: hand-over to ps_rank_sort_kernel (sixteen workgroups) and the
-// finishing launch; 2: the same with the sort kernel giving up at once (what a counter time-out leaves behind).  order_out[lam] = the
+// step above -- impl 0: ps_rank_kernel alone (one workgroup); 1: hand-over to ps_rank_wave_kernel (one wave per 64 individuals) and the
+// finishing launch; 2: the same with the kernel giving up at once (what a counter time-out leaves behind); 6: hand-over to
+// ps_rank_sort_kernel (sixteen workgroups, round 5); 3 - 5: see include/mrbf.h.  order_out[lam] = the
 // individuals in rank order.  Lets the tests put crafted populations (nearly ranked, a few infeasible individuals: the no-swap exit
 // is taken early) through both kernels and compare the orders entry by entry.
 extern "C" int32_t mrbf_debug_ps_rank(mrbf_ctx *ctx, int32_t lam, const double *f, const double *phi, uint64_t seed, int32_t gen,
@@ -1464,8 +1755,8 @@ extern "C" int32_t mrbf_debug_ps_rank(mrbf_ctx *ctx, int32_t lam, const double *
     if (lam < 2 || lam > MAXLAM) return fail(ctx, -2, "mrbf_debug_ps_rank: lam = %d outside 2..%d", lam, MAXLAM);
     if (!f || !phi) return fail(ctx, -3, "f / phi is NULL");
     if (gen < 0) return fail(ctx, -6, "gen < 0");
-    if (impl < 0 || impl > 5) return fail(ctx, -7, "impl must be 0 .. 5");
-    if ((impl == 1 || impl == 2) && lam < RS_MINLAM) return fail(ctx, -7, "mrbf_debug_ps_rank: the several-workgroup ranking takes populations >= %d", RS_MINLAM);
+    if (impl < 0 || impl > 7) return fail(ctx, -7, "impl must be 0 .. 7");
+    if ((impl == 1 || impl == 2 || impl == 6 || impl == 7) && lam < RS_MINLAM) return fail(ctx, -7, "mrbf_debug_ps_rank: the several-workgroup ranking takes populations >= %d", RS_MINLAM);
     if (!order_out) return fail(ctx, -8, "order_out is NULL");
     (void)hipSetDevice(ctx->device);
     double *base;
@@ -1478,7 +1769,7 @@ extern "C" int32_t mrbf_debug_ps_rank(mrbf_ctx *ctx, int32_t lam, const double *
     a.seed = seed;
     a.gen = gen;
     a.xtol_rel = 1e-3;
-    a.dbg = impl == 2 ? 64 : (impl == 3 ? 128 : (impl == 5 ? 256 : (impl == 4 ? 512 : 0)));  // (3: the plain sort as one pair per thread through LDS; 5: no parent selection)
+    a.dbg = impl == 2 ? 64 : (impl == 3 ? 128 : (impl == 5 ? 256 : (impl == 4 ? 512 : (impl == 7 ? 1024 : 0))));  // (3: the plain sort as one pair per thread through LDS; 5: no parent selection)
     R.nvar = 1;
     R.lam = lam;
     R.mu = (impl == 4 || impl == 5) ? (lam + 6) / 7 : lam;  // mu = lam: the whole order comes out; 4 / 5: the step's own mu (order_out beyond it: -1)
@@ -1501,27 +1792,18 @@ extern "C" int32_t mrbf_debug_ps_rank(mrbf_ctx *ctx, int32_t lam, const double *
     MRBF_HIP(ctx, hipFuncSetAttribute((const void *)ps_rank_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
     const int rank_threads = (int)std::min<int64_t>(RANK_THREADS, std::max<int64_t>(64, round_up(N / 2, 64)));
     RankWs rw{};
-    if (impl == 1 || impl == 2) {
-        double *wsb;
-        const size_t per_run = (size_t)MAXLAM * 5 + RS_SYNC / 2;
-        MRBF_TRY(get_buf(ctx, S_PS_RANK, per_run * MAXRUNS + 64, &wsb));
-        rw.f[0] = wsb;
-        rw.f[1] = rw.f[0] + (size_t)MAXLAM * MAXRUNS;
-        rw.phi[0] = rw.f[1] + (size_t)MAXLAM * MAXRUNS;
-        rw.phi[1] = rw.phi[0] + (size_t)MAXLAM * MAXRUNS;
-        rw.idx[0] = reinterpret_cast<int *>(rw.phi[1] + (size_t)MAXLAM * MAXRUNS);
-        rw.idx[1] = rw.idx[0] + (size_t)MAXLAM * MAXRUNS;
-        rw.sync = rw.idx[1] + (size_t)MAXLAM * MAXRUNS;
-        MRBF_HIP(ctx, hipMemsetAsync(rw.sync + RS_SYNC * MAXRUNS, 0, sizeof(int), ctx->stream));
-    }
-    hipLaunchKernelGGL(ps_rank_kernel, dim3(1), dim3(rank_threads), shm, ctx->stream, a, (impl == 1 || impl == 2) ? 1 : 0, rw);
-    if (impl == 1 || impl == 2) {
-        hipLaunchKernelGGL(ps_rank_sort_kernel, dim3(RS_W, 1), dim3(RS_THREADS), 0, ctx->stream, a, rw);
+    const bool several = impl == 1 || impl == 2 || impl == 6 || impl == 7;
+    unsigned long long *draws = nullptr;
+    size_t draws_per_run = 0;
+    if (several) MRBF_TRY(rank_ws_setup(ctx, lam, rw, &draws, &draws_per_run));
+    hipLaunchKernelGGL(ps_rank_kernel, dim3(1), dim3(rank_threads), shm, ctx->stream, a, several ? 1 : 0, rw);
+    if (several) {
+        rank_phases_launch(ctx, a, rw, draws, draws_per_run, lam, impl == 6 ? 2 : 1);
         hipLaunchKernelGGL(ps_rank_kernel, dim3(1), dim3(rank_threads), shm, ctx->stream, a, 2, rw);
     }
     MRBF_HIP(ctx, hipGetLastError());
     int hsync[2] = {0, 0};
-    if (impl == 1 || impl == 2) MRBF_HIP(ctx, hipMemcpyAsync(hsync, rw.sync, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    if (several) MRBF_HIP(ctx, hipMemcpyAsync(hsync, rw.sync, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     MRBF_HIP(ctx, hipMemsetAsync(R.order + R.mu, 0xff, (size_t)(lam - R.mu) * sizeof(int), ctx->stream));
     MRBF_HIP(ctx, hipMemcpyAsync(order_out, R.order, (size_t)lam * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));

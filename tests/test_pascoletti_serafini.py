@@ -224,8 +224,9 @@ def _check_ps_contract(ev_obj, ev_con, x, lb, ub, fx, omega, xt, mt, stats, lin=
 
 @pytest.mark.gpu
 def test_ps_ranking_on_several_compute_units_is_the_same_ranking():
-    """Populations of 1024 individuals and more (d >= 51) are ranked by sixteen workgroups per run (ps_rank_sort_kernel: chunks of 256
-    transposition phases on windows with halos, exchanged through global memory).  Same comparisons, same draws: the step must be THE
+    """Populations of 1024 individuals and more (d >= 51) are ranked on several compute units per run (ps_rank_wave_kernel: one wave per
+    64 individuals, blocks of 32 transposition phases on windows with halos, exchanged through global memory; MRBF_PS_MULTI=2: round 5's
+    sixteen workgroups, ps_rank_sort_kernel).  Same comparisons, same draws: the step must be THE
     step of the one-workgroup ranking (MRBF_PS_MULTI=0) bit for bit -- also when the several-workgroup kernel gives up (MRBF_PS_DBG=64:
     the failure word is set at once and the finishing launch runs the phases itself), and when the phases are forced on generations
     that a sort would rank (MRBF_PS_DBG=4)."""
@@ -241,7 +242,7 @@ def test_ps_ranking_on_several_compute_units_is_the_same_ranking():
     fx = pkg.eval_models_at_sites(mod, None, x[None, :])[0]
     cfg = ps.PascolettiSerafiniConfig()
     out = {}
-    for tag, env in (("multi", {}), ("single", {"MRBF_PS_MULTI": "0"}), ("gave-up", {"MRBF_PS_DBG": "64"}), ("multi/phases", {"MRBF_PS_DBG": "4"}),
+    for tag, env in (("multi", {}), ("single", {"MRBF_PS_MULTI": "0"}), ("workgroups", {"MRBF_PS_MULTI": "2"}), ("gave-up", {"MRBF_PS_DBG": "64"}), ("multi/phases", {"MRBF_PS_DBG": "4"}),
                      ("single/phases", {"MRBF_PS_MULTI": "0", "MRBF_PS_DBG": "4"})):
         os.environ.update(env)
         try:
@@ -251,11 +252,11 @@ def test_ps_ranking_on_several_compute_units_is_the_same_ranking():
         finally:
             for kk in env:
                 os.environ.pop(kk, None)
-    for tag in ("single", "gave-up", "multi/phases", "single/phases"):
+    for tag in ("single", "workgroups", "gave-up", "multi/phases", "single/phases"):
         assert out[tag][0] == out["multi"][0] and np.array_equal(out[tag][1], out["multi"][1]) and out[tag][2] == out["multi"][2], tag
     assert out["multi"][0] > 0
-    print("PS ranking d=%d (lambda %d): %.1f ms on sixteen workgroups per run, %.1f ms on one, %.1f ms after a give-up; identical steps"
-          % (d, 20 * (d + 2), out["multi"][3], out["single"][3], out["gave-up"][3]))
+    print("PS ranking d=%d (lambda %d): %.1f ms with a wave per 64 individuals, %.1f ms on sixteen workgroups per run, %.1f ms on one, %.1f ms after a give-up; identical steps"
+          % (d, 20 * (d + 2), out["multi"][3], out["workgroups"][3], out["single"][3], out["gave-up"][3]))
     mod.free()
 
 
@@ -569,8 +570,10 @@ def test_ps_ranking_kernels_share_one_exit_rule(lam):
     """the one-workgroup ranking used to leave after sixteen quiet phases, the sixteen-workgroup ranking only at its
     256-phase chunk boundaries -- different orders whenever the exit is taken early, e.g. after a counter time-out on a shared device.
     Now one rule per population size.  Crafted generations (nearly ranked, a few infeasible individuals at the parent boundary: the
-    exit IS taken early) through mrbf_debug_ps_rank: one workgroup == sixteen workgroups == sixteen workgroups giving up at once ==
-    the plain NumPy loop of oracle/ps_rank_oracle.py, entry by entry."""
+    exit IS taken early) through mrbf_debug_ps_rank: one workgroup == one wave per 64 individuals on as many compute units (round 6,
+    impl 1) == that kernel giving up at once == sixteen workgroups (round 5's form, impl 6) ==
+    the plain NumPy loop of
+    oracle/ps_rank_oracle.py, entry by entry."""
     import ctypes
 
     from morbit.jl_amd import _lib
@@ -584,14 +587,14 @@ def test_ps_ranking_kernels_share_one_exit_rule(lam):
                 want, phases = pro.stochastic_rank(f, phi, seed=seed, gen=gen)
                 took_early += phases < lam
                 got = {}
-                for impl in (0, 1, 2):
+                for impl in (0, 1, 2, 6):
                     order = np.empty(lam, dtype=np.int32)
                     gave_up = ctypes.c_int32(-1)
                     ctx.check(ctx.lib.mrbf_debug_ps_rank(ctx.h, lam, _lib.as_ptr(f), _lib.as_ptr(phi), seed, gen, impl,
                                                          order.ctypes.data_as(_lib.c_ip), ctypes.byref(gave_up)))
                     assert gave_up.value == (1 if impl == 2 else 0), (name, impl, gave_up.value)
                     got[impl] = order
-                for impl in (0, 1, 2):
+                for impl in (0, 1, 2, 6):
                     assert np.array_equal(got[impl], want), (lam, name, seed, gen, impl, int(np.argmax(got[impl] != want)))
         assert took_early >= 2, took_early     # the fixtures do exercise the early exit
     finally:
