@@ -48,6 +48,7 @@ struct RankWs {  // device work space of the multi-workgroup ranking, run r at o
     int *idx[2];
     int *sync;
     int *cnt;  // ps_rank_wave_kernel's keys: per run MAXLAM counts for f, MAXLAM for phi
+    int count_plain;  // ps_rank_prep_kernel is part of the launch sequence: a generation without violations is ranked by counting there
 };
 
 struct Run {  // one (mu, lambda) run; all pointers into device arenas
@@ -491,20 +492,32 @@ __global__ __launch_bounds__(RANK_THREADS) void ps_rank_kernel(Args a, int mode,
     // array reaches the same order in log2(N) (log2(N) + 1) / 2 phases (91 instead of 5160 at lam = 5160).
     const bool plain_sort = s_infeas == 0 && !(a.dbg & 4);
     if (mode == 1) {
-        // (a NaN has no rank -- ps_rank_wave_kernel's keys are ranks -- so a generation that holds one stays here)
+        // Populations of RS_MINLAM and more leave this workgroup here, either way:
+        //   sy[2] = 1  violations inside the budget: the transposition phases on several compute units (ps_rank_wave_kernel)
+        //   sy[2] = 2  none: the sorted order by COUNTING on the whole chip -- rank(i) = #{j : f_j < f_i, or f_j = f_i and j < i} is the
+        //              position of i in the stable sort by f, lam^2 independent comparisons (ps_rank_prep_kernel, a few us) instead of
+        //              a bitonic network in this one workgroup (34 / 61 / 71 us at lam = 1320 / 2600 / 5160, half of a generation of
+        //              an ideal-point run at d = 128); the finishing launch (mode 2) turns the counts into the parents' list.
+        // (a NaN has no rank, so a generation that holds one stays here)
         bool nan = false;
-        if (!plain_sort)
+        if (lam >= RS_MINLAM)
             for (int i = tid; i < lam; i += NT) nan = nan || R.f[i] != R.f[i] || R.phi[i] != R.phi[i];
-        const bool hand_over = !plain_sort && !(a.dbg & 1) && lam >= RS_MINLAM && !__syncthreads_or(nan ? 1 : 0);
-        for (int i = tid; i < RS_SYNC; i += NT) sy[i] = (i == 2 && hand_over) ? 1 : 0;
-        if (hand_over) {
+        const bool leave = !(a.dbg & 1) && lam >= RS_MINLAM && !__syncthreads_or(nan ? 1 : 0);
+        const int kind = !leave ? 0 : (!plain_sort ? 1 : ((ws.count_plain && !(a.dbg & (128 | 256 | 512))) ? 2 : 0));
+        for (int i = tid; i < RS_SYNC; i += NT) sy[i] = i == 2 ? kind : 0;
+        if (kind) {
             int *cnt = ws.cnt + (size_t)run * 2 * MAXLAM;
             for (int i = tid; i < lam; i += NT) cnt[i] = cnt[MAXLAM + i] = 0;
             return;
         }
     }
     int *sidx;
-    if (mode == 2 && sy[1] == 0) {  // the order found by ps_rank_sort_kernel
+    if (mode == 2 && sy[2] == 2) {  // the positions found by counting (ps_rank_prep_kernel)
+        sidx = (int *)smem;
+        const int *cnt = ws.cnt + (size_t)run * 2 * MAXLAM;
+        for (int i = tid; i < lam; i += NT) sidx[cnt[i]] = i;
+        __syncthreads();
+    } else if (mode == 2 && sy[1] == 0) {  // the order found by ps_rank_wave_kernel / ps_rank_sort_kernel
         sidx = (int *)smem;
         const int *src = ws.idx[sy[3]] + (size_t)run * MAXLAM;
         for (int i = tid; i < lam; i += NT) sidx[i] = src[i];
@@ -684,7 +697,7 @@ __global__ __launch_bounds__(RS_THREADS) void ps_rank_sort_kernel(Args a, RankWs
     const int run = blockIdx.y, w = blockIdx.x, tid = threadIdx.x;
     const Run &R = a.runs[run];
     int *const sy = ws.sync + run * RS_SYNC;
-    if (R.stat[1] || sy[2] == 0) return;
+    if (R.stat[1] || sy[2] != 1) return;
     if (a.dbg & 64) {  // (test switch: give up at once, as after a counter time-out)
         if (threadIdx.x == 0) __hip_atomic_store(sy + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
@@ -816,9 +829,11 @@ __global__ __launch_bounds__(256) void ps_rank_prep_kernel(Args a, RankWs ws, u6
     const int run = blockIdx.y;
     const Run &R = a.runs[run];
     const int *sy = ws.sync + run * RS_SYNC;
-    if (R.stat[1] || sy[2] == 0) return;
+    const int kind = sy[2];  // 1: draws + keys for the transposition phases; 2: the sorted order of a generation without violations
+    if (R.stat[1] || kind == 0) return;
     const int lam = R.lam;
     if ((int)blockIdx.x < draw_blocks) {
+        if (kind != 1) return;
         const int pitch = rw_pitch(lam), nblk = (lam + RW_H - 1) / RW_H, npair = lam / 2;
         u64 *out = draws + (size_t)run * per_run;  // [block of RW_H phases][pair slot]: byte g = the block's g-th group of four phases
         for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < (int64_t)nblk * pitch; e += (int64_t)draw_blocks * 256) {
@@ -853,9 +868,13 @@ __global__ __launch_bounds__(256) void ps_rank_prep_kernel(Args a, RankWs ws, u6
             sp[threadIdx.x] = R.phi[jb + threadIdx.x];
         }
         __syncthreads();
-        for (int j = 0; j < nj; ++j) {
-            cf += sf[j] < fi ? 1 : 0;
-            cp += sp[j] < pi ? 1 : 0;
+        if (kind == 1) {
+            for (int j = 0; j < nj; ++j) {
+                cf += sf[j] < fi ? 1 : 0;
+                cp += sp[j] < pi ? 1 : 0;
+            }
+        } else {  // position in the stable sort by f: ties by index
+            for (int j = 0; j < nj; ++j) cf += (sf[j] < fi || (sf[j] == fi && jb + j < i)) ? 1 : 0;
         }
     }
     if (i < lam) {
@@ -936,7 +955,7 @@ __global__ __launch_bounds__(64) void ps_rank_wave_kernel(Args a, RankWs ws, con
     const int run = blockIdx.y, w = blockIdx.x, lane = threadIdx.x;
     const Run &R = a.runs[run];
     int *const sy = ws.sync + run * RS_SYNC;
-    if (R.stat[1] || sy[2] == 0) return;
+    if (R.stat[1] || sy[2] != 1) return;
     const int lam = R.lam, nw = rw_waves(lam);
     if (w >= nw) return;
     if (a.dbg & 64) {  // (test switch: give up at once, as after a counter time-out)
@@ -1156,7 +1175,8 @@ static int rank_ws_setup(mrbf_ctx *ctx, int maxlam, ps::RankWs &rw, unsigned lon
     MRBF_HIP(ctx, hipMemsetAsync(rw.sync + RS_SYNC * MAXRUNS, 0, sizeof(int), ctx->stream));
     return MRBF_OK;
 }
-static void rank_phases_launch(mrbf_ctx *ctx, const ps::Args &a, const ps::RankWs &rw, unsigned long long *draws, size_t draws_per_run, int maxlam, int form) {
+static void rank_phases_launch(mrbf_ctx *ctx, const ps::Args &a, const ps::RankWs &rw, unsigned long long *draws, size_t draws_per_run, int maxlam, int form,
+                               bool phases_possible) {
     using namespace ps;
     if (form == 2) {
         hipLaunchKernelGGL(ps_rank_sort_kernel, dim3(RS_W, (unsigned)a.nruns), dim3(RS_THREADS), 0, ctx->stream, a, rw);
@@ -1165,7 +1185,8 @@ static void rank_phases_launch(mrbf_ctx *ctx, const ps::Args &a, const ps::RankW
     const int draw_blocks = (int)std::min<size_t>(512, (draws_per_run + 255) / 256);
     const int count_blocks = ((maxlam + RW_CNT_T - 1) / RW_CNT_T) * rw_jsplit(maxlam);
     hipLaunchKernelGGL(ps_rank_prep_kernel, dim3((unsigned)(draw_blocks + count_blocks), (unsigned)a.nruns), dim3(256), 0, ctx->stream, a, rw, draws, draws_per_run, draw_blocks);
-    hipLaunchKernelGGL(ps_rank_wave_kernel, dim3((unsigned)rw_waves(maxlam), (unsigned)a.nruns), dim3(64), 0, ctx->stream, a, rw, draws, draws_per_run, ++ctx->ps_rank_epoch);
+    if (phases_possible)  // (runs without modelled or linear constraints -- ideal-point runs of a box-constrained problem -- never violate anything)
+        hipLaunchKernelGGL(ps_rank_wave_kernel, dim3((unsigned)rw_waves(maxlam), (unsigned)a.nruns), dim3(64), 0, ctx->stream, a, rw, draws, draws_per_run, ++ctx->ps_rank_epoch);
 }
 
 static int ps_eval_points(mrbf_ctx *ctx, const ps::Problem &P, const double *x_host, int m, std::vector<double> &allF, std::vector<double> *Jobj) {
@@ -1563,6 +1584,9 @@ extern "C" int32_t mrbf_ps_step_problem(mrbf_ctx *ctx, const mrbf_ps_problem *pr
         unsigned long long *draws = nullptr;
         size_t draws_per_run = 0;
         if (multi) MRBF_TRY(rank_ws_setup(ctx, maxlam, rw, &draws, &draws_per_run));
+        rw.count_plain = (multi && multi_env != 2) ? 1 : 0;
+        bool phases_possible = a.ncon + a.nlin_eq + a.nlin_ineq > 0 || (a.dbg & 4);
+        for (int q2 = 0; q2 < a.nruns; ++q2) phases_possible = phases_possible || a.runs[q2].kind == 1;
         hipLaunchKernelGGL(ps_init_kernel, dim3((unsigned)((maxel + 255) / 256), (unsigned)a.nruns), dim3(256), 0, ctx->stream, a, start, t0);
         std::vector<int> hstat((size_t)4 * a.nruns);
         const unsigned wave_blocks = (unsigned)((a.rows + 3) / 4);
@@ -1573,7 +1597,7 @@ extern "C" int32_t mrbf_ps_step_problem(mrbf_ctx *ctx, const mrbf_ps_problem *pr
             hipLaunchKernelGGL(ps_score_kernel, dim3(wave_blocks), dim3(256), 0, ctx->stream, a);
             hipLaunchKernelGGL(ps_rank_kernel, dim3((unsigned)a.nruns), dim3(rank_threads), shm, ctx->stream, a, multi ? 1 : 0, rw);
             if (multi) {
-                rank_phases_launch(ctx, a, rw, draws, draws_per_run, maxlam, multi_env == 2 ? 2 : 1);
+                rank_phases_launch(ctx, a, rw, draws, draws_per_run, maxlam, multi_env == 2 ? 2 : 1, phases_possible);
                 hipLaunchKernelGGL(ps_rank_kernel, dim3((unsigned)a.nruns), dim3(rank_threads), shm, ctx->stream, a, 2, rw);
             }
             hipLaunchKernelGGL(ps_breed_kernel, dim3(wave_blocks), dim3(256), 0, ctx->stream, a);
@@ -1796,9 +1820,10 @@ extern "C" int32_t mrbf_debug_ps_rank(mrbf_ctx *ctx, int32_t lam, const double *
     unsigned long long *draws = nullptr;
     size_t draws_per_run = 0;
     if (several) MRBF_TRY(rank_ws_setup(ctx, lam, rw, &draws, &draws_per_run));
+    rw.count_plain = (several && impl != 6) ? 1 : 0;
     hipLaunchKernelGGL(ps_rank_kernel, dim3(1), dim3(rank_threads), shm, ctx->stream, a, several ? 1 : 0, rw);
     if (several) {
-        rank_phases_launch(ctx, a, rw, draws, draws_per_run, lam, impl == 6 ? 2 : 1);
+        rank_phases_launch(ctx, a, rw, draws, draws_per_run, lam, impl == 6 ? 2 : 1, true);
         hipLaunchKernelGGL(ps_rank_kernel, dim3(1), dim3(rank_threads), shm, ctx->stream, a, 2, rw);
     }
     MRBF_HIP(ctx, hipGetLastError());

@@ -607,7 +607,9 @@ def test_ps_plain_sort_in_registers_is_the_sort(lam):
     """A generation without infeasible individuals is ranked by a bitonic network (ps_rank_kernel).  Round 6: E = 2 / 4 / 8 elements per
     thread in registers -- compare-exchanges inside the thread, through wave shuffles, and only the widest strides through LDS.  Against
     NumPy's stable order (objective, ties by index; individuals outside the budget -- f = phi = inf -- last) and against the
-    one-pair-per-thread form it replaces (impl 3): identical orders, also with duplicated objective values."""
+    one-pair-per-thread form it replaces (impl 3): identical orders, also with duplicated objective values.  Populations of 1024 and
+    more are ranked in the step by counting instead (impl 1: rank(i) = #{j : f_j < f_i, or equal and j < i} over the whole chip):
+    the same order again."""
     import ctypes
 
     from morbit.jl_amd import _lib
@@ -625,12 +627,14 @@ def test_ps_plain_sort_in_registers_is_the_sort(lam):
                 f[: lam // 3] = f[lam // 3: 2 * (lam // 3)]
             want = np.lexsort((np.arange(lam), f))
             got = {}
-            for impl in (0, 3):
+            for impl in (0, 3) + ((1,) if lam >= 1024 else ()):
                 order = np.empty(lam, dtype=np.int32)
                 ctx.check(ctx.lib.mrbf_debug_ps_rank(ctx.h, lam, _lib.as_ptr(f), _lib.as_ptr(phi), 5, 1, impl, order.ctypes.data_as(_lib.c_ip), None))
                 got[impl] = order
             assert np.array_equal(got[0], want), (lam, case, int(np.argmax(got[0] != want)))
             assert np.array_equal(got[3], want), (lam, case)
+            if lam >= 1024:     # the step's own path for such populations: positions by counting on the whole chip (ps_rank_prep_kernel)
+                assert np.array_equal(got[1], want), (lam, case, int(np.argmax(got[1] != want)))
             # the step itself only reads the mu = ceil(lam / 7) parents: they are found by a sampled threshold + compaction and ranked
             # alone (select_parents) -- the same parents in the same order as the full sort's prefix (impl 5), whatever the ties
             mu = (lam + 6) // 7
