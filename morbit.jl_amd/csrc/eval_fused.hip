@@ -677,9 +677,13 @@ int eval_nsplit(const mrbf_ctx *ctx, int64_t m, int ntiles, bool check_call) {
 }
 
 // outputs per pass: two when the model has several (at D = 128 with the query block in LDS)
-int outputs_per_pass(int k, int D) {
+int outputs_per_pass(int k, int D, bool want_jac) {
     static const int ko128 = mrbf_env("MRBF_EVAL_KO128") ? atoi(mrbf_env("MRBF_EVAL_KO128")) : 2;
-    if (D == 256) return 1;  // the Jacobian tiles of one output fill the accumulator budget
+    static const int ko256 = mrbf_env("MRBF_EVAL_KO256") ? atoi(mrbf_env("MRBF_EVAL_KO256")) : 2;
+    // D = 256: the Jacobian tiles of one output fill the accumulator budget; a pass for values only carries no such tiles and takes two
+    // outputs -- the distances, the radial function and the centre traffic once instead of twice (a population of the PS solver at
+    // d = 256, k = 2: 2 x 161 -> 1 x ~170 us per generation)
+    if (D == 256) return (want_jac || k < 2) ? 1 : ko256;
     return k >= 2 ? (D == 128 ? ko128 : 2) : 1;
 }
 
@@ -720,6 +724,23 @@ static int launch_split(mrbf_ctx *ctx, bool want_jac, bool final_, dim3 grid, co
     return launch_split_b<KID, false, KOUT, H, ECT>(ctx, want_jac, final_, grid, one, many, l0);
 }
 
+template <int KID, int KOUT, int H, int ECT>
+static int launch_split_vals(mrbf_ctx *ctx, bool final_, dim3 grid, const KP &kp, const EvalDesc &one, const EvalDesc *many, int l0) {
+    const bool fast = kp.fast && (KID == MRBF_MULTIQUADRIC || KID == MRBF_INV_MULTIQUADRIC || KID == MRBF_CUBIC);
+#define MRBF_EFL(FASTV, FINV) \
+    hipLaunchKernelGGL((eval_fused_split_kernel<KID, FASTV, KOUT, H, ECT, false, FINV>), grid, dim3(512), 0, ctx->stream, one, many, l0)
+    if (fast && final_)
+        MRBF_EFL(true, true);
+    else if (fast)
+        MRBF_EFL(true, false);
+    else if (final_)
+        MRBF_EFL(false, true);
+    else
+        MRBF_EFL(false, false);
+#undef MRBF_EFL
+    return 0;
+}
+
 template <int KID, int KOUT, int DT, bool QLDS>
 static int launch_fused(mrbf_ctx *ctx, bool want_jac, bool final_, dim3 grid, const KP &kp, const EvalDesc &one, const EvalDesc *many, int l0) {
     if (kp.fast && (KID == MRBF_MULTIQUADRIC || KID == MRBF_INV_MULTIQUADRIC || KID == MRBF_CUBIC))
@@ -730,15 +751,18 @@ static int launch_fused(mrbf_ctx *ctx, bool want_jac, bool final_, dim3 grid, co
 // the passes over the outputs of one evaluation (single: many == nullptr, `one` by value; batch: blockIdx.z / .y = problem)
 static int run_passes(mrbf_ctx *ctx, const KP &kp, int D, int k, bool want_jac, bool final_, dim3 grid, dim3 cgrid, const EvalDesc &one,
                       const EvalDesc *many) {
-    const int KO = outputs_per_pass(k, D);
+    const int KO = outputs_per_pass(k, D, want_jac);
     for (int l0 = 0; l0 < k; l0 += KO) {
         const int ko = std::min(KO, k - l0);
 #define MRBF_EF(KOV, DTV, QL) MRBF_DISPATCH_KID(kp.kid, MRBF_TRY((launch_fused<KID, KOV, DTV, QL>(ctx, want_jac, final_, grid, kp, one, many, l0))))
         static const int split128 = mrbf_env("MRBF_EVAL_SPLIT128") ? atoi(mrbf_env("MRBF_EVAL_SPLIT128")) : 1;
 #define MRBF_EF128(KOV) MRBF_DISPATCH_KID(kp.kid, MRBF_TRY((launch_split<KID, KOV, 64, 64>(ctx, want_jac, final_, grid, kp, one, many, l0))))
-#define MRBF_EF256() MRBF_DISPATCH_KID(kp.kid, MRBF_TRY((launch_split<KID, 1, 128, 32>(ctx, want_jac, final_, grid, kp, one, many, l0))))
-        if (D == 256) {
-            MRBF_EF256();
+#define MRBF_EF256(KOV) MRBF_DISPATCH_KID(kp.kid, MRBF_TRY((launch_split<KID, KOV, 128, 32>(ctx, want_jac, final_, grid, kp, one, many, l0))))
+        if (D == 256 && ko == 2) {  // (values only)
+            MRBF_DISPATCH_KID(kp.kid, MRBF_TRY((launch_split_vals<KID, 2, 128, 32>(ctx, final_, grid, kp, one, many, l0))));
+            if (!final_) hipLaunchKernelGGL(eval_combine_kernel<2>, cgrid, dim3(128), 0, ctx->stream, one, many, l0, D);
+        } else if (D == 256) {
+            MRBF_EF256(1);
             if (!final_) hipLaunchKernelGGL(eval_combine_kernel<1>, cgrid, dim3(128), 0, ctx->stream, one, many, l0, D);
         } else if (ko == 2) {
             if (D == 64) {
@@ -808,7 +832,7 @@ int eval_fused(mrbf_ctx *ctx, const mrbf_model *M, int64_t m, const double *X, d
     // (n = 2d + 1 = 257 sites are five tiles, not the six of the 128-padded storage: a sixth of a C4 evaluation)
     const int ntiles = (int)((M->n + EC - 1) / EC);
     const int nsplit = eval_nsplit(ctx, m, ntiles, ctx->eval_check_call != 0);
-    const int KO = outputs_per_pass(k, D);
+    const int KO = outputs_per_pass(k, D, jac != nullptr);
     EvalDesc E;
     std::memset(&E, 0, sizeof(E));
     E.X = X;

@@ -80,7 +80,7 @@ struct EvalDesc {
 // the centre-range split a single mrbf_eval of m points on a model with ntiles tiles of 64 centres uses (the batch takes the same one, so
 // that a batch and single calls add up their partial sums in the same order)
 int eval_nsplit(const mrbf_ctx *ctx, int64_t m, int ntiles, bool check_call = false);  // ntiles = ceil(n / 64); check_call: the residual check's evaluation at the sites
-int outputs_per_pass(int k, int D);  // outputs of a model the fused evaluation handles per pass
+int outputs_per_pass(int k, int D, bool want_jac = true);  // outputs of a model the fused evaluation handles per pass
 // all descriptors: same kernel id / fast flag / padded dimension D (64 or 128) / k; dev_descs = the same array in device memory
 // centred: the descriptors' Xq / xsq are already filled (center_pad_batch on all descriptors of a batch, launched beside the fit)
 int eval_fused_batch(mrbf_ctx *ctx, const KP &kp, int D, int k, bool want_jac, const EvalDesc *host_descs, const EvalDesc *dev_descs, int count,

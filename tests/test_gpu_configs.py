@@ -320,3 +320,30 @@ def test_small_fit_cluster_failure_repeats_with_one_workgroup():
     assert np.array_equal(m2.weights, clean.weights)
     for x in (m, m2, clean):
         x.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,m,k", [(300, 700, 2), (2048, 5160, 2), (1500, 130, 3), (2048, 64, 1)])
+def test_values_only_evaluation_at_d256_takes_two_outputs_per_pass(ctx, n, m, k):
+    """129 <= d <= 256: a Jacobian pass carries one output (its accumulator tiles fill the register budget); a pass for values only
+    carries two, so the distances and the radial function are computed once for a pair of outputs (the PS solver's populations:
+    C5-shaped models, k = 2).  Same arithmetic per output: the values of a values-only call are bit for bit those of a call that
+    also asks for the Jacobians (one output per pass), and they match the oracle's model on the same coefficients."""
+    from oracle import rbf_oracle as orc
+
+    d = 200
+    rng = np.random.default_rng(n + m + k)
+    C = rng.random((n, d))
+    Y = np.stack([((C - 0.2 - 0.1 * l) ** 2).sum(1) / d + 0.05 * np.sin(3 * C[:, l]) for l in range(k)], axis=1)
+    cfg = pkg.RbfConfig(kernel="cubic", polynomial_degree=1)
+    kid, a, b = pkg.rbf_model._get_kernel_params(1.0, cfg)
+    mod = pkg.update_model(cfg, C, Y, ctx=ctx)
+    X = rng.random((m, d))
+    V_only = pkg.eval_models_at_sites(mod, None, X)
+    V_both, J = mod.eval_sites(X, want_values=True, want_jac=True)
+    assert V_only.shape == (m, k) and np.array_equal(V_only, V_both)
+    Vo = orc.OracleModel(C, np.asarray(mod.weights), np.asarray(mod.poly), kid, a, b, 1).values(X)
+    assert np.abs(V_only - Vo).max() < 1e-9 * max(1.0, np.abs(Vo).max())
+    # interpolation
+    assert np.abs(pkg.eval_models_at_sites(mod, None, C[:: max(1, n // 50)]) - Y[:: max(1, n // 50)]).max() < 1e-8
+    mod.free()
