@@ -560,6 +560,114 @@ __global__ __launch_bounds__(512, 2) void eval_fused_split_kernel(EvalDesc one, 
     }
 }
 
+// ---- D = 256, values only, split centre range: a wave owns ALL coordinates of its sixteen queries -----------------------------------
+// The two-group form above exists for the Jacobian accumulators.  A pass for values has none, and what the split costs it is an LDS
+// exchange and a workgroup barrier of eight waves per sixteen centres (32 MFMAs per wave): 0.42 of the fp64 MFMA peak on the PS
+// solver's populations (d = 256, 5160 points, 2048 centres).  Here eight waves of one workgroup per CU take 128 queries, each wave
+// keeps its queries' 256 coordinates in registers (128 VGPRs) and runs the 64 MFMAs of a 16 x 16 tile as the SAME two chains --
+// coordinates 0..127 and 128..255, summed S_0 + S_1 -- so the values are bit for bit those of the two-group kernel (and of a call that
+// also asks for Jacobians), with no exchange and one barrier per 32-centre tile.  Non-FINAL only (partials + combine pass).
+template <int KID, bool FAST, int KOUT>
+__global__ __launch_bounds__(512, 1) void eval_vals256_kernel(EvalDesc one, const EvalDesc *__restrict__ many, int l0) {
+    constexpr int D = 256, H = 128, ECT = 32, LDC = D + 2, NCT = ECT / 16, EQW = 128;
+    __shared__ __attribute__((aligned(16))) double Cs[ECT * LDC];
+    __shared__ double Ws[KOUT * ECT];
+    __shared__ double Sq[ECT];
+    const EvalDesc &E = many ? many[blockIdx.z] : one;
+    if (many && ((int64_t)blockIdx.x * EQW >= E.mpad || (int)blockIdx.y >= E.nsplit)) return;
+    const double *__restrict__ Xq = E.Xq;
+    const double *__restrict__ Cc = E.Cc;
+    const double *__restrict__ csq = E.csq;
+    const double *__restrict__ Wc = E.Wc;
+    const int64_t npad = E.npad, mpad = E.mpad;
+    const KP kp = E.kp;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int64_t q0 = (int64_t)blockIdx.x * EQW;
+    const int split = blockIdx.y;
+    const int64_t qrow = q0 + wave * 16 + l15;
+    const bool qin = qrow < mpad;  // (mpad is a multiple of 64: the second half of the last workgroup may lie beyond it)
+    const int64_t qld = qin ? qrow : mpad - 1;
+    double xb[D / 4];  // k-slice s -> Xq[qrow][4 s + l4]
+#pragma unroll
+    for (int s = 0; s < D / 4; ++s) xb[s] = Xq[qld * D + 4 * s + l4];
+    const double xs = E.xsq[qld];
+    double vsum[KOUT];
+#pragma unroll
+    for (int l = 0; l < KOUT; ++l) vsum[l] = 0.0;
+    const int64_t c_begin = (int64_t)split * E.tiles_per_split * EC;
+    const int nsub = __builtin_amdgcn_readfirstlane(E.nsub);
+    const int my_tiles = min(E.tiles_per_split, E.ntiles - split * E.tiles_per_split) * (EC / ECT);
+    constexpr int NLD = ECT * D / 2 / 512;
+    v2d stg[NLD];
+    auto load_tile = [&](int64_t c0) {
+        const v2d *src = reinterpret_cast<const v2d *>(Cc + c0 * D);
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) stg[u] = src[tid + 512 * u];
+    };
+    static_assert((KOUT + 1) * ECT <= 512, "one staged scalar per thread");
+    double stg_w = 0.0;
+    auto load_scalars = [&](int64_t c0) {
+        if (tid < ECT)
+            stg_w = csq[c0 + tid];
+        else if (tid < (KOUT + 1) * ECT)
+            stg_w = Wc[(int64_t)(l0 + (tid - ECT) / ECT) * npad + c0 + ((tid - ECT) % ECT)];
+    };
+    load_tile(c_begin);
+    load_scalars(c_begin);
+    for (int tile = 0; tile < my_tiles; ++tile) {
+        const int64_t c0 = c_begin + (int64_t)tile * ECT;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int e = (tid + 512 * u) * 2;
+            *(v2d *)&Cs[(e / D) * LDC + (e % D)] = stg[u];
+        }
+        if (tid < ECT)
+            Sq[tid] = stg_w;
+        else if (tid < (KOUT + 1) * ECT)
+            Ws[tid - ECT] = stg_w;
+        __syncthreads();
+        if (tile + 1 < my_tiles) {
+            load_tile(c0 + ECT);
+            load_scalars(c0 + ECT);
+        }
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            if ((int)(c0 >> 4) + ct >= nsub) break;  // only padding from here on
+            v4d S0 = {0.0, 0.0, 0.0, 0.0}, S1 = {0.0, 0.0, 0.0, 0.0};
+            const double *crow = &Cs[(16 * ct + l15) * LDC + l4];
+#pragma unroll
+            for (int s = 0; s < H / 4; ++s) {
+                S0 = __builtin_amdgcn_mfma_f64_16x16x4f64(crow[4 * s], xb[s], S0, 0, 0, 0);
+                S1 = __builtin_amdgcn_mfma_f64_16x16x4f64(crow[H + 4 * s], xb[H / 4 + s], S1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = 16 * ct + l4 + 4 * r;
+                double s2 = fma(-2.0, S0[r] + S1[r], xs + Sq[c]);
+                s2 = s2 > 0.0 ? s2 : 0.0;
+                double phi, psi;
+                rbf_phi_psi_t<KID, FAST>(s2, kp, phi, psi);
+#pragma unroll
+                for (int l = 0; l < KOUT; ++l) vsum[l] = fma(Ws[l * ECT + c], phi, vsum[l]);
+            }
+        }
+    }
+#pragma unroll
+    for (int l = 0; l < KOUT; ++l) {
+        vsum[l] += __shfl_xor(vsum[l], 16);
+        vsum[l] += __shfl_xor(vsum[l], 32);
+    }
+    if (l4 == 0 && qin) {
+#pragma unroll
+        for (int l = 0; l < KOUT; ++l) {
+            E.vpart[((int64_t)split * mpad + qrow) * KOUT + l] = vsum[l];
+            E.sapart[((int64_t)split * mpad + qrow) * KOUT + l] = 0.0;  // (the combine pass sums it; only a Jacobian would use it)
+        }
+    }
+}
+
 // vals[p][l0 + l] = sum_s vpart + p_l(x);   jac[p][t*k + l0 + l] = (sum_s sa) xc[p][t] - sum_s G + lam[t+1]
 // One workgroup of 128 threads per query point.  The polynomial tail of the value -- a dot product over d coordinates per output --
 // is spread over the threads that also produce the Jacobian entries and summed in a fixed order through LDS (it used to be a serial
@@ -727,6 +835,15 @@ static int launch_split(mrbf_ctx *ctx, bool want_jac, bool final_, dim3 grid, co
 template <int KID, int KOUT, int H, int ECT>
 static int launch_split_vals(mrbf_ctx *ctx, bool final_, dim3 grid, const KP &kp, const EvalDesc &one, const EvalDesc *many, int l0) {
     const bool fast = kp.fast && (KID == MRBF_MULTIQUADRIC || KID == MRBF_INV_MULTIQUADRIC || KID == MRBF_CUBIC);
+    static const int wide = mrbf_env("MRBF_EVAL_WIDE256") ? atoi(mrbf_env("MRBF_EVAL_WIDE256")) : 1;
+    if (H == 128 && !final_ && wide) {  // values only, split centre range: one wave per sixteen queries with all 256 coordinates
+        const dim3 g2((grid.x + 1) / 2, grid.y, grid.z);
+        if (fast)
+            hipLaunchKernelGGL((eval_vals256_kernel<KID, true, KOUT>), g2, dim3(512), 0, ctx->stream, one, many, l0);
+        else
+            hipLaunchKernelGGL((eval_vals256_kernel<KID, false, KOUT>), g2, dim3(512), 0, ctx->stream, one, many, l0);
+        return 0;
+    }
 #define MRBF_EFL(FASTV, FINV) \
     hipLaunchKernelGGL((eval_fused_split_kernel<KID, FASTV, KOUT, H, ECT, false, FINV>), grid, dim3(512), 0, ctx->stream, one, many, l0)
     if (fast && final_)
@@ -762,7 +879,11 @@ static int run_passes(mrbf_ctx *ctx, const KP &kp, int D, int k, bool want_jac, 
             MRBF_DISPATCH_KID(kp.kid, MRBF_TRY((launch_split_vals<KID, 2, 128, 32>(ctx, final_, grid, kp, one, many, l0))));
             if (!final_) hipLaunchKernelGGL(eval_combine_kernel<2>, cgrid, dim3(128), 0, ctx->stream, one, many, l0, D);
         } else if (D == 256) {
-            MRBF_EF256(1);
+            if (!want_jac) {
+                MRBF_DISPATCH_KID(kp.kid, MRBF_TRY((launch_split_vals<KID, 1, 128, 32>(ctx, final_, grid, kp, one, many, l0))));
+            } else {
+                MRBF_EF256(1);
+            }
             if (!final_) hipLaunchKernelGGL(eval_combine_kernel<1>, cgrid, dim3(128), 0, ctx->stream, one, many, l0, D);
         } else if (ko == 2) {
             if (D == 64) {
