@@ -1202,7 +1202,17 @@ static int ps_eval_points(mrbf_ctx *ctx, const ps::Problem &P, const double *x_h
     // asynchronously in front of ONE stream synchronisation.
     const size_t up_cnt = (size_t)m * d, down_cnt = cnt - up_cnt;
     double *pin = (ctx->pin_base && !ctx->pin_armed && cnt * sizeof(double) <= ((size_t)1 << 20)) ? reinterpret_cast<double *>(ctx->pin_base) : nullptr;
-    if (pin) {
+    // Round 6, second half: no copies at all.  The pinned block is mapped into the device's address space, so the kernels read the
+    // points from it and write values / Jacobians into it (a few KB over the link inside kernels that run anyway) -- two blit launches
+    // and their gaps less per call, ~75 calls per step (MRBF_PS_ZEROCOPY=0: the staged copies).
+    static const int zc_env = mrbf_env("MRBF_PS_ZEROCOPY") ? atoi(mrbf_env("MRBF_PS_ZEROCOPY")) : 1;
+    const bool zero_copy = pin && zc_env;
+    if (zero_copy) {
+        std::memcpy(pin, x_host, up_cnt * sizeof(double));
+        dX = pin;
+        dV = pin + up_cnt;
+        dJ = dV + (size_t)m * P.nftot;
+    } else if (pin) {
         std::memcpy(pin, x_host, up_cnt * sizeof(double));
         MRBF_HIP(ctx, hipMemcpyAsync(dX, pin, up_cnt * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     } else {
@@ -1223,7 +1233,7 @@ static int ps_eval_points(mrbf_ctx *ctx, const ps::Problem &P, const double *x_h
     std::vector<const double *> Jm(P.nmodels, nullptr);
     if (pin) {
         double *down = pin + up_cnt;  // the values, then every model's Jacobian block at its device offset: one download
-        MRBF_HIP(ctx, hipMemcpyAsync(down, dV, down_cnt * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        if (!zero_copy) MRBF_HIP(ctx, hipMemcpyAsync(down, dV, down_cnt * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         blocks = down;
         for (int j = 0; j < P.nmodels; ++j)
             if (jp[j]) Jm[j] = down + (jp[j] - dV);
