@@ -155,9 +155,11 @@ __global__ __launch_bounds__(256, (DT <= 4) ? 2 : 1) void eval_fused_kernel(Eval
                 for (int l = 0; l < KOUT; ++l) {
                     const double w = Ws[l * EC + c];
                     vsum[l] = fma(w, phi, vsum[l]);
-                    const double a = w * psi;
-                    sasum[l] += a;
-                    Aw[l][r] = a;
+                    if constexpr (JAC) {  // (a pass for values only: no psi, no coefficient sums -- a quarter of the tile's vector work)
+                        const double a = w * psi;
+                        sasum[l] += a;
+                        Aw[l][r] = a;
+                    }
                 }
             }
             // ---- phase 3: G_l'[t][q] += sum_c Cc[c][t] a_lc
@@ -401,9 +403,11 @@ __global__ __launch_bounds__(512, 2) void eval_fused_split_kernel(EvalDesc one, 
                 for (int l = 0; l < KOUT; ++l) {
                     const double w = Ws[l * ECT + c];
                     vsum[l] = fma(w, phi, vsum[l]);
-                    const double a = w * psi;
-                    sasum[l] += a;
-                    Aw[l][r] = a;
+                    if constexpr (JAC) {
+                        const double a = w * psi;
+                        sasum[l] += a;
+                        Aw[l][r] = a;
+                    }
                 }
             }
             // ---- phase 3: this group's H Jacobian columns
