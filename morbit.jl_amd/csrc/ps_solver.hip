@@ -1193,7 +1193,7 @@ static int ps_eval_points(mrbf_ctx *ctx, const ps::Problem &P, const double *x_h
     const int d = P.d;
     double *dX;
     size_t cnt = (size_t)m * d + (size_t)m * P.nftot;
-    for (int j = 0; j < P.nmodels; ++j) cnt += (size_t)P.models[j]->k * d;
+    for (int j = 0; j < P.nmodels; ++j) cnt += (size_t)(Jobj ? m : 1) * P.models[j]->k * d;
     MRBF_TRY(get_buf(ctx, S_PS_POLISH, cnt, &dX));
     double *dV = dX + (size_t)m * d, *dJ = dV + (size_t)m * P.nftot;
     // The descent phase calls this some 140 times per step with a few KB each way.  Transfers from / to pageable memory are a
@@ -1221,11 +1221,11 @@ static int ps_eval_points(mrbf_ctx *ctx, const ps::Problem &P, const double *x_h
     std::vector<double *> jp(P.nmodels, nullptr), vp(P.nmodels, nullptr);
     for (int j = 0; j < P.nmodels; ++j) {
         bool need = false;
-        for (int l = 0; Jobj && m == 1 && l < P.nobj; ++l) need = need || P.obj_model[l] == j;
+        for (int l = 0; Jobj && l < P.nobj; ++l) need = need || P.obj_model[l] == j;
         jp[j] = need ? dJ : nullptr;
         vp[j] = dV + (size_t)m * P.foff[j];  // model j's m x k_j block
         MRBF_TRY(eval_model(ctx, P.models[j], m, dX, vp[j], jp[j], nullptr));
-        dJ += (size_t)P.models[j]->k * d;
+        dJ += (size_t)(Jobj ? m : 1) * P.models[j]->k * d;
     }
     std::vector<double> blocks_v;
     std::vector<std::vector<double>> Jm_v(P.nmodels);
@@ -1243,7 +1243,7 @@ static int ps_eval_points(mrbf_ctx *ctx, const ps::Problem &P, const double *x_h
         blocks = blocks_v.data();
         for (int j = 0; j < P.nmodels; ++j)
             if (jp[j]) {
-                Jm_v[j].resize((size_t)P.models[j]->k * d);
+                Jm_v[j].resize((size_t)m * P.models[j]->k * d);
                 MRBF_HIP(ctx, hipMemcpyAsync(Jm_v[j].data(), jp[j], Jm_v[j].size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
                 Jm[j] = Jm_v[j].data();
             }
@@ -1255,12 +1255,14 @@ static int ps_eval_points(mrbf_ctx *ctx, const ps::Problem &P, const double *x_h
         for (int p = 0; p < m; ++p)
             for (int c = 0; c < kj; ++c) allF[(size_t)p * P.nftot + P.foff[j] + c] = blocks[(size_t)m * P.foff[j] + (size_t)p * kj + c];
     }
-    if (Jobj && m == 1) {
-        Jobj->resize((size_t)P.nobj * d);
-        for (int l = 0; l < P.nobj; ++l) {
-            const int j = P.obj_model[l], kj = P.models[j]->k;
-            for (int t = 0; t < d; ++t) (*Jobj)[(size_t)l * d + t] = Jm[j][(size_t)t * kj + P.obj_col[l]];  // per point k x d column-major
-        }
+    if (Jobj) {  // [point][objective][coordinate]
+        Jobj->resize((size_t)m * P.nobj * d);
+        for (int p = 0; p < m; ++p)
+            for (int l = 0; l < P.nobj; ++l) {
+                const int j = P.obj_model[l], kj = P.models[j]->k;
+                const double *Jp = Jm[j] + (size_t)p * kj * d;  // per point k x d column-major
+                for (int t = 0; t < d; ++t) (*Jobj)[((size_t)p * P.nobj + l) * d + t] = Jp[(size_t)t * kj + P.obj_col[l]];
+            }
     }
     return 0;
 }
@@ -1321,16 +1323,23 @@ static int ps_descend(mrbf_ctx *ctx, const ps::Problem &P, const std::vector<dou
                       std::vector<double> &x, int *evals_out) {
     const int d = P.d, k = (int)objs.size();
     constexpr int NSTEP = 12;
-    std::vector<double> allF, J, F(k), gap(k), dir(d), XT((size_t)NSTEP * d), M((size_t)k * k), lam, G((size_t)k * d), row(P.nftot);
+    std::vector<double> allF, allFT, J, JT, F(k), gap(k), dir(d), XT((size_t)NSTEP * d), M((size_t)k * k), lam, G((size_t)k * d), row(P.nftot);
     std::vector<char> fixed(d);
     int evals = 0;
     double width = 0.0;
     for (int t = 0; t < d; ++t) width = std::max(width, ub[t] - lb[t]);
     double frac = 0.25;  // the largest trial step moves the fastest component by this fraction of the box
     int nsmall = 0;
-    while (evals + 1 + NSTEP <= max_evals && width > 0.0) {
-        MRBF_TRY(ps_eval_point(ctx, P, x.data(), allF, &J));
-        ++evals;
+    // One round trip per iteration (round 6): the trial points come back with their Jacobians, so the accepted one needs no evaluation
+    // of its own at the top of the next iteration (before: a one-point Jacobian sweep + the twelve values = two round trips and
+    // thirteen evaluations per iteration; a one-point Jacobian sweep costs the device what a twelve-point one does -- one query tile).
+    bool have = false;  // allF / J hold the values and the objectives' Jacobian rows at x
+    while (evals + (have ? 0 : 1) + NSTEP <= max_evals && width > 0.0) {
+        if (!have) {
+            MRBF_TRY(ps_eval_point(ctx, P, x.data(), allF, &J));
+            ++evals;
+            have = true;
+        }
         double tmax = -INFINITY, gmax = 0.0;
         for (int l = 0; l < k; ++l) {
             F[l] = (P.objective(allF, objs[l]) - off[l]) / scale[l];
@@ -1373,12 +1382,12 @@ static int ps_descend(mrbf_ctx *ctx, const ps::Problem &P, const std::vector<dou
             }
             for (int t = 0; t < d; ++t) XT[(size_t)u * d + t] = std::min(std::max(x[t] + dir[t], lb[t]), ub[t]);
         }
-        MRBF_TRY(ps_eval_points(ctx, P, XT.data(), NSTEP, allF, nullptr));
+        MRBF_TRY(ps_eval_points(ctx, P, XT.data(), NSTEP, allFT, &JT));
         evals += NSTEP;
         int bestj = -1;
         double bestv = val - 1e-13 * std::max(1.0, std::fabs(val));
         for (int j = 0; j < NSTEP; ++j) {
-            for (int c = 0; c < P.nftot; ++c) row[c] = allF[(size_t)j * P.nftot + c];
+            for (int c = 0; c < P.nftot; ++c) row[c] = allFT[(size_t)j * P.nftot + c];
             double tt = -INFINITY;
             for (int l = 0; l < k; ++l) tt = std::max(tt, (P.objective(row, objs[l]) - off[l]) / scale[l]);
             if (!(tt == tt) || !(tt < INFINITY)) continue;
@@ -1404,6 +1413,8 @@ static int ps_descend(mrbf_ctx *ctx, const ps::Problem &P, const std::vector<dou
             small = small && std::fabs(xn2 - x[t]) <= xtol_rel * std::max(std::fabs(xn2), 1e-300);
             x[t] = xn2;
         }
+        allF.assign(allFT.begin() + (size_t)bestj * P.nftot, allFT.begin() + (size_t)(bestj + 1) * P.nftot);
+        J.assign(JT.begin() + (size_t)bestj * P.nobj * d, JT.begin() + (size_t)(bestj + 1) * P.nobj * d);
         val = bestv;
         frac = std::min(1.0, frac * std::ldexp(4.0, -bestj));  // the accepted step sits two levels below the top of the next range
         if (clamp && val <= -1.0) break;
