@@ -768,6 +768,13 @@ int eval_nsplit(const mrbf_ctx *ctx, int64_t m, int ntiles, bool check_call) {
     // splitting them cost C4 1.6 % (19 540 against 19 870 problems/s, three alternating runs); the single fit's check follows the same rule.
     const bool small_batch = !check_call && qtiles * 8 <= slots;
     if (ntiles >= 4 && ntiles <= 8 && small_split > 1 && small_batch) return std::min(small_split, ntiles);
+    // the PS solver's populations (ctx->eval_population, values only): a query batch that fills less than half of the workgroup slots
+    // (round 6: the ideal-point populations of a step at d = 128, 5160 points on n = 257 sites = 81 unsplit workgroups on 256 CUs, 40 us
+    // per generation) takes one tile per workgroup + the combine pass, which for values reads a few bytes per point.  Only there: the
+    // API's own calls keep ONE rule for values and Jacobians (a values-only call and a call with Jacobians return the same bits, and so
+    // does a member of a batch: tests/test_gpu_configs.py), and C4's batches fill the chip by their number.
+    static const int vals_split = mrbf_env("MRBF_EVAL_NSPLIT_VALS") ? atoi(mrbf_env("MRBF_EVAL_NSPLIT_VALS")) : 1;
+    if (ctx->eval_population && vals_split && !check_call && ntiles >= 4 && ntiles <= 8 && qtiles * 2 <= slots) return (int)std::min<int64_t>(ntiles, slots / qtiles);
     if (ntiles <= 8) return 1;
     static const double comb_small = mrbf_env("MRBF_EVAL_COMB_SMALL") ? atof(mrbf_env("MRBF_EVAL_COMB_SMALL")) : 0.1;
     int nsplit = 1;

@@ -1613,8 +1613,11 @@ extern "C" int32_t mrbf_ps_step_problem(mrbf_ctx *ctx, const mrbf_ps_problem *pr
         const unsigned wave_blocks = (unsigned)((a.rows + 3) / 4);
         for (int g = 0; g < max_gens; ++g) {
             a.gen = g;
-            for (int j = 0; j < P.nmodels; ++j)
-                MRBF_TRY(eval_model(ctx, P.models[j], a.rows, a.Xeval, const_cast<double *>(a.F[j]), nullptr, nullptr));
+            ctx->eval_population = 1;
+            int erc = 0;
+            for (int j = 0; j < P.nmodels && !erc; ++j) erc = eval_model(ctx, P.models[j], a.rows, a.Xeval, const_cast<double *>(a.F[j]), nullptr, nullptr);
+            ctx->eval_population = 0;
+            MRBF_TRY(erc);
             hipLaunchKernelGGL(ps_score_kernel, dim3(wave_blocks), dim3(256), 0, ctx->stream, a);
             hipLaunchKernelGGL(ps_rank_kernel, dim3((unsigned)a.nruns), dim3(rank_threads), shm, ctx->stream, a, multi ? 1 : 0, rw);
             if (multi) {
