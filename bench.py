@@ -167,7 +167,8 @@ def measure_callers():
     """Side measurement, not part of `value`: the callers either side of the hot path at the BASELINE dimensions,
     through the same library -- wall time of mrbf_round4 (incl. the upload of the candidates) at d = 64 with 10^4 candidates and at
     d = 128 with 6000 (all accepted), and of one Pascoletti-Serafini step with Morbit's default budgets at d = 64 / 128 / 256 (workloads
-    of tools/round4_bench.py and tools/ps_bench2.py; best of three / two calls after one warm-up call)."""
+    of tools/round4_bench.py and tools/ps_bench2.py; best of three / two calls after one warm-up call), and of the affine filter's pick
+    loop (mrbf_affine_select) at d = 128 with 300 candidates."""
     import numpy as np
     import morbit.jl_amd as pkg
     from morbit.jl_amd import sampling, workloads as wl
@@ -218,6 +219,21 @@ def measure_callers():
                 omega, ne = float(o[0]), int(stt["evals_ideal"] + stt["evals_ps"])
             mod.free()
             res["ps_step_d%d" % d] = {"ms": round(best, 3), "evaluations": ne, "omega": omega, "n": int(C.shape[0])}
+        # the affine filter's pick loop: d = 128, 300 candidates in the box, as tools/affine_bench.py
+        d, mc = 128, 300
+        rng = np.random.default_rng(1)
+        x = rng.random(d)
+        seeds = list(x + 0.2 * (2 * rng.random((mc, d)) - 1))
+        best, npick = 1e30, 0
+        for rep in range(3):
+            flt = sampling.AffinelyIndependentPointFilter(x, seeds, pivot_val=0.02)
+            t0 = time.perf_counter()
+            got = flt.collect()
+            dt = (time.perf_counter() - t0) * 1e3
+            npick = len(got)
+            if rep > 0:
+                best = min(best, dt)
+        res["affine_select_d128_300cand"] = {"ms": round(best, 3), "picks": npick}
     except Exception as e:  # the side measurement must never cost the bench line
         res["error"] = repr(e)
     return res
