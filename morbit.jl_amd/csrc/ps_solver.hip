@@ -1318,31 +1318,53 @@ static void prox_weights(int k, const std::vector<double> &M, const std::vector<
 // taken out and the weights recomputed.  The best feasible improving trial point is taken; the range of sigma follows the accepted
 // steps.  It stops when the budget is used up or no step down to 1e-9 of the box improves (stationarity), NOT at the first line
 // search without improvement.  Every accepted iterate is feasible.  Each iteration costs 1 + NSTEP evaluations.
-static int ps_descend(mrbf_ctx *ctx, const ps::Problem &P, const std::vector<double> &lb, const std::vector<double> &ub, const std::vector<int> &objs,
-                      const std::vector<double> &off, const std::vector<double> &scale, bool clamp, int max_evals, double xtol_rel, double &val,
-                      std::vector<double> &x, int *evals_out) {
-    const int d = P.d, k = (int)objs.size();
-    constexpr int NSTEP = 12;
-    std::vector<double> allF, allFT, J, JT, F(k), gap(k), dir(d), XT((size_t)NSTEP * d), M((size_t)k * k), lam, G((size_t)k * d), row(P.nftot);
-    std::vector<char> fixed(d);
-    int evals = 0;
-    double width = 0.0;
-    for (int t = 0; t < d; ++t) width = std::max(width, ub[t] - lb[t]);
-    double frac = 0.25;  // the largest trial step moves the fastest component by this fraction of the box
-    int nsmall = 0;
-    // One round trip per iteration (round 6): the trial points come back with their Jacobians, so the accepted one needs no evaluation
-    // of its own at the top of the next iteration (before: a one-point Jacobian sweep + the twelve values = two round trips and
-    // thirteen evaluations per iteration; a one-point Jacobian sweep costs the device what a twelve-point one does -- one query tile).
-    bool have = false;  // allF / J hold the values and the objectives' Jacobian rows at x
-    while (evals + (have ? 0 : 1) + NSTEP <= max_evals && width > 0.0) {
-        if (!have) {
-            MRBF_TRY(ps_eval_point(ctx, P, x.data(), allF, &J));
-            ++evals;
-            have = true;
+// One proximal minimax descent as a state machine: `trials` writes the NSTEP trial points of the next iteration (false: the descent has
+// ended), `consume` takes their values and Jacobians.  Several independent descents (the k ideal-point refinements) advance in
+// lockstep through ONE evaluation per iteration (ps_descend_many) -- a round trip per iteration for all of them instead of one each.
+struct Descent {
+    static constexpr int NSTEP = 12;
+    const ps::Problem *P = nullptr;
+    const std::vector<double> *lb = nullptr, *ub = nullptr;
+    std::vector<int> objs;
+    std::vector<double> off, scale;
+    bool clamp = false;
+    int max_evals = 0;
+    double xtol_rel = 0.0;
+    double val = 0.0;
+    std::vector<double> x;
+    // state
+    int evals = 0, nsmall = 0;
+    double width = 0.0, frac = 0.25;  // the largest trial step moves the fastest component by `frac` of the box
+    bool have = false, done = false;  // have: allF / J hold the values and the objectives' Jacobian rows at x
+    std::vector<double> allF, J, XT;
+
+    void start() {
+        const int d = P->d;
+        width = 0.0;
+        for (int t = 0; t < d; ++t) width = std::max(width, (*ub)[t] - (*lb)[t]);
+        XT.assign((size_t)NSTEP * d, 0.0);
+        done = !(width > 0.0);
+    }
+    bool wants_start_eval() const { return !done && !have && evals + 1 + NSTEP <= max_evals; }
+    void take_start(const double *F_row, const double *J_rows) {  // values (nftot) and Jacobian rows (nobj x d) at x
+        allF.assign(F_row, F_row + P->nftot);
+        J.assign(J_rows, J_rows + (size_t)P->nobj * P->d);
+        ++evals;
+        have = true;
+    }
+    // the trial points of the next iteration into XT; false: ended (budget, no gradient, range exhausted)
+    bool trials() {
+        if (done) return false;
+        if (!have || evals + NSTEP > max_evals) {
+            done = true;
+            return false;
         }
+        const int d = P->d, k = (int)objs.size();
+        std::vector<double> F(k), gap(k), dir(d), M((size_t)k * k), lam, G((size_t)k * d);
+        std::vector<char> fixed(d);
         double tmax = -INFINITY, gmax = 0.0;
         for (int l = 0; l < k; ++l) {
-            F[l] = (P.objective(allF, objs[l]) - off[l]) / scale[l];
+            F[l] = (P->objective(allF, objs[l]) - off[l]) / scale[l];
             tmax = std::max(tmax, F[l]);
         }
         for (int l = 0; l < k; ++l) {
@@ -1352,7 +1374,10 @@ static int ps_descend(mrbf_ctx *ctx, const ps::Problem &P, const std::vector<dou
                 gmax = std::max(gmax, std::fabs(G[(size_t)l * d + t]));
             }
         }
-        if (!(gmax > 0.0) || !(gmax < INFINITY)) break;
+        if (!(gmax > 0.0) || !(gmax < INFINITY)) {
+            done = true;
+            return false;
+        }
         const double sigma0 = frac * width / gmax;
         for (int u = 0; u < NSTEP; ++u) {
             const double sigma = sigma0 * std::ldexp(1.0, -u);
@@ -1372,7 +1397,7 @@ static int ps_descend(mrbf_ctx *ctx, const ps::Problem &P, const std::vector<dou
                     if (!fixed[t])
                         for (int a = 0; a < k; ++a) v -= sigma * lam[a] * G[(size_t)a * d + t];
                     dir[t] = v;
-                    if (!fixed[t] && ((x[t] <= lb[t] && v < 0.0) || (x[t] >= ub[t] && v > 0.0))) {
+                    if (!fixed[t] && ((x[t] <= (*lb)[t] && v < 0.0) || (x[t] >= (*ub)[t] && v > 0.0))) {
                         fixed[t] = 1;
                         dir[t] = 0.0;
                         changed = true;
@@ -1380,22 +1405,27 @@ static int ps_descend(mrbf_ctx *ctx, const ps::Problem &P, const std::vector<dou
                 }
                 if (!changed) break;
             }
-            for (int t = 0; t < d; ++t) XT[(size_t)u * d + t] = std::min(std::max(x[t] + dir[t], lb[t]), ub[t]);
+            for (int t = 0; t < d; ++t) XT[(size_t)u * d + t] = std::min(std::max(x[t] + dir[t], (*lb)[t]), (*ub)[t]);
         }
-        MRBF_TRY(ps_eval_points(ctx, P, XT.data(), NSTEP, allFT, &JT));
+        return true;
+    }
+    // values (NSTEP x nftot) and Jacobian rows (NSTEP x nobj x d) of the trial points
+    void consume(const double *allFT, const double *JT) {
+        const int d = P->d, k = (int)objs.size();
+        std::vector<double> row(P->nftot);
         evals += NSTEP;
         int bestj = -1;
         double bestv = val - 1e-13 * std::max(1.0, std::fabs(val));
         for (int j = 0; j < NSTEP; ++j) {
-            for (int c = 0; c < P.nftot; ++c) row[c] = allFT[(size_t)j * P.nftot + c];
+            for (int c = 0; c < P->nftot; ++c) row[c] = allFT[(size_t)j * P->nftot + c];
             double tt = -INFINITY;
-            for (int l = 0; l < k; ++l) tt = std::max(tt, (P.objective(row, objs[l]) - off[l]) / scale[l]);
+            for (int l = 0; l < k; ++l) tt = std::max(tt, (P->objective(row, objs[l]) - off[l]) / scale[l]);
             if (!(tt == tt) || !(tt < INFINITY)) continue;
-            bool feas = P.violation(row, &XT[(size_t)j * d]) == 0.0;
+            bool feas = P->violation(row, &XT[(size_t)j * d]) == 0.0;
             if (clamp) {
                 // tau = the t this x admits, a hair towards 0 so that rounding cannot make the PS constraints fail (descent.jl:443)
                 tt = std::min(std::max(tt < 0.0 ? tt * (1.0 - 1e-14) : tt, -1.0), 0.0);
-                for (int l = 0; l < k; ++l) feas = feas && (P.objective(row, objs[l]) - off[l] - tt * scale[l] <= 0.0);
+                for (int l = 0; l < k; ++l) feas = feas && (P->objective(row, objs[l]) - off[l] - tt * scale[l] <= 0.0);
             }
             if (feas && tt < bestv) {
                 bestv = tt;
@@ -1404,8 +1434,8 @@ static int ps_descend(mrbf_ctx *ctx, const ps::Problem &P, const std::vector<dou
         }
         if (bestj < 0) {
             frac *= std::ldexp(1.0, -NSTEP);  // nothing down to 2^-11 of the range improved: continue below it
-            if (frac < 1e-9) break;
-            continue;
+            if (frac < 1e-9) done = true;
+            return;
         }
         bool small = true;  // NLopt's xtol_rel test (descent.jl:379, :485), on two accepted steps in a row
         for (int t = 0; t < d; ++t) {
@@ -1413,15 +1443,66 @@ static int ps_descend(mrbf_ctx *ctx, const ps::Problem &P, const std::vector<dou
             small = small && std::fabs(xn2 - x[t]) <= xtol_rel * std::max(std::fabs(xn2), 1e-300);
             x[t] = xn2;
         }
-        allF.assign(allFT.begin() + (size_t)bestj * P.nftot, allFT.begin() + (size_t)(bestj + 1) * P.nftot);
-        J.assign(JT.begin() + (size_t)bestj * P.nobj * d, JT.begin() + (size_t)(bestj + 1) * P.nobj * d);
+        allF.assign(allFT + (size_t)bestj * P->nftot, allFT + (size_t)(bestj + 1) * P->nftot);
+        J.assign(JT + (size_t)bestj * P->nobj * d, JT + (size_t)(bestj + 1) * P->nobj * d);
         val = bestv;
         frac = std::min(1.0, frac * std::ldexp(4.0, -bestj));  // the accepted step sits two levels below the top of the next range
-        if (clamp && val <= -1.0) break;
+        if (clamp && val <= -1.0) done = true;
         nsmall = small ? nsmall + 1 : 0;
-        if (nsmall >= 2) break;
+        if (nsmall >= 2) done = true;
     }
-    *evals_out = evals;
+};
+
+// the descents of `ds` in lockstep: one evaluation (values + Jacobians of every active descent's points) per iteration
+static int ps_descend_many(mrbf_ctx *ctx, const ps::Problem &P, std::vector<Descent> &ds) {
+    const int d = P.d;
+    constexpr int NSTEP = Descent::NSTEP;
+    std::vector<double> X, allF, J;
+    std::vector<int> who;
+    for (auto &D : ds) D.start();
+    // the start points (values + Jacobian rows), one call
+    for (size_t i = 0; i < ds.size(); ++i)
+        if (ds[i].wants_start_eval()) who.push_back((int)i);
+    if (!who.empty()) {
+        X.resize(who.size() * (size_t)d);
+        for (size_t w = 0; w < who.size(); ++w) std::copy(ds[who[w]].x.begin(), ds[who[w]].x.end(), X.begin() + w * (size_t)d);
+        MRBF_TRY(ps_eval_points(ctx, P, X.data(), (int)who.size(), allF, &J));
+        for (size_t w = 0; w < who.size(); ++w) ds[who[w]].take_start(&allF[w * (size_t)P.nftot], &J[w * (size_t)P.nobj * d]);
+    }
+    for (;;) {
+        who.clear();
+        for (size_t i = 0; i < ds.size(); ++i)
+            if (ds[i].trials()) who.push_back((int)i);
+        if (who.empty()) break;
+        X.resize(who.size() * (size_t)NSTEP * d);
+        for (size_t w = 0; w < who.size(); ++w) std::copy(ds[who[w]].XT.begin(), ds[who[w]].XT.end(), X.begin() + w * (size_t)NSTEP * d);
+        MRBF_TRY(ps_eval_points(ctx, P, X.data(), (int)who.size() * NSTEP, allF, &J));
+        for (size_t w = 0; w < who.size(); ++w)
+            ds[who[w]].consume(&allF[w * (size_t)NSTEP * P.nftot], &J[w * (size_t)NSTEP * P.nobj * d]);
+    }
+    return 0;
+}
+
+static int ps_descend(mrbf_ctx *ctx, const ps::Problem &P, const std::vector<double> &lb, const std::vector<double> &ub, const std::vector<int> &objs,
+                      const std::vector<double> &off, const std::vector<double> &scale, bool clamp, int max_evals, double xtol_rel, double &val,
+                      std::vector<double> &x, int *evals_out) {
+    std::vector<Descent> ds(1);
+    Descent &D = ds[0];
+    D.P = &P;
+    D.lb = &lb;
+    D.ub = &ub;
+    D.objs = objs;
+    D.off = off;
+    D.scale = scale;
+    D.clamp = clamp;
+    D.max_evals = max_evals;
+    D.xtol_rel = xtol_rel;
+    D.val = val;
+    D.x = x;
+    MRBF_TRY(ps_descend_many(ctx, P, ds));
+    val = D.val;
+    x = D.x;
+    *evals_out = D.evals;
     return 0;
 }
 
@@ -1692,22 +1773,41 @@ extern "C" int32_t mrbf_ps_step_problem(mrbf_ctx *ctx, const mrbf_ps_problem *pr
             MRBF_HIP(ctx, hipMemcpyAsync(&bx[(size_t)l * (d + 2)], a.runs[l].best, (d + 2) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         MRBF_HIP(ctx, hipMemcpyAsync(hs.data(), stat, hs.size() * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         MRBF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        // r = f(x_n) - ideal point (descent.jl:536-538); a run that never met a feasible point contributes its start value.  The runs'
+        // best points are refined by gradient steps on their objective -- all k descents in lockstep, one evaluation per iteration
+        std::vector<double> ideal(k);
+        std::vector<Descent> ds;
+        std::vector<int> dl;
         for (int l = 0; l < k; ++l) {
-            // r = f(x_n) - ideal point (descent.jl:536-538); a run that never met a feasible point contributes its start value
             const double *b = &bx[(size_t)l * (d + 2)];
             const bool found = b[d + 1] == 0.0 && std::isfinite(b[d]);
-            double ideal = found ? b[d] : mx[l];
+            ideal[l] = found ? b[d] : mx[l];
             info->evals_ideal += hs[(size_t)4 * l];
             info->generations += hs[(size_t)4 * l + 2];
             const int left = max_ip - hs[(size_t)4 * l];
-            if (found && left >= 13 && !(dbg_env & 32)) {  // gradient steps on objective l from the run's best point
-                std::vector<double> xl(b, b + d);
-                int pe = 0;
-                MRBF_TRY(ps_descend(ctx, P, hlb, hub, std::vector<int>{l}, std::vector<double>{0.0}, std::vector<double>{1.0}, false, left, xtol, ideal, xl, &pe));
-                info->evals_ideal += pe;
+            if (found && left >= 13 && !(dbg_env & 32)) {
+                ds.emplace_back();
+                Descent &D = ds.back();
+                D.P = &P;
+                D.lb = &hlb;
+                D.ub = &hub;
+                D.objs = std::vector<int>{l};
+                D.off = std::vector<double>{0.0};
+                D.scale = std::vector<double>{1.0};
+                D.clamp = false;
+                D.max_evals = left;
+                D.xtol_rel = xtol;
+                D.val = ideal[l];
+                D.x.assign(b, b + d);
+                dl.push_back(l);
             }
-            r[l] = hfx[l] - ideal;
         }
+        if (!ds.empty()) MRBF_TRY(ps_descend_many(ctx, P, ds));
+        for (size_t i = 0; i < ds.size(); ++i) {
+            ideal[dl[i]] = ds[i].val;
+            info->evals_ideal += ds[i].evals;
+        }
+        for (int l = 0; l < k; ++l) r[l] = hfx[l] - ideal[l];
     }
     info->tau = 0.0;
     bool critical = false;
