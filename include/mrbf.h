@@ -346,7 +346,8 @@ int32_t mrbf_ps_step_problem(mrbf_ctx *ctx, const mrbf_ps_problem *problem, cons
  * generation -- f[lam] objective values, phi[lam] constraint violations (0 feasible, inf outside the budget) -- by the kernels of
  * the step: impl 0 one workgroup, 1 several compute units (lam >= 1024: one wave per 64 individuals, the records in registers),
  * 2 the same giving up at once (the time-out path), 6 the sixteen-workgroup form of round 5 (records in LDS),
- * 7 a timing experiment (1 without the wait for the neighbours: not a ranking),
+ * 7 a timing experiment (1 without the wait for the neighbours: not a ranking), 9 as 0 with the one-pair-per-thread loop through LDS
+ * for populations below 1024 too (round 6 ranks those with a wave per 96 individuals inside the one workgroup),
  * 3 one workgroup with the plain sort of a feasible generation in its one-pair-per-thread form (the form before round 6),
  * 4 one workgroup with the step's own mu = ceil(lam / 7): only the parents are ranked (order_out[mu ..] = -1), 5 the same without
  * the parent selection (the whole population sorted).

@@ -414,6 +414,200 @@ __device__ __forceinline__ bool select_parents(const double *__restrict__ fin, i
 // mode 0: everything in this launch.  Large populations with infeasible individuals (mode 1 / 2): mode 1 does the bookkeeping and, when
 // the transposition phases are due, hands them to ps_rank_sort_kernel (sixteen workgroups per run); mode 2 picks the order up (or runs the
 // phases here after all if that kernel gave up: it never touches f / phi) and finishes the generation.
+constexpr int RW_OWN = 64, RW_H = 32;
+constexpr int RW_CNT_T = 256;  // individuals per counting workgroup
+__host__ __device__ inline int rw_waves(int lam) { return (lam + RW_OWN - 1) / RW_OWN; }
+__host__ __device__ inline int rw_pitch(int lam) { return ((lam / 2 + RW_OWN + 63) / 64) * 64; }  // pair slots of a group, plus the last window's overhang
+__host__ __device__ inline int rw_jsplit(int lam) { return lam > 2048 ? 32 : 8; }                 // the counting's split of the "other individual" loop
+
+typedef unsigned long long u64;
+// lane mask in a scalar register pair ? a : b
+__device__ __forceinline__ unsigned msel(u64 m, unsigned a, unsigned b) {
+    unsigned d;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(d) : "v"(b), "v"(a), "s"(m));
+    return d;
+}
+// 16-bit compares of the two halves of a key, straight into a lane mask
+__device__ __forceinline__ u64 gt_hi16(unsigned a, unsigned b) {
+    u64 m;
+    asm("v_cmp_gt_u16_sdwa %0, %1, %2 src0_sel:WORD_1 src1_sel:WORD_1" : "=s"(m) : "v"(a), "v"(b));
+    return m;
+}
+__device__ __forceinline__ u64 gt_lo16(unsigned a, unsigned b) {
+    u64 m;
+    asm("v_cmp_gt_u16_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b));
+    return m;
+}
+__device__ __forceinline__ u64 zero_lo16(unsigned a) {
+    u64 m;
+    asm("v_cmp_eq_u16_e64 %0, 0, %1" : "=s"(m) : "v"(a));
+    return m;
+}
+// (bound_ctrl: the lane without a source reads 0 -- its pair is masked off -- and the move needs no initialised destination)
+__device__ __forceinline__ unsigned dpp_from_next(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true); }  // wave_shl:1 -- lane l reads lane l + 1
+__device__ __forceinline__ unsigned dpp_from_prev(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true); }  // wave_shr:1 -- lane l reads lane l - 1
+
+// 4 NG phases on a window (KA / KB the keys, IA / IB the individuals of this lane's two positions).  TAIL: the ranking's last, short
+// block -- phases from nph on do nothing.
+template <bool TAIL, int NG>
+__device__ __forceinline__ void rw_block(unsigned &KA, unsigned &KB, unsigned &IA, unsigned &IB, u64 dbits, int nph, u64 mPairE, u64 mPairO, u64 mOwnE,
+                                         u64 mOwnO, u64 &moved) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const unsigned dg = (unsigned)(dbits >> (8 * g));  // (g < 4: low word, else high word -- resolved at compile time)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const u64 live = (!TAIL || 4 * g + q < nph) ? ~0ull : 0ull;
+            const u64 mDraw = __builtin_amdgcn_ballot_w64((dg & (1u << q)) != 0u);
+            if ((q & 1) == 0) {
+                const u64 gtf = gt_hi16(KA, KB), gtp = gt_lo16(KA, KB);
+                const u64 byf = zero_lo16(KA | KB) | mDraw;
+                u64 worse = mPairE & (gtp ^ (byf & (gtf ^ gtp)));
+                if (TAIL) worse &= live;
+                const unsigned tk = KA, ti = IA;
+                KA = msel(worse, KB, KA);
+                IA = msel(worse, IB, IA);
+                KB = msel(worse, tk, KB);
+                IB = msel(worse, ti, IB);
+                moved |= worse & mOwnE;
+            } else {
+                const unsigned KN = dpp_from_next(KA);
+                const u64 gtf = gt_hi16(KB, KN), gtp = gt_lo16(KB, KN);
+                const u64 byf = zero_lo16(KB | KN) | mDraw;
+                u64 worse = mPairO & (gtp ^ (byf & (gtf ^ gtp)));
+                if (TAIL) worse &= live;
+                const u64 wprev = worse << 1;  // lane l + 1 takes lane l's second record when lane l's pair swaps
+                const unsigned IN = dpp_from_next(IA), KP = dpp_from_prev(KB), IP = dpp_from_prev(IB);
+                KB = msel(worse, KN, KB);
+                IB = msel(worse, IN, IB);
+                KA = msel(wprev, KP, KA);
+                IA = msel(wprev, IP, IA);
+                moved |= worse & mOwnO;
+            }
+        }
+    }
+}
+
+
+// ---- populations below RS_MINLAM: the same phases inside ps_rank_kernel's ONE workgroup (round 6).  The one-pair-per-thread loop
+// through LDS costs 0.35 us per phase (a barrier of the whole workgroup per phase: 99 us per ranking at lam = 280, the largest item of
+// a generation at d = 12); here wave w < ceil(lam / 96) holds a window of 128 two-word records in registers (its own 96, 16 of either
+// neighbour), runs sixteen phases on them without a barrier (rw_block), and the waves exchange their parts through LDS at ONE
+// workgroup barrier per sixteen phases -- which is also where this population size tests for sixteen phases without a swap.  Keys by
+// counting and draws (one chunk of 256 phases at a time) are made by all threads of the workgroup.  Same comparisons, same draws,
+// same exit rule as the loop it replaces (MRBF_PS_DBG 2048 keeps that loop; tests compare both with the NumPy oracle).
+constexpr int RWS_OWN = 96, RWS_H = 16;
+__host__ __device__ inline int rws_waves(int lam) { return (lam + RWS_OWN - 1) / RWS_OWN; }
+__host__ __device__ inline int rws_pitch(int lam) { return ((lam / 2 + 64 + 7) / 8) * 8; }
+__host__ __device__ inline size_t rws_smem_bytes(int lam) {  // f, phi | keys | two exchange buffers (key, index) | order | draws of a chunk | words
+    const size_t lp = (size_t)((lam + 1) & ~1);
+    return 16 * lp + 4 * lp + 16 * lp + 4 * lp + (size_t)64 * rws_pitch(lam) + 64;
+}
+// false: the generation holds a NaN (no rank): the caller's loop ranks it.  On success sidx_out[0 .. lam) is the order.
+__device__ __forceinline__ bool rank_small_waves(const Args &a, const Run &R, int run, double *smem, int *&sidx_out) {
+    const int tid = threadIdx.x, NT = blockDim.x, lane = tid & 63, wave = tid >> 6;
+    const int lam = R.lam, lp = (lam + 1) & ~1, nw = rws_waves(lam), pitch = rws_pitch(lam), nslots = lam / 2;
+    double *sf = smem, *sphi = sf + lp;
+    unsigned *skey = reinterpret_cast<unsigned *>(sphi + lp);
+    unsigned *xk = skey + lp;        // [2][lp]
+    unsigned *xi = xk + 2 * lp;      // [2][lp]
+    int *sidx = reinterpret_cast<int *>(xi + 2 * lp);
+    unsigned char *sdraw = reinterpret_cast<unsigned char *>(sidx + lp);
+    int *s_moved = reinterpret_cast<int *>(sdraw + (size_t)64 * pitch);  // three words, used in turn
+    bool nan = false;
+    for (int i = tid; i < lam; i += NT) {
+        const double fi = R.f[i], pi = R.phi[i];
+        sf[i] = fi;
+        sphi[i] = pi;
+        nan = nan || fi != fi || pi != pi;
+    }
+    if (tid < 3) s_moved[tid] = 0;
+    if (__syncthreads_or(nan ? 1 : 0)) return false;
+    // keys: rank(f) << 16 | (0 if phi == 0, else 1 + rank(phi)), rank(x) = #{j : x_j < x}
+    for (int i = tid; i < lam; i += NT) {
+        const double fi = sf[i], pi = sphi[i];
+        int cf = 0, cp = 0;
+        for (int j = 0; j < lam; ++j) {
+            cf += sf[j] < fi ? 1 : 0;
+            cp += sphi[j] < pi ? 1 : 0;
+        }
+        skey[i] = ((unsigned)cf << 16) | (pi == 0.0 ? 0u : 1u + (unsigned)cp);
+    }
+    __syncthreads();
+    const bool ranks = wave < nw;
+    const int s0 = wave * RWS_OWN, e0 = min(lam, s0 + RWS_OWN), ws0 = s0 - RWS_H;
+    const int gA = ws0 + 2 * lane, gB = gA + 1;
+    const bool inA = ranks && gA >= 0 && gA < lam, inB = ranks && gB >= 0 && gB < lam;
+    const bool ownA = ranks && gA >= s0 && gA < e0, ownB = ranks && gB >= s0 && gB < e0;
+    const u64 mPairE = __builtin_amdgcn_ballot_w64(inA && inB), mPairO = __builtin_amdgcn_ballot_w64(inB && gB + 1 < lam && lane < 63);
+    const u64 mOwnE = __builtin_amdgcn_ballot_w64(ownA), mOwnO = __builtin_amdgcn_ballot_w64(ownB);
+    const int slot = max(0, gA >> 1);
+    unsigned KA = inA ? skey[gA] : 0u, KB = inB ? skey[gB] : 0u, IA = (unsigned)gA, IB = (unsigned)gB;
+    int blkno = 0;
+    bool quiet_exit = false;
+    for (int c = 0; c * 256 < lam && !quiet_exit; ++c) {
+        // draws of this chunk: byte [group][pair slot], bit q = phase q of the group compares by objective
+        const int ng = min(64, (lam - 256 * c + 3) / 4);
+        for (int e = tid; e < ng * pitch; e += NT) {
+            const int g = e / pitch, m = e % pitch;
+            unsigned bits = 0;
+            if (m < nslots) {
+                unsigned c4[4] = {(unsigned)m, (unsigned)(256 * c + 4 * g), (unsigned)(a.gen * 16 + 1), (unsigned)run};
+                philox(c4, (unsigned)a.seed, (unsigned)(a.seed >> 32));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bits |= (((double)c4[q] + 0.5) * (1.0 / 4294967296.0) < 0.45) ? (1u << q) : 0u;
+            }
+            sdraw[e] = (unsigned char)bits;
+        }
+        __syncthreads();
+        for (int b = 0; b < 16; ++b, ++blkno) {
+            const int phb = 256 * c + 16 * b;
+            if (phb >= lam) break;
+            const int par = blkno & 1;
+            if (ranks) {
+                u64 dbits = 0;
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    if (4 * b + g < ng) dbits |= (u64)sdraw[(size_t)(4 * b + g) * pitch + slot] << (8 * g);
+                u64 moved = 0;
+                if (phb + 16 <= lam)
+                    rw_block<false, 4>(KA, KB, IA, IB, dbits, 16, mPairE, mPairO, mOwnE, mOwnO, moved);
+                else
+                    rw_block<true, 4>(KA, KB, IA, IB, dbits, lam - phb, mPairE, mPairO, mOwnE, mOwnO, moved);
+                if (ownA) {
+                    xk[par * lp + gA] = KA;
+                    xi[par * lp + gA] = IA;
+                }
+                if (ownB) {
+                    xk[par * lp + gB] = KB;
+                    xi[par * lp + gB] = IB;
+                }
+                if (moved != 0 && lane == 0) s_moved[blkno % 3] = 1;
+            }
+            __syncthreads();
+            const int any = s_moved[blkno % 3];
+            if (tid == 0) s_moved[(blkno + 2) % 3] = 0;  // (its last readers passed this barrier's predecessor; its next writers come after this one)
+            if (!any) {  // sixteen phases without a swap: ranked under the drawn rules
+                quiet_exit = true;
+                break;
+            }
+            if (inA && !ownA) {
+                KA = xk[par * lp + gA];
+                IA = xi[par * lp + gA];
+            }
+            if (inB && !ownB) {
+                KB = xk[par * lp + gB];
+                IB = xi[par * lp + gB];
+            }
+        }
+    }
+    if (ownA) sidx[gA] = (int)IA;
+    if (ownB) sidx[gB] = (int)IB;
+    __syncthreads();
+    sidx_out = sidx;
+    return true;
+}
+
 __global__ __launch_bounds__(RANK_THREADS) void ps_rank_kernel(Args a, int mode, RankWs ws) {
     extern __shared__ double smem[];
     __shared__ double s_red[2 * (RANK_THREADS / 64)];
@@ -573,6 +767,9 @@ __global__ __launch_bounds__(RANK_THREADS) void ps_rank_kernel(Args a, int mode,
         // lam phases of odd-even transposition; a pair is compared by f when both are feasible or with probability 0.45, else by
         // the constraint violation (Runarsson & Yao).  The records themselves are swapped; one Philox call feeds four phases of a
         // pair; one barrier per phase.
+        if (lam < RS_MINLAM && !(a.dbg & 2048) && NT >= 64 * rws_waves(lam) && rank_small_waves(a, R, run, smem, sidx)) {
+            // (the order is in sidx: the records stayed in registers -- see rank_small_waves)
+        } else {
         double *sf = smem, *sphi = sf + lam;
         sidx = (int *)(sphi + lam);
         for (int i = tid; i < lam; i += NT) {
@@ -641,6 +838,7 @@ __global__ __launch_bounds__(RANK_THREADS) void ps_rank_kernel(Args a, int mode,
             }
         }
         __syncthreads();
+        }
     }
     // the parents, in rank order
     for (int i = tid; i < mu; i += NT) R.order[i] = sidx[i];
@@ -815,13 +1013,6 @@ __global__ __launch_bounds__(RS_THREADS) void ps_rank_sort_kernel(Args a, RankWs
 //     two exactly (ties stay ties), so a record is TWO words -- (rank of f) << 16 | (0 if phi == 0, else 1 + rank of phi), and the
 //     index -- instead of five, compared by 16-bit integer compares.  (NaN has no rank: ps_rank_kernel does not hand such a
 //     generation over.)
-constexpr int RW_OWN = 64, RW_H = 32;
-constexpr int RW_CNT_T = 256;  // individuals per counting workgroup
-__host__ __device__ inline int rw_waves(int lam) { return (lam + RW_OWN - 1) / RW_OWN; }
-__host__ __device__ inline int rw_pitch(int lam) { return ((lam / 2 + RW_OWN + 63) / 64) * 64; }  // pair slots of a group, plus the last window's overhang
-__host__ __device__ inline int rw_jsplit(int lam) { return lam > 2048 ? 32 : 8; }                 // the counting's split of the "other individual" loop
-
-typedef unsigned long long u64;
 // grid.x = [draw workgroups | counting workgroups]; the counts (ws.cnt: lam objective counts, then lam violation counts per run) are
 // zeroed by ps_rank_kernel (mode 1) when it hands the generation over
 __global__ __launch_bounds__(256) void ps_rank_prep_kernel(Args a, RankWs ws, u64 *draws, size_t per_run, int draw_blocks) {
@@ -884,73 +1075,6 @@ __global__ __launch_bounds__(256) void ps_rank_prep_kernel(Args a, RankWs ws, u6
     }
 }
 
-// lane mask in a scalar register pair ? a : b
-__device__ __forceinline__ unsigned msel(u64 m, unsigned a, unsigned b) {
-    unsigned d;
-    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(d) : "v"(b), "v"(a), "s"(m));
-    return d;
-}
-// 16-bit compares of the two halves of a key, straight into a lane mask
-__device__ __forceinline__ u64 gt_hi16(unsigned a, unsigned b) {
-    u64 m;
-    asm("v_cmp_gt_u16_sdwa %0, %1, %2 src0_sel:WORD_1 src1_sel:WORD_1" : "=s"(m) : "v"(a), "v"(b));
-    return m;
-}
-__device__ __forceinline__ u64 gt_lo16(unsigned a, unsigned b) {
-    u64 m;
-    asm("v_cmp_gt_u16_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b));
-    return m;
-}
-__device__ __forceinline__ u64 zero_lo16(unsigned a) {
-    u64 m;
-    asm("v_cmp_eq_u16_e64 %0, 0, %1" : "=s"(m) : "v"(a));
-    return m;
-}
-// (bound_ctrl: the lane without a source reads 0 -- its pair is masked off -- and the move needs no initialised destination)
-__device__ __forceinline__ unsigned dpp_from_next(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true); }  // wave_shl:1 -- lane l reads lane l + 1
-__device__ __forceinline__ unsigned dpp_from_prev(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true); }  // wave_shr:1 -- lane l reads lane l - 1
-
-// RW_H phases on a window (KA / KB the keys, IA / IB the individuals of this lane's two positions).  TAIL: the ranking's last, short
-// block -- phases from nph on do nothing.
-template <bool TAIL>
-__device__ __forceinline__ void rw_block(unsigned &KA, unsigned &KB, unsigned &IA, unsigned &IB, u64 dbits, int nph, u64 mPairE, u64 mPairO, u64 mOwnE,
-                                         u64 mOwnO, u64 &moved) {
-#pragma unroll
-    for (int g = 0; g < RW_H / 4; ++g) {
-        const unsigned dg = (unsigned)(dbits >> (8 * g));  // (g < 4: low word, else high word -- resolved at compile time)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const u64 live = (!TAIL || 4 * g + q < nph) ? ~0ull : 0ull;
-            const u64 mDraw = __builtin_amdgcn_ballot_w64((dg & (1u << q)) != 0u);
-            if ((q & 1) == 0) {
-                const u64 gtf = gt_hi16(KA, KB), gtp = gt_lo16(KA, KB);
-                const u64 byf = zero_lo16(KA | KB) | mDraw;
-                u64 worse = mPairE & (gtp ^ (byf & (gtf ^ gtp)));
-                if (TAIL) worse &= live;
-                const unsigned tk = KA, ti = IA;
-                KA = msel(worse, KB, KA);
-                IA = msel(worse, IB, IA);
-                KB = msel(worse, tk, KB);
-                IB = msel(worse, ti, IB);
-                moved |= worse & mOwnE;
-            } else {
-                const unsigned KN = dpp_from_next(KA);
-                const u64 gtf = gt_hi16(KB, KN), gtp = gt_lo16(KB, KN);
-                const u64 byf = zero_lo16(KB | KN) | mDraw;
-                u64 worse = mPairO & (gtp ^ (byf & (gtf ^ gtp)));
-                if (TAIL) worse &= live;
-                const u64 wprev = worse << 1;  // lane l + 1 takes lane l's second record when lane l's pair swaps
-                const unsigned IN = dpp_from_next(IA), KP = dpp_from_prev(KB), IP = dpp_from_prev(IB);
-                KB = msel(worse, KN, KB);
-                IB = msel(worse, IN, IB);
-                KA = msel(wprev, KP, KA);
-                IA = msel(wprev, IP, IA);
-                moved |= worse & mOwnO;
-            }
-        }
-    }
-}
-
 __global__ __launch_bounds__(64) void ps_rank_wave_kernel(Args a, RankWs ws, const u64 *draws, size_t per_run, unsigned epoch) {
     const int run = blockIdx.y, w = blockIdx.x, lane = threadIdx.x;
     const Run &R = a.runs[run];
@@ -993,9 +1117,9 @@ __global__ __launch_bounds__(64) void ps_rank_wave_kernel(Args a, RankWs ws, con
         const u64 dbits = dnext;
         if (blk + 1 < nblk) dnext = dr[(size_t)(blk + 1) * pitch];  // (next block's draws: in flight over this block)
         if (phb + RW_H <= lam)
-            rw_block<false>(KA, KB, IA, IB, dbits, RW_H, mPairE, mPairO, mOwnE, mOwnO, moved);
+            rw_block<false, RW_H / 4>(KA, KB, IA, IB, dbits, RW_H, mPairE, mPairO, mOwnE, mOwnO, moved);
         else
-            rw_block<true>(KA, KB, IA, IB, dbits, lam - phb, mPairE, mPairO, mOwnE, mOwnO, moved);
+            rw_block<true, RW_H / 4>(KA, KB, IA, IB, dbits, lam - phb, mPairE, mPairO, mOwnE, mOwnO, moved);
         // ---- publish this wave's part
         const int db = blk & 1;
         const unsigned tag = ((epoch & 0xffu) << 8) | (unsigned)(blk + 1);
@@ -1673,10 +1797,11 @@ extern "C" int32_t mrbf_ps_step_problem(mrbf_ctx *ctx, const mrbf_ps_problem *pr
         }
         int N = 1;
         while (N < maxlam) N <<= 1;
-        const size_t shm = std::max((size_t)20 * maxlam, (size_t)12 * N);
+        // (populations below RS_MINLAM: room and waves for rank_small_waves -- a wave per 96 individuals, a chunk of draws in LDS)
+        const size_t shm = std::max(std::max((size_t)20 * maxlam, (size_t)12 * N), maxlam < RS_MINLAM ? rws_smem_bytes(maxlam) : (size_t)0);
         MRBF_HIP(ctx, hipFuncSetAttribute((const void *)ps_rank_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
         // one thread per pair of the largest population (the bitonic network's N / 2 pairs), whole waves, at most RANK_THREADS
-        const int rank_threads = (int)std::min<int64_t>(RANK_THREADS, std::max<int64_t>(64, round_up(N / 2, 64)));
+        const int rank_threads = (int)std::min<int64_t>(RANK_THREADS, std::max<int64_t>(std::max<int64_t>(64, round_up(N / 2, 64)), maxlam < RS_MINLAM ? 64 * rws_waves(maxlam) : 0));
         // large populations: the transposition phases on RS_W workgroups per run (MRBF_PS_MULTI=0: one workgroup as in rounds 3 / 4)
         RankWs rw{};
         // (a counter wait that times out -- the workgroups of a run not resident together: a device shared with other work -- costs 5 ms; the
@@ -1903,7 +2028,7 @@ extern "C" int32_t mrbf_debug_ps_rank(mrbf_ctx *ctx, int32_t lam, const double *
     if (lam < 2 || lam > MAXLAM) return fail(ctx, -2, "mrbf_debug_ps_rank: lam = %d outside 2..%d", lam, MAXLAM);
     if (!f || !phi) return fail(ctx, -3, "f / phi is NULL");
     if (gen < 0) return fail(ctx, -6, "gen < 0");
-    if (impl < 0 || impl > 7) return fail(ctx, -7, "impl must be 0 .. 7");
+    if (impl < 0 || impl > 9 || impl == 8) return fail(ctx, -7, "impl must be 0 .. 7 or 9");
     if ((impl == 1 || impl == 2 || impl == 6 || impl == 7) && lam < RS_MINLAM) return fail(ctx, -7, "mrbf_debug_ps_rank: the several-workgroup ranking takes populations >= %d", RS_MINLAM);
     if (!order_out) return fail(ctx, -8, "order_out is NULL");
     (void)hipSetDevice(ctx->device);
@@ -1917,7 +2042,7 @@ extern "C" int32_t mrbf_debug_ps_rank(mrbf_ctx *ctx, int32_t lam, const double *
     a.seed = seed;
     a.gen = gen;
     a.xtol_rel = 1e-3;
-    a.dbg = impl == 2 ? 64 : (impl == 3 ? 128 : (impl == 5 ? 256 : (impl == 4 ? 512 : (impl == 7 ? 1024 : 0))));  // (3: the plain sort as one pair per thread through LDS; 5: no parent selection)
+    a.dbg = impl == 2 ? 64 : (impl == 3 ? 128 : (impl == 5 ? 256 : (impl == 4 ? 512 : (impl == 7 ? 1024 : (impl == 9 ? 2048 : 0)))));  // (3: the plain sort as one pair per thread through LDS; 5: no parent selection)
     R.nvar = 1;
     R.lam = lam;
     R.mu = (impl == 4 || impl == 5) ? (lam + 6) / 7 : lam;  // mu = lam: the whole order comes out; 4 / 5: the step's own mu (order_out beyond it: -1)
@@ -1936,9 +2061,9 @@ extern "C" int32_t mrbf_debug_ps_rank(mrbf_ctx *ctx, int32_t lam, const double *
     MRBF_HIP(ctx, hipMemsetAsync(stat, 0, (size_t)4 * MAXRUNS * sizeof(int), ctx->stream));
     int N = 1;
     while (N < lam) N <<= 1;
-    const size_t shm = std::max((size_t)20 * lam, (size_t)12 * N);
+    const size_t shm = std::max(std::max((size_t)20 * lam, (size_t)12 * N), lam < RS_MINLAM ? rws_smem_bytes(lam) : (size_t)0);
     MRBF_HIP(ctx, hipFuncSetAttribute((const void *)ps_rank_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-    const int rank_threads = (int)std::min<int64_t>(RANK_THREADS, std::max<int64_t>(64, round_up(N / 2, 64)));
+    const int rank_threads = (int)std::min<int64_t>(RANK_THREADS, std::max<int64_t>(std::max<int64_t>(64, round_up(N / 2, 64)), lam < RS_MINLAM ? 64 * rws_waves(lam) : 0));
     RankWs rw{};
     const bool several = impl == 1 || impl == 2 || impl == 6 || impl == 7;
     unsigned long long *draws = nullptr;

@@ -613,6 +613,33 @@ def test_ps_ranking_kernels_share_one_exit_rule(lam):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("lam", [66, 130, 280, 523, 700, 1000, 1023])
+def test_ps_ranking_of_small_populations_in_registers(lam):
+    """Populations below 1024 (d < 50: Morbit's own problem sizes) are ranked inside ps_rank_kernel's one workgroup.  Round 6: a wave
+    per 96 individuals with the records (rank keys + index) in registers, sixteen phases between workgroup barriers, the draws and
+    keys made by all threads (rank_small_waves) -- instead of one pair per thread through LDS with a barrier per phase (impl 9).
+    Same comparisons, draws and exit rule (a no-swap test every sixteen phases): both orders == the NumPy oracle's, entry by entry,
+    on the fixtures that take the early exit, on ties in both keys, and with a NaN (which stays in the old loop)."""
+    from morbit.jl_amd import _lib
+    from oracle import ps_rank_oracle as pro
+
+    ctx = pkg.Context()
+    try:
+        took_early = 0
+        for seed, gen in ((11, 3), (2 ** 40 + 17, 0)):
+            for name, f, phi in _rank_fixtures(lam, seed=lam):
+                want, phases = pro.stochastic_rank(f, phi, seed=seed, gen=gen)
+                took_early += phases < lam
+                for impl in (0, 9):
+                    order = np.empty(lam, dtype=np.int32)
+                    ctx.check(ctx.lib.mrbf_debug_ps_rank(ctx.h, lam, _lib.as_ptr(f), _lib.as_ptr(phi), seed, gen, impl, order.ctypes.data_as(_lib.c_ip), None))
+                    assert np.array_equal(order, want), (lam, name, seed, gen, impl, int(np.argmax(order != want)))
+        assert took_early >= 2, took_early
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("lam", [130, 700, 1320, 2600, 5160, 7000])
 def test_ps_plain_sort_in_registers_is_the_sort(lam):
     """A generation without infeasible individuals is ranked by a bitonic network (ps_rank_kernel).  Round 6: E = 2 / 4 / 8 elements per
