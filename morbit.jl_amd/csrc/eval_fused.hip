@@ -731,6 +731,55 @@ __global__ __launch_bounds__(128) void eval_combine_kernel(EvalDesc one, const E
     }
 }
 
+// The same for a pass without Jacobians (round 6; the PS solver's populations: one such pass per generation), a WAVE per query point:
+// the coefficient sums are not read, the splits' loads are in flight together, four points per workgroup.  Every sum in the order of
+// eval_combine_kernel (splits ascending; tail: the 128 partial products t, t + 128 summed t ascending) -- the values are bit for bit
+// those of a call that also asks for Jacobians.
+template <int KOUT>
+__global__ __launch_bounds__(256) void eval_combine_vals_kernel(EvalDesc one, const EvalDesc *__restrict__ many, int l0) {
+    const EvalDesc &E = many ? many[blockIdx.y] : one;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t p = (int64_t)blockIdx.x * 4 + wave, m = E.m, mpad = E.mpad;
+    const bool active = p < m;
+    const double *__restrict__ vpart = E.vpart, *__restrict__ Xorig = E.X, *__restrict__ lam = E.lam;
+    const int nsplit = E.nsplit, d = E.d, k = E.k, q = E.q;
+    __shared__ double pdot[4][KOUT][128];
+    double v = 0.0;
+    if (active && lane < KOUT && l0 + lane < k) {
+        for (int s0 = 0; s0 < nsplit; s0 += 8) {
+            double x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = s0 + u < nsplit ? vpart[((int64_t)(s0 + u) * mpad + p) * KOUT + lane] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (s0 + u < nsplit) v += x[u];
+        }
+    }
+    if (q > 1) {
+#pragma unroll
+        for (int l = 0; l < KOUT; ++l)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int t0 = lane + 64 * h;
+                double acc = 0.0;
+                if (active && l0 + l < k)
+                    for (int t = t0; t < d; t += 128) acc = fma(lam[(int64_t)(t + 1) * k + l0 + l], Xorig[p * d + t], acc);
+                pdot[wave][l][t0] = acc;
+            }
+    }
+    __syncthreads();
+    if (active && lane < KOUT && l0 + lane < k) {
+        if (q > 0) v += lam[l0 + lane];
+        if (q > 1) {
+            const int nt = d < 128 ? d : 128;
+            double dsum = 0.0;
+            for (int t = 0; t < nt; ++t) dsum += pdot[wave][lane][t];  // fixed order
+            v += dsum;
+        }
+        if (E.vals) E.vals[p * k + l0 + lane] = v;
+    }
+}
+
 // queries: Xq[row][t] = X[row][t] - mean[t] (zero in the padding), xsq[row] = |Xq[row]|^2 -- center_pad_kernel's arithmetic (prep.hip)
 __global__ void center_pad_batch_kernel(const EvalDesc *__restrict__ many, int Dfixed) {
     const EvalDesc &E = many[blockIdx.y];
@@ -876,6 +925,15 @@ static int launch_fused(mrbf_ctx *ctx, bool want_jac, bool final_, dim3 grid, co
     return launch_fused3<KID, false, KOUT, DT, QLDS>(ctx, want_jac, final_, grid, one, many, l0);
 }
 
+template <int KOUT>
+static void launch_combine(mrbf_ctx *ctx, bool want_jac, dim3 cgrid, const EvalDesc &one, const EvalDesc *many, int l0, int D) {
+    static const int vals_combine = mrbf_env("MRBF_EVAL_COMBINE_VALS") ? atoi(mrbf_env("MRBF_EVAL_COMBINE_VALS")) : 1;
+    if (!want_jac && vals_combine)
+        hipLaunchKernelGGL(eval_combine_vals_kernel<KOUT>, dim3((cgrid.x + 3) / 4, cgrid.y), dim3(256), 0, ctx->stream, one, many, l0);
+    else
+        hipLaunchKernelGGL(eval_combine_kernel<KOUT>, cgrid, dim3(128), 0, ctx->stream, one, many, l0, D);
+}
+
 // the passes over the outputs of one evaluation (single: many == nullptr, `one` by value; batch: blockIdx.z / .y = problem)
 static int run_passes(mrbf_ctx *ctx, const KP &kp, int D, int k, bool want_jac, bool final_, dim3 grid, dim3 cgrid, const EvalDesc &one,
                       const EvalDesc *many) {
@@ -888,14 +946,14 @@ static int run_passes(mrbf_ctx *ctx, const KP &kp, int D, int k, bool want_jac, 
 #define MRBF_EF256(KOV) MRBF_DISPATCH_KID(kp.kid, MRBF_TRY((launch_split<KID, KOV, 128, 32>(ctx, want_jac, final_, grid, kp, one, many, l0))))
         if (D == 256 && ko == 2) {  // (values only)
             MRBF_DISPATCH_KID(kp.kid, MRBF_TRY((launch_split_vals<KID, 2, 128, 32>(ctx, final_, grid, kp, one, many, l0))));
-            if (!final_) hipLaunchKernelGGL(eval_combine_kernel<2>, cgrid, dim3(128), 0, ctx->stream, one, many, l0, D);
+            if (!final_) launch_combine<2>(ctx, want_jac, cgrid, one, many, l0, D);
         } else if (D == 256) {
             if (!want_jac) {
                 MRBF_DISPATCH_KID(kp.kid, MRBF_TRY((launch_split_vals<KID, 1, 128, 32>(ctx, final_, grid, kp, one, many, l0))));
             } else {
                 MRBF_EF256(1);
             }
-            if (!final_) hipLaunchKernelGGL(eval_combine_kernel<1>, cgrid, dim3(128), 0, ctx->stream, one, many, l0, D);
+            if (!final_) launch_combine<1>(ctx, want_jac, cgrid, one, many, l0, D);
         } else if (ko == 2) {
             if (D == 64) {
                 MRBF_EF(2, 4, false);
@@ -904,7 +962,7 @@ static int run_passes(mrbf_ctx *ctx, const KP &kp, int D, int k, bool want_jac, 
             } else {
                 MRBF_EF(2, 8, true);
             }
-            if (!final_) hipLaunchKernelGGL(eval_combine_kernel<2>, cgrid, dim3(128), 0, ctx->stream, one, many, l0, D);
+            if (!final_) launch_combine<2>(ctx, want_jac, cgrid, one, many, l0, D);
         } else {
             if (D == 64) {
                 MRBF_EF(1, 4, false);
@@ -913,7 +971,7 @@ static int run_passes(mrbf_ctx *ctx, const KP &kp, int D, int k, bool want_jac, 
             } else {
                 MRBF_EF(1, 8, false);
             }
-            if (!final_) hipLaunchKernelGGL(eval_combine_kernel<1>, cgrid, dim3(128), 0, ctx->stream, one, many, l0, D);
+            if (!final_) launch_combine<1>(ctx, want_jac, cgrid, one, many, l0, D);
         }
 #undef MRBF_EF
 #undef MRBF_EF128
