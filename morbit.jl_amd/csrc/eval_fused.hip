@@ -690,9 +690,19 @@ __global__ __launch_bounds__(128) void eval_combine_kernel(EvalDesc one, const E
     const int tid = threadIdx.x;
     if (tid < KOUT && l0 + tid < k) {
         double v = 0.0, a = 0.0;
-        for (int s = 0; s < nsplit; ++s) {
-            v += vpart[((int64_t)s * mpad + p) * KOUT + tid];
-            a += sapart[((int64_t)s * mpad + p) * KOUT + tid];
+        for (int s0 = 0; s0 < nsplit; s0 += 8) {
+            double xv[8], xa[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                xv[u] = s0 + u < nsplit ? vpart[((int64_t)(s0 + u) * mpad + p) * KOUT + tid] : 0.0;
+                xa[u] = s0 + u < nsplit ? sapart[((int64_t)(s0 + u) * mpad + p) * KOUT + tid] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (s0 + u < nsplit) {
+                    v += xv[u];
+                    a += xa[u];
+                }
         }
         sa[tid] = a;
         sv[tid] = v;
@@ -724,7 +734,14 @@ __global__ __launch_bounds__(128) void eval_combine_kernel(EvalDesc one, const E
         const int l = e / d, t = e % d;
         if (l0 + l >= k) continue;
         double g = 0.0;
-        for (int s = 0; s < nsplit; ++s) g += gpart[(((int64_t)s * mpad + p) * KOUT + l) * D + t];
+        for (int s0 = 0; s0 < nsplit; s0 += 8) {  // eight loads in flight, added in the order of the splits (a load per addition was a memory round trip each)
+            double x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = s0 + u < nsplit ? gpart[(((int64_t)(s0 + u) * mpad + p) * KOUT + l) * D + t] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (s0 + u < nsplit) g += x[u];
+        }
         double v = fma(sa[l], Xq[p * D + t], -g);
         if (q > 1) v += lam[(int64_t)(t + 1) * k + l0 + l];
         jac[p * (int64_t)k * d + (int64_t)t * k + l0 + l] = v;
