@@ -724,13 +724,15 @@ __global__ __launch_bounds__(RANK_THREADS) void ps_rank_kernel(Args a, int mode,
                select_parents(R.f, lam, mu, smem, (int *)(smem + npow2(lam)))) {  // (measured: pays from lam > 4096 on -- 135 against 195 us per ranking at
                                                                                   // lam = 5160; below, its sampling pass costs what the shorter sort saves; dbg 512 forces it)
         sidx = (int *)(smem + npow2(lam));  // (parents found and ranked without sorting the rest: see select_parents)
-    } else if (plain_sort && !(a.dbg & 128) && (npow2(lam) == 2 * NT || npow2(lam) == 4 * NT || npow2(lam) == 8 * NT)) {
+    } else if (plain_sort && !(a.dbg & 128) && (npow2(lam) == NT || npow2(lam) == 2 * NT || npow2(lam) == 4 * NT || npow2(lam) == 8 * NT)) {
         // (the launch's thread count follows the LARGEST population: N / 2 up to N = 2048, 1024 beyond; a run whose padded size is not
         // 2, 4 or 8 elements per thread -- a much smaller run in the same launch -- takes the one-pair-per-thread form below)
         const int N = npow2(lam);
         double *sf = smem;      // N keys: violation is 0 or inf here, and inf comes with f = inf
         sidx = (int *)(sf + N);
-        if (N == 2 * NT)
+        if (N == NT)
+            bitonic_regs<1>(R.f, nullptr, lam, N, sf, sidx);
+        else if (N == 2 * NT)
             bitonic_regs<2>(R.f, nullptr, lam, N, sf, sidx);
         else if (N == 4 * NT)
             bitonic_regs<4>(R.f, nullptr, lam, N, sf, sidx);
@@ -1797,11 +1799,21 @@ extern "C" int32_t mrbf_ps_step_problem(mrbf_ctx *ctx, const mrbf_ps_problem *pr
         }
         int N = 1;
         while (N < maxlam) N <<= 1;
-        // (populations below RS_MINLAM: room and waves for rank_small_waves -- a wave per 96 individuals, a chunk of draws in LDS)
-        const size_t shm = std::max(std::max((size_t)20 * maxlam, (size_t)12 * N), maxlam < RS_MINLAM ? rws_smem_bytes(maxlam) : (size_t)0);
+        // (populations below RS_MINLAM: room and waves for rank_small_waves -- a wave per 96 individuals, a chunk of draws in LDS;
+        //  over ALL runs of the launch: a small run beside a large one must find its room too)
+        size_t small_need = 0;
+        int small_waves = 0;
+        for (int q2 = 0; q2 < a.nruns; ++q2)
+            if (a.runs[q2].lam < RS_MINLAM) {
+                small_need = std::max(small_need, rws_smem_bytes(a.runs[q2].lam));
+                small_waves = std::max(small_waves, rws_waves(a.runs[q2].lam));
+            }
+        const size_t shm = std::max(std::max((size_t)20 * maxlam, (size_t)12 * N), small_need);
         MRBF_HIP(ctx, hipFuncSetAttribute((const void *)ps_rank_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
         // one thread per pair of the largest population (the bitonic network's N / 2 pairs), whole waves, at most RANK_THREADS
-        const int rank_threads = (int)std::min<int64_t>(RANK_THREADS, std::max<int64_t>(std::max<int64_t>(64, round_up(N / 2, 64)), maxlam < RS_MINLAM ? 64 * rws_waves(maxlam) : 0));
+        // (a small population that needs more waves than N / 2 threads hold takes N threads: the plain sort then runs as one element per thread)
+        int rank_threads = (int)std::min<int64_t>(RANK_THREADS, std::max<int64_t>(64, round_up(N / 2, 64)));
+        if (64 * small_waves > rank_threads) rank_threads = (int)std::min<int64_t>(RANK_THREADS, std::max<int64_t>(N, 64 * small_waves));
         // large populations: the transposition phases on RS_W workgroups per run (MRBF_PS_MULTI=0: one workgroup as in rounds 3 / 4)
         RankWs rw{};
         // (a counter wait that times out -- the workgroups of a run not resident together: a device shared with other work -- costs 5 ms; the
@@ -2063,7 +2075,8 @@ extern "C" int32_t mrbf_debug_ps_rank(mrbf_ctx *ctx, int32_t lam, const double *
     while (N < lam) N <<= 1;
     const size_t shm = std::max(std::max((size_t)20 * lam, (size_t)12 * N), lam < RS_MINLAM ? rws_smem_bytes(lam) : (size_t)0);
     MRBF_HIP(ctx, hipFuncSetAttribute((const void *)ps_rank_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-    const int rank_threads = (int)std::min<int64_t>(RANK_THREADS, std::max<int64_t>(std::max<int64_t>(64, round_up(N / 2, 64)), lam < RS_MINLAM ? 64 * rws_waves(lam) : 0));
+    int rank_threads = (int)std::min<int64_t>(RANK_THREADS, std::max<int64_t>(64, round_up(N / 2, 64)));
+    if (lam < RS_MINLAM && 64 * rws_waves(lam) > rank_threads) rank_threads = (int)std::min<int64_t>(RANK_THREADS, std::max<int64_t>(N, 64 * rws_waves(lam)));
     RankWs rw{};
     const bool several = impl == 1 || impl == 2 || impl == 6 || impl == 7;
     unsigned long long *draws = nullptr;

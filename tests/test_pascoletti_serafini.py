@@ -640,7 +640,7 @@ def test_ps_ranking_of_small_populations_in_registers(lam):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("lam", [130, 700, 1320, 2600, 5160, 7000])
+@pytest.mark.parametrize("lam", [130, 400, 700, 1000, 1320, 2600, 5160, 7000])   # (400, 1000: launches of N threads -- one element per thread)
 def test_ps_plain_sort_in_registers_is_the_sort(lam):
     """A generation without infeasible individuals is ranked by a bitonic network (ps_rank_kernel).  Round 6: E = 2 / 4 / 8 elements per
     thread in registers -- compare-exchanges inside the thread, through wave shuffles, and only the widest strides through LDS.  Against
