@@ -105,6 +105,7 @@ struct mrbf_ctx {
     int small_nc = 4;  // 1 after a cluster failure on this context (XCD placement, or a result that one workgroup does not reproduce)
     int small_cluster_ok = 0;    // the device is what the clusters' visibility argument assumes: gfx950, 8 XCDs x 32 CUs (context.hip)
     int small_timeouts = 0;      // barrier time-outs of clustered launches in a row (three: clusters off for this context)
+    const double *eval_pre_xq = nullptr;  // the PS solver's next population already centred / padded in the evaluation's own query buffers (eval_fused skips its centring launch when they are these)
     int eval_population = 0;     // set around the PS solver's population sweeps (values only): eval_nsplit may split small models there
     int eval_check_call = 0;     // set around the residual check's evaluation at the model's own sites: eval_nsplit keeps the pre-round-5 rule for it (batch.hip does the same)
     int live_models = 0, live_round4 = 0;  // handles created through this context and not yet released (MRBF_OPT_LIVE_HANDLES)

@@ -1070,7 +1070,9 @@ int eval_fused(mrbf_ctx *ctx, const mrbf_model *M, int64_t m, const double *X, d
     E.jac = jac;
     const bool timing = ctx->timing && info;
     if (timing) MRBF_HIP(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
-    MRBF_TRY(launch_center_pad(ctx, X, m, d, M->mean, nullptr, E.Xq, mpad, D, E.xsq));
+    // (the PS solver's breeding kernel writes its offspring centred and padded straight into these buffers -- same arithmetic as the
+    //  centring kernel, one launch per generation less; any other caller, or a buffer that moved, takes the launch)
+    if (!(ctx->eval_pre_xq && ctx->eval_pre_xq == E.Xq)) MRBF_TRY(launch_center_pad(ctx, X, m, d, M->mean, nullptr, E.Xq, mpad, D, E.xsq));
     dim3 grid((unsigned)(mpad / EQ), (unsigned)nsplit);
     MRBF_TRY(run_passes(ctx, M->kp, D, k, jac != nullptr, nsplit == 1, grid, dim3((unsigned)m), E, nullptr));
     if (timing) {

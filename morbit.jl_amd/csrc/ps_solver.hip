@@ -82,6 +82,9 @@ struct Args {
     const double *A_eq, *b_eq, *A_ineq, *b_ineq;
     double eq_tol;
     double *Xeval;           // evaluation batch, rows x d
+    double *Xq, *xsq;        // non-null: the breeding kernel also writes the batch centred and padded (rows x xqD, squared norms) for the one model
+    const double *xmean;     //           whose evaluation reads it (the arithmetic of center_pad_kernel, prep.hip)
+    int xqD;
     unsigned long long seed;
     double xtol_rel;
     int gen;
@@ -1206,6 +1209,9 @@ __global__ __launch_bounds__(256) void ps_breed_kernel(Args a) {
     double *xo = Xn + (size_t)o * n, *so = Sn + (size_t)o * n;
     const int skip = R.kind == 1 ? 1 : 0;
     double *xe = a.Xeval + (size_t)row * a.d;  // next generation's row of the evaluation batch (x part)
+    __shared__ double s_row[4][360];           // the wave's new x part (a.Xq: centred below with the centring kernel's lane mapping)
+    double *const srow = s_row[threadIdx.x >> 6];
+    const bool keep = a.Xq != nullptr;
     if (o < nd) {
         // differential variation towards the best individual; kept only if it stays inside the box
         const double *xb = X + (size_t)R.order[0] * n, *xq = X + (size_t)R.order[o + 1] * n;
@@ -1219,7 +1225,10 @@ __global__ __launch_bounds__(256) void ps_breed_kernel(Args a) {
             const double v = inside ? xp[c] + gamma * (xb[c] - xq[c]) : xp[c];
             xo[c] = v;
             so[c] = sp[c];
-            if (c >= skip) xe[c - skip] = v;
+            if (c >= skip) {
+                xe[c - skip] = v;
+                if (keep) srow[c - skip] = v;
+            }
         }
     } else {
         double u0, u1, zg, z1;
@@ -1238,9 +1247,24 @@ __global__ __launch_bounds__(256) void ps_breed_kernel(Args a) {
             }
             if (v < lo || v > hi) v = xp[c];
             xo[c] = v;
-            if (c >= skip) xe[c - skip] = v;
+            if (c >= skip) {
+                xe[c - skip] = v;
+                if (keep) srow[c - skip] = v;
+            }
             so[c] = sp[c] + alpha * (s - sp[c]);  // exponential smoothing
         }
+    }
+    if (keep) {  // Xq[row][t] = x[t] - mean[t] (zero in the padding), xsq[row] = |Xq[row]|^2: center_pad_kernel's arithmetic, lane for lane
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // (the wave's own LDS writes above are read by other lanes below)
+        double ss = 0.0;
+        for (int t = lane; t < a.xqD; t += 64) {
+            double v = 0.0;
+            if (t < a.d) v = srow[t] - a.xmean[t];
+            a.Xq[(size_t)row * a.xqD + t] = v;
+            ss = fma(v, v, ss);
+        }
+        for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+        if (lane == 0) a.xsq[row] = ss;
     }
 }
 
@@ -1826,15 +1850,35 @@ extern "C" int32_t mrbf_ps_step_problem(mrbf_ctx *ctx, const mrbf_ps_problem *pr
         rw.count_plain = (multi && multi_env != 2) ? 1 : 0;
         bool phases_possible = a.ncon + a.nlin_eq + a.nlin_ineq > 0 || (a.dbg & 4);
         for (int q2 = 0; q2 < a.nruns; ++q2) phases_possible = phases_possible || a.runs[q2].kind == 1;
+        // one model, fused evaluation: the breeding kernel writes the next population centred and padded into the evaluation's own query
+        // buffers (a launch per generation less; MRBF_PS_FUSEPAD=0: the evaluation's centring launch).  The buffers are the arena slots the
+        // evaluation will ask for -- same size, same pointer; eval_fused checks that and centres itself otherwise.
+        a.Xq = nullptr;
+        a.xsq = nullptr;
+        a.xmean = nullptr;
+        a.xqD = 0;
+        {
+            const int fusepad = mrbf_env("MRBF_PS_FUSEPAD") ? atoi(mrbf_env("MRBF_PS_FUSEPAD")) : 1;  // (read per call: the tests switch it inside one process)
+            const mrbf_model *M0 = P.models[0];
+            if (fusepad && P.nmodels == 1 && ctx->eval_impl != 1 && (M0->dpad == 64 || M0->dpad == 128 || M0->dpad == 256) && a.d <= 360) {
+                const int64_t mpad = round_up((int64_t)a.rows, 64);
+                MRBF_TRY(get_buf(ctx, S_EVAL_XC, (size_t)mpad * M0->dpad, &a.Xq));
+                MRBF_TRY(get_buf(ctx, S_EVAL_XSQ, (size_t)mpad, &a.xsq));
+                a.xmean = M0->mean;
+                a.xqD = M0->dpad;
+            }
+        }
         hipLaunchKernelGGL(ps_init_kernel, dim3((unsigned)((maxel + 255) / 256), (unsigned)a.nruns), dim3(256), 0, ctx->stream, a, start, t0);
         std::vector<int> hstat((size_t)4 * a.nruns);
         const unsigned wave_blocks = (unsigned)((a.rows + 3) / 4);
         for (int g = 0; g < max_gens; ++g) {
             a.gen = g;
             ctx->eval_population = 1;
+            ctx->eval_pre_xq = (g > 0 && a.Xq) ? a.Xq : nullptr;  // (generation 0 comes from ps_init_kernel: centred by the evaluation's own launch)
             int erc = 0;
             for (int j = 0; j < P.nmodels && !erc; ++j) erc = eval_model(ctx, P.models[j], a.rows, a.Xeval, const_cast<double *>(a.F[j]), nullptr, nullptr);
             ctx->eval_population = 0;
+            ctx->eval_pre_xq = nullptr;
             MRBF_TRY(erc);
             hipLaunchKernelGGL(ps_score_kernel, dim3(wave_blocks), dim3(256), 0, ctx->stream, a);
             hipLaunchKernelGGL(ps_rank_kernel, dim3((unsigned)a.nruns), dim3(rank_threads), shm, ctx->stream, a, multi ? 1 : 0, rw);
