@@ -82,6 +82,7 @@ struct Args {
     const double *A_eq, *b_eq, *A_ineq, *b_ineq;
     double eq_tol;
     double *Xeval;           // evaluation batch, rows x d
+    int score_fused;         // no linear constraints: ps_rank_kernel scores its own run's individuals (no ps_score_kernel launch)
     double *Xq, *xsq;        // non-null: the breeding kernel also writes the batch centred and padded (rows x xqD, squared norms) for the one model
     const double *xmean;     //           whose evaluation reads it (the arithmetic of center_pad_kernel, prep.hip)
     int xqD;
@@ -172,15 +173,11 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-// ---- objective and constraint violation of every individual of every run: one wave per row of the evaluation batch
-__global__ __launch_bounds__(256) void ps_score_kernel(Args a) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= a.rows) return;
-    const int run = run_of_row(a, row);
-    const Run &R = a.runs[run];
-    if (R.stat[1]) return;  // finished earlier
-    const int i = row - R.off;
+// ---- objective and constraint violation of individual i (row `row` of the evaluation batch) of run R.  WAVE: the 64 lanes of a wave
+// work on the row together (the linear constraints' dot products are summed over the lanes); otherwise one thread does the row --
+// problems without linear constraints only (ps_rank_kernel scores its own run that way: a launch per generation less).
+template <bool WAVE>
+__device__ __forceinline__ void score_row(const Args &a, const Run &R, int i, int row, int lane, double &f_out, double &phi_out) {
     const int m = min(R.lam, R.max_evals - R.stat[0]);  // individuals of this generation inside the budget
     double f = INFINITY, phi = INFINITY;
     if (i < m) {
@@ -215,23 +212,40 @@ __global__ __launch_bounds__(256) void ps_score_kernel(Args a) {
             else
                 phi += v > 0.0 ? v * v : (v == v ? 0.0 : INFINITY);
         }
-        const double *x = a.Xeval + (size_t)row * a.d;
-        for (int c = 0; c < a.nlin_eq + a.nlin_ineq; ++c) {  // linear constraints of the MOP in scaled variables
-            const bool eq = c < a.nlin_eq;
-            const double *Ar = eq ? a.A_eq + (size_t)c * a.d : a.A_ineq + (size_t)(c - a.nlin_eq) * a.d;
-            double s = 0.0;
-            for (int j = lane; j < a.d; j += 64) s = fma(Ar[j], x[j], s);
-            s = wave_sum(s) - (eq ? a.b_eq[c] : a.b_ineq[c - a.nlin_eq]);
-            if (eq)
-                phi += fabs(s) > a.eq_tol ? s * s : (s == s ? 0.0 : INFINITY);
-            else
-                phi += s > 0.0 ? s * s : (s == s ? 0.0 : INFINITY);
+        if constexpr (WAVE) {
+            const double *x = a.Xeval + (size_t)row * a.d;
+            for (int c = 0; c < a.nlin_eq + a.nlin_ineq; ++c) {  // linear constraints of the MOP in scaled variables
+                const bool eq = c < a.nlin_eq;
+                const double *Ar = eq ? a.A_eq + (size_t)c * a.d : a.A_ineq + (size_t)(c - a.nlin_eq) * a.d;
+                double s = 0.0;
+                for (int j = lane; j < a.d; j += 64) s = fma(Ar[j], x[j], s);
+                s = wave_sum(s) - (eq ? a.b_eq[c] : a.b_ineq[c - a.nlin_eq]);
+                if (eq)
+                    phi += fabs(s) > a.eq_tol ? s * s : (s == s ? 0.0 : INFINITY);
+                else
+                    phi += s > 0.0 ? s * s : (s == s ? 0.0 : INFINITY);
+            }
         }
         if (!(f == f) || !(phi == phi) || fabs(f) == INFINITY || fabs(phi) == INFINITY) {
             f = INFINITY;
             phi = INFINITY;
         }
     }
+    f_out = f;
+    phi_out = phi;
+}
+
+// one wave per row of the evaluation batch (problems with linear constraints; without, ps_rank_kernel scores its run itself)
+__global__ __launch_bounds__(256) void ps_score_kernel(Args a) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.rows) return;
+    const int run = run_of_row(a, row);
+    const Run &R = a.runs[run];
+    if (R.stat[1]) return;  // finished earlier
+    const int i = row - R.off;
+    double f, phi;
+    score_row<true>(a, R, i, row, lane, f, phi);
     if (lane == 0) {
         R.f[i] = f;
         R.phi[i] = phi;
@@ -631,6 +645,16 @@ __global__ __launch_bounds__(RANK_THREADS) void ps_rank_kernel(Args a, int mode,
         s_stop = 0;
     }
     __syncthreads();
+    // ---- (no linear constraints: the run's individuals are scored here, a thread per individual -- ps_score_kernel's arithmetic)
+    if (mode != 2 && a.score_fused) {
+        for (int i = tid; i < lam; i += NT) {
+            double fi, pi;
+            score_row<false>(a, R, i, R.off + i, 0, fi, pi);
+            R.f[i] = fi;
+            R.phi[i] = pi;
+        }
+        __syncthreads();  // f / phi of the run are read below (and by the launches that follow this one)
+    }
     // ---- this generation's best individual and whether any individual inside the budget violates a constraint
     if (mode != 2) {
         Cand mine{0.0, -1, 0x7fffffff};
@@ -1857,6 +1881,7 @@ extern "C" int32_t mrbf_ps_step_problem(mrbf_ctx *ctx, const mrbf_ps_problem *pr
         a.xsq = nullptr;
         a.xmean = nullptr;
         a.xqD = 0;
+        a.score_fused = (a.nlin_eq + a.nlin_ineq == 0 && !(mrbf_env("MRBF_PS_FUSESCORE") && atoi(mrbf_env("MRBF_PS_FUSESCORE")) == 0)) ? 1 : 0;
         {
             const int fusepad = mrbf_env("MRBF_PS_FUSEPAD") ? atoi(mrbf_env("MRBF_PS_FUSEPAD")) : 1;  // (read per call: the tests switch it inside one process)
             const mrbf_model *M0 = P.models[0];
@@ -1880,7 +1905,7 @@ extern "C" int32_t mrbf_ps_step_problem(mrbf_ctx *ctx, const mrbf_ps_problem *pr
             ctx->eval_population = 0;
             ctx->eval_pre_xq = nullptr;
             MRBF_TRY(erc);
-            hipLaunchKernelGGL(ps_score_kernel, dim3(wave_blocks), dim3(256), 0, ctx->stream, a);
+            if (!a.score_fused) hipLaunchKernelGGL(ps_score_kernel, dim3(wave_blocks), dim3(256), 0, ctx->stream, a);
             hipLaunchKernelGGL(ps_rank_kernel, dim3((unsigned)a.nruns), dim3(rank_threads), shm, ctx->stream, a, multi ? 1 : 0, rw);
             if (multi) {
                 rank_phases_launch(ctx, a, rw, draws, draws_per_run, maxlam, multi_env == 2 ? 2 : 1, phases_possible);

@@ -244,6 +244,7 @@ def test_ps_ranking_on_several_compute_units_is_the_same_ranking():
     out = {}
     for tag, env in (("multi", {}), ("single", {"MRBF_PS_MULTI": "0"}), ("workgroups", {"MRBF_PS_MULTI": "2"}), ("gave-up", {"MRBF_PS_DBG": "64"}), ("multi/phases", {"MRBF_PS_DBG": "4"}),
                      ("own-centring", {"MRBF_PS_FUSEPAD": "0"}),   # the evaluation's centring launch instead of the breeding kernel's centred copy
+                     ("own-scoring", {"MRBF_PS_FUSESCORE": "0"}),  # ps_score_kernel instead of the ranking kernel scoring its own run
                      ("single/phases", {"MRBF_PS_MULTI": "0", "MRBF_PS_DBG": "4"})):
         os.environ.update(env)
         try:
@@ -253,7 +254,7 @@ def test_ps_ranking_on_several_compute_units_is_the_same_ranking():
         finally:
             for kk in env:
                 os.environ.pop(kk, None)
-    for tag in ("single", "workgroups", "gave-up", "multi/phases", "single/phases", "own-centring"):
+    for tag in ("single", "workgroups", "gave-up", "multi/phases", "single/phases", "own-centring", "own-scoring"):
         assert out[tag][0] == out["multi"][0] and np.array_equal(out[tag][1], out["multi"][1]) and out[tag][2] == out["multi"][2], tag
     assert out["multi"][0] > 0
     print("PS ranking d=%d (lambda %d): %.1f ms with a wave per 64 individuals, %.1f ms on sixteen workgroups per run, %.1f ms on one, %.1f ms after a give-up; identical steps"
