@@ -19,7 +19,7 @@ python3 tools/profile_summary.py pmc $IN/pmc_w/w_results.db $IN/pmc_f/f_results.
 python3 tools/profile_summary.py pmc $IN/pmc_w_c2/w_results.db $IN/pmc_f_c2/f_results.db $P/${TAG}_c2_pmc 5 C2
 python3 tools/profile_summary.py pmc $IN/pmc_w_c4/w_results.db $IN/pmc_f_c4/f_results.db $P/${TAG}_c4_pmc 360 C4
 python3 tools/profile_summary.py pmc $IN/pmc_w_c5/w_results.db $IN/pmc_f_c5/f_results.db $P/${TAG}_c5_pmc 5 C5
-{ echo "# tools/round4_bench.py (wall times of mrbf_round4 incl. the upload of the candidates; three repetitions per shape)"; cat $IN/round4_d64.txt $IN/round4_d128.txt $IN/round4_d24.txt; } > $P/${TAG}_round4_timing.txt
+{ echo "# tools/round4_bench.py (wall times of mrbf_round4 incl. the upload of the candidates; three repetitions per shape)"; cat $IN/round4_d64.txt $IN/round4_d128.txt $IN/round4_d24.txt; } > $P/${TAG}_round4_timing.txt   # (check the output for tracebacks before committing it)
 { echo "# per-launch timeline of the last round-4 call under rocprofv3 (tools/r4_timeline.py): start / duration in us, grid, queue (q1 main, the other the side stream)"; echo "## d = 64, 10^4 candidates"; cat $IN/round4_timeline_d64.txt; echo "## d = 128, 6000 candidates"; cat $IN/round4_timeline_d128.txt; } > $P/${TAG}_round4_timeline.txt
 cp $IN/walklab.txt $P/${TAG}_walklab.txt
 { cat $IN/ps_step.txt; cat $IN/ps_step_d12.txt 2>/dev/null || true; } > $P/${TAG}_ps_step_timing.txt
