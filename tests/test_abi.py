@@ -141,3 +141,10 @@ def test_environment_switches_sit_behind_one_gate(lib):
                     raw.append("%s:%d: %s" % (os.path.basename(path), i + 1, line.strip()))
     assert not raw, "environment read outside the gate:\n" + "\n".join(raw)
     assert gated >= 100
+    # every switch is listed in INTEGRATION.md's appendix (regenerate it when one is added: the list is what a maintainer greps)
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    names = set()
+    for path in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.hpp"))):
+        names.update(re.findall(r"mrbf_env\(\"(MRBF_[A-Z0-9_]+)\"\)", open(path).read()))
+    missing = sorted(n for n in names if ("`%s`" % n) not in doc)
+    assert not missing, "switches missing from INTEGRATION.md's appendix: %s" % missing
