@@ -7,6 +7,10 @@ namespace mrbf {
 __global__ void column_mean_kernel(const double *__restrict__ X, int64_t n, int d, double *__restrict__ mean) {
     __shared__ double red[256];
     const int t = blockIdx.x;
+    if (t >= d) {  // (blocks d .. dpad - 1 of launch_center_pad: the padding entries -- a memset launch less in front of every fit)
+        if (threadIdx.x == 0) mean[t] = 0.0;
+        return;
+    }
     double s = 0.0;
     for (int64_t i = threadIdx.x; i < n; i += blockDim.x) s += X[i * d + t];
     red[threadIdx.x] = s;
@@ -39,8 +43,7 @@ int launch_center_pad(mrbf_ctx *ctx, const double *X, int64_t n, int d, const do
                       double *Xc, int64_t npad, int dpad, double *sq) {
     const double *mean = mean_or_null;
     if (!mean) {
-        MRBF_HIP(ctx, hipMemsetAsync(mean_out, 0, sizeof(double) * dpad, ctx->stream));
-        hipLaunchKernelGGL(column_mean_kernel, dim3(d), dim3(256), 0, ctx->stream, X, n, d, mean_out);
+        hipLaunchKernelGGL(column_mean_kernel, dim3(dpad > d ? dpad : d), dim3(256), 0, ctx->stream, X, n, d, mean_out);
         mean = mean_out;
     }
     const int rows_per_block = 4;
